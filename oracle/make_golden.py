@@ -1,0 +1,346 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by running the REFERENCE.
+
+TEST INFRASTRUCTURE.  Run in the build container only (needs /root/reference):
+
+    python oracle/make_golden.py
+
+What executes
+-------------
+``/root/reference/joxsz_funcs.py`` is imported as-is and its own functions are
+called: ``centdistmat``, ``dist``, ``filt_image``, ``mybeam``, ``read_beam``,
+``read_tf``, ``getEdges``, ``CmptPressure.press_fun/press_derivative``,
+``CmptUPPTemperature.temp_fun``, ``mydens_vikhFunction``, ``mydens_prior``,
+``CmptMyMass.mass_fun``, ``get_sz_like`` (outputs 'pp', 'bright', 'chisq',
+'ll'), ``mylikeFromProfs`` and ``getLikelihood``.
+
+The module's top-level imports name packages that this image does not have
+(astropy, mbproj2, PyAbel, h5py; scipy's removed ``simps``).  They are
+satisfied with import-time stand-ins registered in ``sys.modules``:
+
+* ``astropy.io.fits.open`` -> this repo's FITS binary-table reader;
+* ``h5py`` -> empty module (only used by out-of-scope functions);
+* ``scipy.integrate.simps`` -> ``scipy.integrate.simpson`` (same function, renamed upstream);
+* ``mbproj2`` -> a ``Cmpt`` base class, ``physconstants`` and the handful of
+  entry points ``getLikelihood`` reaches, *restated* in
+  ``oracle/mbproj2_parts.py``;
+* ``abel.direct.direct_transform`` -> ``oracle/pyabel_direct.py``.
+
+Consequently the fixtures PIN every line of joxsz_funcs.py:46-134, 275-301,
+321-336, 375-407, 428-437, 439-546 as executed by the reference, but NOT the
+arithmetic inside PyAbel and mbproj2 (restated; "parity unpinned", see
+DESIGN.md section 3).
+
+Outputs: tests/golden/ref_tiny.npz, tests/golden/ref_bundled.npz (complete
+problem tensors + parameter vectors + the reference's outputs) and
+tests/golden/bundled_inputs.npz (the parsed bundled data files).
+"""
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = '/root/reference'
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+from oracle import pyabel_direct, mbproj2_parts as mbp          # noqa: E402
+from joxsz_amd import datasets, setup_host as sh                  # noqa: E402
+from joxsz_amd.problem import Problem, default_par_table          # noqa: E402
+
+
+# ---------------------------------------------------------------------------
+# stand-ins for the absent third-party modules
+# ---------------------------------------------------------------------------
+
+def install_standins():
+    import scipy.integrate as si
+    if not hasattr(si, 'simps'):
+        si.simps = si.simpson
+
+    astropy = types.ModuleType('astropy')
+    aio = types.ModuleType('astropy.io')
+    fits = types.ModuleType('astropy.io.fits')
+
+    class _HDU:
+        def __init__(self, cols):
+            self.data = [cols]
+
+    class _HDUList:
+        def __init__(self, path):
+            self._cols = sh.read_fits_bintable_row(path)
+
+        def __getitem__(self, key):
+            return _HDU(self._cols)
+
+    fits.open = lambda path: _HDUList(path)
+    astropy.io = aio
+    aio.fits = fits
+    sys.modules.update({'astropy': astropy, 'astropy.io': aio, 'astropy.io.fits': fits})
+
+    sys.modules['h5py'] = types.ModuleType('h5py')
+
+    mb = types.ModuleType('mbproj2')
+    pc = types.ModuleType('mbproj2.physconstants')
+    for k in ('keV_erg', 'kpc_cm', 'mu_g', 'G_cgs', 'solar_mass_g'):
+        setattr(pc, k, getattr(mbp, k))
+
+    class Cmpt:
+        def __init__(self, name, annuli):
+            self.name = name
+            self.annuli = annuli
+
+        def prior(self, pars):
+            return 0.
+
+    class ParamBase:
+        def __init__(self, val, frozen=False):
+            self.val = val
+            self.frozen = frozen
+
+    class Param(ParamBase):
+        def __init__(self, val, minval=-1e99, maxval=1e99, frozen=False):
+            ParamBase.__init__(self, val, frozen=frozen)
+            self.minval, self.maxval = minval, maxval
+
+        def prior(self):
+            return mbp.param_prior(self.val, self.minval, self.maxval)
+
+    class ParamGaussian(ParamBase):
+        def __init__(self, val, prior_mu, prior_sigma, frozen=False):
+            ParamBase.__init__(self, val, frozen=frozen)
+            self.prior_mu, self.prior_sigma = prior_mu, prior_sigma
+
+        def prior(self):
+            return mbp.param_gaussian_prior(self.val, self.prior_mu, self.prior_sigma)
+
+    utils = types.ModuleType('mbproj2.utils')
+    utils.cashLogLikelihood = mbp.cash_log_likelihood
+    fitmod = types.ModuleType('mbproj2.fit')
+    fitmod.debugfit = False
+    mb.Cmpt, mb.ParamBase, mb.Param, mb.ParamGaussian = Cmpt, ParamBase, Param, ParamGaussian
+    mb.utils, mb.fit, mb.physconstants = utils, fitmod, pc
+    sys.modules.update({'mbproj2': mb, 'mbproj2.physconstants': pc, 'mbproj2.utils': utils,
+                        'mbproj2.fit': fitmod})
+
+    abel = types.ModuleType('abel')
+    adirect = types.ModuleType('abel.direct')
+
+    def direct_transform(fr, dr=None, r=None, direction='inverse', backend='C', **kw):
+        assert direction == 'forward' and backend == 'Python' and r is not None
+        return pyabel_direct.direct_transform_forward(fr, r)
+
+    adirect.direct_transform = direct_transform
+    abel.direct = adirect
+    sys.modules.update({'abel': abel, 'abel.direct': adirect})
+    return mb
+
+
+# ---------------------------------------------------------------------------
+# a duck-typed mb.Fit around the reference's own functions
+# ---------------------------------------------------------------------------
+
+class _Annuli:
+    def __init__(self, midpt_kpc):
+        self.midpt_kpc = midpt_kpc
+
+
+class _Band:
+    def __init__(self, cts):
+        self.cts = cts
+
+
+class _Bag:
+    pass
+
+
+def build_ref_fit(ref, mb, pb):
+    """Wire the reference's components as joxsz_main.py:128-188 does, over the
+    arrays of ``pb``; the mbproj2 ``Fit`` methods the path calls are restated
+    (``updateThawed``, ``calcProfiles``)."""
+    from types import MethodType
+    from scipy.interpolate import interp1d
+    ref.add_param_unit()
+    annuli = _Annuli(pb.x_r_T_kpc)
+
+    class Vikh(mb.Cmpt):
+        mode = pb.ne_mode
+    Vikh.vikhFunction = ref.mydens_vikhFunction
+    Vikh.defPars = ref.mydens_defPars
+    Vikh.prior = ref.mydens_prior
+    ne_cmpt = Vikh('ne', annuli)
+    press = ref.CmptPressure('p', annuli)
+    T_cmpt = ref.CmptUPPTemperature('T', annuli, press, ne_cmpt)
+
+    pars = {}
+    for k, name in enumerate(pb.par_names):
+        if pb.par_kind[k] == 1:
+            par = mb.ParamGaussian(pb.par_vals[k], prior_mu=pb.par_mu[k], prior_sigma=pb.par_sigma[k])
+        else:
+            par = mb.Param(pb.par_vals[k], minval=pb.par_min[k], maxval=pb.par_max[k], frozen=bool(pb.par_frozen[k]))
+        pars[name] = par
+
+    convert = interp1d(pb.conv_T, pb.conv_v, 'linear', fill_value='extrapolate')       # joxsz_main.py:109
+    sz = ref.SZ_data([pb.m_e, pb.sigma_T], pb.step, pb.kpc_as, convert, pb.flux_data, pb.beam_2d,
+                     pb.radius, pb.S // 2, pb.r_pp, pb.d_mat, pb.filtering)
+
+    fit = _Bag()
+    fit.pars = pars
+    fit.thawed = [n for n, p in pars.items() if not p.frozen]                        # joxsz_main.py:179
+    fit.exclude_unphy_mass = pb.exclude_unphy_mass
+    fit.press = press
+    fit.mass_cmpt = ref.CmptMyMass('m', annuli, press, ne_cmpt)
+    fit.data = _Bag()
+    fit.data.sz = sz
+    fit.data.bands = [_Band(c) for c in pb.cts]
+    fit.model = _Bag()
+    fit.model.T_cmpt = T_cmpt
+    fit.model.ne_cmpt = ne_cmpt
+    fit.model.prior = lambda pars_: ne_cmpt.prior(pars_) + 0. + 0.
+    fit.bestlike = -1e99
+
+    def updateThawed(self, vals):
+        for v, n in zip(vals, self.thawed):
+            self.pars[n].val = v
+
+    def calcProfiles(self):
+        ne = ne_cmpt.vikhFunction(self.pars, pb.x_r_ne_kpc)
+        T = T_cmpt.computeProf(self.pars)                                              # joxsz_funcs.py:338-339
+        Z = self.pars['Z'].val
+        out = []
+        for b in range(pb.cts.shape[0]):
+            rates = mbp.count_rate(pb.lnT, pb.lnrate[b, 0], pb.lnrate[b, 1], T, Z, ne)
+            out.append(mbp.band_proj_profile(pb.projvols, rates, pb.areascales[b], pb.exposures[b],
+                                             pb.backrates[b], pb.geomarea, self.pars['backscale'].val))
+        return out
+
+    fit.updateThawed = MethodType(updateThawed, fit)
+    fit.calcProfiles = MethodType(calcProfiles, fit)
+    fit.get_sz_like = MethodType(ref.get_sz_like, fit)
+    fit.getLikelihood = MethodType(ref.getLikelihood, fit)
+    fit.mylikeFromProfs = MethodType(ref.mylikeFromProfs, fit)
+    return fit
+
+
+def theta_cases(pb):
+    """Parameter vectors: fiducial, perturbed, on/near bounds, far in the
+    Gaussian priors, then the three rejection paths (box prior, r_c > r_s,
+    non-monotone mass)."""
+    t0 = datasets.fiducial_theta(pb)
+    rng = np.random.default_rng(7)
+    cases = [t0]
+    for _ in range(4):
+        cases.append(t0 * (1 + 0.05 * rng.standard_normal(t0.size)))
+    a = t0.copy(); a[7] = 1.9999                                            # P_0 just inside its max
+    cases.append(a)
+    a = t0.copy(); a[6] = 0.0; a[5] = -1.0                                  # Z and log(T_X/T_SZ) ON their lower bounds
+    cases.append(a)
+    a = t0.copy(); a[6] = 1.0; a[5] = 1.0                                   # ... and ON their upper bounds
+    cases.append(a)
+    a = t0.copy(); a[11] = 0.5; a[12] = 1.3                                 # far out in the Gaussian priors
+    cases.append(a)
+    a = t0.copy(); a[7] = 0.01                                              # cold cluster: convert() extrapolates below 1 keV
+    cases.append(a)
+    a = t0.copy(); a[1] = 4.5                                               # REJECT: beta above its box (funcs:519-520)
+    cases.append(a)
+    a = t0.copy(); a[2] = 3.0; a[3] = 2.0                                   # REJECT: r_c > r_s (funcs:397-407)
+    cases.append(a)
+    a = t0.copy(); a[9] = 8.0; a[1] = 0.3                                   # REJECT: non-monotone mass (funcs:522-525)
+    cases.append(a)
+    a = t0.copy(); a[10] = 100.0001                                         # REJECT: mass veto with r_p at its min
+    cases.append(a)
+    return np.array(cases)
+
+
+def run_case(ref, mb, pb, tag, with_stages=True):
+    fit = build_ref_fit(ref, mb, pb)
+    thetas = theta_cases(pb)
+    rec = dict(thetas=thetas)
+    outs = {k: [] for k in ('logp', 'pp', 'dpp', 'ne', 'tsz', 'mass', 'bright', 'chisq', 'll', 'xlike', 'densprior')}
+    for th in thetas:
+        outs['logp'].append(fit.getLikelihood(th))                    # also updates fit.pars (funcs:515-516)
+        P = fit.pars
+        outs['pp'].append(fit.get_sz_like(output='pp'))
+        outs['dpp'].append(fit.press.press_derivative(P, pb.r_pp))
+        outs['ne'].append(fit.model.ne_cmpt.vikhFunction(P, pb.r_pp))
+        outs['tsz'].append(fit.model.T_cmpt.temp_fun(P, pb.r_pp, getT_SZ=True))
+        outs['mass'].append(fit.mass_cmpt.mass_fun(P, pb.r_pp))
+        outs['bright'].append(fit.get_sz_like(output='bright'))
+        outs['chisq'].append(fit.get_sz_like(output='chisq'))
+        outs['ll'].append(fit.get_sz_like(output='ll'))
+        profs = fit.calcProfiles()
+        outs['xlike'].append(fit.mylikeFromProfs(profs) if np.array(profs).min() > 0 else -np.inf)
+        outs['densprior'].append(fit.model.ne_cmpt.prior(P))
+    for k, v in outs.items():
+        rec['ref_' + k] = np.array(v, dtype=np.float64)
+    rec.update(pb.to_dict())
+    path = os.path.join(ROOT, 'tests', 'golden', 'ref_%s.npz' % tag)
+    np.savez_compressed(path, **rec)
+    print(tag, 'logp =', rec['ref_logp'])
+    print('  wrote', path, os.path.getsize(path) // 1024, 'KiB')
+
+
+def main():
+    mb = install_standins()
+    sys.path.insert(0, REF)
+    import joxsz_funcs as ref                                         # the reference module itself
+
+    # ---- bundled shape: every setup tensor through the reference's own setup functions ----
+    d = os.path.join(REF, 'data')
+    step, kpc_as, R_b = 2., datasets.KPC_AS_CLJ1226, 5000.
+    flux_data = ref.read_xy_err(d + '/SZ/press_data_cl1226_flagsource_Xraycent.dat', ncol=3)
+    maxr_data = flux_data[0][-1]
+    beam_2d, fwhm = ref.mybeam(step, maxr_data, approx=False, filename=d + '/SZ/Beam150GHz.fits')
+    mymaxr = (maxr_data + 3 * fwhm) // step * step                     # joxsz_main.py:100-105
+    radius = np.arange(0., mymaxr + step, step)
+    radius = np.append(-radius[:0:-1], radius)
+    r_pp = np.arange(step * kpc_as, R_b + step * kpc_as, step * kpc_as)
+    d_mat = ref.centdistmat(radius * kpc_as)
+    wn_as, tf = ref.read_tf(d + '/SZ/TransferFunction150GHz_CLJ1227.fits')
+    filtering = ref.filt_image(wn_as, tf, d_mat.shape[0], step)
+    t_keV, cjy = np.loadtxt(d + '/SZ/Compton_to_Jy_per_beam.dat', skiprows=1, unpack=True)
+    infg = d + '/X/fg_profnew_%04i_%04i.dat'
+    edges = ref.getEdges(infg, datasets.BAND_EDGES_EV)
+    braw, bprof = ref.read_beam(d + '/SZ/Beam150GHz.fits')
+
+    own = datasets.bundled_problem(d)                                  # this build's loader, same files
+    pb = Problem(**{**{k: getattr(own, k) for k in Problem._ARRAYS + Problem._SCALARS},
+                    'par_names': own.par_names})
+    # overwrite the SZ tensors with the ones the reference's setup functions produced
+    pb.flux_data, pb.beam_2d, pb.radius, pb.r_pp = np.array(flux_data), beam_2d, radius, r_pp
+    pb.d_mat, pb.filtering, pb.conv_T, pb.conv_v = d_mat, filtering, t_keV, 1e3 * cjy
+    pb.validate()
+    run_case(ref, mb, pb, 'bundled')
+
+    np.savez_compressed(os.path.join(ROOT, 'tests', 'golden', 'bundled_inputs.npz'),
+                        flux_data=np.array(flux_data), beam_r=braw, beam_prof=bprof, fwhm=fwhm,
+                        wn_as=wn_as, tf=tf, conv_T=t_keV, conv_jy=cjy, edges_arcmin=edges,
+                        dist9=ref.dist(9), dist8=ref.dist(8),
+                        fg=np.array([np.loadtxt(infg % tuple(b)) for b in datasets.BAND_EDGES_EV]),
+                        bg=np.array([np.loadtxt((d + '/X/bg_profnew_%04i_%04i.dat') % tuple(b))
+                                     for b in datasets.BAND_EDGES_EV]))
+
+    # ---- tiny shape: Gaussian beam / normal-cdf transfer function branches (funcs:69-71, 100-101) ----
+    S, N = 31, 40
+    step_t = 6.
+    flux_r = np.array([3., 14., 29., 44.])
+    beam_t, _ = ref.mybeam(step_t, 0., approx=True, normalize=True, fwhm_beam=8.5)   # |rad|<=25.5 -> B=9
+    radius_t = step_t * (np.arange(S) - S // 2)
+    d_mat_t = ref.centdistmat(radius_t * kpc_as)
+    wn_t = np.linspace(0., 0.4967, 76)
+    tf_t = 0.95 * __import__('scipy.stats').stats.norm.cdf(wn_t, 0., 0.02)
+    filt_t = ref.filt_image(wn_t, tf_t, S, step_t)
+    syn = datasets.synthetic_problem(S=S, N=N, step=step_t, fwhm=8.5)
+    syn.flux_data = np.vstack((flux_r, [-1.1, -0.9, -0.5, -0.2], [0.1, 0.08, 0.07, 0.06]))
+    syn.beam_2d, syn.radius, syn.d_mat, syn.filtering = beam_t, radius_t, d_mat_t, filt_t
+    syn.cts = syn.cts.copy(); syn.cts[2, 3] = np.nan; syn.cts[5, 0] = np.nan      # missing data (funcs:504)
+    syn.validate()
+    assert syn.B == 9
+    run_case(ref, mb, syn, 'tiny')
+
+
+if __name__ == '__main__':
+    main()
