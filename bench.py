@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""Headline benchmark: walker-likelihoods per second of the joint X-ray + SZ
+log-posterior at a 512 x 512 map and a 500-point radial grid (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one evaluation of the log-posterior of every walker of the ensemble
+(what one emcee iteration costs: joxsz_funcs.py:593,600,622 -> getLikelihood
+per walker).  Workload at N=1: BASELINE.json configs[2] -- 1024 walkers, S=512,
+N=500, joint likelihood, synthetic CL J1226.9+3332-shaped inputs, parameter
+vectors already resident in HBM when the timed region starts.  For N>1 every
+rank evaluates its own 1024 walkers (weak scaling, walkers are independent) and
+the log-probabilities are all-gathered over RCCL inside the timed region.
+
+Prints ONE JSON line (rank 0) with the `roofline` of the fused Abel+map kernel
+(algorithmic bytes S*S*8 per walker / HIP-event duration of that kernel) and a
+`cpu_baseline` (the numpy/scipy oracle on this box's host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def _cpu_worker(args):
+    pb, th = args
+    from oracle import joxsz_oracle as orc
+    return orc.log_posterior_batch(pb, th)
+
+
+def cpu_baseline(pb, thetas, target_s=15.0):
+    """The oracle (numpy/scipy restatement of the reference path) mapped over
+    walkers with multiprocessing.Pool on all host cores, exactly the reference's
+    parallelism (joxsz_main.py:203-206), on a bounded sample of the workload."""
+    import multiprocessing as mp
+    from oracle import joxsz_oracle as orc
+    cores = os.cpu_count() or 1
+    t = time.perf_counter()
+    orc.log_posterior_batch(pb, thetas[:1])
+    one = time.perf_counter() - t
+    per_core = max(1, int(target_s / max(one, 1e-3)))
+    n = min(len(thetas), per_core * cores)
+    n = max(cores, (n // cores) * cores)
+    sample = thetas[:n]
+    chunks = [(pb, c) for c in np.array_split(sample, cores)]
+    ctxm = mp.get_context('fork')
+    with ctxm.Pool(cores) as pool:
+        pool.map(_cpu_worker, [(pb, thetas[:1])] * cores)          # warm the workers
+        t = time.perf_counter()
+        res = pool.map(_cpu_worker, chunks)
+        dt = time.perf_counter() - t
+    logp = np.concatenate(res)
+    return dict(value=n / dt, unit='walker-likelihoods/s', cores=cores, kind='port',
+                sample='%d walkers of the same workload, oracle/joxsz_oracle.py over multiprocessing.Pool(%d), %.1f s'
+                       % (n, cores, dt)), sample, logp
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--walkers', type=int, default=1024, help='walkers per GPU')
+    ap.add_argument('--S', type=int, default=512)
+    ap.add_argument('--N', type=int, default=500)
+    ap.add_argument('--sz-only', action='store_true')
+    ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
+    ap.add_argument('--cpu-seconds', type=float, default=15.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('--gpus %d needs a torch.distributed.run launch with that many ranks' % args.gpus)
+        args.gpus = world
+
+    from joxsz_amd import datasets
+    pb = datasets.synthetic_problem(S=args.S, N=args.N, seed=0, sz_only=args.sz_only)
+    W = args.walkers
+
+    # ---- CPU baseline first: it forks, which must happen before HIP is initialised ----
+    cpu = None
+    cpu_sample = cpu_logp = None
+    if rank == 0 and args.gpus == 1 and not args.no_cpu:
+        th_cpu = datasets.walker_ball(pb, 4096, spread=0.02, seed=11)
+        # the data the walkers are scored against do not change the cost; use the placeholder data
+        cpu, cpu_sample, cpu_logp = cpu_baseline(pb, th_cpu, args.cpu_seconds)
+
+    dist = None
+    torch = None
+    if args.gpus > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', rank=rank, world_size=world,
+                                device_id=torch.device('cuda', local_rank))
+
+    from joxsz_amd.posterior import JoxszPosterior
+    post = JoxszPosterior(pb, device=local_rank)
+    ctx = post.ctx
+
+    # parity spot-check of the CPU sample on the very same problem tensors
+    parity = None
+    if cpu_sample is not None:
+        got = ctx.eval(cpu_sample)
+        fin = np.isfinite(cpu_logp)
+        if not np.array_equal(np.isfinite(got), fin):
+            raise SystemExit('bench: GPU/oracle disagree on which walkers are rejected')
+        parity = float(np.max(np.abs(got[fin] - cpu_logp[fin]) / np.abs(cpu_logp[fin]))) if fin.any() else 0.0
+        if parity > 1e-6:
+            raise SystemExit('bench: parity %.3e exceeds 1e-6' % parity)
+
+    # ---- synthetic observations from the model itself at the fiducial vector, then the walker ball ----
+    t0 = datasets.fiducial_theta(pb)
+    bright = ctx.eval_stage(t0, 'bright')[0]
+    xprofs = None if pb.sz_only else ctx.eval_stage(t0, 'xprofs')[0]
+    post.close()
+    datasets.fill_data(pb, bright, xprofs, seed=0)
+    post = JoxszPosterior(pb, device=local_rank)
+    ctx = post.ctx
+    cand = datasets.walker_ball(pb, 4 * W, spread=0.02, seed=100 + rank)
+    lp = ctx.eval(cand)
+    good = cand[np.isfinite(lp)]
+    if len(good) < W:
+        raise SystemExit('bench: only %d finite walkers of %d' % (len(good), len(cand)))
+    theta = np.ascontiguousarray(good[:W])
+
+    # ---- device-resident inputs ----
+    if torch is not None:
+        th_t = torch.from_numpy(theta).cuda()
+        lp_t = torch.empty(W, dtype=torch.float64, device='cuda')
+        all_t = torch.empty(W * world, dtype=torch.float64, device='cuda')
+        th_ptr, lp_ptr = th_t.data_ptr(), lp_t.data_ptr()
+    else:
+        th_ptr = ctx.dev_alloc(theta.nbytes)
+        lp_ptr = ctx.dev_alloc(8 * W)
+        ctx.h2d(th_ptr, theta)
+
+    def step():
+        ctx.eval_device(th_ptr, W, lp_ptr)
+        if dist is not None:
+            ctx.sync()                                   # logp complete before RCCL reads it
+            dist.all_gather_into_tensor(all_t, lp_t)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+        ctx.sync()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ctx.timing_enable(True)
+    ctx.timing_reset()
+    fence()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t_start
+    tm = ctx.timing()
+    ctx.timing_enable(False)
+
+    if dist is not None:
+        e = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(e, op=dist.ReduceOp.MAX)
+        elapsed = float(e.item())
+        final = all_t.cpu().numpy()
+    else:
+        final = np.empty(W)
+        ctx.d2h(final, lp_ptr)
+    if not np.all(np.isfinite(final)):
+        raise SystemExit('bench: non-finite log-probabilities in the timed batch')
+
+    if rank == 0:
+        S = args.S
+        launches = max(1, tm['launches'])
+        k_ms = tm['abel_map_ms'] / launches                  # mean duration of one Abel+map launch
+        walkers_per_launch = tm['walkers'] / launches
+        alg_bytes = walkers_per_launch * S * S * 8.0          # S^2*E written per walker
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        value = W * world * args.steps / elapsed
+        out = {
+            'metric': 'walker-likelihoods/sec at 512^2 map, 500-pt grid' if (S, args.N) == (512, 500)
+                      else 'walker-likelihoods/sec at %d^2 map, %d-pt grid' % (S, args.N),
+            'value': value, 'unit': 'walker-likelihoods/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': '%d walkers/GPU, %dx%d SZ map, %d-pt radial grid, %s likelihood, '
+                                   'synthetic CL J1226.9+3332-shaped inputs (BASELINE configs[2])'
+                                   % (W, S, S, args.N, 'SZ-only' if pb.sz_only else 'joint X-ray+SZ'),
+                       'walkers_per_gpu': W, 'S': S, 'N': args.N, 'B': pb.B, 'fft_pad': ctx.fft_pad,
+                       'chunk': ctx.chunk, 'parallelism': 'walkers sharded x%d' % world, 'device': ctx.device_name},
+            'roofline': {'kernel': 'jx_abel_map_kernel', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
+                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'launch_ms': k_ms, 'bytes_per_launch': alg_bytes},
+            'cpu_baseline': cpu,
+            'stage_ms_per_step': {k: tm[k] / args.steps for k in
+                                  ('prep_ms', 'abel_map_ms', 'beam_fft_ms', 'tf_fft_ms', 'tail_ms', 'total_ms')},
+            'parity_max_rel_err': parity,
+        }
+        print(json.dumps(out))
+    post.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

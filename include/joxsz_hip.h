@@ -1,0 +1,184 @@
+/*
+ * joxsz_hip.h -- C-ABI of the MI355X (gfx950) JoXSZ log-posterior library.
+ *
+ * The reference (fcastagna/JoXSZ) is pure Python and has no FFI of its own;
+ * its "plugin API" for this path is the bound callable installed on the Fit
+ * object at joxsz_main.py:186-188 and handed to emcee at joxsz_main.py:206:
+ *
+ *     fit.getLikelihood(vals) -> float        (joxsz_funcs.py:507-546)
+ *
+ * This header is what a ctypes binding of that callable binds (see
+ * INTEGRATION.md).  Plain pointers and sizes only; no C++ or torch types.
+ * Every function returns 0 on success or a negative jx_status; nothing throws
+ * across the boundary.  Physics rejections (parameter outside its prior box,
+ * r_c > r_s, non-monotone hydrostatic mass, non-positive X-ray model) are NOT
+ * errors: they are -inf entries in the output, exactly as the reference
+ * returns them (joxsz_funcs.py:519-520, 524-525, 532, 397-407).
+ *
+ * Ownership: the caller owns all host buffers; the context owns all device
+ * memory, the rocFFT plans and the HIP stream; jx_upload copies.
+ * Threading: one context per device per host thread; a context is not
+ * thread-safe.  Multi-GPU = one process, one context per device.
+ */
+#ifndef JOXSZ_HIP_H
+#define JOXSZ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JX_ABI_VERSION 1
+
+typedef struct jx_ctx jx_ctx;
+
+typedef enum jx_status {
+    JX_OK = 0,
+    JX_ERR_INVALID = -1,      /* bad argument / inconsistent sizes            */
+    JX_ERR_STATE = -2,        /* call order (upload after finalize, ...)      */
+    JX_ERR_MISSING = -3,      /* a required tensor was never uploaded         */
+    JX_ERR_HIP = -4,          /* HIP runtime error (jx_last_error has detail) */
+    JX_ERR_ROCFFT = -5,       /* rocFFT error                                 */
+    JX_ERR_NOMEM = -6,        /* host or device allocation failed             */
+    JX_ERR_NODEVICE = -7,     /* no usable gfx950 device                      */
+    JX_ERR_UNSUPPORTED = -8   /* size outside what the kernels support        */
+} jx_status;
+
+/* Sizes and scalars of one problem: the shapes of SZ_data (joxsz_funcs.py:157-170)
+ * and of the X-ray Data/Annuli/Band objects (joxsz_main.py:116-125). */
+typedef struct jx_config {
+    int32_t abi_version;      /* = JX_ABI_VERSION                                              */
+    int32_t S;                /* SZ map side: d_mat is S x S              (joxsz_main.py:105)  */
+    int32_t N;                /* radial grid points: len(r_pp)            (joxsz_main.py:104)  */
+    int32_t B;                /* beam image side (odd)                    (joxsz_funcs.py:64-68)*/
+    int32_t nflux;            /* SZ flux data points: flux_data is 3 x nflux (joxsz_main.py:97)*/
+    int32_t nconv;            /* Compton->Jy/beam table points            (joxsz_main.py:108)  */
+    int32_t nann;             /* X-ray annuli                             (joxsz_main.py:116)  */
+    int32_t nband;            /* X-ray energy bands                       (joxsz_main.py:73)   */
+    int32_t ntab;             /* count-rate table length (CountRate.Tlogvals, joxsz_funcs.py:669)*/
+    int32_t npar;             /* parameter table length: 16 (single) or 19 (double beta)       */
+    int32_t ndim;             /* thawed parameters = len(fit.thawed)      (joxsz_main.py:179)  */
+    int32_t ne_mode;          /* 0 = 'single', 1 = 'double'               (joxsz_main.py:135)  */
+    int32_t exclude_unphy_mass; /* joxsz_main.py:88                                            */
+    int32_t sz_only;          /* 1 = skip the X-ray term (build extension, BASELINE configs[1])*/
+    int32_t device;           /* HIP device ordinal                                            */
+    int32_t max_batch;        /* walkers processed per internal chunk (0 = library default)    */
+    int32_t fft_pad;          /* padded side of the beam convolution (0 = library default)     */
+    int32_t map_split;        /* row slabs per walker in the Abel+map kernel (0 = default)     */
+    double step;              /* arcsec                                   (joxsz_main.py:21)   */
+    double kpc_as;            /* kpc per arcsec                           (joxsz_main.py:96)   */
+    double m_e;               /* keV                                      (joxsz_main.py:22)   */
+    double sigma_T;           /* cm^2                                     (joxsz_main.py:23)   */
+    double kpc_cm;            /* mbproj2.physconstants.kpc_cm             (joxsz_funcs.py:6)   */
+} jx_config;
+
+/* Constant tensors, all float64 row-major unless noted. */
+typedef enum jx_tensor {
+    JX_T_R_PP = 0,        /* [N]            kpc                 SZ_data.r_pp      */
+    JX_T_D_MAT,           /* [S,S]          kpc                 SZ_data.d_mat     */
+    JX_T_BEAM_2D,         /* [B,B]                              SZ_data.beam_2d   */
+    JX_T_FILTERING,       /* [S,S]          FFT layout          SZ_data.filtering */
+    JX_T_RADIUS,          /* [S]            arcsec              SZ_data.radius    */
+    JX_T_FLUX_DATA,       /* [3,nflux]      r, flux, err        SZ_data.flux_data */
+    JX_T_CONV_T,          /* [nconv]        keV                 joxsz_main.py:108 */
+    JX_T_CONV_V,          /* [nconv]        1e3*Jy/beam         joxsz_main.py:109 */
+    JX_T_PAR_VALS,        /* [npar]   current value of every parameter (frozen ones matter) */
+    JX_T_PAR_MIN,         /* [npar]   Param.minval                                          */
+    JX_T_PAR_MAX,         /* [npar]   Param.maxval                                          */
+    JX_T_PAR_KIND,        /* [npar]   int32: 0 = Param (box), 1 = ParamGaussian             */
+    JX_T_PAR_MU,          /* [npar]   ParamGaussian.prior_mu                                */
+    JX_T_PAR_SIGMA,       /* [npar]   ParamGaussian.prior_sigma                             */
+    JX_T_THAWED_IDX,      /* [ndim]   int32: slot of each thawed value, order of fit.thawed */
+    JX_T_X_R_NE,          /* [nann]   kpc: radii where n_e is evaluated                     */
+    JX_T_X_R_T,           /* [nann]   kpc: annuli.midpt_kpc (joxsz_funcs.py:339)            */
+    JX_T_PROJVOLS,        /* [nann,nann] cm^3: annuli.projvols                              */
+    JX_T_CTS,             /* [nband,nann]  band.cts (NaN = missing, joxsz_funcs.py:504)     */
+    JX_T_AREASCALES,      /* [nband,nann]  joxsz_funcs.py:204                               */
+    JX_T_EXPOSURES,       /* [nband,nann]  joxsz_funcs.py:201                               */
+    JX_T_BACKRATES,       /* [nband,nann]  joxsz_funcs.py:207                               */
+    JX_T_GEOMAREA,        /* [nann]   arcmin^2: annuli.geomarea_arcmin2                     */
+    JX_T_LNT,             /* [ntab]   CountRate.Tlogvals                                    */
+    JX_T_LNRATE,          /* [nband,2,ntab] ln(rate) at Z=0 and Z=1 (joxsz_funcs.py:680)    */
+    JX_T_COUNT
+} jx_tensor;
+
+/* Intermediate quantities that can be read back per walker (parity taps).
+ * The names follow get_sz_like's `output` argument (joxsz_funcs.py:439-493). */
+typedef enum jx_stage {
+    JX_STAGE_PP = 0,      /* [W,N]      pressure profile            joxsz_funcs.py:453 */
+    JX_STAGE_AB,          /* [W,N]      Abel transform              joxsz_funcs.py:457 */
+    JX_STAGE_Y,           /* [W,N]      Compton y(r)                joxsz_funcs.py:459 */
+    JX_STAGE_Y2D,         /* [W,S,S]    Compton-y map               joxsz_funcs.py:462 */
+    JX_STAGE_CONV2D,      /* [W,S,S]    beam-convolved map          joxsz_funcs.py:464 */
+    JX_STAGE_MAPROW,      /* [W,nrow]   map_out[S//2, S//2:]        joxsz_funcs.py:472 */
+    JX_STAGE_BRIGHT,      /* [W,nrow]   output='bright'             joxsz_funcs.py:473 */
+    JX_STAGE_CHISQ,       /* [W]        output='chisq'              joxsz_funcs.py:478 */
+    JX_STAGE_TPROF,       /* [W,nrow]   [h(0), t_prof]              joxsz_funcs.py:469-473 */
+    JX_STAGE_XPROFS,      /* [W,nband,nann] calcProfiles()          joxsz_funcs.py:527 */
+    JX_STAGE_PARTS,       /* [W,4]      xray like, sz like, prior, reject mask (bit0 box, bit1 mass, bit2 r_c>r_s, bit3 xray<=0) */
+    JX_STAGE_COUNT
+} jx_stage;
+
+/* GPU time per stage, accumulated over launches since the last reset, measured
+ * with HIP events on the context's stream. */
+typedef struct jx_timing {
+    double prep_ms;       /* priors, mass veto, T profile, X-ray Cash      */
+    double abel_map_ms;   /* fused profile -> Abel -> spline -> y map      */
+    double beam_fft_ms;   /* rocFFT R2C + spectrum multiply + rocFFT C2R   */
+    double tf_fft_ms;     /* rocFFT R2C of the S x S window                */
+    double tail_ms;       /* filter + central row + conversion + chi^2     */
+    double total_ms;      /* first event to last event of each launch      */
+    int64_t launches;     /* internal chunks timed                         */
+    int64_t walkers;      /* walkers those chunks processed                */
+} jx_timing;
+
+int  jx_create(const jx_config* cfg, jx_ctx** out);
+int  jx_upload(jx_ctx* ctx, int tensor_id, const void* host, size_t nbytes);
+/* Build the walker-independent tables (Abel weights, spline operators, beam
+ * spectrum, transfer-function reduction table), the rocFFT plans and the work
+ * buffers.  Must be called once after all uploads and before jx_eval. */
+int  jx_finalize(jx_ctx* ctx);
+
+/* theta: [nwalkers, ndim] row-major float64; logp: [nwalkers] float64.
+ * The call returns after logp is complete (synchronous on the context's stream). */
+int  jx_eval(jx_ctx* ctx, const double* theta_host, int nwalkers, double* logp_host);
+/* Same with DEVICE pointers (hipMalloc'ed by jx_dev_alloc or by any other HIP
+ * allocator of this process on the context's device).  Asynchronous: returns
+ * once the work is enqueued on the context's stream; pair with jx_sync. */
+int  jx_eval_device(jx_ctx* ctx, const double* theta_dev, int nwalkers, double* logp_dev);
+int  jx_sync(jx_ctx* ctx);
+/* Parity/debug tap: evaluates and copies one intermediate quantity to host. */
+int  jx_eval_stage(jx_ctx* ctx, const double* theta_host, int nwalkers, int stage_id,
+                   double* out_host, size_t nbytes);
+
+/* Replace the stored value of one parameter-table entry (keeps a frozen
+ * parameter, or the "current parameters" of getLikelihood(None), in step with
+ * the host-side fit object; joxsz_funcs.py:515-516). */
+int  jx_set_par_vals(jx_ctx* ctx, const double* par_vals, int npar);
+
+/* Device memory helpers so that the host side needs no other GPU runtime. */
+int  jx_dev_alloc(jx_ctx* ctx, size_t nbytes, void** dev_out);
+int  jx_dev_free(jx_ctx* ctx, void* dev);
+int  jx_memcpy_h2d(jx_ctx* ctx, void* dev, const void* host, size_t nbytes);
+int  jx_memcpy_d2h(jx_ctx* ctx, void* host, const void* dev, size_t nbytes);
+
+int  jx_timing_reset(jx_ctx* ctx);
+int  jx_timing_enable(jx_ctx* ctx, int on);
+int  jx_timing_get(jx_ctx* ctx, jx_timing* out);   /* synchronises the stream */
+
+/* Introspection: derived sizes chosen by the library. */
+int  jx_get_info(jx_ctx* ctx, int32_t* fft_pad, int32_t* chunk, int32_t* spline_band,
+                 int32_t* nrow, int64_t* device_bytes);
+int  jx_device_count(void);
+const char* jx_device_name(jx_ctx* ctx);
+
+const char* jx_strerror(int status);
+const char* jx_last_error(jx_ctx* ctx);            /* detail of the last failure on this context */
+void jx_destroy(jx_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JOXSZ_HIP_H */

@@ -1,0 +1,700 @@
+// C-ABI implementation (include/joxsz_hip.h) for gfx950: context, uploads, table
+// building, rocFFT plans and the per-chunk launch sequence.
+#include <hip/hip_runtime.h>
+#include <rocfft/rocfft.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/joxsz_hip.h"
+#include "jx_kernels.hpp"
+#include "jx_tables.hpp"
+
+namespace {
+
+struct Plan3 {
+    rocfft_plan beam_fwd = nullptr, beam_inv = nullptr, tf_fwd = nullptr;
+    size_t work_bytes = 0;
+};
+
+struct EvSet {
+    hipEvent_t e[6];
+    int walkers;
+};
+
+}  // namespace
+
+struct jx_ctx {
+    jx_config cfg;
+    bool finalized = false;
+    std::string err;
+    std::string devname;
+    hipStream_t stream = nullptr;
+
+    // host copies of the uploaded tensors
+    std::vector<std::vector<unsigned char>> host;
+    std::vector<bool> have;
+
+    // derived sizes
+    int P = 0, Ph = 0, Sh = 0, nrow = 0, nt = 0, K = 0, chunk = 0, map_split = 1, map_threads = 256;
+    int64_t device_bytes = 0;
+
+    // device constants
+    std::vector<void*> dev_allocs;
+    JxDev d;
+    double* d_par_vals = nullptr;
+
+    // work buffers (chunk capacity)
+    double *d_pvec = nullptr, *d_base = nullptr, *d_cfac = nullptr;
+    double *d_img = nullptr, *d_conv = nullptr;
+    double2 *d_spec = nullptr, *d_tfspec = nullptr;
+    void* d_work = nullptr;
+    size_t work_cap = 0;
+    // batch staging for the host-pointer API
+    double *d_theta = nullptr, *d_logp = nullptr;
+    int batch_cap = 0;
+    // taps
+    double *t_pp = nullptr, *t_ab = nullptr, *t_y = nullptr, *t_row = nullptr, *t_bright = nullptr,
+           *t_chisq = nullptr, *t_tprof = nullptr, *t_xprofs = nullptr, *t_parts = nullptr;
+
+    std::map<int, Plan3> plans;
+    rocfft_execution_info info = nullptr;
+
+    // timing
+    bool timing_on = false;
+    std::vector<EvSet> ev_inflight, ev_free;
+    jx_timing acc{};
+};
+
+static int g_rocfft_refs = 0;
+
+#define HIPCHK(ctx, call)                                                                          \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                        \
+            return (e_ == hipErrorOutOfMemory) ? JX_ERR_NOMEM : JX_ERR_HIP;                        \
+        }                                                                                          \
+    } while (0)
+
+#define FFTCHK(ctx, call)                                                                          \
+    do {                                                                                           \
+        rocfft_status s_ = (call);                                                                 \
+        if (s_ != rocfft_status_success) {                                                         \
+            (ctx)->err = std::string(#call) + ": rocfft status " + std::to_string((int)s_);        \
+            return JX_ERR_ROCFFT;                                                                  \
+        }                                                                                          \
+    } while (0)
+
+static size_t tensor_bytes(const jx_config& c, int id) {
+    const size_t f = sizeof(double);
+    switch (id) {
+        case JX_T_R_PP: return f * c.N;
+        case JX_T_D_MAT: return f * (size_t)c.S * c.S;
+        case JX_T_BEAM_2D: return f * (size_t)c.B * c.B;
+        case JX_T_FILTERING: return f * (size_t)c.S * c.S;
+        case JX_T_RADIUS: return f * c.S;
+        case JX_T_FLUX_DATA: return f * 3 * c.nflux;
+        case JX_T_CONV_T: case JX_T_CONV_V: return f * c.nconv;
+        case JX_T_PAR_VALS: case JX_T_PAR_MIN: case JX_T_PAR_MAX: case JX_T_PAR_MU: case JX_T_PAR_SIGMA:
+            return f * c.npar;
+        case JX_T_PAR_KIND: return sizeof(int32_t) * c.npar;
+        case JX_T_THAWED_IDX: return sizeof(int32_t) * c.ndim;
+        case JX_T_X_R_NE: case JX_T_X_R_T: case JX_T_GEOMAREA: return f * c.nann;
+        case JX_T_PROJVOLS: return f * (size_t)c.nann * c.nann;
+        case JX_T_CTS: case JX_T_AREASCALES: case JX_T_EXPOSURES: case JX_T_BACKRATES:
+            return f * (size_t)c.nband * c.nann;
+        case JX_T_LNT: return f * c.ntab;
+        case JX_T_LNRATE: return f * (size_t)c.nband * 2 * c.ntab;
+    }
+    return 0;
+}
+
+static bool tensor_is_xray(int id) { return id >= JX_T_X_R_NE && id <= JX_T_LNRATE; }
+
+template <typename T>
+static int dev_put(jx_ctx* ctx, const T* src, size_t count, T** out) {
+    void* p = nullptr;
+    HIPCHK(ctx, hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)));
+    ctx->dev_allocs.push_back(p);
+    ctx->device_bytes += (int64_t)(count * sizeof(T));
+    if (count) HIPCHK(ctx, hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice));
+    *out = (T*)p;
+    return JX_OK;
+}
+
+template <typename T>
+static int dev_new(jx_ctx* ctx, size_t count, T** out, bool zero = false) {
+    void* p = nullptr;
+    HIPCHK(ctx, hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)));
+    ctx->dev_allocs.push_back(p);
+    ctx->device_bytes += (int64_t)(count * sizeof(T));
+    if (zero) HIPCHK(ctx, hipMemset(p, 0, count * sizeof(T)));
+    *out = (T*)p;
+    return JX_OK;
+}
+
+template <typename T>
+static std::vector<T> host_vec(jx_ctx* ctx, int id) {
+    const auto& b = ctx->host[id];
+    std::vector<T> v(b.size() / sizeof(T));
+    if (!v.empty()) memcpy(v.data(), b.data(), b.size());
+    return v;
+}
+
+extern "C" {
+
+const char* jx_strerror(int s) {
+    switch (s) {
+        case JX_OK: return "ok";
+        case JX_ERR_INVALID: return "invalid argument";
+        case JX_ERR_STATE: return "call out of order";
+        case JX_ERR_MISSING: return "required tensor not uploaded";
+        case JX_ERR_HIP: return "HIP runtime error";
+        case JX_ERR_ROCFFT: return "rocFFT error";
+        case JX_ERR_NOMEM: return "out of memory";
+        case JX_ERR_NODEVICE: return "no usable HIP device";
+        case JX_ERR_UNSUPPORTED: return "unsupported size";
+    }
+    return "unknown status";
+}
+
+const char* jx_last_error(jx_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int jx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* jx_device_name(jx_ctx* ctx) { return ctx ? ctx->devname.c_str() : ""; }
+
+int jx_create(const jx_config* cfg, jx_ctx** out) {
+    if (!cfg || !out) return JX_ERR_INVALID;
+    *out = nullptr;
+    if (cfg->abi_version != JX_ABI_VERSION) return JX_ERR_INVALID;
+    const jx_config& c = *cfg;
+    if (c.S < 7 || c.N < 4 || c.B < 1 || (c.B % 2) == 0 || c.nflux < 1 || c.nconv < 2) return JX_ERR_INVALID;
+    if (c.npar != 16 && c.npar != 19) return JX_ERR_INVALID;
+    if ((c.ne_mode == 1) != (c.npar == 19)) return JX_ERR_INVALID;
+    if (c.ndim < 1 || c.ndim > c.npar) return JX_ERR_INVALID;
+    if (!c.sz_only && (c.nann < 1 || c.nband < 1 || c.ntab < 2)) return JX_ERR_INVALID;
+    if (c.N < c.S - c.S / 2) return JX_ERR_INVALID;       // r_pp[:nrow-1] must exist (joxsz_funcs.py:469)
+    if (!(c.step > 0) || !(c.kpc_as > 0) || !(c.m_e > 0) || !(c.sigma_T > 0) || !(c.kpc_cm > 0)) return JX_ERR_INVALID;
+    if (c.nann > 64 || c.nband > 64 || c.N > 4096 || c.S > 4096) return JX_ERR_UNSUPPORTED;
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return JX_ERR_NODEVICE;
+    if (c.device < 0 || c.device >= ndev) return JX_ERR_NODEVICE;
+
+    jx_ctx* ctx = new (std::nothrow) jx_ctx();
+    if (!ctx) return JX_ERR_NOMEM;
+    ctx->cfg = c;
+    ctx->host.resize(JX_T_COUNT);
+    ctx->have.assign(JX_T_COUNT, false);
+    if (hipSetDevice(c.device) != hipSuccess) { delete ctx; return JX_ERR_NODEVICE; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, c.device) != hipSuccess) { delete ctx; return JX_ERR_NODEVICE; }
+    ctx->devname = std::string(prop.name) + " (" + prop.gcnArchName + ")";
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return JX_ERR_HIP; }
+    if (g_rocfft_refs++ == 0) rocfft_setup();
+    *out = ctx;
+    return JX_OK;
+}
+
+int jx_upload(jx_ctx* ctx, int id, const void* host, size_t nbytes) {
+    if (!ctx || !host) return JX_ERR_INVALID;
+    if (ctx->finalized) { ctx->err = "jx_upload after jx_finalize"; return JX_ERR_STATE; }
+    if (id < 0 || id >= JX_T_COUNT) return JX_ERR_INVALID;
+    const size_t want = tensor_bytes(ctx->cfg, id);
+    if (nbytes != want) {
+        ctx->err = "tensor " + std::to_string(id) + ": got " + std::to_string(nbytes) + " bytes, expected " + std::to_string(want);
+        return JX_ERR_INVALID;
+    }
+    ctx->host[id].assign((const unsigned char*)host, (const unsigned char*)host + nbytes);
+    ctx->have[id] = true;
+    return JX_OK;
+}
+
+static int make_plans(jx_ctx* ctx, int batch, Plan3** out) {
+    auto it = ctx->plans.find(batch);
+    if (it != ctx->plans.end()) { *out = &it->second; return JX_OK; }
+    Plan3 pl;
+    const size_t P = ctx->P, Ph = ctx->Ph, S = ctx->cfg.S, Sh = ctx->Sh;
+    {   // beam convolution forward: real [P][P] -> hermitian [P][Ph]
+        size_t len[2] = {P, P};
+        FFTCHK(ctx, rocfft_plan_create(&pl.beam_fwd, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
+                                       rocfft_precision_double, 2, len, (size_t)batch, nullptr));
+        FFTCHK(ctx, rocfft_plan_create(&pl.beam_inv, rocfft_placement_notinplace, rocfft_transform_type_real_inverse,
+                                       rocfft_precision_double, 2, len, (size_t)batch, nullptr));
+    }
+    {   // transfer function forward: real S x S window of the padded image (row stride P)
+        rocfft_plan_description desc = nullptr;
+        FFTCHK(ctx, rocfft_plan_description_create(&desc));
+        size_t istr[2] = {1, P}, ostr[2] = {1, Sh};
+        FFTCHK(ctx, rocfft_plan_description_set_data_layout(desc, rocfft_array_type_real, rocfft_array_type_hermitian_interleaved,
+                                                            nullptr, nullptr, 2, istr, P * P, 2, ostr, S * Sh));
+        size_t len[2] = {S, S};
+        FFTCHK(ctx, rocfft_plan_create(&pl.tf_fwd, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
+                                       rocfft_precision_double, 2, len, (size_t)batch, desc));
+        rocfft_plan_description_destroy(desc);
+    }
+    size_t w1 = 0, w2 = 0, w3 = 0;
+    FFTCHK(ctx, rocfft_plan_get_work_buffer_size(pl.beam_fwd, &w1));
+    FFTCHK(ctx, rocfft_plan_get_work_buffer_size(pl.beam_inv, &w2));
+    FFTCHK(ctx, rocfft_plan_get_work_buffer_size(pl.tf_fwd, &w3));
+    pl.work_bytes = std::max(w1, std::max(w2, w3));
+    if (pl.work_bytes > ctx->work_cap) {
+        if (ctx->d_work) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(ctx->d_work)); ctx->d_work = nullptr; }
+        HIPCHK(ctx, hipMalloc(&ctx->d_work, pl.work_bytes));
+        ctx->device_bytes += (int64_t)pl.work_bytes - (int64_t)ctx->work_cap;
+        ctx->work_cap = pl.work_bytes;
+    }
+    if (ctx->work_cap) FFTCHK(ctx, rocfft_execution_info_set_work_buffer(ctx->info, ctx->d_work, ctx->work_cap));
+    ctx->plans[batch] = pl;
+    *out = &ctx->plans[batch];
+    return JX_OK;
+}
+
+int jx_finalize(jx_ctx* ctx) {
+    if (!ctx) return JX_ERR_INVALID;
+    if (ctx->finalized) { ctx->err = "jx_finalize called twice"; return JX_ERR_STATE; }
+    const jx_config& c = ctx->cfg;
+    for (int id = 0; id < JX_T_COUNT; ++id) {
+        if (c.sz_only && tensor_is_xray(id)) continue;
+        if (!ctx->have[id]) { ctx->err = "tensor " + std::to_string(id) + " missing"; return JX_ERR_MISSING; }
+    }
+    HIPCHK(ctx, hipSetDevice(c.device));
+
+    const int S = c.S, N = c.N, B = c.B;
+    ctx->nrow = S - S / 2;
+    ctx->nt = ctx->nrow - 1;
+    ctx->Sh = S / 2 + 1;
+    const int o = (B - 1) / 2;
+    int P = c.fft_pad > 0 ? c.fft_pad : jxt::next_smooth_even(S + o);
+    if (const char* e = getenv("JOXSZ_FFT_PAD")) { int v = atoi(e); if (v > 0) P = v; }
+    if (P < S + o) { ctx->err = "fft_pad smaller than S + (B-1)/2"; return JX_ERR_INVALID; }
+    ctx->P = P;
+    ctx->Ph = P / 2 + 1;
+
+    std::vector<double> r = host_vec<double>(ctx, JX_T_R_PP);
+    for (int i = 0; i < N; ++i) {
+        if (!(r[i] > 0) || (i && !(r[i] > r[i - 1]))) { ctx->err = "r_pp must be positive and increasing"; return JX_ERR_INVALID; }
+    }
+    std::vector<int32_t> thawed = host_vec<int32_t>(ctx, JX_T_THAWED_IDX);
+    for (int k = 0; k < c.ndim; ++k)
+        if (thawed[k] < 0 || thawed[k] >= c.npar) { ctx->err = "thawed_idx out of range"; return JX_ERR_INVALID; }
+
+    JxDev& d = ctx->d;
+    memset(&d, 0, sizeof(d));
+    d.S = S; d.N = N; d.B = B; d.P = P; d.Ph = ctx->Ph; d.Sh = ctx->Sh; d.nrow = ctx->nrow; d.nt = ctx->nt;
+    d.nflux = c.nflux; d.nconv = c.nconv; d.nann = c.nann; d.nband = c.nband; d.ntab = c.ntab;
+    d.npar = c.npar; d.ndim = c.ndim; d.ne_mode = c.ne_mode; d.exclude_unphy_mass = c.exclude_unphy_mass;
+    d.sz_only = c.sz_only;
+    d.y_scale = c.kpc_cm * c.sigma_T / c.m_e;
+    d.r_first = r[0];
+    d.inv_h_mean = (double)(N - 1) / (r[N - 1] - r[0]);
+
+    int rc;
+    // ---- Abel weights, transposed so that a wave reads consecutive rows i of one source column j
+    {
+        std::vector<double> A, AT((size_t)N * N);
+        jxt::abel_matrix(r, A);
+        for (int i = 0; i < N; ++i)
+            for (int j = 0; j < N; ++j) AT[(size_t)j * N + i] = A[(size_t)i * N + j];
+        double* p; if ((rc = dev_put(ctx, AT.data(), AT.size(), &p))) return rc; d.abelT = p;
+    }
+    // ---- spline moment operator of the mirrored grid, stored as a band
+    {
+        std::vector<double> G;
+        if (!jxt::mirrored_spline_op(r, G)) { ctx->err = "spline operator: singular system"; return JX_ERR_INVALID; }
+        int K = jxt::band_halfwidth(G, N, 1e-20);
+        ctx->K = d.K = K;
+        std::vector<double> band((size_t)(2 * K + 1) * N, 0.0);
+        for (int i = 0; i < N; ++i)
+            for (int k = -K; k <= K; ++k) {
+                const int j = i + k;
+                if (j >= 0 && j < N) band[(size_t)(k + K) * N + i] = G[(size_t)i * N + j];
+            }
+        double* p; if ((rc = dev_put(ctx, band.data(), band.size(), &p))) return rc; d.gband = p;
+    }
+    // ---- h(0) weights: spline through (+-r_pp[:nt], t) evaluated at 0 (joxsz_funcs.py:470-473)
+    {
+        std::vector<double> rt(r.begin(), r.begin() + ctx->nt), G;
+        if (!jxt::mirrored_spline_op(rt, G)) { ctx->err = "h(0) operator: singular system"; return JX_ERR_INVALID; }
+        std::vector<double> hw(ctx->nt);
+        for (int j = 0; j < ctx->nt; ++j) hw[j] = -0.5 * rt[0] * rt[0] * G[j];
+        hw[0] += 1.0;
+        double* p; if ((rc = dev_put(ctx, hw.data(), hw.size(), &p))) return rc; d.hw = p;
+    }
+    // ---- evaluation matrix of g at the data radii (joxsz_funcs.py:476)
+    {
+        std::vector<double> radius = host_vec<double>(ctx, JX_T_RADIUS);
+        std::vector<double> xk(radius.begin() + S / 2, radius.end());
+        for (size_t i = 1; i < xk.size(); ++i)
+            if (!(xk[i] > xk[i - 1])) { ctx->err = "radius[S//2:] must be increasing"; return JX_ERR_INVALID; }
+        std::vector<double> flux = host_vec<double>(ctx, JX_T_FLUX_DATA);
+        std::vector<double> q(flux.begin(), flux.begin() + c.nflux), E;
+        if (!jxt::nak_eval_matrix(xk, q, E)) { ctx->err = "profile spline: singular system"; return JX_ERR_INVALID; }
+        double* p; if ((rc = dev_put(ctx, E.data(), E.size(), &p))) return rc; d.emat = p;
+        if ((rc = dev_put(ctx, flux.data(), flux.size(), &p))) return rc; d.flux = p;
+    }
+    // ---- beam spectrum and transfer-function row table
+    {
+        std::vector<double> beam = host_vec<double>(ctx, JX_T_BEAM_2D), bh;
+        jxt::beam_spectrum(beam, B, P, c.step * c.step / ((double)P * (double)P), bh);
+        double* p; if ((rc = dev_put(ctx, bh.data(), bh.size(), &p))) return rc; d.bhat = p;
+        std::vector<double> filt = host_vec<double>(ctx, JX_T_FILTERING), H;
+        jxt::tf_row_table(filt, S, H);
+        if ((rc = dev_put(ctx, H.data(), H.size(), &p))) return rc; d.htab = p;
+        std::vector<double> tw((size_t)S * 2);
+        for (int m = 0; m < S; ++m) { tw[2 * m] = std::cos(2.0 * jxt::kPi * m / S); tw[2 * m + 1] = std::sin(2.0 * jxt::kPi * m / S); }
+        if ((rc = dev_put(ctx, tw.data(), tw.size(), &p))) return rc; d.twid = p;
+    }
+    // ---- plain copies
+    {
+        double* p; int* q;
+#define PUTD(field, id) { std::vector<double> v = host_vec<double>(ctx, id); if ((rc = dev_put(ctx, v.data(), v.size(), &p))) return rc; d.field = p; }
+#define PUTI(field, id) { std::vector<int32_t> v = host_vec<int32_t>(ctx, id); if ((rc = dev_put(ctx, v.data(), v.size(), &q))) return rc; d.field = q; }
+        PUTD(r_pp, JX_T_R_PP) PUTD(d_mat, JX_T_D_MAT) PUTD(conv_T, JX_T_CONV_T) PUTD(conv_v, JX_T_CONV_V)
+        PUTD(par_vals, JX_T_PAR_VALS) PUTD(par_min, JX_T_PAR_MIN) PUTD(par_max, JX_T_PAR_MAX)
+        PUTD(par_mu, JX_T_PAR_MU) PUTD(par_sigma, JX_T_PAR_SIGMA)
+        PUTI(par_kind, JX_T_PAR_KIND) PUTI(thawed_idx, JX_T_THAWED_IDX)
+        ctx->d_par_vals = const_cast<double*>(d.par_vals);
+        if (!c.sz_only) {
+            PUTD(x_r_ne, JX_T_X_R_NE) PUTD(x_r_T, JX_T_X_R_T) PUTD(projvols, JX_T_PROJVOLS) PUTD(cts, JX_T_CTS)
+            PUTD(areascales, JX_T_AREASCALES) PUTD(exposures, JX_T_EXPOSURES) PUTD(backrates, JX_T_BACKRATES)
+            PUTD(geomarea, JX_T_GEOMAREA) PUTD(lnT, JX_T_LNT) PUTD(lnrate, JX_T_LNRATE)
+        }
+#undef PUTD
+#undef PUTI
+    }
+
+    // ---- chunk capacity and work buffers
+    const size_t per_walker = sizeof(double) * ((size_t)P * P * 2 + (size_t)P * ctx->Ph * 2 + (size_t)S * ctx->Sh * 2);
+    int chunk = c.max_batch > 0 ? c.max_batch : 512;
+    if (const char* e = getenv("JOXSZ_CHUNK")) { int v = atoi(e); if (v > 0) chunk = v; }
+    const size_t budget = (size_t)24 << 30;
+    while (chunk > 1 && per_walker * chunk > budget) chunk /= 2;
+    ctx->chunk = chunk;
+    int split = c.map_split > 0 ? c.map_split : 1;
+    if (const char* e = getenv("JOXSZ_MAP_SPLIT")) { int v = atoi(e); if (v > 0) split = v; }
+    ctx->map_split = d.map_split = std::min(split, S);
+    ctx->map_threads = 1024;
+    if (const char* e = getenv("JOXSZ_MAP_THREADS")) { int v = atoi(e); if (v >= 64 && v <= 1024 && v % 64 == 0) ctx->map_threads = v; }
+
+    if ((rc = dev_new(ctx, (size_t)chunk * JX_MAX_PAR, &ctx->d_pvec))) return rc;
+    if ((rc = dev_new(ctx, (size_t)chunk, &ctx->d_base))) return rc;
+    if ((rc = dev_new(ctx, (size_t)chunk * ctx->nrow, &ctx->d_cfac))) return rc;
+    if ((rc = dev_new(ctx, (size_t)chunk * P * P, &ctx->d_img, true))) return rc;     // padding stays zero for ever
+    if ((rc = dev_new(ctx, (size_t)chunk * P * P, &ctx->d_conv))) return rc;
+    if ((rc = dev_new(ctx, (size_t)chunk * P * ctx->Ph, &ctx->d_spec))) return rc;
+    if ((rc = dev_new(ctx, (size_t)chunk * S * ctx->Sh, &ctx->d_tfspec))) return rc;
+
+    FFTCHK(ctx, rocfft_execution_info_create(&ctx->info));
+    FFTCHK(ctx, rocfft_execution_info_set_stream(ctx->info, ctx->stream));
+    ctx->finalized = true;
+    return JX_OK;
+}
+
+static int ensure_batch(jx_ctx* ctx, int n) {
+    if (n <= ctx->batch_cap) return JX_OK;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_theta) { hipFree(ctx->d_theta); hipFree(ctx->d_logp); }
+    HIPCHK(ctx, hipMalloc((void**)&ctx->d_theta, sizeof(double) * (size_t)n * ctx->cfg.ndim));
+    HIPCHK(ctx, hipMalloc((void**)&ctx->d_logp, sizeof(double) * (size_t)n));
+    ctx->batch_cap = n;
+    return JX_OK;
+}
+
+static int get_evset(jx_ctx* ctx, EvSet* out) {
+    if (!ctx->ev_free.empty()) { *out = ctx->ev_free.back(); ctx->ev_free.pop_back(); return JX_OK; }
+    for (int k = 0; k < 6; ++k) HIPCHK(ctx, hipEventCreate(&out->e[k]));
+    return JX_OK;
+}
+
+static int drain_events(jx_ctx* ctx) {
+    if (ctx->ev_inflight.empty()) return JX_OK;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto& es : ctx->ev_inflight) {
+        float ms[5], tot;
+        for (int k = 0; k < 5; ++k) HIPCHK(ctx, hipEventElapsedTime(&ms[k], es.e[k], es.e[k + 1]));
+        HIPCHK(ctx, hipEventElapsedTime(&tot, es.e[0], es.e[5]));
+        ctx->acc.prep_ms += ms[0]; ctx->acc.abel_map_ms += ms[1]; ctx->acc.beam_fft_ms += ms[2];
+        ctx->acc.tf_fft_ms += ms[3]; ctx->acc.tail_ms += ms[4]; ctx->acc.total_ms += tot;
+        ctx->acc.launches += 1; ctx->acc.walkers += es.walkers;
+        ctx->ev_free.push_back(es);
+    }
+    ctx->ev_inflight.clear();
+    return JX_OK;
+}
+
+struct Taps {
+    double *pp = nullptr, *ab = nullptr, *y = nullptr, *row = nullptr, *bright = nullptr, *chisq = nullptr,
+           *tprof = nullptr, *xprofs = nullptr, *parts = nullptr;
+};
+
+// One chunk: walkers [w0, w0+n) of the batch whose thetas live at theta_dev.
+static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int w0, int n, const Taps& t) {
+    Plan3* pl = nullptr;
+    int rc = make_plans(ctx, n, &pl);
+    if (rc) return rc;
+    const JxDev& d = ctx->d;
+    hipStream_t st = ctx->stream;
+    EvSet es;
+    const bool tm = ctx->timing_on;
+    if (tm) {
+        if (ctx->ev_inflight.size() > 2048 && (rc = drain_events(ctx))) return rc;
+        if ((rc = get_evset(ctx, &es))) return rc;
+        es.walkers = n;
+        HIPCHK(ctx, hipEventRecord(es.e[0], st));
+    }
+    {
+        const size_t sh = sizeof(double) * ((size_t)d.N + 2 * d.nann + (size_t)d.nband * d.nann + 8);
+        hipLaunchKernelGGL(jx_prep_kernel, dim3(n), dim3(JX_PREP_THREADS), sh, st, d, theta_dev, w0, ctx->d_pvec,
+                           ctx->d_base, ctx->d_cfac, t.tprof, t.xprofs, t.parts);
+    }
+    if (tm) HIPCHK(ctx, hipEventRecord(es.e[1], st));
+    {
+        const size_t sh = sizeof(double) * (size_t)d.N * 8;
+        const bool vec2 = (d.S % 2 == 0) && (d.P % 2 == 0);
+        if (vec2)
+            hipLaunchKernelGGL(jx_abel_map_kernel<true>, dim3(n * d.map_split), dim3(ctx->map_threads), sh, st, d, ctx->d_pvec,
+                               ctx->d_img, t.pp, t.ab, t.y);
+        else
+            hipLaunchKernelGGL(jx_abel_map_kernel<false>, dim3(n * d.map_split), dim3(ctx->map_threads), sh, st, d, ctx->d_pvec,
+                               ctx->d_img, t.pp, t.ab, t.y);
+    }
+    if (tm) HIPCHK(ctx, hipEventRecord(es.e[2], st));
+    {
+        void* in[1] = {ctx->d_img};
+        void* out[1] = {ctx->d_spec};
+        FFTCHK(ctx, rocfft_execute(pl->beam_fwd, in, out, ctx->info));
+        const size_t per = (size_t)d.P * d.Ph, total = per * n;
+        const int blocks = (int)std::min<size_t>((total + 255) / 256, 8192);
+        hipLaunchKernelGGL(jx_beam_mul_kernel, dim3(blocks), dim3(256), 0, st, ctx->d_spec, (const double2*)d.bhat, per, total);
+        void* in2[1] = {ctx->d_spec};
+        void* out2[1] = {ctx->d_conv};
+        FFTCHK(ctx, rocfft_execute(pl->beam_inv, in2, out2, ctx->info));
+    }
+    if (tm) HIPCHK(ctx, hipEventRecord(es.e[3], st));
+    {
+        void* in[1] = {ctx->d_conv};
+        void* out[1] = {ctx->d_tfspec};
+        FFTCHK(ctx, rocfft_execute(pl->tf_fwd, in, out, ctx->info));
+    }
+    if (tm) HIPCHK(ctx, hipEventRecord(es.e[4], st));
+    {
+        const size_t sh = sizeof(double) * ((size_t)2 * d.Sh + d.nrow + 8);
+        hipLaunchKernelGGL(jx_tail_kernel, dim3(n), dim3(JX_TAIL_THREADS), sh, st, d, ctx->d_tfspec, ctx->d_cfac, ctx->d_base,
+                           logp_dev, w0, t.row, t.bright, t.chisq, t.parts);
+    }
+    if (tm) {
+        HIPCHK(ctx, hipEventRecord(es.e[5], st));
+        ctx->ev_inflight.push_back(es);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return JX_OK;
+}
+
+int jx_eval_device(jx_ctx* ctx, const double* theta_dev, int nwalkers, double* logp_dev) {
+    if (!ctx || !theta_dev || !logp_dev || nwalkers < 0) return JX_ERR_INVALID;
+    if (!ctx->finalized) { ctx->err = "jx_eval before jx_finalize"; return JX_ERR_STATE; }
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    Taps none;
+    for (int w0 = 0; w0 < nwalkers; w0 += ctx->chunk) {
+        const int n = std::min(ctx->chunk, nwalkers - w0);
+        int rc = run_chunk(ctx, theta_dev, logp_dev, w0, n, none);
+        if (rc) return rc;
+    }
+    return JX_OK;
+}
+
+int jx_sync(jx_ctx* ctx) {
+    if (!ctx) return JX_ERR_INVALID;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return JX_OK;
+}
+
+int jx_eval(jx_ctx* ctx, const double* theta, int nwalkers, double* logp) {
+    if (!ctx || nwalkers < 0 || (nwalkers && (!theta || !logp))) return JX_ERR_INVALID;
+    if (!ctx->finalized) { ctx->err = "jx_eval before jx_finalize"; return JX_ERR_STATE; }
+    if (nwalkers == 0) return JX_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    int rc = ensure_batch(ctx, nwalkers);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_theta, theta, sizeof(double) * (size_t)nwalkers * ctx->cfg.ndim, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = jx_eval_device(ctx, ctx->d_theta, nwalkers, ctx->d_logp))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(logp, ctx->d_logp, sizeof(double) * (size_t)nwalkers, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return JX_OK;
+}
+
+static int ensure_taps(jx_ctx* ctx) {
+    if (ctx->t_pp) return JX_OK;
+    const jx_config& c = ctx->cfg;
+    const size_t C = ctx->chunk;
+    int rc;
+    if ((rc = dev_new(ctx, C * c.N, &ctx->t_pp))) return rc;
+    if ((rc = dev_new(ctx, C * c.N, &ctx->t_ab))) return rc;
+    if ((rc = dev_new(ctx, C * c.N, &ctx->t_y))) return rc;
+    if ((rc = dev_new(ctx, C * ctx->nrow, &ctx->t_row))) return rc;
+    if ((rc = dev_new(ctx, C * ctx->nrow, &ctx->t_bright))) return rc;
+    if ((rc = dev_new(ctx, C * ctx->nrow, &ctx->t_tprof))) return rc;
+    if ((rc = dev_new(ctx, C, &ctx->t_chisq))) return rc;
+    if ((rc = dev_new(ctx, C * std::max(1, c.nband * c.nann), &ctx->t_xprofs, true))) return rc;
+    if ((rc = dev_new(ctx, C * 4, &ctx->t_parts, true))) return rc;
+    return JX_OK;
+}
+
+int jx_eval_stage(jx_ctx* ctx, const double* theta, int nwalkers, int stage, double* out, size_t nbytes) {
+    if (!ctx || !theta || !out || nwalkers <= 0) return JX_ERR_INVALID;
+    if (!ctx->finalized) { ctx->err = "jx_eval_stage before jx_finalize"; return JX_ERR_STATE; }
+    if (stage < 0 || stage >= JX_STAGE_COUNT) return JX_ERR_INVALID;
+    const jx_config& c = ctx->cfg;
+    const size_t S = c.S, P = ctx->P;
+    size_t per = 0;
+    switch (stage) {
+        case JX_STAGE_PP: case JX_STAGE_AB: case JX_STAGE_Y: per = c.N; break;
+        case JX_STAGE_Y2D: case JX_STAGE_CONV2D: per = S * S; break;
+        case JX_STAGE_MAPROW: case JX_STAGE_BRIGHT: case JX_STAGE_TPROF: per = ctx->nrow; break;
+        case JX_STAGE_CHISQ: per = 1; break;
+        case JX_STAGE_XPROFS: per = (size_t)c.nband * c.nann; break;
+        case JX_STAGE_PARTS: per = 4; break;
+    }
+    if (stage == JX_STAGE_XPROFS && c.sz_only) { ctx->err = "no X-ray profiles in sz_only mode"; return JX_ERR_INVALID; }
+    if (nbytes != per * sizeof(double) * (size_t)nwalkers) { ctx->err = "jx_eval_stage: wrong output size"; return JX_ERR_INVALID; }
+    HIPCHK(ctx, hipSetDevice(c.device));
+    int rc;
+    if ((rc = ensure_taps(ctx))) return rc;
+    if ((rc = ensure_batch(ctx, nwalkers))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_theta, theta, sizeof(double) * (size_t)nwalkers * c.ndim, hipMemcpyHostToDevice, ctx->stream));
+    Taps t;
+    t.pp = ctx->t_pp; t.ab = ctx->t_ab; t.y = ctx->t_y; t.row = ctx->t_row; t.bright = ctx->t_bright;
+    t.chisq = ctx->t_chisq; t.tprof = ctx->t_tprof; t.xprofs = c.sz_only ? nullptr : ctx->t_xprofs; t.parts = ctx->t_parts;
+    for (int w0 = 0; w0 < nwalkers; w0 += ctx->chunk) {
+        const int n = std::min(ctx->chunk, nwalkers - w0);
+        if ((rc = run_chunk(ctx, ctx->d_theta, ctx->d_logp, w0, n, t))) return rc;
+        double* dst = out + per * (size_t)w0;
+        const double* src = nullptr;
+        switch (stage) {
+            case JX_STAGE_PP: src = ctx->t_pp; break;
+            case JX_STAGE_AB: src = ctx->t_ab; break;
+            case JX_STAGE_Y: src = ctx->t_y; break;
+            case JX_STAGE_MAPROW: src = ctx->t_row; break;
+            case JX_STAGE_BRIGHT: src = ctx->t_bright; break;
+            case JX_STAGE_TPROF: src = ctx->t_tprof; break;
+            case JX_STAGE_CHISQ: src = ctx->t_chisq; break;
+            case JX_STAGE_XPROFS: src = ctx->t_xprofs; break;
+            case JX_STAGE_PARTS: src = ctx->t_parts; break;
+            default: break;
+        }
+        if (src) {
+            HIPCHK(ctx, hipMemcpyAsync(dst, src, per * sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+        } else {
+            const double* base = (stage == JX_STAGE_Y2D) ? ctx->d_img : ctx->d_conv;
+            for (int w = 0; w < n; ++w)
+                HIPCHK(ctx, hipMemcpy2DAsync(dst + (size_t)w * S * S, S * sizeof(double), base + (size_t)w * P * P,
+                                             P * sizeof(double), S * sizeof(double), S, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return JX_OK;
+}
+
+int jx_set_par_vals(jx_ctx* ctx, const double* v, int npar) {
+    if (!ctx || !v || npar != ctx->cfg.npar) return JX_ERR_INVALID;
+    if (!ctx->finalized) return jx_upload(ctx, JX_T_PAR_VALS, v, sizeof(double) * npar);
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_par_vals, v, sizeof(double) * npar, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return JX_OK;
+}
+
+int jx_dev_alloc(jx_ctx* ctx, size_t nbytes, void** out) {
+    if (!ctx || !out) return JX_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    HIPCHK(ctx, hipMalloc(out, std::max<size_t>(nbytes, 8)));
+    return JX_OK;
+}
+
+int jx_dev_free(jx_ctx* ctx, void* p) {
+    if (!ctx) return JX_ERR_INVALID;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipFree(p));
+    return JX_OK;
+}
+
+int jx_memcpy_h2d(jx_ctx* ctx, void* dev, const void* host, size_t n) {
+    if (!ctx || !dev || !host) return JX_ERR_INVALID;
+    HIPCHK(ctx, hipMemcpyAsync(dev, host, n, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return JX_OK;
+}
+
+int jx_memcpy_d2h(jx_ctx* ctx, void* host, const void* dev, size_t n) {
+    if (!ctx || !dev || !host) return JX_ERR_INVALID;
+    HIPCHK(ctx, hipMemcpyAsync(host, dev, n, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return JX_OK;
+}
+
+int jx_timing_enable(jx_ctx* ctx, int on) {
+    if (!ctx) return JX_ERR_INVALID;
+    ctx->timing_on = on != 0;
+    return JX_OK;
+}
+
+int jx_timing_reset(jx_ctx* ctx) {
+    if (!ctx) return JX_ERR_INVALID;
+    int rc = drain_events(ctx);
+    if (rc) return rc;
+    memset(&ctx->acc, 0, sizeof(ctx->acc));
+    return JX_OK;
+}
+
+int jx_timing_get(jx_ctx* ctx, jx_timing* out) {
+    if (!ctx || !out) return JX_ERR_INVALID;
+    int rc = drain_events(ctx);
+    if (rc) return rc;
+    *out = ctx->acc;
+    return JX_OK;
+}
+
+int jx_get_info(jx_ctx* ctx, int32_t* fft_pad, int32_t* chunk, int32_t* band, int32_t* nrow, int64_t* bytes) {
+    if (!ctx || !ctx->finalized) return JX_ERR_STATE;
+    if (fft_pad) *fft_pad = ctx->P;
+    if (chunk) *chunk = ctx->chunk;
+    if (band) *band = ctx->K;
+    if (nrow) *nrow = ctx->nrow;
+    if (bytes) *bytes = ctx->device_bytes;
+    return JX_OK;
+}
+
+void jx_destroy(jx_ctx* ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->cfg.device);
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    for (auto& kv : ctx->plans) {
+        if (kv.second.beam_fwd) rocfft_plan_destroy(kv.second.beam_fwd);
+        if (kv.second.beam_inv) rocfft_plan_destroy(kv.second.beam_inv);
+        if (kv.second.tf_fwd) rocfft_plan_destroy(kv.second.tf_fwd);
+    }
+    if (ctx->info) rocfft_execution_info_destroy(ctx->info);
+    for (auto& es : ctx->ev_inflight) for (int k = 0; k < 6; ++k) hipEventDestroy(es.e[k]);
+    for (auto& es : ctx->ev_free) for (int k = 0; k < 6; ++k) hipEventDestroy(es.e[k]);
+    for (void* p : ctx->dev_allocs) hipFree(p);
+    if (ctx->d_work) hipFree(ctx->d_work);
+    if (ctx->d_theta) hipFree(ctx->d_theta);
+    if (ctx->d_logp) hipFree(ctx->d_logp);
+    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    if (--g_rocfft_refs == 0) rocfft_cleanup();
+    delete ctx;
+}
+
+}  // extern "C"

@@ -1,0 +1,493 @@
+// Device kernels of the JoXSZ log-posterior for gfx950 (CDNA4, wave64).
+//
+// All arithmetic is IEEE fp64 like the reference.  No MFMA: the path is
+// memory-bound integration (HBM write of the y map, FFT passes), not a dense
+// contraction.  Kernel list (one launch each per chunk of walkers):
+//
+//   jx_prep_kernel      theta -> parameter vector, priors, mass veto, T_SZ profile,
+//                       Compton->mJy/beam factors, X-ray counts + Cash likelihood
+//   jx_abel_map_kernel  FUSED gNFW profile -> Abel integral -> Compton y -> cubic
+//                       spline -> S x S map written into the zero-padded FFT image
+//   jx_beam_mul_kernel  spectrum *= beam spectrum
+//   jx_tail_kernel      transfer function + central row + conversion + chi^2 + sum
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define JX_MAX_PAR 19
+#define JX_PREP_THREADS 256
+#define JX_MAP_THREADS 256
+#define JX_TAIL_THREADS 256
+
+// semantic slots of the parameter vector (joxsz_amd/problem.py PAR_SLOTS)
+enum {
+    P_LOGN0 = 0, P_BETA, P_LOGRC, P_LOGRS, P_ALPHA, P_EPS, P_GAMMA, P_LOGTR, P_Z,
+    P_P0, P_A, P_B, P_C, P_RP, P_BACKSCALE, P_CALIB, P_LOGN02, P_BETA2, P_LOGRC2
+};
+
+enum { REJ_BOX = 1, REJ_MASS = 2, REJ_RCRS = 4, REJ_XRAY = 8 };
+
+struct JxDev {
+    // sizes
+    int S, N, B, P, Ph, Sh, nrow, nt, nflux, nconv, nann, nband, ntab, npar, ndim;
+    int ne_mode, exclude_unphy_mass, sz_only;
+    int K;                       // half-bandwidth of the spline moment operator
+    int map_split;               // row slabs per walker in the Abel+map kernel
+    int uniform_hint;            // 1: r_pp close to uniform -> O(1) interval lookup
+    double y_scale;              // kpc_cm * sigma_T / m_e            (joxsz_funcs.py:459)
+    double r_first, inv_h_mean;
+    // constant tensors (device)
+    const double* r_pp;          // [N]
+    const double* d_mat;         // [S*S]
+    const double* abelT;         // [N*N] abelT[j*N+i] = A[i][j] (column of weights per source j)
+    const double* gband;         // [(2K+1)*N] gband[(k+K)*N+i] = G[i][i+k]
+    const double* bhat;          // [P*Ph*2]
+    const double* htab;          // [S*Sh*2]
+    const double* twid;          // [S*2] cos, sin of 2 pi m / S
+    const double* hw;            // [nt]   h(0) = sum hw[k] t[k]     (joxsz_funcs.py:470-473)
+    const double* emat;          // [nflux*nrow]
+    const double* flux;          // [3*nflux]
+    const double* conv_T; const double* conv_v;   // [nconv]
+    const double* par_vals; const double* par_min; const double* par_max;
+    const double* par_mu; const double* par_sigma; const int* par_kind; const int* thawed_idx;
+    const double* x_r_ne; const double* x_r_T; const double* projvols; const double* cts;
+    const double* areascales; const double* exposures; const double* backrates;
+    const double* geomarea; const double* lnT; const double* lnrate;
+};
+
+// ------------------------------------------------------------------------------------
+// physics helpers
+// ------------------------------------------------------------------------------------
+
+// joxsz_funcs.py:275-287
+__device__ __forceinline__ double jx_press(const double* p, double r) {
+    const double x = r / p[P_RP];
+    return p[P_P0] / (pow(x, p[P_C]) * pow(1.0 + pow(x, p[P_A]), (p[P_B] - p[P_C]) / p[P_A]));
+}
+
+// joxsz_funcs.py:289-301
+__device__ __forceinline__ double jx_press_deriv(const double* p, double r) {
+    const double x = r / p[P_RP];
+    const double xa = pow(x, p[P_A]);
+    return -p[P_P0] * (p[P_C] + p[P_B] * xa) /
+           (p[P_RP] * pow(x, p[P_C] + 1.0) * pow(1.0 + xa, (p[P_B] - p[P_C] + p[P_A]) / p[P_A]));
+}
+
+// joxsz_funcs.py:375-395
+__device__ __forceinline__ double jx_ne(const double* p, double r, int mode) {
+    const double n0 = pow(10.0, p[P_LOGN0]);
+    const double rc = pow(10.0, p[P_LOGRC]);
+    const double rs = pow(10.0, p[P_LOGRS]);
+    const double x = r / rc;
+    double res = n0 * n0 * pow(x, -p[P_ALPHA]) /
+                 (pow(1.0 + x * x, 3.0 * p[P_BETA] - p[P_ALPHA] / 2.0) *
+                  pow(1.0 + pow(r / rs, p[P_GAMMA]), p[P_EPS] / p[P_GAMMA]));
+    if (mode == 1) {
+        const double n02 = pow(10.0, p[P_LOGN02]);
+        const double rc2 = pow(10.0, p[P_LOGRC2]);
+        const double x2 = r / rc2;
+        res += n02 * n02 / pow(1.0 + x2 * x2, 3.0 * p[P_BETA2]);
+    }
+    return sqrt(res);
+}
+
+// linear interp1d with fill_value='extrapolate' (joxsz_main.py:109)
+__device__ __forceinline__ double jx_convert(const JxDev& c, double T) {
+    int hi = 1;
+    while (hi < c.nconv - 1 && T > c.conv_T[hi]) ++hi;
+    const int lo = hi - 1;
+    const double slope = (c.conv_v[hi] - c.conv_v[lo]) / (c.conv_T[hi] - c.conv_T[lo]);
+    return slope * (T - c.conv_T[lo]) + c.conv_v[lo];
+}
+
+// np.interp(x, xp, fp): clamped linear interpolation
+__device__ __forceinline__ double jx_interp_clamped(const double* xp, const double* fp, int n, double x) {
+    if (x != x) return x;
+    if (x <= xp[0]) return fp[0];
+    if (x >= xp[n - 1]) return fp[n - 1];
+    int lo = 0, hi = n - 1;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (xp[mid] <= x) lo = mid; else hi = mid;
+    }
+    const double slope = (fp[hi] - fp[lo]) / (xp[hi] - xp[lo]);
+    return slope * (x - xp[lo]) + fp[lo];
+}
+
+__device__ __forceinline__ double jx_block_sum(double v, double* red /*[>=4]*/) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wv] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int k = 0; k < nw; ++k) t += red[k];
+    return t;
+}
+
+__device__ __forceinline__ int jx_block_or(int v, int* redi) {
+    __syncthreads();
+    if (threadIdx.x == 0) *redi = 0;
+    __syncthreads();
+    if (v) atomicOr(redi, v);
+    __syncthreads();
+    return *redi;
+}
+
+// ------------------------------------------------------------------------------------
+// K0: per-walker scalar work.  One 256-thread block per walker.
+//   pvec  [W, JX_MAX_PAR]  full parameter vector (updateThawed, joxsz_funcs.py:516)
+//   base  [W]  parprior + model prior + X-ray log-likelihood, or -inf when rejected
+//   cfac  [W, nrow]  convert([h(0), t_prof]) * calibration   (joxsz_funcs.py:473)
+//   optional taps: tprof [W,nrow], xprofs [W,nband,nann], parts [W,4]
+// ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(JX_PREP_THREADS)
+jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0, double* __restrict__ pvec,
+               double* __restrict__ base, double* __restrict__ cfac, double* __restrict__ tap_tprof,
+               double* __restrict__ tap_xprofs, double* __restrict__ tap_parts) {
+    extern __shared__ double sm[];
+    __shared__ double p[JX_MAX_PAR];
+    __shared__ double red[8];
+    __shared__ int redi;
+    const int w = blockIdx.x;                 // walker within the chunk
+    const int gw = w0 + w;                    // walker within the batch
+    const int tid = threadIdx.x, nth = blockDim.x;
+
+    double* s_m = sm;                         // [N] mass profile, then reused
+    double* s_ne = sm + c.N;                  // [nann]
+    double* s_T = s_ne + c.nann;              // [nann]
+    double* s_rate = s_T + c.nann;            // [nband*nann]
+
+    if (tid < JX_MAX_PAR) p[tid] = (tid < c.npar) ? c.par_vals[tid] : 0.0;
+    __syncthreads();
+    if (tid < c.ndim) p[c.thawed_idx[tid]] = theta[(size_t)gw * c.ndim + tid];
+    __syncthreads();
+    if (tid < JX_MAX_PAR) pvec[(size_t)w * JX_MAX_PAR + tid] = p[tid];
+
+    // ---- priors on every parameter (joxsz_funcs.py:518) ----
+    double pr = 0.0;
+    int rej = 0;
+    if (tid < c.npar) {
+        const double v = p[tid];
+        if (c.par_kind[tid] == 1) {
+            const double sg = c.par_sigma[tid];
+            if (sg <= 0.0) { rej |= REJ_BOX; }
+            else {
+                const double z = (v - c.par_mu[tid]) / sg;
+                pr = -0.5 * log(2.0 * 3.14159265358979323846) - log(sg) - 0.5 * z * z;
+            }
+        } else if (v < c.par_min[tid] || v > c.par_max[tid]) rej |= REJ_BOX;
+        if (v != v) rej |= REJ_BOX;           // NaN parameter: reject (emcee cannot use NaN)
+    }
+    const double parprior = jx_block_sum(pr, red);
+
+    // ---- model prior: r_c <= r_s (joxsz_funcs.py:397-407) ----
+    if (tid == 0 && pow(10.0, p[P_LOGRC]) > pow(10.0, p[P_LOGRS])) rej |= REJ_RCRS;
+
+    // ---- hydrostatic-mass monotonicity veto (joxsz_funcs.py:522-525, 428-437) ----
+    if (c.exclude_unphy_mass) {
+        for (int i = tid; i < c.N; i += nth) {
+            const double r = c.r_pp[i];
+            // positive constant factors of mass_fun cannot change the sign test
+            s_m[i] = -jx_press_deriv(p, r) * r * r / jx_ne(p, r, c.ne_mode);
+        }
+        __syncthreads();
+        for (int i = tid; i < c.N; i += nth) {
+            double g;                          // np.gradient(m, 1)
+            if (i == 0) g = s_m[1] - s_m[0];
+            else if (i == c.N - 1) g = s_m[c.N - 1] - s_m[c.N - 2];
+            else g = (s_m[i + 1] - s_m[i - 1]) / 2.0;
+            if (!(g > 0.0)) rej |= REJ_MASS;
+        }
+        __syncthreads();
+    }
+
+    // ---- T_SZ on r_pp[:nt], h(0), conversion factors (joxsz_funcs.py:469-473) ----
+    double* s_t = s_m;                         // reuse [nt] (nt < N)
+    double part = 0.0;
+    for (int k = tid; k < c.nt; k += nth) {
+        const double r = c.r_pp[k];
+        const double t = jx_press(p, r) / jx_ne(p, r, c.ne_mode);
+        s_t[k] = t;
+        part += c.hw[k] * t;
+    }
+    const double t0 = jx_block_sum(part, red);
+    for (int k = tid; k < c.nrow; k += nth) {
+        const double T = (k == 0) ? t0 : s_t[k - 1];
+        cfac[(size_t)w * c.nrow + k] = jx_convert(c, T) * p[P_CALIB];
+        if (tap_tprof) tap_tprof[(size_t)w * c.nrow + k] = T;
+    }
+    __syncthreads();
+
+    // ---- X-ray: calcProfiles + Cash (joxsz_funcs.py:527-532, 495-505) ----
+    double xlike = 0.0;
+    if (!c.sz_only) {
+        if (tid < c.nann) {
+            s_ne[tid] = jx_ne(p, c.x_r_ne[tid], c.ne_mode);
+            const double r = c.x_r_T[tid];
+            s_T[tid] = jx_press(p, r) / jx_ne(p, r, c.ne_mode) * pow(10.0, p[P_LOGTR]);   // T_X
+        }
+        __syncthreads();
+        const int nba = c.nband * c.nann;
+        for (int q = tid; q < nba; q += nth) {
+            const int b = q / c.nann, j = q - b * c.nann;
+            const double lt = log(s_T[j]);
+            const double* tab = c.lnrate + (size_t)b * 2 * c.ntab;
+            const double z0 = exp(jx_interp_clamped(c.lnT, tab, c.ntab, lt));
+            const double z1 = exp(jx_interp_clamped(c.lnT, tab + c.ntab, c.ntab, lt));
+            s_rate[q] = (z0 + (z1 - z0) * p[P_Z]) * s_ne[j] * s_ne[j];
+        }
+        __syncthreads();
+        double lk = 0.0;
+        int bad = 0;
+        for (int q = tid; q < nba; q += nth) {
+            const int b = q / c.nann, i = q - b * c.nann;
+            double proj = 0.0;
+            for (int j = 0; j < c.nann; ++j) proj += c.projvols[i * c.nann + j] * s_rate[b * c.nann + j];
+            const double ae = c.areascales[q] * c.exposures[q];
+            const double model = proj * ae + c.backrates[q] * c.geomarea[i] * ae * p[P_BACKSCALE];
+            if (tap_xprofs) tap_xprofs[(size_t)w * nba + q] = model;
+            if (!(model > 0.0)) bad = 1;       // np.array(profs).min() > 0 fails (NaN included)
+            const double ct = c.cts[q];
+            if (ct == ct) lk += ct * log(model) - model;
+        }
+        xlike = jx_block_sum(lk, red);
+        if (jx_block_or(bad, &redi)) rej |= REJ_XRAY;
+        // cashLogLikelihood returns -inf for a non-finite sum; per band in the reference,
+        // a non-finite band makes the total non-finite as well
+        if (!(fabs(xlike) <= 1.79769313486231570e308)) rej |= REJ_XRAY;
+    }
+    const int rejall = jx_block_or(rej, &redi);
+    if (tid == 0) {
+        double prior = parprior;
+        // the reference returns early on REJ_BOX / REJ_MASS; REJ_RCRS and REJ_XRAY add -inf
+        double b = (rejall != 0) ? -INFINITY : (prior + xlike);
+        base[w] = b;
+        if (tap_parts) {
+            tap_parts[(size_t)w * 4 + 0] = (rejall & REJ_XRAY) ? -INFINITY : xlike;
+            tap_parts[(size_t)w * 4 + 2] = (rejall & (REJ_BOX | REJ_RCRS)) ? -INFINITY : prior;
+            tap_parts[(size_t)w * 4 + 3] = (double)rejall;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// K1: FUSED profile -> Abel -> y -> spline -> map.  grid = (chunk walkers * map_split).
+//
+// Phase 1  pp_j = gNFW(r_j)                       -> LDS            (joxsz_funcs.py:453)
+// Phase 2  ab_i = sum_{j>=i} A[i][j] pp_j         thread-per-row, weights streamed
+//          coalesced from the shared table (L2), pp broadcast from LDS (joxsz_funcs.py:457)
+// Phase 3  y = y_scale * ab ; M = G_band y        (joxsz_funcs.py:459-460)
+// Phase 4  per-interval cubic coefficients        -> LDS
+// Phase 5  y_2d[p] = spline(d_mat[p]) for the block's row slab, coalesced reads of the
+//          shared radius matrix, coalesced 16-byte stores into the padded FFT image
+//          (joxsz_funcs.py:462).  This is the HBM-write-bound phase: S*S*8 bytes per walker.
+// ------------------------------------------------------------------------------------
+template <bool VEC2>
+__global__ void __launch_bounds__(1024)
+jx_abel_map_kernel(JxDev c, const double* __restrict__ pvec, double* __restrict__ img /*[chunk][P][P]*/,
+                   double* __restrict__ tap_pp, double* __restrict__ tap_ab, double* __restrict__ tap_y) {
+    extern __shared__ double sm[];
+    const int N = c.N;
+    double* s_r = sm;                 // [N] knots
+    double* s_pp = s_r + N;           // [N] pp, later y
+    double* s_y = s_pp + N;           // [N]
+    double* s_M = s_y + N;            // [N]
+    double* s_cf = s_M + N;           // [4N] a,b,c,d per interval k = [r_k, r_{k+1}]
+    __shared__ double p[JX_MAX_PAR];
+
+    const int tid = threadIdx.x, nth = blockDim.x;
+    const int w = blockIdx.x / c.map_split;
+    const int part = blockIdx.x - w * c.map_split;
+
+    if (tid < JX_MAX_PAR) p[tid] = pvec[(size_t)w * JX_MAX_PAR + tid];
+    __syncthreads();
+
+    // Phase 1
+    for (int j = tid; j < N; j += nth) {
+        const double r = c.r_pp[j];
+        s_r[j] = r;
+        const double v = jx_press(p, r);
+        s_pp[j] = v;
+        if (tap_pp && part == 0) tap_pp[(size_t)w * N + j] = v;
+    }
+    __syncthreads();
+
+    // Phase 2: row i of the upper-triangular product, 4 partial sums for ILP
+    for (int i = tid; i < N; i += nth) {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        const double* col = c.abelT + i;
+        int j = i;
+        for (; j + 3 < N; j += 4) {
+            a0 = fma(col[(size_t)j * N], s_pp[j], a0);
+            a1 = fma(col[(size_t)(j + 1) * N], s_pp[j + 1], a1);
+            a2 = fma(col[(size_t)(j + 2) * N], s_pp[j + 2], a2);
+            a3 = fma(col[(size_t)(j + 3) * N], s_pp[j + 3], a3);
+        }
+        for (; j < N; ++j) a0 = fma(col[(size_t)j * N], s_pp[j], a0);
+        const double ab = (a0 + a1) + (a2 + a3);
+        const double y = c.y_scale * ab;
+        s_y[i] = y;
+        if (part == 0) {
+            if (tap_ab) tap_ab[(size_t)w * N + i] = ab;
+            if (tap_y) tap_y[(size_t)w * N + i] = y;
+        }
+    }
+    __syncthreads();
+
+    // Phase 3: spline moments through the banded operator
+    const int K = c.K;
+    for (int i = tid; i < N; i += nth) {
+        const int k0 = max(-K, -i), k1 = min(K, N - 1 - i);
+        double m = 0.0;
+        for (int k = k0; k <= k1; ++k) m = fma(c.gband[(size_t)(k + K) * N + i], s_y[i + k], m);
+        s_M[i] = m;
+    }
+    __syncthreads();
+
+    // Phase 4: coefficients of interval k = [r_k, r_{k+1}], local abscissa t = x - r_k
+    for (int k = tid; k < N - 1; k += nth) {
+        const double h = s_r[k + 1] - s_r[k];
+        const double y0 = s_y[k], y1 = s_y[k + 1], m0 = s_M[k], m1 = s_M[k + 1];
+        s_cf[4 * k + 0] = y0;
+        s_cf[4 * k + 1] = (y1 - y0) / h - h * (2.0 * m0 + m1) / 6.0;
+        s_cf[4 * k + 2] = 0.5 * m0;
+        s_cf[4 * k + 3] = (m1 - m0) / (6.0 * h);
+    }
+    __syncthreads();
+    const double y_first = s_y[0], m_first = s_M[0], r_first = s_r[0], r_last = s_r[N - 1];
+
+    // Phase 5: the map slab
+    const int S = c.S, P = c.P;
+    const int rows_per = (S + c.map_split - 1) / c.map_split;
+    const int row0 = part * rows_per, row1 = min(S, row0 + rows_per);
+    const int lane = tid & 63, wv = tid >> 6, nwv = nth >> 6;
+    double* out = img + (size_t)w * P * P;
+
+    auto eval = [&](double d) -> double {
+        // interp1d(..., bounds_error=False, fill_value=(0,0)): 0 outside [-r_N, r_N];
+        // NaN radius propagates
+        if (!(d <= r_last)) return (d != d) ? d : 0.0;
+        if (d < r_first) return y_first + 0.5 * m_first * (d * d - r_first * r_first);
+        int k = (int)((d - r_first) * c.inv_h_mean);
+        k = min(max(k, 0), N - 2);
+        while (k < N - 2 && d >= s_r[k + 1]) ++k;
+        while (k > 0 && d < s_r[k]) --k;
+        const double t = d - s_r[k];
+        const double* cf = s_cf + 4 * k;
+        return fma(t, fma(t, fma(t, cf[3], cf[2]), cf[1]), cf[0]);
+    };
+
+    for (int iy = row0 + wv; iy < row1; iy += nwv) {
+        const double* drow = c.d_mat + (size_t)iy * S;
+        double* orow = out + (size_t)iy * P;
+        if (VEC2) {
+            for (int ix = 2 * lane; ix < S; ix += 128) {
+                const double2 d = *reinterpret_cast<const double2*>(drow + ix);
+                double2 v;
+                v.x = eval(d.x);
+                v.y = eval(d.y);
+                *reinterpret_cast<double2*>(orow + ix) = v;
+            }
+        } else {
+            for (int ix = lane; ix < S; ix += 64) orow[ix] = eval(drow[ix]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// K3: spectrum *= beam spectrum (complex, [chunk][P][Ph]).  Grid-stride, 16 B per lane.
+// ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+jx_beam_mul_kernel(double2* __restrict__ spec, const double2* __restrict__ bhat, size_t per_walker, size_t total) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const double2 b = bhat[i % per_walker];
+        const double2 a = spec[i];
+        double2 r;
+        r.x = a.x * b.x - a.y * b.y;
+        r.y = a.x * b.y + a.y * b.x;
+        spec[i] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// K6+K7: transfer function, central row, conversion, chi^2, total.  One block per walker.
+//   tfspec [chunk][S][Sh] = rfft2 of the beam-convolved S x S window (unnormalised)
+//   Z[kc]  = sum_kr tfspec[kr][kc] * H[kr][kc]          (threads over kc: coalesced)
+//   row[c] = sum_kc Re(Z[kc] e^{2 pi i kc c/S}),  c = S//2 .. S-1   (joxsz_funcs.py:467,472)
+//   map_prof = row * cfac                                           (joxsz_funcs.py:473)
+//   model_d = sum_k E[d][k] map_prof[k]                             (joxsz_funcs.py:476)
+//   chisq = nansum(((flux - model)/err)^2); logp = base - chisq/2   (joxsz_funcs.py:478-479, 538)
+// ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(JX_TAIL_THREADS)
+jx_tail_kernel(JxDev c, const double2* __restrict__ tfspec, const double* __restrict__ cfac,
+               const double* __restrict__ base, double* __restrict__ logp, int w0,
+               double* __restrict__ tap_row, double* __restrict__ tap_bright, double* __restrict__ tap_chisq,
+               double* __restrict__ tap_parts) {
+    extern __shared__ double sm[];
+    __shared__ double red[8];
+    const int S = c.S, Sh = c.Sh, nrow = c.nrow;
+    double* s_zr = sm;                 // [Sh]
+    double* s_zi = s_zr + Sh;          // [Sh]
+    double* s_prof = s_zi + Sh;        // [nrow]
+    const int w = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
+    const double2* X = tfspec + (size_t)w * S * Sh;
+    const double2* H = reinterpret_cast<const double2*>(c.htab);
+
+    for (int kc = tid; kc < Sh; kc += nth) {
+        double zr0 = 0.0, zi0 = 0.0, zr1 = 0.0, zi1 = 0.0;
+        int kr = 0;
+        for (; kr + 1 < S; kr += 2) {
+            const double2 x0 = X[(size_t)kr * Sh + kc], h0 = H[(size_t)kr * Sh + kc];
+            const double2 x1 = X[(size_t)(kr + 1) * Sh + kc], h1 = H[(size_t)(kr + 1) * Sh + kc];
+            zr0 += x0.x * h0.x - x0.y * h0.y;  zi0 += x0.x * h0.y + x0.y * h0.x;
+            zr1 += x1.x * h1.x - x1.y * h1.y;  zi1 += x1.x * h1.y + x1.y * h1.x;
+        }
+        for (; kr < S; ++kr) {
+            const double2 x0 = X[(size_t)kr * Sh + kc], h0 = H[(size_t)kr * Sh + kc];
+            zr0 += x0.x * h0.x - x0.y * h0.y;  zi0 += x0.x * h0.y + x0.y * h0.x;
+        }
+        s_zr[kc] = zr0 + zr1;
+        s_zi[kc] = zi0 + zi1;
+    }
+    __syncthreads();
+
+    const double2* tw = reinterpret_cast<const double2*>(c.twid);
+    const int c0 = S / 2;
+    for (int k = tid; k < nrow; k += nth) {
+        const int col = c0 + k;
+        double acc = 0.0;
+        int ph = 0;                                  // (kc * col) mod S
+        for (int kc = 0; kc < Sh; ++kc) {
+            const double2 t = tw[ph];
+            acc += s_zr[kc] * t.x - s_zi[kc] * t.y;
+            ph += col; if (ph >= S) ph -= S;
+        }
+        if (tap_row) tap_row[(size_t)w * nrow + k] = acc;
+        const double b = acc * cfac[(size_t)w * nrow + k];
+        s_prof[k] = b;
+        if (tap_bright) tap_bright[(size_t)w * nrow + k] = b;
+    }
+    __syncthreads();
+
+    double part = 0.0;
+    for (int d = tid; d < c.nflux; d += nth) {
+        const double* e = c.emat + (size_t)d * nrow;
+        double m = 0.0;
+        for (int k = 0; k < nrow; ++k) m = fma(e[k], s_prof[k], m);
+        const double z = (c.flux[c.nflux + d] - m) / c.flux[2 * c.nflux + d];
+        const double z2 = z * z;
+        if (z2 == z2) part += z2;                    // np.nansum drops NaN terms
+    }
+    const double chisq = jx_block_sum(part, red);
+    if (tid == 0) {
+        const double ll = -chisq / 2.0;
+        const double b = base[w];
+        double tot = (b == -INFINITY) ? -INFINITY : b + ll;
+        if (tot != tot) tot = -INFINITY;             // never hand NaN to the sampler
+        logp[w0 + w] = tot;
+        if (tap_chisq) tap_chisq[w] = chisq;
+        if (tap_parts) tap_parts[(size_t)w * 4 + 1] = ll;
+    }
+}

@@ -1,0 +1,308 @@
+// Walker-independent tables, built once per context on the host (setup, not hot path).
+//
+//  * abel_matrix          : the forward Abel transform the reference obtains from
+//                           PyAbel's direct_transform(..., backend='Python')
+//                           (joxsz_funcs.py:457) as explicit upper-triangular weights.
+//  * mirrored_spline_op   : second-derivative ("moment") operator of the not-a-knot
+//                           cubic spline through the mirrored samples (-r, y), (r, y)
+//                           that interp1d(..., 'cubic') builds at joxsz_funcs.py:460, 470.
+//  * nak_eval_matrix      : evaluation matrix of the plain not-a-knot cubic spline with
+//                           extrapolation (joxsz_funcs.py:476) at fixed abscissae.
+//  * beam_spectrum        : half-spectrum of the zero-padded, centre-shifted beam image
+//                           for the FFT convolution of joxsz_funcs.py:464.
+//  * tf_row_table         : transfer-function weights that collapse the inverse FFT of
+//                           joxsz_funcs.py:467 to the single row joxsz_funcs.py:472 reads.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+namespace jxt {
+
+static const double kPi = 3.14159265358979323846264338327950288;
+
+// ---------------------------------------------------------------------------------------
+// Banded Gaussian elimination with partial pivoting on dense row-major storage.
+// A is n x n with lower bandwidth kl and upper bandwidth ku; Bm is n x m (row-major).
+// On return Bm holds A^-1 Bm.  Returns false on a zero pivot.
+// ---------------------------------------------------------------------------------------
+inline bool solve_banded(std::vector<double>& A, int n, int kl, int ku, std::vector<double>& Bm, int m) {
+    const int kue = ku + kl;                       // fill-in from row swaps
+    for (int k = 0; k < n; ++k) {
+        int piv = k;
+        double best = std::fabs(A[(size_t)k * n + k]);
+        const int rmax = std::min(n - 1, k + kl);
+        for (int r = k + 1; r <= rmax; ++r) {
+            double v = std::fabs(A[(size_t)r * n + k]);
+            if (v > best) { best = v; piv = r; }
+        }
+        if (best == 0.0) return false;
+        const int cmax = std::min(n - 1, k + kue);
+        if (piv != k) {
+            for (int c = k; c <= cmax; ++c) std::swap(A[(size_t)k * n + c], A[(size_t)piv * n + c]);
+            for (int c = 0; c < m; ++c) std::swap(Bm[(size_t)k * m + c], Bm[(size_t)piv * m + c]);
+        }
+        const double inv = 1.0 / A[(size_t)k * n + k];
+        for (int r = k + 1; r <= rmax; ++r) {
+            const double f = A[(size_t)r * n + k] * inv;
+            if (f == 0.0) continue;
+            A[(size_t)r * n + k] = 0.0;
+            for (int c = k + 1; c <= cmax; ++c) A[(size_t)r * n + c] -= f * A[(size_t)k * n + c];
+            double* br = &Bm[(size_t)r * m];
+            const double* bk = &Bm[(size_t)k * m];
+            for (int c = 0; c < m; ++c) br[c] -= f * bk[c];
+        }
+    }
+    for (int k = n - 1; k >= 0; --k) {
+        const int cmax = std::min(n - 1, k + kue);
+        double* bk = &Bm[(size_t)k * m];
+        for (int c = k + 1; c <= cmax; ++c) {
+            const double a = A[(size_t)k * n + c];
+            if (a == 0.0) continue;
+            const double* bc = &Bm[(size_t)c * m];
+            for (int j = 0; j < m; ++j) bk[j] -= a * bc[j];
+        }
+        const double inv = 1.0 / A[(size_t)k * n + k];
+        for (int j = 0; j < m; ++j) bk[j] *= inv;
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------
+// Forward Abel transform weights.  ab = A pp, A[i][j] = 0 for j < i.
+// Follows the published algorithm of PyAbel's _pyabel_direct_integral with
+// correction=1 and int_func=np.trapz (restated in oracle/pyabel_direct.py):
+// trapezoid rule over F_j/sqrt(r_j^2-r_i^2), j>i, with F_j = 2 r_j pp_j; minus half the
+// trapezoid integral of the first cell's lone sample; plus the analytic integral of the
+// singular cell for F linear on [r_i, r_{i+1}].
+// ---------------------------------------------------------------------------------------
+inline bool grid_is_uniform(const std::vector<double>& r) {
+    // PyAbel's is_uniform_sampling: all second differences within 1e-13 of zero
+    for (size_t i = 0; i + 2 < r.size(); ++i) {
+        const double dd = (r[i + 2] - r[i + 1]) - (r[i + 1] - r[i]);
+        if (!(std::fabs(dd) <= 1e-13)) return false;
+    }
+    return true;
+}
+
+inline void abel_matrix(const std::vector<double>& r, std::vector<double>& A) {
+    const int n = (int)r.size();
+    A.assign((size_t)n * n, 0.0);
+    const bool uni = grid_is_uniform(r);
+    const double dx = std::fabs(r[1] - r[0]);
+    // trapezoid weight of sample j over the whole grid
+    std::vector<double> wt(n);
+    for (int j = 0; j < n; ++j) {
+        if (uni) wt[j] = (j == 0 || j == n - 1) ? 0.5 * dx : dx;
+        else {
+            const double dl = (j > 0) ? r[j] - r[j - 1] : 0.0;
+            const double dr = (j < n - 1) ? r[j + 1] - r[j] : 0.0;
+            wt[j] = 0.5 * (dl + dr);
+        }
+    }
+    for (int i = 0; i < n - 1; ++i) {
+        double* row = &A[(size_t)i * n];
+        for (int j = i + 1; j < n; ++j) {
+            const double isq = 1.0 / std::sqrt(r[j] * r[j] - r[i] * r[i]);
+            row[j] = wt[j] * isq;                           // coefficient of F_j
+        }
+        row[i + 1] *= 0.5;                                   // "extra triangle" correction
+        const double d = r[i + 1] - r[i];
+        const double s = std::sqrt(r[i + 1] * r[i + 1] - r[i] * r[i]);
+        double acr;
+        if (i == 0 && r[0] < r[1] * 1e-8) acr = std::acosh(std::cosh(1.0));
+        else acr = std::acosh(r[i + 1] / r[i]);
+        // s*F' + acr*(F_i - F' r_i),  F' = (F_{i+1}-F_i)/d
+        row[i]     += -s / d + acr * (1.0 + r[i] / d);
+        row[i + 1] +=  s / d - acr * r[i] / d;
+        for (int j = i; j < n; ++j) row[j] *= 2.0 * r[j];    // F_j = 2 r_j pp_j
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Moment operator of the mirrored not-a-knot spline: M = G y, with y the samples at the
+// positive knots r_0 < ... < r_{n-1}, the knot set being {-r_{n-1},..,-r_0, r_0,..,r_{n-1}}
+// (no knot at 0: the centre interval is [-r_0, r_0]).  By symmetry the spline is even, so
+// M(-r_0) = M(r_0) and the centre-interval polynomial is y_0 + M_0 (x^2 - r_0^2)/2.
+// Not-a-knot at the outer end: third derivative continuous at r_{n-2}.
+// G is returned dense (n x n, row-major).
+// ---------------------------------------------------------------------------------------
+inline bool mirrored_spline_op(const std::vector<double>& r, std::vector<double>& G) {
+    const int n = (int)r.size();
+    if (n < 3) return false;
+    std::vector<double> A((size_t)n * n, 0.0);
+    G.assign((size_t)n * n, 0.0);                            // starts as D (rhs operator)
+    const double L = 2.0 * r[0];
+    {
+        const double h0 = r[1] - r[0];
+        A[0] = L / 2.0 + h0 / 3.0;
+        A[1] = h0 / 6.0;
+        G[0] = -1.0 / h0;
+        G[1] = 1.0 / h0;
+    }
+    for (int i = 1; i < n - 1; ++i) {
+        const double hl = r[i] - r[i - 1], hr = r[i + 1] - r[i];
+        A[(size_t)i * n + i - 1] = hl / 6.0;
+        A[(size_t)i * n + i] = (hl + hr) / 3.0;
+        A[(size_t)i * n + i + 1] = hr / 6.0;
+        G[(size_t)i * n + i - 1] = 1.0 / hl;
+        G[(size_t)i * n + i] = -1.0 / hl - 1.0 / hr;
+        G[(size_t)i * n + i + 1] = 1.0 / hr;
+    }
+    {
+        const double ha = r[n - 2] - r[n - 3], hb = r[n - 1] - r[n - 2];
+        A[(size_t)(n - 1) * n + n - 3] = hb;
+        A[(size_t)(n - 1) * n + n - 2] = -(ha + hb);
+        A[(size_t)(n - 1) * n + n - 1] = ha;
+    }
+    return solve_banded(A, n, 2, 1, G, n);
+}
+
+// Plain not-a-knot cubic spline (both ends), moment operator M = G y on knots x.
+inline bool nak_spline_op(const std::vector<double>& x, std::vector<double>& G) {
+    const int n = (int)x.size();
+    if (n < 4) return false;
+    std::vector<double> A((size_t)n * n, 0.0);
+    G.assign((size_t)n * n, 0.0);
+    {
+        const double h0 = x[1] - x[0], h1 = x[2] - x[1];
+        A[0] = h1; A[1] = -(h0 + h1); A[2] = h0;
+    }
+    for (int i = 1; i < n - 1; ++i) {
+        const double hl = x[i] - x[i - 1], hr = x[i + 1] - x[i];
+        A[(size_t)i * n + i - 1] = hl / 6.0;
+        A[(size_t)i * n + i] = (hl + hr) / 3.0;
+        A[(size_t)i * n + i + 1] = hr / 6.0;
+        G[(size_t)i * n + i - 1] = 1.0 / hl;
+        G[(size_t)i * n + i] = -1.0 / hl - 1.0 / hr;
+        G[(size_t)i * n + i + 1] = 1.0 / hr;
+    }
+    {
+        const double ha = x[n - 2] - x[n - 3], hb = x[n - 1] - x[n - 2];
+        A[(size_t)(n - 1) * n + n - 3] = hb;
+        A[(size_t)(n - 1) * n + n - 2] = -(ha + hb);
+        A[(size_t)(n - 1) * n + n - 1] = ha;
+    }
+    return solve_banded(A, n, 2, 2, G, n);
+}
+
+// E[d][k]: value at q[d] of the plain not-a-knot spline through (x_k, y_k) is sum_k E[d][k] y_k.
+// Outside [x_0, x_{n-1}] the end polynomial is continued (interp1d fill_value='extrapolate').
+// A NaN abscissa gives a NaN row.
+inline bool nak_eval_matrix(const std::vector<double>& x, const std::vector<double>& q, std::vector<double>& E) {
+    const int n = (int)x.size(), nq = (int)q.size();
+    std::vector<double> G;
+    if (!nak_spline_op(x, G)) return false;
+    E.assign((size_t)nq * n, 0.0);
+    for (int d = 0; d < nq; ++d) {
+        double* e = &E[(size_t)d * n];
+        if (std::isnan(q[d])) { for (int k = 0; k < n; ++k) e[k] = NAN; continue; }
+        int k = (int)(std::upper_bound(x.begin(), x.end(), q[d]) - x.begin()) - 1;
+        k = std::max(0, std::min(n - 2, k));
+        const double h = x[k + 1] - x[k], t = q[d] - x[k];
+        const double wa = 1.0 - t / h, wb = t / h;
+        const double wm0 = -t * h / 3.0 + t * t / 2.0 - t * t * t / (6.0 * h);
+        const double wm1 = -t * h / 6.0 + t * t * t / (6.0 * h);
+        const double* g0 = &G[(size_t)k * n];
+        const double* g1 = &G[(size_t)(k + 1) * n];
+        for (int j = 0; j < n; ++j) e[j] = wm0 * g0[j] + wm1 * g1[j];
+        e[k] += wa;
+        e[k + 1] += wb;
+    }
+    return true;
+}
+
+// Half-bandwidth beyond which every |G[i][j]| is below eps * max|G|.
+inline int band_halfwidth(const std::vector<double>& G, int n, double eps) {
+    double mx = 0.0;
+    for (double v : G) mx = std::max(mx, std::fabs(v));
+    const double thr = eps * mx;
+    int K = 0;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j)
+            if (std::fabs(G[(size_t)i * n + j]) > thr) K = std::max(K, std::abs(i - j));
+    return K;
+}
+
+// ---------------------------------------------------------------------------------------
+// Beam half-spectrum for the 'same' FFT convolution of joxsz_funcs.py:464.
+// The B x B beam is placed in a P x P zero image shifted by -(B-1)/2 in both axes
+// (circularly), so that the circular convolution restricted to [0,S)^2 equals
+// fftconvolve(y_2d, beam, 'same') whenever P >= S + (B-1)/2.  Output: [P][P/2+1] complex
+// (re, im interleaved), multiplied by `scale` (= step^2 / P^2 for the unnormalised FFT pair).
+// Only B rows/columns are non-zero, so the DFT is done directly in O(P^2 B).
+// ---------------------------------------------------------------------------------------
+inline void beam_spectrum(const std::vector<double>& beam, int B, int P, double scale, std::vector<double>& out) {
+    const int o = (B - 1) / 2, Ph = P / 2 + 1;
+    std::vector<double> cs(P), sn(P);
+    for (int m = 0; m < P; ++m) { cs[m] = std::cos(2.0 * kPi * m / P); sn[m] = std::sin(2.0 * kPi * m / P); }
+    // stage 1: along x for each beam row u: T[u][kx] = sum_v beam[u][v] e^{-2 pi i kx (v-o)/P}
+    std::vector<double> Tr((size_t)B * Ph), Ti((size_t)B * Ph);
+    for (int u = 0; u < B; ++u)
+        for (int kx = 0; kx < Ph; ++kx) {
+            double ar = 0.0, ai = 0.0;
+            for (int v = 0; v < B; ++v) {
+                long long ph = ((long long)kx * (v - o)) % P; if (ph < 0) ph += P;
+                ar += beam[(size_t)u * B + v] * cs[ph];
+                ai -= beam[(size_t)u * B + v] * sn[ph];
+            }
+            Tr[(size_t)u * Ph + kx] = ar; Ti[(size_t)u * Ph + kx] = ai;
+        }
+    out.assign((size_t)P * Ph * 2, 0.0);
+    for (int ky = 0; ky < P; ++ky)
+        for (int kx = 0; kx < Ph; ++kx) {
+            double ar = 0.0, ai = 0.0;
+            for (int u = 0; u < B; ++u) {
+                long long ph = ((long long)ky * (u - o)) % P; if (ph < 0) ph += P;
+                const double c = cs[ph], s = -sn[ph];
+                const double tr = Tr[(size_t)u * Ph + kx], ti = Ti[(size_t)u * Ph + kx];
+                ar += tr * c - ti * s;
+                ai += tr * s + ti * c;
+            }
+            out[((size_t)ky * Ph + kx) * 2] = ar * scale;
+            out[((size_t)ky * Ph + kx) * 2 + 1] = ai * scale;
+        }
+}
+
+// ---------------------------------------------------------------------------------------
+// Transfer-function row table.  The reference computes real(ifft2(fft2(conv) * filtering))
+// (joxsz_funcs.py:466-467) and keeps only row r0 = S//2 from column S//2 on
+// (joxsz_funcs.py:472).  With X = rfft2(conv) (unnormalised, [S][S/2+1]):
+//     Z[kc]  = sum_kr X[kr][kc] * H[kr][kc]
+//     row[c] = sum_kc Re( Z[kc] e^{+2 pi i kc c / S} )
+// where H[kr][kc] = Fs[kr][kc] * e^{+2 pi i kr r0 / S} * w_kc / S^2, Fs is the
+// Hermitian-symmetrised filter (Fs[k] = (F[k]+F[-k])/2: taking the real part of the
+// inverse transform of a real-input spectrum times a real filter is exactly that), and
+// w_kc = 1 for kc = 0 and for kc = S/2 when S is even, else 2.
+// ---------------------------------------------------------------------------------------
+inline void tf_row_table(const std::vector<double>& filt, int S, std::vector<double>& H) {
+    const int Sh = S / 2 + 1, r0 = S / 2;
+    H.assign((size_t)S * Sh * 2, 0.0);
+    const double inv = 1.0 / ((double)S * (double)S);
+    for (int kr = 0; kr < S; ++kr) {
+        const long long ph = ((long long)kr * r0) % S;
+        const double c = std::cos(2.0 * kPi * ph / S), s = std::sin(2.0 * kPi * ph / S);
+        const int mr = (S - kr) % S;
+        for (int kc = 0; kc < Sh; ++kc) {
+            const int mc = (S - kc) % S;
+            const double fs = 0.5 * (filt[(size_t)kr * S + kc] + filt[(size_t)mr * S + mc]);
+            const double w = (kc == 0 || (S % 2 == 0 && kc == S / 2)) ? 1.0 : 2.0;
+            H[((size_t)kr * Sh + kc) * 2] = fs * c * w * inv;
+            H[((size_t)kr * Sh + kc) * 2 + 1] = fs * s * w * inv;
+        }
+    }
+}
+
+// smallest even 2^a 3^b 5^c >= n
+inline int next_smooth_even(int n) {
+    for (int m = std::max(2, n + (n & 1));; m += 2) {
+        int v = m;
+        while (v % 2 == 0) v /= 2;
+        while (v % 3 == 0) v /= 3;
+        while (v % 5 == 0) v /= 5;
+        if (v == 1) return m;
+    }
+}
+
+}  // namespace jxt

@@ -1,0 +1,46 @@
+// Host-only C entry points over jx_tables.hpp so that the table builders can be
+// checked on a machine without a GPU (tests/test_host_tables.py, ctypes).
+#include <cstring>
+#include <vector>
+#include "jx_tables.hpp"
+
+extern "C" {
+
+int jxt_abel_matrix(const double* r, int n, double* out /*[n*n]*/) {
+    std::vector<double> rv(r, r + n), A;
+    jxt::abel_matrix(rv, A);
+    memcpy(out, A.data(), sizeof(double) * (size_t)n * n);
+    return 0;
+}
+
+int jxt_mirrored_spline_op(const double* r, int n, double* out /*[n*n]*/) {
+    std::vector<double> rv(r, r + n), G;
+    if (!jxt::mirrored_spline_op(rv, G)) return -1;
+    memcpy(out, G.data(), sizeof(double) * (size_t)n * n);
+    return jxt::band_halfwidth(G, n, 1e-20);
+}
+
+int jxt_nak_eval_matrix(const double* x, int n, const double* q, int nq, double* out /*[nq*n]*/) {
+    std::vector<double> xv(x, x + n), qv(q, q + nq), E;
+    if (!jxt::nak_eval_matrix(xv, qv, E)) return -1;
+    memcpy(out, E.data(), sizeof(double) * (size_t)nq * n);
+    return 0;
+}
+
+int jxt_beam_spectrum(const double* beam, int B, int P, double scale, double* out /*[P*(P/2+1)*2]*/) {
+    std::vector<double> bv(beam, beam + (size_t)B * B), o;
+    jxt::beam_spectrum(bv, B, P, scale, o);
+    memcpy(out, o.data(), sizeof(double) * o.size());
+    return 0;
+}
+
+int jxt_tf_row_table(const double* filt, int S, double* out /*[S*(S/2+1)*2]*/) {
+    std::vector<double> fv(filt, filt + (size_t)S * S), H;
+    jxt::tf_row_table(fv, S, H);
+    memcpy(out, H.data(), sizeof(double) * H.size());
+    return 0;
+}
+
+int jxt_next_smooth_even(int n) { return jxt::next_smooth_even(n); }
+
+}  // extern "C"

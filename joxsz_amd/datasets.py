@@ -34,6 +34,10 @@ KPC_AS_CLJ1226 = 8.0012          # flat LCDM, z=0.888, H0=67.32, Om=0.3158 (joxs
 THETA0 = np.array([-1.9, 0.6, 2.0, 2.9, 3.0, 0.0, 0.3, 0.12, 1.33, 4.13, 400., 1.0, 1.0])
 
 
+# log(n_02), beta_2, log(r_c2) of the 'double' density mode (joxsz_funcs.py:367-372): a faint compact core
+THETA0_DOUBLE_EXTRA = np.array([-3.0, 0.6, 1.2])
+
+
 def synthetic_count_rate_tables(nband=10, ntab=100):
     """Smooth bremsstrahlung-like ln(rate) tables on mbproj2's ln T grid
     (0.06-60 keV, 100 points; layout of joxsz_funcs.py:667-680).  XSPEC is not
@@ -98,8 +102,7 @@ def fiducial_theta(pb):
     """THETA0 extended to the problem's thawed vector (double-beta mode adds three)."""
     if pb.ndim == THETA0.size:
         return THETA0.copy()
-    extra = pb.thawed_vals()[THETA0.size:]
-    return np.concatenate((THETA0, extra))
+    return np.concatenate((THETA0, THETA0_DOUBLE_EXTRA))
 
 
 def fill_data(pb, bright, xprofs, seed=0):

@@ -1,0 +1,242 @@
+"""ctypes binding of the C-ABI in ``include/joxsz_hip.h``.
+
+There is no CPU fallback: if ``joxsz_amd/csrc/libjoxsz_hip.so`` is missing or
+no gfx950 device answers, construction raises ``JoxszHipError``.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libjoxsz_hip.so')
+ABI_VERSION = 1
+
+# must list every function include/joxsz_hip.h declares (tests/test_abi.py checks this)
+EXPORTS = (
+    'jx_create', 'jx_upload', 'jx_finalize', 'jx_eval', 'jx_eval_device', 'jx_sync', 'jx_eval_stage',
+    'jx_set_par_vals', 'jx_dev_alloc', 'jx_dev_free', 'jx_memcpy_h2d', 'jx_memcpy_d2h',
+    'jx_timing_reset', 'jx_timing_enable', 'jx_timing_get', 'jx_get_info', 'jx_device_count',
+    'jx_device_name', 'jx_strerror', 'jx_last_error', 'jx_destroy',
+)
+
+TENSORS = ('r_pp', 'd_mat', 'beam_2d', 'filtering', 'radius', 'flux_data', 'conv_T', 'conv_v',
+           'par_vals', 'par_min', 'par_max', 'par_kind', 'par_mu', 'par_sigma', 'thawed_idx',
+           'x_r_ne_kpc', 'x_r_T_kpc', 'projvols', 'cts', 'areascales', 'exposures', 'backrates',
+           'geomarea', 'lnT', 'lnrate')
+_INT_TENSORS = ('par_kind', 'thawed_idx')
+_XRAY_FIRST = TENSORS.index('x_r_ne_kpc')
+
+STAGES = ('pp', 'ab', 'y', 'y_2d', 'conv_2d', 'map_row', 'bright', 'chisq', 'tprof', 'xprofs', 'parts')
+
+
+class JoxszHipError(RuntimeError):
+    pass
+
+
+class JxConfig(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        'abi_version', 'S', 'N', 'B', 'nflux', 'nconv', 'nann', 'nband', 'ntab', 'npar', 'ndim',
+        'ne_mode', 'exclude_unphy_mass', 'sz_only', 'device', 'max_batch', 'fft_pad', 'map_split')] + \
+        [(n, ctypes.c_double) for n in ('step', 'kpc_as', 'm_e', 'sigma_T', 'kpc_cm')]
+
+
+class JxTiming(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_double) for n in (
+        'prep_ms', 'abel_map_ms', 'beam_fft_ms', 'tf_fft_ms', 'tail_ms', 'total_ms')] + \
+        [('launches', ctypes.c_int64), ('walkers', ctypes.c_int64)]
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen the HIP library and declare the prototypes.  Raises if absent."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise JoxszHipError('%s not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                            '(there is no CPU fallback)' % path)
+    lib = ctypes.CDLL(path)
+    vp, ci, cs = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+    dp = ctypes.POINTER(ctypes.c_double)
+    lib.jx_create.argtypes = [ctypes.POINTER(JxConfig), ctypes.POINTER(vp)]
+    lib.jx_upload.argtypes = [vp, ci, vp, cs]
+    lib.jx_finalize.argtypes = [vp]
+    lib.jx_eval.argtypes = [vp, dp, ci, dp]
+    lib.jx_eval_device.argtypes = [vp, vp, ci, vp]
+    lib.jx_sync.argtypes = [vp]
+    lib.jx_eval_stage.argtypes = [vp, dp, ci, ci, dp, cs]
+    lib.jx_set_par_vals.argtypes = [vp, dp, ci]
+    lib.jx_dev_alloc.argtypes = [vp, cs, ctypes.POINTER(vp)]
+    lib.jx_dev_free.argtypes = [vp, vp]
+    lib.jx_memcpy_h2d.argtypes = [vp, vp, vp, cs]
+    lib.jx_memcpy_d2h.argtypes = [vp, vp, vp, cs]
+    lib.jx_timing_reset.argtypes = [vp]
+    lib.jx_timing_enable.argtypes = [vp, ci]
+    lib.jx_timing_get.argtypes = [vp, ctypes.POINTER(JxTiming)]
+    i32p, i64p = ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int64)
+    lib.jx_get_info.argtypes = [vp, i32p, i32p, i32p, i32p, i64p]
+    lib.jx_device_count.argtypes = []
+    lib.jx_device_name.argtypes = [vp]
+    lib.jx_device_name.restype = ctypes.c_char_p
+    lib.jx_strerror.argtypes = [ci]
+    lib.jx_strerror.restype = ctypes.c_char_p
+    lib.jx_last_error.argtypes = [vp]
+    lib.jx_last_error.restype = ctypes.c_char_p
+    lib.jx_destroy.argtypes = [vp]
+    lib.jx_destroy.restype = None
+    for name in EXPORTS:
+        if name not in ('jx_device_name', 'jx_strerror', 'jx_last_error', 'jx_destroy'):
+            getattr(lib, name).restype = ci
+    if path == LIB_PATH:
+        _lib = lib
+    return lib
+
+
+def config_from_problem(pb, device=0, max_batch=0, fft_pad=0, map_split=0):
+    cfg = JxConfig()
+    cfg.abi_version = ABI_VERSION
+    cfg.S, cfg.N, cfg.B = pb.S, pb.N, pb.B
+    cfg.nflux = int(pb.flux_data.shape[1])
+    cfg.nconv = int(np.size(pb.conv_T))
+    cfg.nband, cfg.nann = (int(v) for v in pb.cts.shape)
+    cfg.ntab = int(np.size(pb.lnT))
+    cfg.npar = len(pb.par_names)
+    cfg.ndim = pb.ndim
+    cfg.ne_mode = 1 if pb.ne_mode == 'double' else 0
+    cfg.exclude_unphy_mass = int(bool(pb.exclude_unphy_mass))
+    cfg.sz_only = int(bool(pb.sz_only))
+    cfg.device, cfg.max_batch, cfg.fft_pad, cfg.map_split = device, max_batch, fft_pad, map_split
+    cfg.step, cfg.kpc_as = float(pb.step), float(pb.kpc_as)
+    cfg.m_e, cfg.sigma_T, cfg.kpc_cm = float(pb.m_e), float(pb.sigma_T), float(pb.kpc_cm)
+    return cfg
+
+
+class HipContext:
+    """Thin owner of one ``jx_ctx``: uploads a ``Problem`` and evaluates batches."""
+
+    def __init__(self, pb, device=0, max_batch=0, fft_pad=0, map_split=0, lib_path=None):
+        self._h = ctypes.c_void_p()
+        self.lib = load_library(lib_path)
+        pb.validate()
+        self.pb = pb
+        self.ndim = pb.ndim
+        cfg = config_from_problem(pb, device, max_batch, fft_pad, map_split)
+        rc = self.lib.jx_create(ctypes.byref(cfg), ctypes.byref(self._h))
+        if rc != 0:
+            self._h = ctypes.c_void_p()
+            raise JoxszHipError('jx_create: %s' % self.lib.jx_strerror(rc).decode())
+        try:
+            for tid, name in enumerate(TENSORS):
+                if pb.sz_only and tid >= _XRAY_FIRST:
+                    continue
+                a = pb.thawed_idx if name == 'thawed_idx' else getattr(pb, name)
+                a = np.ascontiguousarray(a, dtype=np.int32 if name in _INT_TENSORS else np.float64)
+                self._chk(self.lib.jx_upload(self._h, tid, a.ctypes.data_as(ctypes.c_void_p), a.nbytes),
+                          'jx_upload(%s)' % name)
+            self._chk(self.lib.jx_finalize(self._h), 'jx_finalize')
+        except Exception:
+            self.close()
+            raise
+        f, c, b, n = (ctypes.c_int32() for _ in range(4))
+        nb = ctypes.c_int64()
+        self._chk(self.lib.jx_get_info(self._h, f, c, b, n, nb), 'jx_get_info')
+        self.fft_pad, self.chunk, self.spline_band, self.nrow, self.device_bytes = f.value, c.value, b.value, n.value, nb.value
+        self.device_name = self.lib.jx_device_name(self._h).decode()
+
+    # -- plumbing --
+    def _chk(self, rc, what):
+        if rc != 0:
+            detail = self.lib.jx_last_error(self._h).decode() if self._h else ''
+            raise JoxszHipError('%s failed: %s%s' % (what, self.lib.jx_strerror(rc).decode(),
+                                                     (' -- ' + detail) if detail else ''))
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self.lib.jx_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _theta(self, theta):
+        t = np.ascontiguousarray(theta, dtype=np.float64)
+        if t.ndim == 1:
+            t = t[None, :]
+        if t.ndim != 2 or t.shape[1] != self.ndim:
+            raise ValueError('theta must have shape (nwalkers, %d); got %r' % (self.ndim, np.shape(theta)))
+        return t
+
+    # -- evaluation --
+    def eval(self, theta):
+        """theta [W, ndim] float64 (host) -> log-posterior [W] float64 (host)."""
+        t = self._theta(theta)
+        out = np.empty(t.shape[0], dtype=np.float64)
+        dp = ctypes.POINTER(ctypes.c_double)
+        self._chk(self.lib.jx_eval(self._h, t.ctypes.data_as(dp), t.shape[0], out.ctypes.data_as(dp)), 'jx_eval')
+        return out
+
+    def eval_stage(self, theta, stage):
+        t = self._theta(theta)
+        W = t.shape[0]
+        pb = self.pb
+        shapes = {'pp': (W, pb.N), 'ab': (W, pb.N), 'y': (W, pb.N), 'y_2d': (W, pb.S, pb.S),
+                  'conv_2d': (W, pb.S, pb.S), 'map_row': (W, self.nrow), 'bright': (W, self.nrow),
+                  'chisq': (W,), 'tprof': (W, self.nrow), 'xprofs': (W,) + tuple(pb.cts.shape), 'parts': (W, 4)}
+        out = np.empty(shapes[stage], dtype=np.float64)
+        dp = ctypes.POINTER(ctypes.c_double)
+        self._chk(self.lib.jx_eval_stage(self._h, t.ctypes.data_as(dp), W, STAGES.index(stage),
+                                         out.ctypes.data_as(dp), out.nbytes), 'jx_eval_stage(%s)' % stage)
+        return out
+
+    def set_par_vals(self, vals):
+        v = np.ascontiguousarray(vals, dtype=np.float64)
+        self._chk(self.lib.jx_set_par_vals(self._h, v.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), v.size),
+                  'jx_set_par_vals')
+
+    # -- device-resident path (bench, multi-GPU) --
+    def dev_alloc(self, nbytes):
+        p = ctypes.c_void_p()
+        self._chk(self.lib.jx_dev_alloc(self._h, nbytes, ctypes.byref(p)), 'jx_dev_alloc')
+        return p.value
+
+    def dev_free(self, ptr):
+        self._chk(self.lib.jx_dev_free(self._h, ctypes.c_void_p(ptr)), 'jx_dev_free')
+
+    def h2d(self, ptr, arr):
+        a = np.ascontiguousarray(arr)
+        self._chk(self.lib.jx_memcpy_h2d(self._h, ctypes.c_void_p(ptr), a.ctypes.data_as(ctypes.c_void_p), a.nbytes), 'jx_memcpy_h2d')
+
+    def d2h(self, arr, ptr):
+        assert arr.flags['C_CONTIGUOUS']
+        self._chk(self.lib.jx_memcpy_d2h(self._h, arr.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(ptr), arr.nbytes), 'jx_memcpy_d2h')
+
+    def eval_device(self, theta_ptr, nwalkers, logp_ptr):
+        self._chk(self.lib.jx_eval_device(self._h, ctypes.c_void_p(theta_ptr), nwalkers, ctypes.c_void_p(logp_ptr)), 'jx_eval_device')
+
+    def sync(self):
+        self._chk(self.lib.jx_sync(self._h), 'jx_sync')
+
+    # -- timing --
+    def timing_enable(self, on=True):
+        self._chk(self.lib.jx_timing_enable(self._h, int(on)), 'jx_timing_enable')
+
+    def timing_reset(self):
+        self._chk(self.lib.jx_timing_reset(self._h), 'jx_timing_reset')
+
+    def timing(self):
+        t = JxTiming()
+        self._chk(self.lib.jx_timing_get(self._h, ctypes.byref(t)), 'jx_timing_get')
+        return {n: getattr(t, n) for n, _ in JxTiming._fields_}

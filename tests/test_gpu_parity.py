@@ -1,0 +1,162 @@
+"""Parity of the HIP path (through the C-ABI) against the CPU oracle and against
+the reference's golden vectors.  Needs an MI355X: run with -m gpu."""
+import numpy as np
+import pytest
+
+from oracle import joxsz_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-6          # BASELINE.json north_star: <= 1e-6 relative on the log-posterior
+RTOL_STAGE = 1e-9    # fp64 end to end: intermediate arrays agree far tighter
+
+
+def _post(pb, **kw):
+    from joxsz_amd.posterior import JoxszPosterior
+    return JoxszPosterior(pb, device=0, **kw)
+
+
+def _relerr(got, want, scale=None):
+    want = np.asarray(want)
+    s = np.abs(want).max() if scale is None else scale
+    return np.abs(np.asarray(got) - want).max() / s
+
+
+def test_golden_logp(golden):
+    """The reference's own log-posteriors (tests/golden) on identical parameter vectors."""
+    pb, ref = golden
+    post = _post(pb)
+    got = post.log_prob(ref['thetas'])
+    want = ref['ref_logp']
+    post.close()
+    fin = np.isfinite(want)
+    assert np.array_equal(np.isfinite(got), fin)
+    assert np.all(got[~fin] == -np.inf)
+    np.testing.assert_allclose(got[fin], want[fin], rtol=RTOL)
+    assert np.max(np.abs(got[fin] - want[fin]) / np.abs(want[fin])) < 1e-9
+
+
+def test_golden_stages(golden):
+    pb, ref = golden
+    post = _post(pb)
+    th = ref['thetas']
+    fin = np.isfinite(ref['ref_logp'])
+    pp = post.stage(th, 'pp')
+    bright = post.stage(th, 'bright')
+    chisq = post.stage(th, 'chisq')
+    parts = post.stage(th, 'parts')
+    post.close()
+    for k in np.flatnonzero(fin):
+        assert _relerr(pp[k], ref['ref_pp'][k]) < 1e-13
+        assert _relerr(bright[k], ref['ref_bright'][k]) < RTOL_STAGE
+        assert abs(chisq[k] - ref['ref_chisq'][k]) <= RTOL_STAGE * abs(ref['ref_chisq'][k])
+        assert abs(parts[k, 0] - ref['ref_xlike'][k]) <= 1e-11 * abs(ref['ref_xlike'][k])
+        assert parts[k, 3] == 0
+    # rejection reasons: box prior, r_c > r_s, mass veto, mass veto
+    rej = parts[~fin, 3].astype(int)
+    assert rej[0] & 1 and rej[1] & 4 and rej[2] & 2 and rej[3] & 2
+
+
+def test_stage_by_stage_vs_oracle(golden_tiny):
+    pb, ref = golden_tiny
+    post = _post(pb)
+    th = ref['thetas'][:5]
+    got = {s: post.stage(th, s) for s in ('pp', 'ab', 'y', 'y_2d', 'conv_2d', 'map_row', 'bright', 'chisq', 'tprof', 'xprofs')}
+    post.close()
+    for k, t in enumerate(th):
+        p = orc.pars_dict(pb, t)
+        st = orc.sz_stages(pb, p)
+        for name in ('pp', 'ab', 'y', 'y_2d', 'conv_2d', 'map_row', 'bright'):
+            assert _relerr(got[name][k], st[name]) < RTOL_STAGE, name
+        assert abs(got['chisq'][k] - st['chisq']) < RTOL_STAGE * st['chisq']
+        assert _relerr(got['tprof'][k], np.append(st['t0'], st['t_prof'])) < 1e-11
+        assert _relerr(got['xprofs'][k], orc.calc_profiles(pb, p)) < 1e-12
+
+
+@pytest.mark.parametrize('S,N', [(31, 40), (32, 40), (64, 80), (171, 313), (256, 300)])
+def test_random_walkers_vs_oracle(S, N):
+    """Odd (reference-shaped) and even (BASELINE-shaped) map sides, seeded walkers."""
+    from joxsz_amd import datasets
+    pb = datasets.synthetic_problem(S=S, N=N, seed=S)
+    p0 = orc.pars_dict(pb, datasets.fiducial_theta(pb))
+    datasets.fill_data(pb, orc.sz_stages(pb, p0)['bright'], orc.calc_profiles(pb, p0), seed=S)
+    W = 24 if S <= 64 else 6
+    th = datasets.walker_ball(pb, W, spread=0.05, seed=S)
+    th[1, 1] = 9.0                                    # one rejected walker in the batch
+    post = _post(pb)
+    got = post.log_prob(th)
+    post.close()
+    want = orc.log_posterior_batch(pb, th)
+    fin = np.isfinite(want)
+    assert fin.sum() >= W // 2
+    assert np.array_equal(np.isfinite(got), fin)
+    np.testing.assert_allclose(got[fin], want[fin], rtol=RTOL)
+
+
+def test_sz_only_and_double_beta():
+    from joxsz_amd import datasets
+    for kw in (dict(sz_only=True), dict(ne_mode='double')):
+        pb = datasets.synthetic_problem(S=48, N=60, seed=5, **kw)
+        p0 = orc.pars_dict(pb, datasets.fiducial_theta(pb))
+        datasets.fill_data(pb, orc.sz_stages(pb, p0)['bright'], orc.calc_profiles(pb, p0), seed=5)
+        th = datasets.walker_ball(pb, 8, spread=0.03, seed=5)
+        post = _post(pb)
+        got = post.log_prob(th)
+        post.close()
+        want = orc.log_posterior_batch(pb, th)
+        fin = np.isfinite(want)
+        assert fin.any() and np.array_equal(np.isfinite(got), fin)
+        np.testing.assert_allclose(got[fin], want[fin], rtol=RTOL)
+
+
+def test_reference_signature(golden_tiny):
+    """getLikelihood(vals) -> float with the side effect of joxsz_funcs.py:515-516."""
+    pb, ref = golden_tiny
+    post = _post(pb)
+    v = post.getLikelihood(ref['thetas'][1])
+    assert isinstance(v, float)
+    np.testing.assert_allclose(v, ref['ref_logp'][1], rtol=RTOL)
+    np.testing.assert_allclose(post.thawedParVals(), ref['thetas'][1])
+    np.testing.assert_allclose(post.getLikelihood(), ref['ref_logp'][1], rtol=RTOL)      # vals=None: current pars
+    np.testing.assert_allclose(post.get_sz_like('bright'), ref['ref_bright'][1], rtol=1e-8, atol=1e-12)
+    np.testing.assert_allclose(post.get_sz_like('ll'), ref['ref_ll'][1], rtol=1e-8)
+    assert post.getLikelihood(ref['thetas'][10]) == -np.inf
+    assert list(post.pool().map(None, ref['thetas'][:3])) == list(post.log_prob(ref['thetas'][:3]))
+    post.close()
+
+
+def test_chunking_and_ragged_batches(golden_tiny):
+    """Batches that do not divide the chunk, a batch of one, and an empty batch."""
+    pb, ref = golden_tiny
+    post = _post(pb, max_batch=4)
+    th = np.repeat(ref['thetas'][:5], 3, axis=0)[:13]
+    got = post.log_prob(th)
+    np.testing.assert_allclose(got, np.repeat(ref['ref_logp'][:5], 3)[:13], rtol=RTOL)
+    assert post.log_prob(th[:1]).shape == (1,)
+    assert post.log_prob(np.zeros((0, pb.ndim))).shape == (0,)
+    post.close()
+
+
+def test_linearity_full_size():
+    """Size-independent property at BASELINE's headline size (S=512, N=500): every
+    stage after the pressure profile is linear in it, so the surface-brightness
+    profile scales with P_0 and the maps of two walkers add."""
+    from joxsz_amd import datasets
+    pb = datasets.synthetic_problem(S=512, N=500, seed=0)
+    t0 = datasets.fiducial_theta(pb)
+    th = np.array([t0, t0, t0])
+    th[1, 7] *= 2.0                                   # P_0 doubled: same T shape only if n_e fixed -> use map_row
+    th[2, 7] *= 3.0
+    post = _post(pb)
+    rows = post.stage(th, 'map_row')
+    y2d = post.stage(th[:2], 'y_2d')
+    post.close()
+    np.testing.assert_allclose(rows[1], 2.0 * rows[0], rtol=1e-10, atol=1e-18)
+    np.testing.assert_allclose(rows[2], 3.0 * rows[0], rtol=1e-10, atol=1e-18)
+    np.testing.assert_allclose(y2d[1], 2.0 * y2d[0], rtol=1e-12)
+    # 8-fold symmetry of the map about the centre pixel (d_mat is symmetric)
+    m = y2d[0]
+    c = 256
+    np.testing.assert_allclose(m[c + 5, c + 9], m[c - 5, c - 9], rtol=1e-14)
+    np.testing.assert_allclose(m[c + 5, c + 9], m[c + 9, c + 5], rtol=1e-14)
+    assert m[c, c] == m.max()

@@ -1,0 +1,135 @@
+"""Host-side table builders of the C library (joxsz_amd/csrc/jx_tables.hpp) against
+scipy and the oracle.  CPU only: uses the host-only build libjx_tables_host.so."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+from scipy.interpolate import interp1d, CubicSpline
+from scipy.signal import fftconvolve
+from scipy.fftpack import fft2, ifft2
+
+from oracle import pyabel_direct
+
+LIB = os.path.join(os.path.dirname(__file__), '..', 'joxsz_amd', 'csrc', 'libjx_tables_host.so')
+DP = ctypes.POINTER(ctypes.c_double)
+
+
+@pytest.fixture(scope='module')
+def lib():
+    if not os.path.exists(LIB):
+        import __graft_entry__
+        __graft_entry__.build_host_tables()
+    return ctypes.CDLL(LIB)
+
+
+def _p(a):
+    return a.ctypes.data_as(DP)
+
+
+GRIDS = {
+    'uniform': 16.0024 * np.arange(1, 61),
+    'arange': np.arange(2 * 8.0012, 5000. + 2 * 8.0012, 2 * 8.0012),      # joxsz_main.py:104
+    'ragged': np.cumsum(np.random.default_rng(3).uniform(5., 25., 47)),
+}
+
+
+@pytest.mark.parametrize('name', list(GRIDS))
+def test_abel_matrix(lib, name):
+    r = np.ascontiguousarray(GRIDS[name])
+    n = r.size
+    A = np.zeros((n, n))
+    lib.jxt_abel_matrix(_p(r), n, _p(A))
+    want = pyabel_direct.abel_weight_matrix(r)
+    assert np.all(np.tril(A, -1) == 0)
+    np.testing.assert_allclose(A, want, rtol=1e-12, atol=1e-12 * np.abs(want).max())
+    f = np.exp(-(r / 300.) ** 2)
+    np.testing.assert_allclose(A @ f, pyabel_direct.direct_transform_forward(f, r), rtol=1e-12)
+
+
+@pytest.mark.parametrize('name', list(GRIDS))
+def test_mirrored_spline(lib, name):
+    r = np.ascontiguousarray(GRIDS[name])
+    n = r.size
+    G = np.zeros((n, n))
+    K = lib.jxt_mirrored_spline_op(_p(r), n, _p(G))
+    assert 0 < K <= n
+    y = 1. / (1. + (r / 150.) ** 2) ** 1.5
+    f = interp1d(np.append(-r, r), np.append(y, y), 'cubic', bounds_error=False, fill_value=(0., 0.))
+    cs = CubicSpline(np.concatenate((-r[::-1], r)), np.concatenate((y[::-1], y)), bc_type='not-a-knot')
+    M = G @ y
+    np.testing.assert_allclose(M, cs(r, 2), rtol=1e-9, atol=1e-12 * np.abs(M).max())
+    # evaluate through the per-interval cubic exactly as the kernel does
+    q = np.sort(np.random.default_rng(0).uniform(0., r[-1], 400))
+    q = np.concatenate(([0., r[0] * 0.5, r[0], r[-1]], q))
+    got = np.empty_like(q)
+    for m, x in enumerate(q):
+        if x < r[0]:
+            got[m] = y[0] + 0.5 * M[0] * (x * x - r[0] ** 2)
+            continue
+        k = min(max(np.searchsorted(r, x, side='right') - 1, 0), n - 2)
+        h = r[k + 1] - r[k]
+        t = x - r[k]
+        b = (y[k + 1] - y[k]) / h - h * (2 * M[k] + M[k + 1]) / 6
+        got[m] = y[k] + t * (b + t * (M[k] / 2 + t * (M[k + 1] - M[k]) / (6 * h)))
+    np.testing.assert_allclose(got, f(q), rtol=1e-11, atol=1e-14)
+    if name != 'ragged':
+        assert K < 50          # Green's function of a near-uniform grid decays like 0.268^|i-j|
+
+
+def test_nak_eval_matrix(lib):
+    x = 2.0 * np.arange(86)
+    q = np.array([3.136, 9.409, 59.59, 116.1, 170.0, 180.5, -4.0, 0.0, 2.0])
+    E = np.zeros((q.size, x.size))
+    assert lib.jxt_nak_eval_matrix(_p(x), x.size, _p(q), q.size, _p(E)) == 0
+    y = -2.5 * np.exp(-x / 40.) + 0.01 * np.sin(x)
+    g = interp1d(x, y, 'cubic', fill_value='extrapolate')
+    np.testing.assert_allclose(E @ y, g(q), rtol=1e-11, atol=1e-13)
+    qn = np.array([1.0, np.nan])
+    En = np.zeros((2, x.size))
+    lib.jxt_nak_eval_matrix(_p(x), x.size, _p(qn), 2, _p(En))
+    assert np.isnan(En[1]).all() and np.isfinite(En[0]).all()
+
+
+@pytest.mark.parametrize('S,B,P', [(31, 9, 36), (32, 9, 36), (40, 11, 45), (64, 55, 96)])
+def test_beam_spectrum(lib, S, B, P):
+    rng = np.random.default_rng(S)
+    img = rng.standard_normal((S, S))
+    beam = rng.random((B, B))
+    Ph = P // 2 + 1
+    spec = np.zeros((P, Ph, 2))
+    lib.jxt_beam_spectrum(_p(beam), B, P, ctypes.c_double(0.25 / P ** 2), _p(spec))
+    bh = spec[..., 0] + 1j * spec[..., 1]
+    pad = np.zeros((P, P))
+    pad[:S, :S] = img
+    conv = np.fft.irfft2(np.fft.rfft2(pad) * bh, s=(P, P)) * P ** 2       # unnormalised pair
+    want = fftconvolve(img, beam, 'same') * 0.25
+    np.testing.assert_allclose(conv[:S, :S], want, rtol=1e-10, atol=1e-12 * np.abs(want).max())
+
+
+@pytest.mark.parametrize('S', [31, 32, 171])
+def test_tf_row_table(lib, S):
+    rng = np.random.default_rng(S)
+    x = rng.standard_normal((S, S))
+    for sym in (True, False):
+        if sym:
+            ax = np.linspace(-S // 2 + 1, S // 2, S)
+            filt = np.roll(np.exp(-np.sqrt(ax ** 2 + ax[:, None] ** 2) / 9.), S // 2 + 1, axis=(0, 1))
+        else:
+            filt = rng.random((S, S))          # arbitrary real filter: np.real() symmetrises it
+        Sh = S // 2 + 1
+        H = np.zeros((S, Sh, 2))
+        lib.jxt_tf_row_table(_p(np.ascontiguousarray(filt)), S, _p(H))
+        Hc = H[..., 0] + 1j * H[..., 1]
+        X = np.fft.rfft2(x)
+        Z = (X * Hc).sum(axis=0)
+        cols = np.arange(S // 2, S)
+        row = np.array([np.real(Z * np.exp(2j * np.pi * np.arange(Sh) * c / S)).sum() for c in cols])
+        want = np.real(ifft2(fft2(x) * filt))[S // 2, S // 2:]
+        np.testing.assert_allclose(row, want, rtol=1e-10, atol=1e-12 * np.abs(want).max())
+
+
+def test_next_smooth_even(lib):
+    assert lib.jxt_next_smooth_even(539) == 540
+    assert lib.jxt_next_smooth_even(198) == 200
+    assert lib.jxt_next_smooth_even(1051) == 1080
