@@ -67,6 +67,8 @@ typedef struct jx_config {
     int32_t max_batch;        /* walkers processed per internal chunk (0 = library default)    */
     int32_t fft_pad;          /* padded side of the beam convolution (0 = library default)     */
     int32_t map_split;        /* row slabs per walker in the Abel+map kernel (0 = default)     */
+    int32_t conv_mode;        /* beam+TF convolution: 0 auto, 1 rocFFT, 2 hand-written passes  */
+    int32_t reserved0;        /* keep the doubles 8-byte aligned; must be 0                    */
     double step;              /* arcsec                                   (joxsz_main.py:21)   */
     double kpc_as;            /* kpc per arcsec                           (joxsz_main.py:96)   */
     double m_e;               /* keV                                      (joxsz_main.py:22)   */
@@ -126,8 +128,8 @@ typedef enum jx_stage {
 typedef struct jx_timing {
     double prep_ms;       /* priors, mass veto, T profile, X-ray Cash      */
     double abel_map_ms;   /* fused profile -> Abel -> spline -> y map      */
-    double beam_fft_ms;   /* rocFFT R2C + spectrum multiply + rocFFT C2R   */
-    double tf_fft_ms;     /* rocFFT R2C of the S x S window                */
+    double beam_fft_ms;   /* beam convolution: rocFFT R2C + multiply + C2R, or hand-written passes 1+2 */
+    double tf_fft_ms;     /* rocFFT R2C of the S x S window, or hand-written pass 3                    */
     double tail_ms;       /* filter + central row + conversion + chi^2     */
     double total_ms;      /* first event to last event of each launch      */
     int64_t launches;     /* internal chunks timed                         */
@@ -171,6 +173,8 @@ int  jx_timing_get(jx_ctx* ctx, jx_timing* out);   /* synchronises the stream */
 /* Introspection: derived sizes chosen by the library. */
 int  jx_get_info(jx_ctx* ctx, int32_t* fft_pad, int32_t* chunk, int32_t* spline_band,
                  int32_t* nrow, int64_t* device_bytes);
+/* 1 = rocFFT, 2 = hand-written passes (what `conv_mode` resolved to); <0 on error */
+int  jx_get_conv_mode(jx_ctx* ctx);
 int  jx_device_count(void);
 const char* jx_device_name(jx_ctx* ctx);
 

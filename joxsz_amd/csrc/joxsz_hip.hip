@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <rocfft/rocfft.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -13,6 +14,7 @@
 
 #include "../../include/joxsz_hip.h"
 #include "jx_kernels.hpp"
+#include "jx_conv.hpp"
 #include "jx_tables.hpp"
 
 namespace {
@@ -42,6 +44,7 @@ struct jx_ctx {
 
     // derived sizes
     int P = 0, Ph = 0, Sh = 0, nrow = 0, nt = 0, K = 0, chunk = 0, map_split = 1, map_threads = 256;
+    size_t map_lds_bytes = 0;
     int64_t device_bytes = 0;
 
     // device constants
@@ -53,6 +56,13 @@ struct jx_ctx {
     double *d_pvec = nullptr, *d_base = nullptr, *d_cfac = nullptr;
     double *d_img = nullptr, *d_conv = nullptr;
     double2 *d_spec = nullptr, *d_tfspec = nullptr;
+    // hand-written convolution (conv_mode 2)
+    int conv_mode = 1;
+    JxConv cv;
+    cplx *d_Y = nullptr, *d_C = nullptr, *d_part = nullptr;
+    size_t p1_lds = 0, p2_lds = 0, p3_lds = 0;
+    int p13_rows = 8;
+    double* t_conv = nullptr;
     void* d_work = nullptr;
     size_t work_cap = 0;
     // batch staging for the host-pointer API
@@ -72,6 +82,9 @@ struct jx_ctx {
 };
 
 static int g_rocfft_refs = 0;
+
+// (LP, LS, rows per block) triples the hand-written convolution is instantiated for
+#define JX_CONV_PAIRS(X) X(18, 16, 8) X(48, 24, 8) X(48, 32, 8) X(96, 64, 8) X(144, 128, 8) X(288, 256, 8) X(576, 512, 4)
 
 #define HIPCHK(ctx, call)                                                                          \
     do {                                                                                           \
@@ -276,8 +289,24 @@ int jx_finalize(jx_ctx* ctx) {
     ctx->nt = ctx->nrow - 1;
     ctx->Sh = S / 2 + 1;
     const int o = (B - 1) / 2;
+    // ---- which convolution: rocFFT sequence or the hand-written mixed-domain passes
+    int want = c.conv_mode;
+    if (const char* e = getenv("JOXSZ_CONV")) {
+        if (!strcmp(e, "rocfft")) want = 1; else if (!strcmp(e, "custom")) want = 2; else if (!strcmp(e, "auto")) want = 0;
+    }
+    if (want < 0 || want > 2) { ctx->err = "conv_mode must be 0, 1 or 2"; return JX_ERR_INVALID; }
+    std::vector<double> beam_h = host_vec<double>(ctx, JX_T_BEAM_2D);
+    const int lp_custom = jxt::custom_conv_lp(S, o);
+    const size_t fir_lds = sizeof(double) * ((size_t)2 * (JX_FIR_TILE + 2 * o) * 64 + (size_t)(o + 1) * 64);
+    const bool eligible = lp_custom > 0 && jxt::beam_is_symmetric(beam_h, B) && fir_lds <= 150 * 1024 && c.fft_pad == 0;
+    if (want == 2 && !eligible) {
+        ctx->err = "hand-written convolution needs S/2 in {16,24,32,64,128,256,512}, a flip-symmetric beam with (B-1)/2 <= 34 and fft_pad = 0";
+        return JX_ERR_UNSUPPORTED;
+    }
+    ctx->conv_mode = (want == 2 || (want == 0 && eligible)) ? 2 : 1;
     int P = c.fft_pad > 0 ? c.fft_pad : jxt::next_smooth_even(S + o);
-    if (const char* e = getenv("JOXSZ_FFT_PAD")) { int v = atoi(e); if (v > 0) P = v; }
+    if (const char* e = getenv("JOXSZ_FFT_PAD")) { int v = atoi(e); if (v > 0 && ctx->conv_mode == 1) P = v; }
+    if (ctx->conv_mode == 2) P = 2 * lp_custom;
     if (P < S + o) { ctx->err = "fft_pad smaller than S + (B-1)/2"; return JX_ERR_INVALID; }
     ctx->P = P;
     ctx->Ph = P / 2 + 1;
@@ -296,6 +325,7 @@ int jx_finalize(jx_ctx* ctx) {
     d.nflux = c.nflux; d.nconv = c.nconv; d.nann = c.nann; d.nband = c.nband; d.ntab = c.ntab;
     d.npar = c.npar; d.ndim = c.ndim; d.ne_mode = c.ne_mode; d.exclude_unphy_mass = c.exclude_unphy_mass;
     d.sz_only = c.sz_only;
+    if (const char* e = getenv("JOXSZ_DBG")) d.dbg = atoi(e);      // timing-only ablations, results are wrong
     d.y_scale = c.kpc_cm * c.sigma_T / c.m_e;
     d.r_first = r[0];
     d.inv_h_mean = (double)(N - 1) / (r[N - 1] - r[0]);
@@ -344,17 +374,40 @@ int jx_finalize(jx_ctx* ctx) {
         double* p; if ((rc = dev_put(ctx, E.data(), E.size(), &p))) return rc; d.emat = p;
         if ((rc = dev_put(ctx, flux.data(), flux.size(), &p))) return rc; d.flux = p;
     }
-    // ---- beam spectrum and transfer-function row table
+    // ---- twiddles of the final inverse transform of the extracted row (both modes)
     {
-        std::vector<double> beam = host_vec<double>(ctx, JX_T_BEAM_2D), bh;
-        jxt::beam_spectrum(beam, B, P, c.step * c.step / ((double)P * (double)P), bh);
+        double* p;
+        std::vector<double> tw((size_t)S * 2);
+        for (int m = 0; m < S; ++m) { tw[2 * m] = std::cos(2.0 * jxt::kPi * m / S); tw[2 * m + 1] = std::sin(2.0 * jxt::kPi * m / S); }
+        if ((rc = dev_put(ctx, tw.data(), tw.size(), &p))) return rc; d.twid = p;
+    }
+    if (ctx->conv_mode == 1) {
+        // ---- rocFFT sequence: beam spectrum and transfer-function row table
+        std::vector<double> bh;
+        jxt::beam_spectrum(beam_h, B, P, c.step * c.step / ((double)P * (double)P), bh);
         double* p; if ((rc = dev_put(ctx, bh.data(), bh.size(), &p))) return rc; d.bhat = p;
         std::vector<double> filt = host_vec<double>(ctx, JX_T_FILTERING), H;
         jxt::tf_row_table(filt, S, H);
         if ((rc = dev_put(ctx, H.data(), H.size(), &p))) return rc; d.htab = p;
-        std::vector<double> tw((size_t)S * 2);
-        for (int m = 0; m < S; ++m) { tw[2 * m] = std::cos(2.0 * jxt::kPi * m / S); tw[2 * m + 1] = std::sin(2.0 * jxt::kPi * m / S); }
-        if ((rc = dev_put(ctx, tw.data(), tw.size(), &p))) return rc; d.twid = p;
+    } else {
+        // ---- hand-written passes: twiddles, real FIR taps of the beam, Hy table
+        JxConv& cv = ctx->cv;
+        memset(&cv, 0, sizeof(cv));
+        cv.S = S; cv.Sh = ctx->Sh; cv.B = B; cv.o = o; cv.P = P; cv.Ph = ctx->Ph; cv.LP = P / 2; cv.LS = S / 2; cv.ntap = o + 1;
+        ctx->p13_rows = (cv.LP <= 288) ? 8 : 4;
+        cv.nblk3 = (S + ctx->p13_rows - 1) / ctx->p13_rows;
+        std::vector<double> v;
+        double* p;
+        jxt::twiddles(cv.LP, cv.LP, v); if ((rc = dev_put(ctx, v.data(), v.size(), &p))) return rc; cv.tw_lp = (const cplx*)p;
+        jxt::twiddles(cv.LS, cv.LS, v); if ((rc = dev_put(ctx, v.data(), v.size(), &p))) return rc; cv.tw_ls = (const cplx*)p;
+        jxt::twiddles(P, cv.LP + 1, v); if ((rc = dev_put(ctx, v.data(), v.size(), &p))) return rc; cv.tw_p = (const cplx*)p;
+        jxt::twiddles(S, cv.LS + 1, v); if ((rc = dev_put(ctx, v.data(), v.size(), &p))) return rc; cv.tw_s = (const cplx*)p;
+        jxt::beam_fir_taps(beam_h, B, P, c.step * c.step / (double)P, v);
+        if ((rc = dev_put(ctx, v.data(), v.size(), &p))) return rc; cv.taps = p;
+        std::vector<double> filt = host_vec<double>(ctx, JX_T_FILTERING);
+        jxt::tf_hy_table(filt, S, v);
+        if ((rc = dev_put(ctx, v.data(), v.size(), &p))) return rc; cv.hy = (const cplx*)p;
+        ctx->p2_lds = fir_lds;
     }
     // ---- plain copies
     {
@@ -375,8 +428,51 @@ int jx_finalize(jx_ctx* ctx) {
 #undef PUTI
     }
 
+    // ---- symmetric-map tables: d_mat[iy][ix] = Q[|iy-c|][|ix-c|] (what centdistmat builds)
+    {
+        std::vector<double> dm = host_vec<double>(ctx, JX_T_D_MAT);
+        const int cc = S / 2, na = std::max(cc, S - 1 - cc) + 1;
+        std::vector<double> Q((size_t)na * na);
+        for (int b = 0; b < na; ++b)
+            for (int a = 0; a < na; ++a) {
+                const int iy = (cc + b < S) ? cc + b : cc - b, ix = (cc + a < S) ? cc + a : cc - a;
+                Q[(size_t)b * na + a] = dm[(size_t)iy * S + ix];
+            }
+        bool sym = true;
+        for (int iy = 0; iy < S && sym; ++iy)
+            for (int ix = 0; ix < S; ++ix) {
+                const double q = Q[(size_t)std::abs(iy - cc) * na + std::abs(ix - cc)];
+                if (memcmp(&q, &dm[(size_t)iy * S + ix], sizeof(double)) != 0) { sym = false; break; }
+            }
+        if (const char* e = getenv("JOXSZ_GENERIC_MAP")) { if (atoi(e) > 0) sym = false; }
+        if (na > 9 * 64) sym = false;                 // register-resident half row: |ix-c| < 576
+        d.fast_map = sym ? 1 : 0;
+        d.q_na = d.q_nb = na;
+        if (sym) {
+            std::vector<int32_t> qk((size_t)na * na);
+            std::vector<double> qt((size_t)na * na);
+            for (size_t e = 0; e < Q.size(); ++e) {
+                const double dd = Q[e];
+                if (!(dd <= r[N - 1])) { qk[e] = N; qt[e] = (dd != dd) ? dd : 0.0; }       // fill value 0 / NaN
+                else if (dd < r[0]) { qk[e] = N - 1; qt[e] = dd; }                           // centre interval
+                else {
+                    int k = (int)(std::upper_bound(r.begin(), r.end(), dd) - r.begin()) - 1;
+                    k = std::max(0, std::min(N - 2, k));
+                    qk[e] = k; qt[e] = dd - r[k];
+                }
+            }
+            int* qi; double* qd;
+            if ((rc = dev_put(ctx, qk.data(), qk.size(), &qi))) return rc; d.q_k = qi;
+            if ((rc = dev_put(ctx, qt.data(), qt.size(), &qd))) return rc; d.q_t = qd;
+        }
+    }
+
     // ---- chunk capacity and work buffers
-    const size_t per_walker = sizeof(double) * ((size_t)P * P * 2 + (size_t)P * ctx->Ph * 2 + (size_t)S * ctx->Sh * 2);
+    const size_t per_walker = (ctx->conv_mode == 1)
+        ? sizeof(double) * ((size_t)P * P * 2 + (size_t)P * ctx->Ph * 2 + (size_t)S * ctx->Sh * 2)
+        : sizeof(double) * ((size_t)S * S + (size_t)S * ctx->Ph * 4 + (size_t)ctx->cv.nblk3 * ctx->Sh * 2);
+    d.img_ld = (ctx->conv_mode == 1) ? P : S;
+    d.img_ws = (ctx->conv_mode == 1) ? (long long)P * P : (long long)S * S;
     int chunk = c.max_batch > 0 ? c.max_batch : 512;
     if (const char* e = getenv("JOXSZ_CHUNK")) { int v = atoi(e); if (v > 0) chunk = v; }
     const size_t budget = (size_t)24 << 30;
@@ -388,13 +484,48 @@ int jx_finalize(jx_ctx* ctx) {
     ctx->map_threads = 1024;
     if (const char* e = getenv("JOXSZ_MAP_THREADS")) { int v = atoi(e); if (v >= 64 && v <= 1024 && v % 64 == 0) ctx->map_threads = v; }
 
+    {
+        const size_t LDS_MAX = 160 * 1024;
+        auto need = [&](int threads) {
+            size_t dbl = JX_MAP_LDS_DOUBLES(N);
+            if (d.fast_map) dbl += (size_t)(threads / 64) * ((S + 3) & ~1);
+            return dbl * sizeof(double);
+        };
+        while (ctx->map_threads > 64 && need(ctx->map_threads) > LDS_MAX - 1024) ctx->map_threads /= 2;
+        ctx->map_lds_bytes = need(ctx->map_threads);
+        if (ctx->map_lds_bytes > LDS_MAX - 1024) { ctx->err = "radial grid too long for the LDS-resident spline"; return JX_ERR_UNSUPPORTED; }
+        const int lds = (int)ctx->map_lds_bytes;
+#define JX_ATTR(V, NA) HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_abel_map_sym_kernel<V, NA>, hipFuncAttributeMaxDynamicSharedMemorySize, lds))
+        JX_ATTR(true, 3); JX_ATTR(true, 5); JX_ATTR(true, 9); JX_ATTR(false, 3); JX_ATTR(false, 5); JX_ATTR(false, 9);
+#undef JX_ATTR
+        HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_abel_map_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_abel_map_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    }
+
     if ((rc = dev_new(ctx, (size_t)chunk * JX_MAX_PAR, &ctx->d_pvec))) return rc;
     if ((rc = dev_new(ctx, (size_t)chunk, &ctx->d_base))) return rc;
     if ((rc = dev_new(ctx, (size_t)chunk * ctx->nrow, &ctx->d_cfac))) return rc;
-    if ((rc = dev_new(ctx, (size_t)chunk * P * P, &ctx->d_img, true))) return rc;     // padding stays zero for ever
-    if ((rc = dev_new(ctx, (size_t)chunk * P * P, &ctx->d_conv))) return rc;
-    if ((rc = dev_new(ctx, (size_t)chunk * P * ctx->Ph, &ctx->d_spec))) return rc;
-    if ((rc = dev_new(ctx, (size_t)chunk * S * ctx->Sh, &ctx->d_tfspec))) return rc;
+    if (ctx->conv_mode == 1) {
+        if ((rc = dev_new(ctx, (size_t)chunk * P * P, &ctx->d_img, true))) return rc;     // padding stays zero for ever
+        if ((rc = dev_new(ctx, (size_t)chunk * P * P, &ctx->d_conv))) return rc;
+        if ((rc = dev_new(ctx, (size_t)chunk * P * ctx->Ph, &ctx->d_spec))) return rc;
+        if ((rc = dev_new(ctx, (size_t)chunk * S * ctx->Sh, &ctx->d_tfspec))) return rc;
+    } else {
+        const JxConv& cv = ctx->cv;
+        if ((rc = dev_new(ctx, (size_t)chunk * S * S, &ctx->d_img))) return rc;
+        if ((rc = dev_new(ctx, (size_t)chunk * S * cv.Ph, &ctx->d_Y))) return rc;
+        if ((rc = dev_new(ctx, (size_t)chunk * S * cv.Ph, &ctx->d_C))) return rc;
+        if ((rc = dev_new(ctx, (size_t)chunk * cv.nblk3 * cv.Sh, &ctx->d_part))) return rc;
+        const int R = ctx->p13_rows;
+        ctx->p1_lds = sizeof(cplx) * ((size_t)2 * R * cv.LP + cv.LP);
+        ctx->p3_lds = sizeof(cplx) * ((size_t)2 * R * cv.LP + cv.LP + cv.LS);
+#define JX_ATTR13(LPv, LSv, Rv) if (cv.LP == LPv && cv.LS == LSv) { \
+            HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_rowfft_kernel<LPv, Rv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->p1_lds)); \
+            HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_rowtf_kernel<LPv, LSv, Rv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->p3_lds)); }
+        JX_CONV_PAIRS(JX_ATTR13)
+#undef JX_ATTR13
+        HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_beamfir_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->p2_lds));
+    }
 
     FFTCHK(ctx, rocfft_execution_info_create(&ctx->info));
     FFTCHK(ctx, rocfft_execution_info_set_stream(ctx->info, ctx->stream));
@@ -405,7 +536,7 @@ int jx_finalize(jx_ctx* ctx) {
 static int ensure_batch(jx_ctx* ctx, int n) {
     if (n <= ctx->batch_cap) return JX_OK;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->d_theta) { hipFree(ctx->d_theta); hipFree(ctx->d_logp); }
+    if (ctx->d_theta) { (void)hipFree(ctx->d_theta); (void)hipFree(ctx->d_logp); }
     HIPCHK(ctx, hipMalloc((void**)&ctx->d_theta, sizeof(double) * (size_t)n * ctx->cfg.ndim));
     HIPCHK(ctx, hipMalloc((void**)&ctx->d_logp, sizeof(double) * (size_t)n));
     ctx->batch_cap = n;
@@ -436,13 +567,40 @@ static int drain_events(jx_ctx* ctx) {
 
 struct Taps {
     double *pp = nullptr, *ab = nullptr, *y = nullptr, *row = nullptr, *bright = nullptr, *chisq = nullptr,
-           *tprof = nullptr, *xprofs = nullptr, *parts = nullptr;
+           *tprof = nullptr, *xprofs = nullptr, *parts = nullptr, *conv = nullptr;
 };
+
+
+static int launch_custom_conv(jx_ctx* ctx, int n, double* tap_conv, EvSet* es) {
+    const JxConv& cv = ctx->cv;
+    const JxDev& d = ctx->d;
+    hipStream_t st = ctx->stream;
+    const int R = ctx->p13_rows;
+    const dim3 g13((cv.S + R - 1) / R, n);
+    bool done = false;
+#define JX_P1(LPv, LSv, Rv) if (!done && cv.LP == LPv && cv.LS == LSv) { \
+        hipLaunchKernelGGL((jx_rowfft_kernel<LPv, Rv>), g13, dim3(256), ctx->p1_lds, st, cv, ctx->d_img, (size_t)d.img_ld, (size_t)d.img_ws, ctx->d_Y); done = true; }
+    JX_CONV_PAIRS(JX_P1)
+#undef JX_P1
+    if (!done) { ctx->err = "no pass-1 kernel for this size"; return JX_ERR_UNSUPPORTED; }
+    {
+        const dim3 g2((cv.Ph + 63) / 64, (cv.S + JX_FIR_TILE - 1) / JX_FIR_TILE, n);
+        hipLaunchKernelGGL(jx_beamfir_kernel, g2, dim3(512), ctx->p2_lds, st, cv, ctx->d_Y, ctx->d_C);
+    }
+    if (es) HIPCHK(ctx, hipEventRecord(es->e[3], st));
+    done = false;
+#define JX_P3(LPv, LSv, Rv) if (!done && cv.LP == LPv && cv.LS == LSv) { \
+        hipLaunchKernelGGL((jx_rowtf_kernel<LPv, LSv, Rv>), g13, dim3(256), ctx->p3_lds, st, cv, ctx->d_C, ctx->d_part, tap_conv); done = true; }
+    JX_CONV_PAIRS(JX_P3)
+#undef JX_P3
+    if (es) HIPCHK(ctx, hipEventRecord(es->e[4], st));
+    return JX_OK;
+}
 
 // One chunk: walkers [w0, w0+n) of the batch whose thetas live at theta_dev.
 static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int w0, int n, const Taps& t) {
     Plan3* pl = nullptr;
-    int rc = make_plans(ctx, n, &pl);
+    int rc = (ctx->conv_mode == 1) ? make_plans(ctx, n, &pl) : JX_OK;
     if (rc) return rc;
     const JxDev& d = ctx->d;
     hipStream_t st = ctx->stream;
@@ -461,38 +619,54 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
     }
     if (tm) HIPCHK(ctx, hipEventRecord(es.e[1], st));
     {
-        const size_t sh = sizeof(double) * (size_t)d.N * 8;
         const bool vec2 = (d.S % 2 == 0) && (d.P % 2 == 0);
-        if (vec2)
-            hipLaunchKernelGGL(jx_abel_map_kernel<true>, dim3(n * d.map_split), dim3(ctx->map_threads), sh, st, d, ctx->d_pvec,
-                               ctx->d_img, t.pp, t.ab, t.y);
-        else
-            hipLaunchKernelGGL(jx_abel_map_kernel<false>, dim3(n * d.map_split), dim3(ctx->map_threads), sh, st, d, ctx->d_pvec,
-                               ctx->d_img, t.pp, t.ab, t.y);
+        const dim3 grid(n * d.map_split), block(ctx->map_threads);
+        if (d.fast_map) {
+            const size_t sh = ctx->map_lds_bytes;
+#define JX_SYM_LAUNCH(V, NA) hipLaunchKernelGGL((jx_abel_map_sym_kernel<V, NA>), grid, block, sh, st, d, ctx->d_pvec, ctx->d_img, t.pp, t.ab, t.y)
+            const int nait = (d.q_na + 63) / 64;
+            if (vec2) { if (nait <= 3) JX_SYM_LAUNCH(true, 3); else if (nait <= 5) JX_SYM_LAUNCH(true, 5); else JX_SYM_LAUNCH(true, 9); }
+            else      { if (nait <= 3) JX_SYM_LAUNCH(false, 3); else if (nait <= 5) JX_SYM_LAUNCH(false, 5); else JX_SYM_LAUNCH(false, 9); }
+#undef JX_SYM_LAUNCH
+        } else {
+            const size_t sh = ctx->map_lds_bytes;
+            if (vec2) hipLaunchKernelGGL(jx_abel_map_kernel<true>, grid, block, sh, st, d, ctx->d_pvec, ctx->d_img, t.pp, t.ab, t.y);
+            else hipLaunchKernelGGL(jx_abel_map_kernel<false>, grid, block, sh, st, d, ctx->d_pvec, ctx->d_img, t.pp, t.ab, t.y);
+        }
     }
     if (tm) HIPCHK(ctx, hipEventRecord(es.e[2], st));
-    {
-        void* in[1] = {ctx->d_img};
-        void* out[1] = {ctx->d_spec};
-        FFTCHK(ctx, rocfft_execute(pl->beam_fwd, in, out, ctx->info));
-        const size_t per = (size_t)d.P * d.Ph, total = per * n;
-        const int blocks = (int)std::min<size_t>((total + 255) / 256, 8192);
-        hipLaunchKernelGGL(jx_beam_mul_kernel, dim3(blocks), dim3(256), 0, st, ctx->d_spec, (const double2*)d.bhat, per, total);
-        void* in2[1] = {ctx->d_spec};
-        void* out2[1] = {ctx->d_conv};
-        FFTCHK(ctx, rocfft_execute(pl->beam_inv, in2, out2, ctx->info));
+    const cplx* zpart = nullptr;
+    int nblk = 0;
+    if (ctx->conv_mode == 1) {
+        {
+            void* in[1] = {ctx->d_img};
+            void* out[1] = {ctx->d_spec};
+            FFTCHK(ctx, rocfft_execute(pl->beam_fwd, in, out, ctx->info));
+            const size_t per = (size_t)d.P * d.Ph, total = per * n;
+            const int blocks = (int)std::min<size_t>((total + 255) / 256, 8192);
+            hipLaunchKernelGGL(jx_beam_mul_kernel, dim3(blocks), dim3(256), 0, st, ctx->d_spec, (const double2*)d.bhat, per, total);
+            void* in2[1] = {ctx->d_spec};
+            void* out2[1] = {ctx->d_conv};
+            FFTCHK(ctx, rocfft_execute(pl->beam_inv, in2, out2, ctx->info));
+        }
+        if (tm) HIPCHK(ctx, hipEventRecord(es.e[3], st));
+        {
+            void* in[1] = {ctx->d_conv};
+            void* out[1] = {ctx->d_tfspec};
+            FFTCHK(ctx, rocfft_execute(pl->tf_fwd, in, out, ctx->info));
+        }
+        if (tm) HIPCHK(ctx, hipEventRecord(es.e[4], st));
+    } else {
+        const JxConv& cv = ctx->cv;
+        int rc2 = launch_custom_conv(ctx, n, t.conv, tm ? &es : nullptr);
+        if (rc2) return rc2;
+        zpart = ctx->d_part;
+        nblk = cv.nblk3;
     }
-    if (tm) HIPCHK(ctx, hipEventRecord(es.e[3], st));
-    {
-        void* in[1] = {ctx->d_conv};
-        void* out[1] = {ctx->d_tfspec};
-        FFTCHK(ctx, rocfft_execute(pl->tf_fwd, in, out, ctx->info));
-    }
-    if (tm) HIPCHK(ctx, hipEventRecord(es.e[4], st));
     {
         const size_t sh = sizeof(double) * ((size_t)2 * d.Sh + d.nrow + 8);
-        hipLaunchKernelGGL(jx_tail_kernel, dim3(n), dim3(JX_TAIL_THREADS), sh, st, d, ctx->d_tfspec, ctx->d_cfac, ctx->d_base,
-                           logp_dev, w0, t.row, t.bright, t.chisq, t.parts);
+        hipLaunchKernelGGL(jx_tail_kernel, dim3(n), dim3(JX_TAIL_THREADS), sh, st, d, ctx->d_tfspec, zpart, nblk, ctx->d_cfac,
+                           ctx->d_base, logp_dev, w0, t.row, t.bright, t.chisq, t.parts);
     }
     if (tm) {
         HIPCHK(ctx, hipEventRecord(es.e[5], st));
@@ -549,6 +723,7 @@ static int ensure_taps(jx_ctx* ctx) {
     if ((rc = dev_new(ctx, C, &ctx->t_chisq))) return rc;
     if ((rc = dev_new(ctx, C * std::max(1, c.nband * c.nann), &ctx->t_xprofs, true))) return rc;
     if ((rc = dev_new(ctx, C * 4, &ctx->t_parts, true))) return rc;
+    if (ctx->conv_mode == 2 && (rc = dev_new(ctx, C * c.S * c.S, &ctx->t_conv))) return rc;
     return JX_OK;
 }
 
@@ -576,6 +751,7 @@ int jx_eval_stage(jx_ctx* ctx, const double* theta, int nwalkers, int stage, dou
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_theta, theta, sizeof(double) * (size_t)nwalkers * c.ndim, hipMemcpyHostToDevice, ctx->stream));
     Taps t;
     t.pp = ctx->t_pp; t.ab = ctx->t_ab; t.y = ctx->t_y; t.row = ctx->t_row; t.bright = ctx->t_bright;
+    t.conv = (stage == JX_STAGE_CONV2D) ? ctx->t_conv : nullptr;
     t.chisq = ctx->t_chisq; t.tprof = ctx->t_tprof; t.xprofs = c.sz_only ? nullptr : ctx->t_xprofs; t.parts = ctx->t_parts;
     for (int w0 = 0; w0 < nwalkers; w0 += ctx->chunk) {
         const int n = std::min(ctx->chunk, nwalkers - w0);
@@ -597,10 +773,13 @@ int jx_eval_stage(jx_ctx* ctx, const double* theta, int nwalkers, int stage, dou
         if (src) {
             HIPCHK(ctx, hipMemcpyAsync(dst, src, per * sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
         } else {
-            const double* base = (stage == JX_STAGE_Y2D) ? ctx->d_img : ctx->d_conv;
+            const bool dense = (stage == JX_STAGE_CONV2D && ctx->conv_mode == 2);
+            const double* base = (stage == JX_STAGE_Y2D) ? ctx->d_img : (dense ? ctx->t_conv : ctx->d_conv);
+            const size_t ld = (stage == JX_STAGE_Y2D) ? (size_t)ctx->d.img_ld : (dense ? S : P);
+            const size_t ws = (stage == JX_STAGE_Y2D) ? (size_t)ctx->d.img_ws : (dense ? S * S : P * P);
             for (int w = 0; w < n; ++w)
-                HIPCHK(ctx, hipMemcpy2DAsync(dst + (size_t)w * S * S, S * sizeof(double), base + (size_t)w * P * P,
-                                             P * sizeof(double), S * sizeof(double), S, hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHK(ctx, hipMemcpy2DAsync(dst + (size_t)w * S * S, S * sizeof(double), base + (size_t)w * ws,
+                                             ld * sizeof(double), S * sizeof(double), S, hipMemcpyDeviceToHost, ctx->stream));
         }
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
@@ -676,23 +855,28 @@ int jx_get_info(jx_ctx* ctx, int32_t* fft_pad, int32_t* chunk, int32_t* band, in
     return JX_OK;
 }
 
+int jx_get_conv_mode(jx_ctx* ctx) {
+    if (!ctx || !ctx->finalized) return JX_ERR_STATE;
+    return ctx->conv_mode;
+}
+
 void jx_destroy(jx_ctx* ctx) {
     if (!ctx) return;
-    hipSetDevice(ctx->cfg.device);
-    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    (void)hipSetDevice(ctx->cfg.device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (auto& kv : ctx->plans) {
         if (kv.second.beam_fwd) rocfft_plan_destroy(kv.second.beam_fwd);
         if (kv.second.beam_inv) rocfft_plan_destroy(kv.second.beam_inv);
         if (kv.second.tf_fwd) rocfft_plan_destroy(kv.second.tf_fwd);
     }
     if (ctx->info) rocfft_execution_info_destroy(ctx->info);
-    for (auto& es : ctx->ev_inflight) for (int k = 0; k < 6; ++k) hipEventDestroy(es.e[k]);
-    for (auto& es : ctx->ev_free) for (int k = 0; k < 6; ++k) hipEventDestroy(es.e[k]);
-    for (void* p : ctx->dev_allocs) hipFree(p);
-    if (ctx->d_work) hipFree(ctx->d_work);
-    if (ctx->d_theta) hipFree(ctx->d_theta);
-    if (ctx->d_logp) hipFree(ctx->d_logp);
-    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    for (auto& es : ctx->ev_inflight) for (int k = 0; k < 6; ++k) (void)hipEventDestroy(es.e[k]);
+    for (auto& es : ctx->ev_free) for (int k = 0; k < 6; ++k) (void)hipEventDestroy(es.e[k]);
+    for (void* p : ctx->dev_allocs) (void)hipFree(p);
+    if (ctx->d_work) (void)hipFree(ctx->d_work);
+    if (ctx->d_theta) (void)hipFree(ctx->d_theta);
+    if (ctx->d_logp) (void)hipFree(ctx->d_logp);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (--g_rocfft_refs == 0) rocfft_cleanup();
     delete ctx;
 }

@@ -39,6 +39,11 @@ struct JxDev {
     // constant tensors (device)
     const double* r_pp;          // [N]
     const double* d_mat;         // [S*S]
+    long long img_ld, img_ws;    // row and walker strides (doubles) of the y-map image
+    int dbg;                     // timing-only ablations (JOXSZ_DBG): 1 skip phases 1-4, 2 skip phase 5, 4 phase 5 stores only
+    int fast_map, q_na, q_nb;    // symmetric-map form: table sizes (|ix-c|, |iy-c|)
+    const int* q_k;              // [q_nb*q_na] coefficient slot of each quadrant radius
+    const double* q_t;           // [q_nb*q_na] local abscissa within that slot
     const double* abelT;         // [N*N] abelT[j*N+i] = A[i][j] (column of weights per source j)
     const double* gband;         // [(2K+1)*N] gband[(k+K)*N+i] = G[i][i+k]
     const double* bhat;          // [P*Ph*2]
@@ -275,14 +280,124 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0, double* __rest
 // K1: FUSED profile -> Abel -> y -> spline -> map.  grid = (chunk walkers * map_split).
 //
 // Phase 1  pp_j = gNFW(r_j)                       -> LDS            (joxsz_funcs.py:453)
-// Phase 2  ab_i = sum_{j>=i} A[i][j] pp_j         thread-per-row, weights streamed
+// Phase 2  ab_i = sum_{j>=i} A[i][j] pp_j         thread-per-(half-)row, weights streamed
 //          coalesced from the shared table (L2), pp broadcast from LDS (joxsz_funcs.py:457)
 // Phase 3  y = y_scale * ab ; M = G_band y        (joxsz_funcs.py:459-460)
 // Phase 4  per-interval cubic coefficients        -> LDS
-// Phase 5  y_2d[p] = spline(d_mat[p]) for the block's row slab, coalesced reads of the
-//          shared radius matrix, coalesced 16-byte stores into the padded FFT image
-//          (joxsz_funcs.py:462).  This is the HBM-write-bound phase: S*S*8 bytes per walker.
+// Phase 5  y_2d[p] = spline(d_mat[p]) for the block's rows, coalesced 16-byte stores into
+//          the padded FFT image (joxsz_funcs.py:462).  This is the HBM-write-bound phase:
+//          S*S*8 bytes per walker.  Two forms:
+//          * symmetric (d_mat[iy][ix] depends on |iy-c|, |ix-c| only, which is what
+//            centdistmat builds, joxsz_funcs.py:78-88): each wave evaluates the half row
+//            |ix-c| = 0..na-1 once from the precomputed (interval, offset) table of the
+//            shared radius grid, stages it in LDS and stores the two mirrored rows;
+//          * generic: any d_mat, interval search per pixel.
+//
+// LDS coefficient slots: k = 0..N-2 intervals [r_k, r_{k+1}] in t = x - r_k;
+// k = N-1 the centre interval [-r_0, r_0] in t = x (even polynomial); k = N zero (outside).
 // ------------------------------------------------------------------------------------
+__device__ __forceinline__ void jx_profile_to_coefs(const JxDev& c, const double* p, int w, bool taps, double* s_r,
+                                                    double* s_pp, double* s_y, double* s_M, double* s_cf,
+                                                    double* tap_pp, double* tap_ab, double* tap_y) {
+    const int N = c.N, tid = threadIdx.x, nth = blockDim.x;
+    // Phase 1
+    for (int j = tid; j < N; j += nth) {
+        const double r = c.r_pp[j];
+        s_r[j] = r;
+        const double v = (c.dbg & 32) ? r : jx_press(p, r);
+        s_pp[j] = v;
+        if (taps && tap_pp) tap_pp[(size_t)w * N + j] = v;
+    }
+    __syncthreads();
+
+    // Phase 2: rows i of the upper-triangular product.  With >= 2N threads each row is
+    // split in two halves [i, mid) and [mid, N) handled by threads i and i + nth/2.
+    const bool two = (nth >= 2 * N);
+    const int half = nth >> 1;
+    for (int i0 = 0; i0 < N; i0 += (two ? half : nth)) {
+        int i, jb, je;
+        if (two) {
+            const int hsel = tid >= half;
+            i = i0 + tid - hsel * half;
+            const int mid = (i + N + 1) >> 1;
+            jb = hsel ? mid : i;
+            je = hsel ? N : mid;
+        } else {
+            i = i0 + tid; jb = i; je = N;
+        }
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0, a5 = 0.0, a6 = 0.0, a7 = 0.0;
+        if (i < N && !(c.dbg & 8)) {
+            const double* col = c.abelT + i;
+            int j = jb;
+            for (; j + 7 < je; j += 8) {
+                const double w0 = col[(size_t)j * N], w1 = col[(size_t)(j + 1) * N], w2 = col[(size_t)(j + 2) * N],
+                             w3 = col[(size_t)(j + 3) * N], w4 = col[(size_t)(j + 4) * N], w5 = col[(size_t)(j + 5) * N],
+                             w6 = col[(size_t)(j + 6) * N], w7 = col[(size_t)(j + 7) * N];
+                a0 = fma(w0, s_pp[j], a0);     a1 = fma(w1, s_pp[j + 1], a1);
+                a2 = fma(w2, s_pp[j + 2], a2); a3 = fma(w3, s_pp[j + 3], a3);
+                a4 = fma(w4, s_pp[j + 4], a4); a5 = fma(w5, s_pp[j + 5], a5);
+                a6 = fma(w6, s_pp[j + 6], a6); a7 = fma(w7, s_pp[j + 7], a7);
+            }
+            for (; j < je; ++j) a0 = fma(col[(size_t)j * N], s_pp[j], a0);
+        }
+        a0 += a4; a1 += a5; a2 += a6; a3 += a7;
+        const double part = (a0 + a1) + (a2 + a3);
+        if (two) {
+            if (tid >= half && i < N) s_M[i] = part;           // s_M is free until phase 3
+            __syncthreads();
+            if (tid < half && i < N) {
+                const double ab = part + s_M[i];
+                s_y[i] = c.y_scale * ab;
+                if (taps && tap_ab) tap_ab[(size_t)w * N + i] = ab;
+            }
+            __syncthreads();
+        } else if (i < N) {
+            s_y[i] = c.y_scale * part;
+            if (taps && tap_ab) tap_ab[(size_t)w * N + i] = part;
+        }
+    }
+    __syncthreads();
+    if (taps && tap_y) for (int i = tid; i < N; i += nth) tap_y[(size_t)w * N + i] = s_y[i];
+
+    // Phase 3: spline moments through the banded operator
+    const int K = c.K;
+    for (int i = tid; i < N; i += nth) {
+        const int k0 = max(-K, -i), k1 = (c.dbg & 16) ? k0 - 1 : min(K, N - 1 - i);
+        double m0 = 0.0, m1 = 0.0;
+        int k = k0;
+        for (; k + 1 <= k1; k += 2) {
+            m0 = fma(c.gband[(size_t)(k + K) * N + i], s_y[i + k], m0);
+            m1 = fma(c.gband[(size_t)(k + 1 + K) * N + i], s_y[i + k + 1], m1);
+        }
+        if (k <= k1) m0 = fma(c.gband[(size_t)(k + K) * N + i], s_y[i + k], m0);
+        s_M[i] = m0 + m1;
+    }
+    __syncthreads();
+
+    // Phase 4: cubic coefficients
+    for (int k = tid; k < N + 1; k += nth) {
+        double c0, c1, c2, c3;
+        if (k < N - 1) {
+            const double h = s_r[k + 1] - s_r[k];
+            const double y0 = s_y[k], y1 = s_y[k + 1], m0 = s_M[k], m1 = s_M[k + 1];
+            c0 = y0;
+            c1 = (y1 - y0) / h - h * (2.0 * m0 + m1) / 6.0;
+            c2 = 0.5 * m0;
+            c3 = (m1 - m0) / (6.0 * h);
+        } else if (k == N - 1) {                            // centre: y_0 + M_0 (x^2 - r_0^2)/2
+            c0 = s_y[0] - 0.5 * s_M[0] * s_r[0] * s_r[0];
+            c1 = 0.0; c2 = 0.5 * s_M[0]; c3 = 0.0;
+        } else {
+            c0 = c1 = c2 = c3 = 0.0;                        // outside [-r_N, r_N]: fill value 0
+        }
+        s_cf[4 * k + 0] = c0; s_cf[4 * k + 1] = c1; s_cf[4 * k + 2] = c2; s_cf[4 * k + 3] = c3;
+    }
+    __syncthreads();
+}
+
+// LDS doubles needed by the profile-to-coefficients phases
+#define JX_MAP_LDS_DOUBLES(N) (8 * (size_t)(N) + 8)
+
 template <bool VEC2>
 __global__ void __launch_bounds__(1024)
 jx_abel_map_kernel(JxDev c, const double* __restrict__ pvec, double* __restrict__ img /*[chunk][P][P]*/,
@@ -290,10 +405,10 @@ jx_abel_map_kernel(JxDev c, const double* __restrict__ pvec, double* __restrict_
     extern __shared__ double sm[];
     const int N = c.N;
     double* s_r = sm;                 // [N] knots
-    double* s_pp = s_r + N;           // [N] pp, later y
+    double* s_pp = s_r + N;           // [N]
     double* s_y = s_pp + N;           // [N]
     double* s_M = s_y + N;            // [N]
-    double* s_cf = s_M + N;           // [4N] a,b,c,d per interval k = [r_k, r_{k+1}]
+    double* s_cf = s_M + N;           // [4(N+1)]
     __shared__ double p[JX_MAX_PAR];
 
     const int tid = threadIdx.x, nth = blockDim.x;
@@ -302,85 +417,37 @@ jx_abel_map_kernel(JxDev c, const double* __restrict__ pvec, double* __restrict_
 
     if (tid < JX_MAX_PAR) p[tid] = pvec[(size_t)w * JX_MAX_PAR + tid];
     __syncthreads();
+    jx_profile_to_coefs(c, p, w, part == 0, s_r, s_pp, s_y, s_M, s_cf, tap_pp, tap_ab, tap_y);
 
-    // Phase 1
-    for (int j = tid; j < N; j += nth) {
-        const double r = c.r_pp[j];
-        s_r[j] = r;
-        const double v = jx_press(p, r);
-        s_pp[j] = v;
-        if (tap_pp && part == 0) tap_pp[(size_t)w * N + j] = v;
-    }
-    __syncthreads();
-
-    // Phase 2: row i of the upper-triangular product, 4 partial sums for ILP
-    for (int i = tid; i < N; i += nth) {
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-        const double* col = c.abelT + i;
-        int j = i;
-        for (; j + 3 < N; j += 4) {
-            a0 = fma(col[(size_t)j * N], s_pp[j], a0);
-            a1 = fma(col[(size_t)(j + 1) * N], s_pp[j + 1], a1);
-            a2 = fma(col[(size_t)(j + 2) * N], s_pp[j + 2], a2);
-            a3 = fma(col[(size_t)(j + 3) * N], s_pp[j + 3], a3);
-        }
-        for (; j < N; ++j) a0 = fma(col[(size_t)j * N], s_pp[j], a0);
-        const double ab = (a0 + a1) + (a2 + a3);
-        const double y = c.y_scale * ab;
-        s_y[i] = y;
-        if (part == 0) {
-            if (tap_ab) tap_ab[(size_t)w * N + i] = ab;
-            if (tap_y) tap_y[(size_t)w * N + i] = y;
-        }
-    }
-    __syncthreads();
-
-    // Phase 3: spline moments through the banded operator
-    const int K = c.K;
-    for (int i = tid; i < N; i += nth) {
-        const int k0 = max(-K, -i), k1 = min(K, N - 1 - i);
-        double m = 0.0;
-        for (int k = k0; k <= k1; ++k) m = fma(c.gband[(size_t)(k + K) * N + i], s_y[i + k], m);
-        s_M[i] = m;
-    }
-    __syncthreads();
-
-    // Phase 4: coefficients of interval k = [r_k, r_{k+1}], local abscissa t = x - r_k
-    for (int k = tid; k < N - 1; k += nth) {
-        const double h = s_r[k + 1] - s_r[k];
-        const double y0 = s_y[k], y1 = s_y[k + 1], m0 = s_M[k], m1 = s_M[k + 1];
-        s_cf[4 * k + 0] = y0;
-        s_cf[4 * k + 1] = (y1 - y0) / h - h * (2.0 * m0 + m1) / 6.0;
-        s_cf[4 * k + 2] = 0.5 * m0;
-        s_cf[4 * k + 3] = (m1 - m0) / (6.0 * h);
-    }
-    __syncthreads();
-    const double y_first = s_y[0], m_first = s_M[0], r_first = s_r[0], r_last = s_r[N - 1];
-
-    // Phase 5: the map slab
+    // Phase 5 (generic): the block's slab of rows
     const int S = c.S, P = c.P;
     const int rows_per = (S + c.map_split - 1) / c.map_split;
     const int row0 = part * rows_per, row1 = min(S, row0 + rows_per);
     const int lane = tid & 63, wv = tid >> 6, nwv = nth >> 6;
-    double* out = img + (size_t)w * P * P;
+    double* out = img + (size_t)w * c.img_ws;
+    const double r_first = s_r[0], r_last = s_r[N - 1];
 
     auto eval = [&](double d) -> double {
         // interp1d(..., bounds_error=False, fill_value=(0,0)): 0 outside [-r_N, r_N];
         // NaN radius propagates
         if (!(d <= r_last)) return (d != d) ? d : 0.0;
-        if (d < r_first) return y_first + 0.5 * m_first * (d * d - r_first * r_first);
-        int k = (int)((d - r_first) * c.inv_h_mean);
-        k = min(max(k, 0), N - 2);
-        while (k < N - 2 && d >= s_r[k + 1]) ++k;
-        while (k > 0 && d < s_r[k]) --k;
-        const double t = d - s_r[k];
+        int k;
+        double t;
+        if (d < r_first) { k = N - 1; t = d; }
+        else {
+            k = (int)((d - r_first) * c.inv_h_mean);
+            k = min(max(k, 0), N - 2);
+            while (k < N - 2 && d >= s_r[k + 1]) ++k;
+            while (k > 0 && d < s_r[k]) --k;
+            t = d - s_r[k];
+        }
         const double* cf = s_cf + 4 * k;
         return fma(t, fma(t, fma(t, cf[3], cf[2]), cf[1]), cf[0]);
     };
 
     for (int iy = row0 + wv; iy < row1; iy += nwv) {
         const double* drow = c.d_mat + (size_t)iy * S;
-        double* orow = out + (size_t)iy * P;
+        double* orow = out + (size_t)iy * c.img_ld;
         if (VEC2) {
             for (int ix = 2 * lane; ix < S; ix += 128) {
                 const double2 d = *reinterpret_cast<const double2*>(drow + ix);
@@ -392,6 +459,123 @@ jx_abel_map_kernel(JxDev c, const double* __restrict__ pvec, double* __restrict_
         } else {
             for (int ix = lane; ix < S; ix += 64) orow[ix] = eval(drow[ix]);
         }
+    }
+}
+
+// Symmetric form of K1.  q_k / q_t: [q_nb][q_na] interval slot and local abscissa of the
+// radius at (|iy-c|, |ix-c|), built once from d_mat and r_pp at jx_finalize.
+//
+// Phase 5 here is software-pipelined per wave: the (slot, abscissa) entries of the wave's
+// NEXT half row are loaded into registers before the stores of the current two mirrored
+// rows are issued, so the loads never queue behind those stores (vector memory operations
+// return in order) and the stores stay in flight behind a counted vmcnt.  The half row is
+// evaluated once (|ix-c| = 0..na-1), mirrored into a full row in the wave's private LDS
+// buffer, and both rows iy = c+b and c-b are written from it with aligned 16-byte stores.
+// NAIT = ceil(q_na / 64) register slots per lane.
+template <bool VEC2, int NAIT>
+__global__ void __launch_bounds__(1024)
+jx_abel_map_sym_kernel(JxDev c, const double* __restrict__ pvec, double* __restrict__ img,
+                       double* __restrict__ tap_pp, double* __restrict__ tap_ab, double* __restrict__ tap_y) {
+    extern __shared__ double sm[];
+    const int N = c.N;
+    double* s_r = sm;
+    double* s_pp = s_r + N;
+    double* s_y = s_pp + N;
+    double* s_M = s_y + N;
+    double* s_cf = s_M + N;                         // [4(N+1)]
+    double* s_row = sm + JX_MAP_LDS_DOUBLES(N);     // [nwaves][row_pad]
+    __shared__ double p[JX_MAX_PAR];
+
+    const int tid = threadIdx.x, nth = blockDim.x;
+    const int w = blockIdx.x / c.map_split;
+    const int part = blockIdx.x - w * c.map_split;
+
+    if (tid < JX_MAX_PAR) p[tid] = pvec[(size_t)w * JX_MAX_PAR + tid];
+    __syncthreads();
+    if (!(c.dbg & 1)) jx_profile_to_coefs(c, p, w, part == 0, s_r, s_pp, s_y, s_M, s_cf, tap_pp, tap_ab, tap_y);
+    else { for (int k = tid; k < 4 * (N + 1); k += nth) s_cf[k] = 0.0; __syncthreads(); }
+    if (c.dbg & 2) return;
+
+    const int S = c.S, P = c.P, na = c.q_na, nb = c.q_nb, cc = c.S / 2;
+    const int lane = tid & 63, wv = tid >> 6, nwv = nth >> 6;
+    const int row_pad = (S + 3) & ~1;
+    double* rowfull = s_row + (size_t)wv * row_pad;
+    double* out = img + (size_t)w * c.img_ws;
+    const int b_per = (nb + c.map_split - 1) / c.map_split;
+    const int b0 = part * b_per, b1 = min(nb, b0 + b_per);
+
+    int kq[NAIT];
+    double tq[NAIT];
+    int b = b0 + wv;
+    if (c.dbg & 4) {                                 // ablation: the store stream alone
+        for (int ix = lane; ix < row_pad; ix += 64) rowfull[ix] = 1.0;
+        __builtin_amdgcn_wave_barrier();
+        for (; b < b1; b += nwv) {
+            const int iy1 = cc + b, iy2 = cc - b;
+            const bool do1 = iy1 < S, do2 = (b > 0) && (iy2 >= 0);
+            double* orow1 = out + (size_t)iy1 * c.img_ld;
+            double* orow2 = out + (size_t)iy2 * c.img_ld;
+            for (int ix = 2 * lane; ix + 1 < S; ix += 128) {
+                const double2 v = *reinterpret_cast<const double2*>(rowfull + ix);
+                if (do1) *reinterpret_cast<double2*>(orow1 + ix) = v;
+                if (do2) *reinterpret_cast<double2*>(orow2 + ix) = v;
+            }
+        }
+        return;
+    }
+    if (b < b1) {
+#pragma unroll
+        for (int u = 0; u < NAIT; ++u) {
+            const int a = lane + 64 * u;
+            const bool ok = a < na;
+            kq[u] = ok ? c.q_k[(size_t)b * na + a] : N;
+            tq[u] = ok ? c.q_t[(size_t)b * na + a] : 0.0;
+        }
+    }
+    for (; b < b1; b += nwv) {
+        // evaluate the half row and mirror it into the full row
+#pragma unroll
+        for (int u = 0; u < NAIT; ++u) {
+            const int a = lane + 64 * u;
+            const double t = tq[u];
+            const double* cf = s_cf + 4 * kq[u];
+            const double v = fma(t, fma(t, fma(t, cf[3], cf[2]), cf[1]), cf[0]);
+            if (a < na) {
+                if (cc + a < S) rowfull[cc + a] = v;
+                if (cc - a >= 0) rowfull[cc - a] = v;
+            }
+        }
+        // prefetch the next half row's table entries (older than the stores below)
+        const int bn = b + nwv;
+        if (bn < b1) {
+#pragma unroll
+            for (int u = 0; u < NAIT; ++u) {
+                const int a = lane + 64 * u;
+                const bool ok = a < na;
+                kq[u] = ok ? c.q_k[(size_t)bn * na + a] : N;
+                tq[u] = ok ? c.q_t[(size_t)bn * na + a] : 0.0;
+            }
+        }
+        // rowfull is private to this wave; LDS operations of one wave complete in order
+        __builtin_amdgcn_wave_barrier();
+        const int iy1 = cc + b, iy2 = cc - b;
+        const bool do1 = iy1 < S, do2 = (b > 0) && (iy2 >= 0);
+        double* orow1 = out + (size_t)iy1 * c.img_ld;
+        double* orow2 = out + (size_t)iy2 * c.img_ld;
+        if (VEC2) {
+            for (int ix = 2 * lane; ix < S; ix += 128) {
+                const double2 v = *reinterpret_cast<const double2*>(rowfull + ix);
+                if (do1) *reinterpret_cast<double2*>(orow1 + ix) = v;
+                if (do2) *reinterpret_cast<double2*>(orow2 + ix) = v;
+            }
+        } else {
+            for (int ix = lane; ix < S; ix += 64) {
+                const double v = rowfull[ix];
+                if (do1) orow1[ix] = v;
+                if (do2) orow2[ix] = v;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -421,7 +605,8 @@ jx_beam_mul_kernel(double2* __restrict__ spec, const double2* __restrict__ bhat,
 //   chisq = nansum(((flux - model)/err)^2); logp = base - chisq/2   (joxsz_funcs.py:478-479, 538)
 // ------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(JX_TAIL_THREADS)
-jx_tail_kernel(JxDev c, const double2* __restrict__ tfspec, const double* __restrict__ cfac,
+jx_tail_kernel(JxDev c, const double2* __restrict__ tfspec, const double2* __restrict__ zpart, int nblk,
+               const double* __restrict__ cfac,
                const double* __restrict__ base, double* __restrict__ logp, int w0,
                double* __restrict__ tap_row, double* __restrict__ tap_bright, double* __restrict__ tap_chisq,
                double* __restrict__ tap_parts) {
@@ -435,21 +620,32 @@ jx_tail_kernel(JxDev c, const double2* __restrict__ tfspec, const double* __rest
     const double2* X = tfspec + (size_t)w * S * Sh;
     const double2* H = reinterpret_cast<const double2*>(c.htab);
 
-    for (int kc = tid; kc < Sh; kc += nth) {
-        double zr0 = 0.0, zi0 = 0.0, zr1 = 0.0, zi1 = 0.0;
-        int kr = 0;
-        for (; kr + 1 < S; kr += 2) {
-            const double2 x0 = X[(size_t)kr * Sh + kc], h0 = H[(size_t)kr * Sh + kc];
-            const double2 x1 = X[(size_t)(kr + 1) * Sh + kc], h1 = H[(size_t)(kr + 1) * Sh + kc];
-            zr0 += x0.x * h0.x - x0.y * h0.y;  zi0 += x0.x * h0.y + x0.y * h0.x;
-            zr1 += x1.x * h1.x - x1.y * h1.y;  zi1 += x1.x * h1.y + x1.y * h1.x;
+    if (zpart) {
+        // hand-written convolution: Z arrives as per-block partial sums [nblk][Sh], added in a fixed order
+        const double2* Zp = zpart + (size_t)w * nblk * Sh;
+        for (int kc = tid; kc < Sh; kc += nth) {
+            double zr = 0.0, zi = 0.0;
+            for (int b = 0; b < nblk; ++b) { const double2 v = Zp[(size_t)b * Sh + kc]; zr += v.x; zi += v.y; }
+            s_zr[kc] = zr;
+            s_zi[kc] = zi;
         }
-        for (; kr < S; ++kr) {
-            const double2 x0 = X[(size_t)kr * Sh + kc], h0 = H[(size_t)kr * Sh + kc];
-            zr0 += x0.x * h0.x - x0.y * h0.y;  zi0 += x0.x * h0.y + x0.y * h0.x;
+    } else {
+        for (int kc = tid; kc < Sh; kc += nth) {
+            double zr0 = 0.0, zi0 = 0.0, zr1 = 0.0, zi1 = 0.0;
+            int kr = 0;
+            for (; kr + 1 < S; kr += 2) {
+                const double2 x0 = X[(size_t)kr * Sh + kc], h0 = H[(size_t)kr * Sh + kc];
+                const double2 x1 = X[(size_t)(kr + 1) * Sh + kc], h1 = H[(size_t)(kr + 1) * Sh + kc];
+                zr0 += x0.x * h0.x - x0.y * h0.y;  zi0 += x0.x * h0.y + x0.y * h0.x;
+                zr1 += x1.x * h1.x - x1.y * h1.y;  zi1 += x1.x * h1.y + x1.y * h1.x;
+            }
+            for (; kr < S; ++kr) {
+                const double2 x0 = X[(size_t)kr * Sh + kc], h0 = H[(size_t)kr * Sh + kc];
+                zr0 += x0.x * h0.x - x0.y * h0.y;  zi0 += x0.x * h0.y + x0.y * h0.x;
+            }
+            s_zr[kc] = zr0 + zr1;
+            s_zi[kc] = zi0 + zi1;
         }
-        s_zr[kc] = zr0 + zr1;
-        s_zi[kc] = zi0 + zi1;
     }
     __syncthreads();
 

@@ -294,6 +294,117 @@ inline void tf_row_table(const std::vector<double>& filt, int S, std::vector<dou
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Small host FFT (recursive Cooley-Tukey on the smallest prime factor, naive DFT for
+// primes); sign = -1 forward, +1 inverse, unnormalised.  Used only to build tables.
+// ---------------------------------------------------------------------------------------
+inline void host_fft(std::vector<double>& re, std::vector<double>& im, int sign) {
+    const int n = (int)re.size();
+    if (n <= 1) return;
+    int p = 0;
+    for (int f = 2; f * f <= n; ++f) if (n % f == 0) { p = f; break; }
+    if (p == 0) {                                            // prime length: direct
+        std::vector<double> orr(n), oi(n);
+        for (int k = 0; k < n; ++k) {
+            double ar = 0, ai = 0;
+            for (int j = 0; j < n; ++j) {
+                const long long ph = ((long long)j * k) % n;
+                const double c = std::cos(2.0 * kPi * ph / n), s2 = sign * std::sin(2.0 * kPi * ph / n);
+                ar += re[j] * c - im[j] * s2; ai += re[j] * s2 + im[j] * c;
+            }
+            orr[k] = ar; oi[k] = ai;
+        }
+        re.swap(orr); im.swap(oi);
+        return;
+    }
+    const int m = n / p;
+    std::vector<std::vector<double>> sr(p, std::vector<double>(m)), si(p, std::vector<double>(m));
+    for (int q = 0; q < p; ++q)
+        for (int j = 0; j < m; ++j) { sr[q][j] = re[j * p + q]; si[q][j] = im[j * p + q]; }
+    for (int q = 0; q < p; ++q) host_fft(sr[q], si[q], sign);
+    for (int k = 0; k < n; ++k) {
+        double ar = 0, ai = 0;
+        for (int q = 0; q < p; ++q) {
+            const long long ph = ((long long)q * k) % n;
+            const double c = std::cos(2.0 * kPi * ph / n), s2 = sign * std::sin(2.0 * kPi * ph / n);
+            const double xr = sr[q][k % m], xi = si[q][k % m];
+            ar += xr * c - xi * s2; ai += xr * s2 + xi * c;
+        }
+        re[k] = ar; im[k] = ai;
+    }
+}
+
+// exp(-2 pi i n / L), n = 0..count-1, interleaved re, im
+inline void twiddles(int L, int count, std::vector<double>& out) {
+    out.resize((size_t)count * 2);
+    for (int n = 0; n < count; ++n) { out[2 * n] = std::cos(2.0 * kPi * n / L); out[2 * n + 1] = -std::sin(2.0 * kPi * n / L); }
+}
+
+// Is the beam image symmetric under both flips (then its row transforms are real and
+// symmetric in the row index)?
+inline bool beam_is_symmetric(const std::vector<double>& beam, int B) {
+    double mx = 0;
+    for (double v : beam) mx = std::max(mx, std::fabs(v));
+    const double tol = 1e-14 * mx;
+    for (int u = 0; u < B; ++u)
+        for (int v = 0; v < B; ++v) {
+            const double a = beam[(size_t)u * B + v];
+            if (!(std::fabs(a - beam[(size_t)(B - 1 - u) * B + v]) <= tol)) return false;
+            if (!(std::fabs(a - beam[(size_t)u * B + (B - 1 - v)]) <= tol)) return false;
+        }
+    return true;
+}
+
+// Real FIR taps of the mixed-domain beam convolution: taps[t][kx], t = |row offset| = 0..o,
+//   taps[t][kx] = scale * sum_v beam[o - t][v] cos(2 pi kx (v - o) / P)
+inline void beam_fir_taps(const std::vector<double>& beam, int B, int P, double scale, std::vector<double>& taps) {
+    const int o = (B - 1) / 2, Ph = P / 2 + 1;
+    taps.assign((size_t)(o + 1) * Ph, 0.0);
+    for (int t = 0; t <= o; ++t)
+        for (int kx = 0; kx < Ph; ++kx) {
+            double a = 0.0;
+            for (int v = 0; v < B; ++v) {
+                long long ph = ((long long)kx * (v - o)) % P; if (ph < 0) ph += P;
+                a += beam[(size_t)(o - t) * B + v] * std::cos(2.0 * kPi * ph / P);
+            }
+            taps[(size_t)t * Ph + kx] = a * scale;
+        }
+}
+
+// Hy[r][kc] = w_kc / S^2 * sum_kr Fs[kr][kc] e^{2 pi i kr (c - r)/S}: the symmetrised transfer
+// function taken back to real space along y, at the row offset of the extracted row c = S//2.
+inline void tf_hy_table(const std::vector<double>& filt, int S, std::vector<double>& Hy) {
+    const int Sh = S / 2 + 1, c = S / 2;
+    Hy.assign((size_t)S * Sh * 2, 0.0);
+    const double inv = 1.0 / ((double)S * (double)S);
+    std::vector<double> re(S), im(S);
+    for (int kc = 0; kc < Sh; ++kc) {
+        const int mc = (S - kc) % S;
+        for (int kr = 0; kr < S; ++kr) {
+            const int mr = (S - kr) % S;
+            re[kr] = 0.5 * (filt[(size_t)kr * S + kc] + filt[(size_t)mr * S + mc]);
+            im[kr] = 0.0;
+        }
+        host_fft(re, im, +1);                                 // g[n] = sum_kr Fs e^{+2 pi i kr n/S}
+        const double w = (kc == 0 || (S % 2 == 0 && kc == S / 2)) ? 1.0 : 2.0;
+        for (int r = 0; r < S; ++r) {
+            const int n = ((c - r) % S + S) % S;
+            Hy[((size_t)r * Sh + kc) * 2] = re[n] * w * inv;
+            Hy[((size_t)r * Sh + kc) * 2 + 1] = im[n] * w * inv;
+        }
+    }
+}
+
+// supported (LS = S/2, LP = P/2) pairs of the hand-written convolution
+inline int custom_conv_lp(int S, int o) {
+    static const int pairs[][2] = {{16, 18}, {24, 48}, {32, 48}, {64, 96}, {128, 144}, {256, 288}, {512, 576}};
+    if (S % 2) return 0;
+    for (auto& pr : pairs)
+        if (pr[0] == S / 2 && 2 * pr[1] >= S + o) return pr[1];
+    return 0;
+}
+
 // smallest even 2^a 3^b 5^c >= n
 inline int next_smooth_even(int n) {
     for (int m = std::max(2, n + (n & 1));; m += 2) {

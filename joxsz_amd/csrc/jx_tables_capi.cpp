@@ -41,6 +41,31 @@ int jxt_tf_row_table(const double* filt, int S, double* out /*[S*(S/2+1)*2]*/) {
     return 0;
 }
 
+int jxt_beam_fir_taps(const double* beam, int B, int P, double scale, double* out /*[(o+1)*(P/2+1)]*/) {
+    std::vector<double> bv(beam, beam + (size_t)B * B), t;
+    if (!jxt::beam_is_symmetric(bv, B)) return -1;
+    jxt::beam_fir_taps(bv, B, P, scale, t);
+    memcpy(out, t.data(), sizeof(double) * t.size());
+    return 0;
+}
+
+int jxt_tf_hy_table(const double* filt, int S, double* out /*[S*(S/2+1)*2]*/) {
+    std::vector<double> fv(filt, filt + (size_t)S * S), H;
+    jxt::tf_hy_table(fv, S, H);
+    memcpy(out, H.data(), sizeof(double) * H.size());
+    return 0;
+}
+
+int jxt_host_fft(double* re, double* im, int n, int sign) {
+    std::vector<double> r(re, re + n), i(im, im + n);
+    jxt::host_fft(r, i, sign);
+    memcpy(re, r.data(), sizeof(double) * n);
+    memcpy(im, i.data(), sizeof(double) * n);
+    return 0;
+}
+
+int jxt_custom_conv_lp(int S, int o) { return jxt::custom_conv_lp(S, o); }
+
 int jxt_next_smooth_even(int n) { return jxt::next_smooth_even(n); }
 
 }  // extern "C"

@@ -16,7 +16,7 @@ ABI_VERSION = 1
 EXPORTS = (
     'jx_create', 'jx_upload', 'jx_finalize', 'jx_eval', 'jx_eval_device', 'jx_sync', 'jx_eval_stage',
     'jx_set_par_vals', 'jx_dev_alloc', 'jx_dev_free', 'jx_memcpy_h2d', 'jx_memcpy_d2h',
-    'jx_timing_reset', 'jx_timing_enable', 'jx_timing_get', 'jx_get_info', 'jx_device_count',
+    'jx_timing_reset', 'jx_timing_enable', 'jx_timing_get', 'jx_get_info', 'jx_get_conv_mode', 'jx_device_count',
     'jx_device_name', 'jx_strerror', 'jx_last_error', 'jx_destroy',
 )
 
@@ -37,7 +37,8 @@ class JoxszHipError(RuntimeError):
 class JxConfig(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
         'abi_version', 'S', 'N', 'B', 'nflux', 'nconv', 'nann', 'nband', 'ntab', 'npar', 'ndim',
-        'ne_mode', 'exclude_unphy_mass', 'sz_only', 'device', 'max_batch', 'fft_pad', 'map_split')] + \
+        'ne_mode', 'exclude_unphy_mass', 'sz_only', 'device', 'max_batch', 'fft_pad', 'map_split',
+        'conv_mode', 'reserved0')] + \
         [(n, ctypes.c_double) for n in ('step', 'kpc_as', 'm_e', 'sigma_T', 'kpc_cm')]
 
 
@@ -79,6 +80,7 @@ def load_library(path=None):
     lib.jx_timing_get.argtypes = [vp, ctypes.POINTER(JxTiming)]
     i32p, i64p = ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int64)
     lib.jx_get_info.argtypes = [vp, i32p, i32p, i32p, i32p, i64p]
+    lib.jx_get_conv_mode.argtypes = [vp]
     lib.jx_device_count.argtypes = []
     lib.jx_device_name.argtypes = [vp]
     lib.jx_device_name.restype = ctypes.c_char_p
@@ -96,7 +98,10 @@ def load_library(path=None):
     return lib
 
 
-def config_from_problem(pb, device=0, max_batch=0, fft_pad=0, map_split=0):
+CONV_MODES = {'auto': 0, 'rocfft': 1, 'custom': 2}
+
+
+def config_from_problem(pb, device=0, max_batch=0, fft_pad=0, map_split=0, conv='auto'):
     cfg = JxConfig()
     cfg.abi_version = ABI_VERSION
     cfg.S, cfg.N, cfg.B = pb.S, pb.N, pb.B
@@ -110,6 +115,7 @@ def config_from_problem(pb, device=0, max_batch=0, fft_pad=0, map_split=0):
     cfg.exclude_unphy_mass = int(bool(pb.exclude_unphy_mass))
     cfg.sz_only = int(bool(pb.sz_only))
     cfg.device, cfg.max_batch, cfg.fft_pad, cfg.map_split = device, max_batch, fft_pad, map_split
+    cfg.conv_mode = CONV_MODES[conv]
     cfg.step, cfg.kpc_as = float(pb.step), float(pb.kpc_as)
     cfg.m_e, cfg.sigma_T, cfg.kpc_cm = float(pb.m_e), float(pb.sigma_T), float(pb.kpc_cm)
     return cfg
@@ -118,13 +124,13 @@ def config_from_problem(pb, device=0, max_batch=0, fft_pad=0, map_split=0):
 class HipContext:
     """Thin owner of one ``jx_ctx``: uploads a ``Problem`` and evaluates batches."""
 
-    def __init__(self, pb, device=0, max_batch=0, fft_pad=0, map_split=0, lib_path=None):
+    def __init__(self, pb, device=0, max_batch=0, fft_pad=0, map_split=0, conv='auto', lib_path=None):
         self._h = ctypes.c_void_p()
         self.lib = load_library(lib_path)
         pb.validate()
         self.pb = pb
         self.ndim = pb.ndim
-        cfg = config_from_problem(pb, device, max_batch, fft_pad, map_split)
+        cfg = config_from_problem(pb, device, max_batch, fft_pad, map_split, conv)
         rc = self.lib.jx_create(ctypes.byref(cfg), ctypes.byref(self._h))
         if rc != 0:
             self._h = ctypes.c_void_p()
@@ -146,6 +152,7 @@ class HipContext:
         self._chk(self.lib.jx_get_info(self._h, f, c, b, n, nb), 'jx_get_info')
         self.fft_pad, self.chunk, self.spline_band, self.nrow, self.device_bytes = f.value, c.value, b.value, n.value, nb.value
         self.device_name = self.lib.jx_device_name(self._h).decode()
+        self.conv = {1: 'rocfft', 2: 'custom'}.get(self.lib.jx_get_conv_mode(self._h), '?')
 
     # -- plumbing --
     def _chk(self, rc, what):

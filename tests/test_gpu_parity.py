@@ -73,9 +73,11 @@ def test_stage_by_stage_vs_oracle(golden_tiny):
         assert _relerr(got['xprofs'][k], orc.calc_profiles(pb, p)) < 1e-12
 
 
-@pytest.mark.parametrize('S,N', [(31, 40), (32, 40), (64, 80), (171, 313), (256, 300)])
-def test_random_walkers_vs_oracle(S, N):
-    """Odd (reference-shaped) and even (BASELINE-shaped) map sides, seeded walkers."""
+@pytest.mark.parametrize('S,N,conv', [(31, 40, 'rocfft'), (32, 40, 'rocfft'), (64, 80, 'rocfft'), (64, 80, 'custom'),
+                                      (48, 60, 'custom'), (171, 313, 'auto'), (256, 300, 'rocfft'), (256, 300, 'custom')])
+def test_random_walkers_vs_oracle(S, N, conv):
+    """Odd (reference-shaped) and even (BASELINE-shaped) map sides, seeded walkers, both
+    convolution back ends (rocFFT sequence / hand-written mixed-domain passes)."""
     from joxsz_amd import datasets
     pb = datasets.synthetic_problem(S=S, N=N, seed=S)
     p0 = orc.pars_dict(pb, datasets.fiducial_theta(pb))
@@ -83,7 +85,8 @@ def test_random_walkers_vs_oracle(S, N):
     W = 24 if S <= 64 else 6
     th = datasets.walker_ball(pb, W, spread=0.05, seed=S)
     th[1, 1] = 9.0                                    # one rejected walker in the batch
-    post = _post(pb)
+    post = _post(pb, conv=conv)
+    assert post.ctx.conv == ('rocfft' if conv == 'auto' else conv)      # odd S: only rocFFT is eligible
     got = post.log_prob(th)
     post.close()
     want = orc.log_posterior_batch(pb, th)
@@ -147,10 +150,14 @@ def test_linearity_full_size():
     th = np.array([t0, t0, t0])
     th[1, 7] *= 2.0                                   # P_0 doubled: same T shape only if n_e fixed -> use map_row
     th[2, 7] *= 3.0
-    post = _post(pb)
+    post = _post(pb, conv='rocfft', max_batch=8)
+    rows_fft = post.stage(th, 'map_row')
+    post.close()
+    post = _post(pb, conv='custom', max_batch=8)
     rows = post.stage(th, 'map_row')
     y2d = post.stage(th[:2], 'y_2d')
     post.close()
+    np.testing.assert_allclose(rows, rows_fft, rtol=1e-9, atol=1e-12 * np.abs(rows_fft).max())
     np.testing.assert_allclose(rows[1], 2.0 * rows[0], rtol=1e-10, atol=1e-18)
     np.testing.assert_allclose(rows[2], 3.0 * rows[0], rtol=1e-10, atol=1e-18)
     np.testing.assert_allclose(y2d[1], 2.0 * y2d[0], rtol=1e-12)
@@ -160,3 +167,32 @@ def test_linearity_full_size():
     np.testing.assert_allclose(m[c + 5, c + 9], m[c - 5, c - 9], rtol=1e-14)
     np.testing.assert_allclose(m[c + 5, c + 9], m[c + 9, c + 5], rtol=1e-14)
     assert m[c, c] == m.max()
+
+
+@pytest.mark.parametrize('S,N,step,fwhm', [(32, 40, 6., 8.5), (64, 80, 2., 18.5)])
+def test_custom_conv_stages(S, N, step, fwhm):
+    """Hand-written convolution passes: beam-convolved map and extracted row against the
+    oracle, and against the rocFFT back end on the same context inputs."""
+    from joxsz_amd import datasets
+    pb = datasets.synthetic_problem(S=S, N=N, seed=3, step=step, fwhm=fwhm)
+    th = datasets.walker_ball(pb, 5, spread=0.04, seed=3)
+    out = {}
+    for conv in ('custom', 'rocfft'):
+        post = _post(pb, conv=conv)
+        assert post.ctx.conv == conv
+        out[conv] = {s: post.stage(th, s) for s in ('y_2d', 'conv_2d', 'map_row', 'bright', 'chisq')}
+        out[conv]['logp'] = post.log_prob(th)
+        post.close()
+    for k, t in enumerate(th):
+        st = orc.sz_stages(pb, orc.pars_dict(pb, t))
+        for name in ('y_2d', 'conv_2d', 'map_row', 'bright'):
+            assert _relerr(out['custom'][name][k], st[name]) < RTOL_STAGE, name
+    for name in ('conv_2d', 'map_row', 'chisq', 'logp'):
+        np.testing.assert_allclose(out['custom'][name], out['rocfft'][name], rtol=1e-9, atol=1e-30)
+
+
+def test_custom_conv_refuses_what_it_cannot_do(golden_tiny):
+    from joxsz_amd.hip_backend import JoxszHipError
+    pb, _ = golden_tiny                                # S = 31: odd side
+    with pytest.raises(JoxszHipError):
+        _post(pb, conv='custom')

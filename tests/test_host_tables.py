@@ -133,3 +133,47 @@ def test_next_smooth_even(lib):
     assert lib.jxt_next_smooth_even(539) == 540
     assert lib.jxt_next_smooth_even(198) == 200
     assert lib.jxt_next_smooth_even(1051) == 1080
+
+
+def test_host_fft(lib):
+    rng = np.random.default_rng(1)
+    for n in (1, 2, 19, 171, 512, 540):
+        x = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+        for sign, want in ((-1, np.fft.fft(x)), (+1, np.fft.ifft(x) * n)):
+            re, im = np.ascontiguousarray(x.real), np.ascontiguousarray(x.imag)
+            lib.jxt_host_fft(_p(re), _p(im), n, sign)
+            np.testing.assert_allclose(re + 1j * im, want, rtol=0, atol=1e-11 * max(1, np.abs(want).max()))
+
+
+@pytest.mark.parametrize('S,B,P', [(32, 9, 36), (64, 55, 96), (48, 11, 96)])
+def test_mixed_domain_tables(lib, S, B, P):
+    """Pass structure of jx_conv.hpp in numpy, fed with the C-built tables, against scipy."""
+    from oracle.joxsz_oracle import centdistmat
+    rng = np.random.default_rng(S)
+    o, Ph, Sh, c = (B - 1) // 2, P // 2 + 1, S // 2 + 1, S // 2
+    ax = np.arange(B) - o
+    beam = np.exp(-centdistmat(ax) ** 2 / (2 * (B / 5.) ** 2)) * (1 + 0.1 * np.cos(centdistmat(ax)))
+    y2d = rng.standard_normal((S, S))
+    axf = np.linspace(-S // 2 + 1, S // 2, S)
+    filt = np.roll(1 - np.exp(-np.sqrt(axf ** 2 + axf[:, None] ** 2) / 4.), S // 2 + 1, axis=(0, 1))
+    taps = np.zeros((o + 1, Ph))
+    assert lib.jxt_beam_fir_taps(_p(np.ascontiguousarray(beam)), B, P, ctypes.c_double(4.0 / P), _p(taps)) == 0
+    Hy = np.zeros((S, Sh, 2))
+    lib.jxt_tf_hy_table(_p(np.ascontiguousarray(filt)), S, _p(Hy))
+    Hy = Hy[..., 0] + 1j * Hy[..., 1]
+    Y = np.fft.rfft(np.pad(y2d, ((0, 0), (0, P - S))), axis=1)
+    C = np.zeros((S, Ph), complex)
+    for r in range(S):
+        for m in range(max(0, r - o), min(S, r + o + 1)):
+            C[r] += taps[abs(r - m)] * Y[m]
+    conv = (np.fft.irfft(C, P, axis=1) * P)[:, :S]
+    want = fftconvolve(y2d, beam, 'same') * 4.0
+    np.testing.assert_allclose(conv, want, rtol=0, atol=1e-12 * np.abs(want).max())
+    Z = (np.fft.rfft(conv, axis=1) * Hy).sum(0)
+    row = np.array([np.real(Z * np.exp(2j * np.pi * np.arange(Sh) * x / S)).sum() for x in range(c, S)])
+    want_row = np.real(ifft2(fft2(want) * filt))[c, c:]
+    np.testing.assert_allclose(row, want_row, rtol=0, atol=1e-12 * np.abs(want_row).max())
+    # an asymmetric beam is refused (the rocFFT path handles it)
+    bad = beam.copy(); bad[0, 1] *= 1.5
+    assert lib.jxt_beam_fir_taps(_p(bad), B, P, ctypes.c_double(1.0), _p(taps)) == -1
+    assert lib.jxt_custom_conv_lp(512, 27) == 288 and lib.jxt_custom_conv_lp(171, 27) == 0
