@@ -36,13 +36,28 @@ def _cpu_worker(args):
     return orc.log_posterior_batch(pb, th)
 
 
+def host_cores():
+    """Cores this process may actually use: the scheduler affinity mask capped by the
+    cgroup CPU quota (a GPU box exposes all host CPUs but grants a share of them)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    if os.environ.get('JOXSZ_CPU_CORES'):
+        n = int(os.environ['JOXSZ_CPU_CORES'])
+    return max(1, n)
+
+
 def cpu_baseline(pb, thetas, target_s=15.0):
     """The oracle (numpy/scipy restatement of the reference path) mapped over
     walkers with multiprocessing.Pool on all host cores, exactly the reference's
     parallelism (joxsz_main.py:203-206), on a bounded sample of the workload."""
     import multiprocessing as mp
     from oracle import joxsz_oracle as orc
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     t = time.perf_counter()
     orc.log_posterior_batch(pb, thetas[:1])
     one = time.perf_counter() - t
@@ -203,7 +218,7 @@ def main():
                                    'synthetic CL J1226.9+3332-shaped inputs (BASELINE configs[2])'
                                    % (W, S, S, args.N, 'SZ-only' if pb.sz_only else 'joint X-ray+SZ'),
                        'walkers_per_gpu': W, 'S': S, 'N': args.N, 'B': pb.B, 'fft_pad': ctx.fft_pad,
-                       'chunk': ctx.chunk, 'parallelism': 'walkers sharded x%d' % world, 'device': ctx.device_name},
+                       'chunk': ctx.chunk, 'conv': ctx.conv, 'parallelism': 'walkers sharded x%d' % world, 'device': ctx.device_name},
             'roofline': {'kernel': 'jx_abel_map_kernel', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
                          'launch_ms': k_ms, 'bytes_per_launch': alg_bytes},
