@@ -1,0 +1,94 @@
+"""Cross-checks of the parts of the oracle that the reference cannot pin (PyAbel and
+mbproj2 are absent): analytic known answers and structural identities."""
+import math
+
+import numpy as np
+from scipy.special import gamma
+
+from oracle import pyabel_direct, mbproj2_parts as mbp, joxsz_oracle as orc
+
+
+def test_abel_gaussian_known_answer():
+    # A[exp(-r^2/s^2)](y) = s sqrt(pi) exp(-y^2/s^2); the discretisation (trapezoid + linear
+    # end cell, truncated at r_N) agrees to its own error, not to rounding
+    r = 2.0 * np.arange(1, 1200)
+    s = 180.0
+    got = pyabel_direct.direct_transform_forward(np.exp(-(r / s) ** 2), r)
+    want = s * math.sqrt(math.pi) * np.exp(-(r / s) ** 2)
+    # the trapezoid next to the inverse-square-root singularity converges like sqrt(h): ~2e-3 at h=2
+    assert np.max(np.abs(got - want)) / want.max() < 3e-3
+    r2 = 0.5 * np.arange(1, 4800)
+    got2 = pyabel_direct.direct_transform_forward(np.exp(-(r2 / s) ** 2), r2)
+    want2 = s * math.sqrt(math.pi) * np.exp(-(r2 / s) ** 2)
+    assert np.max(np.abs(got2 - want2)) / want2.max() < 0.55 * np.max(np.abs(got - want)) / want.max()
+
+
+def test_abel_beta_model_known_answer():
+    # gNFW with a=2, c=0: P0 (1+x^2)^(-b/2) -> sqrt(pi) Gamma((b-1)/2)/Gamma(b/2) r_p P0 (1+y^2/r_p^2)^((1-b)/2)
+    r = 4.0 * np.arange(1, 3000)
+    rp, b, P0 = 300., 5.0, 0.3
+    p = {'P_0': P0, 'r_p': rp, 'a': 2., 'b': b, 'c': 0.}
+    got = pyabel_direct.direct_transform_forward(orc.press_fun(p, r), r)
+    want = math.sqrt(math.pi) * gamma((b - 1) / 2) / gamma(b / 2) * rp * P0 * (1 + (r / rp) ** 2) ** ((1 - b) / 2)
+    sel = r < 2000.
+    assert np.max(np.abs(got[sel] - want[sel])) / want.max() < 5e-3
+
+
+def test_abel_is_linear_and_last_point_zero():
+    r = 16.0024 * np.arange(1, 80)
+    rng = np.random.default_rng(0)
+    f, g = rng.random(r.size), rng.random(r.size)
+    T = pyabel_direct.direct_transform_forward
+    np.testing.assert_allclose(T(2 * f + 3 * g, r), 2 * T(f, r) + 3 * T(g, r), rtol=1e-13)
+    assert T(f, r)[-1] == 0.0
+    A = pyabel_direct.abel_weight_matrix(r)
+    np.testing.assert_allclose(A @ f, T(f, r), rtol=1e-13)
+
+
+def test_uniform_vs_nonuniform_trapezoid_branches_agree():
+    # the arange grid of joxsz_main.py:104 fails PyAbel's 1e-13 uniformity test (ulp noise at
+    # r ~ 5000); both branches must give the same numbers to rounding
+    r_exact = 16.0 * np.arange(1, 314)                   # exactly uniform
+    r_noisy = np.arange(2 * 8.0012, 5000. + 2 * 8.0012, 2 * 8.0012)
+    assert pyabel_direct.is_uniform_sampling(r_exact)
+    f = 1. / (1. + (r_noisy / 300.) ** 2) ** 2
+    a = pyabel_direct.direct_transform_forward(f, r_noisy)
+    rr = r_noisy.copy()
+    b = pyabel_direct._trapz(np.ones((1, rr.size)), rr, False)
+    assert abs(b[0] - (rr[-1] - rr[0])) < 1e-9
+    assert np.all(np.isfinite(a)) and a[0] > a[10] > a[100] > 0
+
+
+def test_sz_path_is_linear_in_pressure(golden_tiny):
+    """Everything after pp is linear: bright(P_0 = 2x) = 2 bright when the T profile is held."""
+    pb, ref = golden_tiny
+    p = orc.pars_dict(pb, ref['thetas'][0])
+    st1 = orc.sz_stages(pb, p)
+    p2 = dict(p); p2['P_0'] *= 2
+    st2 = orc.sz_stages(pb, p2)
+    np.testing.assert_allclose(st2['map_row'], 2 * st1['map_row'], rtol=1e-11, atol=1e-20)
+    np.testing.assert_allclose(st2['y_2d'], 2 * st1['y_2d'], rtol=1e-13)
+
+
+def test_priors_and_cash():
+    assert mbp.param_prior(0.5, 0., 1.) == 0.0
+    assert mbp.param_prior(1.0, 0., 1.) == 0.0            # bounds are inclusive
+    assert mbp.param_prior(1.0000001, 0., 1.) == -np.inf
+    g = mbp.param_gaussian_prior(1.07, 1.0, 0.07)
+    assert abs(g - (-0.5 * math.log(2 * math.pi) - math.log(0.07) - 0.5)) < 1e-14
+    assert mbp.param_gaussian_prior(1.0, 1.0, 0.0) == -np.inf
+    d, m = np.array([3., 0., 7.]), np.array([2.5, 0.4, 6.0])
+    want = 3 * math.log(2.5) - 2.5 + 0 - 0.4 + 7 * math.log(6.0) - 6.0
+    assert abs(mbp.cash_log_likelihood(d, m) - want) < 1e-13
+    assert mbp.cash_log_likelihood(np.array([1.0]), np.array([0.0])) == -np.inf
+
+
+def test_count_rate_interpolation_clamps():
+    lnT = np.linspace(math.log(0.06), math.log(60.), 100)
+    z0 = -150. + 0.5 * lnT
+    z1 = z0 + 0.3
+    lo = mbp.count_rate(lnT, z0, z1, np.array([0.01]), 0.5, np.array([1e-2]))
+    edge = mbp.count_rate(lnT, z0, z1, np.array([0.06]), 0.5, np.array([1e-2]))
+    np.testing.assert_allclose(lo, edge, rtol=1e-14)
+    mid = mbp.count_rate(lnT, z0, z1, np.array([3.0]), 0.0, np.array([2e-3]))
+    np.testing.assert_allclose(mid, np.exp(-150. + 0.5 * math.log(3.0)) * 4e-6, rtol=1e-12)
