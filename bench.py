@@ -219,7 +219,7 @@ def main():
                                    % (W, S, S, args.N, 'SZ-only' if pb.sz_only else 'joint X-ray+SZ'),
                        'walkers_per_gpu': W, 'S': S, 'N': args.N, 'B': pb.B, 'fft_pad': ctx.fft_pad,
                        'chunk': ctx.chunk, 'conv': ctx.conv, 'parallelism': 'walkers sharded x%d' % world, 'device': ctx.device_name},
-            'roofline': {'kernel': 'jx_abel_map_kernel', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
+            'roofline': {'kernel': 'jx_abel_map_sym_kernel', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
                          'launch_ms': k_ms, 'bytes_per_launch': alg_bytes},
             'cpu_baseline': cpu,

@@ -331,13 +331,14 @@ int jx_finalize(jx_ctx* ctx) {
     d.inv_h_mean = (double)(N - 1) / (r[N - 1] - r[0]);
 
     int rc;
-    // ---- Abel weights, transposed so that a wave reads consecutive rows i of one source column j
+    // ---- Abel weights in on-the-fly form (per-source factor, diagonal, first off-diagonal)
     {
-        std::vector<double> A, AT((size_t)N * N);
-        jxt::abel_matrix(r, A);
-        for (int i = 0; i < N; ++i)
-            for (int j = 0; j < N; ++j) AT[(size_t)j * N + i] = A[(size_t)i * N + j];
-        double* p; if ((rc = dev_put(ctx, AT.data(), AT.size(), &p))) return rc; d.abelT = p;
+        std::vector<double> cj, dg, sp;
+        jxt::abel_onfly_tables(r, cj, dg, sp);
+        std::vector<double> tab((size_t)N * 4);
+        for (int j = 0; j < N; ++j) { tab[4 * j] = r[j]; tab[4 * j + 1] = cj[j]; tab[4 * j + 2] = dg[j]; tab[4 * j + 3] = sp[j]; }
+        double* p;
+        if ((rc = dev_put(ctx, tab.data(), tab.size(), &p))) return rc; d.abel_tab = p;
     }
     // ---- spline moment operator of the mirrored grid, stored as a band
     {
@@ -481,7 +482,7 @@ int jx_finalize(jx_ctx* ctx) {
     int split = c.map_split > 0 ? c.map_split : 1;
     if (const char* e = getenv("JOXSZ_MAP_SPLIT")) { int v = atoi(e); if (v > 0) split = v; }
     ctx->map_split = d.map_split = std::min(split, S);
-    ctx->map_threads = 1024;
+    ctx->map_threads = 512;                     // two 8-wave blocks per CU measured best (profiles/r01_sweeps.md)
     if (const char* e = getenv("JOXSZ_MAP_THREADS")) { int v = atoi(e); if (v >= 64 && v <= 1024 && v % 64 == 0) ctx->map_threads = v; }
 
     {
@@ -498,8 +499,6 @@ int jx_finalize(jx_ctx* ctx) {
 #define JX_ATTR(V, NA) HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_abel_map_sym_kernel<V, NA>, hipFuncAttributeMaxDynamicSharedMemorySize, lds))
         JX_ATTR(true, 3); JX_ATTR(true, 5); JX_ATTR(true, 9); JX_ATTR(false, 3); JX_ATTR(false, 5); JX_ATTR(false, 9);
 #undef JX_ATTR
-        HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_abel_map_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_abel_map_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     }
 
     if ((rc = dev_new(ctx, (size_t)chunk * JX_MAX_PAR, &ctx->d_pvec))) return rc;
@@ -613,7 +612,7 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
         HIPCHK(ctx, hipEventRecord(es.e[0], st));
     }
     {
-        const size_t sh = sizeof(double) * ((size_t)d.N + 2 * d.nann + (size_t)d.nband * d.nann + 8);
+        const size_t sh = sizeof(double) * (JX_LDS_HDR + (size_t)d.N + 2 * d.nann + (size_t)d.nband * d.nann + 8);
         hipLaunchKernelGGL(jx_prep_kernel, dim3(n), dim3(JX_PREP_THREADS), sh, st, d, theta_dev, w0, ctx->d_pvec,
                            ctx->d_base, ctx->d_cfac, t.tprof, t.xprofs, t.parts);
     }
@@ -664,7 +663,7 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
         nblk = cv.nblk3;
     }
     {
-        const size_t sh = sizeof(double) * ((size_t)2 * d.Sh + d.nrow + 8);
+        const size_t sh = sizeof(double) * (JX_LDS_HDR + (size_t)2 * d.Sh + d.nrow + 8);
         hipLaunchKernelGGL(jx_tail_kernel, dim3(n), dim3(JX_TAIL_THREADS), sh, st, d, ctx->d_tfspec, zpart, nblk, ctx->d_cfac,
                            ctx->d_base, logp_dev, w0, t.row, t.bright, t.chisq, t.parts);
     }

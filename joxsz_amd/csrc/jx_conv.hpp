@@ -124,7 +124,7 @@ struct JxConv {
 template <int LP, int ROWS>
 __global__ void __launch_bounds__(256)
 jx_rowfft_kernel(JxConv c, const double* __restrict__ img, size_t img_ld, size_t img_ws, cplx* __restrict__ Y) {
-    extern __shared__ double sm[];
+    extern __shared__ __attribute__((aligned(16))) double sm[];
     cplx* bufA = reinterpret_cast<cplx*>(sm);
     cplx* bufB = bufA + ROWS * LP;
     cplx* tw = bufB + ROWS * LP;
@@ -163,7 +163,7 @@ jx_rowfft_kernel(JxConv c, const double* __restrict__ img, size_t img_ld, size_t
 // ------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(512)
 jx_beamfir_kernel(JxConv c, const cplx* __restrict__ Y, cplx* __restrict__ C) {
-    extern __shared__ double sm[];
+    extern __shared__ __attribute__((aligned(16))) double sm[];
     const int o = c.o, Ph = c.Ph, S = c.S;
     const int nin = JX_FIR_TILE + 2 * o;
     cplx* tile = reinterpret_cast<cplx*>(sm);                 // [nin][64]
@@ -226,7 +226,7 @@ jx_beamfir_kernel(JxConv c, const cplx* __restrict__ Y, cplx* __restrict__ C) {
 template <int LP, int LS, int ROWS>
 __global__ void __launch_bounds__(256)
 jx_rowtf_kernel(JxConv c, const cplx* __restrict__ C, cplx* __restrict__ part, double* __restrict__ tap_conv) {
-    extern __shared__ double sm[];
+    extern __shared__ __attribute__((aligned(16))) double sm[];
     cplx* bufA = reinterpret_cast<cplx*>(sm);
     cplx* bufB = bufA + ROWS * LP;
     cplx* twp = bufB + ROWS * LP;          // [LP]

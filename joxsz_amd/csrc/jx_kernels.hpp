@@ -15,6 +15,11 @@
 #include <stdint.h>
 
 #define JX_MAX_PAR 19
+// All LDS lives in the dynamic region, 16-byte aligned, with 16-byte-multiple carve offsets: a static
+// __shared__ in front of it shifts the base and every ds_read/write_b128 is then replayed at ~64 cycles
+// (cdna_hip_programming.md Guideline 17).  The first JX_LDS_HDR doubles hold the small per-block scalars.
+#define JX_LDS_DECL extern __shared__ __attribute__((aligned(16))) double sm[]
+#define JX_LDS_HDR 32          // [0..18] parameter vector, [20..27] reduction scratch, [28] int flag
 #define JX_PREP_THREADS 256
 #define JX_MAP_THREADS 256
 #define JX_TAIL_THREADS 256
@@ -44,7 +49,8 @@ struct JxDev {
     int fast_map, q_na, q_nb;    // symmetric-map form: table sizes (|ix-c|, |iy-c|)
     const int* q_k;              // [q_nb*q_na] coefficient slot of each quadrant radius
     const double* q_t;           // [q_nb*q_na] local abscissa within that slot
-    const double* abelT;         // [N*N] abelT[j*N+i] = A[i][j] (column of weights per source j)
+    const double* abel_tab;      // [N][4] (r_j, cj_j, dg_j, sp_j):  A[i][j] = cj_j / sqrt(r_j^2 - r_i^2) for j >= i+2,
+                                 //        A[i][i] = dg_i (analytic end cell), A[i][i+1] = sp_i (half cell + end cell)
     const double* gband;         // [(2K+1)*N] gband[(k+K)*N+i] = G[i][i+k]
     const double* bhat;          // [P*Ph*2]
     const double* htab;          // [S*Sh*2]
@@ -150,16 +156,16 @@ __global__ void __launch_bounds__(JX_PREP_THREADS)
 jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0, double* __restrict__ pvec,
                double* __restrict__ base, double* __restrict__ cfac, double* __restrict__ tap_tprof,
                double* __restrict__ tap_xprofs, double* __restrict__ tap_parts) {
-    extern __shared__ double sm[];
-    __shared__ double p[JX_MAX_PAR];
-    __shared__ double red[8];
-    __shared__ int redi;
+    JX_LDS_DECL;
+    double* p = sm;
+    double* red = sm + 20;
+    int& redi = *reinterpret_cast<int*>(sm + 28);
     const int w = blockIdx.x;                 // walker within the chunk
     const int gw = w0 + w;                    // walker within the batch
     const int tid = threadIdx.x, nth = blockDim.x;
 
-    double* s_m = sm;                         // [N] mass profile, then reused
-    double* s_ne = sm + c.N;                  // [nann]
+    double* s_m = sm + JX_LDS_HDR;            // [N] mass profile, then reused
+    double* s_ne = s_m + c.N;                 // [nann]
     double* s_T = s_ne + c.nann;              // [nann]
     double* s_rate = s_T + c.nann;            // [nband*nann]
 
@@ -296,81 +302,109 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0, double* __rest
 // LDS coefficient slots: k = 0..N-2 intervals [r_k, r_{k+1}] in t = x - r_k;
 // k = N-1 the centre interval [-r_0, r_0] in t = x (even polynomial); k = N zero (outside).
 // ------------------------------------------------------------------------------------
+// fast 1/sqrt(x) in fp64: hardware estimate y0 (relative error e ~ 2^-23) refined by one third-order
+// (Halley) step  y = y0 (1 + e/2 + 3 e^2/8),  e = 1 - x y0^2  ->  error O(e^3), i.e. rounding only.
+__device__ __forceinline__ double jx_rsqrt(double x) {
+    const double y0 = __builtin_amdgcn_rsq(x);
+    const double e = fma(-x * y0, y0, 1.0);
+    return fma(y0 * e, fma(e, 0.375, 0.5), y0);
+}
+
+// sum over j = j0, j0+4, ... < N of q_j / sqrt(r_j^2 - ri2): four independent chains in flight
+__device__ __forceinline__ double jx_abel_row(const double2* s_rq, double ri2, int j0, int N) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int j = j0;
+    for (; j + 12 < N; j += 16) {
+        const double2 q0 = s_rq[j], q1 = s_rq[j + 4], q2 = s_rq[j + 8], q3 = s_rq[j + 12];
+        const double t0 = jx_rsqrt(q0.x - ri2), t1 = jx_rsqrt(q1.x - ri2), t2 = jx_rsqrt(q2.x - ri2), t3 = jx_rsqrt(q3.x - ri2);
+        a0 = fma(q0.y, t0, a0); a1 = fma(q1.y, t1, a1); a2 = fma(q2.y, t2, a2); a3 = fma(q3.y, t3, a3);
+    }
+    for (; j < N; j += 4) {
+        const double2 q0 = s_rq[j];
+        a0 = fma(q0.y, jx_rsqrt(q0.x - ri2), a0);
+    }
+    return (a0 + a1) + (a2 + a3);
+}
+
 __device__ __forceinline__ void jx_profile_to_coefs(const JxDev& c, const double* p, int w, bool taps, double* s_r,
-                                                    double* s_pp, double* s_y, double* s_M, double* s_cf,
-                                                    double* tap_pp, double* tap_ab, double* tap_y) {
+                                                    double* s_pp, double* s_y, double* s_M, double* s_cf, double2* s_rq,
+                                                    double2* s_ds, double* tap_pp, double* tap_ab, double* tap_y) {
     const int N = c.N, tid = threadIdx.x, nth = blockDim.x;
-    // Phase 1
+    // Phase 1: profile; s_rq[j] = (r_j^2, q_j) with q_j = cj_j * pp_j; the grid table (r, cj, dg, sp) comes
+    // in one 32-byte load per knot so that the launch pays one cold-miss latency for it, not four.
     for (int j = tid; j < N; j += nth) {
-        const double r = c.r_pp[j];
+        const double2 t0 = *reinterpret_cast<const double2*>(c.abel_tab + 4 * (size_t)j);
+        const double2 t1 = *reinterpret_cast<const double2*>(c.abel_tab + 4 * (size_t)j + 2);
+        const double r = t0.x;
         s_r[j] = r;
+        s_ds[j] = t1;
         const double v = (c.dbg & 32) ? r : jx_press(p, r);
         s_pp[j] = v;
+        s_rq[j] = make_double2(r * r, t0.y * v);
         if (taps && tap_pp) tap_pp[(size_t)w * N + j] = v;
     }
     __syncthreads();
 
-    // Phase 2: rows i of the upper-triangular product.  With >= 2N threads each row is
-    // split in two halves [i, mid) and [mid, N) handled by threads i and i + nth/2.
-    const bool two = (nth >= 2 * N);
-    const int half = nth >> 1;
-    for (int i0 = 0; i0 < N; i0 += (two ? half : nth)) {
-        int i, jb, je;
-        if (two) {
-            const int hsel = tid >= half;
-            i = i0 + tid - hsel * half;
-            const int mid = (i + N + 1) >> 1;
-            jb = hsel ? mid : i;
-            je = hsel ? N : mid;
-        } else {
-            i = i0 + tid; jb = i; je = N;
-        }
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0, a5 = 0.0, a6 = 0.0, a7 = 0.0;
-        if (i < N && !(c.dbg & 8)) {
-            const double* col = c.abelT + i;
-            int j = jb;
-            for (; j + 7 < je; j += 8) {
-                const double w0 = col[(size_t)j * N], w1 = col[(size_t)(j + 1) * N], w2 = col[(size_t)(j + 2) * N],
-                             w3 = col[(size_t)(j + 3) * N], w4 = col[(size_t)(j + 4) * N], w5 = col[(size_t)(j + 5) * N],
-                             w6 = col[(size_t)(j + 6) * N], w7 = col[(size_t)(j + 7) * N];
-                a0 = fma(w0, s_pp[j], a0);     a1 = fma(w1, s_pp[j + 1], a1);
-                a2 = fma(w2, s_pp[j + 2], a2); a3 = fma(w3, s_pp[j + 3], a3);
-                a4 = fma(w4, s_pp[j + 4], a4); a5 = fma(w5, s_pp[j + 5], a5);
-                a6 = fma(w6, s_pp[j + 6], a6); a7 = fma(w7, s_pp[j + 7], a7);
+    // Phase 2: Abel integral, weights generated on the fly from the radius grid in LDS:
+    //   ab_i = dg_i pp_i + sp_i pp_{i+1} + sum_{j>=i+2} q_j / sqrt(r_j^2 - r_i^2)
+    // Rows i and N-1-i are paired (their trapezoid sums have N-3 terms together) and each pair is
+    // shared by 4 adjacent lanes (terms e = sub, sub+4, ...), reduced with two shuffles.
+    const int npair = (N + 1) >> 1;
+    for (int p0 = 0; p0 < npair; p0 += (nth >> 2)) {
+        const int pr = p0 + (tid >> 2), sub = tid & 3;
+        double acc1 = 0.0, acc2 = 0.0;
+        const int i1 = pr, i2 = N - 1 - pr;
+        if (pr < npair && !(c.dbg & 8)) {
+            if (c.dbg & 128) {            // ablation: same loop without the reciprocal square root
+                const double ri1 = s_rq[i1].x, ri2 = s_rq[i2].x;
+                for (int j = i1 + 2 + sub; j < N; j += 4) { const double2 q = s_rq[j]; acc1 = fma(q.y, q.x - ri1, acc1); }
+                for (int j = i2 + 2 + sub; j < N; j += 4) { const double2 q = s_rq[j]; acc2 = fma(q.y, q.x - ri2, acc2); }
+            } else {
+                acc1 = jx_abel_row(s_rq, s_rq[i1].x, i1 + 2 + sub, N);
+                if (i2 != i1) acc2 = jx_abel_row(s_rq, s_rq[i2].x, i2 + 2 + sub, N);
             }
-            for (; j < je; ++j) a0 = fma(col[(size_t)j * N], s_pp[j], a0);
         }
-        a0 += a4; a1 += a5; a2 += a6; a3 += a7;
-        const double part = (a0 + a1) + (a2 + a3);
-        if (two) {
-            if (tid >= half && i < N) s_M[i] = part;           // s_M is free until phase 3
-            __syncthreads();
-            if (tid < half && i < N) {
-                const double ab = part + s_M[i];
-                s_y[i] = c.y_scale * ab;
-                if (taps && tap_ab) tap_ab[(size_t)w * N + i] = ab;
+        acc1 += __shfl_xor(acc1, 1, 64); acc1 += __shfl_xor(acc1, 2, 64);
+        acc2 += __shfl_xor(acc2, 1, 64); acc2 += __shfl_xor(acc2, 2, 64);
+        if (pr < npair && sub == 0) {
+            const double2 ds1 = s_ds[i1];
+            double ab = fma(ds1.x, s_pp[i1], acc1);
+            if (i1 + 1 < N) ab = fma(ds1.y, s_pp[i1 + 1], ab);
+            s_y[i1] = c.y_scale * ab;
+            if (taps && tap_ab) tap_ab[(size_t)w * N + i1] = ab;
+            if (i2 != i1) {
+                const double2 ds2 = s_ds[i2];
+                double ab2 = fma(ds2.x, s_pp[i2], acc2);
+                if (i2 + 1 < N) ab2 = fma(ds2.y, s_pp[i2 + 1], ab2);
+                s_y[i2] = c.y_scale * ab2;
+                if (taps && tap_ab) tap_ab[(size_t)w * N + i2] = ab2;
             }
-            __syncthreads();
-        } else if (i < N) {
-            s_y[i] = c.y_scale * part;
-            if (taps && tap_ab) tap_ab[(size_t)w * N + i] = part;
         }
     }
     __syncthreads();
     if (taps && tap_y) for (int i = tid; i < N; i += nth) tap_y[(size_t)w * N + i] = s_y[i];
 
-    // Phase 3: spline moments through the banded operator
+    // Phase 3: spline moments through the banded operator, two lanes per row
     const int K = c.K;
-    for (int i = tid; i < N; i += nth) {
-        const int k0 = max(-K, -i), k1 = (c.dbg & 16) ? k0 - 1 : min(K, N - 1 - i);
-        double m0 = 0.0, m1 = 0.0;
-        int k = k0;
-        for (; k + 1 <= k1; k += 2) {
-            m0 = fma(c.gband[(size_t)(k + K) * N + i], s_y[i + k], m0);
-            m1 = fma(c.gband[(size_t)(k + 1 + K) * N + i], s_y[i + k + 1], m1);
+    for (int i0 = 0; i0 < N; i0 += (nth >> 1)) {
+        const int i = i0 + (tid >> 1), hsel = tid & 1;
+        double m0 = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0;
+        if (i < N && !(c.dbg & 16)) {
+            const int k0 = max(-K, -i), k1 = min(K, N - 1 - i);
+            const int km = (k0 + k1 + 1) >> 1;
+            const int ka = hsel ? km : k0, kb = hsel ? k1 + 1 : km;      // [ka, kb)
+            int k = ka;
+            for (; k + 3 < kb; k += 4) {
+                const double g0 = c.gband[(size_t)(k + K) * N + i], g1 = c.gband[(size_t)(k + 1 + K) * N + i],
+                             g2 = c.gband[(size_t)(k + 2 + K) * N + i], g3 = c.gband[(size_t)(k + 3 + K) * N + i];
+                m0 = fma(g0, s_y[i + k], m0);     m1 = fma(g1, s_y[i + k + 1], m1);
+                m2 = fma(g2, s_y[i + k + 2], m2); m3 = fma(g3, s_y[i + k + 3], m3);
+            }
+            for (; k < kb; ++k) m0 = fma(c.gband[(size_t)(k + K) * N + i], s_y[i + k], m0);
         }
-        if (k <= k1) m0 = fma(c.gband[(size_t)(k + K) * N + i], s_y[i + k], m0);
-        s_M[i] = m0 + m1;
+        double m = (m0 + m1) + (m2 + m3);
+        m += __shfl_xor(m, 1, 64);
+        if (i < N && hsel == 0) s_M[i] = m;
     }
     __syncthreads();
 
@@ -396,20 +430,22 @@ __device__ __forceinline__ void jx_profile_to_coefs(const JxDev& c, const double
 }
 
 // LDS doubles needed by the profile-to-coefficients phases
-#define JX_MAP_LDS_DOUBLES(N) (8 * (size_t)(N) + 8)
+#define JX_MAP_LDS_DOUBLES(N) (JX_LDS_HDR + 12 * (size_t)(((N) + 1) & ~1) + 8)
 
 template <bool VEC2>
 __global__ void __launch_bounds__(1024)
 jx_abel_map_kernel(JxDev c, const double* __restrict__ pvec, double* __restrict__ img /*[chunk][P][P]*/,
                    double* __restrict__ tap_pp, double* __restrict__ tap_ab, double* __restrict__ tap_y) {
-    extern __shared__ double sm[];
+    JX_LDS_DECL;
     const int N = c.N;
-    double* s_r = sm;                 // [N] knots
+    double* p = sm;
+    double* s_r = sm + JX_LDS_HDR;    // [N] knots
     double* s_pp = s_r + N;           // [N]
     double* s_y = s_pp + N;           // [N]
     double* s_M = s_y + N;            // [N]
     double* s_cf = s_M + N;           // [4(N+1)]
-    __shared__ double p[JX_MAX_PAR];
+    double2* s_rq = reinterpret_cast<double2*>(s_cf + 4 * (N + 1));   // [N] (r^2, cj*pp)
+    double2* s_ds = s_rq + ((N + 1) & ~1);                            // [N] (dg, sp)
 
     const int tid = threadIdx.x, nth = blockDim.x;
     const int w = blockIdx.x / c.map_split;
@@ -417,7 +453,7 @@ jx_abel_map_kernel(JxDev c, const double* __restrict__ pvec, double* __restrict_
 
     if (tid < JX_MAX_PAR) p[tid] = pvec[(size_t)w * JX_MAX_PAR + tid];
     __syncthreads();
-    jx_profile_to_coefs(c, p, w, part == 0, s_r, s_pp, s_y, s_M, s_cf, tap_pp, tap_ab, tap_y);
+    jx_profile_to_coefs(c, p, w, part == 0, s_r, s_pp, s_y, s_M, s_cf, s_rq, s_ds, tap_pp, tap_ab, tap_y);
 
     // Phase 5 (generic): the block's slab of rows
     const int S = c.S, P = c.P;
@@ -476,15 +512,17 @@ template <bool VEC2, int NAIT>
 __global__ void __launch_bounds__(1024)
 jx_abel_map_sym_kernel(JxDev c, const double* __restrict__ pvec, double* __restrict__ img,
                        double* __restrict__ tap_pp, double* __restrict__ tap_ab, double* __restrict__ tap_y) {
-    extern __shared__ double sm[];
+    JX_LDS_DECL;
     const int N = c.N;
-    double* s_r = sm;
+    double* p = sm;
+    double* s_r = sm + JX_LDS_HDR;
     double* s_pp = s_r + N;
     double* s_y = s_pp + N;
     double* s_M = s_y + N;
     double* s_cf = s_M + N;                         // [4(N+1)]
-    double* s_row = sm + JX_MAP_LDS_DOUBLES(N);     // [nwaves][row_pad]
-    __shared__ double p[JX_MAX_PAR];
+    double2* s_rq = reinterpret_cast<double2*>(s_cf + 4 * (N + 1));   // [N] (r^2, cj*pp)
+    double2* s_ds = s_rq + ((N + 1) & ~1);                            // [N] (dg, sp)
+    double* s_row = sm + JX_MAP_LDS_DOUBLES(N);     // [nwaves][row_pad]  (offset is a multiple of 2 doubles)
 
     const int tid = threadIdx.x, nth = blockDim.x;
     const int w = blockIdx.x / c.map_split;
@@ -492,7 +530,7 @@ jx_abel_map_sym_kernel(JxDev c, const double* __restrict__ pvec, double* __restr
 
     if (tid < JX_MAX_PAR) p[tid] = pvec[(size_t)w * JX_MAX_PAR + tid];
     __syncthreads();
-    if (!(c.dbg & 1)) jx_profile_to_coefs(c, p, w, part == 0, s_r, s_pp, s_y, s_M, s_cf, tap_pp, tap_ab, tap_y);
+    if (!(c.dbg & 1)) jx_profile_to_coefs(c, p, w, part == 0, s_r, s_pp, s_y, s_M, s_cf, s_rq, s_ds, tap_pp, tap_ab, tap_y);
     else { for (int k = tid; k < 4 * (N + 1); k += nth) s_cf[k] = 0.0; __syncthreads(); }
     if (c.dbg & 2) return;
 
@@ -515,10 +553,19 @@ jx_abel_map_sym_kernel(JxDev c, const double* __restrict__ pvec, double* __restr
             const bool do1 = iy1 < S, do2 = (b > 0) && (iy2 >= 0);
             double* orow1 = out + (size_t)iy1 * c.img_ld;
             double* orow2 = out + (size_t)iy2 * c.img_ld;
-            for (int ix = 2 * lane; ix + 1 < S; ix += 128) {
-                const double2 v = *reinterpret_cast<const double2*>(rowfull + ix);
-                if (do1) *reinterpret_cast<double2*>(orow1 + ix) = v;
-                if (do2) *reinterpret_cast<double2*>(orow2 + ix) = v;
+            if (c.dbg & 64) {
+                typedef double jx_d2 __attribute__((ext_vector_type(2)));
+                for (int ix = 2 * lane; ix + 1 < S; ix += 128) {
+                    const jx_d2 v = *reinterpret_cast<const jx_d2*>(rowfull + ix);
+                    if (do1) __builtin_nontemporal_store(v, reinterpret_cast<jx_d2*>(orow1 + ix));
+                    if (do2) __builtin_nontemporal_store(v, reinterpret_cast<jx_d2*>(orow2 + ix));
+                }
+            } else {
+                for (int ix = 2 * lane; ix + 1 < S; ix += 128) {
+                    const double2 v = *reinterpret_cast<const double2*>(rowfull + ix);
+                    if (do1) *reinterpret_cast<double2*>(orow1 + ix) = v;
+                    if (do2) *reinterpret_cast<double2*>(orow2 + ix) = v;
+                }
             }
         }
         return;
@@ -610,10 +657,10 @@ jx_tail_kernel(JxDev c, const double2* __restrict__ tfspec, const double2* __res
                const double* __restrict__ base, double* __restrict__ logp, int w0,
                double* __restrict__ tap_row, double* __restrict__ tap_bright, double* __restrict__ tap_chisq,
                double* __restrict__ tap_parts) {
-    extern __shared__ double sm[];
-    __shared__ double red[8];
+    JX_LDS_DECL;
+    double* red = sm + 20;
     const int S = c.S, Sh = c.Sh, nrow = c.nrow;
-    double* s_zr = sm;                 // [Sh]
+    double* s_zr = sm + JX_LDS_HDR;    // [Sh]
     double* s_zi = s_zr + Sh;          // [Sh]
     double* s_prof = s_zi + Sh;        // [nrow]
     const int w = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;

@@ -120,6 +120,28 @@ inline void abel_matrix(const std::vector<double>& r, std::vector<double>& A) {
     }
 }
 
+// The same weights in the form the kernel regenerates on the fly:
+//   A[i][j] = cj[j] / sqrt(r_j^2 - r_i^2)  for j >= i+2,   A[i][i] = dg[i],   A[i][i+1] = sp[i].
+inline void abel_onfly_tables(const std::vector<double>& r, std::vector<double>& cj, std::vector<double>& dg,
+                              std::vector<double>& sp) {
+    const int n = (int)r.size();
+    std::vector<double> A;
+    abel_matrix(r, A);
+    cj.assign(n, 0.0); dg.assign(n, 0.0); sp.assign(n, 0.0);
+    const bool uni = grid_is_uniform(r);
+    const double dx = std::fabs(r[1] - r[0]);
+    for (int j = 0; j < n; ++j) {
+        double wt;
+        if (uni) wt = (j == 0 || j == n - 1) ? 0.5 * dx : dx;
+        else wt = 0.5 * (((j > 0) ? r[j] - r[j - 1] : 0.0) + ((j < n - 1) ? r[j + 1] - r[j] : 0.0));
+        cj[j] = 2.0 * r[j] * wt;
+    }
+    for (int i = 0; i < n; ++i) {
+        dg[i] = A[(size_t)i * n + i];
+        if (i + 1 < n) sp[i] = A[(size_t)i * n + i + 1];
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // Moment operator of the mirrored not-a-knot spline: M = G y, with y the samples at the
 // positive knots r_0 < ... < r_{n-1}, the knot set being {-r_{n-1},..,-r_0, r_0,..,r_{n-1}}

@@ -13,6 +13,15 @@ int jxt_abel_matrix(const double* r, int n, double* out /*[n*n]*/) {
     return 0;
 }
 
+int jxt_abel_onfly(const double* r, int n, double* cj, double* dg, double* sp) {
+    std::vector<double> rv(r, r + n), a, b, c;
+    jxt::abel_onfly_tables(rv, a, b, c);
+    memcpy(cj, a.data(), sizeof(double) * n);
+    memcpy(dg, b.data(), sizeof(double) * n);
+    memcpy(sp, c.data(), sizeof(double) * n);
+    return 0;
+}
+
 int jxt_mirrored_spline_op(const double* r, int n, double* out /*[n*n]*/) {
     std::vector<double> rv(r, r + n), G;
     if (!jxt::mirrored_spline_op(rv, G)) return -1;

@@ -177,3 +177,21 @@ def test_mixed_domain_tables(lib, S, B, P):
     bad = beam.copy(); bad[0, 1] *= 1.5
     assert lib.jxt_beam_fir_taps(_p(bad), B, P, ctypes.c_double(1.0), _p(taps)) == -1
     assert lib.jxt_custom_conv_lp(512, 27) == 288 and lib.jxt_custom_conv_lp(171, 27) == 0
+
+
+@pytest.mark.parametrize('name', list(GRIDS))
+def test_abel_onfly_tables(lib, name):
+    """The kernel regenerates A[i][j] = cj[j]/sqrt(r_j^2-r_i^2) (j >= i+2) on the fly."""
+    r = np.ascontiguousarray(GRIDS[name])
+    n = r.size
+    cj, dg, sp = np.zeros(n), np.zeros(n), np.zeros(n)
+    lib.jxt_abel_onfly(_p(r), n, _p(cj), _p(dg), _p(sp))
+    A = np.zeros((n, n))
+    for i in range(n):
+        A[i, i] = dg[i]
+        if i + 1 < n:
+            A[i, i + 1] = sp[i]
+        j = np.arange(i + 2, n)
+        A[i, j] = cj[j] / np.sqrt(r[j] ** 2 - r[i] ** 2)
+    want = pyabel_direct.abel_weight_matrix(r)
+    np.testing.assert_allclose(A, want, rtol=1e-12, atol=1e-13 * np.abs(want).max())
