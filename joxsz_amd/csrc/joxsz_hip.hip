@@ -61,7 +61,7 @@ struct jx_ctx {
     JxConv cv;
     cplx *d_Y = nullptr, *d_C = nullptr, *d_part = nullptr;
     size_t p1_lds = 0, p2_lds = 0, p3_lds = 0;
-    int p13_rows = 8;
+    int p13_rows = 8, p1_rows = 8, conv_v2 = 0;
     double* t_conv = nullptr;
     void* d_work = nullptr;
     size_t work_cap = 0;
@@ -85,6 +85,8 @@ static int g_rocfft_refs = 0;
 
 // (LP, LS, rows per block) triples the hand-written convolution is instantiated for
 #define JX_CONV_PAIRS(X) X(18, 16, 8) X(48, 24, 8) X(48, 32, 8) X(96, 64, 8) X(144, 128, 8) X(288, 256, 8) X(576, 512, 4)
+// two-level (register-blocked) forms: (LP, LS, rows per block in pass 1, rows per block in pass 3)
+#define JX_CONV2_PAIRS(X) X(18, 16, 42, 42) X(48, 24, 32, 32) X(48, 32, 32, 32) X(96, 64, 21, 21) X(144, 128, 21, 16) X(288, 256, 14, 14)
 
 #define HIPCHK(ctx, call)                                                                          \
     do {                                                                                           \
@@ -395,7 +397,12 @@ int jx_finalize(jx_ctx* ctx) {
         JxConv& cv = ctx->cv;
         memset(&cv, 0, sizeof(cv));
         cv.S = S; cv.Sh = ctx->Sh; cv.B = B; cv.o = o; cv.P = P; cv.Ph = ctx->Ph; cv.LP = P / 2; cv.LS = S / 2; cv.ntap = o + 1;
-        ctx->p13_rows = (cv.LP <= 288) ? 8 : 4;
+        ctx->p13_rows = ctx->p1_rows = (cv.LP <= 288) ? 8 : 4;
+        ctx->conv_v2 = 0;
+#define JX_SEL2(LPv, LSv, R1v, R3v) if (cv.LP == LPv && cv.LS == LSv) { ctx->conv_v2 = 1; ctx->p1_rows = R1v; ctx->p13_rows = R3v; }
+        JX_CONV2_PAIRS(JX_SEL2)
+#undef JX_SEL2
+        if (const char* e = getenv("JOXSZ_CONV_V1")) { if (atoi(e) > 0) { ctx->conv_v2 = 0; ctx->p13_rows = ctx->p1_rows = (cv.LP <= 288) ? 8 : 4; } }
         cv.nblk3 = (S + ctx->p13_rows - 1) / ctx->p13_rows;
         std::vector<double> v;
         double* p;
@@ -408,7 +415,8 @@ int jx_finalize(jx_ctx* ctx) {
         std::vector<double> filt = host_vec<double>(ctx, JX_T_FILTERING);
         jxt::tf_hy_table(filt, S, v);
         if ((rc = dev_put(ctx, v.data(), v.size(), &p))) return rc; cv.hy = (const cplx*)p;
-        ctx->p2_lds = fir_lds;
+        ctx->p2_lds = ctx->conv_v2 ? sizeof(double) * ((size_t)2 * (JX_FIR_TILE + 2 * o) * JX_FIR2_KX + (size_t)(o + 1) * JX_FIR2_KX)
+                                   : fir_lds;
     }
     // ---- plain copies
     {
@@ -515,15 +523,27 @@ int jx_finalize(jx_ctx* ctx) {
         if ((rc = dev_new(ctx, (size_t)chunk * S * cv.Ph, &ctx->d_Y))) return rc;
         if ((rc = dev_new(ctx, (size_t)chunk * S * cv.Ph, &ctx->d_C))) return rc;
         if ((rc = dev_new(ctx, (size_t)chunk * cv.nblk3 * cv.Sh, &ctx->d_part))) return rc;
-        const int R = ctx->p13_rows;
-        ctx->p1_lds = sizeof(cplx) * ((size_t)2 * R * cv.LP + cv.LP);
-        ctx->p3_lds = sizeof(cplx) * ((size_t)2 * R * cv.LP + cv.LP + cv.LS);
+        if (!ctx->conv_v2) {
+            const int R = ctx->p13_rows;
+            ctx->p1_lds = sizeof(cplx) * ((size_t)2 * R * cv.LP + cv.LP);
+            ctx->p3_lds = sizeof(cplx) * ((size_t)2 * R * cv.LP + cv.LP + cv.LS);
 #define JX_ATTR13(LPv, LSv, Rv) if (cv.LP == LPv && cv.LS == LSv) { \
-            HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_rowfft_kernel<LPv, Rv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->p1_lds)); \
-            HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_rowtf_kernel<LPv, LSv, Rv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->p3_lds)); }
-        JX_CONV_PAIRS(JX_ATTR13)
+                HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_rowfft_kernel<LPv, Rv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->p1_lds)); \
+                HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_rowtf_kernel<LPv, LSv, Rv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->p3_lds)); }
+            JX_CONV_PAIRS(JX_ATTR13)
 #undef JX_ATTR13
-        HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_beamfir_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->p2_lds));
+            HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_beamfir_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->p2_lds));
+        } else {
+#define JX_ATTR2(LPv, LSv, R1v, R3v) if (cv.LP == LPv && cv.LS == LSv) { \
+                constexpr int rs1 = jx_lay<LPv>::RS, rs3 = jx_lay<LPv>::RS > jx_lay<LSv>::RS ? jx_lay<LPv>::RS : jx_lay<LSv>::RS; \
+                ctx->p1_lds = sizeof(cplx) * ((size_t)R1v * rs1 + LPv); \
+                ctx->p3_lds = sizeof(cplx) * ((size_t)R3v * rs3 + LPv + LSv); \
+                HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_rowfft2_kernel<LPv, R1v>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->p1_lds)); \
+                HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_rowtf2_kernel<LPv, LSv, R3v>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->p3_lds)); }
+            JX_CONV2_PAIRS(JX_ATTR2)
+#undef JX_ATTR2
+            HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_beamfir2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->p2_lds));
+        }
     }
 
     FFTCHK(ctx, rocfft_execution_info_create(&ctx->info));
@@ -574,24 +594,39 @@ static int launch_custom_conv(jx_ctx* ctx, int n, double* tap_conv, EvSet* es) {
     const JxConv& cv = ctx->cv;
     const JxDev& d = ctx->d;
     hipStream_t st = ctx->stream;
-    const int R = ctx->p13_rows;
-    const dim3 g13((cv.S + R - 1) / R, n);
     bool done = false;
-#define JX_P1(LPv, LSv, Rv) if (!done && cv.LP == LPv && cv.LS == LSv) { \
-        hipLaunchKernelGGL((jx_rowfft_kernel<LPv, Rv>), g13, dim3(256), ctx->p1_lds, st, cv, ctx->d_img, (size_t)d.img_ld, (size_t)d.img_ws, ctx->d_Y); done = true; }
-    JX_CONV_PAIRS(JX_P1)
+    if (ctx->conv_v2) {
+        const dim3 g1((cv.S + ctx->p1_rows - 1) / ctx->p1_rows, n), g3((cv.S + ctx->p13_rows - 1) / ctx->p13_rows, n);
+#define JX_P1(LPv, LSv, R1v, R3v) if (!done && cv.LP == LPv && cv.LS == LSv) { \
+            hipLaunchKernelGGL((jx_rowfft2_kernel<LPv, R1v>), g1, dim3(256), ctx->p1_lds, st, cv, ctx->d_img, (size_t)d.img_ld, (size_t)d.img_ws, ctx->d_Y); done = true; }
+        JX_CONV2_PAIRS(JX_P1)
 #undef JX_P1
-    if (!done) { ctx->err = "no pass-1 kernel for this size"; return JX_ERR_UNSUPPORTED; }
-    {
+        if (!done) { ctx->err = "no pass-1 kernel for this size"; return JX_ERR_UNSUPPORTED; }
+        const dim3 g2((cv.Ph + JX_FIR2_KX - 1) / JX_FIR2_KX, (cv.S + JX_FIR_TILE - 1) / JX_FIR_TILE, n);
+        hipLaunchKernelGGL(jx_beamfir2_kernel, g2, dim3(256), ctx->p2_lds, st, cv, ctx->d_Y, ctx->d_C);
+        if (es) HIPCHK(ctx, hipEventRecord(es->e[3], st));
+        done = false;
+#define JX_P3(LPv, LSv, R1v, R3v) if (!done && cv.LP == LPv && cv.LS == LSv) { \
+            hipLaunchKernelGGL((jx_rowtf2_kernel<LPv, LSv, R3v>), g3, dim3(256), ctx->p3_lds, st, cv, ctx->d_C, ctx->d_part, tap_conv); done = true; }
+        JX_CONV2_PAIRS(JX_P3)
+#undef JX_P3
+    } else {
+        const int R = ctx->p13_rows;
+        const dim3 g13((cv.S + R - 1) / R, n);
+#define JX_P1(LPv, LSv, Rv) if (!done && cv.LP == LPv && cv.LS == LSv) { \
+            hipLaunchKernelGGL((jx_rowfft_kernel<LPv, Rv>), g13, dim3(256), ctx->p1_lds, st, cv, ctx->d_img, (size_t)d.img_ld, (size_t)d.img_ws, ctx->d_Y); done = true; }
+        JX_CONV_PAIRS(JX_P1)
+#undef JX_P1
+        if (!done) { ctx->err = "no pass-1 kernel for this size"; return JX_ERR_UNSUPPORTED; }
         const dim3 g2((cv.Ph + 63) / 64, (cv.S + JX_FIR_TILE - 1) / JX_FIR_TILE, n);
         hipLaunchKernelGGL(jx_beamfir_kernel, g2, dim3(512), ctx->p2_lds, st, cv, ctx->d_Y, ctx->d_C);
-    }
-    if (es) HIPCHK(ctx, hipEventRecord(es->e[3], st));
-    done = false;
+        if (es) HIPCHK(ctx, hipEventRecord(es->e[3], st));
+        done = false;
 #define JX_P3(LPv, LSv, Rv) if (!done && cv.LP == LPv && cv.LS == LSv) { \
-        hipLaunchKernelGGL((jx_rowtf_kernel<LPv, LSv, Rv>), g13, dim3(256), ctx->p3_lds, st, cv, ctx->d_C, ctx->d_part, tap_conv); done = true; }
-    JX_CONV_PAIRS(JX_P3)
+            hipLaunchKernelGGL((jx_rowtf_kernel<LPv, LSv, Rv>), g13, dim3(256), ctx->p3_lds, st, cv, ctx->d_C, ctx->d_part, tap_conv); done = true; }
+        JX_CONV_PAIRS(JX_P3)
 #undef JX_P3
+    }
     if (es) HIPCHK(ctx, hipEventRecord(es->e[4], st));
     return JX_OK;
 }

@@ -3,6 +3,15 @@
 #include <cstring>
 #include <vector>
 #include "jx_tables.hpp"
+#include "jx_regfft.hpp"
+
+// in-register FFT of every supported small length, for the host test
+template <int N> static void regfft_any(double* re, double* im, int inv) {
+    jx_c x[N];
+    for (int i = 0; i < N; ++i) x[i] = jxc(re[i], im[i]);
+    if (inv) jx_regfft<N, true>::run(x); else jx_regfft<N, false>::run(x);
+    for (int i = 0; i < N; ++i) { re[i] = x[i].x; im[i] = x[i].y; }
+}
 
 extern "C" {
 
@@ -72,6 +81,17 @@ int jxt_host_fft(double* re, double* im, int n, int sign) {
     memcpy(im, i.data(), sizeof(double) * n);
     return 0;
 }
+
+int jxt_regfft(int n, int inv, double* re, double* im) {
+    switch (n) {
+#define C(N) case N: regfft_any<N>(re, im, inv); return 0;
+        C(2) C(3) C(4) C(6) C(8) C(9) C(12) C(16) C(18) C(24) C(27) C(32)
+#undef C
+    }
+    return -1;
+}
+double jxt_cx_cos2pi(long long k, long long n) { return jx_cx_cos2pi(k, n); }
+double jxt_cx_sin2pi(long long k, long long n) { return jx_cx_sin2pi(k, n); }
 
 int jxt_custom_conv_lp(int S, int o) { return jxt::custom_conv_lp(S, o); }
 

@@ -195,3 +195,25 @@ def test_abel_onfly_tables(lib, name):
         A[i, j] = cj[j] / np.sqrt(r[j] ** 2 - r[i] ** 2)
     want = pyabel_direct.abel_weight_matrix(r)
     np.testing.assert_allclose(A, want, rtol=1e-12, atol=1e-13 * np.abs(want).max())
+
+
+def test_constexpr_trig(lib):
+    lib.jxt_cx_cos2pi.restype = ctypes.c_double
+    lib.jxt_cx_sin2pi.restype = ctypes.c_double
+    lib.jxt_cx_cos2pi.argtypes = lib.jxt_cx_sin2pi.argtypes = [ctypes.c_longlong, ctypes.c_longlong]
+    pi = np.longdouble('3.14159265358979323846264338327950288')
+    for n in (3, 4, 7, 16, 18, 288, 576, 1152):
+        for k in list(range(-3, n + 3)) if n < 300 else (0, 1, n // 8, n // 4, n // 3, n // 2, n - 1, 5 * n + 7):
+            t = 2 * pi * np.longdouble(k % n) / np.longdouble(n)          # 80-bit reference
+            assert abs(lib.jxt_cx_cos2pi(k, n) - float(np.cos(t))) < 2.3e-16, (k, n)
+            assert abs(lib.jxt_cx_sin2pi(k, n) - float(np.sin(t))) < 2.3e-16, (k, n)
+
+
+@pytest.mark.parametrize('n', [2, 3, 4, 6, 8, 9, 12, 16, 18, 24, 27, 32])
+def test_register_fft(lib, n):
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    for inv, want in ((0, np.fft.fft(x)), (1, np.fft.ifft(x) * n)):
+        re, im = np.ascontiguousarray(x.real), np.ascontiguousarray(x.imag)
+        assert lib.jxt_regfft(n, inv, _p(re), _p(im)) == 0
+        np.testing.assert_allclose(re + 1j * im, want, rtol=0, atol=2e-15 * n * np.abs(x).max())
