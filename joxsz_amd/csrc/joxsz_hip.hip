@@ -61,7 +61,9 @@ struct jx_ctx {
     JxConv cv;
     cplx *d_Y = nullptr, *d_C = nullptr, *d_part = nullptr;
     size_t p1_lds = 0, p2_lds = 0, p3_lds = 0;
-    int p13_rows = 8, p1_rows = 8, conv_v2 = 0;
+    int p13_rows = 8, p1_rows = 8;
+    int* d_rowjob = nullptr;
+    double* t_convjobs = nullptr;
     double* t_conv = nullptr;
     void* d_work = nullptr;
     size_t work_cap = 0;
@@ -83,10 +85,8 @@ struct jx_ctx {
 
 static int g_rocfft_refs = 0;
 
-// (LP, LS, rows per block) triples the hand-written convolution is instantiated for
-#define JX_CONV_PAIRS(X) X(18, 16, 8) X(48, 24, 8) X(48, 32, 8) X(96, 64, 8) X(144, 128, 8) X(288, 256, 8) X(576, 512, 4)
 // two-level (register-blocked) forms: (LP, LS, rows per block in pass 1, rows per block in pass 3)
-#define JX_CONV2_PAIRS(X) X(18, 16, 42, 42) X(48, 24, 32, 32) X(48, 32, 32, 32) X(96, 64, 21, 21) X(144, 128, 21, 16) X(288, 256, 14, 14)
+#define JX_CONV2_PAIRS(X) X(18, 16, 42, 42) X(48, 24, 32, 32) X(48, 32, 32, 32) X(96, 64, 21, 21) X(144, 128, 21, 16) X(288, 256, 14, 14) X(576, 512, 10, 8)
 
 #define HIPCHK(ctx, call)                                                                          \
     do {                                                                                           \
@@ -299,10 +299,10 @@ int jx_finalize(jx_ctx* ctx) {
     if (want < 0 || want > 2) { ctx->err = "conv_mode must be 0, 1 or 2"; return JX_ERR_INVALID; }
     std::vector<double> beam_h = host_vec<double>(ctx, JX_T_BEAM_2D);
     const int lp_custom = jxt::custom_conv_lp(S, o);
-    const size_t fir_lds = sizeof(double) * ((size_t)2 * (JX_FIR_TILE + 2 * o) * 64 + (size_t)(o + 1) * 64);
-    const bool eligible = lp_custom > 0 && jxt::beam_is_symmetric(beam_h, B) && fir_lds <= 150 * 1024 && c.fft_pad == 0;
+    const size_t fir_lds = sizeof(double) * ((size_t)2 * JX_FIR_RING * JX_FIR_KX + (size_t)(o + 1) * JX_FIR_KX);
+    const bool eligible = lp_custom > 0 && jxt::beam_is_symmetric(beam_h, B) && JX_FIR_TILE + 2 * o <= JX_FIR_RING && c.fft_pad == 0;
     if (want == 2 && !eligible) {
-        ctx->err = "hand-written convolution needs S/2 in {16,24,32,64,128,256,512}, a flip-symmetric beam with (B-1)/2 <= 34 and fft_pad = 0";
+        ctx->err = "hand-written convolution needs S/2 in {16,24,32,64,128,256,512}, a flip-symmetric beam with (B-1)/2 <= 32 and fft_pad = 0";
         return JX_ERR_UNSUPPORTED;
     }
     ctx->conv_mode = (want == 2 || (want == 0 && eligible)) ? 2 : 1;
@@ -377,6 +377,24 @@ int jx_finalize(jx_ctx* ctx) {
         double* p; if ((rc = dev_put(ctx, E.data(), E.size(), &p))) return rc; d.emat = p;
         if ((rc = dev_put(ctx, flux.data(), flux.size(), &p))) return rc; d.flux = p;
     }
+    // ---- does d_mat have the mirror structure d_mat[iy][ix] = Q[|iy-c|][|ix-c|] (what centdistmat builds)?
+    std::vector<double> dm_h = host_vec<double>(ctx, JX_T_D_MAT);
+    const int cc0 = S / 2, qn = std::max(cc0, S - 1 - cc0) + 1;
+    std::vector<double> Qtab((size_t)qn * qn);
+    bool dmat_mirror = true;
+    {
+        for (int b = 0; b < qn; ++b)
+            for (int a = 0; a < qn; ++a) {
+                const int iy = (cc0 + b < S) ? cc0 + b : cc0 - b, ix = (cc0 + a < S) ? cc0 + a : cc0 - a;
+                Qtab[(size_t)b * qn + a] = dm_h[(size_t)iy * S + ix];
+            }
+        for (int iy = 0; iy < S && dmat_mirror; ++iy)
+            for (int ix = 0; ix < S; ++ix) {
+                const double q = Qtab[(size_t)std::abs(iy - cc0) * qn + std::abs(ix - cc0)];
+                if (memcmp(&q, &dm_h[(size_t)iy * S + ix], sizeof(double)) != 0) { dmat_mirror = false; break; }
+            }
+    }
+
     // ---- twiddles of the final inverse transform of the extracted row (both modes)
     {
         double* p;
@@ -397,13 +415,26 @@ int jx_finalize(jx_ctx* ctx) {
         JxConv& cv = ctx->cv;
         memset(&cv, 0, sizeof(cv));
         cv.S = S; cv.Sh = ctx->Sh; cv.B = B; cv.o = o; cv.P = P; cv.Ph = ctx->Ph; cv.LP = P / 2; cv.LS = S / 2; cv.ntap = o + 1;
-        ctx->p13_rows = ctx->p1_rows = (cv.LP <= 288) ? 8 : 4;
-        ctx->conv_v2 = 0;
-#define JX_SEL2(LPv, LSv, R1v, R3v) if (cv.LP == LPv && cv.LS == LSv) { ctx->conv_v2 = 1; ctx->p1_rows = R1v; ctx->p13_rows = R3v; }
+        ctx->p13_rows = ctx->p1_rows = 0;
+#define JX_SEL2(LPv, LSv, R1v, R3v) if (cv.LP == LPv && cv.LS == LSv) { ctx->p1_rows = R1v; ctx->p13_rows = R3v; }
         JX_CONV2_PAIRS(JX_SEL2)
 #undef JX_SEL2
-        if (const char* e = getenv("JOXSZ_CONV_V1")) { if (atoi(e) > 0) { ctx->conv_v2 = 0; ctx->p13_rows = ctx->p1_rows = (cv.LP <= 288) ? 8 : 4; } }
-        cv.nblk3 = (S + ctx->p13_rows - 1) / ctx->p13_rows;
+        if (!ctx->p1_rows) { ctx->err = "no convolution kernels for this size"; return JX_ERR_UNSUPPORTED; }
+        // row bookkeeping: distinct map rows, conv jobs, segments (identity tables without the mirror structure)
+        bool use_mirror = dmat_mirror;
+        if (const char* e = getenv("JOXSZ_CONV_NOSYM")) { if (atoi(e) > 0) use_mirror = false; }
+        jxt::ConvRows rows;
+        jxt::conv_row_tables(S, o, use_mirror, rows);
+        cv.NU = rows.NU; cv.NJ = rows.NJ; cv.nseg = rows.nseg;
+        cv.nblk3 = (cv.NJ + ctx->p13_rows - 1) / ctx->p13_rows;
+        {
+            int* q;
+            if ((rc = dev_put(ctx, rows.urow.data(), rows.urow.size(), &q))) return rc; cv.urow = q;
+            if ((rc = dev_put(ctx, rows.umap.data(), rows.umap.size(), &q))) return rc; cv.umap = q;
+            if ((rc = dev_put(ctx, rows.jrow.data(), rows.jrow.size(), &q))) return rc; cv.jrow = q;
+            if ((rc = dev_put(ctx, rows.seg.data(), rows.seg.size(), &q))) return rc; cv.seg = q;
+            if ((rc = dev_put(ctx, rows.rowjob.data(), rows.rowjob.size(), &q))) return rc; ctx->d_rowjob = q;
+        }
         std::vector<double> v;
         double* p;
         jxt::twiddles(cv.LP, cv.LP, v); if ((rc = dev_put(ctx, v.data(), v.size(), &p))) return rc; cv.tw_lp = (const cplx*)p;
@@ -412,11 +443,16 @@ int jx_finalize(jx_ctx* ctx) {
         jxt::twiddles(S, cv.LS + 1, v); if ((rc = dev_put(ctx, v.data(), v.size(), &p))) return rc; cv.tw_s = (const cplx*)p;
         jxt::beam_fir_taps(beam_h, B, P, c.step * c.step / (double)P, v);
         if ((rc = dev_put(ctx, v.data(), v.size(), &p))) return rc; cv.taps = p;
-        std::vector<double> filt = host_vec<double>(ctx, JX_T_FILTERING);
-        jxt::tf_hy_table(filt, S, v);
-        if ((rc = dev_put(ctx, v.data(), v.size(), &p))) return rc; cv.hy = (const cplx*)p;
-        ctx->p2_lds = ctx->conv_v2 ? sizeof(double) * ((size_t)2 * (JX_FIR_TILE + 2 * o) * JX_FIR2_KX + (size_t)(o + 1) * JX_FIR2_KX)
-                                   : fir_lds;
+        std::vector<double> filt = host_vec<double>(ctx, JX_T_FILTERING), hy;
+        jxt::tf_hy_table(filt, S, hy);
+        // Hy weights summed over the conv rows of each job
+        std::vector<double> hyc((size_t)cv.NJ * cv.Sh * 2, 0.0);
+        for (int r = 0; r < S; ++r) {
+            const size_t q = rows.rowjob[r];
+            for (int k = 0; k < cv.Sh * 2; ++k) hyc[q * cv.Sh * 2 + k] += hy[(size_t)r * cv.Sh * 2 + k];
+        }
+        if ((rc = dev_put(ctx, hyc.data(), hyc.size(), &p))) return rc; cv.hy = (const cplx*)p;
+        ctx->p2_lds = fir_lds;
     }
     // ---- plain copies
     {
@@ -439,20 +475,9 @@ int jx_finalize(jx_ctx* ctx) {
 
     // ---- symmetric-map tables: d_mat[iy][ix] = Q[|iy-c|][|ix-c|] (what centdistmat builds)
     {
-        std::vector<double> dm = host_vec<double>(ctx, JX_T_D_MAT);
-        const int cc = S / 2, na = std::max(cc, S - 1 - cc) + 1;
-        std::vector<double> Q((size_t)na * na);
-        for (int b = 0; b < na; ++b)
-            for (int a = 0; a < na; ++a) {
-                const int iy = (cc + b < S) ? cc + b : cc - b, ix = (cc + a < S) ? cc + a : cc - a;
-                Q[(size_t)b * na + a] = dm[(size_t)iy * S + ix];
-            }
-        bool sym = true;
-        for (int iy = 0; iy < S && sym; ++iy)
-            for (int ix = 0; ix < S; ++ix) {
-                const double q = Q[(size_t)std::abs(iy - cc) * na + std::abs(ix - cc)];
-                if (memcmp(&q, &dm[(size_t)iy * S + ix], sizeof(double)) != 0) { sym = false; break; }
-            }
+        const int na = qn;
+        const std::vector<double>& Q = Qtab;
+        bool sym = dmat_mirror;
         if (const char* e = getenv("JOXSZ_GENERIC_MAP")) { if (atoi(e) > 0) sym = false; }
         if (na > 9 * 64) sym = false;                 // register-resident half row: |ix-c| < 576
         d.fast_map = sym ? 1 : 0;
@@ -479,10 +504,10 @@ int jx_finalize(jx_ctx* ctx) {
     // ---- chunk capacity and work buffers
     const size_t per_walker = (ctx->conv_mode == 1)
         ? sizeof(double) * ((size_t)P * P * 2 + (size_t)P * ctx->Ph * 2 + (size_t)S * ctx->Sh * 2)
-        : sizeof(double) * ((size_t)S * S + (size_t)S * ctx->Ph * 4 + (size_t)ctx->cv.nblk3 * ctx->Sh * 2);
+        : sizeof(double) * ((size_t)S * S + (size_t)(ctx->cv.NU + ctx->cv.NJ) * ctx->Ph * 2 + (size_t)ctx->cv.nblk3 * ctx->Sh * 2);
     d.img_ld = (ctx->conv_mode == 1) ? P : S;
     d.img_ws = (ctx->conv_mode == 1) ? (long long)P * P : (long long)S * S;
-    int chunk = c.max_batch > 0 ? c.max_batch : 512;
+    int chunk = c.max_batch > 0 ? c.max_batch : 1024;   // >= 4 map blocks per CU: launches desynchronise, stores overlap compute
     if (const char* e = getenv("JOXSZ_CHUNK")) { int v = atoi(e); if (v > 0) chunk = v; }
     const size_t budget = (size_t)24 << 30;
     while (chunk > 1 && per_walker * chunk > budget) chunk /= 2;
@@ -520,30 +545,18 @@ int jx_finalize(jx_ctx* ctx) {
     } else {
         const JxConv& cv = ctx->cv;
         if ((rc = dev_new(ctx, (size_t)chunk * S * S, &ctx->d_img))) return rc;
-        if ((rc = dev_new(ctx, (size_t)chunk * S * cv.Ph, &ctx->d_Y))) return rc;
-        if ((rc = dev_new(ctx, (size_t)chunk * S * cv.Ph, &ctx->d_C))) return rc;
+        if ((rc = dev_new(ctx, (size_t)chunk * cv.NU * cv.Ph, &ctx->d_Y))) return rc;
+        if ((rc = dev_new(ctx, (size_t)chunk * cv.NJ * cv.Ph, &ctx->d_C))) return rc;
         if ((rc = dev_new(ctx, (size_t)chunk * cv.nblk3 * cv.Sh, &ctx->d_part))) return rc;
-        if (!ctx->conv_v2) {
-            const int R = ctx->p13_rows;
-            ctx->p1_lds = sizeof(cplx) * ((size_t)2 * R * cv.LP + cv.LP);
-            ctx->p3_lds = sizeof(cplx) * ((size_t)2 * R * cv.LP + cv.LP + cv.LS);
-#define JX_ATTR13(LPv, LSv, Rv) if (cv.LP == LPv && cv.LS == LSv) { \
-                HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_rowfft_kernel<LPv, Rv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->p1_lds)); \
-                HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_rowtf_kernel<LPv, LSv, Rv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->p3_lds)); }
-            JX_CONV_PAIRS(JX_ATTR13)
-#undef JX_ATTR13
-            HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_beamfir_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->p2_lds));
-        } else {
 #define JX_ATTR2(LPv, LSv, R1v, R3v) if (cv.LP == LPv && cv.LS == LSv) { \
-                constexpr int rs1 = jx_lay<LPv>::RS, rs3 = jx_lay<LPv>::RS > jx_lay<LSv>::RS ? jx_lay<LPv>::RS : jx_lay<LSv>::RS; \
-                ctx->p1_lds = sizeof(cplx) * ((size_t)R1v * rs1 + LPv); \
-                ctx->p3_lds = sizeof(cplx) * ((size_t)R3v * rs3 + LPv + LSv); \
-                HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_rowfft2_kernel<LPv, R1v>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->p1_lds)); \
-                HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_rowtf2_kernel<LPv, LSv, R3v>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->p3_lds)); }
-            JX_CONV2_PAIRS(JX_ATTR2)
+            constexpr int rs1 = jx_lay<LPv>::RS, rs3 = jx_lay<LPv>::RS > jx_lay<LSv>::RS ? jx_lay<LPv>::RS : jx_lay<LSv>::RS; \
+            ctx->p1_lds = sizeof(cplx) * ((size_t)R1v * rs1 + LPv); \
+            ctx->p3_lds = sizeof(cplx) * ((size_t)R3v * rs3 + LPv + LSv); \
+            HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_rowfft2_kernel<LPv, R1v>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->p1_lds)); \
+            HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_rowtf2_kernel<LPv, LSv, R3v>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->p3_lds)); }
+        JX_CONV2_PAIRS(JX_ATTR2)
 #undef JX_ATTR2
-            HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_beamfir2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->p2_lds));
-        }
+        HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_beamfir_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->p2_lds));
     }
 
     FFTCHK(ctx, rocfft_execution_info_create(&ctx->info));
@@ -590,43 +603,27 @@ struct Taps {
 };
 
 
-static int launch_custom_conv(jx_ctx* ctx, int n, double* tap_conv, EvSet* es) {
+static int launch_custom_conv(jx_ctx* ctx, int n, double* tap_convjobs, EvSet* es) {
     const JxConv& cv = ctx->cv;
     const JxDev& d = ctx->d;
     hipStream_t st = ctx->stream;
     bool done = false;
-    if (ctx->conv_v2) {
-        const dim3 g1((cv.S + ctx->p1_rows - 1) / ctx->p1_rows, n), g3((cv.S + ctx->p13_rows - 1) / ctx->p13_rows, n);
+    const dim3 g1((cv.NU + ctx->p1_rows - 1) / ctx->p1_rows, n), g3(cv.nblk3, n);
 #define JX_P1(LPv, LSv, R1v, R3v) if (!done && cv.LP == LPv && cv.LS == LSv) { \
-            hipLaunchKernelGGL((jx_rowfft2_kernel<LPv, R1v>), g1, dim3(256), ctx->p1_lds, st, cv, ctx->d_img, (size_t)d.img_ld, (size_t)d.img_ws, ctx->d_Y); done = true; }
-        JX_CONV2_PAIRS(JX_P1)
+        hipLaunchKernelGGL((jx_rowfft2_kernel<LPv, R1v>), g1, dim3(256), ctx->p1_lds, st, cv, ctx->d_img, (size_t)d.img_ld, (size_t)d.img_ws, ctx->d_Y); done = true; }
+    JX_CONV2_PAIRS(JX_P1)
 #undef JX_P1
-        if (!done) { ctx->err = "no pass-1 kernel for this size"; return JX_ERR_UNSUPPORTED; }
-        const dim3 g2((cv.Ph + JX_FIR2_KX - 1) / JX_FIR2_KX, (cv.S + JX_FIR_TILE - 1) / JX_FIR_TILE, n);
-        hipLaunchKernelGGL(jx_beamfir2_kernel, g2, dim3(256), ctx->p2_lds, st, cv, ctx->d_Y, ctx->d_C);
-        if (es) HIPCHK(ctx, hipEventRecord(es->e[3], st));
-        done = false;
+    if (!done) { ctx->err = "no pass-1 kernel for this size"; return JX_ERR_UNSUPPORTED; }
+    const dim3 g2((cv.Ph + JX_FIR_KX - 1) / JX_FIR_KX, n);
+    hipLaunchKernelGGL(jx_beamfir_kernel, g2, dim3(256), ctx->p2_lds, st, cv, ctx->d_Y, ctx->d_C);
+    if (es) HIPCHK(ctx, hipEventRecord(es->e[3], st));
+    done = false;
 #define JX_P3(LPv, LSv, R1v, R3v) if (!done && cv.LP == LPv && cv.LS == LSv) { \
-            hipLaunchKernelGGL((jx_rowtf2_kernel<LPv, LSv, R3v>), g3, dim3(256), ctx->p3_lds, st, cv, ctx->d_C, ctx->d_part, tap_conv); done = true; }
-        JX_CONV2_PAIRS(JX_P3)
+        hipLaunchKernelGGL((jx_rowtf2_kernel<LPv, LSv, R3v>), g3, dim3(256), ctx->p3_lds, st, cv, ctx->d_C, ctx->d_part, tap_convjobs); done = true; }
+    JX_CONV2_PAIRS(JX_P3)
 #undef JX_P3
-    } else {
-        const int R = ctx->p13_rows;
-        const dim3 g13((cv.S + R - 1) / R, n);
-#define JX_P1(LPv, LSv, Rv) if (!done && cv.LP == LPv && cv.LS == LSv) { \
-            hipLaunchKernelGGL((jx_rowfft_kernel<LPv, Rv>), g13, dim3(256), ctx->p1_lds, st, cv, ctx->d_img, (size_t)d.img_ld, (size_t)d.img_ws, ctx->d_Y); done = true; }
-        JX_CONV_PAIRS(JX_P1)
-#undef JX_P1
-        if (!done) { ctx->err = "no pass-1 kernel for this size"; return JX_ERR_UNSUPPORTED; }
-        const dim3 g2((cv.Ph + 63) / 64, (cv.S + JX_FIR_TILE - 1) / JX_FIR_TILE, n);
-        hipLaunchKernelGGL(jx_beamfir_kernel, g2, dim3(512), ctx->p2_lds, st, cv, ctx->d_Y, ctx->d_C);
-        if (es) HIPCHK(ctx, hipEventRecord(es->e[3], st));
-        done = false;
-#define JX_P3(LPv, LSv, Rv) if (!done && cv.LP == LPv && cv.LS == LSv) { \
-            hipLaunchKernelGGL((jx_rowtf_kernel<LPv, LSv, Rv>), g13, dim3(256), ctx->p3_lds, st, cv, ctx->d_C, ctx->d_part, tap_conv); done = true; }
-        JX_CONV_PAIRS(JX_P3)
-#undef JX_P3
-    }
+    if (tap_convjobs)
+        hipLaunchKernelGGL(jx_expand_rows_kernel, dim3(cv.S, n), dim3(256), 0, st, tap_convjobs, ctx->d_rowjob, cv.S, cv.NJ, ctx->t_conv);
     if (es) HIPCHK(ctx, hipEventRecord(es->e[4], st));
     return JX_OK;
 }
@@ -758,6 +755,7 @@ static int ensure_taps(jx_ctx* ctx) {
     if ((rc = dev_new(ctx, C * std::max(1, c.nband * c.nann), &ctx->t_xprofs, true))) return rc;
     if ((rc = dev_new(ctx, C * 4, &ctx->t_parts, true))) return rc;
     if (ctx->conv_mode == 2 && (rc = dev_new(ctx, C * c.S * c.S, &ctx->t_conv))) return rc;
+    if (ctx->conv_mode == 2 && (rc = dev_new(ctx, C * ctx->cv.NJ * c.S, &ctx->t_convjobs))) return rc;
     return JX_OK;
 }
 
@@ -785,7 +783,7 @@ int jx_eval_stage(jx_ctx* ctx, const double* theta, int nwalkers, int stage, dou
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_theta, theta, sizeof(double) * (size_t)nwalkers * c.ndim, hipMemcpyHostToDevice, ctx->stream));
     Taps t;
     t.pp = ctx->t_pp; t.ab = ctx->t_ab; t.y = ctx->t_y; t.row = ctx->t_row; t.bright = ctx->t_bright;
-    t.conv = (stage == JX_STAGE_CONV2D) ? ctx->t_conv : nullptr;
+    t.conv = (stage == JX_STAGE_CONV2D) ? ctx->t_convjobs : nullptr;
     t.chisq = ctx->t_chisq; t.tprof = ctx->t_tprof; t.xprofs = c.sz_only ? nullptr : ctx->t_xprofs; t.parts = ctx->t_parts;
     for (int w0 = 0; w0 < nwalkers; w0 += ctx->chunk) {
         const int n = std::min(ctx->chunk, nwalkers - w0);

@@ -418,6 +418,65 @@ inline void tf_hy_table(const std::vector<double>& filt, int S, std::vector<doub
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Row bookkeeping of the hand-written convolution.
+//   mirror = true : map row m equals map row m' whenever |m - c| == |m' - c| (c = S/2), which is
+//                   what a d_mat built by centdistmat gives; otherwise every row is distinct.
+//   umap[m]  distinct-row index of map row m; urow[u] a map row carrying distinct row u.
+//   Conv row r = sum_m tap[|r-m|] * Y[umap[m]] over |r-m| <= o, 0 <= m < S.  Two conv rows are
+//   identical when their multisets of (umap[m], |r-m|) agree; each class becomes one job,
+//   represented by its largest row; jobs ascending; seg = maximal runs of consecutive rows.
+//   rowjob[r] = job of conv row r.
+// ---------------------------------------------------------------------------------------
+struct ConvRows {
+    std::vector<int> umap, urow, jrow, seg, rowjob;
+    int NU = 0, NJ = 0, nseg = 0;
+};
+
+inline void conv_row_tables(int S, int o, bool mirror, ConvRows& t) {
+    const int c = S / 2;
+    t.umap.assign(S, 0);
+    if (mirror) {
+        const int kmax = std::max(c, S - 1 - c);
+        t.NU = kmax + 1;
+        t.urow.assign(t.NU, 0);
+        for (int k = 0; k <= kmax; ++k) t.urow[k] = (c + k < S) ? c + k : c - k;
+        for (int m = 0; m < S; ++m) t.umap[m] = std::abs(m - c);
+    } else {
+        t.NU = S;
+        t.urow.resize(S);
+        for (int m = 0; m < S; ++m) { t.umap[m] = m; t.urow[m] = m; }
+    }
+    // signature of conv row r: sorted list of (u, t) pairs
+    std::vector<std::vector<long long>> sig(S);
+    for (int r = 0; r < S; ++r) {
+        for (int m = std::max(0, r - o); m <= std::min(S - 1, r + o); ++m)
+            sig[r].push_back((long long)t.umap[m] * 4096 + std::abs(r - m));
+        std::sort(sig[r].begin(), sig[r].end());
+    }
+    std::vector<int> rep(S);
+    for (int r = 0; r < S; ++r) {
+        rep[r] = r;
+        for (int r2 = S - 1; r2 > r; --r2)
+            if (sig[r2] == sig[r]) { rep[r] = r2; break; }
+    }
+    t.jrow.clear();
+    for (int r = 0; r < S; ++r) if (rep[r] == r) t.jrow.push_back(r);
+    t.NJ = (int)t.jrow.size();
+    std::vector<int> jobof(S, -1);
+    for (int q = 0; q < t.NJ; ++q) jobof[t.jrow[q]] = q;
+    t.rowjob.assign(S, 0);
+    for (int r = 0; r < S; ++r) t.rowjob[r] = jobof[rep[r]];
+    t.seg.clear();
+    for (int q = 0; q < t.NJ;) {
+        int e = q;
+        while (e + 1 < t.NJ && t.jrow[e + 1] == t.jrow[e] + 1) ++e;
+        t.seg.push_back(t.jrow[q]); t.seg.push_back(e - q + 1); t.seg.push_back(q);
+        q = e + 1;
+    }
+    t.nseg = (int)t.seg.size() / 3;
+}
+
 // supported (LS = S/2, LP = P/2) pairs of the hand-written convolution
 inline int custom_conv_lp(int S, int o) {
     static const int pairs[][2] = {{16, 18}, {24, 48}, {32, 48}, {64, 96}, {128, 144}, {256, 288}, {512, 576}};

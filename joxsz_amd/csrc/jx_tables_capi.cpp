@@ -93,6 +93,19 @@ int jxt_regfft(int n, int inv, double* re, double* im) {
 double jxt_cx_cos2pi(long long k, long long n) { return jx_cx_cos2pi(k, n); }
 double jxt_cx_sin2pi(long long k, long long n) { return jx_cx_sin2pi(k, n); }
 
+int jxt_conv_row_tables(int S, int o, int mirror, int* umap /*[S]*/, int* urow /*[S]*/, int* jrow /*[S]*/,
+                        int* rowjob /*[S]*/, int* seg /*[3*S]*/, int* counts /*[3]: NU, NJ, nseg*/) {
+    jxt::ConvRows t;
+    jxt::conv_row_tables(S, o, mirror != 0, t);
+    memcpy(umap, t.umap.data(), sizeof(int) * S);
+    memcpy(urow, t.urow.data(), sizeof(int) * t.NU);
+    memcpy(jrow, t.jrow.data(), sizeof(int) * t.NJ);
+    memcpy(rowjob, t.rowjob.data(), sizeof(int) * S);
+    memcpy(seg, t.seg.data(), sizeof(int) * t.seg.size());
+    counts[0] = t.NU; counts[1] = t.NJ; counts[2] = t.nseg;
+    return 0;
+}
+
 int jxt_custom_conv_lp(int S, int o) { return jxt::custom_conv_lp(S, o); }
 
 int jxt_next_smooth_even(int n) { return jxt::next_smooth_even(n); }

@@ -196,3 +196,24 @@ def test_custom_conv_refuses_what_it_cannot_do(golden_tiny):
     pb, _ = golden_tiny                                # S = 31: odd side
     with pytest.raises(JoxszHipError):
         _post(pb, conv='custom')
+
+
+def test_custom_conv_with_and_without_row_symmetry(monkeypatch):
+    """The row bookkeeping (distinct map rows, conv jobs) must not change any number:
+    identity tables (JOXSZ_CONV_NOSYM=1) against the mirrored ones, even and 'odd-like' cases."""
+    from joxsz_amd import datasets
+    for S, N in ((64, 80), (256, 300)):
+        pb = datasets.synthetic_problem(S=S, N=N, seed=9)
+        th = datasets.walker_ball(pb, 4, spread=0.04, seed=9)
+        res = {}
+        for nosym in ('0', '1'):
+            monkeypatch.setenv('JOXSZ_CONV_NOSYM', nosym)
+            post = _post(pb, conv='custom')
+            res[nosym] = (post.stage(th, 'conv_2d'), post.stage(th, 'map_row'), post.log_prob(th))
+            post.close()
+        monkeypatch.delenv('JOXSZ_CONV_NOSYM')
+        for a, b in zip(res['0'], res['1']):
+            np.testing.assert_allclose(a, b, rtol=1e-11, atol=1e-13 * np.abs(b).max())
+        st = orc.sz_stages(pb, orc.pars_dict(pb, th[0]))
+        assert _relerr(res['0'][0][0], st['conv_2d']) < RTOL_STAGE
+        assert _relerr(res['0'][1][0], st['map_row']) < RTOL_STAGE

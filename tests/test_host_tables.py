@@ -217,3 +217,32 @@ def test_register_fft(lib, n):
         re, im = np.ascontiguousarray(x.real), np.ascontiguousarray(x.imag)
         assert lib.jxt_regfft(n, inv, _p(re), _p(im)) == 0
         np.testing.assert_allclose(re + 1j * im, want, rtol=0, atol=2e-15 * n * np.abs(x).max())
+
+
+@pytest.mark.parametrize('S,o,mirror', [(31, 4, 1), (32, 4, 1), (64, 27, 1), (32, 4, 0), (171, 27, 1)])
+def test_conv_row_tables(lib, S, o, mirror):
+    """Jobs computed once must reproduce every conv row of a FIR over mirrored map rows."""
+    IP = ctypes.POINTER(ctypes.c_int)
+    umap, urow, jrow, rowjob = (np.zeros(S, np.int32) for _ in range(4))
+    seg, cnt = np.zeros(3 * S, np.int32), np.zeros(3, np.int32)
+    lib.jxt_conv_row_tables(S, o, mirror, *[a.ctypes.data_as(IP) for a in (umap, urow, jrow, rowjob, seg, cnt)])
+    NU, NJ, nseg = (int(v) for v in cnt)
+    rng = np.random.default_rng(S)
+    c = S // 2
+    if mirror:
+        base = rng.standard_normal(S)                 # one value per |m - c|
+        Y = np.array([base[abs(m - c)] for m in range(S)])
+        assert NU == max(c, S - 1 - c) + 1
+    else:
+        Y = rng.standard_normal(S)
+        assert NU == S and NJ == S and nseg == 1
+    np.testing.assert_array_equal(Y[urow[:NU]][umap], Y)             # distinct rows carry every row
+    tap = rng.standard_normal(o + 1)
+    conv = np.array([sum(tap[abs(r - m)] * Y[m] for m in range(max(0, r - o), min(S, r + o + 1))) for r in range(S)])
+    np.testing.assert_allclose(conv[jrow[:NJ]][rowjob], conv, rtol=1e-13, atol=1e-13)
+    segs = seg[:3 * nseg].reshape(-1, 3)
+    rows = np.concatenate([np.arange(a, a + n) for a, n, _ in segs])
+    np.testing.assert_array_equal(rows, jrow[:NJ])
+    assert all(q == sum(n for _, n, _ in segs[:i]) for i, (_, _, q) in enumerate(segs))
+    if mirror and S % 2 == 1:
+        assert NJ == c + 1 and nseg == 1                              # odd side: exact mirror, half the rows
