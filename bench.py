@@ -30,6 +30,27 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
+def pmc_traffic(kernel, walkers_per_launch, S):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC measurement
+    (scripts/measure_traffic.py -> profiles/*_pmc_traffic.json), rescaled to this launch size.
+    The counters cannot be read from inside the benchmark process; None when no file is there."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json')))
+    if not files:
+        return None
+    try:
+        j = json.load(open(files[-1]))
+        for name, d in j['kernels'].items():
+            if kernel in name:
+                per_walker = d['total_bytes'] / j.get('walkers_per_launch', 1024)
+                if j.get('S', 512) != S:
+                    return None
+                return per_walker * walkers_per_launch
+    except Exception:
+        return None
+    return None
+
+
 def _cpu_worker(args):
     pb, th = args
     from oracle import joxsz_oracle as orc
@@ -220,7 +241,8 @@ def main():
                        'walkers_per_gpu': W, 'S': S, 'N': args.N, 'B': pb.B, 'fft_pad': ctx.fft_pad,
                        'chunk': ctx.chunk, 'conv': ctx.conv, 'parallelism': 'walkers sharded x%d' % world, 'device': ctx.device_name},
             'roofline': {'kernel': 'jx_abel_map_sym_kernel', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                         'traffic': pmc_traffic('jx_abel_map', walkers_per_launch, S),
                          'launch_ms': k_ms, 'bytes_per_launch': alg_bytes},
             'cpu_baseline': cpu,
             'stage_ms_per_step': {k: tm[k] / args.steps for k in

@@ -63,6 +63,8 @@ struct jx_ctx {
     size_t p1_lds = 0, p2_lds = 0, p3_lds = 0;
     int p13_rows = 8, p1_rows = 8;
     int* d_rowjob = nullptr;
+    int* d_runs = nullptr;
+    int nrun = 0, fir_reg = 0;
     double* t_convjobs = nullptr;
     double* t_conv = nullptr;
     void* d_work = nullptr;
@@ -84,6 +86,9 @@ struct jx_ctx {
 };
 
 static int g_rocfft_refs = 0;
+
+// beam half-widths (B-1)/2 for which the register-window FIR is instantiated
+#define JX_FIR_REG_O(X) X(4) X(5) X(13) X(27)
 
 // two-level (register-blocked) forms: (LP, LS, rows per block in pass 1, rows per block in pass 3)
 #define JX_CONV2_PAIRS(X) X(18, 16, 42, 42) X(48, 24, 32, 32) X(48, 32, 32, 32) X(96, 64, 21, 21) X(144, 128, 21, 16) X(288, 256, 14, 14) X(576, 512, 10, 8)
@@ -299,7 +304,7 @@ int jx_finalize(jx_ctx* ctx) {
     if (want < 0 || want > 2) { ctx->err = "conv_mode must be 0, 1 or 2"; return JX_ERR_INVALID; }
     std::vector<double> beam_h = host_vec<double>(ctx, JX_T_BEAM_2D);
     const int lp_custom = jxt::custom_conv_lp(S, o);
-    const size_t fir_lds = sizeof(double) * ((size_t)2 * JX_FIR_RING * JX_FIR_KX + (size_t)(o + 1) * JX_FIR_KX);
+    const size_t fir_lds = sizeof(double) * ((size_t)2 * JX_FIR_RING * JX_FIR_KX + (size_t)(o + 1) * JX_FIR_KX) + sizeof(int) * (size_t)(S + 4);
     const bool eligible = lp_custom > 0 && jxt::beam_is_symmetric(beam_h, B) && JX_FIR_TILE + 2 * o <= JX_FIR_RING && c.fft_pad == 0;
     if (want == 2 && !eligible) {
         ctx->err = "hand-written convolution needs S/2 in {16,24,32,64,128,256,512}, a flip-symmetric beam with (B-1)/2 <= 32 and fft_pad = 0";
@@ -453,6 +458,25 @@ int jx_finalize(jx_ctx* ctx) {
         }
         if ((rc = dev_put(ctx, hyc.data(), hyc.size(), &p))) return rc; cv.hy = (const cplx*)p;
         ctx->p2_lds = fir_lds;
+        // runs of the register-window FIR: every segment cut into pieces of at most `runlen` conv rows
+        {
+            int runlen = 64;
+            if (const char* e = getenv("JOXSZ_FIR_RUN")) { int v2 = atoi(e); if (v2 >= 8) runlen = v2; }
+            std::vector<int> runs;
+            for (int sg = 0; sg < rows.nseg; ++sg) {
+                const int ra = rows.seg[3 * sg], cnt = rows.seg[3 * sg + 1], qa = rows.seg[3 * sg + 2];
+                const int pieces = (cnt + runlen - 1) / runlen, len = (cnt + pieces - 1) / pieces;
+                for (int t0 = 0; t0 < cnt; t0 += len) { runs.push_back(ra + t0); runs.push_back(std::min(len, cnt - t0)); runs.push_back(qa + t0); }
+            }
+            ctx->nrun = (int)runs.size() / 3;
+            int* q;
+            if ((rc = dev_put(ctx, runs.data(), runs.size(), &q))) return rc; ctx->d_runs = q;
+            ctx->fir_reg = 0;
+#define JX_HAS_O(Ov) if (o == Ov) ctx->fir_reg = 1;
+            JX_FIR_REG_O(JX_HAS_O)
+#undef JX_HAS_O
+            if (const char* e = getenv("JOXSZ_FIR_LDS")) { if (atoi(e) > 0) ctx->fir_reg = 0; }
+        }
     }
     // ---- plain copies
     {
@@ -614,8 +638,17 @@ static int launch_custom_conv(jx_ctx* ctx, int n, double* tap_convjobs, EvSet* e
     JX_CONV2_PAIRS(JX_P1)
 #undef JX_P1
     if (!done) { ctx->err = "no pass-1 kernel for this size"; return JX_ERR_UNSUPPORTED; }
-    const dim3 g2((cv.Ph + JX_FIR_KX - 1) / JX_FIR_KX, n);
-    hipLaunchKernelGGL(jx_beamfir_kernel, g2, dim3(256), ctx->p2_lds, st, cv, ctx->d_Y, ctx->d_C);
+    if (ctx->fir_reg) {
+        const int nslab = (2 * cv.Ph + 63) / 64, units = nslab * n;
+        const dim3 g2((unsigned)(((units + 7) / 8) * 8 * ctx->nrun));
+        const size_t sh = sizeof(int) * (size_t)(cv.S + 4);
+#define JX_FIRREG(Ov) if (cv.o == Ov) hipLaunchKernelGGL((jx_beamfir_reg_kernel<Ov>), g2, dim3(64), sh, st, cv, ctx->d_runs, ctx->nrun, n, ctx->d_Y, ctx->d_C);
+        JX_FIR_REG_O(JX_FIRREG)
+#undef JX_FIRREG
+    } else {
+        const dim3 g2((cv.Ph + JX_FIR_KX - 1) / JX_FIR_KX, n);
+        hipLaunchKernelGGL(jx_beamfir_kernel, g2, dim3(256), ctx->p2_lds, st, cv, ctx->d_Y, ctx->d_C);
+    }
     if (es) HIPCHK(ctx, hipEventRecord(es->e[3], st));
     done = false;
 #define JX_P3(LPv, LSv, R1v, R3v) if (!done && cv.LP == LPv && cv.LS == LSv) { \

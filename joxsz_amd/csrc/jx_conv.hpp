@@ -274,27 +274,49 @@ jx_beamfir_kernel(JxConv c, const cplx* __restrict__ Y, cplx* __restrict__ C) {
     const int o = c.o, Ph = c.Ph, S = c.S;
     cplx* ring = reinterpret_cast<cplx*>(sm);                         // [128][32]
     double* taps = sm + (size_t)2 * JX_FIR_RING * JX_FIR_KX;          // [o+1][32]
+    int* s_umap = reinterpret_cast<int*>(taps + (size_t)(o + 1) * JX_FIR_KX);   // [S]
     const int tid = threadIdx.x;
     const int lx = tid & 31, grp = tid >> 5;
     const int kx = blockIdx.x * JX_FIR_KX + lx, w = blockIdx.y;
     const bool kok = kx < Ph;
-    const cplx* Yw = Y + (size_t)w * c.NU * Ph;
-    cplx* Cw = C + (size_t)w * c.NJ * Ph;
+    const cplx* Yw = Y + (size_t)w * c.NU * Ph + kx;
+    cplx* Cw = C + (size_t)w * c.NJ * Ph + kx;
     for (int t = grp; t <= o; t += 8) taps[t * JX_FIR_KX + lx] = kok ? c.taps[(size_t)t * Ph + kx] : 0.0;
+    for (int m = tid; m < S; m += 256) s_umap[m] = c.umap[m];
     const int nin = JX_FIR_TILE + 2 * o;
+    constexpr int NPRE = JX_FIR_TILE / 8;                             // rows each group fetches per chunk
+    const cplx zero = make_double2(0.0, 0.0);
 
     for (int sg = 0; sg < c.nseg; ++sg) {
         const int ra = c.seg[3 * sg], cnt = c.seg[3 * sg + 1], qa = c.seg[3 * sg + 2];
         const int base = ra - o;                                      // map row held by ring slot 0 (mod 128)
-        __syncthreads();                                              // previous segment fully consumed
-        for (int rr = grp; rr < nin; rr += 8) {
-            const int m = base + rr;
-            cplx v = make_double2(0.0, 0.0);
-            if (kok && m >= 0 && m < S) v = Yw[(size_t)c.umap[m] * Ph + kx];
-            ring[(rr & (JX_FIR_RING - 1)) * JX_FIR_KX + lx] = v;
+        __syncthreads();                                              // previous segment consumed; s_umap ready
+        // prime the ring with the first nin rows: two batches of independent loads
+        for (int rr0 = 0; rr0 < nin; rr0 += 8 * NPRE) {
+            cplx pre[NPRE];
+#pragma unroll
+            for (int u = 0; u < NPRE; ++u) {
+                const int rr = rr0 + grp + 8 * u, m = base + rr;
+                pre[u] = (kok && rr < nin && m >= 0 && m < S) ? Yw[(size_t)s_umap[m] * Ph] : zero;
+            }
+#pragma unroll
+            for (int u = 0; u < NPRE; ++u) {
+                const int rr = rr0 + grp + 8 * u;
+                if (rr < nin) ring[(rr & (JX_FIR_RING - 1)) * JX_FIR_KX + lx] = pre[u];
+            }
         }
         __syncthreads();
         for (int t0 = 0; t0 < cnt; t0 += JX_FIR_TILE) {               // t0: first output of the chunk, segment-relative
+            const bool more = t0 + JX_FIR_TILE < cnt;
+            // the next chunk's 64 input rows are requested now and land in registers while this chunk computes
+            cplx pre[NPRE];
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < NPRE; ++u) {
+                    const int m = base + t0 + nin + grp + 8 * u;
+                    pre[u] = (kok && m >= 0 && m < S) ? Yw[(size_t)s_umap[m] * Ph] : zero;
+                }
+            }
             const int rb = t0 + grp * JX_FIR_NR;                      // this thread's first output, segment-relative
             if (rb < cnt) {
                 double ar[JX_FIR_NR], ai[JX_FIR_NR], tp[JX_FIR_NR];
@@ -328,22 +350,116 @@ jx_beamfir_kernel(JxConv c, const cplx* __restrict__ Y, cplx* __restrict__ C) {
                 if (kok) {
 #pragma unroll
                     for (int j = 0; j < JX_FIR_NR; ++j)
-                        if (rb + j < cnt) Cw[(size_t)(qa + rb + j) * Ph + kx] = make_double2(ar[j], ai[j]);
+                        if (rb + j < cnt) Cw[(size_t)(qa + rb + j) * Ph] = make_double2(ar[j], ai[j]);
                 }
             }
-            if (t0 + JX_FIR_TILE < cnt) {                             // bring in the next 64 input rows
-                __syncthreads();
-                for (int rr = grp; rr < JX_FIR_TILE; rr += 8) {
-                    const int off = t0 + nin + rr;                    // offset from base
-                    const int m = base + off;
-                    cplx v = make_double2(0.0, 0.0);
-                    if (kok && m >= 0 && m < S) v = Yw[(size_t)c.umap[m] * Ph + kx];
-                    ring[(off & (JX_FIR_RING - 1)) * JX_FIR_KX + lx] = v;
+            if (more) {
+                __syncthreads();                                      // everyone done reading the rows about to be replaced
+#pragma unroll
+                for (int u = 0; u < NPRE; ++u) {
+                    const int off = t0 + nin + grp + 8 * u;
+                    ring[(off & (JX_FIR_RING - 1)) * JX_FIR_KX + lx] = pre[u];
                 }
                 __syncthreads();
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------
+// pass 2, register form (beam half-width O known at compile time).  The taps are real, so
+// the real and imaginary parts of a spectrum column are two independent real series: the
+// [row][kx] complex arrays are read as [row][2 Ph] doubles and one lane owns one such
+// column.  A wave = 64 adjacent columns of one run of consecutive conv jobs.  The 2O+1 most
+// recent inputs live in registers (a window whose slot NAMES rotate with the unrolled phase,
+// so nothing is ever moved), the O+1 taps of the lane's kx too; each output costs one
+// coalesced 512-byte row load, requested DEPTH rows ahead, and 2O+1 FMAs.  No LDS traffic in
+// the loop, no barrier.  1-D grid of ceil(slabs * walkers / 8) * 8 * runs workgroups of 64 threads.
+//   runs [nrun][3]: first conv row, number of rows, first job
+// ------------------------------------------------------------------------------------
+template <int W> constexpr int jx_fir_depth() {
+    for (int d = 8; d < W; ++d) if (W % d == 0) return d;      // rows requested ahead: >= 8 phases of FMAs cover an HBM miss
+    return W;
+}
+
+template <int O, int PH>
+struct jx_fir_phase {
+    static constexpr int W = 2 * O + 1;
+    // one output: the newest input (map row r + O) enters slot PH; input i = 0..2O sits in slot (PH + 1 + i) % W
+    template <int I>
+    static __device__ __forceinline__ void acc(const double (&win)[W], const double (&tap)[O + 1], double (&a)[4]) {
+        if constexpr (I < W) {
+            constexpr int slot = (PH + 1 + I) % W;
+            constexpr int t = I < O ? O - I : I - O;
+            a[I & 3] = fma(tap[t], win[slot], a[I & 3]);
+            acc<I + 1>(win, tap, a);
+        }
+    }
+};
+
+template <int O, int PH>
+__device__ __forceinline__ void jx_fir_run_phases(double (&win)[2 * O + 1], double (&fifo)[jx_fir_depth<2 * O + 1>()],
+                                                  const double (&tap)[O + 1], const int* s_umap, const double* Yw, double* Cw,
+                                                  int ld, int S, bool ok, int r /*conv row of phase 0*/, int q /*job of phase 0*/,
+                                                  int nleft) {
+    constexpr int W = 2 * O + 1, D = jx_fir_depth<W>();
+    if constexpr (PH < W) {
+        if (PH < nleft) {
+            win[PH] = fifo[PH % D];                                   // map row r + PH + O, requested D phases ago
+            const int mn = r + PH + O + D;                            // request the row needed D phases from now
+            fifo[PH % D] = (ok && mn >= 0 && mn < S) ? Yw[(size_t)s_umap[mn] * ld] : 0.0;
+            double a[4] = {0.0, 0.0, 0.0, 0.0};
+            jx_fir_phase<O, PH>::template acc<0>(win, tap, a);
+            if (ok) Cw[(size_t)(q + PH) * ld] = (a[0] + a[1]) + (a[2] + a[3]);
+            jx_fir_run_phases<O, PH + 1>(win, fifo, tap, s_umap, Yw, Cw, ld, S, ok, r, q, nleft);
+        }
+    }
+}
+
+template <int O>
+__global__ void __launch_bounds__(64)
+jx_beamfir_reg_kernel(JxConv c, const int* __restrict__ runs, int nrun, int nwalk, const cplx* __restrict__ Y,
+                      cplx* __restrict__ C) {
+    constexpr int W = 2 * O + 1, D = jx_fir_depth<W>();
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    int* s_umap = reinterpret_cast<int*>(sm);                         // [S]
+    const int lane = threadIdx.x, S = c.S, ld = 2 * c.Ph;
+    // XCD-aware decode of the 1-D grid: workgroups are dealt round-robin over the 8 XCDs, so ids that agree
+    // mod 8 share an L2.  All runs of one (walker, column slab) unit get the same id mod 8 and consecutive
+    // id / 8, so the 2O halo rows two neighbouring runs both read are served by that L2 (speed only).
+    const int nslab = (ld + 63) / 64;
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int unit = (seq / nrun) * 8 + xcd, run = seq - (seq / nrun) * nrun;
+    if (unit >= nslab * nwalk) return;
+    const int w = unit / nslab, slab = unit - w * nslab;
+    const int col = slab * 64 + lane;                                 // column of the [row][2 Ph] double view
+    const bool ok = col < ld;
+    const int r0 = runs[3 * run], cnt = runs[3 * run + 1], q0 = runs[3 * run + 2];
+    for (int m = lane; m < S; m += 64) s_umap[m] = c.umap[m];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const double* Yw = reinterpret_cast<const double*>(Y) + (size_t)w * c.NU * ld + col;
+    double* Cw = reinterpret_cast<double*>(C) + (size_t)w * c.NJ * ld + col;
+    double tap[O + 1];
+#pragma unroll
+    for (int t = 0; t <= O; ++t) tap[t] = ok ? c.taps[(size_t)t * c.Ph + (col >> 1)] : 0.0;
+    double win[W], fifo[D];
+    // window before phase 0 of conv row r0: input i (map row r0 - O + i), i = 0..2O-1, sits in slot (1 + i) % W;
+    // the row r0 + O (i = 2O) arrives through the fifo at phase 0, then r0+O+1.. for the following phases
+#pragma unroll
+    for (int i = 0; i < 2 * O; ++i) {
+        const int m = r0 - O + i;
+        win[(1 + i) % W] = (ok && m >= 0 && m < S) ? Yw[(size_t)s_umap[m] * ld] : 0.0;
+    }
+    win[0] = 0.0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const int m = r0 + O + d;
+        fifo[d] = (ok && m >= 0 && m < S) ? Yw[(size_t)s_umap[m] * ld] : 0.0;
+    }
+    for (int t0 = 0; t0 < cnt; t0 += W)
+        jx_fir_run_phases<O, 0>(win, fifo, tap, s_umap, Yw, Cw, ld, S, ok, r0 + t0, q0 + t0, cnt - t0);
 }
 
 // expand job rows to the full S x S beam-convolved map (parity tap only)

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""HBM traffic of every kernel of one bench step from rocprofv3 PMC counters.
+
+Runs bench.py twice under rocprofv3 (FETCH_SIZE and WRITE_SIZE need separate passes: the TCC
+block has 4 slots, FETCH_SIZE takes 3 and WRITE_SIZE 2 -- MI355X_MICROARCH.md "rocprofv3 PMC
+slots"), averages the counters over the full-size dispatches of each kernel, applies the gfx950
+correction of the same guide (FETCH_SIZE reports half the bytes of a wide coalesced read stream;
+WRITE_SIZE is exact for 16-byte-per-lane streaming stores; both are in KiB) and writes
+profiles/<tag>_pmc_traffic.json, which bench.py quotes in roofline.traffic.
+
+    python scripts/measure_traffic.py r01        (on the GPU box, from the repo root)
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def collect(counter, outdir):
+    cmd = ['rocprofv3', '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', outdir, '--',
+           sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '1', '--no-cpu']
+    env = dict(os.environ, TMPDIR='/tmp')
+    res = subprocess.run(cmd, check=True, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+    collect.bench = json.loads(res.stdout.strip().splitlines()[-1])
+    f = glob.glob(outdir + '/*/*counter_collection.csv')[0]
+    rows = list(csv.DictReader(open(f)))
+    big = collections.defaultdict(int)
+    for r in rows:
+        big[r['Kernel_Name']] = max(big[r['Kernel_Name']], int(r['Grid_Size']))
+    acc = collections.defaultdict(list)
+    for r in rows:
+        if r['Counter_Name'] == counter and int(r['Grid_Size']) == big[r['Kernel_Name']]:
+            acc[r['Kernel_Name']].append(float(r['Counter_Value']))
+    return {k: sum(v) / len(v) for k, v in acc.items() if not k.startswith('__amd')}
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+    scratch = os.path.join(ROOT, 'gpurun_out', 'traffic_' + tag)
+    fetch = collect('FETCH_SIZE', scratch + '_fetch')
+    write = collect('WRITE_SIZE', scratch + '_write')
+    cfg = collect.bench['config']
+    out = {'unit': 'bytes per launch', 'S': cfg['S'], 'N': cfg['N'], 'walkers_per_launch': cfg['chunk'], 'conv': cfg['conv'],
+           'command': 'rocprofv3 --kernel-trace --pmc <FETCH_SIZE|WRITE_SIZE> -- python3 bench.py --steps 3 --warmup 1 --no-cpu', 'note': 'FETCH_SIZE KiB x 1024 x 2 (gfx950 wide-read correction), WRITE_SIZE KiB x 1024',
+           'kernels': {}}
+    for k in sorted(set(fetch) | set(write)):
+        rd = fetch.get(k, 0.0) * 1024 * 2
+        wr = write.get(k, 0.0) * 1024
+        out['kernels'][k.split('(')[0].strip()] = {'read_bytes': rd, 'write_bytes': wr, 'total_bytes': rd + wr,
+                                                     'fetch_size_kib_raw': fetch.get(k, 0.0), 'write_size_kib_raw': write.get(k, 0.0)}
+    path = os.path.join(ROOT, 'gpurun_out', '%s_pmc_traffic.json' % tag)
+    json.dump(out, open(path, 'w'), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == '__main__':
+    main()
