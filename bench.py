@@ -128,13 +128,15 @@ def main():
     cpu = None
     cpu_sample = cpu_logp = None
     if rank == 0 and args.gpus == 1 and not args.no_cpu:
-        th_cpu = datasets.walker_ball(pb, 4096, spread=0.02, seed=11)
+        th_cpu = datasets.walker_ball(pb, 16384, spread=0.02, seed=11)
         # the data the walkers are scored against do not change the cost; use the placeholder data
         cpu, cpu_sample, cpu_logp = cpu_baseline(pb, th_cpu, args.cpu_seconds)
 
     dist = None
     torch = None
-    if args.gpus > 1:
+    if args.gpus > 1 or os.environ.get('JOXSZ_BENCH_FORCE_DIST'):      # the env switch rehearses the N>1 plumbing at N=1
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)

@@ -220,7 +220,7 @@ int jx_create(const jx_config* cfg, jx_ctx** out) {
     if (hipSetDevice(c.device) != hipSuccess) { delete ctx; return JX_ERR_NODEVICE; }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, c.device) != hipSuccess) { delete ctx; return JX_ERR_NODEVICE; }
-    ctx->devname = std::string(prop.name) + " (" + prop.gcnArchName + ")";
+    ctx->devname = std::string(prop.name[0] ? prop.name : "AMD GPU") + " (" + prop.gcnArchName + ", " + std::to_string(prop.multiProcessorCount) + " CUs)";
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return JX_ERR_HIP; }
     if (g_rocfft_refs++ == 0) rocfft_setup();
     *out = ctx;

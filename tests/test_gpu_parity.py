@@ -217,3 +217,17 @@ def test_custom_conv_with_and_without_row_symmetry(monkeypatch):
         st = orc.sz_stages(pb, orc.pars_dict(pb, th[0]))
         assert _relerr(res['0'][0][0], st['conv_2d']) < RTOL_STAGE
         assert _relerr(res['0'][1][0], st['map_row']) < RTOL_STAGE
+
+
+def test_largest_config_shape():
+    """BASELINE configs[4] shape (S=1024, N=1000): two walkers against the oracle, both back ends."""
+    from joxsz_amd import datasets
+    pb = datasets.synthetic_problem(S=1024, N=1000, seed=4)
+    th = datasets.walker_ball(pb, 2, spread=0.02, seed=4)
+    want = orc.log_posterior_batch(pb, th)
+    assert np.isfinite(want).all()
+    for conv in ('custom', 'rocfft'):
+        post = _post(pb, conv=conv, max_batch=2)
+        got = post.log_prob(th)
+        post.close()
+        np.testing.assert_allclose(got, want, rtol=RTOL)
