@@ -110,6 +110,7 @@ def main():
     ap.add_argument('--sz-only', action='store_true')
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
+    ap.add_argument('--fwhm', type=float, default=18.5, help='beam FWHM in arcsec (B = 2*floor(3*fwhm/step)+1)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -121,7 +122,7 @@ def main():
         args.gpus = world
 
     from joxsz_amd import datasets
-    pb = datasets.synthetic_problem(S=args.S, N=args.N, seed=0, sz_only=args.sz_only)
+    pb = datasets.synthetic_problem(S=args.S, N=args.N, seed=0, sz_only=args.sz_only, fwhm=args.fwhm)
     W = args.walkers
 
     # ---- CPU baseline first: it forks, which must happen before HIP is initialised ----
@@ -160,8 +161,9 @@ def main():
 
     # ---- synthetic observations from the model itself at the fiducial vector, then the walker ball ----
     t0 = datasets.fiducial_theta(pb)
-    bright = ctx.eval_stage(t0, 'bright')[0]
-    xprofs = None if pb.sz_only else ctx.eval_stage(t0, 'xprofs')[0]
+    t0w = np.repeat(t0[None, :], W, axis=0)              # full-size launches only: the rocprof averages stay comparable
+    bright = ctx.eval_stage(t0w, 'bright')[0]
+    xprofs = None if pb.sz_only else ctx.eval_stage(t0w, 'xprofs')[0]
     post.close()
     datasets.fill_data(pb, bright, xprofs, seed=0)
     post = JoxszPosterior(pb, device=local_rank)

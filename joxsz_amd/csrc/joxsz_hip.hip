@@ -787,8 +787,6 @@ static int ensure_taps(jx_ctx* ctx) {
     if ((rc = dev_new(ctx, C, &ctx->t_chisq))) return rc;
     if ((rc = dev_new(ctx, C * std::max(1, c.nband * c.nann), &ctx->t_xprofs, true))) return rc;
     if ((rc = dev_new(ctx, C * 4, &ctx->t_parts, true))) return rc;
-    if (ctx->conv_mode == 2 && (rc = dev_new(ctx, C * c.S * c.S, &ctx->t_conv))) return rc;
-    if (ctx->conv_mode == 2 && (rc = dev_new(ctx, C * ctx->cv.NJ * c.S, &ctx->t_convjobs))) return rc;
     return JX_OK;
 }
 
@@ -812,6 +810,10 @@ int jx_eval_stage(jx_ctx* ctx, const double* theta, int nwalkers, int stage, dou
     HIPCHK(ctx, hipSetDevice(c.device));
     int rc;
     if ((rc = ensure_taps(ctx))) return rc;
+    if (stage == JX_STAGE_CONV2D && ctx->conv_mode == 2 && !ctx->t_conv) {          // the big ones only when asked for
+        if ((rc = dev_new(ctx, (size_t)ctx->chunk * S * S, &ctx->t_conv))) return rc;
+        if ((rc = dev_new(ctx, (size_t)ctx->chunk * ctx->cv.NJ * S, &ctx->t_convjobs))) return rc;
+    }
     if ((rc = ensure_batch(ctx, nwalkers))) return rc;
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_theta, theta, sizeof(double) * (size_t)nwalkers * c.ndim, hipMemcpyHostToDevice, ctx->stream));
     Taps t;

@@ -377,8 +377,11 @@ jx_beamfir_kernel(JxConv c, const cplx* __restrict__ Y, cplx* __restrict__ C) {
 // the loop, no barrier.  1-D grid of ceil(slabs * walkers / 8) * 8 * runs workgroups of 64 threads.
 //   runs [nrun][3]: first conv row, number of rows, first job
 // ------------------------------------------------------------------------------------
+#ifndef JX_FIR_MIN_DEPTH
+#define JX_FIR_MIN_DEPTH 8
+#endif
 template <int W> constexpr int jx_fir_depth() {
-    for (int d = 8; d < W; ++d) if (W % d == 0) return d;      // rows requested ahead: >= 8 phases of FMAs cover an HBM miss
+    for (int d = JX_FIR_MIN_DEPTH; d < W; ++d) if (W % d == 0) return d;      // rows requested ahead (must divide W)
     return W;
 }
 
@@ -387,11 +390,11 @@ struct jx_fir_phase {
     static constexpr int W = 2 * O + 1;
     // one output: the newest input (map row r + O) enters slot PH; input i = 0..2O sits in slot (PH + 1 + i) % W
     template <int I>
-    static __device__ __forceinline__ void acc(const double (&win)[W], const double (&tap)[O + 1], double (&a)[4]) {
+    static __device__ __forceinline__ void acc(const double (&win)[W], const double (&tap)[O + 1], double (&a)[8]) {
         if constexpr (I < W) {
             constexpr int slot = (PH + 1 + I) % W;
             constexpr int t = I < O ? O - I : I - O;
-            a[I & 3] = fma(tap[t], win[slot], a[I & 3]);
+            a[I & 7] = fma(tap[t], win[slot], a[I & 7]);
             acc<I + 1>(win, tap, a);
         }
     }
@@ -400,18 +403,18 @@ struct jx_fir_phase {
 template <int O, int PH>
 __device__ __forceinline__ void jx_fir_run_phases(double (&win)[2 * O + 1], double (&fifo)[jx_fir_depth<2 * O + 1>()],
                                                   const double (&tap)[O + 1], const int* s_umap, const double* Yw, double* Cw,
-                                                  int ld, int S, bool ok, int r /*conv row of phase 0*/, int q /*job of phase 0*/,
-                                                  int nleft) {
+                                                  int ld, int S, bool ok, bool okst, int r /*conv row of phase 0*/,
+                                                  int q /*job of phase 0*/, int nleft) {
     constexpr int W = 2 * O + 1, D = jx_fir_depth<W>();
     if constexpr (PH < W) {
         if (PH < nleft) {
             win[PH] = fifo[PH % D];                                   // map row r + PH + O, requested D phases ago
             const int mn = r + PH + O + D;                            // request the row needed D phases from now
             fifo[PH % D] = (ok && mn >= 0 && mn < S) ? Yw[(size_t)s_umap[mn] * ld] : 0.0;
-            double a[4] = {0.0, 0.0, 0.0, 0.0};
+            double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
             jx_fir_phase<O, PH>::template acc<0>(win, tap, a);
-            if (ok) Cw[(size_t)(q + PH) * ld] = (a[0] + a[1]) + (a[2] + a[3]);
-            jx_fir_run_phases<O, PH + 1>(win, fifo, tap, s_umap, Yw, Cw, ld, S, ok, r, q, nleft);
+            if (okst) Cw[(size_t)(q + PH) * ld] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+            jx_fir_run_phases<O, PH + 1>(win, fifo, tap, s_umap, Yw, Cw, ld, S, ok, okst, r, q, nleft);
         }
     }
 }
@@ -459,7 +462,7 @@ jx_beamfir_reg_kernel(JxConv c, const int* __restrict__ runs, int nrun, int nwal
         fifo[d] = (ok && m >= 0 && m < S) ? Yw[(size_t)s_umap[m] * ld] : 0.0;
     }
     for (int t0 = 0; t0 < cnt; t0 += W)
-        jx_fir_run_phases<O, 0>(win, fifo, tap, s_umap, Yw, Cw, ld, S, ok, r0 + t0, q0 + t0, cnt - t0);
+        jx_fir_run_phases<O, 0>(win, fifo, tap, s_umap, Yw, Cw, ld, S, ok, ok, r0 + t0, q0 + t0, cnt - t0);
 }
 
 // expand job rows to the full S x S beam-convolved map (parity tap only)

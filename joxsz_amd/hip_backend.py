@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libjoxsz_hip.so')
+LIB_PATH = os.environ.get('JOXSZ_LIB') or os.path.join(_HERE, 'csrc', 'libjoxsz_hip.so')    # JOXSZ_LIB: A/B builds
 ABI_VERSION = 1
 
 # must list every function include/joxsz_hip.h declares (tests/test_abi.py checks this)
