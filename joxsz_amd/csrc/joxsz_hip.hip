@@ -88,7 +88,7 @@ struct jx_ctx {
 static int g_rocfft_refs = 0;
 
 // beam half-widths (B-1)/2 for which the register-window FIR is instantiated
-#define JX_FIR_REG_O(X) X(4) X(5) X(13) X(27)
+#define JX_FIR_REG_O(X) X(4) X(5) X(13) X(27)          // all >= 4: the FIR's 8 accumulator chains need 2O+1 >= 8
 
 // two-level (register-blocked) forms: (LP, LS, rows per block in pass 1, rows per block in pass 3)
 #define JX_CONV2_PAIRS(X) X(18, 16, 42, 42) X(48, 24, 32, 32) X(48, 32, 32, 32) X(96, 64, 21, 21) X(144, 128, 21, 16) X(288, 256, 14, 14) X(576, 512, 10, 8)
@@ -430,7 +430,7 @@ int jx_finalize(jx_ctx* ctx) {
         if (const char* e = getenv("JOXSZ_CONV_NOSYM")) { if (atoi(e) > 0) use_mirror = false; }
         jxt::ConvRows rows;
         jxt::conv_row_tables(S, o, use_mirror, rows);
-        cv.NU = rows.NU; cv.NJ = rows.NJ; cv.nseg = rows.nseg;
+        cv.NU = rows.NU; cv.NJ = rows.NJ; cv.nseg = rows.nseg; cv.CROWS = rows.NJ + 1; cv.mirror = use_mirror ? 1 : 0;
         cv.nblk3 = (cv.NJ + ctx->p13_rows - 1) / ctx->p13_rows;
         {
             int* q;
@@ -460,7 +460,7 @@ int jx_finalize(jx_ctx* ctx) {
         ctx->p2_lds = fir_lds;
         // runs of the register-window FIR: every segment cut into pieces of at most `runlen` conv rows
         {
-            int runlen = 64;
+            int runlen = 128;
             if (const char* e = getenv("JOXSZ_FIR_RUN")) { int v2 = atoi(e); if (v2 >= 8) runlen = v2; }
             std::vector<int> runs;
             for (int sg = 0; sg < rows.nseg; ++sg) {
@@ -528,7 +528,7 @@ int jx_finalize(jx_ctx* ctx) {
     // ---- chunk capacity and work buffers
     const size_t per_walker = (ctx->conv_mode == 1)
         ? sizeof(double) * ((size_t)P * P * 2 + (size_t)P * ctx->Ph * 2 + (size_t)S * ctx->Sh * 2)
-        : sizeof(double) * ((size_t)S * S + (size_t)(ctx->cv.NU + ctx->cv.NJ) * ctx->Ph * 2 + (size_t)ctx->cv.nblk3 * ctx->Sh * 2);
+        : sizeof(double) * ((size_t)S * S + (size_t)(ctx->cv.NU + ctx->cv.CROWS) * ctx->Ph * 2 + (size_t)ctx->cv.nblk3 * ctx->Sh * 2);
     d.img_ld = (ctx->conv_mode == 1) ? P : S;
     d.img_ws = (ctx->conv_mode == 1) ? (long long)P * P : (long long)S * S;
     int chunk = c.max_batch > 0 ? c.max_batch : 1024;   // >= 4 map blocks per CU: launches desynchronise, stores overlap compute
@@ -570,7 +570,7 @@ int jx_finalize(jx_ctx* ctx) {
         const JxConv& cv = ctx->cv;
         if ((rc = dev_new(ctx, (size_t)chunk * S * S, &ctx->d_img))) return rc;
         if ((rc = dev_new(ctx, (size_t)chunk * cv.NU * cv.Ph, &ctx->d_Y))) return rc;
-        if ((rc = dev_new(ctx, (size_t)chunk * cv.NJ * cv.Ph, &ctx->d_C))) return rc;
+        if ((rc = dev_new(ctx, (size_t)chunk * cv.CROWS * cv.Ph, &ctx->d_C))) return rc;
         if ((rc = dev_new(ctx, (size_t)chunk * cv.nblk3 * cv.Sh, &ctx->d_part))) return rc;
 #define JX_ATTR2(LPv, LSv, R1v, R3v) if (cv.LP == LPv && cv.LS == LSv) { \
             constexpr int rs1 = jx_lay<LPv>::RS, rs3 = jx_lay<LPv>::RS > jx_lay<LSv>::RS ? jx_lay<LPv>::RS : jx_lay<LSv>::RS; \
@@ -641,8 +641,7 @@ static int launch_custom_conv(jx_ctx* ctx, int n, double* tap_convjobs, EvSet* e
     if (ctx->fir_reg) {
         const int nslab = (2 * cv.Ph + 63) / 64, units = nslab * n;
         const dim3 g2((unsigned)(((units + 7) / 8) * 8 * ctx->nrun));
-        const size_t sh = sizeof(int) * (size_t)(cv.S + 4);
-#define JX_FIRREG(Ov) if (cv.o == Ov) hipLaunchKernelGGL((jx_beamfir_reg_kernel<Ov>), g2, dim3(64), sh, st, cv, ctx->d_runs, ctx->nrun, n, ctx->d_Y, ctx->d_C);
+#define JX_FIRREG(Ov) if (cv.o == Ov) hipLaunchKernelGGL((jx_beamfir_reg_kernel<Ov>), g2, dim3(64), 0, st, cv, ctx->d_runs, ctx->nrun, n, ctx->d_Y, ctx->d_C);
         JX_FIR_REG_O(JX_FIRREG)
 #undef JX_FIRREG
     } else {

@@ -43,6 +43,8 @@ struct JxConv {
     int S, Sh, B, o, P, Ph, LP, LS;
     int ntap;                       // o + 1
     int NU, NJ, nseg;               // distinct map rows, conv jobs, contiguous job segments
+    int CROWS;                      // rows per walker in C: NJ + 1 (one spare row for store overshoot)
+    int mirror;                     // 1: umap[m] = |m - S/2| (mirror structure), 0: umap[m] = m
     int nblk3;                      // pass-3 blocks per walker (partials to sum in the tail)
     const cplx* tw_lp;              // [LP]   exp(-2 pi i n / LP)
     const cplx* tw_ls;              // [LS]   exp(-2 pi i n / LS)
@@ -183,7 +185,7 @@ jx_rowtf2_kernel(JxConv c, const cplx* __restrict__ C, cplx* __restrict__ part, 
     // Z[k] = (X[k] + conj X[LP-k]) + i e^{+2 pi i k/P} (X[k] - conj X[LP-k]) into the padded layout of n = k
     for (int e = tid; e < nrows * LP; e += nth) {
         const int row = e / LP, k = e - row * LP;
-        const cplx* Xr = C + ((size_t)w * NJ + r0 + row) * Ph;
+        const cplx* Xr = C + ((size_t)w * c.CROWS + r0 + row) * Ph;
         const cplx xk = Xr[k], xc = c_conj(Xr[LP - k]);
         const cplx s = c_add(xk, xc), d = c_mulc(c_sub(xk, xc), c.tw_p[k]);
         const int n1 = k / P2, n2 = k - n1 * P2;
@@ -280,7 +282,7 @@ jx_beamfir_kernel(JxConv c, const cplx* __restrict__ Y, cplx* __restrict__ C) {
     const int kx = blockIdx.x * JX_FIR_KX + lx, w = blockIdx.y;
     const bool kok = kx < Ph;
     const cplx* Yw = Y + (size_t)w * c.NU * Ph + kx;
-    cplx* Cw = C + (size_t)w * c.NJ * Ph + kx;
+    cplx* Cw = C + (size_t)w * c.CROWS * Ph + kx;
     for (int t = grp; t <= o; t += 8) taps[t * JX_FIR_KX + lx] = kok ? c.taps[(size_t)t * Ph + kx] : 0.0;
     for (int m = tid; m < S; m += 256) s_umap[m] = c.umap[m];
     const int nin = JX_FIR_TILE + 2 * o;
@@ -394,28 +396,39 @@ struct jx_fir_phase {
         if constexpr (I < W) {
             constexpr int slot = (PH + 1 + I) % W;
             constexpr int t = I < O ? O - I : I - O;
-            a[I & 7] = fma(tap[t], win[slot], a[I & 7]);
+            if constexpr (I < 8) a[I] = tap[t] * win[slot];           // the 8 chains start as products: no zero fill
+            else a[I & 7] = fma(tap[t], win[slot], a[I & 7]);
             acc<I + 1>(win, tap, a);
         }
     }
 };
 
+// One batch of W = 2O+1 phases, STRAIGHT-LINE: no branch at all, so that hipcc can keep counted
+// s_waitcnt vmcnt(N) between the row requests and their use (with a branch per phase it falls
+// back to vmcnt(0) everywhere, which serialises every phase behind its own store and request).
+// Out-of-range rows are read from a clamped row and multiplied away; phases past the end of the
+// run store into the walker's spare row (index NJ) of C.
 template <int O, int PH>
 __device__ __forceinline__ void jx_fir_run_phases(double (&win)[2 * O + 1], double (&fifo)[jx_fir_depth<2 * O + 1>()],
-                                                  const double (&tap)[O + 1], const int* s_umap, const double* Yw, double* Cw,
-                                                  int ld, int S, bool ok, bool okst, int r /*conv row of phase 0*/,
+                                                  const double (&tap)[O + 1], int mirror, const double* Yw,
+                                                  double* Cw, int ld, int S, int NJ, int r /*conv row of phase 0*/,
                                                   int q /*job of phase 0*/, int nleft) {
     constexpr int W = 2 * O + 1, D = jx_fir_depth<W>();
     if constexpr (PH < W) {
-        if (PH < nleft) {
-            win[PH] = fifo[PH % D];                                   // map row r + PH + O, requested D phases ago
-            const int mn = r + PH + O + D;                            // request the row needed D phases from now
-            fifo[PH % D] = (ok && mn >= 0 && mn < S) ? Yw[(size_t)s_umap[mn] * ld] : 0.0;
-            double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-            jx_fir_phase<O, PH>::template acc<0>(win, tap, a);
-            if (okst) Cw[(size_t)(q + PH) * ld] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
-            jx_fir_run_phases<O, PH + 1>(win, fifo, tap, s_umap, Yw, Cw, ld, S, ok, okst, r, q, nleft);
-        }
+        // map row r + PH + O was requested D phases ago (raw, from a clamped row); it is masked only now,
+        // at its first use, so that nothing waits on a request right after issuing it
+        const int mu = r + PH + O;
+        win[PH] = fifo[PH % D] * ((mu >= 0 && mu < S) ? 1.0 : 0.0);
+        const int mc = min(max(mu + D, 0), S - 1);                    // wave-uniform: scalar path
+        const int uc = mirror ? abs(mc - (S >> 1)) : mc;              // distinct-row index (== umap[mc]), SALU only
+        fifo[PH % D] = Yw[(size_t)uc * ld];                           // the row needed D phases from now
+        double a[8];
+        jx_fir_phase<O, PH>::template acc<0>(win, tap, a);
+        const int row = (PH < nleft) ? q + PH : NJ;                   // spare row swallows the overshoot
+        Cw[(size_t)row * ld] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+        __builtin_amdgcn_sched_barrier(0);                            // keep each phase's request where it is: hoisting
+                                                                      // them in groups costs 130 more registers
+        jx_fir_run_phases<O, PH + 1>(win, fifo, tap, mirror, Yw, Cw, ld, S, NJ, r, q, nleft);
     }
 }
 
@@ -424,8 +437,7 @@ __global__ void __launch_bounds__(64)
 jx_beamfir_reg_kernel(JxConv c, const int* __restrict__ runs, int nrun, int nwalk, const cplx* __restrict__ Y,
                       cplx* __restrict__ C) {
     constexpr int W = 2 * O + 1, D = jx_fir_depth<W>();
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    int* s_umap = reinterpret_cast<int*>(sm);                         // [S]
+    static_assert(W >= 8, "the accumulator chains assume at least 8 taps");
     const int lane = threadIdx.x, S = c.S, ld = 2 * c.Ph;
     // XCD-aware decode of the 1-D grid: workgroups are dealt round-robin over the 8 XCDs, so ids that agree
     // mod 8 share an L2.  All runs of one (walker, column slab) unit get the same id mod 8 and consecutive
@@ -435,34 +447,40 @@ jx_beamfir_reg_kernel(JxConv c, const int* __restrict__ runs, int nrun, int nwal
     const int unit = (seq / nrun) * 8 + xcd, run = seq - (seq / nrun) * nrun;
     if (unit >= nslab * nwalk) return;
     const int w = unit / nslab, slab = unit - w * nslab;
-    const int col = slab * 64 + lane;                                 // column of the [row][2 Ph] double view
-    const bool ok = col < ld;
+    // lanes past the last column redo the last column (same loads, same value, same address): no predication
+    const int col = min(slab * 64 + lane, ld - 1);
     const int r0 = runs[3 * run], cnt = runs[3 * run + 1], q0 = runs[3 * run + 2];
-    for (int m = lane; m < S; m += 64) s_umap[m] = c.umap[m];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int mirror = c.mirror, cen = S >> 1;
     const double* Yw = reinterpret_cast<const double*>(Y) + (size_t)w * c.NU * ld + col;
-    double* Cw = reinterpret_cast<double*>(C) + (size_t)w * c.NJ * ld + col;
+    double* Cw = reinterpret_cast<double*>(C) + (size_t)w * c.CROWS * ld + col;
     double tap[O + 1];
 #pragma unroll
-    for (int t = 0; t <= O; ++t) tap[t] = ok ? c.taps[(size_t)t * c.Ph + (col >> 1)] : 0.0;
+    for (int t = 0; t <= O; ++t) tap[t] = c.taps[(size_t)t * c.Ph + (col >> 1)];
     double win[W], fifo[D];
     // window before phase 0 of conv row r0: input i (map row r0 - O + i), i = 0..2O-1, sits in slot (1 + i) % W;
-    // the row r0 + O (i = 2O) arrives through the fifo at phase 0, then r0+O+1.. for the following phases
+    // the row r0 + O (i = 2O) arrives through the fifo at phase 0, then r0+O+1.. for the following phases.
+    // All 2O + D requests go out back to back (clamped rows, raw values); the masks follow behind a
+    // scheduling barrier (otherwise hipcc pairs every request with its mask multiply and waits in between).
+#pragma unroll
+    for (int i = 0; i < 2 * O; ++i) {
+        const int mc = min(max(r0 - O + i, 0), S - 1);
+        win[(1 + i) % W] = Yw[(size_t)(mirror ? abs(mc - cen) : mc) * ld];
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const int mc = min(max(r0 + O + d, 0), S - 1);
+        fifo[d] = Yw[(size_t)(mirror ? abs(mc - cen) : mc) * ld];
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < 2 * O; ++i) {
         const int m = r0 - O + i;
-        win[(1 + i) % W] = (ok && m >= 0 && m < S) ? Yw[(size_t)s_umap[m] * ld] : 0.0;
+        win[(1 + i) % W] *= (m >= 0 && m < S) ? 1.0 : 0.0;
     }
     win[0] = 0.0;
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-        const int m = r0 + O + d;
-        fifo[d] = (ok && m >= 0 && m < S) ? Yw[(size_t)s_umap[m] * ld] : 0.0;
-    }
+    __builtin_amdgcn_sched_barrier(0);
     for (int t0 = 0; t0 < cnt; t0 += W)
-        jx_fir_run_phases<O, 0>(win, fifo, tap, s_umap, Yw, Cw, ld, S, ok, ok, r0 + t0, q0 + t0, cnt - t0);
+        jx_fir_run_phases<O, 0>(win, fifo, tap, mirror, Yw, Cw, ld, S, c.NJ, r0 + t0, q0 + t0, cnt - t0);
 }
 
 // expand job rows to the full S x S beam-convolved map (parity tap only)

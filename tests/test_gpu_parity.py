@@ -231,3 +231,24 @@ def test_largest_config_shape():
         got = post.log_prob(th)
         post.close()
         np.testing.assert_allclose(got, want, rtol=RTOL)
+
+
+@pytest.mark.parametrize('fwhm,B', [(6.5, 19), (9.0, 27), (21.0, 63)])
+def test_other_beam_widths(fwhm, B):
+    """Beam half-widths without a register-window FIR instance use the LDS-ring FIR (B=19, 63);
+    B=27 has its own instance.  All against the oracle."""
+    from joxsz_amd import datasets
+    pb = datasets.synthetic_problem(S=128, N=150, seed=11, fwhm=fwhm)
+    assert pb.B == B
+    p0 = orc.pars_dict(pb, datasets.fiducial_theta(pb))
+    datasets.fill_data(pb, orc.sz_stages(pb, p0)['bright'], orc.calc_profiles(pb, p0), seed=11)
+    th = datasets.walker_ball(pb, 6, spread=0.04, seed=11)
+    post = _post(pb, conv='custom')
+    got, conv = post.log_prob(th), post.stage(th[:2], 'conv_2d')
+    post.close()
+    want = orc.log_posterior_batch(pb, th)
+    fin = np.isfinite(want)
+    assert fin.sum() >= 4 and np.array_equal(np.isfinite(got), fin)
+    np.testing.assert_allclose(got[fin], want[fin], rtol=RTOL)
+    st = orc.sz_stages(pb, orc.pars_dict(pb, th[0]))
+    assert _relerr(conv[0], st['conv_2d']) < RTOL_STAGE
