@@ -574,7 +574,7 @@ int jx_finalize(jx_ctx* ctx) {
         if ((rc = dev_new(ctx, (size_t)chunk * cv.nblk3 * cv.Sh, &ctx->d_part))) return rc;
 #define JX_ATTR2(LPv, LSv, R1v, R3v) if (cv.LP == LPv && cv.LS == LSv) { \
             constexpr int rs1 = jx_lay<LPv>::RS, rs3 = jx_lay<LPv>::RS > jx_lay<LSv>::RS ? jx_lay<LPv>::RS : jx_lay<LSv>::RS; \
-            ctx->p1_lds = sizeof(cplx) * ((size_t)R1v * rs1 + LPv); \
+            ctx->p1_lds = sizeof(cplx) * ((size_t)R1v * rs1 + 2 * LPv + 2); \
             ctx->p3_lds = sizeof(cplx) * ((size_t)R3v * rs3 + LPv + LSv); \
             HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_rowfft2_kernel<LPv, R1v>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->p1_lds)); \
             HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_rowtf2_kernel<LPv, LSv, R3v>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->p3_lds)); }

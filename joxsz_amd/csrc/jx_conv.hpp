@@ -119,17 +119,21 @@ jx_rowfft2_kernel(JxConv c, const double* __restrict__ img, size_t img_ld, size_
     static_assert(ROWS * Lay::TMAX <= 256, "one task per thread");
     extern __shared__ __attribute__((aligned(16))) double sm[];
     cplx* M = reinterpret_cast<cplx*>(sm);                  // [ROWS][RS]
-    cplx* tw = M + ROWS * RS;                               // [LP]
+    cplx* tw = M + ROWS * RS;                               // [LP]     e^{-2 pi i n / LP}
+    cplx* twp = tw + LP;                                    // [LP + 1] e^{-2 pi i k / P}
     const int tid = threadIdx.x, nth = blockDim.x;
     const int r0 = blockIdx.x * ROWS, w = blockIdx.y;               // r0: first distinct row u of the block
     const int nrows = min(ROWS, c.NU - r0), half = c.S / 2;
     for (int n = tid; n < LP; n += nth) tw[n] = c.tw_lp[n];
+    for (int n = tid; n <= LP; n += nth) twp[n] = c.tw_p[n];
 
     const int rowA = tid / L2, n2 = tid - rowA * L2;
     const bool actA = tid < ROWS * L2 && rowA < nrows;
     jx_c x[L1];
     if (actA) {
-        const double* src = img + (size_t)w * img_ws + (size_t)c.urow[r0 + rowA] * img_ld;
+        const int u = r0 + rowA;                                    // == c.urow[u] without the dependent load
+        const int mrow = c.mirror ? ((half + u < c.S) ? half + u : half - u) : u;
+        const double* src = img + (size_t)w * img_ws + (size_t)mrow * img_ld;
 #pragma unroll
         for (int n1 = 0; n1 < L1; ++n1) {
             const int n = n1 * L2 + n2;
@@ -155,7 +159,7 @@ jx_rowfft2_kernel(JxConv c, const double* __restrict__ img, size_t img_ld, size_
         const int row = e / Ph, k = e - row * Ph;
         const cplx zk = M[row * RS + (k == LP ? 0 : k)];
         const cplx zc = c_conj(M[row * RS + (k == 0 ? 0 : LP - k)]);
-        const cplx s = c_add(zk, zc), d = c_mul(c_sub(zk, zc), c.tw_p[k]);
+        const cplx s = c_add(zk, zc), d = c_mul(c_sub(zk, zc), twp[k]);
         Y[((size_t)w * c.NU + r0 + row) * Ph + k] = make_double2(0.5 * (s.x + d.y), 0.5 * (s.y - d.x));
     }
 }
@@ -174,22 +178,40 @@ jx_rowtf2_kernel(JxConv c, const cplx* __restrict__ C, cplx* __restrict__ part, 
     static_assert(ROWS * LayP::TMAX <= 256 && ROWS * LayS::TMAX <= 256, "one task per thread");
     extern __shared__ __attribute__((aligned(16))) double sm[];
     cplx* M = reinterpret_cast<cplx*>(sm);                  // [ROWS][RS]
-    cplx* twp = M + ROWS * RS;                              // [LP]
-    cplx* tws = twp + LP;                                   // [LS]
+    cplx* twp = M + ROWS * RS;                              // [LP]     e^{-2 pi i n / LP}
+    cplx* tws = twp + LP;                                   // [LS]     e^{-2 pi i n / LS}
     const int tid = threadIdx.x, nth = blockDim.x;
     const int r0 = blockIdx.x * ROWS, w = blockIdx.y;
     const int S = c.S, Ph = c.Ph, Sh = c.Sh, NJ = c.NJ;             // r0: first job q of the block
     const int nrows = min(ROWS, NJ - r0);
     for (int n = tid; n < LP; n += nth) twp[n] = c.tw_lp[n];
     for (int n = tid; n < LS; n += nth) tws[n] = c.tw_ls[n];
-    // Z[k] = (X[k] + conj X[LP-k]) + i e^{+2 pi i k/P} (X[k] - conj X[LP-k]) into the padded layout of n = k
-    for (int e = tid; e < nrows * LP; e += nth) {
-        const int row = e / LP, k = e - row * LP;
-        const cplx* Xr = C + ((size_t)w * c.CROWS + r0 + row) * Ph;
-        const cplx xk = Xr[k], xc = c_conj(Xr[LP - k]);
-        const cplx s = c_add(xk, xc), d = c_mulc(c_sub(xk, xc), c.tw_p[k]);
-        const int n1 = k / P2, n2 = k - n1 * P2;
-        M[row * RS + n1 * P2P + n2] = make_double2(s.x - d.y, s.y + d.x);
+    // Z[k] = (X[k] + conj X[LP-k]) + i e^{+2 pi i k/P} (X[k] - conj X[LP-k]) into the padded layout of n = k.
+    // Four elements per thread and trip: their eight row reads are requested before anything is used.
+    const cplx* Cblk = C + ((size_t)w * c.CROWS + r0) * Ph;
+    const int npre = nrows * LP;
+    // (the e^{-2 pi i k/P} factors come from global memory with the same batch: an LDS copy would push
+    // the block past 80 KB and halve the residency)
+    for (int e0 = tid; e0 < npre; e0 += 4 * nth) {
+        cplx xk[4], xc[4], tp[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = min(e0 + u * nth, npre - 1), row = e / LP, k = e - row * LP;
+            xk[u] = Cblk[(size_t)row * Ph + k];
+            xc[u] = Cblk[(size_t)row * Ph + LP - k];
+            tp[u] = c.tw_p[k];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * nth;
+            if (e < npre) {
+                const int row = e / LP, k = e - row * LP;
+                const cplx xcc = c_conj(xc[u]);
+                const cplx s = c_add(xk[u], xcc), d = c_mulc(c_sub(xk[u], xcc), tp[u]);
+                const int n1 = k / P2, n2 = k - n1 * P2;
+                M[row * RS + n1 * P2P + n2] = make_double2(s.x - d.y, s.y + d.x);
+            }
+        }
     }
     __syncthreads();
     {   // inverse transform of length LP
@@ -245,20 +267,24 @@ jx_rowtf2_kernel(JxConv c, const cplx* __restrict__ C, cplx* __restrict__ part, 
     }
     for (int k = tid; k < Sh; k += nth) {
         const cplx tk = c.tw_s[k];
+        cplx h[ROWS];                                        // the Hy weights of the block's jobs, requested up front
+#pragma unroll
+        for (int row = 0; row < ROWS; ++row) h[row] = c.hy[(size_t)min(r0 + row, NJ - 1) * Sh + k];
         double zr = 0.0, zi = 0.0;
-        for (int row = 0; row < nrows; ++row) {
-            const cplx zk = M[row * RS + (k == LS ? 0 : k)];
-            const cplx zc = c_conj(M[row * RS + (k == 0 ? 0 : LS - k)]);
-            const cplx s = c_add(zk, zc), d = c_mul(c_sub(zk, zc), tk);
-            const cplx x = make_double2(0.5 * (s.x + d.y), 0.5 * (s.y - d.x));
-            const cplx h = c.hy[(size_t)(r0 + row) * Sh + k];
-            zr += x.x * h.x - x.y * h.y;
-            zi += x.x * h.y + x.y * h.x;
+#pragma unroll
+        for (int row = 0; row < ROWS; ++row) {
+            if (row < nrows) {
+                const cplx zk = M[row * RS + (k == LS ? 0 : k)];
+                const cplx zc = c_conj(M[row * RS + (k == 0 ? 0 : LS - k)]);
+                const cplx s = c_add(zk, zc), d = c_mul(c_sub(zk, zc), tk);
+                const cplx x = make_double2(0.5 * (s.x + d.y), 0.5 * (s.y - d.x));
+                zr += x.x * h[row].x - x.y * h[row].y;
+                zi += x.x * h[row].y + x.y * h[row].x;
+            }
         }
         part[((size_t)w * c.nblk3 + blockIdx.x) * Sh + k] = make_double2(zr, zi);
     }
 }
-
 
 // ------------------------------------------------------------------------------------
 // pass 2: FIR along rows, streaming.  grid = (ceil(Ph/32), walkers), 256 threads: lane & 31
