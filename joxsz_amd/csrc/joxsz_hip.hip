@@ -545,8 +545,9 @@ int jx_finalize(jx_ctx* ctx) {
     {
         const size_t LDS_MAX = 160 * 1024;
         auto need = [&](int threads) {
-            size_t dbl = JX_MAP_LDS_DOUBLES(N);
-            if (d.fast_map) dbl += (size_t)(threads / 64) * ((S + 3) & ~1);
+            size_t scratch = JX_MAP_SCRATCH_DOUBLES(N);
+            if (d.fast_map) scratch = std::max(scratch, (size_t)(threads / 64) * ((S + 3) & ~1));
+            const size_t dbl = JX_MAP_FIXED_DOUBLES(N) + scratch;
             return dbl * sizeof(double);
         };
         while (ctx->map_threads > 64 && need(ctx->map_threads) > LDS_MAX - 1024) ctx->map_threads /= 2;

@@ -430,7 +430,12 @@ __device__ __forceinline__ void jx_profile_to_coefs(const JxDev& c, const double
 }
 
 // LDS doubles needed by the profile-to-coefficients phases
-#define JX_MAP_LDS_DOUBLES(N) (JX_LDS_HDR + 12 * (size_t)(((N) + 1) & ~1) + 8)
+// LDS layout of the map kernels (doubles): [header][cubic coefficients 4(N+1)] then the phase-1-4 scratch
+// (knots, pp, y, M, (r^2,q), (dg,sp) = 8 N), which the symmetric kernel re-uses for its per-wave row buffers
+// in phase 5: the block stays under 53 KB and three of them fit a CU.
+#define JX_MAP_NE(N) ((size_t)(((N) + 1) & ~1))
+#define JX_MAP_FIXED_DOUBLES(N) (JX_LDS_HDR + 4 * JX_MAP_NE(N) + 8)
+#define JX_MAP_SCRATCH_DOUBLES(N) (8 * JX_MAP_NE(N))
 
 template <bool VEC2>
 __global__ void __launch_bounds__(1024)
@@ -439,13 +444,14 @@ jx_abel_map_kernel(JxDev c, const double* __restrict__ pvec, double* __restrict_
     JX_LDS_DECL;
     const int N = c.N;
     double* p = sm;
-    double* s_r = sm + JX_LDS_HDR;    // [N] knots
-    double* s_pp = s_r + N;           // [N]
-    double* s_y = s_pp + N;           // [N]
-    double* s_M = s_y + N;            // [N]
-    double* s_cf = s_M + N;           // [4(N+1)]
-    double2* s_rq = reinterpret_cast<double2*>(s_cf + 4 * (N + 1));   // [N] (r^2, cj*pp)
-    double2* s_ds = s_rq + ((N + 1) & ~1);                            // [N] (dg, sp)
+    const int Ne = (N + 1) & ~1;
+    double* s_cf = sm + JX_LDS_HDR;                                   // [4(N+1)] cubic coefficients (live in phase 5)
+    double* s_r = sm + JX_MAP_FIXED_DOUBLES(N);                       // [N] knots         -- scratch from here on
+    double* s_pp = s_r + Ne;                                          // [N]
+    double* s_y = s_pp + Ne;                                          // [N]
+    double* s_M = s_y + Ne;                                           // [N]
+    double2* s_rq = reinterpret_cast<double2*>(s_M + Ne);             // [N] (r^2, cj*pp)
+    double2* s_ds = s_rq + Ne;                                        // [N] (dg, sp)
 
     const int tid = threadIdx.x, nth = blockDim.x;
     const int w = blockIdx.x / c.map_split;
@@ -515,14 +521,15 @@ jx_abel_map_sym_kernel(JxDev c, const double* __restrict__ pvec, double* __restr
     JX_LDS_DECL;
     const int N = c.N;
     double* p = sm;
-    double* s_r = sm + JX_LDS_HDR;
-    double* s_pp = s_r + N;
-    double* s_y = s_pp + N;
-    double* s_M = s_y + N;
-    double* s_cf = s_M + N;                         // [4(N+1)]
-    double2* s_rq = reinterpret_cast<double2*>(s_cf + 4 * (N + 1));   // [N] (r^2, cj*pp)
-    double2* s_ds = s_rq + ((N + 1) & ~1);                            // [N] (dg, sp)
-    double* s_row = sm + JX_MAP_LDS_DOUBLES(N);     // [nwaves][row_pad]  (offset is a multiple of 2 doubles)
+    const int Ne = (N + 1) & ~1;
+    double* s_cf = sm + JX_LDS_HDR;                                   // [4(N+1)] cubic coefficients (live in phase 5)
+    double* s_r = sm + JX_MAP_FIXED_DOUBLES(N);                       // [N] knots         -- scratch from here on
+    double* s_pp = s_r + Ne;                                          // [N]
+    double* s_y = s_pp + Ne;                                          // [N]
+    double* s_M = s_y + Ne;                                           // [N]
+    double2* s_rq = reinterpret_cast<double2*>(s_M + Ne);             // [N] (r^2, cj*pp)
+    double2* s_ds = s_rq + Ne;                                        // [N] (dg, sp)
+    double* s_row = sm + JX_MAP_FIXED_DOUBLES(N);                     // [nwaves][row_pad] over the dead scratch
 
     const int tid = threadIdx.x, nth = blockDim.x;
     const int w = blockIdx.x / c.map_split;
