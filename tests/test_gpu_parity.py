@@ -252,3 +252,28 @@ def test_other_beam_widths(fwhm, B):
     np.testing.assert_allclose(got[fin], want[fin], rtol=RTOL)
     st = orc.sz_stages(pb, orc.pars_dict(pb, th[0]))
     assert _relerr(conv[0], st['conv_2d']) < RTOL_STAGE
+
+
+def test_full_size_determinism_and_permutation():
+    """Size-independent properties at the headline size (S=512, N=500, 1024+ walkers): two
+    evaluations are bitwise equal (partials are summed in a fixed order, no float atomics), a
+    walker's value does not depend on its position in the batch or on the chunking, and the
+    scalar entry point agrees bitwise with the batched one."""
+    from joxsz_amd import datasets
+    pb = datasets.synthetic_problem(S=512, N=500, seed=0)
+    th = datasets.walker_ball(pb, 1100, spread=0.02, seed=21)     # not a multiple of the chunk
+    post = _post(pb)
+    a = post.log_prob(th)
+    b = post.log_prob(th)
+    perm = np.random.default_rng(0).permutation(len(th))
+    c = post.log_prob(th[perm])
+    one = post.getLikelihood(th[17])
+    post.close()
+    assert np.isfinite(a).sum() > 1000
+    np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(c, a[perm])
+    assert one == a[17] or (np.isinf(one) and np.isinf(a[17]))
+    small = _post(pb, max_batch=96)
+    d = small.log_prob(th[:300])
+    small.close()
+    np.testing.assert_array_equal(d, a[:300])
