@@ -245,7 +245,7 @@ static int make_plans(jx_ctx* ctx, int batch, Plan3** out) {
     auto it = ctx->plans.find(batch);
     if (it != ctx->plans.end()) { *out = &it->second; return JX_OK; }
     Plan3 pl;
-    const size_t P = ctx->P, Ph = ctx->Ph, S = ctx->cfg.S, Sh = ctx->Sh;
+    const size_t P = ctx->P, S = ctx->cfg.S, Sh = ctx->Sh;
     {   // beam convolution forward: real [P][P] -> hermitian [P][Ph]
         size_t len[2] = {P, P};
         FFTCHK(ctx, rocfft_plan_create(&pl.beam_fwd, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
@@ -334,7 +334,6 @@ int jx_finalize(jx_ctx* ctx) {
     d.sz_only = c.sz_only;
     if (const char* e = getenv("JOXSZ_DBG")) d.dbg = atoi(e);      // timing-only ablations, results are wrong
     d.y_scale = c.kpc_cm * c.sigma_T / c.m_e;
-    d.r_first = r[0];
     d.inv_h_mean = (double)(N - 1) / (r[N - 1] - r[0]);
 
     int rc;

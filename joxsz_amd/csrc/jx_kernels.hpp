@@ -1,15 +1,21 @@
 // Device kernels of the JoXSZ log-posterior for gfx950 (CDNA4, wave64).
 //
 // All arithmetic is IEEE fp64 like the reference.  No MFMA: the path is
-// memory-bound integration (HBM write of the y map, FFT passes), not a dense
-// contraction.  Kernel list (one launch each per chunk of walkers):
+// memory-bound integration (HBM write of the y map, FFT/FIR passes), not a dense
+// contraction.  Kernels of this file (one launch each per chunk of walkers):
 //
-//   jx_prep_kernel      theta -> parameter vector, priors, mass veto, T_SZ profile,
-//                       Compton->mJy/beam factors, X-ray counts + Cash likelihood
-//   jx_abel_map_kernel  FUSED gNFW profile -> Abel integral -> Compton y -> cubic
-//                       spline -> S x S map written into the zero-padded FFT image
-//   jx_beam_mul_kernel  spectrum *= beam spectrum
-//   jx_tail_kernel      transfer function + central row + conversion + chi^2 + sum
+//   jx_prep_kernel          theta -> parameter vector, priors, mass veto, T_SZ profile,
+//                           Compton->mJy/beam factors, X-ray counts + Cash likelihood
+//   jx_abel_map_sym_kernel  FUSED gNFW profile -> Abel integral -> Compton y -> cubic
+//   jx_abel_map_kernel      spline -> S x S map (symmetric d_mat / any d_mat)
+//   jx_beam_mul_kernel      spectrum *= beam spectrum (rocFFT back end only)
+//   jx_tail_kernel          extracted row of the filtered map, conversion, chi^2, total
+// The hand-written convolution passes live in jx_conv.hpp.
+//
+// JOXSZ_DBG (JxDev::dbg) holds timing-only ablation switches of the map kernel; results are
+// wrong when any is set: 1 skip phases 1-4, 2 skip phase 5, 4 phase 5 = stores only,
+// 8 skip the Abel sums, 16 skip the spline moments, 32 skip the pow() of the profile,
+// 64 non-temporal stores (with 4), 128 Abel loop without the reciprocal square root.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -21,7 +27,6 @@
 #define JX_LDS_DECL extern __shared__ __attribute__((aligned(16))) double sm[]
 #define JX_LDS_HDR 32          // [0..18] parameter vector, [20..27] reduction scratch, [28] int flag
 #define JX_PREP_THREADS 256
-#define JX_MAP_THREADS 256
 #define JX_TAIL_THREADS 256
 
 // semantic slots of the parameter vector (joxsz_amd/problem.py PAR_SLOTS)
@@ -38,9 +43,8 @@ struct JxDev {
     int ne_mode, exclude_unphy_mass, sz_only;
     int K;                       // half-bandwidth of the spline moment operator
     int map_split;               // row slabs per walker in the Abel+map kernel
-    int uniform_hint;            // 1: r_pp close to uniform -> O(1) interval lookup
     double y_scale;              // kpc_cm * sigma_T / m_e            (joxsz_funcs.py:459)
-    double r_first, inv_h_mean;
+    double inv_h_mean;           // (N-1)/(r_N - r_1): first guess of the interval index in the generic map kernel
     // constant tensors (device)
     const double* r_pp;          // [N]
     const double* d_mat;         // [S*S]
@@ -462,7 +466,7 @@ jx_abel_map_kernel(JxDev c, const double* __restrict__ pvec, double* __restrict_
     jx_profile_to_coefs(c, p, w, part == 0, s_r, s_pp, s_y, s_M, s_cf, s_rq, s_ds, tap_pp, tap_ab, tap_y);
 
     // Phase 5 (generic): the block's slab of rows
-    const int S = c.S, P = c.P;
+    const int S = c.S;
     const int rows_per = (S + c.map_split - 1) / c.map_split;
     const int row0 = part * rows_per, row1 = min(S, row0 + rows_per);
     const int lane = tid & 63, wv = tid >> 6, nwv = nth >> 6;
@@ -541,7 +545,7 @@ jx_abel_map_sym_kernel(JxDev c, const double* __restrict__ pvec, double* __restr
     else { for (int k = tid; k < 4 * (N + 1); k += nth) s_cf[k] = 0.0; __syncthreads(); }
     if (c.dbg & 2) return;
 
-    const int S = c.S, P = c.P, na = c.q_na, nb = c.q_nb, cc = c.S / 2;
+    const int S = c.S, na = c.q_na, nb = c.q_nb, cc = c.S / 2;
     const int lane = tid & 63, wv = tid >> 6, nwv = nth >> 6;
     const int row_pad = (S + 3) & ~1;
     double* rowfull = s_row + (size_t)wv * row_pad;
