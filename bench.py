@@ -240,8 +240,9 @@ def main():
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': '%d walkers/GPU, %dx%d SZ map, %d-pt radial grid, %s likelihood, '
-                                   'synthetic CL J1226.9+3332-shaped inputs (BASELINE configs[2])'
-                                   % (W, S, S, args.N, 'SZ-only' if pb.sz_only else 'joint X-ray+SZ'),
+                                   'synthetic CL J1226.9+3332-shaped inputs%s'
+                                   % (W, S, S, args.N, 'SZ-only' if pb.sz_only else 'joint X-ray+SZ',
+                                      ' (BASELINE configs[2])' if (W, S, args.N, pb.sz_only) == (1024, 512, 500, False) else ''),
                        'walkers_per_gpu': W, 'S': S, 'N': args.N, 'B': pb.B, 'fft_pad': ctx.fft_pad,
                        'chunk': ctx.chunk, 'conv': ctx.conv, 'parallelism': 'walkers sharded x%d' % world, 'device': ctx.device_name},
             'roofline': {'kernel': 'jx_abel_map_sym_kernel', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
