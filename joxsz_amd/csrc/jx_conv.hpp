@@ -228,32 +228,43 @@ jx_rowtf2_kernel(JxConv c, const cplx* __restrict__ C, cplx* __restrict__ part, 
         const bool actB = tid < ROWS * P1 && rowB < nrows;
         jx_c y[P2];
         if (actB) jx_stepB_load<LP, true>(y, k1, M + rowB * RS);
-        __syncthreads();
-        if (actB) {
-            // z[n] = (conv[2n], conv[2n+1]), n = k1 + P1 k2; the first LS of them are the cropped row
+        // z[n] = (conv[2n], conv[2n+1]), n = k1 + P1 k2; the first LS of them are the cropped row
+        if (tap_conv && actB) {
 #pragma unroll
             for (int k2 = 0; k2 < P2; ++k2) {
                 const int n = k1 + P1 * k2;
-                if (n < LS) {
-                    const int a = n / S2, b = n - a * S2;
-                    jx_st(M + rowB * RS + a * S2P + b, y[k2]);
-                    if (tap_conv)
-                        *reinterpret_cast<double2*>(tap_conv + ((size_t)w * NJ + r0 + rowB) * S + 2 * n) = make_double2(y[k2].x, y[k2].y);
-                }
+                if (n < LS)
+                    *reinterpret_cast<double2*>(tap_conv + ((size_t)w * NJ + r0 + rowB) * S + 2 * n) = make_double2(y[k2].x, y[k2].y);
             }
         }
-        __syncthreads();
-    }
-    {   // forward transform of length LS
-        const int rowA = tid / S2, n2 = tid - rowA * S2;
-        const bool actA = tid < ROWS * S2 && rowA < nrows;
-        jx_c x[S1];
-        if (actA) {
+        if constexpr (P1 == S2 && P2 >= S1) {
+            // The outputs this thread holds, n = k1 + S2 k2 (k2 < S1), are exactly the inputs of step A of the forward
+            // transform for (row, n2 = k1): no LDS round trip and no barrier between the two transforms.
+            __syncthreads();                                        // every thread has read its step-B inputs
+            if (actB) jx_stepA_store<LS, false>(y, k1, M + rowB * RS, tws);
+            __syncthreads();
+        } else {
+            __syncthreads();
+            if (actB) {
 #pragma unroll
-            for (int n1 = 0; n1 < S1; ++n1) x[n1] = jx_ld(M + rowA * RS + n1 * S2P + n2);
-            jx_stepA_store<LS, false>(x, n2, M + rowA * RS, tws);
+                for (int k2 = 0; k2 < P2; ++k2) {
+                    const int n = k1 + P1 * k2;
+                    if (n < LS) { const int a2 = n / S2, b2 = n - a2 * S2; jx_st(M + rowB * RS + a2 * S2P + b2, y[k2]); }
+                }
+            }
+            __syncthreads();
+            const int rowA2 = tid / S2, n2b = tid - rowA2 * S2;
+            const bool actA2 = tid < ROWS * S2 && rowA2 < nrows;
+            jx_c x[S1];
+            if (actA2) {
+#pragma unroll
+                for (int n1 = 0; n1 < S1; ++n1) x[n1] = jx_ld(M + rowA2 * RS + n1 * S2P + n2b);
+                jx_stepA_store<LS, false>(x, n2b, M + rowA2 * RS, tws);
+            }
+            __syncthreads();
         }
-        __syncthreads();
+    }
+    {   // forward transform of length LS, step B
         const int rowB = tid / S1, k1 = tid - rowB * S1;
         const bool actB = tid < ROWS * S1 && rowB < nrows;
         jx_c y[S2];
