@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <complex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -88,7 +89,6 @@ struct jx_ctx {
 static int g_rocfft_refs = 0;
 
 // beam half-widths (B-1)/2 for which the register-window FIR is instantiated
-#define JX_FIR_REG_O(X) X(4) X(5) X(13) X(27)          // all >= 4: the FIR's 8 accumulator chains need 2O+1 >= 8
 
 // two-level (register-blocked) forms: (LP, LS, rows per block in pass 1, rows per block in pass 3)
 #define JX_CONV2_PAIRS(X) X(18, 16, 42, 42) X(48, 24, 32, 32) X(48, 32, 32, 32) X(96, 64, 21, 21) X(144, 128, 21, 16) X(288, 256, 14, 14) X(576, 512, 10, 8)
@@ -476,6 +476,33 @@ int jx_finalize(jx_ctx* ctx) {
 #undef JX_HAS_O
             if (const char* e = getenv("JOXSZ_FIR_LDS")) { if (atoi(e) > 0) ctx->fir_reg = 0; }
         }
+        // x-symmetric rows: one real array per row between the passes (needs the mirror structure of d_mat, which makes
+        // every map row symmetric about column S/2, and the register-window FIR)
+        cv.xsym = (use_mirror && ctx->fir_reg && S <= 1024 && o < JX_XSYM_MAXT) ? 1 : 0;
+        if (const char* e = getenv("JOXSZ_CONV_XSYM")) { if (atoi(e) == 0) cv.xsym = 0; }
+        cv.fir_ld = cv.xsym ? cv.Ph : 2 * cv.Ph;
+        if (cv.xsym) {
+            // Z[k] = (X[k] + conj X[LP-k]) + i w (X[k] - conj X[LP-k]),  w = e^{+2 pi i k/P},  X[k] = e^{-i phi_k} Rc[k]
+            const int LPn = cv.LP, cS = S / 2;
+            auto cis = [&](long long num) {                           // e^{2 pi i num / P}, argument reduced on the integers
+                const long long j = ((num % P) + P) % P;
+                return std::complex<double>(std::cos(2.0 * jxt::kPi * (double)j / P), std::sin(2.0 * jxt::kPi * (double)j / P));
+            };
+            std::vector<double> zab((size_t)LPn * 4);
+            const std::complex<double> I(0.0, 1.0);
+            for (int k = 0; k < LPn; ++k) {
+                const std::complex<double> wk = cis(k);
+                const std::complex<double> za = cis(-(long long)k * cS) * (1.0 + I * wk);
+                const std::complex<double> zb = cis((long long)(LPn - k) * cS) * (1.0 - I * wk);
+                zab[4 * k] = za.real(); zab[4 * k + 1] = za.imag(); zab[4 * k + 2] = zb.real(); zab[4 * k + 3] = zb.imag();
+            }
+            if ((rc = dev_put(ctx, zab.data(), zab.size(), &p))) return rc; cv.zab = (const cplx*)p;
+            const int nt = o + 1;
+            std::vector<double> bc((size_t)nt * nt);
+            for (int t = 0; t < nt; ++t)
+                for (int x = 0; x < nt; ++x) bc[(size_t)t * nt + x] = c.step * c.step * beam_h[(size_t)(o + t) * B + o + x];
+            if ((rc = dev_put(ctx, bc.data(), bc.size(), &p))) return rc; cv.bcol = p;
+        }
     }
     // ---- plain copies
     {
@@ -527,7 +554,7 @@ int jx_finalize(jx_ctx* ctx) {
     // ---- chunk capacity and work buffers
     const size_t per_walker = (ctx->conv_mode == 1)
         ? sizeof(double) * ((size_t)P * P * 2 + (size_t)P * ctx->Ph * 2 + (size_t)S * ctx->Sh * 2)
-        : sizeof(double) * ((size_t)S * S + (size_t)(ctx->cv.NU + ctx->cv.CROWS) * ctx->Ph * 2 + (size_t)ctx->cv.nblk3 * ctx->Sh * 2);
+        : sizeof(double) * ((size_t)S * S + (size_t)(ctx->cv.NU + ctx->cv.CROWS) * ctx->cv.fir_ld + (size_t)ctx->cv.NJ * 28 + (size_t)ctx->cv.nblk3 * ctx->Sh * 2);
     d.img_ld = (ctx->conv_mode == 1) ? P : S;
     d.img_ws = (ctx->conv_mode == 1) ? (long long)P * P : (long long)S * S;
     int chunk = c.max_batch > 0 ? c.max_batch : 1024;   // >= 4 map blocks per CU: launches desynchronise, stores overlap compute
@@ -569,13 +596,15 @@ int jx_finalize(jx_ctx* ctx) {
     } else {
         const JxConv& cv = ctx->cv;
         if ((rc = dev_new(ctx, (size_t)chunk * S * S, &ctx->d_img))) return rc;
-        if ((rc = dev_new(ctx, (size_t)chunk * cv.NU * cv.Ph, &ctx->d_Y))) return rc;
-        if ((rc = dev_new(ctx, (size_t)chunk * cv.CROWS * cv.Ph, &ctx->d_C))) return rc;
+        const size_t spec_div = cv.xsym ? 2 : 1;                           // real arrays need half the complex count
+        if ((rc = dev_new(ctx, ((size_t)chunk * cv.NU * cv.Ph + 1) / spec_div, &ctx->d_Y))) return rc;
+        if ((rc = dev_new(ctx, ((size_t)chunk * cv.CROWS * cv.Ph + 1) / spec_div, &ctx->d_C))) return rc;
+        if (cv.xsym && (rc = dev_new(ctx, (size_t)chunk * cv.NJ * (cv.o + 1), &ctx->cv.col0))) return rc;
         if ((rc = dev_new(ctx, (size_t)chunk * cv.nblk3 * cv.Sh, &ctx->d_part))) return rc;
 #define JX_ATTR2(LPv, LSv, R1v, R3v) if (cv.LP == LPv && cv.LS == LSv) { \
             constexpr int rs1 = jx_lay<LPv>::RS, rs3 = jx_lay<LPv>::RS > jx_lay<LSv>::RS ? jx_lay<LPv>::RS : jx_lay<LSv>::RS; \
-            ctx->p1_lds = sizeof(cplx) * ((size_t)R1v * rs1 + 2 * LPv + 2); \
-            ctx->p3_lds = sizeof(cplx) * ((size_t)R3v * rs3 + LPv + LSv); \
+            ctx->p1_lds = sizeof(cplx) * ((size_t)R1v * rs1 + 2 * LPv + 2) + sizeof(double) * R1v; \
+            ctx->p3_lds = sizeof(cplx) * ((size_t)R3v * rs3 + LPv + LSv) + (cv.xsym ? sizeof(double) * R3v * (cv.o + 1) : 0); \
             HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_rowfft2_kernel<LPv, R1v>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->p1_lds)); \
             HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_rowtf2_kernel<LPv, LSv, R3v>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->p3_lds)); }
         JX_CONV2_PAIRS(JX_ATTR2)
@@ -638,8 +667,10 @@ static int launch_custom_conv(jx_ctx* ctx, int n, double* tap_convjobs, EvSet* e
     JX_CONV2_PAIRS(JX_P1)
 #undef JX_P1
     if (!done) { ctx->err = "no pass-1 kernel for this size"; return JX_ERR_UNSUPPORTED; }
+    if (cv.xsym)
+        hipLaunchKernelGGL(jx_col0_kernel, dim3(n), dim3(256), 0, st, cv, ctx->d_img, (size_t)d.img_ld, (size_t)d.img_ws, cv.col0);
     if (ctx->fir_reg) {
-        const int nslab = (2 * cv.Ph + 63) / 64, units = nslab * n;
+        const int nslab = (cv.fir_ld + 63) / 64, units = nslab * n;
         const dim3 g2((unsigned)(((units + 7) / 8) * 8 * ctx->nrun));
 #define JX_FIRREG(Ov) if (cv.o == Ov) hipLaunchKernelGGL((jx_beamfir_reg_kernel<Ov>), g2, dim3(64), 0, st, cv, ctx->d_runs, ctx->nrun, n, ctx->d_Y, ctx->d_C);
         JX_FIR_REG_O(JX_FIRREG)
@@ -924,6 +955,24 @@ int jx_get_info(jx_ctx* ctx, int32_t* fft_pad, int32_t* chunk, int32_t* band, in
 int jx_get_conv_mode(jx_ctx* ctx) {
     if (!ctx || !ctx->finalized) return JX_ERR_STATE;
     return ctx->conv_mode;
+}
+
+int jx_debug_workspace(jx_ctx* ctx, int which, void** dev, int32_t geom[4]) {
+    if (!ctx || !ctx->finalized || !dev || !geom) return JX_ERR_STATE;
+    if (ctx->conv_mode != 2) { ctx->err = "work buffers of the hand-written convolution only"; return JX_ERR_UNSUPPORTED; }
+    const JxConv& cv = ctx->cv;
+    geom[0] = ctx->chunk; geom[3] = cv.xsym;
+    switch (which) {
+        case 0: *dev = ctx->d_img; geom[1] = cv.S; geom[2] = cv.S; break;
+        case 1: *dev = ctx->d_Y; geom[1] = cv.NU; geom[2] = cv.fir_ld; break;
+        case 2: *dev = ctx->d_C; geom[1] = cv.CROWS; geom[2] = cv.fir_ld; break;
+        case 3: if (!cv.xsym) { ctx->err = "no column-0 terms in this mode"; return JX_ERR_UNSUPPORTED; }
+                *dev = cv.col0; geom[1] = cv.NJ; geom[2] = cv.o + 1; break;
+        case 4: *dev = const_cast<int*>(cv.jrow); geom[0] = 1; geom[1] = cv.NJ; geom[2] = 1; break;
+        case 5: *dev = const_cast<int*>(cv.umap); geom[0] = 1; geom[1] = cv.S; geom[2] = 1; break;
+        default: ctx->err = "unknown work buffer"; return JX_ERR_INVALID;
+    }
+    return JX_OK;
 }
 
 void jx_destroy(jx_ctx* ctx) {

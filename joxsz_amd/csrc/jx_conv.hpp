@@ -19,6 +19,14 @@
 // transformed (urow/umap), and conv rows that are provably identical (same multiset of
 // (source row, tap) pairs) are computed once ("jobs", r_q) with their Hy weights summed.
 // Without the structure the tables are the identity and every row is its own job.
+// x symmetry (xsym): a map row that is mirror-symmetric about column c = S/2, with its one unpaired
+// column 0 (even S) set aside, has
+//     Y(kx) = e^{-i phi} R(kx),  phi = 2 pi kx c / P,  R real.
+// The FIR taps are real, so C(kx) = e^{-i phi} Rc(kx) with Rc = FIR(R) real: pass 1 stores R (and x0, the
+// column-0 value of each distinct row), pass 2 filters the real array R (half the bytes and half the
+// FMAs), pass 3 rebuilds Z from Rc with one precomputed complex factor per term.  What column 0 adds to
+// the convolved row is put back in real space after the inverse transform: it only reaches output
+// columns 0..o,  conv[r][x] += step^2 sum_t beam[o+t][o+x] (x0[r-t] + x0[r+t]).
 // Every pass keeps rows contiguous in memory ([row][kx], 16-byte complex), so all global
 // accesses are coalesced wave transactions and no transpose is needed.
 //
@@ -45,6 +53,11 @@ struct JxConv {
     int NU, NJ, nseg;               // distinct map rows, conv jobs, contiguous job segments
     int CROWS;                      // rows per walker in C: NJ + 1 (one spare row for store overshoot)
     int mirror;                     // 1: umap[m] = |m - S/2| (mirror structure), 0: umap[m] = m
+    int xsym;                       // 1: map rows are also mirror-symmetric in x: Y and C hold ONE real array per row
+    int fir_ld;                     // doubles per row of Y / C: Ph (xsym) or 2 Ph
+    const cplx* zab;                // [LP][2] pass-3 pre-process factors: Z[k] = zab[k][0] Rc[k] + zab[k][1] Rc[LP-k]   (xsym)
+    const double* bcol;             // [o+1][o+1] step^2 beam[o+t][o+x]: what column 0 of a map row adds to output column x  (xsym)
+    double* col0;                   // [walkers][NJ][o+1] what column 0 of the map adds to output columns 0..o of each job (xsym)
     int nblk3;                      // pass-3 blocks per walker (partials to sum in the tail)
     const cplx* tw_lp;              // [LP]   exp(-2 pi i n / LP)
     const cplx* tw_ls;              // [LS]   exp(-2 pi i n / LS)
@@ -61,6 +74,9 @@ struct JxConv {
 #define JX_FIR_TILE 64              // output rows per chunk of pass 2
 #define JX_FIR_NR 8                 // consecutive output rows per thread
 #define JX_FIR_KX 32                // kx per slab
+// beam half-widths o = (B-1)/2 with a register-window FIR instance (and an x-symmetric pass-3 pre-process)
+#define JX_XSYM_MAXT 28              // taps (o + 1) of the widest such beam
+#define JX_FIR_REG_O(X) X(4) X(5) X(13) X(27)          // all >= 4: the FIR's 8 accumulator chains need 2O+1 >= 8
 #define JX_FIR_RING 128             // LDS ring of input rows (>= JX_FIR_TILE + 2 o)
 
 // ====================================================================================
@@ -121,6 +137,7 @@ jx_rowfft2_kernel(JxConv c, const double* __restrict__ img, size_t img_ld, size_
     cplx* M = reinterpret_cast<cplx*>(sm);                  // [ROWS][RS]
     cplx* tw = M + ROWS * RS;                               // [LP]     e^{-2 pi i n / LP}
     cplx* twp = tw + LP;                                    // [LP + 1] e^{-2 pi i k / P}
+    double* s_x0 = reinterpret_cast<double*>(twp + LP + 1);  // [ROWS] unpaired column 0 of each row (xsym)
     const int tid = threadIdx.x, nth = blockDim.x;
     const int r0 = blockIdx.x * ROWS, w = blockIdx.y;               // r0: first distinct row u of the block
     const int nrows = min(ROWS, c.NU - r0), half = c.S / 2;
@@ -140,6 +157,7 @@ jx_rowfft2_kernel(JxConv c, const double* __restrict__ img, size_t img_ld, size_
             x[n1] = jxc(0.0, 0.0);
             if (n < half) { const double2 v = *reinterpret_cast<const double2*>(src + 2 * n); x[n1] = jxc(v.x, v.y); }
         }
+        if (n2 == 0) s_x0[rowA] = (c.S & 1) ? 0.0 : x[0].x;           // column 0 has no mirror partner on an even side
     }
     __syncthreads();
     if (actA) jx_stepA_store<LP, false>(x, n2, M + rowA * RS, tw);
@@ -160,13 +178,43 @@ jx_rowfft2_kernel(JxConv c, const double* __restrict__ img, size_t img_ld, size_
         const cplx zk = M[row * RS + (k == LP ? 0 : k)];
         const cplx zc = c_conj(M[row * RS + (k == 0 ? 0 : LP - k)]);
         const cplx s = c_add(zk, zc), d = c_mul(c_sub(zk, zc), twp[k]);
-        Y[((size_t)w * c.NU + r0 + row) * Ph + k] = make_double2(0.5 * (s.x + d.y), 0.5 * (s.y - d.x));
+        const cplx X = make_double2(0.5 * (s.x + d.y), 0.5 * (s.y - d.x));
+        if (c.xsym) {                                                 // R = Re[(X - x0) e^{+i phi}]
+            const int j = (k * (c.S >> 1)) % c.P;                     // e^{+i phi} = conj(tw_P[j]) = tw_P[P - j]
+            const cplx t = twp[j <= LP ? j : c.P - j];
+            const double sn = j <= LP ? -t.y : t.y;
+            reinterpret_cast<double*>(Y)[((size_t)w * c.NU + r0 + row) * Ph + k] = (X.x - s_x0[row]) * t.x - X.y * sn;
+        } else {
+            Y[((size_t)w * c.NU + r0 + row) * Ph + k] = X;
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------
 // pass 3 (two-level): grid = (ceil(S / ROWS), walkers), 256 threads
 // ------------------------------------------------------------------------------------
+// x-symmetric mode: the unpaired column 0 of the map, convolved with the beam, reaches output columns 0..o only:
+//     col0[w][q][x] = sum_t bcol[t][x] (x0[r_q - t] + x0[r_q + t]),   x0[m] = map[m][0],  r_q = conv row of job q.
+// One block per walker; pass 3 adds the result to the cropped rows in real space.
+__global__ void __launch_bounds__(256)
+jx_col0_kernel(JxConv c, const double* __restrict__ img, size_t img_ld, size_t img_ws, double* __restrict__ col0) {
+    __shared__ double s_x0[1024 + 2 * JX_XSYM_MAXT];                 // zero margin of o rows on both sides
+    __shared__ double s_b[JX_XSYM_MAXT * JX_XSYM_MAXT];
+    const int tid = threadIdx.x, nth = blockDim.x, w = blockIdx.x, S = c.S, o = c.o, nt = o + 1;
+    for (int m = tid; m < S + 2 * o; m += nth) {
+        const int r = m - o;
+        s_x0[m] = (r >= 0 && r < S) ? img[(size_t)w * img_ws + (size_t)r * img_ld] : 0.0;
+    }
+    for (int e = tid; e < nt * nt; e += nth) s_b[e] = c.bcol[e];
+    __syncthreads();
+    for (int e = tid; e < c.NJ * nt; e += nth) {
+        const int q = e / nt, x = e - q * nt, r = c.jrow[q] + o;
+        double a = s_b[x] * s_x0[r];
+        for (int t = 1; t < nt; ++t) a = fma(s_b[t * nt + x], s_x0[r - t] + s_x0[r + t], a);
+        col0[(size_t)w * c.NJ * nt + e] = a;
+    }
+}
+
 template <int LP, int LS, int ROWS>
 __global__ void __launch_bounds__(256)
 jx_rowtf2_kernel(JxConv c, const cplx* __restrict__ C, cplx* __restrict__ part, double* __restrict__ tap_conv) {
@@ -190,6 +238,39 @@ jx_rowtf2_kernel(JxConv c, const cplx* __restrict__ C, cplx* __restrict__ part, 
     // Four elements per thread and trip: their eight row reads are requested before anything is used.
     const cplx* Cblk = C + ((size_t)w * c.CROWS + r0) * Ph;
     const int npre = nrows * LP;
+    double* s_s = reinterpret_cast<double*>(tws + LS);               // [ROWS][o + 1] column-0 terms of the block's jobs (xsym)
+    constexpr int NSL = (ROWS * JX_XSYM_MAXT + 255) / 256;          // entries of s_s per thread (blockDim = 256)
+    if (c.xsym) {
+        // Z[k] = zab[k][0] Rc[k] + zab[k][1] Rc[LP-k], four elements per thread and trip as below
+        const double* Rblk = reinterpret_cast<const double*>(C) + ((size_t)w * c.CROWS + r0) * Ph;
+        const int nt = c.o + 1, ns = nrows * nt;
+        double cz[NSL];                                              // this block's slice of col0, requested first
+#pragma unroll
+        for (int u = 0; u < NSL; ++u) cz[u] = c.col0[((size_t)w * NJ + r0) * nt + min(tid + u * nth, ns - 1)];
+        for (int e0 = tid; e0 < npre; e0 += 4 * nth) {
+            double rk[4], rc[4];
+            cplx za[4], zb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = min(e0 + u * nth, npre - 1), row = e / LP, k = e - row * LP;
+                rk[u] = Rblk[(size_t)row * Ph + k];
+                rc[u] = Rblk[(size_t)row * Ph + LP - k];
+                za[u] = c.zab[2 * k];
+                zb[u] = c.zab[2 * k + 1];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + u * nth;
+                if (e < npre) {
+                    const int row = e / LP, k = e - row * LP;
+                    const int n1 = k / P2, n2 = k - n1 * P2;
+                    M[row * RS + n1 * P2P + n2] = make_double2(fma(za[u].x, rk[u], zb[u].x * rc[u]), fma(za[u].y, rk[u], zb[u].y * rc[u]));
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NSL; ++u) if (tid + u * nth < ns) s_s[tid + u * nth] = cz[u];
+    } else
     // (the e^{-2 pi i k/P} factors come from global memory with the same batch: an LDS copy would push
     // the block past 80 KB and halve the residency)
     for (int e0 = tid; e0 < npre; e0 += 4 * nth) {
@@ -229,22 +310,56 @@ jx_rowtf2_kernel(JxConv c, const cplx* __restrict__ C, cplx* __restrict__ part, 
         jx_c y[P2];
         if (actB) jx_stepB_load<LP, true>(y, k1, M + rowB * RS);
         // z[n] = (conv[2n], conv[2n+1]), n = k1 + P1 k2; the first LS of them are the cropped row
-        if (tap_conv && actB) {
-#pragma unroll
-            for (int k2 = 0; k2 < P2; ++k2) {
-                const int n = k1 + P1 * k2;
-                if (n < LS)
-                    *reinterpret_cast<double2*>(tap_conv + ((size_t)w * NJ + r0 + rowB) * S + 2 * n) = make_double2(y[k2].x, y[k2].y);
-            }
-        }
         if constexpr (P1 == S2 && P2 >= S1) {
             // The outputs this thread holds, n = k1 + S2 k2 (k2 < S1), are exactly the inputs of step A of the forward
             // transform for (row, n2 = k1): no LDS round trip and no barrier between the two transforms.
             __syncthreads();                                        // every thread has read its step-B inputs
+            if (actB) {
+                if (c.xsym) {                                        // column 0 reaches output columns 0..o only
+                    const int o = c.o;
+#pragma unroll
+                    for (int k2 = 0; k2 < P2; ++k2) {
+                        const int n = k1 + P1 * k2;
+                        if (2 * n <= o) {
+                            y[k2].x += s_s[rowB * (o + 1) + 2 * n];
+                            if (2 * n + 1 <= o) y[k2].y += s_s[rowB * (o + 1) + 2 * n + 1];
+                        }
+                    }
+                }
+                if (tap_conv) {
+#pragma unroll
+                    for (int k2 = 0; k2 < P2; ++k2) {
+                        const int n = k1 + P1 * k2;
+                        if (n < LS)
+                            *reinterpret_cast<double2*>(tap_conv + ((size_t)w * NJ + r0 + rowB) * S + 2 * n) = make_double2(y[k2].x, y[k2].y);
+                    }
+                }
+            }
             if (actB) jx_stepA_store<LS, false>(y, k1, M + rowB * RS, tws);
             __syncthreads();
         } else {
             __syncthreads();
+            if (actB) {
+                if (c.xsym) {                                        // column 0 reaches output columns 0..o only
+                    const int o = c.o;
+#pragma unroll
+                    for (int k2 = 0; k2 < P2; ++k2) {
+                        const int n = k1 + P1 * k2;
+                        if (2 * n <= o) {
+                            y[k2].x += s_s[rowB * (o + 1) + 2 * n];
+                            if (2 * n + 1 <= o) y[k2].y += s_s[rowB * (o + 1) + 2 * n + 1];
+                        }
+                    }
+                }
+                if (tap_conv) {
+#pragma unroll
+                    for (int k2 = 0; k2 < P2; ++k2) {
+                        const int n = k1 + P1 * k2;
+                        if (n < LS)
+                            *reinterpret_cast<double2*>(tap_conv + ((size_t)w * NJ + r0 + rowB) * S + 2 * n) = make_double2(y[k2].x, y[k2].y);
+                    }
+                }
+            }
             if (actB) {
 #pragma unroll
                 for (int k2 = 0; k2 < P2; ++k2) {
@@ -475,7 +590,7 @@ jx_beamfir_reg_kernel(JxConv c, const int* __restrict__ runs, int nrun, int nwal
                       cplx* __restrict__ C) {
     constexpr int W = 2 * O + 1, D = jx_fir_depth<W>();
     static_assert(W >= 8, "the accumulator chains assume at least 8 taps");
-    const int lane = threadIdx.x, S = c.S, ld = 2 * c.Ph;
+    const int lane = threadIdx.x, S = c.S, ld = c.fir_ld;             // Ph real columns (xsym) or 2 Ph (re, im interleaved)
     // XCD-aware decode of the 1-D grid: workgroups are dealt round-robin over the 8 XCDs, so ids that agree
     // mod 8 share an L2.  All runs of one (walker, column slab) unit get the same id mod 8 and consecutive
     // id / 8, so the 2O halo rows two neighbouring runs both read are served by that L2 (speed only).
@@ -491,8 +606,9 @@ jx_beamfir_reg_kernel(JxConv c, const int* __restrict__ runs, int nrun, int nwal
     const double* Yw = reinterpret_cast<const double*>(Y) + (size_t)w * c.NU * ld + col;
     double* Cw = reinterpret_cast<double*>(C) + (size_t)w * c.CROWS * ld + col;
     double tap[O + 1];
+    const int tcol = c.xsym ? col : (col >> 1);
 #pragma unroll
-    for (int t = 0; t <= O; ++t) tap[t] = c.taps[(size_t)t * c.Ph + (col >> 1)];
+    for (int t = 0; t <= O; ++t) tap[t] = c.taps[(size_t)t * c.Ph + tcol];
     double win[W], fifo[D];
     // window before phase 0 of conv row r0: input i (map row r0 - O + i), i = 0..2O-1, sits in slot (1 + i) % W;
     // the row r0 + O (i = 2O) arrives through the fifo at phase 0, then r0+O+1.. for the following phases.

@@ -16,7 +16,7 @@ ABI_VERSION = 1
 EXPORTS = (
     'jx_create', 'jx_upload', 'jx_finalize', 'jx_eval', 'jx_eval_device', 'jx_sync', 'jx_eval_stage',
     'jx_set_par_vals', 'jx_dev_alloc', 'jx_dev_free', 'jx_memcpy_h2d', 'jx_memcpy_d2h',
-    'jx_timing_reset', 'jx_timing_enable', 'jx_timing_get', 'jx_get_info', 'jx_get_conv_mode', 'jx_device_count',
+    'jx_timing_reset', 'jx_timing_enable', 'jx_timing_get', 'jx_get_info', 'jx_get_conv_mode', 'jx_debug_workspace', 'jx_device_count',
     'jx_device_name', 'jx_strerror', 'jx_last_error', 'jx_destroy',
 )
 
@@ -81,6 +81,7 @@ def load_library(path=None):
     i32p, i64p = ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int64)
     lib.jx_get_info.argtypes = [vp, i32p, i32p, i32p, i32p, i64p]
     lib.jx_get_conv_mode.argtypes = [vp]
+    lib.jx_debug_workspace.argtypes = [vp, ci, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int32)]
     lib.jx_device_count.argtypes = []
     lib.jx_device_name.argtypes = [vp]
     lib.jx_device_name.restype = ctypes.c_char_p
@@ -225,6 +226,18 @@ class HipContext:
     def h2d(self, ptr, arr):
         a = np.ascontiguousarray(arr)
         self._chk(self.lib.jx_memcpy_h2d(self._h, ctypes.c_void_p(ptr), a.ctypes.data_as(ctypes.c_void_p), a.nbytes), 'jx_memcpy_h2d')
+
+    def workspace(self, which, walkers=None):
+        """Test hook: copy of a work buffer of the hand-written convolution (``jx_debug_workspace``)."""
+        ids = {'y_2d': 0, 'row_spectra': 1, 'fir_rows': 2, 'col0': 3, 'job_rows': 4, 'row_index': 5}
+        ptr = ctypes.c_void_p()
+        geom = (ctypes.c_int32 * 4)()
+        self._chk(self.lib.jx_debug_workspace(self._h, ids[which], ctypes.byref(ptr), geom), 'jx_debug_workspace')
+        n = geom[0] if walkers is None else min(walkers, geom[0])
+        out = np.empty((n, geom[1], geom[2]), np.int32 if ids[which] >= 4 else np.float64)
+        self.sync()
+        self.d2h(out, ptr.value)
+        return out, bool(geom[3])
 
     def d2h(self, arr, ptr):
         assert arr.flags['C_CONTIGUOUS']

@@ -199,24 +199,30 @@ def test_custom_conv_refuses_what_it_cannot_do(golden_tiny):
 
 
 def test_custom_conv_with_and_without_row_symmetry(monkeypatch):
-    """The row bookkeeping (distinct map rows, conv jobs) must not change any number:
-    identity tables (JOXSZ_CONV_NOSYM=1) against the mirrored ones, even and 'odd-like' cases."""
+    """The row bookkeeping (distinct map rows, conv jobs) and the real-spectrum form of x-symmetric
+    rows must not change any number: identity tables (JOXSZ_CONV_NOSYM=1), mirrored rows with complex
+    spectra (JOXSZ_CONV_XSYM=0) and the default (both symmetries) against each other and the oracle."""
     from joxsz_amd import datasets
-    for S, N in ((64, 80), (256, 300)):
-        pb = datasets.synthetic_problem(S=S, N=N, seed=9)
+    modes = {'full': {}, 'rows_only': {'JOXSZ_CONV_XSYM': '0'}, 'none': {'JOXSZ_CONV_NOSYM': '1'}}
+    for S, N, fwhm in ((64, 80, 18.5), (256, 300, 18.5), (512, 300, 9.0)):
+        pb = datasets.synthetic_problem(S=S, N=N, seed=9, fwhm=fwhm)
         th = datasets.walker_ball(pb, 4, spread=0.04, seed=9)
         res = {}
-        for nosym in ('0', '1'):
-            monkeypatch.setenv('JOXSZ_CONV_NOSYM', nosym)
+        for mode, env in modes.items():
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
             post = _post(pb, conv='custom')
-            res[nosym] = (post.stage(th, 'conv_2d'), post.stage(th, 'map_row'), post.log_prob(th))
+            res[mode] = (post.stage(th, 'conv_2d'), post.stage(th, 'map_row'), post.log_prob(th))
             post.close()
-        monkeypatch.delenv('JOXSZ_CONV_NOSYM')
-        for a, b in zip(res['0'], res['1']):
-            np.testing.assert_allclose(a, b, rtol=1e-11, atol=1e-13 * np.abs(b).max())
+            for k in env:
+                monkeypatch.delenv(k)
+        for mode in ('rows_only', 'none'):
+            for a, b in zip(res['full'][:2], res[mode][:2]):
+                np.testing.assert_allclose(a, b, rtol=1e-11, atol=1e-13 * np.abs(b).max(), err_msg=mode)
+            np.testing.assert_allclose(res['full'][2], res[mode][2], rtol=1e-9, err_msg=mode)     # chi^2 amplifies round-off
         st = orc.sz_stages(pb, orc.pars_dict(pb, th[0]))
-        assert _relerr(res['0'][0][0], st['conv_2d']) < RTOL_STAGE
-        assert _relerr(res['0'][1][0], st['map_row']) < RTOL_STAGE
+        assert _relerr(res['full'][0][0], st['conv_2d']) < RTOL_STAGE
+        assert _relerr(res['full'][1][0], st['map_row']) < RTOL_STAGE
 
 
 def test_largest_config_shape():
