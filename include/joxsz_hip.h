@@ -176,7 +176,8 @@ int  jx_get_info(jx_ctx* ctx, int32_t* fft_pad, int32_t* chunk, int32_t* spline_
 /* 1 = rocFFT, 2 = hand-written passes (what `conv_mode` resolved to); <0 on error */
 int  jx_get_conv_mode(jx_ctx* ctx);
 /* Test hook (hand-written convolution only): device address and geometry of a work buffer, holding the last
- * evaluated chunk.  which: 0 Compton-y maps [chunk][S][S], 1 pass-1 row spectra [chunk][NU][ld], 2 FIR output
+ * evaluated chunk.  which: 0 Compton-y maps [chunk][S][S] (geom[3] = 0) or their quadrant of
+ * distinct pixels [chunk][S/2+1][ld], entry (|iy-c|, |ix-c|) (geom[3] = 1), 1 pass-1 row spectra [chunk][NU][ld], 2 FIR output
  * [chunk][NJ+1][ld], 3 column-0 terms [chunk][NJ][o+1] (doubles); 4 conv row of each job [NJ], 5 distinct-row index
  * of each map row [S] (int32).  geom = {chunk, rows, ld, xsym}: ld doubles per row, xsym = 1 when rows 1 and 2 hold
  * the real array R of  Y(kx) = x0 + e^{-2 pi i kx (S/2)/P} R(kx),  0 when they hold (re, im) pairs. */

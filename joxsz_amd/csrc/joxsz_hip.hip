@@ -68,6 +68,7 @@ struct jx_ctx {
     int nrun = 0, fir_reg = 0;
     double* t_convjobs = nullptr;
     double* t_conv = nullptr;
+    double* t_y2d = nullptr;          // full Compton-y maps mirrored out of the quadrant (Y2D stage tap only)
     void* d_work = nullptr;
     size_t work_cap = 0;
     // batch staging for the host-pointer API
@@ -532,6 +533,10 @@ int jx_finalize(jx_ctx* ctx) {
         if (na > 9 * 64) sym = false;                 // register-resident half row: |ix-c| < 576
         d.fast_map = sym ? 1 : 0;
         d.q_na = d.q_nb = na;
+        // x-symmetric convolution + symmetric map kernel: only the quadrant of distinct pixels is ever stored
+        d.quad = (ctx->conv_mode == 2 && ctx->cv.xsym && sym && na == S / 2 + 1) ? 1 : 0;
+        if (const char* e = getenv("JOXSZ_FULL_MAP")) { if (atoi(e) > 0) d.quad = 0; }
+        ctx->cv.quad = d.quad;
         if (sym) {
             std::vector<int32_t> qk((size_t)na * na);
             std::vector<double> qt((size_t)na * na);
@@ -554,9 +559,10 @@ int jx_finalize(jx_ctx* ctx) {
     // ---- chunk capacity and work buffers
     const size_t per_walker = (ctx->conv_mode == 1)
         ? sizeof(double) * ((size_t)P * P * 2 + (size_t)P * ctx->Ph * 2 + (size_t)S * ctx->Sh * 2)
-        : sizeof(double) * ((size_t)S * S + (size_t)(ctx->cv.NU + ctx->cv.CROWS) * ctx->cv.fir_ld + (size_t)ctx->cv.NJ * 28 + (size_t)ctx->cv.nblk3 * ctx->Sh * 2);
+        : sizeof(double) * ((d.quad ? (size_t)d.q_nb * (d.q_na + 3) : (size_t)S * S) + (size_t)(ctx->cv.NU + ctx->cv.CROWS) * ctx->cv.fir_ld + (size_t)ctx->cv.NJ * 28 + (size_t)ctx->cv.nblk3 * ctx->Sh * 2);
     d.img_ld = (ctx->conv_mode == 1) ? P : S;
     d.img_ws = (ctx->conv_mode == 1) ? (long long)P * P : (long long)S * S;
+    if (d.quad) { d.img_ld = (d.q_na + 3) & ~1; d.img_ws = (long long)d.q_nb * d.img_ld; }     // even stride, >= 1 spare column
     int chunk = c.max_batch > 0 ? c.max_batch : 1024;   // >= 4 map blocks per CU: launches desynchronise, stores overlap compute
     if (const char* e = getenv("JOXSZ_CHUNK")) { int v = atoi(e); if (v > 0) chunk = v; }
     const size_t budget = (size_t)24 << 30;
@@ -595,7 +601,7 @@ int jx_finalize(jx_ctx* ctx) {
         if ((rc = dev_new(ctx, (size_t)chunk * S * ctx->Sh, &ctx->d_tfspec))) return rc;
     } else {
         const JxConv& cv = ctx->cv;
-        if ((rc = dev_new(ctx, (size_t)chunk * S * S, &ctx->d_img))) return rc;
+        if ((rc = dev_new(ctx, (size_t)chunk * d.img_ws, &ctx->d_img, true))) return rc;
         const size_t spec_div = cv.xsym ? 2 : 1;                           // real arrays need half the complex count
         if ((rc = dev_new(ctx, ((size_t)chunk * cv.NU * cv.Ph + 1) / spec_div, &ctx->d_Y))) return rc;
         if ((rc = dev_new(ctx, ((size_t)chunk * cv.CROWS * cv.Ph + 1) / spec_div, &ctx->d_C))) return rc;
@@ -844,6 +850,8 @@ int jx_eval_stage(jx_ctx* ctx, const double* theta, int nwalkers, int stage, dou
         if ((rc = dev_new(ctx, (size_t)ctx->chunk * S * S, &ctx->t_conv))) return rc;
         if ((rc = dev_new(ctx, (size_t)ctx->chunk * ctx->cv.NJ * S, &ctx->t_convjobs))) return rc;
     }
+    const bool y2d_quad = (stage == JX_STAGE_Y2D && ctx->d.quad);
+    if (y2d_quad && !ctx->t_y2d && (rc = dev_new(ctx, (size_t)ctx->chunk * S * S, &ctx->t_y2d))) return rc;
     if ((rc = ensure_batch(ctx, nwalkers))) return rc;
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_theta, theta, sizeof(double) * (size_t)nwalkers * c.ndim, hipMemcpyHostToDevice, ctx->stream));
     Taps t;
@@ -871,9 +879,12 @@ int jx_eval_stage(jx_ctx* ctx, const double* theta, int nwalkers, int stage, dou
             HIPCHK(ctx, hipMemcpyAsync(dst, src, per * sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
         } else {
             const bool dense = (stage == JX_STAGE_CONV2D && ctx->conv_mode == 2);
-            const double* base = (stage == JX_STAGE_Y2D) ? ctx->d_img : (dense ? ctx->t_conv : ctx->d_conv);
-            const size_t ld = (stage == JX_STAGE_Y2D) ? (size_t)ctx->d.img_ld : (dense ? S : P);
-            const size_t ws = (stage == JX_STAGE_Y2D) ? (size_t)ctx->d.img_ws : (dense ? S * S : P * P);
+            if (y2d_quad)
+                hipLaunchKernelGGL(jx_expand_quad_kernel, dim3((unsigned)S, n), dim3(256), 0, ctx->stream, ctx->d_img, (size_t)ctx->d.img_ld,
+                                   (size_t)ctx->d.img_ws, (int)S, ctx->t_y2d);
+            const double* base = (stage == JX_STAGE_Y2D) ? (y2d_quad ? ctx->t_y2d : ctx->d_img) : (dense ? ctx->t_conv : ctx->d_conv);
+            const size_t ld = (stage == JX_STAGE_Y2D) ? (y2d_quad ? (size_t)S : (size_t)ctx->d.img_ld) : (dense ? S : P);
+            const size_t ws = (stage == JX_STAGE_Y2D) ? (y2d_quad ? (size_t)S * S : (size_t)ctx->d.img_ws) : (dense ? S * S : P * P);
             for (int w = 0; w < n; ++w)
                 HIPCHK(ctx, hipMemcpy2DAsync(dst + (size_t)w * S * S, S * sizeof(double), base + (size_t)w * ws,
                                              ld * sizeof(double), S * sizeof(double), S, hipMemcpyDeviceToHost, ctx->stream));
@@ -963,7 +974,7 @@ int jx_debug_workspace(jx_ctx* ctx, int which, void** dev, int32_t geom[4]) {
     const JxConv& cv = ctx->cv;
     geom[0] = ctx->chunk; geom[3] = cv.xsym;
     switch (which) {
-        case 0: *dev = ctx->d_img; geom[1] = cv.S; geom[2] = cv.S; break;
+        case 0: *dev = ctx->d_img; geom[1] = ctx->d.quad ? ctx->d.q_nb : cv.S; geom[2] = (int)ctx->d.img_ld; geom[3] = ctx->d.quad; break;
         case 1: *dev = ctx->d_Y; geom[1] = cv.NU; geom[2] = cv.fir_ld; break;
         case 2: *dev = ctx->d_C; geom[1] = cv.CROWS; geom[2] = cv.fir_ld; break;
         case 3: if (!cv.xsym) { ctx->err = "no column-0 terms in this mode"; return JX_ERR_UNSUPPORTED; }

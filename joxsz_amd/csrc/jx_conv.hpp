@@ -55,6 +55,7 @@ struct JxConv {
     int mirror;                     // 1: umap[m] = |m - S/2| (mirror structure), 0: umap[m] = m
     int xsym;                       // 1: map rows are also mirror-symmetric in x: Y and C hold ONE real array per row
     int fir_ld;                     // doubles per row of Y / C: Ph (xsym) or 2 Ph
+    int quad;                       // 1: the map arrives as its quadrant [S/2+1][img_ld] of distinct pixels (|iy-c|, |ix-c|)
     const cplx* zab;                // [LP][2] pass-3 pre-process factors: Z[k] = zab[k][0] Rc[k] + zab[k][1] Rc[LP-k]   (xsym)
     const double* bcol;             // [o+1][o+1] step^2 beam[o+t][o+x]: what column 0 of a map row adds to output column x  (xsym)
     double* col0;                   // [walkers][NJ][o+1] what column 0 of the map adds to output columns 0..o of each job (xsym)
@@ -147,7 +148,39 @@ jx_rowfft2_kernel(JxConv c, const double* __restrict__ img, size_t img_ld, size_
     const int rowA = tid / L2, n2 = tid - rowA * L2;
     const bool actA = tid < ROWS * L2 && rowA < nrows;
     jx_c x[L1];
-    if (actA) {
+    if (c.quad) {
+        // quadrant row u = r0 + row holds q[a] = map[.][c +- a], a = 0..c (c = S/2, even).  Staged through the row's own
+        // LDS slot with coalesced 16-byte loads; columns (2n, 2n+1) are (q[c-2n], q[c-2n-1]) left of the centre and
+        // (q[2n-c], q[2n-c+1]) from it on.
+        const int npair = (half >> 1) + 1;                            // q[0..c] in pairs (the spare column rides along)
+        const double* qb = img + (size_t)w * img_ws + (size_t)r0 * img_ld;
+        constexpr int NIT = (ROWS * (LP / 2 + 1) + 255) / 256;         // npair <= LP/2 + 1, blockDim = 256
+        const int tot = nrows * npair;
+        double2 stg[NIT];
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {                               // every request before the first use
+            const int e = min(tid + i * nth, tot - 1), row = e / npair, j = e - row * npair;
+            stg[i] = *reinterpret_cast<const double2*>(qb + (size_t)row * img_ld + 2 * j);
+        }
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int e = tid + i * nth, row = e / npair, j = e - row * npair;
+            if (e < tot) *reinterpret_cast<double2*>(reinterpret_cast<double*>(M + row * RS) + 2 * j) = stg[i];
+        }
+        __syncthreads();
+        if (actA) {
+            const double* q = reinterpret_cast<const double*>(M + rowA * RS);
+#pragma unroll
+            for (int n1 = 0; n1 < L1; ++n1) {
+                const int n = n1 * L2 + n2;
+                x[n1] = jxc(0.0, 0.0);
+                if (n < half) {
+                    if (2 * n < half) x[n1] = jxc(q[half - 2 * n], q[half - 2 * n - 1]);
+                    else { const double2 v = *reinterpret_cast<const double2*>(q + 2 * n - half); x[n1] = jxc(v.x, v.y); }
+                }
+            }
+        }
+    } else if (actA) {
         const int u = r0 + rowA;                                    // == c.urow[u] without the dependent load
         const int mrow = c.mirror ? ((half + u < c.S) ? half + u : half - u) : u;
         const double* src = img + (size_t)w * img_ws + (size_t)mrow * img_ld;
@@ -157,6 +190,8 @@ jx_rowfft2_kernel(JxConv c, const double* __restrict__ img, size_t img_ld, size_
             x[n1] = jxc(0.0, 0.0);
             if (n < half) { const double2 v = *reinterpret_cast<const double2*>(src + 2 * n); x[n1] = jxc(v.x, v.y); }
         }
+    }
+    if (actA) {
         if (n2 == 0) s_x0[rowA] = (c.S & 1) ? 0.0 : x[0].x;           // column 0 has no mirror partner on an even side
     }
     __syncthreads();
@@ -203,7 +238,8 @@ jx_col0_kernel(JxConv c, const double* __restrict__ img, size_t img_ld, size_t i
     const int tid = threadIdx.x, nth = blockDim.x, w = blockIdx.x, S = c.S, o = c.o, nt = o + 1;
     for (int m = tid; m < S + 2 * o; m += nth) {
         const int r = m - o;
-        s_x0[m] = (r >= 0 && r < S) ? img[(size_t)w * img_ws + (size_t)r * img_ld] : 0.0;
+        s_x0[m] = (r >= 0 && r < S) ? (c.quad ? img[(size_t)w * img_ws + (size_t)abs(r - (S >> 1)) * img_ld + (S >> 1)]
+                                               : img[(size_t)w * img_ws + (size_t)r * img_ld]) : 0.0;
     }
     for (int e = tid; e < nt * nt; e += nth) s_b[e] = c.bcol[e];
     __syncthreads();
@@ -247,24 +283,24 @@ jx_rowtf2_kernel(JxConv c, const cplx* __restrict__ C, cplx* __restrict__ part, 
         double cz[NSL];                                              // this block's slice of col0, requested first
 #pragma unroll
         for (int u = 0; u < NSL; ++u) cz[u] = c.col0[((size_t)w * NJ + r0) * nt + min(tid + u * nth, ns - 1)];
-        for (int e0 = tid; e0 < npre; e0 += 4 * nth) {
-            double rk[4], rc[4];
-            cplx za[4], zb[4];
+        // one thread per pair (k, LP-k): the same two reals of every row make Z[k] and Z[LP-k]; all rows requested at once
+        for (int k = tid; 2 * k <= LP; k += nth) {
+            const int kp = LP - k, kq = kp == LP ? 0 : kp;
+            double r1[ROWS], r2[ROWS];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = min(e0 + u * nth, npre - 1), row = e / LP, k = e - row * LP;
-                rk[u] = Rblk[(size_t)row * Ph + k];
-                rc[u] = Rblk[(size_t)row * Ph + LP - k];
-                za[u] = c.zab[2 * k];
-                zb[u] = c.zab[2 * k + 1];
+            for (int row = 0; row < ROWS; ++row) {
+                const int rr = min(row, nrows - 1);
+                r1[row] = Rblk[(size_t)rr * Ph + k];
+                r2[row] = Rblk[(size_t)rr * Ph + kp];
             }
+            const cplx za1 = c.zab[2 * k], zb1 = c.zab[2 * k + 1], za2 = c.zab[2 * kq], zb2 = c.zab[2 * kq + 1];
+            const int n1a = k / P2, n2a = k - n1a * P2, n1b = kq / P2, n2b = kq - n1b * P2;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = e0 + u * nth;
-                if (e < npre) {
-                    const int row = e / LP, k = e - row * LP;
-                    const int n1 = k / P2, n2 = k - n1 * P2;
-                    M[row * RS + n1 * P2P + n2] = make_double2(fma(za[u].x, rk[u], zb[u].x * rc[u]), fma(za[u].y, rk[u], zb[u].y * rc[u]));
+            for (int row = 0; row < ROWS; ++row) {
+                if (row < nrows) {
+                    M[row * RS + n1a * P2P + n2a] = make_double2(fma(za1.x, r1[row], zb1.x * r2[row]), fma(za1.y, r1[row], zb1.y * r2[row]));
+                    if (kp != k && kp != LP)
+                        M[row * RS + n1b * P2P + n2b] = make_double2(fma(za2.x, r2[row], zb2.x * r1[row]), fma(za2.y, r2[row], zb2.y * r1[row]));
                 }
             }
         }
@@ -391,24 +427,37 @@ jx_rowtf2_kernel(JxConv c, const cplx* __restrict__ C, cplx* __restrict__ part, 
         }
         __syncthreads();
     }
-    for (int k = tid; k < Sh; k += nth) {
-        const cplx tk = c.tw_s[k];
-        cplx h[ROWS];                                        // the Hy weights of the block's jobs, requested up front
+    {
+        // Hy-weighted sum over the block's jobs, k = tid + 256 j.  The weights of every k of this thread are requested
+        // before the first use (k = LS alone would otherwise cost a second round trip).
+        constexpr int NKT = (LS + 1 + 255) / 256;
+        cplx h[NKT][ROWS], tk[NKT];
 #pragma unroll
-        for (int row = 0; row < ROWS; ++row) h[row] = c.hy[(size_t)min(r0 + row, NJ - 1) * Sh + k];
-        double zr = 0.0, zi = 0.0;
+        for (int j = 0; j < NKT; ++j) {
+            const int k = min(tid + j * nth, Sh - 1);
+            tk[j] = c.tw_s[k];
 #pragma unroll
-        for (int row = 0; row < ROWS; ++row) {
-            if (row < nrows) {
-                const cplx zk = M[row * RS + (k == LS ? 0 : k)];
-                const cplx zc = c_conj(M[row * RS + (k == 0 ? 0 : LS - k)]);
-                const cplx s = c_add(zk, zc), d = c_mul(c_sub(zk, zc), tk);
-                const cplx x = make_double2(0.5 * (s.x + d.y), 0.5 * (s.y - d.x));
-                zr += x.x * h[row].x - x.y * h[row].y;
-                zi += x.x * h[row].y + x.y * h[row].x;
+            for (int row = 0; row < ROWS; ++row) h[j][row] = c.hy[(size_t)min(r0 + row, NJ - 1) * Sh + k];
+        }
+#pragma unroll
+        for (int j = 0; j < NKT; ++j) {
+            const int k = tid + j * nth;
+            if (k < Sh) {
+                double zr = 0.0, zi = 0.0;
+#pragma unroll
+                for (int row = 0; row < ROWS; ++row) {
+                    if (row < nrows) {
+                        const cplx zk = M[row * RS + (k == LS ? 0 : k)];
+                        const cplx zc = c_conj(M[row * RS + (k == 0 ? 0 : LS - k)]);
+                        const cplx s = c_add(zk, zc), d = c_mul(c_sub(zk, zc), tk[j]);
+                        const cplx x = make_double2(0.5 * (s.x + d.y), 0.5 * (s.y - d.x));
+                        zr += x.x * h[j][row].x - x.y * h[j][row].y;
+                        zi += x.x * h[j][row].y + x.y * h[j][row].x;
+                    }
+                }
+                part[((size_t)w * c.nblk3 + blockIdx.x) * Sh + k] = make_double2(zr, zi);
             }
         }
-        part[((size_t)w * c.nblk3 + blockIdx.x) * Sh + k] = make_double2(zr, zi);
     }
 }
 
@@ -634,6 +683,15 @@ jx_beamfir_reg_kernel(JxConv c, const int* __restrict__ runs, int nrun, int nwal
     __builtin_amdgcn_sched_barrier(0);
     for (int t0 = 0; t0 < cnt; t0 += W)
         jx_fir_run_phases<O, 0>(win, fifo, tap, mirror, Yw, Cw, ld, S, c.NJ, r0 + t0, q0 + t0, cnt - t0);
+}
+
+// mirror the quadrant of distinct pixels into the full S x S Compton-y map (parity tap only)
+__global__ void __launch_bounds__(256)
+jx_expand_quad_kernel(const double* __restrict__ quad, size_t q_ld, size_t q_ws, int S, double* __restrict__ full /*[W][S][S]*/) {
+    const int r = blockIdx.x, w = blockIdx.y, c = S >> 1;
+    const double* src = quad + (size_t)w * q_ws + (size_t)abs(r - c) * q_ld;
+    double* dst = full + ((size_t)w * S + r) * S;
+    for (int x = threadIdx.x; x < S; x += blockDim.x) dst[x] = src[abs(x - c)];
 }
 
 // expand job rows to the full S x S beam-convolved map (parity tap only)

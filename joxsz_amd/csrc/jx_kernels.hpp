@@ -51,6 +51,7 @@ struct JxDev {
     long long img_ld, img_ws;    // row and walker strides (doubles) of the y-map image
     int dbg;                     // timing-only ablations (JOXSZ_DBG): 1 skip phases 1-4, 2 skip phase 5, 4 phase 5 stores only
     int fast_map, q_na, q_nb;    // symmetric-map form: table sizes (|ix-c|, |iy-c|)
+    int quad;                    // 1: the image is the quadrant [q_nb][img_ld] (|iy-c|, |ix-c|) alone, nothing mirrored
     const int* q_k;              // [q_nb*q_na] coefficient slot of each quadrant radius
     const double* q_t;           // [q_nb*q_na] local abscissa within that slot
     const double* abel_tab;      // [N][4] (r_j, cj_j, dg_j, sp_j):  A[i][j] = cj_j / sqrt(r_j^2 - r_i^2) for j >= i+2,
@@ -589,6 +590,35 @@ jx_abel_map_sym_kernel(JxDev c, const double* __restrict__ pvec, double* __restr
             kq[u] = ok ? c.q_k[(size_t)b * na + a] : N;
             tq[u] = ok ? c.q_t[(size_t)b * na + a] : 0.0;
         }
+    }
+    if (c.quad) {
+        // the distinct pixels only: row b of the quadrant, one coalesced store per 64 abscissae
+        for (; b < b1; b += nwv) {
+            double v[NAIT];
+#pragma unroll
+            for (int u = 0; u < NAIT; ++u) {
+                const double t = tq[u];
+                const double* cf = s_cf + 4 * kq[u];
+                v[u] = fma(t, fma(t, fma(t, cf[3], cf[2]), cf[1]), cf[0]);
+            }
+            const int bn = b + nwv;
+            if (bn < b1) {
+#pragma unroll
+                for (int u = 0; u < NAIT; ++u) {
+                    const int a = lane + 64 * u;
+                    const bool ok = a < na;
+                    kq[u] = ok ? c.q_k[(size_t)bn * na + a] : N;
+                    tq[u] = ok ? c.q_t[(size_t)bn * na + a] : 0.0;
+                }
+            }
+            double* orow = out + (size_t)b * c.img_ld;
+#pragma unroll
+            for (int u = 0; u < NAIT; ++u) {
+                const int a = lane + 64 * u;
+                if (a < na) orow[a] = v[u];
+            }
+        }
+        return;
     }
     for (; b < b1; b += nwv) {
         // evaluate the half row and mirror it into the full row

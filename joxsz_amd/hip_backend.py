@@ -229,7 +229,7 @@ class HipContext:
 
     def workspace(self, which, walkers=None):
         """Test hook: copy of a work buffer of the hand-written convolution (``jx_debug_workspace``)."""
-        ids = {'y_2d': 0, 'row_spectra': 1, 'fir_rows': 2, 'col0': 3, 'job_rows': 4, 'row_index': 5}
+        ids = {'y_map': 0, 'row_spectra': 1, 'fir_rows': 2, 'col0': 3, 'job_rows': 4, 'row_index': 5}
         ptr = ctypes.c_void_p()
         geom = (ctypes.c_int32 * 4)()
         self._chk(self.lib.jx_debug_workspace(self._h, ids[which], ctypes.byref(ptr), geom), 'jx_debug_workspace')

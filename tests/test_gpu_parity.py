@@ -225,6 +225,59 @@ def test_custom_conv_with_and_without_row_symmetry(monkeypatch):
         assert _relerr(res['full'][1][0], st['map_row']) < RTOL_STAGE
 
 
+@pytest.mark.parametrize('S,N', [(64, 80), (512, 500)])
+def test_conv_work_buffers_against_numpy(S, N):
+    """Each hand-written pass on its own (jx_debug_workspace): row spectra, FIR output and the
+    column-0 terms against numpy FFTs of the Compton-y map the same evaluation produced."""
+    from joxsz_amd import datasets
+    pb = datasets.synthetic_problem(S=S, N=N, seed=5)
+    th = datasets.walker_ball(pb, 2, spread=0.03, seed=5)
+    post = _post(pb, conv='custom', max_batch=2)
+    y2d = post.stage(th, 'y_2d')
+    post.log_prob(th)
+    ctx = post.ctx
+    y, quad = ctx.workspace('y_map')
+    if quad:                                                  # only the distinct pixels (|iy-c|, |ix-c|) are stored
+        idx = np.abs(np.arange(S) - S // 2)
+        y = y[:, idx][:, :, idx]
+    np.testing.assert_array_equal(y, y2d)
+    Y, xsym = ctx.workspace('row_spectra')
+    C, _ = ctx.workspace('fir_rows')
+    jrow = ctx.workspace('job_rows')[0][0, :, 0]
+    umap = ctx.workspace('row_index')[0][0, :, 0]
+    assert xsym, 'default mode for a mirror-symmetric d_mat and this beam width'
+    col0, _ = ctx.workspace('col0')
+    post.close()
+    Ph = Y.shape[2]; P = 2 * (Ph - 1); c = S // 2; B = pb.B; o = (B - 1) // 2
+    phase = np.exp(2j * np.pi * np.arange(Ph) * c / P)
+    beam = np.asarray(pb.beam_2d, float)
+    # beam spectrum along x per row offset d = -o..o (centred: column o is x offset 0)
+    bhat = np.fft.rfft(np.roll(np.pad(beam, ((0, 0), (0, P - B))), -o, axis=1), axis=1) * pb.step ** 2 / P
+    first = np.array([np.nonzero(umap == u)[0][0] for u in range(Y.shape[1])])
+    for w in range(2):
+        m0 = y[w].copy(); m0[:, 0] = 0.0                      # the unpaired column travels separately
+        spec = np.fft.rfft(m0, n=P, axis=1)
+        want = spec[first] * phase
+        scale = np.abs(want).max()
+        assert np.abs(want.imag).max() < 1e-13 * scale
+        assert np.abs(Y[w] - want.real).max() < 1e-13 * scale
+        conv = np.zeros((len(jrow), Ph), complex)
+        for q, r in enumerate(jrow):
+            for d in range(-o, o + 1):
+                if 0 <= r - d < S:
+                    conv[q] += bhat[o + d] * spec[r - d]
+        want_c = conv * phase
+        scale = np.abs(want_c).max()
+        assert np.abs(want_c.imag).max() < 1e-12 * scale
+        assert np.abs(C[w][:len(jrow)] - want_c.real).max() < 1e-12 * scale
+        want0 = np.zeros((len(jrow), o + 1))
+        for q, r in enumerate(jrow):
+            for d in range(-o, o + 1):
+                if 0 <= r - d < S:
+                    want0[q] += pb.step ** 2 * beam[o + d, o:] * y[w][r - d, 0]
+        assert np.abs(col0[w] - want0).max() < 1e-13 * np.abs(want0).max()
+
+
 def test_largest_config_shape():
     """BASELINE configs[4] shape (S=1024, N=1000): two walkers against the oracle, both back ends."""
     from joxsz_amd import datasets
