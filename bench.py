@@ -232,6 +232,11 @@ def main():
         walkers_per_launch = tm['walkers'] / launches
         alg_bytes = walkers_per_launch * S * S * 8.0          # S^2*E written per walker
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        lay = ctx.conv_layout or {}
+        quad = bool(lay.get('quad'))
+        # what the kernel really stores: with the x-symmetric convolution only the distinct pixels (|iy-c|, |ix-c|)
+        stored_bytes = walkers_per_launch * (lay['img_rows'] * lay['img_ld'] + lay['img_rows']) * 8.0 if quad else alg_bytes
+        stored_rate = stored_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         value = W * world * args.steps / elapsed
         out = {
             'metric': 'walker-likelihoods/sec at 512^2 map, 500-pt grid' if (S, args.N) == (512, 500)
@@ -244,11 +249,16 @@ def main():
                                    % (W, S, S, args.N, 'SZ-only' if pb.sz_only else 'joint X-ray+SZ',
                                       ' (BASELINE configs[2])' if (W, S, args.N, pb.sz_only) == (1024, 512, 500, False) else ''),
                        'walkers_per_gpu': W, 'S': S, 'N': args.N, 'B': pb.B, 'fft_pad': ctx.fft_pad,
-                       'chunk': ctx.chunk, 'conv': ctx.conv, 'parallelism': 'walkers sharded x%d' % world, 'device': ctx.device_name},
+                       'chunk': ctx.chunk, 'conv': ctx.conv, 'conv_layout': ctx.conv_layout, 'parallelism': 'walkers sharded x%d' % world, 'device': ctx.device_name},
             'roofline': {'kernel': 'jx_abel_map_sym_kernel', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': pmc_traffic('jx_abel_map', walkers_per_launch, S),
-                         'launch_ms': k_ms, 'bytes_per_launch': alg_bytes},
+                         'launch_ms': k_ms, 'bytes_per_launch': alg_bytes,
+                         'stored_bytes_per_launch': stored_bytes, 'stored_GBps': stored_rate, 'stored_frac': stored_rate / HBM_PEAK_GBS,
+                         'note': ('achieved/frac use SURVEY 8(d)\'s algorithmic figure, S^2*8 B per walker; the kernel stores only the '
+                                  '(S/2+1)^2 distinct pixels of the mirror-symmetric map (stored_*), so frac can exceed 1 and the '
+                                  'kernel is bound by fp64 issue, not by HBM; JOXSZ_FULL_MAP=1 stores the full map') if quad
+                                 else 'full S x S map stored'},
             'cpu_baseline': cpu,
             'stage_ms_per_step': {k: tm[k] / args.steps for k in
                                   ('prep_ms', 'abel_map_ms', 'beam_fft_ms', 'tf_fft_ms', 'tail_ms', 'total_ms')},

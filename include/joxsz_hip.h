@@ -175,10 +175,15 @@ int  jx_get_info(jx_ctx* ctx, int32_t* fft_pad, int32_t* chunk, int32_t* spline_
                  int32_t* nrow, int64_t* device_bytes);
 /* 1 = rocFFT, 2 = hand-written passes (what `conv_mode` resolved to); <0 on error */
 int  jx_get_conv_mode(jx_ctx* ctx);
+/* Layout the library chose for the hand-written convolution: out = {xsym, quad, NU, NJ, ld, img_rows, img_ld, P}.
+ * xsym: row spectra travel as one real array (ld doubles per row); quad: the Abel+map kernel stores only the
+ * img_rows x img_ld quadrant of distinct pixels per walker instead of the S x S map; NU distinct map rows, NJ
+ * convolution jobs, P padded transform length.  JX_ERR_UNSUPPORTED with the rocFFT back end. */
+int  jx_get_conv_layout(jx_ctx* ctx, int32_t out[8]);
 /* Test hook (hand-written convolution only): device address and geometry of a work buffer, holding the last
  * evaluated chunk.  which: 0 Compton-y maps [chunk][S][S] (geom[3] = 0) or their quadrant of
  * distinct pixels [chunk][S/2+1][ld], entry (|iy-c|, |ix-c|) (geom[3] = 1), 1 pass-1 row spectra [chunk][NU][ld], 2 FIR output
- * [chunk][NJ+1][ld], 3 column-0 terms [chunk][NJ][o+1] (doubles); 4 conv row of each job [NJ], 5 distinct-row index
+ * [chunk][NJ+1][ld], 3 column-0 terms [chunk][o+1][NJ] (doubles); 4 conv row of each job [NJ], 5 distinct-row index
  * of each map row [S] (int32).  geom = {chunk, rows, ld, xsym}: ld doubles per row, xsym = 1 when rows 1 and 2 hold
  * the real array R of  Y(kx) = x0 + e^{-2 pi i kx (S/2)/P} R(kx),  0 when they hold (re, im) pairs. */
 int  jx_debug_workspace(jx_ctx* ctx, int which, void** dev, int32_t geom[4]);

@@ -54,7 +54,7 @@ struct jx_ctx {
     double* d_par_vals = nullptr;
 
     // work buffers (chunk capacity)
-    double *d_pvec = nullptr, *d_base = nullptr, *d_cfac = nullptr;
+    double *d_base = nullptr, *d_cfac = nullptr;
     double *d_img = nullptr, *d_conv = nullptr;
     double2 *d_spec = nullptr, *d_tfspec = nullptr;
     // hand-written convolution (conv_mode 2)
@@ -499,9 +499,9 @@ int jx_finalize(jx_ctx* ctx) {
             }
             if ((rc = dev_put(ctx, zab.data(), zab.size(), &p))) return rc; cv.zab = (const cplx*)p;
             const int nt = o + 1;
-            std::vector<double> bc((size_t)nt * nt);
+            std::vector<double> bc((size_t)nt * JX_COL0_LD, 0.0);
             for (int t = 0; t < nt; ++t)
-                for (int x = 0; x < nt; ++x) bc[(size_t)t * nt + x] = c.step * c.step * beam_h[(size_t)(o + t) * B + o + x];
+                for (int x = 0; x < nt; ++x) bc[(size_t)t * JX_COL0_LD + x] = c.step * c.step * beam_h[(size_t)(o + t) * B + o + x];
             if ((rc = dev_put(ctx, bc.data(), bc.size(), &p))) return rc; cv.bcol = p;
         }
     }
@@ -591,7 +591,6 @@ int jx_finalize(jx_ctx* ctx) {
 #undef JX_ATTR
     }
 
-    if ((rc = dev_new(ctx, (size_t)chunk * JX_MAX_PAR, &ctx->d_pvec))) return rc;
     if ((rc = dev_new(ctx, (size_t)chunk, &ctx->d_base))) return rc;
     if ((rc = dev_new(ctx, (size_t)chunk * ctx->nrow, &ctx->d_cfac))) return rc;
     if (ctx->conv_mode == 1) {
@@ -602,6 +601,7 @@ int jx_finalize(jx_ctx* ctx) {
     } else {
         const JxConv& cv = ctx->cv;
         if ((rc = dev_new(ctx, (size_t)chunk * d.img_ws, &ctx->d_img, true))) return rc;
+        if (d.quad && (rc = dev_new(ctx, (size_t)chunk * d.q_nb, &d.xcol))) return rc;
         const size_t spec_div = cv.xsym ? 2 : 1;                           // real arrays need half the complex count
         if ((rc = dev_new(ctx, ((size_t)chunk * cv.NU * cv.Ph + 1) / spec_div, &ctx->d_Y))) return rc;
         if ((rc = dev_new(ctx, ((size_t)chunk * cv.CROWS * cv.Ph + 1) / spec_div, &ctx->d_C))) return rc;
@@ -674,7 +674,7 @@ static int launch_custom_conv(jx_ctx* ctx, int n, double* tap_convjobs, EvSet* e
 #undef JX_P1
     if (!done) { ctx->err = "no pass-1 kernel for this size"; return JX_ERR_UNSUPPORTED; }
     if (cv.xsym)
-        hipLaunchKernelGGL(jx_col0_kernel, dim3(n), dim3(256), 0, st, cv, ctx->d_img, (size_t)d.img_ld, (size_t)d.img_ws, cv.col0);
+        hipLaunchKernelGGL(jx_col0_kernel, dim3(n, (cv.o + JX_COL0_XG) / JX_COL0_XG), dim3(256), 0, st, cv, ctx->d_img, (size_t)d.img_ld, (size_t)d.img_ws, d.xcol, cv.col0);
     if (ctx->fir_reg) {
         const int nslab = (cv.fir_ld + 63) / 64, units = nslab * n;
         const dim3 g2((unsigned)(((units + 7) / 8) * 8 * ctx->nrun));
@@ -714,7 +714,7 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
     }
     {
         const size_t sh = sizeof(double) * (JX_LDS_HDR + (size_t)d.N + 2 * d.nann + (size_t)d.nband * d.nann + 8);
-        hipLaunchKernelGGL(jx_prep_kernel, dim3(n), dim3(JX_PREP_THREADS), sh, st, d, theta_dev, w0, ctx->d_pvec,
+        hipLaunchKernelGGL(jx_prep_kernel, dim3(n), dim3(JX_PREP_THREADS), sh, st, d, theta_dev, w0,
                            ctx->d_base, ctx->d_cfac, t.tprof, t.xprofs, t.parts);
     }
     if (tm) HIPCHK(ctx, hipEventRecord(es.e[1], st));
@@ -723,15 +723,15 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
         const dim3 grid(n * d.map_split), block(ctx->map_threads);
         if (d.fast_map) {
             const size_t sh = ctx->map_lds_bytes;
-#define JX_SYM_LAUNCH(V, NA) hipLaunchKernelGGL((jx_abel_map_sym_kernel<V, NA>), grid, block, sh, st, d, ctx->d_pvec, ctx->d_img, t.pp, t.ab, t.y)
+#define JX_SYM_LAUNCH(V, NA) hipLaunchKernelGGL((jx_abel_map_sym_kernel<V, NA>), grid, block, sh, st, d, theta_dev, w0, ctx->d_img, t.pp, t.ab, t.y)
             const int nait = (d.q_na + 63) / 64;
             if (vec2) { if (nait <= 3) JX_SYM_LAUNCH(true, 3); else if (nait <= 5) JX_SYM_LAUNCH(true, 5); else JX_SYM_LAUNCH(true, 9); }
             else      { if (nait <= 3) JX_SYM_LAUNCH(false, 3); else if (nait <= 5) JX_SYM_LAUNCH(false, 5); else JX_SYM_LAUNCH(false, 9); }
 #undef JX_SYM_LAUNCH
         } else {
             const size_t sh = ctx->map_lds_bytes;
-            if (vec2) hipLaunchKernelGGL(jx_abel_map_kernel<true>, grid, block, sh, st, d, ctx->d_pvec, ctx->d_img, t.pp, t.ab, t.y);
-            else hipLaunchKernelGGL(jx_abel_map_kernel<false>, grid, block, sh, st, d, ctx->d_pvec, ctx->d_img, t.pp, t.ab, t.y);
+            if (vec2) hipLaunchKernelGGL(jx_abel_map_kernel<true>, grid, block, sh, st, d, theta_dev, w0, ctx->d_img, t.pp, t.ab, t.y);
+            else hipLaunchKernelGGL(jx_abel_map_kernel<false>, grid, block, sh, st, d, theta_dev, w0, ctx->d_img, t.pp, t.ab, t.y);
         }
     }
     if (tm) HIPCHK(ctx, hipEventRecord(es.e[2], st));
@@ -968,6 +968,15 @@ int jx_get_conv_mode(jx_ctx* ctx) {
     return ctx->conv_mode;
 }
 
+int jx_get_conv_layout(jx_ctx* ctx, int32_t out[8]) {
+    if (!ctx || !ctx->finalized || !out) return JX_ERR_STATE;
+    if (ctx->conv_mode != 2) { ctx->err = "layout of the hand-written convolution only"; return JX_ERR_UNSUPPORTED; }
+    const JxConv& cv = ctx->cv;
+    out[0] = cv.xsym; out[1] = ctx->d.quad; out[2] = cv.NU; out[3] = cv.NJ; out[4] = cv.fir_ld;
+    out[5] = ctx->d.quad ? ctx->d.q_nb : cv.S; out[6] = (int32_t)ctx->d.img_ld; out[7] = cv.P;
+    return JX_OK;
+}
+
 int jx_debug_workspace(jx_ctx* ctx, int which, void** dev, int32_t geom[4]) {
     if (!ctx || !ctx->finalized || !dev || !geom) return JX_ERR_STATE;
     if (ctx->conv_mode != 2) { ctx->err = "work buffers of the hand-written convolution only"; return JX_ERR_UNSUPPORTED; }
@@ -978,7 +987,7 @@ int jx_debug_workspace(jx_ctx* ctx, int which, void** dev, int32_t geom[4]) {
         case 1: *dev = ctx->d_Y; geom[1] = cv.NU; geom[2] = cv.fir_ld; break;
         case 2: *dev = ctx->d_C; geom[1] = cv.CROWS; geom[2] = cv.fir_ld; break;
         case 3: if (!cv.xsym) { ctx->err = "no column-0 terms in this mode"; return JX_ERR_UNSUPPORTED; }
-                *dev = cv.col0; geom[1] = cv.NJ; geom[2] = cv.o + 1; break;
+                *dev = cv.col0; geom[1] = cv.o + 1; geom[2] = cv.NJ; break;
         case 4: *dev = const_cast<int*>(cv.jrow); geom[0] = 1; geom[1] = cv.NJ; geom[2] = 1; break;
         case 5: *dev = const_cast<int*>(cv.umap); geom[0] = 1; geom[1] = cv.S; geom[2] = 1; break;
         default: ctx->err = "unknown work buffer"; return JX_ERR_INVALID;

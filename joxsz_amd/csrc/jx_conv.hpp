@@ -57,8 +57,8 @@ struct JxConv {
     int fir_ld;                     // doubles per row of Y / C: Ph (xsym) or 2 Ph
     int quad;                       // 1: the map arrives as its quadrant [S/2+1][img_ld] of distinct pixels (|iy-c|, |ix-c|)
     const cplx* zab;                // [LP][2] pass-3 pre-process factors: Z[k] = zab[k][0] Rc[k] + zab[k][1] Rc[LP-k]   (xsym)
-    const double* bcol;             // [o+1][o+1] step^2 beam[o+t][o+x]: what column 0 of a map row adds to output column x  (xsym)
-    double* col0;                   // [walkers][NJ][o+1] what column 0 of the map adds to output columns 0..o of each job (xsym)
+    const double* bcol;             // [o+1][JX_COL0_LD] step^2 beam[o+t][o+x], zero beyond x = o: what column 0 of a map row adds to output column x  (xsym)
+    double* col0;                   // [walkers][o+1][NJ] what column 0 of the map adds to output columns 0..o of each job (xsym)
     int nblk3;                      // pass-3 blocks per walker (partials to sum in the tail)
     const cplx* tw_lp;              // [LP]   exp(-2 pi i n / LP)
     const cplx* tw_ls;              // [LS]   exp(-2 pi i n / LS)
@@ -77,6 +77,8 @@ struct JxConv {
 #define JX_FIR_KX 32                // kx per slab
 // beam half-widths o = (B-1)/2 with a register-window FIR instance (and an x-symmetric pass-3 pre-process)
 #define JX_XSYM_MAXT 28              // taps (o + 1) of the widest such beam
+#define JX_COL0_XG 7                // output columns per block of the column-0 kernel
+#define JX_COL0_LD 28               // row stride of its beam table (a multiple of JX_COL0_XG, >= JX_XSYM_MAXT)
 #define JX_FIR_REG_O(X) X(4) X(5) X(13) X(27)          // all >= 4: the FIR's 8 accumulator chains need 2O+1 >= 8
 #define JX_FIR_RING 128             // LDS ring of input rows (>= JX_FIR_TILE + 2 o)
 
@@ -129,7 +131,8 @@ __device__ __forceinline__ void jx_stepB_load(jx_c* y, int k1, const cplx* Mrow)
 // pass 1 (two-level): grid = (ceil(S / ROWS), walkers), 256 threads, ROWS = 256 / max(L1, L2)
 // ------------------------------------------------------------------------------------
 template <int LP, int ROWS>
-__global__ void __launch_bounds__(256)
+// (LDS admits two blocks per CU = two waves per SIMD: registers are not the occupancy limit)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
 jx_rowfft2_kernel(JxConv c, const double* __restrict__ img, size_t img_ld, size_t img_ws, cplx* __restrict__ Y) {
     typedef jx_lay<LP> Lay;
     constexpr int L1 = Lay::L1, L2 = Lay::L2, RS = Lay::RS;
@@ -142,8 +145,14 @@ jx_rowfft2_kernel(JxConv c, const double* __restrict__ img, size_t img_ld, size_
     const int tid = threadIdx.x, nth = blockDim.x;
     const int r0 = blockIdx.x * ROWS, w = blockIdx.y;               // r0: first distinct row u of the block
     const int nrows = min(ROWS, c.NU - r0), half = c.S / 2;
-    for (int n = tid; n < LP; n += nth) tw[n] = c.tw_lp[n];
-    for (int n = tid; n <= LP; n += nth) twp[n] = c.tw_p[n];
+    // twiddle tables: requested now, stored behind the row loads below (one round trip for everything)
+    constexpr int NTW = (LP + 1 + 255) / 256;
+    double tw_r[NTW][4];                                             // (scalars: an aggregate copy out of a register array ends up in scratch)
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        const cplx a = c.tw_lp[min(tid + i * 256, LP - 1)], b = c.tw_p[min(tid + i * 256, LP)];
+        tw_r[i][0] = a.x; tw_r[i][1] = a.y; tw_r[i][2] = b.x; tw_r[i][3] = b.y;
+    }
 
     const int rowA = tid / L2, n2 = tid - rowA * L2;
     const bool actA = tid < ROWS * L2 && rowA < nrows;
@@ -165,19 +174,20 @@ jx_rowfft2_kernel(JxConv c, const double* __restrict__ img, size_t img_ld, size_
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
             const int e = tid + i * nth, row = e / npair, j = e - row * npair;
-            if (e < tot) *reinterpret_cast<double2*>(reinterpret_cast<double*>(M + row * RS) + 2 * j) = stg[i];
+            // odd rows sit one double further: the 8-byte gathers of neighbouring rows then fall on different banks
+            if (e < tot) {
+                double* dst = reinterpret_cast<double*>(M + row * RS) + (row & 1) + 2 * j;
+                dst[0] = stg[i].x; dst[1] = stg[i].y;
+            }
         }
         __syncthreads();
         if (actA) {
-            const double* q = reinterpret_cast<const double*>(M + rowA * RS);
+            const double* q = reinterpret_cast<const double*>(M + rowA * RS) + (rowA & 1);
 #pragma unroll
             for (int n1 = 0; n1 < L1; ++n1) {
                 const int n = n1 * L2 + n2;
                 x[n1] = jxc(0.0, 0.0);
-                if (n < half) {
-                    if (2 * n < half) x[n1] = jxc(q[half - 2 * n], q[half - 2 * n - 1]);
-                    else { const double2 v = *reinterpret_cast<const double2*>(q + 2 * n - half); x[n1] = jxc(v.x, v.y); }
-                }
+                if (n < half) x[n1] = (2 * n < half) ? jxc(q[half - 2 * n], q[half - 2 * n - 1]) : jxc(q[2 * n - half], q[2 * n - half + 1]);
             }
         }
     } else if (actA) {
@@ -193,6 +203,12 @@ jx_rowfft2_kernel(JxConv c, const double* __restrict__ img, size_t img_ld, size_
     }
     if (actA) {
         if (n2 == 0) s_x0[rowA] = (c.S & 1) ? 0.0 : x[0].x;           // column 0 has no mirror partner on an even side
+    }
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        const int n = tid + i * 256;
+        if (n < LP) tw[n] = make_double2(tw_r[i][0], tw_r[i][1]);
+        if (n <= LP) twp[n] = make_double2(tw_r[i][2], tw_r[i][3]);
     }
     __syncthreads();
     if (actA) jx_stepA_store<LP, false>(x, n2, M + rowA * RS, tw);
@@ -229,30 +245,43 @@ jx_rowfft2_kernel(JxConv c, const double* __restrict__ img, size_t img_ld, size_
 // pass 3 (two-level): grid = (ceil(S / ROWS), walkers), 256 threads
 // ------------------------------------------------------------------------------------
 // x-symmetric mode: the unpaired column 0 of the map, convolved with the beam, reaches output columns 0..o only:
-//     col0[w][q][x] = sum_t bcol[t][x] (x0[r_q - t] + x0[r_q + t]),   x0[m] = map[m][0],  r_q = conv row of job q.
-// One block per walker; pass 3 adds the result to the cropped rows in real space.
+//     col0[w][x][q] = sum_t bcol[t][x] (x0[r_q - t] + x0[r_q + t]),   x0[m] = map[m][0],  r_q = conv row of job q.
+// grid (walkers, ceil((o+1)/7)); pass 3 adds the result to the cropped rows in real space.
 __global__ void __launch_bounds__(256)
-jx_col0_kernel(JxConv c, const double* __restrict__ img, size_t img_ld, size_t img_ws, double* __restrict__ col0) {
+jx_col0_kernel(JxConv c, const double* __restrict__ img, size_t img_ld, size_t img_ws, const double* __restrict__ xcol,
+               double* __restrict__ col0) {
+    constexpr int XG = JX_COL0_XG;                                   // output columns per block
     __shared__ double s_x0[1024 + 2 * JX_XSYM_MAXT];                 // zero margin of o rows on both sides
-    __shared__ double s_b[JX_XSYM_MAXT * JX_XSYM_MAXT];
-    const int tid = threadIdx.x, nth = blockDim.x, w = blockIdx.x, S = c.S, o = c.o, nt = o + 1;
+    const int tid = threadIdx.x, nth = blockDim.x, w = blockIdx.x, S = c.S, o = c.o, nt = o + 1, NJ = c.NJ;
     for (int m = tid; m < S + 2 * o; m += nth) {
         const int r = m - o;
-        s_x0[m] = (r >= 0 && r < S) ? (c.quad ? img[(size_t)w * img_ws + (size_t)abs(r - (S >> 1)) * img_ld + (S >> 1)]
+        s_x0[m] = (r >= 0 && r < S) ? (c.quad ? xcol[(size_t)w * ((S >> 1) + 1) + abs(r - (S >> 1))]      // the map kernel's compact copy
                                                : img[(size_t)w * img_ws + (size_t)r * img_ld]) : 0.0;
     }
-    for (int e = tid; e < nt * nt; e += nth) s_b[e] = c.bcol[e];
     __syncthreads();
-    for (int e = tid; e < c.NJ * nt; e += nth) {
-        const int q = e / nt, x = e - q * nt, r = c.jrow[q] + o;
-        double a = s_b[x] * s_x0[r];
-        for (int t = 1; t < nt; ++t) a = fma(s_b[t * nt + x], s_x0[r - t] + s_x0[r + t], a);
-        col0[(size_t)w * c.NJ * nt + e] = a;
+    // consecutive lanes take consecutive jobs; the beam values are block-uniform (scalar loads, no LDS traffic)
+    const double* bq = c.bcol + blockIdx.y * XG;                      // [o+1][JX_COL0_LD], zero beyond column o
+    const int xb = blockIdx.y * XG;
+    for (int q = tid; q < NJ; q += nth) {
+        const int r = c.jrow[q] + o;
+        double a[XG];
+        const double s0 = s_x0[r];
+#pragma unroll
+        for (int j = 0; j < XG; ++j) a[j] = bq[j] * s0;
+#pragma unroll 4
+        for (int t = 1; t < nt; ++t) {
+            const double sv = s_x0[r - t] + s_x0[r + t];
+#pragma unroll
+            for (int j = 0; j < XG; ++j) a[j] = fma(bq[t * JX_COL0_LD + j], sv, a[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < XG; ++j)
+            if (xb + j < nt) col0[((size_t)w * nt + xb + j) * NJ + q] = a[j];             // [x][q]: coalesced over the jobs
     }
 }
 
 template <int LP, int LS, int ROWS>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
 jx_rowtf2_kernel(JxConv c, const cplx* __restrict__ C, cplx* __restrict__ part, double* __restrict__ tap_conv) {
     typedef jx_lay<LP> LayP;
     typedef jx_lay<LS> LayS;
@@ -268,8 +297,13 @@ jx_rowtf2_kernel(JxConv c, const cplx* __restrict__ C, cplx* __restrict__ part, 
     const int r0 = blockIdx.x * ROWS, w = blockIdx.y;
     const int S = c.S, Ph = c.Ph, Sh = c.Sh, NJ = c.NJ;             // r0: first job q of the block
     const int nrows = min(ROWS, NJ - r0);
-    for (int n = tid; n < LP; n += nth) twp[n] = c.tw_lp[n];
-    for (int n = tid; n < LS; n += nth) tws[n] = c.tw_ls[n];
+    constexpr int NTW = ((LP > LS ? LP : LS) + 255) / 256;           // twiddle tables: requested now, stored behind the row loads
+    double tw_r[NTW][4];                                             // (scalars: an aggregate copy out of a register array ends up in scratch)
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        const cplx a = c.tw_lp[min(tid + i * 256, LP - 1)], b = c.tw_ls[min(tid + i * 256, LS - 1)];
+        tw_r[i][0] = a.x; tw_r[i][1] = a.y; tw_r[i][2] = b.x; tw_r[i][3] = b.y;
+    }
     // Z[k] = (X[k] + conj X[LP-k]) + i e^{+2 pi i k/P} (X[k] - conj X[LP-k]) into the padded layout of n = k.
     // Four elements per thread and trip: their eight row reads are requested before anything is used.
     const cplx* Cblk = C + ((size_t)w * c.CROWS + r0) * Ph;
@@ -282,7 +316,10 @@ jx_rowtf2_kernel(JxConv c, const cplx* __restrict__ C, cplx* __restrict__ part, 
         const int nt = c.o + 1, ns = nrows * nt;
         double cz[NSL];                                              // this block's slice of col0, requested first
 #pragma unroll
-        for (int u = 0; u < NSL; ++u) cz[u] = c.col0[((size_t)w * NJ + r0) * nt + min(tid + u * nth, ns - 1)];
+        for (int u = 0; u < NSL; ++u) {
+            const int e = min(tid + u * nth, ns - 1), row = e / nt, xo = e - row * nt;
+            cz[u] = c.col0[((size_t)w * nt + xo) * NJ + r0 + row];
+        }
         // one thread per pair (k, LP-k): the same two reals of every row make Z[k] and Z[LP-k]; all rows requested at once
         for (int k = tid; 2 * k <= LP; k += nth) {
             const int kp = LP - k, kq = kp == LP ? 0 : kp;
@@ -329,6 +366,12 @@ jx_rowtf2_kernel(JxConv c, const cplx* __restrict__ C, cplx* __restrict__ part, 
                 M[row * RS + n1 * P2P + n2] = make_double2(s.x - d.y, s.y + d.x);
             }
         }
+    }
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        const int n = tid + i * 256;
+        if (n < LP) twp[n] = make_double2(tw_r[i][0], tw_r[i][1]);
+        if (n < LS) tws[n] = make_double2(tw_r[i][2], tw_r[i][3]);
     }
     __syncthreads();
     {   // inverse transform of length LP

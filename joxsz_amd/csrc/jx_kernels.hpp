@@ -51,6 +51,7 @@ struct JxDev {
     long long img_ld, img_ws;    // row and walker strides (doubles) of the y-map image
     int dbg;                     // timing-only ablations (JOXSZ_DBG): 1 skip phases 1-4, 2 skip phase 5, 4 phase 5 stores only
     int fast_map, q_na, q_nb;    // symmetric-map form: table sizes (|ix-c|, |iy-c|)
+    double* xcol;                // [chunk][q_nb] quad mode: copy of the quadrant's last column (map column 0), contiguous
     int quad;                    // 1: the image is the quadrant [q_nb][img_ld] (|iy-c|, |ix-c|) alone, nothing mirrored
     const int* q_k;              // [q_nb*q_na] coefficient slot of each quadrant radius
     const double* q_t;           // [q_nb*q_na] local abscissa within that slot
@@ -150,15 +151,24 @@ __device__ __forceinline__ int jx_block_or(int v, int* redi) {
     return *redi;
 }
 
+// full parameter vector of batch walker gw into p[0..JX_MAX_PAR) (LDS): the current values with the thawed ones
+// replaced by theta (updateThawed, joxsz_funcs.py:516).  Ends with a barrier.
+__device__ __forceinline__ void jx_load_params(const JxDev& c, const double* __restrict__ theta, int gw, double* p) {
+    const int tid = threadIdx.x;
+    if (tid < JX_MAX_PAR) p[tid] = (tid < c.npar) ? c.par_vals[tid] : 0.0;
+    __syncthreads();
+    if (tid < c.ndim) p[c.thawed_idx[tid]] = theta[(size_t)gw * c.ndim + tid];
+    __syncthreads();
+}
+
 // ------------------------------------------------------------------------------------
 // K0: per-walker scalar work.  One 256-thread block per walker.
-//   pvec  [W, JX_MAX_PAR]  full parameter vector (updateThawed, joxsz_funcs.py:516)
 //   base  [W]  parprior + model prior + X-ray log-likelihood, or -inf when rejected
 //   cfac  [W, nrow]  convert([h(0), t_prof]) * calibration   (joxsz_funcs.py:473)
 //   optional taps: tprof [W,nrow], xprofs [W,nband,nann], parts [W,4]
 // ------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(JX_PREP_THREADS)
-jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0, double* __restrict__ pvec,
+jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
                double* __restrict__ base, double* __restrict__ cfac, double* __restrict__ tap_tprof,
                double* __restrict__ tap_xprofs, double* __restrict__ tap_parts) {
     JX_LDS_DECL;
@@ -174,11 +184,7 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0, double* __rest
     double* s_T = s_ne + c.nann;              // [nann]
     double* s_rate = s_T + c.nann;            // [nband*nann]
 
-    if (tid < JX_MAX_PAR) p[tid] = (tid < c.npar) ? c.par_vals[tid] : 0.0;
-    __syncthreads();
-    if (tid < c.ndim) p[c.thawed_idx[tid]] = theta[(size_t)gw * c.ndim + tid];
-    __syncthreads();
-    if (tid < JX_MAX_PAR) pvec[(size_t)w * JX_MAX_PAR + tid] = p[tid];
+    jx_load_params(c, theta, gw, p);
 
     // ---- priors on every parameter (joxsz_funcs.py:518) ----
     double pr = 0.0;
@@ -444,7 +450,7 @@ __device__ __forceinline__ void jx_profile_to_coefs(const JxDev& c, const double
 
 template <bool VEC2>
 __global__ void __launch_bounds__(1024)
-jx_abel_map_kernel(JxDev c, const double* __restrict__ pvec, double* __restrict__ img /*[chunk][P][P]*/,
+jx_abel_map_kernel(JxDev c, const double* __restrict__ theta, int w0, double* __restrict__ img /*[chunk][P][P]*/,
                    double* __restrict__ tap_pp, double* __restrict__ tap_ab, double* __restrict__ tap_y) {
     JX_LDS_DECL;
     const int N = c.N;
@@ -462,8 +468,7 @@ jx_abel_map_kernel(JxDev c, const double* __restrict__ pvec, double* __restrict_
     const int w = blockIdx.x / c.map_split;
     const int part = blockIdx.x - w * c.map_split;
 
-    if (tid < JX_MAX_PAR) p[tid] = pvec[(size_t)w * JX_MAX_PAR + tid];
-    __syncthreads();
+    jx_load_params(c, theta, w0 + w, p);
     jx_profile_to_coefs(c, p, w, part == 0, s_r, s_pp, s_y, s_M, s_cf, s_rq, s_ds, tap_pp, tap_ab, tap_y);
 
     // Phase 5 (generic): the block's slab of rows
@@ -521,7 +526,7 @@ jx_abel_map_kernel(JxDev c, const double* __restrict__ pvec, double* __restrict_
 // NAIT = ceil(q_na / 64) register slots per lane.
 template <bool VEC2, int NAIT>
 __global__ void __launch_bounds__(1024)
-jx_abel_map_sym_kernel(JxDev c, const double* __restrict__ pvec, double* __restrict__ img,
+jx_abel_map_sym_kernel(JxDev c, const double* __restrict__ theta, int w0, double* __restrict__ img,
                        double* __restrict__ tap_pp, double* __restrict__ tap_ab, double* __restrict__ tap_y) {
     JX_LDS_DECL;
     const int N = c.N;
@@ -540,8 +545,7 @@ jx_abel_map_sym_kernel(JxDev c, const double* __restrict__ pvec, double* __restr
     const int w = blockIdx.x / c.map_split;
     const int part = blockIdx.x - w * c.map_split;
 
-    if (tid < JX_MAX_PAR) p[tid] = pvec[(size_t)w * JX_MAX_PAR + tid];
-    __syncthreads();
+    jx_load_params(c, theta, w0 + w, p);
     if (!(c.dbg & 1)) jx_profile_to_coefs(c, p, w, part == 0, s_r, s_pp, s_y, s_M, s_cf, s_rq, s_ds, tap_pp, tap_ab, tap_y);
     else { for (int k = tid; k < 4 * (N + 1); k += nth) s_cf[k] = 0.0; __syncthreads(); }
     if (c.dbg & 2) return;
@@ -616,6 +620,7 @@ jx_abel_map_sym_kernel(JxDev c, const double* __restrict__ pvec, double* __restr
             for (int u = 0; u < NAIT; ++u) {
                 const int a = lane + 64 * u;
                 if (a < na) orow[a] = v[u];
+                if (a == na - 1) c.xcol[(size_t)w * nb + b] = v[u];
             }
         }
         return;

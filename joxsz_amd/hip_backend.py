@@ -16,7 +16,7 @@ ABI_VERSION = 1
 EXPORTS = (
     'jx_create', 'jx_upload', 'jx_finalize', 'jx_eval', 'jx_eval_device', 'jx_sync', 'jx_eval_stage',
     'jx_set_par_vals', 'jx_dev_alloc', 'jx_dev_free', 'jx_memcpy_h2d', 'jx_memcpy_d2h',
-    'jx_timing_reset', 'jx_timing_enable', 'jx_timing_get', 'jx_get_info', 'jx_get_conv_mode', 'jx_debug_workspace', 'jx_device_count',
+    'jx_timing_reset', 'jx_timing_enable', 'jx_timing_get', 'jx_get_info', 'jx_get_conv_mode', 'jx_get_conv_layout', 'jx_debug_workspace', 'jx_device_count',
     'jx_device_name', 'jx_strerror', 'jx_last_error', 'jx_destroy',
 )
 
@@ -81,6 +81,7 @@ def load_library(path=None):
     i32p, i64p = ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int64)
     lib.jx_get_info.argtypes = [vp, i32p, i32p, i32p, i32p, i64p]
     lib.jx_get_conv_mode.argtypes = [vp]
+    lib.jx_get_conv_layout.argtypes = [vp, ctypes.POINTER(ctypes.c_int32)]
     lib.jx_debug_workspace.argtypes = [vp, ci, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int32)]
     lib.jx_device_count.argtypes = []
     lib.jx_device_name.argtypes = [vp]
@@ -154,6 +155,11 @@ class HipContext:
         self.fft_pad, self.chunk, self.spline_band, self.nrow, self.device_bytes = f.value, c.value, b.value, n.value, nb.value
         self.device_name = self.lib.jx_device_name(self._h).decode()
         self.conv = {1: 'rocfft', 2: 'custom'}.get(self.lib.jx_get_conv_mode(self._h), '?')
+        self.conv_layout = None
+        if self.conv == 'custom':
+            lay = (ctypes.c_int32 * 8)()
+            self._chk(self.lib.jx_get_conv_layout(self._h, lay), 'jx_get_conv_layout')
+            self.conv_layout = dict(zip(('xsym', 'quad', 'NU', 'NJ', 'ld', 'img_rows', 'img_ld', 'P'), [int(v) for v in lay]))
 
     # -- plumbing --
     def _chk(self, rc, what):

@@ -275,7 +275,7 @@ def test_conv_work_buffers_against_numpy(S, N):
             for d in range(-o, o + 1):
                 if 0 <= r - d < S:
                     want0[q] += pb.step ** 2 * beam[o + d, o:] * y[w][r - d, 0]
-        assert np.abs(col0[w] - want0).max() < 1e-13 * np.abs(want0).max()
+        assert np.abs(col0[w].T - want0).max() < 1e-13 * np.abs(want0).max()       # stored [x][job]
 
 
 def test_largest_config_shape():
