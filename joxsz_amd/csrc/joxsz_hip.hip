@@ -763,7 +763,16 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
         zpart = ctx->d_part;
         nblk = cv.nblk3;
     }
-    {
+    bool tail_done = false;
+    if (ctx->conv_mode == 2 && d.nrow == ctx->cv.LS && !getenv("JOXSZ_TAIL_DFT")) {
+        const JxConv& cv = ctx->cv;
+#define JX_TAILF(LPv, LSv, R1v, R3v) if (!tail_done && cv.LP == LPv && cv.LS == LSv) { \
+            hipLaunchKernelGGL((jx_tail_fft_kernel<LSv>), dim3(n), dim3(256), 0, st, d, cv, zpart, ctx->d_cfac, ctx->d_base, logp_dev, w0, \
+                               t.row, t.bright, t.chisq, t.parts); tail_done = true; }
+        JX_CONV2_PAIRS(JX_TAILF)
+#undef JX_TAILF
+    }
+    if (!tail_done) {
         const size_t sh = sizeof(double) * (JX_LDS_HDR + (size_t)2 * d.Sh + d.nrow + 8);
         hipLaunchKernelGGL(jx_tail_kernel, dim3(n), dim3(JX_TAIL_THREADS), sh, st, d, ctx->d_tfspec, zpart, nblk, ctx->d_cfac,
                            ctx->d_base, logp_dev, w0, t.row, t.bright, t.chisq, t.parts);

@@ -728,6 +728,119 @@ jx_beamfir_reg_kernel(JxConv c, const int* __restrict__ runs, int nrun, int nwal
         jx_fir_run_phases<O, 0>(win, fifo, tap, mirror, Yw, Cw, ld, S, c.NJ, r0 + t0, q0 + t0, cnt - t0);
 }
 
+// ------------------------------------------------------------------------------------
+// tail of the hand-written path.  One 256-thread block per walker:
+//   Z[kc]  = sum over pass-3 blocks of the partial sums (fixed order)
+//   row[k] = sum_kc Re(Z[kc] e^{2 pi i kc (S/2 + k)/S}),  k = 0..S/2-1   (joxsz_funcs.py:467,472)
+//            as ONE inverse real transform of length S = 2 LS (half-length complex FFT in registers + LDS)
+//   bright = row * cfac;  chi^2 against the flux points;  log-posterior  (joxsz_funcs.py:473-493, 544)
+// The one-sided sum above is x[m] = V0 + 2 sum Re(V[k] e^{..}) + V[LS] (-1)^m with V0 = Re Z0, V[k] = Z[k]/2,
+// V[LS] = Re Z[LS];  z[n] = x[2n] + i x[2n+1] is the inverse FFT of
+//   Zc[k] = (V[k] + conj V[LS-k]) + i e^{+2 pi i k/S} (V[k] - conj V[LS-k]),  k = 0..LS-1.
+// ------------------------------------------------------------------------------------
+template <int LS>
+__global__ void __launch_bounds__(256)
+jx_tail_fft_kernel(JxDev c, JxConv cv, const cplx* __restrict__ zpart, const double* __restrict__ cfac,
+                   const double* __restrict__ base, double* __restrict__ logp, int w0,
+                   double* __restrict__ tap_row, double* __restrict__ tap_bright, double* __restrict__ tap_chisq,
+                   double* __restrict__ tap_parts) {
+    typedef jx_lay<LS> Lay;
+    constexpr int L1 = Lay::L1, L2 = Lay::L2, RS = Lay::RS;
+    constexpr int NK = (LS + 1 + 255) / 256;                         // spectrum entries per thread
+    __shared__ cplx s_M[RS];                                          // (16-byte aligned: every LDS access below is b128 or b64)
+    __shared__ cplx s_tw[LS];                                         // e^{-2 pi i n / LS}
+    __shared__ cplx s_v[LS + 1];                                      // Z
+    __shared__ double s_prof[LS];
+    __shared__ double s_red[8];
+    const int tid = threadIdx.x, w = blockIdx.x, nblk = cv.nblk3, Sh = LS + 1, nrow = LS;
+
+    // everything this thread will want from global memory before the first barrier is requested up front
+    double twr[NK][2];
+#pragma unroll
+    for (int j = 0; j < NK; ++j) { const cplx t = cv.tw_ls[min(tid + j * 256, LS - 1)]; twr[j][0] = t.x; twr[j][1] = t.y; }
+    double wk[L1][2];                                                 // e^{-2 pi i k/S}, k = n1 L2 + tid (step-A threads)
+#pragma unroll
+    for (int n1 = 0; n1 < L1; ++n1) { const cplx t = cv.tw_s[min(n1 * L2 + tid, LS)]; wk[n1][0] = t.x; wk[n1][1] = t.y; }
+    const cplx* Zp = zpart + (size_t)w * nblk * Sh;
+    double zr[NK], zi[NK];
+#pragma unroll
+    for (int j = 0; j < NK; ++j) { zr[j] = 0.0; zi[j] = 0.0; }
+    for (int b0 = 0; b0 < nblk; b0 += 8) {
+        cplx v[NK][8];
+#pragma unroll
+        for (int j = 0; j < NK; ++j)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[j][u] = Zp[(size_t)min(b0 + u, nblk - 1) * Sh + min(tid + j * 256, Sh - 1)];
+#pragma unroll
+        for (int j = 0; j < NK; ++j)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (b0 + u < nblk) { zr[j] += v[j][u].x; zi[j] += v[j][u].y; }
+    }
+#pragma unroll
+    for (int j = 0; j < NK; ++j) {
+        const int k = tid + j * 256;
+        if (k < Sh) s_v[k] = make_double2(zr[j], zi[j]);
+        if (k < LS) s_tw[k] = make_double2(twr[j][0], twr[j][1]);
+    }
+    __syncthreads();
+    if (tid < L2) {
+        jx_c x[L1];
+#pragma unroll
+        for (int n1 = 0; n1 < L1; ++n1) {
+            const int k = n1 * L2 + tid;
+            const cplx a = s_v[k], b = s_v[LS - k];
+            // V[k], conj V[LS-k] with the end points real
+            const double vx = (k == 0) ? a.x : 0.5 * a.x, vy = (k == 0) ? 0.0 : 0.5 * a.y;
+            const double px = (k == 0) ? b.x : 0.5 * b.x, py = (k == 0) ? 0.0 : -0.5 * b.y;
+            const double sx = vx + px, sy = vy + py, dx = vx - px, dy = vy - py;
+            // i e^{+2 pi i k/S} (dx + i dy),  e^{+..} = conj(wk)
+            const double cr = wk[n1][0], ci = -wk[n1][1];
+            const double ex = dx * cr - dy * ci, ey = dx * ci + dy * cr;
+            x[n1] = jxc(sx - ey, sy + ex);
+        }
+        jx_stepA_store<LS, true>(x, tid, s_M, s_tw);
+    }
+    __syncthreads();
+    if (tid < L1) {
+        jx_c y[L2];
+        jx_stepB_load<LS, true>(y, tid, s_M);
+#pragma unroll
+        for (int k2 = 0; k2 < L2; ++k2) {
+            const int n = tid + L1 * k2, k = 2 * n - LS;             // z[n] = (x[2n], x[2n+1]); row index k = column - S/2
+            if (k >= 0) {
+                const double2 cf = *reinterpret_cast<const double2*>(cfac + (size_t)w * nrow + k);
+                if (tap_row) *reinterpret_cast<double2*>(tap_row + (size_t)w * nrow + k) = make_double2(y[k2].x, y[k2].y);
+                const double b0v = y[k2].x * cf.x, b1v = y[k2].y * cf.y;
+                s_prof[k] = b0v; s_prof[k + 1] = b1v;
+                if (tap_bright) *reinterpret_cast<double2*>(tap_bright + (size_t)w * nrow + k) = make_double2(b0v, b1v);
+            }
+        }
+    }
+    __syncthreads();
+    // chi^2: eight lanes per flux point, each over every eighth radius
+    double part = 0.0;
+    for (int d = tid >> 3; d < c.nflux; d += 32) {
+        const double* e = c.emat + (size_t)d * nrow;
+        double m = 0.0;
+#pragma unroll 8
+        for (int k = tid & 7; k < nrow; k += 8) m = fma(e[k], s_prof[k], m);
+        m += __shfl_xor(m, 1, 64); m += __shfl_xor(m, 2, 64); m += __shfl_xor(m, 4, 64);
+        const double z = (c.flux[c.nflux + d] - m) / c.flux[2 * c.nflux + d];
+        const double z2 = z * z;
+        if ((tid & 7) == 0 && z2 == z2) part += z2;                  // np.nansum drops NaN terms
+    }
+    const double chisq = jx_block_sum(part, s_red);
+    if (tid == 0) {
+        const double ll = -chisq / 2.0;
+        const double b = base[w];
+        double tot = (b == -INFINITY) ? -INFINITY : b + ll;
+        if (tot != tot) tot = -INFINITY;                             // never hand NaN to the sampler
+        logp[w0 + w] = tot;
+        if (tap_chisq) tap_chisq[w] = chisq;
+        if (tap_parts) tap_parts[(size_t)w * 4 + 1] = ll;
+    }
+}
+
 // mirror the quadrant of distinct pixels into the full S x S Compton-y map (parity tap only)
 __global__ void __launch_bounds__(256)
 jx_expand_quad_kernel(const double* __restrict__ quad, size_t q_ld, size_t q_ws, int S, double* __restrict__ full /*[W][S][S]*/) {
