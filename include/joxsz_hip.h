@@ -175,11 +175,14 @@ int  jx_get_info(jx_ctx* ctx, int32_t* fft_pad, int32_t* chunk, int32_t* spline_
                  int32_t* nrow, int64_t* device_bytes);
 /* 1 = rocFFT, 2 = hand-written passes (what `conv_mode` resolved to); <0 on error */
 int  jx_get_conv_mode(jx_ctx* ctx);
-/* Layout the library chose for the hand-written convolution: out = {xsym, quad, NU, NJ, ld, img_rows, img_ld, P}.
+/* Layout the library chose for the hand-written convolution: out = {xsym, quad, NU, NJ, ld, img_rows, img_ld, P,
+ * rank, 0, 0, 0}.
  * xsym: row spectra travel as one real array (ld doubles per row); quad: the Abel+map kernel stores only the
  * img_rows x img_ld quadrant of distinct pixels per walker instead of the S x S map; NU distinct map rows, NJ
- * convolution jobs, P padded transform length.  JX_ERR_UNSUPPORTED with the rocFFT back end. */
-int  jx_get_conv_layout(jx_ctx* ctx, int32_t out[8]);
+ * convolution jobs, P padded transform length; rank > 0: the transfer-function weights are applied in their
+ * low-rank form and pass 3 transforms `rank` combined rows per walker instead of NJ (JOXSZ_LOWRANK=0 turns it
+ * off, JOXSZ_LOWRANK_TOL sets the singular-value cut, default 1e-13).  JX_ERR_UNSUPPORTED with the rocFFT back end. */
+int  jx_get_conv_layout(jx_ctx* ctx, int32_t out[12]);
 /* Test hook (hand-written convolution only): device address and geometry of a work buffer, holding the last
  * evaluated chunk.  which: 0 Compton-y maps [chunk][S][S] (geom[3] = 0) or their quadrant of
  * distinct pixels [chunk][S/2+1][ld], entry (|iy-c|, |ix-c|) (geom[3] = 1), 1 pass-1 row spectra [chunk][NU][ld], 2 FIR output

@@ -60,9 +60,16 @@ struct jx_ctx {
     // hand-written convolution (conv_mode 2)
     int conv_mode = 1;
     JxConv cv;
+    JxConv cv_lr;                      // pass 3 over the r combined rows of the low-rank form (NJ = CROWS = r)
+    JxLowrank lr;                      // lr.r == 0: every job goes through pass 3
+    double *d_Clr = nullptr, *d_col0lr = nullptr;
+    const cplx* lr_vt = nullptr;       // [r][Sh] right singular vectors as (v, 0)
     cplx *d_Y = nullptr, *d_C = nullptr, *d_part = nullptr;
     size_t p1_lds = 0, p2_lds = 0, p3_lds = 0;
     int p13_rows = 8, p1_rows = 8;
+    int lr_bucket = 0;                // k-steps compiled into the low-rank kernel in use
+    int last_nblk3 = 0;               // pass-3 blocks per walker of the launch sequence just queued
+    int num_cu = 256;
     int* d_rowjob = nullptr;
     int* d_runs = nullptr;
     int nrun = 0, fir_reg = 0;
@@ -221,6 +228,7 @@ int jx_create(const jx_config* cfg, jx_ctx** out) {
     if (hipSetDevice(c.device) != hipSuccess) { delete ctx; return JX_ERR_NODEVICE; }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, c.device) != hipSuccess) { delete ctx; return JX_ERR_NODEVICE; }
+    ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     ctx->devname = std::string(prop.name[0] ? prop.name : "AMD GPU") + " (" + prop.gcnArchName + ", " + std::to_string(prop.multiProcessorCount) + " CUs)";
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return JX_ERR_HIP; }
     if (g_rocfft_refs++ == 0) rocfft_setup();
@@ -457,6 +465,40 @@ int jx_finalize(jx_ctx* ctx) {
             for (int k = 0; k < cv.Sh * 2; ++k) hyc[q * cv.Sh * 2 + k] += hy[(size_t)r * cv.Sh * 2 + k];
         }
         if ((rc = dev_put(ctx, hyc.data(), hyc.size(), &p))) return rc; cv.hy = (const cplx*)p;
+        // low-rank form of the weights (see jx_lowrank_kernel): real weights, few enough jobs for the register-held U tile
+        memset(&ctx->lr, 0, sizeof(ctx->lr));
+        {
+            double tol = 1e-13;
+            bool want = true;
+            if (const char* e = getenv("JOXSZ_LOWRANK")) { if (atoi(e) == 0) want = false; }
+            if (const char* e = getenv("JOXSZ_LOWRANK_TOL")) { const double v2 = atof(e); if (v2 > 0.0 && v2 < 1e-6) tol = v2; }
+            double maxre = 0.0, maxim = 0.0;
+            for (size_t e = 0; e < hyc.size(); e += 2) { maxre = std::max(maxre, std::fabs(hyc[e])); maxim = std::max(maxim, std::fabs(hyc[e + 1])); }
+            if (want && cv.NJ <= 4 * JX_LR_KS && cv.NJ >= 32 && maxim <= 1e-15 * maxre) {
+                std::vector<double> A((size_t)cv.NJ * cv.Sh), L, Rt;
+                for (size_t e = 0; e < A.size(); ++e) A[e] = hyc[2 * e];
+                const int r = jxt::lowrank_factor(A.data(), cv.NJ, cv.Sh, tol, L, Rt);
+                int bucket = 0;
+#define JX_LR_PICK(K) if (!bucket && (cv.NJ + 3) / 4 <= K) bucket = K;
+                JX_LR_BUCKETS(JX_LR_PICK)
+#undef JX_LR_PICK
+                ctx->lr_bucket = bucket;
+                const size_t lds_need = (size_t)((r + 15) / 16) * bucket * 64 * sizeof(double);
+                if (bucket && r > 0 && 2 * r <= cv.NJ && r <= 64 && lds_need <= JX_LR_LDS_MAX) {
+                    JxLowrank& lr = ctx->lr;
+                    lr.r = r; lr.nq = cv.NJ; lr.ks = (cv.NJ + 3) / 4; lr.KQ = 4 * lr.ks;
+                    const int RP = ((r + 15) / 16) * 16;
+                    std::vector<double> U((size_t)RP * lr.KQ, 0.0), vt((size_t)r * cv.Sh * 2, 0.0);
+                    for (int rho = 0; rho < r; ++rho) {
+                        for (int q = 0; q < cv.NJ; ++q) U[(size_t)rho * lr.KQ + q] = L[(size_t)rho * cv.NJ + q];
+                        for (int k = 0; k < cv.Sh; ++k) vt[((size_t)rho * cv.Sh + k) * 2] = Rt[(size_t)rho * cv.Sh + k];
+                    }
+                    if ((rc = dev_put(ctx, U.data(), U.size(), &p))) return rc; lr.U = p;
+                    if ((rc = dev_put(ctx, vt.data(), vt.size(), &p))) return rc;
+                    ctx->lr_vt = (const cplx*)p;
+                }
+            }
+        }
         ctx->p2_lds = fir_lds;
         // runs of the register-window FIR: every segment cut into pieces of at most `runlen` conv rows
         {
@@ -481,7 +523,7 @@ int jx_finalize(jx_ctx* ctx) {
         // every map row symmetric about column S/2, and the register-window FIR)
         cv.xsym = (use_mirror && ctx->fir_reg && S <= 1024 && o < JX_XSYM_MAXT) ? 1 : 0;
         if (const char* e = getenv("JOXSZ_CONV_XSYM")) { if (atoi(e) == 0) cv.xsym = 0; }
-        cv.fir_ld = cv.xsym ? cv.Ph : 2 * cv.Ph;
+        cv.fir_ld = cv.xsym ? ((cv.Ph + 15) & ~15) : 2 * cv.Ph;
         if (cv.xsym) {
             // Z[k] = (X[k] + conj X[LP-k]) + i w (X[k] - conj X[LP-k]),  w = e^{+2 pi i k/P},  X[k] = e^{-i phi_k} Rc[k]
             const int LPn = cv.LP, cS = S / 2;
@@ -602,11 +644,21 @@ int jx_finalize(jx_ctx* ctx) {
         const JxConv& cv = ctx->cv;
         if ((rc = dev_new(ctx, (size_t)chunk * d.img_ws, &ctx->d_img, true))) return rc;
         if (d.quad && (rc = dev_new(ctx, (size_t)chunk * d.q_nb, &d.xcol))) return rc;
-        const size_t spec_div = cv.xsym ? 2 : 1;                           // real arrays need half the complex count
-        if ((rc = dev_new(ctx, ((size_t)chunk * cv.NU * cv.Ph + 1) / spec_div, &ctx->d_Y))) return rc;
-        if ((rc = dev_new(ctx, ((size_t)chunk * cv.CROWS * cv.Ph + 1) / spec_div, &ctx->d_C))) return rc;
-        if (cv.xsym && (rc = dev_new(ctx, (size_t)chunk * cv.NJ * (cv.o + 1), &ctx->cv.col0))) return rc;
+        // (counts in complex elements: fir_ld doubles per row in either mode)
+        if ((rc = dev_new(ctx, ((size_t)chunk * cv.NU * cv.fir_ld + 1) / 2, &ctx->d_Y, true))) return rc;
+        // (zeroed, with slack rows: the low-rank combination reads up to 4 JX_LR_KS rows from a walker's first row, against U = 0)
+        if ((rc = dev_new(ctx, ((size_t)chunk * cv.CROWS * cv.fir_ld + 1) / 2 + (size_t)2 * JX_LR_KS * cv.fir_ld, &ctx->d_C, true))) return rc;
+        if (cv.xsym && (rc = dev_new(ctx, (size_t)chunk * cv.NJ * (cv.o + 1) + 4 * JX_LR_KS, &ctx->cv.col0, true))) return rc;
         if ((rc = dev_new(ctx, (size_t)chunk * cv.nblk3 * cv.Sh, &ctx->d_part))) return rc;
+        if (ctx->lr.r > 0) {
+            if ((rc = dev_new(ctx, (size_t)chunk * ctx->lr.r * cv.fir_ld, &ctx->d_Clr))) return rc;
+            if (cv.xsym && (rc = dev_new(ctx, (size_t)chunk * (cv.o + 1) * ctx->lr.r, &ctx->d_col0lr))) return rc;
+            ctx->cv_lr = ctx->cv;                                  // cv is final here
+            ctx->cv_lr.hy = ctx->lr_vt;
+            ctx->cv_lr.col0 = ctx->d_col0lr;
+            ctx->cv_lr.NJ = ctx->lr.r; ctx->cv_lr.CROWS = ctx->lr.r;
+            ctx->cv_lr.nblk3 = (ctx->lr.r + ctx->p13_rows - 1) / ctx->p13_rows;
+        }
 #define JX_ATTR2(LPv, LSv, R1v, R3v) if (cv.LP == LPv && cv.LS == LSv) { \
             constexpr int rs1 = jx_lay<LPv>::RS, rs3 = jx_lay<LPv>::RS > jx_lay<LSv>::RS ? jx_lay<LPv>::RS : jx_lay<LSv>::RS; \
             ctx->p1_lds = sizeof(cplx) * ((size_t)R1v * rs1 + 2 * LPv + 2) + sizeof(double) * R1v; \
@@ -616,6 +668,9 @@ int jx_finalize(jx_ctx* ctx) {
         JX_CONV2_PAIRS(JX_ATTR2)
 #undef JX_ATTR2
         HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_beamfir_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->p2_lds));
+#define JX_LR_ATTR(K, T) HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_lowrank_kernel<K, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)JX_LR_LDS_MAX));
+        JX_LR_KINDS(JX_LR_ATTR)
+#undef JX_LR_ATTR
     }
 
     FFTCHK(ctx, rocfft_execution_info_create(&ctx->info));
@@ -667,7 +722,7 @@ static int launch_custom_conv(jx_ctx* ctx, int n, double* tap_convjobs, EvSet* e
     const JxDev& d = ctx->d;
     hipStream_t st = ctx->stream;
     bool done = false;
-    const dim3 g1((cv.NU + ctx->p1_rows - 1) / ctx->p1_rows, n), g3(cv.nblk3, n);
+    const dim3 g1((cv.NU + ctx->p1_rows - 1) / ctx->p1_rows, n);
 #define JX_P1(LPv, LSv, R1v, R3v) if (!done && cv.LP == LPv && cv.LS == LSv) { \
         hipLaunchKernelGGL((jx_rowfft2_kernel<LPv, R1v>), g1, dim3(256), ctx->p1_lds, st, cv, ctx->d_img, (size_t)d.img_ld, (size_t)d.img_ws, ctx->d_Y); done = true; }
     JX_CONV2_PAIRS(JX_P1)
@@ -687,8 +742,29 @@ static int launch_custom_conv(jx_ctx* ctx, int n, double* tap_convjobs, EvSet* e
     }
     if (es) HIPCHK(ctx, hipEventRecord(es->e[3], st));
     done = false;
+    // the beam-convolved map is only materialised job by job (parity tap) without the low-rank combination
+    const bool lowrank = ctx->lr.r > 0 && !tap_convjobs;
+    ctx->last_nblk3 = lowrank ? ctx->cv_lr.nblk3 : cv.nblk3;
+    if (lowrank) {
+        const JxLowrank& lr = ctx->lr;
+        const int ntr = (lr.r + 15) / 16, threads = 512;
+        const size_t lds = (size_t)ntr * ctx->lr_bucket * 64 * sizeof(double);
+        const dim3 blocks(ctx->num_cu);
+        const long long ld = cv.fir_ld, nt = cv.o + 1;
+#define JX_LR_GO(K, T) if (ctx->lr_bucket == K && ntr == T) { \
+            hipLaunchKernelGGL((jx_lowrank_kernel<K, T>), blocks, dim3(threads), lds, st, lr, reinterpret_cast<const double*>(ctx->d_C), \
+                               (long long)cv.CROWS * ld, ld, 1LL, ctx->d_Clr, (long long)lr.r * ld, ld, 1LL, cv.xsym ? cv.Ph : 2 * cv.Ph, n); \
+            if (cv.xsym) \
+                hipLaunchKernelGGL((jx_lowrank_kernel<K, T>), blocks, dim3(threads), lds, st, lr, cv.col0, nt * cv.NJ, 1LL, (long long)cv.NJ, \
+                                   ctx->d_col0lr, nt * lr.r, 1LL, (long long)lr.r, (int)nt, n); }
+        JX_LR_KINDS(JX_LR_GO)
+#undef JX_LR_GO
+    }
+    const JxConv& c3 = lowrank ? ctx->cv_lr : cv;
+    const cplx* in3 = lowrank ? reinterpret_cast<const cplx*>(ctx->d_Clr) : ctx->d_C;
+    const dim3 g3b(c3.nblk3, n);
 #define JX_P3(LPv, LSv, R1v, R3v) if (!done && cv.LP == LPv && cv.LS == LSv) { \
-        hipLaunchKernelGGL((jx_rowtf2_kernel<LPv, LSv, R3v>), g3, dim3(256), ctx->p3_lds, st, cv, ctx->d_C, ctx->d_part, tap_convjobs); done = true; }
+        hipLaunchKernelGGL((jx_rowtf2_kernel<LPv, LSv, R3v>), g3b, dim3(256), ctx->p3_lds, st, c3, in3, ctx->d_part, tap_convjobs); done = true; }
     JX_CONV2_PAIRS(JX_P3)
 #undef JX_P3
     if (tap_convjobs)
@@ -761,13 +837,13 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
         int rc2 = launch_custom_conv(ctx, n, t.conv, tm ? &es : nullptr);
         if (rc2) return rc2;
         zpart = ctx->d_part;
-        nblk = cv.nblk3;
+        nblk = ctx->last_nblk3;
     }
     bool tail_done = false;
     if (ctx->conv_mode == 2 && d.nrow == ctx->cv.LS && !getenv("JOXSZ_TAIL_DFT")) {
         const JxConv& cv = ctx->cv;
 #define JX_TAILF(LPv, LSv, R1v, R3v) if (!tail_done && cv.LP == LPv && cv.LS == LSv) { \
-            hipLaunchKernelGGL((jx_tail_fft_kernel<LSv>), dim3(n), dim3(256), 0, st, d, cv, zpart, ctx->d_cfac, ctx->d_base, logp_dev, w0, \
+            hipLaunchKernelGGL((jx_tail_fft_kernel<LSv>), dim3(n), dim3(256), 0, st, d, cv, zpart, nblk, ctx->d_cfac, ctx->d_base, logp_dev, w0, \
                                t.row, t.bright, t.chisq, t.parts); tail_done = true; }
         JX_CONV2_PAIRS(JX_TAILF)
 #undef JX_TAILF
@@ -977,12 +1053,13 @@ int jx_get_conv_mode(jx_ctx* ctx) {
     return ctx->conv_mode;
 }
 
-int jx_get_conv_layout(jx_ctx* ctx, int32_t out[8]) {
+int jx_get_conv_layout(jx_ctx* ctx, int32_t out[12]) {
     if (!ctx || !ctx->finalized || !out) return JX_ERR_STATE;
     if (ctx->conv_mode != 2) { ctx->err = "layout of the hand-written convolution only"; return JX_ERR_UNSUPPORTED; }
     const JxConv& cv = ctx->cv;
     out[0] = cv.xsym; out[1] = ctx->d.quad; out[2] = cv.NU; out[3] = cv.NJ; out[4] = cv.fir_ld;
     out[5] = ctx->d.quad ? ctx->d.q_nb : cv.S; out[6] = (int32_t)ctx->d.img_ld; out[7] = cv.P;
+    out[8] = ctx->lr.r; out[9] = out[10] = out[11] = 0;
     return JX_OK;
 }
 

@@ -54,7 +54,7 @@ struct JxConv {
     int CROWS;                      // rows per walker in C: NJ + 1 (one spare row for store overshoot)
     int mirror;                     // 1: umap[m] = |m - S/2| (mirror structure), 0: umap[m] = m
     int xsym;                       // 1: map rows are also mirror-symmetric in x: Y and C hold ONE real array per row
-    int fir_ld;                     // doubles per row of Y / C: Ph (xsym) or 2 Ph
+    int fir_ld;                     // doubles per row of Y / C: Ph rounded up to 16 (xsym: rows start on cache lines) or 2 Ph
     int quad;                       // 1: the map arrives as its quadrant [S/2+1][img_ld] of distinct pixels (|iy-c|, |ix-c|)
     const cplx* zab;                // [LP][2] pass-3 pre-process factors: Z[k] = zab[k][0] Rc[k] + zab[k][1] Rc[LP-k]   (xsym)
     const double* bcol;             // [o+1][JX_COL0_LD] step^2 beam[o+t][o+x], zero beyond x = o: what column 0 of a map row adds to output column x  (xsym)
@@ -234,7 +234,7 @@ jx_rowfft2_kernel(JxConv c, const double* __restrict__ img, size_t img_ld, size_
             const int j = (k * (c.S >> 1)) % c.P;                     // e^{+i phi} = conj(tw_P[j]) = tw_P[P - j]
             const cplx t = twp[j <= LP ? j : c.P - j];
             const double sn = j <= LP ? -t.y : t.y;
-            reinterpret_cast<double*>(Y)[((size_t)w * c.NU + r0 + row) * Ph + k] = (X.x - s_x0[row]) * t.x - X.y * sn;
+            reinterpret_cast<double*>(Y)[((size_t)w * c.NU + r0 + row) * c.fir_ld + k] = (X.x - s_x0[row]) * t.x - X.y * sn;
         } else {
             Y[((size_t)w * c.NU + r0 + row) * Ph + k] = X;
         }
@@ -312,7 +312,8 @@ jx_rowtf2_kernel(JxConv c, const cplx* __restrict__ C, cplx* __restrict__ part, 
     constexpr int NSL = (ROWS * JX_XSYM_MAXT + 255) / 256;          // entries of s_s per thread (blockDim = 256)
     if (c.xsym) {
         // Z[k] = zab[k][0] Rc[k] + zab[k][1] Rc[LP-k], four elements per thread and trip as below
-        const double* Rblk = reinterpret_cast<const double*>(C) + ((size_t)w * c.CROWS + r0) * Ph;
+        const int ldr = c.fir_ld;                                    // row stride of the real arrays (Ph rounded up to whole cache lines)
+        const double* Rblk = reinterpret_cast<const double*>(C) + ((size_t)w * c.CROWS + r0) * ldr;
         const int nt = c.o + 1, ns = nrows * nt;
         double cz[NSL];                                              // this block's slice of col0, requested first
 #pragma unroll
@@ -327,8 +328,8 @@ jx_rowtf2_kernel(JxConv c, const cplx* __restrict__ C, cplx* __restrict__ part, 
 #pragma unroll
             for (int row = 0; row < ROWS; ++row) {
                 const int rr = min(row, nrows - 1);
-                r1[row] = Rblk[(size_t)rr * Ph + k];
-                r2[row] = Rblk[(size_t)rr * Ph + kp];
+                r1[row] = Rblk[(size_t)rr * ldr + k];
+                r2[row] = Rblk[(size_t)rr * ldr + kp];
             }
             const cplx za1 = c.zab[2 * k], zb1 = c.zab[2 * k + 1], za2 = c.zab[2 * kq], zb2 = c.zab[2 * kq + 1];
             const int n1a = k / P2, n2a = k - n1a * P2, n1b = kq / P2, n2b = kq - n1b * P2;
@@ -698,7 +699,7 @@ jx_beamfir_reg_kernel(JxConv c, const int* __restrict__ runs, int nrun, int nwal
     const double* Yw = reinterpret_cast<const double*>(Y) + (size_t)w * c.NU * ld + col;
     double* Cw = reinterpret_cast<double*>(C) + (size_t)w * c.CROWS * ld + col;
     double tap[O + 1];
-    const int tcol = c.xsym ? col : (col >> 1);
+    const int tcol = c.xsym ? min(col, c.Ph - 1) : (col >> 1);        // (columns past Ph are line padding)
 #pragma unroll
     for (int t = 0; t <= O; ++t) tap[t] = c.taps[(size_t)t * c.Ph + tcol];
     double win[W], fifo[D];
@@ -729,6 +730,93 @@ jx_beamfir_reg_kernel(JxConv c, const int* __restrict__ runs, int nrun, int nwal
 }
 
 // ------------------------------------------------------------------------------------
+// Low-rank form of the transfer-function weights.  The weights Hy[job][kx] of pass 3 factor as
+// sum_rho U[rho][job] v_rho[kx] with a few dozen terms (jx_tables.hpp lowrank_factor, to rounding), and
+// everything between the FIR and the weighting is linear and the same for every job, so
+//     Z(kx) = sum_q Hy[q](kx) X_q(kx) = sum_rho v_rho(kx) T( sum_q U[rho][q] C_q )(kx):
+// the jobs are combined FIRST and pass 3 transforms r rows per walker instead of NJ.
+// This kernel is the combination  D[w][rho][j] = sum_q U[rho][q] B[w][q][j]  as a batched GEMM on the fp64
+// matrix cores (v_mfma_f64_16x16x4: A = U tile, lane l holds U[rho0 + (l & 15)][4 s + (l >> 4)] for every
+// k-step s of its share, kept in registers for the whole launch; B lane l = B[q = 4 s + (l >> 4)][j = j0 + (l & 15)];
+// D lane l, register g = D[rho0 + (l >> 4) + 4 g][j0 + (l & 15)]).  Persistent blocks walk the (walker, column tile) tasks.
+// Generic strides serve both the FIR rows (j = kx) and the column-0 terms (j = output column x).
+// ------------------------------------------------------------------------------------
+#define JX_LR_KS 72                 // k-steps per task, B values of all of them in flight at once: jobs <= 4 * JX_LR_KS
+#define JX_LR_LDS_MAX (150 * 1024)  // the U fragments of every rho tile live in LDS
+struct JxLowrank {
+    const double* U;                // [RP][KQ] sigma u, zero padded (RP multiple of 16, KQ = 4 ks)
+    int r, ks, KQ, nq;              // rank, k-steps, padded and true job count
+};
+
+typedef double jx_v4d __attribute__((ext_vector_type(4)));
+
+// One wave per column tile, all NTR rho tiles of it (NTR accumulators): every B value is requested once per CU, its NTR
+// A fragments come from LDS (fragment order [tile][k-step][lane]).  KS = k-steps compiled in (>= lr.ks, the U fragments
+// beyond lr.ks are zero): no branch inside the load and MFMA sequences.  No barrier inside the task loop.
+template <int KS, int NTR>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 2)))
+jx_lowrank_kernel(JxLowrank lr, const double* __restrict__ B, long long bws, long long bq, long long bj,
+                  double* __restrict__ D, long long dws, long long dr, long long dj, int ncols, int nwalk) {
+    extern __shared__ __attribute__((aligned(16))) double s_a[];      // [NTR][KS][64]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    for (int e = threadIdx.x; e < NTR * KS * 64; e += blockDim.x) {
+        const int l = e & 63, s = (e >> 6) % KS, t = (e >> 6) / KS;
+        s_a[e] = (s < lr.ks) ? lr.U[(size_t)(t * 16 + (l & 15)) * lr.KQ + 4 * s + (l >> 4)] : 0.0;
+    }
+    __syncthreads();
+    const double* sa = s_a + lane;
+    const int ntile = (ncols + 15) >> 4, ntask = ntile * nwalk, stride = gridDim.x * nwave;
+    const long long step = 4 * bq;
+    // B rows 4 s + lk, s < KS.  Rows past the last job are read too (U = 0 there): the caller keeps 4 KS rows behind every
+    // walker allocated and finite.  Each B register is refilled with the row half a task ahead (this task's or the next
+    // one's) right after its MFMAs: a value is requested KS/2 k-steps before it is used.
+    auto bptr = [&](int task) {
+        const int w = task / ntile, jt = task - w * ntile;
+        return B + (size_t)w * bws + (size_t)min(jt * 16 + li, ncols - 1) * bj + (size_t)lk * bq;
+    };
+    int task = blockIdx.x * nwave + wave;
+    if (task >= ntask) return;
+    constexpr int H = KS / 2;                                         // B values in flight: half a task
+    double b[H];
+    const double* pb = bptr(task);
+#pragma unroll
+    for (int u = 0; u < H; ++u) b[u] = pb[u * step];
+    while (task < ntask) {
+        const int next = task + stride;
+        const double* pbn = bptr(min(next, ntask - 1));                // past the end: a valid address, never used
+        jx_v4d acc[NTR];
+#pragma unroll
+        for (int t = 0; t < NTR; ++t) acc[t] = jx_v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int u = 0; u < KS; ++u) {
+#pragma unroll
+#ifndef JX_LR_DBG
+#define JX_LR_DBG 0
+#endif
+            for (int t = 0; t < NTR; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64((JX_LR_DBG & 2) ? 1.5 : sa[(t * KS + u) * 64], b[u % H], acc[t], 0, 0, 0);
+            if (!(JX_LR_DBG & 1)) b[u % H] = (u + H < KS) ? pb[(u + H) * step] : pbn[(u + H - KS) * step];
+            if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // keep the LDS reads of later groups where they are
+        }
+        pb = pbn;
+        const int w = task / ntile, jt = task - w * ntile;
+        if (jt * 16 + li < ncols) {
+            double* Dp = D + (size_t)w * dws + (size_t)(jt * 16 + li) * dj;
+#pragma unroll
+            for (int t = 0; t < NTR; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int rho = t * 16 + lk + 4 * g;
+                    if (rho < lr.r) Dp[(size_t)rho * dr] = acc[t][g];
+                }
+        }
+        task = next;
+    }
+}
+#define JX_LR_BUCKETS(X) X(24) X(40) X(72)
+#define JX_LR_KINDS(X) X(24, 1) X(24, 2) X(24, 3) X(24, 4) X(40, 1) X(40, 2) X(40, 3) X(40, 4) X(72, 1) X(72, 2) X(72, 3) X(72, 4)
+
+// ------------------------------------------------------------------------------------
 // tail of the hand-written path.  One 256-thread block per walker:
 //   Z[kc]  = sum over pass-3 blocks of the partial sums (fixed order)
 //   row[k] = sum_kc Re(Z[kc] e^{2 pi i kc (S/2 + k)/S}),  k = 0..S/2-1   (joxsz_funcs.py:467,472)
@@ -740,7 +828,7 @@ jx_beamfir_reg_kernel(JxConv c, const int* __restrict__ runs, int nrun, int nwal
 // ------------------------------------------------------------------------------------
 template <int LS>
 __global__ void __launch_bounds__(256)
-jx_tail_fft_kernel(JxDev c, JxConv cv, const cplx* __restrict__ zpart, const double* __restrict__ cfac,
+jx_tail_fft_kernel(JxDev c, JxConv cv, const cplx* __restrict__ zpart, int nblk, const double* __restrict__ cfac,
                    const double* __restrict__ base, double* __restrict__ logp, int w0,
                    double* __restrict__ tap_row, double* __restrict__ tap_bright, double* __restrict__ tap_chisq,
                    double* __restrict__ tap_parts) {
@@ -752,7 +840,7 @@ jx_tail_fft_kernel(JxDev c, JxConv cv, const cplx* __restrict__ zpart, const dou
     __shared__ cplx s_v[LS + 1];                                      // Z
     __shared__ double s_prof[LS];
     __shared__ double s_red[8];
-    const int tid = threadIdx.x, w = blockIdx.x, nblk = cv.nblk3, Sh = LS + 1, nrow = LS;
+    const int tid = threadIdx.x, w = blockIdx.x, Sh = LS + 1, nrow = LS;       // nblk: pass-3 blocks per walker of this launch
 
     // everything this thread will want from global memory before the first barrier is requested up front
     double twr[NK][2];

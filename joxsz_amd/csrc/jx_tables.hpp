@@ -419,6 +419,81 @@ inline void tf_hy_table(const std::vector<double>& filt, int S, std::vector<doub
 }
 
 // ---------------------------------------------------------------------------------------
+// Truncated singular value decomposition  A[m][n] ~ sum_{rho < r} L[rho][i] Rt[rho][j]  by one-sided
+// (Hestenes) Jacobi rotations on the columns of A: afterwards the columns are orthogonal, their norms
+// are the singular values and the accumulated rotations are the right singular vectors.  L carries
+// the singular value (L = sigma u), Rt has unit rows.  Terms are sorted by singular value; r counts
+// those above tol * sigma_max.  The transfer-function weights Hy[job][kx] have a numerical rank of a
+// few dozen, which lets pass 3 transform r combined rows per walker instead of one per job.
+// Returns r; sigma_out (optional) receives all n singular values, sorted.
+// ---------------------------------------------------------------------------------------
+inline int lowrank_factor(const double* A, int m, int n, double tol, std::vector<double>& L, std::vector<double>& Rt,
+                          std::vector<double>* sigma_out = nullptr) {
+    std::vector<double> G((size_t)n * m), V((size_t)n * n, 0.0);            // column-major: G[j*m + i], V[j*n + k]
+    for (int i = 0; i < m; ++i)
+        for (int j = 0; j < n; ++j) G[(size_t)j * m + i] = A[(size_t)i * n + j];
+    for (int j = 0; j < n; ++j) V[(size_t)j * n + j] = 1.0;
+    std::vector<double> nrm(n);
+    double big = 0.0;
+    for (int j = 0; j < n; ++j) {
+        double a = 0.0;
+        for (int i = 0; i < m; ++i) a += G[(size_t)j * m + i] * G[(size_t)j * m + i];
+        nrm[j] = a; big = std::max(big, a);
+    }
+    const double negl = big * 1e-36;                                          // columns this small never matter at double precision
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        int rotations = 0;
+        for (int p = 0; p < n - 1; ++p) {
+            for (int q = p + 1; q < n; ++q) {
+                const double alpha = nrm[p], beta = nrm[q];
+                if (alpha <= negl && beta <= negl) continue;
+                double* gp = &G[(size_t)p * m];
+                double* gq = &G[(size_t)q * m];
+                double gamma = 0.0;
+                for (int i = 0; i < m; ++i) gamma += gp[i] * gq[i];
+                if (std::fabs(gamma) <= 1e-15 * std::sqrt(alpha * beta) || gamma == 0.0) continue;
+                ++rotations;
+                const double zeta = (beta - alpha) / (2.0 * gamma);
+                const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+                const double cs = 1.0 / std::sqrt(1.0 + t * t), sn = cs * t;
+                double a2 = 0.0, b2 = 0.0;
+                for (int i = 0; i < m; ++i) {
+                    const double x = gp[i], y = gq[i];
+                    const double xn = cs * x - sn * y, yn = sn * x + cs * y;
+                    gp[i] = xn; gq[i] = yn; a2 += xn * xn; b2 += yn * yn;
+                }
+                nrm[p] = a2; nrm[q] = b2;
+                double* vp = &V[(size_t)p * n];
+                double* vq = &V[(size_t)q * n];
+                for (int k = 0; k < n; ++k) {
+                    const double x = vp[k], y = vq[k];
+                    vp[k] = cs * x - sn * y; vq[k] = sn * x + cs * y;
+                }
+            }
+        }
+        if (!rotations) break;
+    }
+    std::vector<int> order(n);
+    for (int j = 0; j < n; ++j) order[j] = j;
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return nrm[a] > nrm[b]; });
+    const double smax = std::sqrt(nrm[order[0]]);
+    int r = 0;
+    while (r < n && std::sqrt(nrm[order[r]]) > tol * smax) ++r;
+    L.assign((size_t)r * m, 0.0);
+    Rt.assign((size_t)r * n, 0.0);
+    for (int rho = 0; rho < r; ++rho) {
+        const int j = order[rho];
+        for (int i = 0; i < m; ++i) L[(size_t)rho * m + i] = G[(size_t)j * m + i];
+        for (int k = 0; k < n; ++k) Rt[(size_t)rho * n + k] = V[(size_t)j * n + k];
+    }
+    if (sigma_out) {
+        sigma_out->resize(n);
+        for (int j = 0; j < n; ++j) (*sigma_out)[j] = std::sqrt(nrm[order[j]]);
+    }
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------
 // Row bookkeeping of the hand-written convolution.
 //   mirror = true : map row m equals map row m' whenever |m - c| == |m' - c| (c = S/2), which is
 //                   what a d_mat built by centdistmat gives; otherwise every row is distinct.

@@ -106,6 +106,16 @@ int jxt_conv_row_tables(int S, int o, int mirror, int* umap /*[S]*/, int* urow /
     return 0;
 }
 
+// truncated SVD: returns the rank r; L [r][m], Rt [r][n] (caller sizes them for min(m, n) terms), sigma [n]
+int jxt_lowrank_factor(const double* A, int m, int n, double tol, double* L, double* Rt, double* sigma) {
+    std::vector<double> l, rt, sg;
+    const int r = jxt::lowrank_factor(A, m, n, tol, l, rt, &sg);
+    std::copy(l.begin(), l.end(), L);
+    std::copy(rt.begin(), rt.end(), Rt);
+    std::copy(sg.begin(), sg.end(), sigma);
+    return r;
+}
+
 int jxt_custom_conv_lp(int S, int o) { return jxt::custom_conv_lp(S, o); }
 
 int jxt_next_smooth_even(int n) { return jxt::next_smooth_even(n); }

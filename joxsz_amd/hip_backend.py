@@ -157,9 +157,9 @@ class HipContext:
         self.conv = {1: 'rocfft', 2: 'custom'}.get(self.lib.jx_get_conv_mode(self._h), '?')
         self.conv_layout = None
         if self.conv == 'custom':
-            lay = (ctypes.c_int32 * 8)()
+            lay = (ctypes.c_int32 * 12)()
             self._chk(self.lib.jx_get_conv_layout(self._h, lay), 'jx_get_conv_layout')
-            self.conv_layout = dict(zip(('xsym', 'quad', 'NU', 'NJ', 'ld', 'img_rows', 'img_ld', 'P'), [int(v) for v in lay]))
+            self.conv_layout = dict(zip(('xsym', 'quad', 'NU', 'NJ', 'ld', 'img_rows', 'img_ld', 'P', 'rank'), [int(v) for v in lay]))
 
     # -- plumbing --
     def _chk(self, rc, what):

@@ -248,7 +248,8 @@ def test_conv_work_buffers_against_numpy(S, N):
     assert xsym, 'default mode for a mirror-symmetric d_mat and this beam width'
     col0, _ = ctx.workspace('col0')
     post.close()
-    Ph = Y.shape[2]; P = 2 * (Ph - 1); c = S // 2; B = pb.B; o = (B - 1) // 2
+    P = ctx.conv_layout['P']; Ph = P // 2 + 1; c = S // 2; B = pb.B; o = (B - 1) // 2
+    Y = Y[:, :, :Ph]; C = C[:, :, :Ph]                      # rows are padded to whole cache lines
     phase = np.exp(2j * np.pi * np.arange(Ph) * c / P)
     beam = np.asarray(pb.beam_2d, float)
     # beam spectrum along x per row offset d = -o..o (centred: column o is x offset 0)
@@ -276,6 +277,31 @@ def test_conv_work_buffers_against_numpy(S, N):
                 if 0 <= r - d < S:
                     want0[q] += pb.step ** 2 * beam[o + d, o:] * y[w][r - d, 0]
         assert np.abs(col0[w].T - want0).max() < 1e-13 * np.abs(want0).max()       # stored [x][job]
+
+
+def test_lowrank_weights_against_full_weights(monkeypatch):
+    """The transfer-function weights in low-rank form (jobs combined before pass 3, truncation at 1e-13 of the
+    largest singular value) against one pass-3 row per job (JOXSZ_LOWRANK=0), and both against the oracle."""
+    from joxsz_amd import datasets
+    for S, N in ((256, 300), (512, 500)):
+        pb = datasets.synthetic_problem(S=S, N=N, seed=11)
+        th = datasets.walker_ball(pb, 6, spread=0.05, seed=11)
+        res = {}
+        for mode in ('1', '0'):
+            monkeypatch.setenv('JOXSZ_LOWRANK', mode)
+            post = _post(pb, conv='custom')
+            rank = post.ctx.conv_layout['rank']
+            assert (rank > 0) == (mode == '1') and rank < post.ctx.conv_layout['NJ'] // 2
+            res[mode] = (post.stage(th, 'map_row'), post.stage(th, 'bright'), post.log_prob(th))
+            post.close()
+        monkeypatch.delenv('JOXSZ_LOWRANK')
+        for a, b in zip(res['1'][:2], res['0'][:2]):
+            np.testing.assert_allclose(a, b, rtol=1e-10, atol=1e-11 * np.abs(b).max())
+        np.testing.assert_allclose(res['1'][2], res['0'][2], rtol=1e-9)
+        want = orc.log_posterior_batch(pb, th)
+        np.testing.assert_allclose(res['1'][2], want, rtol=RTOL)
+        st = orc.sz_stages(pb, orc.pars_dict(pb, th[0]))
+        assert _relerr(res['1'][0][0], st['map_row']) < RTOL_STAGE
 
 
 def test_largest_config_shape():

@@ -246,3 +246,24 @@ def test_conv_row_tables(lib, S, o, mirror):
     assert all(q == sum(n for _, n, _ in segs[:i]) for i, (_, _, q) in enumerate(segs))
     if mirror and S % 2 == 1:
         assert NJ == c + 1 and nseg == 1                              # odd side: exact mirror, half the rows
+
+
+def test_lowrank_factor(lib):
+    """Jacobi SVD of the host tables against numpy: singular values, reconstruction at the chosen rank."""
+    rng = np.random.default_rng(5)
+    m, n, true_rank = 60, 45, 9
+    A = rng.standard_normal((m, true_rank)) @ np.diag(10.0 ** -np.arange(true_rank)) @ rng.standard_normal((true_rank, n))
+    A += 1e-13 * rng.standard_normal((m, n))
+    L = np.zeros((n, m)); Rt = np.zeros((n, n)); sg = np.zeros(n)
+    lib.jxt_lowrank_factor.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_double] + [ctypes.c_void_p] * 3
+    r = lib.jxt_lowrank_factor(_p(np.ascontiguousarray(A)), m, n, 1e-10, _p(L), _p(Rt), _p(sg))
+    want = np.linalg.svd(A, compute_uv=False)
+    assert r == int((want > 1e-10 * want[0]).sum()) == true_rank
+    np.testing.assert_allclose(sg[:true_rank], want[:true_rank], rtol=1e-12, atol=1e-14 * want[0])
+    approx = L[:r].T @ Rt[:r]
+    assert np.abs(approx - A).max() < 1e-9 * np.abs(A).max()
+    np.testing.assert_allclose(np.linalg.norm(Rt[:r], axis=1), 1.0, rtol=1e-12)
+    # full rank request reproduces the matrix to rounding
+    r2 = lib.jxt_lowrank_factor(_p(np.ascontiguousarray(A)), m, n, 0.0, _p(L), _p(Rt), _p(sg))
+    assert r2 == n
+    assert np.abs(L[:r2].T @ Rt[:r2] - A).max() < 1e-13 * np.abs(A).max()
