@@ -176,18 +176,21 @@ int  jx_get_info(jx_ctx* ctx, int32_t* fft_pad, int32_t* chunk, int32_t* spline_
 /* 1 = rocFFT, 2 = hand-written passes (what `conv_mode` resolved to); <0 on error */
 int  jx_get_conv_mode(jx_ctx* ctx);
 /* Layout the library chose for the hand-written convolution: out = {xsym, quad, NU, NJ, ld, img_rows, img_ld, P,
- * rank, 0, 0, 0}.
+ * rank, fused, 0, 0}.
  * xsym: row spectra travel as one real array (ld doubles per row); quad: the Abel+map kernel stores only the
  * img_rows x img_ld quadrant of distinct pixels per walker instead of the S x S map; NU distinct map rows, NJ
  * convolution jobs, P padded transform length; rank > 0: the transfer-function weights are applied in their
  * low-rank form and pass 3 transforms `rank` combined rows per walker instead of NJ (JOXSZ_LOWRANK=0 turns it
- * off, JOXSZ_LOWRANK_TOL sets the singular-value cut, default 1e-13).  JX_ERR_UNSUPPORTED with the rocFFT back end. */
+ * off, JOXSZ_LOWRANK_TOL sets the singular-value cut, default 1e-13); fused = 1: the FIR along rows and that
+ * combination run as one matrix product per column kx on walker-minor row spectra (JOXSZ_FUSED=0: separate kernels).  JX_ERR_UNSUPPORTED with the rocFFT back end. */
 int  jx_get_conv_layout(jx_ctx* ctx, int32_t out[12]);
 /* Test hook (hand-written convolution only): device address and geometry of a work buffer, holding the last
  * evaluated chunk.  which: 0 Compton-y maps [chunk][S][S] (geom[3] = 0) or their quadrant of
  * distinct pixels [chunk][S/2+1][ld], entry (|iy-c|, |ix-c|) (geom[3] = 1), 1 pass-1 row spectra [chunk][NU][ld], 2 FIR output
  * [chunk][NJ+1][ld], 3 column-0 terms [chunk][o+1][NJ] (doubles); 4 conv row of each job [NJ], 5 distinct-row index
- * of each map row [S] (int32).  geom = {chunk, rows, ld, xsym}: ld doubles per row, xsym = 1 when rows 1 and 2 hold
+ * of each map row [S] (int32); fused route: 6 walker-minor row spectra [Ph][KU][tW], 7 combined rows [tW][Ph][64],
+ * 8 their column-0 terms [tW][32][64], 9 walker-minor map column 0 [KU][tW]; low-rank route with separate kernels: 10 combined rows
+ * [chunk][rank][ld], 11 their column-0 terms [chunk][o+1][rank] (geom[3] = rank).  geom = {chunk, rows, ld, xsym}: ld doubles per row, xsym = 1 when rows 1 and 2 hold
  * the real array R of  Y(kx) = x0 + e^{-2 pi i kx (S/2)/P} R(kx),  0 when they hold (re, im) pairs. */
 int  jx_debug_workspace(jx_ctx* ctx, int which, void** dev, int32_t geom[4]);
 int  jx_device_count(void);

@@ -64,6 +64,13 @@ struct jx_ctx {
     JxLowrank lr;                      // lr.r == 0: every job goes through pass 3
     double *d_Clr = nullptr, *d_col0lr = nullptr;
     const cplx* lr_vt = nullptr;       // [r][Sh] right singular vectors as (v, 0)
+    // fused FIR + job combination (one GEMM per column, walker-minor row spectra): tables, buffers, launch copy of JxConv
+    JxLowrank lrf, lrf0;               // lrf.r == 0: not available.  A = Wk [Ph][RP][KU] / V0 [o+1][RP][KU]
+    JxConv cv_f;
+    int fused_bucket = 0, tW = 0, tKU = 0;
+    double *d_Rt = nullptr, *d_Ct = nullptr, *d_Ct0 = nullptr, *d_x0t = nullptr;
+    std::vector<double> h_L, h_taps;   // finalize scratch: U [r][NJ], FIR taps [o+1][Ph]
+    jxt::ConvRows h_rows;
     cplx *d_Y = nullptr, *d_C = nullptr, *d_part = nullptr;
     size_t p1_lds = 0, p2_lds = 0, p3_lds = 0;
     int p13_rows = 8, p1_rows = 8;
@@ -456,6 +463,7 @@ int jx_finalize(jx_ctx* ctx) {
         jxt::twiddles(S, cv.LS + 1, v); if ((rc = dev_put(ctx, v.data(), v.size(), &p))) return rc; cv.tw_s = (const cplx*)p;
         jxt::beam_fir_taps(beam_h, B, P, c.step * c.step / (double)P, v);
         if ((rc = dev_put(ctx, v.data(), v.size(), &p))) return rc; cv.taps = p;
+        ctx->h_taps = v; ctx->h_rows = rows;
         std::vector<double> filt = host_vec<double>(ctx, JX_T_FILTERING), hy;
         jxt::tf_hy_table(filt, S, hy);
         // Hy weights summed over the conv rows of each job
@@ -467,6 +475,8 @@ int jx_finalize(jx_ctx* ctx) {
         if ((rc = dev_put(ctx, hyc.data(), hyc.size(), &p))) return rc; cv.hy = (const cplx*)p;
         // low-rank form of the weights (see jx_lowrank_kernel): real weights, few enough jobs for the register-held U tile
         memset(&ctx->lr, 0, sizeof(ctx->lr));
+        memset(&ctx->lrf, 0, sizeof(ctx->lrf));
+        memset(&ctx->lrf0, 0, sizeof(ctx->lrf0));
         {
             double tol = 1e-13;
             bool want = true;
@@ -496,6 +506,7 @@ int jx_finalize(jx_ctx* ctx) {
                     if ((rc = dev_put(ctx, U.data(), U.size(), &p))) return rc; lr.U = p;
                     if ((rc = dev_put(ctx, vt.data(), vt.size(), &p))) return rc;
                     ctx->lr_vt = (const cplx*)p;
+                    ctx->h_L = L;
                 }
             }
         }
@@ -658,6 +669,35 @@ int jx_finalize(jx_ctx* ctx) {
             ctx->cv_lr.col0 = ctx->d_col0lr;
             ctx->cv_lr.NJ = ctx->lr.r; ctx->cv_lr.CROWS = ctx->lr.r;
             ctx->cv_lr.nblk3 = (ctx->lr.r + ctx->p13_rows - 1) / ctx->p13_rows;
+            // fused FIR + combination: needs the real row spectra and the quadrant map (walker-minor column-0 copy)
+            bool fuse = cv.xsym && d.quad;
+            if (const char* e = getenv("JOXSZ_FUSED")) { if (atoi(e) == 0) fuse = false; }
+            const int r = ctx->lr.r, RP = ((r + 15) / 16) * 16, KU = (cv.NU + 3) & ~3, nt = cv.o + 1;
+            int fb = 0;
+#define JX_LR_PICK(K) if (!fb && KU / 4 <= K) fb = K;
+            JX_LR_BUCKETS(JX_LR_PICK)
+#undef JX_LR_PICK
+            if (fuse && fb && (size_t)(RP / 16) * fb * 64 * sizeof(double) <= JX_LR_LDS_MAX) {
+                std::vector<double> Wk, V0, bc((size_t)nt * JX_COL0_LD, 0.0);
+                jxt::fused_row_operator(ctx->h_L, r, ctx->h_rows, S, cv.o, ctx->h_taps.data(), cv.Ph, cv.Ph, RP, KU, Wk);
+                for (int t = 0; t < nt; ++t)
+                    for (int x = 0; x < nt; ++x) bc[(size_t)t * JX_COL0_LD + x] = c.step * c.step * beam_h[(size_t)(cv.o + t) * B + cv.o + x];
+                jxt::fused_row_operator(ctx->h_L, r, ctx->h_rows, S, cv.o, bc.data(), nt, JX_COL0_LD, RP, KU, V0);
+                double* p2;
+                if ((rc = dev_put(ctx, Wk.data(), Wk.size(), &p2))) return rc;
+                ctx->lrf.U = p2; ctx->lrf.r = r; ctx->lrf.ks = KU / 4; ctx->lrf.KQ = KU; ctx->lrf.nq = cv.NU;
+                if ((rc = dev_put(ctx, V0.data(), V0.size(), &p2))) return rc;
+                ctx->lrf0 = ctx->lrf; ctx->lrf0.U = p2;
+                ctx->fused_bucket = fb; ctx->tKU = KU; ctx->tW = (chunk + 15) & ~15;
+                const size_t tW = ctx->tW, slack_rows = (size_t)4 * fb - KU + 4;
+                if ((rc = dev_new(ctx, ((size_t)cv.Ph * KU + slack_rows) * tW, &ctx->d_Rt, true))) return rc;
+                if ((rc = dev_new(ctx, tW * cv.Ph * 64 + 64, &ctx->d_Ct, true))) return rc;
+                if ((rc = dev_new(ctx, tW * 32 * 64 + 64, &ctx->d_Ct0, true))) return rc;
+                if ((rc = dev_new(ctx, ((size_t)KU + slack_rows) * tW, &ctx->d_x0t, true))) return rc;
+                ctx->cv_f = ctx->cv_lr;
+                ctx->cv_f.tmode = 1; ctx->cv_f.tW = ctx->tW; ctx->cv_f.tKU = KU; ctx->cv_f.ct0 = ctx->d_Ct0;
+            }
+            ctx->h_L.clear(); ctx->h_taps.clear();
         }
 #define JX_ATTR2(LPv, LSv, R1v, R3v) if (cv.LP == LPv && cv.LS == LSv) { \
             constexpr int rs1 = jx_lay<LPv>::RS, rs3 = jx_lay<LPv>::RS > jx_lay<LSv>::RS ? jx_lay<LPv>::RS : jx_lay<LSv>::RS; \
@@ -675,6 +715,8 @@ int jx_finalize(jx_ctx* ctx) {
 
     FFTCHK(ctx, rocfft_execution_info_create(&ctx->info));
     FFTCHK(ctx, rocfft_execution_info_set_stream(ctx->info, ctx->stream));
+    // the zero fills above ran on the null stream, which the context's non-blocking stream does not wait for
+    HIPCHK(ctx, hipDeviceSynchronize());
     ctx->finalized = true;
     return JX_OK;
 }
@@ -717,6 +759,53 @@ struct Taps {
 };
 
 
+// true when this launch takes the fused route (decided before the map kernel: it changes where column 0 is copied to)
+static bool use_fused(const jx_ctx* ctx, const double* tap_convjobs) {
+    return ctx->conv_mode == 2 && ctx->lrf.r > 0 && !tap_convjobs;
+}
+
+// map -> pass 1 (walker-minor rows) -> one GEMM per column (FIR + job combination) -> pass 3 over the combined rows
+static int launch_fused_conv(jx_ctx* ctx, int n, EvSet* es) {
+    const JxConv& cv = ctx->cv;
+    const JxDev& d = ctx->d;
+    hipStream_t st = ctx->stream;
+    JxConv cf = ctx->cv_f;
+    cf.tn = n;
+    bool done = false;
+    const dim3 g1(cv.NU, (n + ctx->p1_rows - 1) / ctx->p1_rows);
+#define JX_P1(LPv, LSv, R1v, R3v) if (!done && cv.LP == LPv && cv.LS == LSv) { \
+        hipLaunchKernelGGL((jx_rowfft2_kernel<LPv, R1v>), g1, dim3(256), ctx->p1_lds, st, cf, ctx->d_img, (size_t)d.img_ld, (size_t)d.img_ws, \
+                           reinterpret_cast<cplx*>(ctx->d_Rt)); done = true; }
+    JX_CONV2_PAIRS(JX_P1)
+#undef JX_P1
+    if (!done) { ctx->err = "no pass-1 kernel for this size"; return JX_ERR_UNSUPPORTED; }
+    if (es) HIPCHK(ctx, hipEventRecord(es->e[3], st));
+    {
+        const JxLowrank& lr = ctx->lrf;
+        const int ntr = (lr.r + 15) / 16, ncols = (n + 15) & ~15, ntile = ncols / 16;
+        const size_t lds = (size_t)ntr * ctx->fused_bucket * 64 * sizeof(double);
+        const long long tW = ctx->tW, KU = ctx->tKU, RP = 16LL * ntr, nt = cv.o + 1;
+        const int gx = std::max(1, (ntile + 15) / 16);                // two tasks per wave: the A tile is loaded once per block
+#define JX_LR_GO(K, T) if (ctx->fused_bucket == K && ntr == T) { \
+            hipLaunchKernelGGL((jx_lowrank_kernel<K, T>), dim3(gx, cv.Ph), dim3(512), lds, st, lr, ctx->d_Rt, 0LL, tW, 1LL, \
+                               ctx->d_Ct, 0LL, 1LL, (long long)cv.Ph * 64, ncols, 1, RP * KU, KU * tW, 64LL); \
+            hipLaunchKernelGGL((jx_lowrank_kernel<K, T>), dim3(gx, (unsigned)nt), dim3(512), lds, st, ctx->lrf0, ctx->d_x0t, 0LL, tW, 1LL, \
+                               ctx->d_Ct0, 0LL, 1LL, 32LL * 64, ncols, 1, RP * KU, 0LL, 64LL); }
+        JX_LR_KINDS(JX_LR_GO)
+#undef JX_LR_GO
+    }
+    ctx->last_nblk3 = cf.nblk3;
+    done = false;
+    const dim3 g3(cf.nblk3, n);
+#define JX_P3(LPv, LSv, R1v, R3v) if (!done && cv.LP == LPv && cv.LS == LSv) { \
+        hipLaunchKernelGGL((jx_rowtf2_kernel<LPv, LSv, R3v>), g3, dim3(256), ctx->p3_lds, st, cf, reinterpret_cast<const cplx*>(ctx->d_Ct), \
+                           ctx->d_part, (double*)nullptr); done = true; }
+    JX_CONV2_PAIRS(JX_P3)
+#undef JX_P3
+    if (es) HIPCHK(ctx, hipEventRecord(es->e[4], st));
+    return JX_OK;
+}
+
 static int launch_custom_conv(jx_ctx* ctx, int n, double* tap_convjobs, EvSet* es) {
     const JxConv& cv = ctx->cv;
     const JxDev& d = ctx->d;
@@ -753,10 +842,10 @@ static int launch_custom_conv(jx_ctx* ctx, int n, double* tap_convjobs, EvSet* e
         const long long ld = cv.fir_ld, nt = cv.o + 1;
 #define JX_LR_GO(K, T) if (ctx->lr_bucket == K && ntr == T) { \
             hipLaunchKernelGGL((jx_lowrank_kernel<K, T>), blocks, dim3(threads), lds, st, lr, reinterpret_cast<const double*>(ctx->d_C), \
-                               (long long)cv.CROWS * ld, ld, 1LL, ctx->d_Clr, (long long)lr.r * ld, ld, 1LL, cv.xsym ? cv.Ph : 2 * cv.Ph, n); \
+                               (long long)cv.CROWS * ld, ld, 1LL, ctx->d_Clr, (long long)lr.r * ld, ld, 1LL, cv.xsym ? cv.Ph : 2 * cv.Ph, n, 0LL, 0LL, 0LL); \
             if (cv.xsym) \
                 hipLaunchKernelGGL((jx_lowrank_kernel<K, T>), blocks, dim3(threads), lds, st, lr, cv.col0, nt * cv.NJ, 1LL, (long long)cv.NJ, \
-                                   ctx->d_col0lr, nt * lr.r, 1LL, (long long)lr.r, (int)nt, n); }
+                                   ctx->d_col0lr, nt * lr.r, 1LL, (long long)lr.r, (int)nt, n, 0LL, 0LL, 0LL); }
         JX_LR_KINDS(JX_LR_GO)
 #undef JX_LR_GO
     }
@@ -799,7 +888,9 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
         const dim3 grid(n * d.map_split), block(ctx->map_threads);
         if (d.fast_map) {
             const size_t sh = ctx->map_lds_bytes;
-#define JX_SYM_LAUNCH(V, NA) hipLaunchKernelGGL((jx_abel_map_sym_kernel<V, NA>), grid, block, sh, st, d, theta_dev, w0, ctx->d_img, t.pp, t.ab, t.y)
+            JxDev dm = d;                                          // fused route: column 0 is copied walker-minor
+            if (use_fused(ctx, t.conv)) { dm.xcol = ctx->d_x0t; dm.xcol_ld = ctx->tW; }
+#define JX_SYM_LAUNCH(V, NA) hipLaunchKernelGGL((jx_abel_map_sym_kernel<V, NA>), grid, block, sh, st, dm, theta_dev, w0, ctx->d_img, t.pp, t.ab, t.y)
             const int nait = (d.q_na + 63) / 64;
             if (vec2) { if (nait <= 3) JX_SYM_LAUNCH(true, 3); else if (nait <= 5) JX_SYM_LAUNCH(true, 5); else JX_SYM_LAUNCH(true, 9); }
             else      { if (nait <= 3) JX_SYM_LAUNCH(false, 3); else if (nait <= 5) JX_SYM_LAUNCH(false, 5); else JX_SYM_LAUNCH(false, 9); }
@@ -834,7 +925,7 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
         if (tm) HIPCHK(ctx, hipEventRecord(es.e[4], st));
     } else {
         const JxConv& cv = ctx->cv;
-        int rc2 = launch_custom_conv(ctx, n, t.conv, tm ? &es : nullptr);
+        int rc2 = use_fused(ctx, t.conv) ? launch_fused_conv(ctx, n, tm ? &es : nullptr) : launch_custom_conv(ctx, n, t.conv, tm ? &es : nullptr);
         if (rc2) return rc2;
         zpart = ctx->d_part;
         nblk = ctx->last_nblk3;
@@ -1059,7 +1150,7 @@ int jx_get_conv_layout(jx_ctx* ctx, int32_t out[12]) {
     const JxConv& cv = ctx->cv;
     out[0] = cv.xsym; out[1] = ctx->d.quad; out[2] = cv.NU; out[3] = cv.NJ; out[4] = cv.fir_ld;
     out[5] = ctx->d.quad ? ctx->d.q_nb : cv.S; out[6] = (int32_t)ctx->d.img_ld; out[7] = cv.P;
-    out[8] = ctx->lr.r; out[9] = out[10] = out[11] = 0;
+    out[8] = ctx->lr.r; out[9] = ctx->lrf.r > 0 ? 1 : 0; out[10] = out[11] = 0;
     return JX_OK;
 }
 
@@ -1076,6 +1167,20 @@ int jx_debug_workspace(jx_ctx* ctx, int which, void** dev, int32_t geom[4]) {
                 *dev = cv.col0; geom[1] = cv.o + 1; geom[2] = cv.NJ; break;
         case 4: *dev = const_cast<int*>(cv.jrow); geom[0] = 1; geom[1] = cv.NJ; geom[2] = 1; break;
         case 5: *dev = const_cast<int*>(cv.umap); geom[0] = 1; geom[1] = cv.S; geom[2] = 1; break;
+        case 10: case 11:
+            if (ctx->lr.r == 0) { ctx->err = "no combined rows in this mode"; return JX_ERR_UNSUPPORTED; }
+            geom[3] = ctx->lr.r;
+            if (which == 10) { *dev = ctx->d_Clr; geom[1] = ctx->lr.r; geom[2] = cv.fir_ld; }
+            else { *dev = ctx->d_col0lr; geom[1] = cv.o + 1; geom[2] = ctx->lr.r; }
+            break;
+        case 6: case 7: case 8: case 9:
+            if (ctx->lrf.r == 0) { ctx->err = "no fused buffers in this mode"; return JX_ERR_UNSUPPORTED; }
+            geom[3] = ctx->lrf.r;
+            if (which == 6) { *dev = ctx->d_Rt; geom[0] = cv.Ph; geom[1] = ctx->tKU; geom[2] = ctx->tW; }
+            if (which == 7) { *dev = ctx->d_Ct; geom[0] = ctx->tW; geom[1] = cv.Ph; geom[2] = 64; }
+            if (which == 8) { *dev = ctx->d_Ct0; geom[0] = ctx->tW; geom[1] = 32; geom[2] = 64; }
+            if (which == 9) { *dev = ctx->d_x0t; geom[0] = 1; geom[1] = ctx->tKU; geom[2] = ctx->tW; }
+            break;
         default: ctx->err = "unknown work buffer"; return JX_ERR_INVALID;
     }
     return JX_OK;

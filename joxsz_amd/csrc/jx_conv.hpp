@@ -55,6 +55,10 @@ struct JxConv {
     int mirror;                     // 1: umap[m] = |m - S/2| (mirror structure), 0: umap[m] = m
     int xsym;                       // 1: map rows are also mirror-symmetric in x: Y and C hold ONE real array per row
     int fir_ld;                     // doubles per row of Y / C: Ph rounded up to 16 (xsym: rows start on cache lines) or 2 Ph
+    // fused FIR + job combination (JxFused): pass 1 writes its rows walker-minor, pass 3 reads rho-minor
+    int tmode;                      // 1: pass 1 -> Rt[k][tKU][tW] (block = distinct row x walker group); pass 3 <- Ct[w][Ph][64], Ct0[w][32][64]
+    int tW, tKU, tn;                // walker stride (multiple of 16), padded distinct-row count, walkers in this launch
+    const double* ct0;              // [tW][32][64] column-0 terms of the combined rows
     int quad;                       // 1: the map arrives as its quadrant [S/2+1][img_ld] of distinct pixels (|iy-c|, |ix-c|)
     const cplx* zab;                // [LP][2] pass-3 pre-process factors: Z[k] = zab[k][0] Rc[k] + zab[k][1] Rc[LP-k]   (xsym)
     const double* bcol;             // [o+1][JX_COL0_LD] step^2 beam[o+t][o+x], zero beyond x = o: what column 0 of a map row adds to output column x  (xsym)
@@ -143,8 +147,10 @@ jx_rowfft2_kernel(JxConv c, const double* __restrict__ img, size_t img_ld, size_
     cplx* twp = tw + LP;                                    // [LP + 1] e^{-2 pi i k / P}
     double* s_x0 = reinterpret_cast<double*>(twp + LP + 1);  // [ROWS] unpaired column 0 of each row (xsym)
     const int tid = threadIdx.x, nth = blockDim.x;
-    const int r0 = blockIdx.x * ROWS, w = blockIdx.y;               // r0: first distinct row u of the block
-    const int nrows = min(ROWS, c.NU - r0), half = c.S / 2;
+    // normal: block = (ROWS distinct rows from r0, walker w).  tmode: block = (distinct row r0, ROWS walkers from w).
+    const int r0 = c.tmode ? blockIdx.x : blockIdx.x * ROWS, w = c.tmode ? blockIdx.y * ROWS : blockIdx.y;
+    const int nrows = c.tmode ? min(ROWS, c.tn - w) : min(ROWS, c.NU - r0), half = c.S / 2;
+    const size_t row_ws = c.tmode ? img_ws : 0, row_ld = c.tmode ? 0 : img_ld;       // what one step in `row` adds to the source address
     // twiddle tables: requested now, stored behind the row loads below (one round trip for everything)
     constexpr int NTW = (LP + 1 + 255) / 256;
     double tw_r[NTW][4];                                             // (scalars: an aggregate copy out of a register array ends up in scratch)
@@ -162,14 +168,14 @@ jx_rowfft2_kernel(JxConv c, const double* __restrict__ img, size_t img_ld, size_
         // LDS slot with coalesced 16-byte loads; columns (2n, 2n+1) are (q[c-2n], q[c-2n-1]) left of the centre and
         // (q[2n-c], q[2n-c+1]) from it on.
         const int npair = (half >> 1) + 1;                            // q[0..c] in pairs (the spare column rides along)
-        const double* qb = img + (size_t)w * img_ws + (size_t)r0 * img_ld;
+        const double* qb = img + (size_t)w * img_ws + (size_t)r0 * img_ld;     // + row * (row_ws + row_ld)
         constexpr int NIT = (ROWS * (LP / 2 + 1) + 255) / 256;         // npair <= LP/2 + 1, blockDim = 256
         const int tot = nrows * npair;
         double2 stg[NIT];
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {                               // every request before the first use
             const int e = min(tid + i * nth, tot - 1), row = e / npair, j = e - row * npair;
-            stg[i] = *reinterpret_cast<const double2*>(qb + (size_t)row * img_ld + 2 * j);
+            stg[i] = *reinterpret_cast<const double2*>(qb + (size_t)row * (row_ws + row_ld) + 2 * j);
         }
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
@@ -191,9 +197,9 @@ jx_rowfft2_kernel(JxConv c, const double* __restrict__ img, size_t img_ld, size_
             }
         }
     } else if (actA) {
-        const int u = r0 + rowA;                                    // == c.urow[u] without the dependent load
+        const int u = c.tmode ? r0 : r0 + rowA;                     // == c.urow[u] without the dependent load
         const int mrow = c.mirror ? ((half + u < c.S) ? half + u : half - u) : u;
-        const double* src = img + (size_t)w * img_ws + (size_t)mrow * img_ld;
+        const double* src = img + (size_t)(c.tmode ? w + rowA : w) * img_ws + (size_t)mrow * img_ld;
 #pragma unroll
         for (int n1 = 0; n1 < L1; ++n1) {
             const int n = n1 * L2 + n2;
@@ -224,6 +230,22 @@ jx_rowfft2_kernel(JxConv c, const double* __restrict__ img, size_t img_ld, size_
     }
     __syncthreads();
     const int Ph = c.Ph;
+    if (c.tmode) {
+        // walker-minor output Rt[k][u][w]: consecutive lanes take consecutive walkers of the same k
+        double* Rt = reinterpret_cast<double*>(Y);
+        for (int e = tid; e < nrows * Ph; e += nth) {
+            const int k = e / nrows, row = e - k * nrows;
+            const cplx zk = M[row * RS + (k == LP ? 0 : k)];
+            const cplx zc = c_conj(M[row * RS + (k == 0 ? 0 : LP - k)]);
+            const cplx s = c_add(zk, zc), d = c_mul(c_sub(zk, zc), twp[k]);
+            const cplx X = make_double2(0.5 * (s.x + d.y), 0.5 * (s.y - d.x));
+            const int j = (k * (c.S >> 1)) % c.P;
+            const cplx t = twp[j <= LP ? j : c.P - j];
+            const double sn = j <= LP ? -t.y : t.y;
+            Rt[((size_t)k * c.tKU + r0) * c.tW + w + row] = (X.x - s_x0[row]) * t.x - X.y * sn;
+        }
+        return;
+    }
     for (int e = tid; e < nrows * Ph; e += nth) {
         const int row = e / Ph, k = e - row * Ph;
         const cplx zk = M[row * RS + (k == LP ? 0 : k)];
@@ -310,7 +332,51 @@ jx_rowtf2_kernel(JxConv c, const cplx* __restrict__ C, cplx* __restrict__ part, 
     const int npre = nrows * LP;
     double* s_s = reinterpret_cast<double*>(tws + LS);               // [ROWS][o + 1] column-0 terms of the block's jobs (xsym)
     constexpr int NSL = (ROWS * JX_XSYM_MAXT + 255) / 256;          // entries of s_s per thread (blockDim = 256)
-    if (c.xsym) {
+    if (c.xsym && c.tmode) {
+        // combined rows arrive rho-minor: Ct[w][k][64], the block's rows r0.. are 16-byte pairs of that last axis.
+        // Work item = (pair (k, LP-k), two rows): NSUB consecutive lanes read the block's rows of one k (a 128-byte line for
+        // 14 rows).  All trips' loads first.
+        const double* Cw = reinterpret_cast<const double*>(C) + (size_t)w * Ph * 64 + r0;
+        const int nt = c.o + 1, ns = nrows * nt;
+        double cz[NSL];
+#pragma unroll
+        for (int u = 0; u < NSL; ++u) {
+            const int e = min(tid + u * nth, ns - 1), row = e / nt, xo = e - row * nt;
+            cz[u] = c.ct0[((size_t)w * 32 + xo) * 64 + r0 + row];
+        }
+        constexpr int HR = (ROWS + 1) / 2;                            // row pairs
+        constexpr int NSUB = HR <= 4 ? 4 : (HR <= 8 ? 8 : (HR <= 16 ? 16 : 32)), LSUB = NSUB == 4 ? 2 : (NSUB == 8 ? 3 : (NSUB == 16 ? 4 : 5));
+        static_assert(HR <= 32, "row pairs of a block share one group of lanes");
+        constexpr int NPAIR = LP / 2 + 1, NTRIP = (NPAIR * NSUB + 255) / 256;
+        double2 ra[NTRIP], rb[NTRIP];
+#pragma unroll
+        for (int i = 0; i < NTRIP; ++i) {
+            const int e = min(tid + i * 256, NPAIR * NSUB - 1), k = e >> LSUB, sub = min(e & (NSUB - 1), HR - 1);
+            ra[i] = *reinterpret_cast<const double2*>(Cw + (size_t)k * 64 + 2 * sub);
+            rb[i] = *reinterpret_cast<const double2*>(Cw + (size_t)(LP - k) * 64 + 2 * sub);
+        }
+#pragma unroll
+        for (int i = 0; i < NTRIP; ++i) {
+            const int e = tid + i * 256, k = e >> LSUB, sub = e & (NSUB - 1);
+            if (e < NPAIR * NSUB && 2 * sub < nrows) {
+                const int kp = LP - k, kq = kp == LP ? 0 : kp;
+                const cplx za1 = c.zab[2 * k], zb1 = c.zab[2 * k + 1], za2 = c.zab[2 * kq], zb2 = c.zab[2 * kq + 1];
+                const int n1a = k / P2, n2a = k - n1a * P2, n1b = kq / P2, n2b = kq - n1b * P2;
+                const double r1[2] = {ra[i].x, ra[i].y}, r2[2] = {rb[i].x, rb[i].y};
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int row = 2 * sub + h;
+                    if (row < nrows) {
+                        M[row * RS + n1a * P2P + n2a] = make_double2(fma(za1.x, r1[h], zb1.x * r2[h]), fma(za1.y, r1[h], zb1.y * r2[h]));
+                        if (kp != k && kp != LP)
+                            M[row * RS + n1b * P2P + n2b] = make_double2(fma(za2.x, r2[h], zb2.x * r1[h]), fma(za2.y, r2[h], zb2.y * r1[h]));
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NSL; ++u) if (tid + u * nth < ns) s_s[tid + u * nth] = cz[u];
+    } else if (c.xsym) {
         // Z[k] = zab[k][0] Rc[k] + zab[k][1] Rc[LP-k], four elements per thread and trip as below
         const int ldr = c.fir_ld;                                    // row stride of the real arrays (Ph rounded up to whole cache lines)
         const double* Rblk = reinterpret_cast<const double*>(C) + ((size_t)w * c.CROWS + r0) * ldr;
@@ -756,13 +822,18 @@ typedef double jx_v4d __attribute__((ext_vector_type(4)));
 template <int KS, int NTR>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 2)))
 jx_lowrank_kernel(JxLowrank lr, const double* __restrict__ B, long long bws, long long bq, long long bj,
-                  double* __restrict__ D, long long dws, long long dr, long long dj, int ncols, int nwalk) {
+                  double* __restrict__ D, long long dws, long long dr, long long dj, int ncols, int nwalk,
+                  long long a_batch, long long b_batch, long long d_batch) {
     extern __shared__ __attribute__((aligned(16))) double s_a[];      // [NTR][KS][64]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
     const int li = lane & 15, lk = lane >> 4;
+    // blockIdx.y = batch: its own A matrix and B / D base (the fused FIR + combination has one matrix per column kx)
+    const double* Ab = lr.U + (size_t)blockIdx.y * a_batch;
+    B += (size_t)blockIdx.y * b_batch;
+    D += (size_t)blockIdx.y * d_batch;
     for (int e = threadIdx.x; e < NTR * KS * 64; e += blockDim.x) {
         const int l = e & 63, s = (e >> 6) % KS, t = (e >> 6) / KS;
-        s_a[e] = (s < lr.ks) ? lr.U[(size_t)(t * 16 + (l & 15)) * lr.KQ + 4 * s + (l >> 4)] : 0.0;
+        s_a[e] = (s < lr.ks) ? Ab[(size_t)(t * 16 + (l & 15)) * lr.KQ + 4 * s + (l >> 4)] : 0.0;
     }
     __syncthreads();
     const double* sa = s_a + lane;
@@ -813,8 +884,9 @@ jx_lowrank_kernel(JxLowrank lr, const double* __restrict__ B, long long bws, lon
         task = next;
     }
 }
-#define JX_LR_BUCKETS(X) X(24) X(40) X(72)
-#define JX_LR_KINDS(X) X(24, 1) X(24, 2) X(24, 3) X(24, 4) X(40, 1) X(40, 2) X(40, 3) X(40, 4) X(72, 1) X(72, 2) X(72, 3) X(72, 4)
+#define JX_LR_BUCKETS(X) X(24) X(40) X(68) X(72)
+#define JX_LR_KINDS(X) X(24, 1) X(24, 2) X(24, 3) X(24, 4) X(40, 1) X(40, 2) X(40, 3) X(40, 4) X(68, 1) X(68, 2) X(68, 3) X(68, 4) \
+    X(72, 1) X(72, 2) X(72, 3) X(72, 4)
 
 // ------------------------------------------------------------------------------------
 // tail of the hand-written path.  One 256-thread block per walker:

@@ -51,7 +51,8 @@ struct JxDev {
     long long img_ld, img_ws;    // row and walker strides (doubles) of the y-map image
     int dbg;                     // timing-only ablations (JOXSZ_DBG): 1 skip phases 1-4, 2 skip phase 5, 4 phase 5 stores only
     int fast_map, q_na, q_nb;    // symmetric-map form: table sizes (|ix-c|, |iy-c|)
-    double* xcol;                // [chunk][q_nb] quad mode: copy of the quadrant's last column (map column 0), contiguous
+    double* xcol;                // quad mode: copy of the quadrant's last column (map column 0): [chunk][q_nb], or walker-minor
+    long long xcol_ld;           //   [q_nb padded][xcol_ld] when xcol_ld > 0 (fused FIR path)
     int quad;                    // 1: the image is the quadrant [q_nb][img_ld] (|iy-c|, |ix-c|) alone, nothing mirrored
     const int* q_k;              // [q_nb*q_na] coefficient slot of each quadrant radius
     const double* q_t;           // [q_nb*q_na] local abscissa within that slot
@@ -620,7 +621,7 @@ jx_abel_map_sym_kernel(JxDev c, const double* __restrict__ theta, int w0, double
             for (int u = 0; u < NAIT; ++u) {
                 const int a = lane + 64 * u;
                 if (a < na) orow[a] = v[u];
-                if (a == na - 1) c.xcol[(size_t)w * nb + b] = v[u];
+                if (a == na - 1) c.xcol[c.xcol_ld > 0 ? (size_t)b * c.xcol_ld + w : (size_t)w * nb + b] = v[u];
             }
         }
         return;

@@ -552,6 +552,41 @@ inline void conv_row_tables(int S, int o, bool mirror, ConvRows& t) {
     t.nseg = (int)t.seg.size() / 3;
 }
 
+// ---------------------------------------------------------------------------------------
+// The FIR along map rows followed by the low-rank combination of the jobs is one linear map per
+// column b (b = kx for the row spectra, b = output column x for the column-0 terms):
+//     Ct[rho][b] = sum_q U[rho][q] sum_{m : |r_q - m| <= o} coef[|r_q - m|][b] R[umap[m]][b]
+//                = sum_u T[b][rho][u] R[u][b],
+//     T[b][rho][u] = sum_q U[rho][q] sum_{m : umap[m] = u, |r_q - m| <= o} coef[|r_q - m|][b].
+// coef is [o+1][ldc] (t major); out is [nb][RP][KU], zero padded (RP >= r rows, KU >= NU columns).
+// ---------------------------------------------------------------------------------------
+inline void fused_row_operator(const std::vector<double>& U /*[r][NJ]*/, int r, const ConvRows& rows, int S, int o,
+                               const double* coef, int nb, int ldc, int RP, int KU, std::vector<double>& out) {
+    const int NJ = rows.NJ, NU = rows.NU;
+    out.assign((size_t)nb * RP * KU, 0.0);
+    std::vector<double> g((size_t)NJ * NU);                          // G[q][u] = sum over the m of (q, u) of coef[|r_q - m|][b]
+    for (int b = 0; b < nb; ++b) {
+        std::fill(g.begin(), g.end(), 0.0);
+        for (int q = 0; q < NJ; ++q) {
+            const int rq = rows.jrow[q];
+            for (int m = std::max(0, rq - o); m <= std::min(S - 1, rq + o); ++m)
+                g[(size_t)q * NU + rows.umap[m]] += coef[(size_t)std::abs(rq - m) * ldc + b];
+        }
+        double* ob = &out[(size_t)b * RP * KU];
+        for (int rho = 0; rho < r; ++rho) {
+            double* orow = ob + (size_t)rho * KU;
+            for (int q = 0; q < NJ; ++q) {
+                const double uq = U[(size_t)rho * NJ + q];
+                const double* gq = &g[(size_t)q * NU];
+                const int rq = rows.jrow[q];                          // only |umap[m]| reachable from r_q are non-zero
+                int ulo = NU, uhi = -1;
+                for (int m = std::max(0, rq - o); m <= std::min(S - 1, rq + o); ++m) { ulo = std::min(ulo, rows.umap[m]); uhi = std::max(uhi, rows.umap[m]); }
+                for (int u = ulo; u <= uhi; ++u) orow[u] += uq * gq[u];
+            }
+        }
+    }
+}
+
 // supported (LS = S/2, LP = P/2) pairs of the hand-written convolution
 inline int custom_conv_lp(int S, int o) {
     static const int pairs[][2] = {{16, 18}, {24, 48}, {32, 48}, {64, 96}, {128, 144}, {256, 288}, {512, 576}};

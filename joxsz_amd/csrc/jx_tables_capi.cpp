@@ -116,6 +116,16 @@ int jxt_lowrank_factor(const double* A, int m, int n, double tol, double* L, dou
     return r;
 }
 
+// fused FIR + job combination: out [nb][RP][KU] (see jx_tables.hpp fused_row_operator); mirror row structure
+int jxt_fused_row_operator(const double* U, int r, int S, int o, int mirror, const double* coef, int nb, int ldc, int RP, int KU, double* out) {
+    jxt::ConvRows rows;
+    jxt::conv_row_tables(S, o, mirror != 0, rows);
+    std::vector<double> u(U, U + (size_t)r * rows.NJ), w;
+    jxt::fused_row_operator(u, r, rows, S, o, coef, nb, ldc, RP, KU, w);
+    std::copy(w.begin(), w.end(), out);
+    return rows.NJ;
+}
+
 int jxt_custom_conv_lp(int S, int o) { return jxt::custom_conv_lp(S, o); }
 
 int jxt_next_smooth_even(int n) { return jxt::next_smooth_even(n); }

@@ -159,7 +159,7 @@ class HipContext:
         if self.conv == 'custom':
             lay = (ctypes.c_int32 * 12)()
             self._chk(self.lib.jx_get_conv_layout(self._h, lay), 'jx_get_conv_layout')
-            self.conv_layout = dict(zip(('xsym', 'quad', 'NU', 'NJ', 'ld', 'img_rows', 'img_ld', 'P', 'rank'), [int(v) for v in lay]))
+            self.conv_layout = dict(zip(('xsym', 'quad', 'NU', 'NJ', 'ld', 'img_rows', 'img_ld', 'P', 'rank', 'fused'), [int(v) for v in lay]))
 
     # -- plumbing --
     def _chk(self, rc, what):
@@ -235,12 +235,13 @@ class HipContext:
 
     def workspace(self, which, walkers=None):
         """Test hook: copy of a work buffer of the hand-written convolution (``jx_debug_workspace``)."""
-        ids = {'y_map': 0, 'row_spectra': 1, 'fir_rows': 2, 'col0': 3, 'job_rows': 4, 'row_index': 5}
+        ids = {'y_map': 0, 'row_spectra': 1, 'fir_rows': 2, 'col0': 3, 'job_rows': 4, 'row_index': 5,
+               'rows_t': 6, 'combined_t': 7, 'combined_col0_t': 8, 'x0_t': 9, 'combined': 10, 'combined_col0': 11}
         ptr = ctypes.c_void_p()
         geom = (ctypes.c_int32 * 4)()
         self._chk(self.lib.jx_debug_workspace(self._h, ids[which], ctypes.byref(ptr), geom), 'jx_debug_workspace')
         n = geom[0] if walkers is None else min(walkers, geom[0])
-        out = np.empty((n, geom[1], geom[2]), np.int32 if ids[which] >= 4 else np.float64)
+        out = np.empty((n, geom[1], geom[2]), np.int32 if ids[which] in (4, 5) else np.float64)
         self.sync()
         self.d2h(out, ptr.value)
         return out, bool(geom[3])

@@ -226,10 +226,12 @@ def test_custom_conv_with_and_without_row_symmetry(monkeypatch):
 
 
 @pytest.mark.parametrize('S,N', [(64, 80), (512, 500)])
-def test_conv_work_buffers_against_numpy(S, N):
+def test_conv_work_buffers_against_numpy(S, N, monkeypatch):
     """Each hand-written pass on its own (jx_debug_workspace): row spectra, FIR output and the
-    column-0 terms against numpy FFTs of the Compton-y map the same evaluation produced."""
+    column-0 terms against numpy FFTs of the Compton-y map the same evaluation produced.  (The route
+    with separate kernels, JOXSZ_FUSED=0: the fused route keeps these intermediates walker-minor.)"""
     from joxsz_amd import datasets
+    monkeypatch.setenv('JOXSZ_FUSED', '0')
     pb = datasets.synthetic_problem(S=S, N=N, seed=5)
     th = datasets.walker_ball(pb, 2, spread=0.03, seed=5)
     post = _post(pb, conv='custom', max_batch=2)
@@ -280,28 +282,35 @@ def test_conv_work_buffers_against_numpy(S, N):
 
 
 def test_lowrank_weights_against_full_weights(monkeypatch):
-    """The transfer-function weights in low-rank form (jobs combined before pass 3, truncation at 1e-13 of the
-    largest singular value) against one pass-3 row per job (JOXSZ_LOWRANK=0), and both against the oracle."""
+    """The transfer-function weights in low-rank form (truncation at 1e-13 of the largest singular value):
+    'fused' = FIR + job combination as one matrix product per column on walker-minor row spectra (default),
+    'lowrank' = FIR kernel, then the combination (JOXSZ_FUSED=0), 'full' = one pass-3 row per job
+    (JOXSZ_LOWRANK=0).  All three against each other and against the oracle; ragged walker counts included."""
     from joxsz_amd import datasets
-    for S, N in ((256, 300), (512, 500)):
+    modes = {'fused': {}, 'lowrank': {'JOXSZ_FUSED': '0'}, 'full': {'JOXSZ_LOWRANK': '0'}}
+    for S, N, nw in ((256, 300, 6), (512, 500, 37)):
         pb = datasets.synthetic_problem(S=S, N=N, seed=11)
-        th = datasets.walker_ball(pb, 6, spread=0.05, seed=11)
+        th = datasets.walker_ball(pb, nw, spread=0.05, seed=11)
         res = {}
-        for mode in ('1', '0'):
-            monkeypatch.setenv('JOXSZ_LOWRANK', mode)
+        for mode, env in modes.items():
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
             post = _post(pb, conv='custom')
-            rank = post.ctx.conv_layout['rank']
-            assert (rank > 0) == (mode == '1') and rank < post.ctx.conv_layout['NJ'] // 2
+            lay = post.ctx.conv_layout
+            assert (lay['rank'] > 0) == (mode != 'full') and lay['rank'] < lay['NJ'] // 2
+            assert bool(lay['fused']) == (mode == 'fused')
             res[mode] = (post.stage(th, 'map_row'), post.stage(th, 'bright'), post.log_prob(th))
             post.close()
-        monkeypatch.delenv('JOXSZ_LOWRANK')
-        for a, b in zip(res['1'][:2], res['0'][:2]):
-            np.testing.assert_allclose(a, b, rtol=1e-10, atol=1e-11 * np.abs(b).max())
-        np.testing.assert_allclose(res['1'][2], res['0'][2], rtol=1e-9)
-        want = orc.log_posterior_batch(pb, th)
-        np.testing.assert_allclose(res['1'][2], want, rtol=RTOL)
+            for k in env:
+                monkeypatch.delenv(k)
+        for mode in ('fused', 'lowrank'):
+            for a, b in zip(res[mode][:2], res['full'][:2]):
+                np.testing.assert_allclose(a, b, rtol=1e-10, atol=1e-11 * np.abs(b).max(), err_msg=mode)
+            np.testing.assert_allclose(res[mode][2], res['full'][2], rtol=1e-9, err_msg=mode)
+        want = orc.log_posterior_batch(pb, th[:8])
+        np.testing.assert_allclose(res['fused'][2][:8], want, rtol=RTOL)
         st = orc.sz_stages(pb, orc.pars_dict(pb, th[0]))
-        assert _relerr(res['1'][0][0], st['map_row']) < RTOL_STAGE
+        assert _relerr(res['fused'][0][0], st['map_row']) < RTOL_STAGE
 
 
 def test_largest_config_shape():

@@ -267,3 +267,28 @@ def test_lowrank_factor(lib):
     r2 = lib.jxt_lowrank_factor(_p(np.ascontiguousarray(A)), m, n, 0.0, _p(L), _p(Rt), _p(sg))
     assert r2 == n
     assert np.abs(L[:r2].T @ Rt[:r2] - A).max() < 1e-13 * np.abs(A).max()
+
+
+def test_fused_row_operator(lib):
+    """FIR along rows + job combination as one matrix per column, against the two steps done one after the other."""
+    S, o, r, nb = 32, 4, 5, 7
+    IP = ctypes.POINTER(ctypes.c_int)
+    umap = np.zeros(S, np.int32); urow = np.zeros(S, np.int32); jrow = np.zeros(S, np.int32); rowjob = np.zeros(S, np.int32)
+    seg = np.zeros(3 * S, np.int32); cnt = np.zeros(3, np.int32)
+    lib.jxt_conv_row_tables(S, o, 1, *[a.ctypes.data_as(IP) for a in (umap, urow, jrow, rowjob, seg, cnt)])
+    NU, NJ = int(cnt[0]), int(cnt[1])
+    rng = np.random.default_rng(2)
+    U = rng.standard_normal((r, NJ)); coef = rng.standard_normal((o + 1, nb)); R = rng.standard_normal((NU, nb))
+    RP, KU = 16, NU + 3
+    out = np.zeros((nb, RP, KU))
+    assert lib.jxt_fused_row_operator(_p(U), r, S, o, 1, _p(coef), nb, nb, RP, KU, _p(out)) == NJ
+    # step by step: FIR per job, then the combination
+    C = np.zeros((NJ, nb))
+    for q in range(NJ):
+        rq = jrow[q]
+        for m in range(max(0, rq - o), min(S - 1, rq + o) + 1):
+            C[q] += coef[abs(rq - m)] * R[umap[m]]
+    want = U @ C                                             # [r][nb]
+    got = np.einsum('bru,ub->rb', out[:, :r, :NU], R)
+    np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-13)
+    assert not out[:, r:].any() and not out[:, :, NU:].any()
