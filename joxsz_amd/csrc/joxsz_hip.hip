@@ -785,12 +785,12 @@ static int launch_fused_conv(jx_ctx* ctx, int n, EvSet* es) {
         const int ntr = (lr.r + 15) / 16, ncols = (n + 15) & ~15, ntile = ncols / 16;
         const size_t lds = (size_t)ntr * ctx->fused_bucket * 64 * sizeof(double);
         const long long tW = ctx->tW, KU = ctx->tKU, RP = 16LL * ntr, nt = cv.o + 1;
-        const int gx = std::max(1, (ntile + 15) / 16);                // two tasks per wave: the A tile is loaded once per block
+        (void)ntile;
 #define JX_LR_GO(K, T) if (ctx->fused_bucket == K && ntr == T) { \
-            hipLaunchKernelGGL((jx_lowrank_kernel<K, T>), dim3(gx, cv.Ph), dim3(512), lds, st, lr, ctx->d_Rt, 0LL, tW, 1LL, \
-                               ctx->d_Ct, 0LL, 1LL, (long long)cv.Ph * 64, ncols, 1, RP * KU, KU * tW, 64LL); \
-            hipLaunchKernelGGL((jx_lowrank_kernel<K, T>), dim3(gx, (unsigned)nt), dim3(512), lds, st, ctx->lrf0, ctx->d_x0t, 0LL, tW, 1LL, \
-                               ctx->d_Ct0, 0LL, 1LL, 32LL * 64, ncols, 1, RP * KU, 0LL, 64LL); }
+            hipLaunchKernelGGL((jx_lowrank_kernel<K, T>), dim3(ctx->num_cu), dim3(512), lds, st, lr, ctx->d_Rt, 0LL, tW, 1LL, \
+                               ctx->d_Ct, 0LL, 1LL, (long long)cv.Ph * 64, ncols, 1, cv.Ph, RP * KU, KU * tW, 64LL); \
+            hipLaunchKernelGGL((jx_lowrank_kernel<K, T>), dim3(ctx->num_cu), dim3(512), lds, st, ctx->lrf0, ctx->d_x0t, 0LL, tW, 1LL, \
+                               ctx->d_Ct0, 0LL, 1LL, 32LL * 64, ncols, 1, (int)nt, RP * KU, 0LL, 64LL); }
         JX_LR_KINDS(JX_LR_GO)
 #undef JX_LR_GO
     }
@@ -842,10 +842,10 @@ static int launch_custom_conv(jx_ctx* ctx, int n, double* tap_convjobs, EvSet* e
         const long long ld = cv.fir_ld, nt = cv.o + 1;
 #define JX_LR_GO(K, T) if (ctx->lr_bucket == K && ntr == T) { \
             hipLaunchKernelGGL((jx_lowrank_kernel<K, T>), blocks, dim3(threads), lds, st, lr, reinterpret_cast<const double*>(ctx->d_C), \
-                               (long long)cv.CROWS * ld, ld, 1LL, ctx->d_Clr, (long long)lr.r * ld, ld, 1LL, cv.xsym ? cv.Ph : 2 * cv.Ph, n, 0LL, 0LL, 0LL); \
+                               (long long)cv.CROWS * ld, ld, 1LL, ctx->d_Clr, (long long)lr.r * ld, ld, 1LL, cv.xsym ? cv.Ph : 2 * cv.Ph, n, 1, 0LL, 0LL, 0LL); \
             if (cv.xsym) \
                 hipLaunchKernelGGL((jx_lowrank_kernel<K, T>), blocks, dim3(threads), lds, st, lr, cv.col0, nt * cv.NJ, 1LL, (long long)cv.NJ, \
-                                   ctx->d_col0lr, nt * lr.r, 1LL, (long long)lr.r, (int)nt, n, 0LL, 0LL, 0LL); }
+                                   ctx->d_col0lr, nt * lr.r, 1LL, (long long)lr.r, (int)nt, n, 1, 0LL, 0LL, 0LL); }
         JX_LR_KINDS(JX_LR_GO)
 #undef JX_LR_GO
     }

@@ -817,71 +817,75 @@ struct JxLowrank {
 typedef double jx_v4d __attribute__((ext_vector_type(4)));
 
 // One wave per column tile, all NTR rho tiles of it (NTR accumulators): every B value is requested once per CU, its NTR
-// A fragments come from LDS (fragment order [tile][k-step][lane]).  KS = k-steps compiled in (>= lr.ks, the U fragments
-// beyond lr.ks are zero): no branch inside the load and MFMA sequences.  No barrier inside the task loop.
+// A fragments come from LDS (fragment order [tile][k-step][lane]).  KS = k-steps compiled in (>= lr.ks, the A fragments
+// beyond lr.ks are zero): no branch inside the load and MFMA sequences, no barrier between the tasks of one A tile.
 template <int KS, int NTR>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 2)))
 jx_lowrank_kernel(JxLowrank lr, const double* __restrict__ B, long long bws, long long bq, long long bj,
                   double* __restrict__ D, long long dws, long long dr, long long dj, int ncols, int nwalk,
-                  long long a_batch, long long b_batch, long long d_batch) {
+                  int nbatch, long long a_batch, long long b_batch, long long d_batch) {
     extern __shared__ __attribute__((aligned(16))) double s_a[];      // [NTR][KS][64]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
     const int li = lane & 15, lk = lane >> 4;
-    // blockIdx.y = batch: its own A matrix and B / D base (the fused FIR + combination has one matrix per column kx)
-    const double* Ab = lr.U + (size_t)blockIdx.y * a_batch;
-    B += (size_t)blockIdx.y * b_batch;
-    D += (size_t)blockIdx.y * d_batch;
-    for (int e = threadIdx.x; e < NTR * KS * 64; e += blockDim.x) {
-        const int l = e & 63, s = (e >> 6) % KS, t = (e >> 6) / KS;
-        s_a[e] = (s < lr.ks) ? Ab[(size_t)(t * 16 + (l & 15)) * lr.KQ + 4 * s + (l >> 4)] : 0.0;
-    }
-    __syncthreads();
     const double* sa = s_a + lane;
-    const int ntile = (ncols + 15) >> 4, ntask = ntile * nwalk, stride = gridDim.x * nwave;
+    // Work: batches (each with its own A matrix and B / D base: the fused FIR + combination has one per column kx) of
+    // units (walker, 16-column tile); a group = nwave consecutive units of one batch, one per wave.  Persistent blocks
+    // take CONTIGUOUS ranges of groups, so a block changes its A tile (refill of the LDS copy, two barriers) rarely.
+    const int ntile = (ncols + 15) >> 4, nunit = ntile * nwalk, gpb = (nunit + nwave - 1) / nwave;
+    const long long G = (long long)nbatch * gpb;
+    const int g0 = (int)(G * blockIdx.x / gridDim.x), g1 = (int)(G * (blockIdx.x + 1) / gridDim.x);
+    if (g0 >= g1) return;
     const long long step = 4 * bq;
-    // B rows 4 s + lk, s < KS.  Rows past the last job are read too (U = 0 there): the caller keeps 4 KS rows behind every
-    // walker allocated and finite.  Each B register is refilled with the row half a task ahead (this task's or the next
-    // one's) right after its MFMAs: a value is requested KS/2 k-steps before it is used.
-    auto bptr = [&](int task) {
-        const int w = task / ntile, jt = task - w * ntile;
-        return B + (size_t)w * bws + (size_t)min(jt * 16 + li, ncols - 1) * bj + (size_t)lk * bq;
+    // B rows 4 s + lk, s < KS.  Rows past the last one are read too (A = 0 there): the caller keeps 4 KS rows behind every
+    // B block allocated and finite.  Each B register is refilled with the row half a task ahead (this task's or the next
+    // one's) right after its MFMAs: a value is requested H k-steps before it is used.
+    auto bptr = [&](int g) {
+        const int batch = g / gpb, unit = min((g - batch * gpb) * nwave + wave, nunit - 1);
+        const int w = unit / ntile, jt = unit - w * ntile;
+        return B + (size_t)batch * b_batch + (size_t)w * bws + (size_t)min(jt * 16 + li, ncols - 1) * bj + (size_t)lk * bq;
     };
-    int task = blockIdx.x * nwave + wave;
-    if (task >= ntask) return;
-    constexpr int H = KS / 2;                                         // B values in flight: half a task
+    constexpr int H = (KS % 4 == 0 && KS / 4 >= 12) ? KS / 4 : KS / 2;   // B values in flight (must divide KS): >= 12 k-steps ahead
     double b[H];
-    const double* pb = bptr(task);
+    const double* pb = bptr(g0);
 #pragma unroll
     for (int u = 0; u < H; ++u) b[u] = pb[u * step];
-    while (task < ntask) {
-        const int next = task + stride;
-        const double* pbn = bptr(min(next, ntask - 1));                // past the end: a valid address, never used
+    int cur = -1;
+    for (int g = g0; g < g1; ++g) {
+        const int batch = g / gpb;
+        if (batch != cur) {                                           // block-uniform
+            if (cur >= 0) __syncthreads();                            // every wave is done with the old tile
+            const double* Ab = lr.U + (size_t)batch * a_batch;
+            for (int e = threadIdx.x; e < NTR * KS * 64; e += blockDim.x) {
+                const int l = e & 63, s = (e >> 6) % KS, t = (e >> 6) / KS;
+                s_a[e] = (s < lr.ks) ? Ab[(size_t)(t * 16 + (l & 15)) * lr.KQ + 4 * s + (l >> 4)] : 0.0;
+            }
+            __syncthreads();
+            cur = batch;
+        }
+        const double* pbn = bptr(min(g + 1, g1 - 1));                  // past the end: a valid address, never used
         jx_v4d acc[NTR];
 #pragma unroll
         for (int t = 0; t < NTR; ++t) acc[t] = jx_v4d{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int u = 0; u < KS; ++u) {
 #pragma unroll
-#ifndef JX_LR_DBG
-#define JX_LR_DBG 0
-#endif
-            for (int t = 0; t < NTR; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64((JX_LR_DBG & 2) ? 1.5 : sa[(t * KS + u) * 64], b[u % H], acc[t], 0, 0, 0);
-            if (!(JX_LR_DBG & 1)) b[u % H] = (u + H < KS) ? pb[(u + H) * step] : pbn[(u + H - KS) * step];
+            for (int t = 0; t < NTR; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[(t * KS + u) * 64], b[u % H], acc[t], 0, 0, 0);
+            b[u % H] = (u + H < KS) ? pb[(u + H) * step] : pbn[(u + H - KS) * step];
             if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // keep the LDS reads of later groups where they are
         }
         pb = pbn;
-        const int w = task / ntile, jt = task - w * ntile;
-        if (jt * 16 + li < ncols) {
-            double* Dp = D + (size_t)w * dws + (size_t)(jt * 16 + li) * dj;
+        const int unit = (g - batch * gpb) * nwave + wave;
+        const int w = unit / ntile, jt = unit - w * ntile;
+        if (unit < nunit && jt * 16 + li < ncols) {
+            double* Dp = D + (size_t)batch * d_batch + (size_t)w * dws + (size_t)(jt * 16 + li) * dj;
 #pragma unroll
             for (int t = 0; t < NTR; ++t)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int rho = t * 16 + lk + 4 * g;
-                    if (rho < lr.r) Dp[(size_t)rho * dr] = acc[t][g];
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int rho = t * 16 + lk + 4 * gq;
+                    if (rho < lr.r) Dp[(size_t)rho * dr] = acc[t][gq];
                 }
         }
-        task = next;
     }
 }
 #define JX_LR_BUCKETS(X) X(24) X(40) X(68) X(72)
