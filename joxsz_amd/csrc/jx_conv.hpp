@@ -844,11 +844,19 @@ jx_lowrank_kernel(JxLowrank lr, const double* __restrict__ B, long long bws, lon
         const int w = unit / ntile, jt = unit - w * ntile;
         return B + (size_t)batch * b_batch + (size_t)w * bws + (size_t)min(jt * 16 + li, ncols - 1) * bj + (size_t)lk * bq;
     };
-    constexpr int H = (KS % 4 == 0 && KS / 4 >= 12) ? KS / 4 : KS / 2;   // B values in flight (must divide KS): >= 12 k-steps ahead
-    double b[H];
-    const double* pb = bptr(g0);
+    // one LDS base per rho tile: the k-step offsets then fit the 16-bit immediate of ds_read (a single base would need an
+    // address register for every (tile, step) past 64 KB)
+    int sat[NTR];                                                    // element offsets into s_a
 #pragma unroll
-    for (int u = 0; u < H; ++u) b[u] = pb[u * step];
+    for (int t = 0; t < NTR; ++t) {
+        sat[t] = lane + t * KS * 64;
+        asm volatile("" : "+v"(sat[t]));                              // opaque: keeps the bases apart
+    }
+    constexpr int H = KS / 2;                                         // B values in flight (must divide KS): half a task ahead
+    double b[H];
+    const double* pl = bptr(g0);                                       // running load pointer (no table of row addresses in registers)
+#pragma unroll
+    for (int u = 0; u < H; ++u) { b[u] = *pl; pl += step; }
     int cur = -1;
     for (int g = g0; g < g1; ++g) {
         const int batch = g / gpb;
@@ -866,14 +874,25 @@ jx_lowrank_kernel(JxLowrank lr, const double* __restrict__ B, long long bws, lon
         jx_v4d acc[NTR];
 #pragma unroll
         for (int t = 0; t < NTR; ++t) acc[t] = jx_v4d{0.0, 0.0, 0.0, 0.0};
+        // A fragments: the next step's NTR values are read from LDS while this step's MFMAs run (explicit two-deep buffer;
+        // left to itself the scheduler hoists whole groups of reads and spills)
+        double ac[NTR], an[NTR];
+#pragma unroll
+        for (int t = 0; t < NTR; ++t) ac[t] = s_a[sat[t]];
 #pragma unroll
         for (int u = 0; u < KS; ++u) {
+            if (u + 1 < KS) {
 #pragma unroll
-            for (int t = 0; t < NTR; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[(t * KS + u) * 64], b[u % H], acc[t], 0, 0, 0);
-            b[u % H] = (u + H < KS) ? pb[(u + H) * step] : pbn[(u + H - KS) * step];
-            if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // keep the LDS reads of later groups where they are
+                for (int t = 0; t < NTR; ++t) an[t] = s_a[sat[t] + (u + 1) * 64];
+            }
+#pragma unroll
+            for (int t = 0; t < NTR; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[t], b[u % H], acc[t], 0, 0, 0);
+            if (u + H == KS) pl = pbn;                               // the ring moves on to the next task's rows
+            b[u % H] = *pl; pl += step;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < NTR; ++t) ac[t] = an[t];
         }
-        pb = pbn;
         const int unit = (g - batch * gpb) * nwave + wave;
         const int w = unit / ntile, jt = unit - w * ntile;
         if (unit < nunit && jt * 16 + li < ncols) {
