@@ -109,6 +109,26 @@ __device__ __forceinline__ double jx_ne(const double* p, double r, int mode) {
     return sqrt(res);
 }
 
+// the same density with its radius-independent factors (five pow() of parameters only) taken out of the per-radius
+// loops: pc = {n0^2, rc, rs, n02^2, rc2}
+__device__ __forceinline__ void jx_ne_consts(const double* p, int mode, double* pc) {
+    const double n0 = pow(10.0, p[P_LOGN0]);
+    pc[0] = n0 * n0; pc[1] = pow(10.0, p[P_LOGRC]); pc[2] = pow(10.0, p[P_LOGRS]);
+    const double n02 = (mode == 1) ? pow(10.0, p[P_LOGN02]) : 0.0;
+    pc[3] = n02 * n02; pc[4] = (mode == 1) ? pow(10.0, p[P_LOGRC2]) : 1.0;
+}
+__device__ __forceinline__ double jx_ne_pc(const double* p, const double* pc, double r, int mode) {
+    const double x = r / pc[1];
+    double res = pc[0] * pow(x, -p[P_ALPHA]) /
+                 (pow(1.0 + x * x, 3.0 * p[P_BETA] - p[P_ALPHA] / 2.0) *
+                  pow(1.0 + pow(r / pc[2], p[P_GAMMA]), p[P_EPS] / p[P_GAMMA]));
+    if (mode == 1) {
+        const double x2 = r / pc[4];
+        res += pc[3] / pow(1.0 + x2 * x2, 3.0 * p[P_BETA2]);
+    }
+    return sqrt(res);
+}
+
 // linear interp1d with fill_value='extrapolate' (joxsz_main.py:109)
 __device__ __forceinline__ double jx_convert(const JxDev& c, double T) {
     int hi = 1;
@@ -186,6 +206,8 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
     double* s_rate = s_T + c.nann;            // [nband*nann]
 
     jx_load_params(c, theta, gw, p);
+    double pc[5];                             // radius-independent factors of the density (every thread its own copy)
+    jx_ne_consts(p, c.ne_mode, pc);
 
     // ---- priors on every parameter (joxsz_funcs.py:518) ----
     double pr = 0.0;
@@ -212,7 +234,7 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
         for (int i = tid; i < c.N; i += nth) {
             const double r = c.r_pp[i];
             // positive constant factors of mass_fun cannot change the sign test
-            s_m[i] = -jx_press_deriv(p, r) * r * r / jx_ne(p, r, c.ne_mode);
+            s_m[i] = -jx_press_deriv(p, r) * r * r / jx_ne_pc(p, pc, r, c.ne_mode);
         }
         __syncthreads();
         for (int i = tid; i < c.N; i += nth) {
@@ -230,7 +252,7 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
     double part = 0.0;
     for (int k = tid; k < c.nt; k += nth) {
         const double r = c.r_pp[k];
-        const double t = jx_press(p, r) / jx_ne(p, r, c.ne_mode);
+        const double t = jx_press(p, r) / jx_ne_pc(p, pc, r, c.ne_mode);
         s_t[k] = t;
         part += c.hw[k] * t;
     }
@@ -246,9 +268,9 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
     double xlike = 0.0;
     if (!c.sz_only) {
         if (tid < c.nann) {
-            s_ne[tid] = jx_ne(p, c.x_r_ne[tid], c.ne_mode);
+            s_ne[tid] = jx_ne_pc(p, pc, c.x_r_ne[tid], c.ne_mode);
             const double r = c.x_r_T[tid];
-            s_T[tid] = jx_press(p, r) / jx_ne(p, r, c.ne_mode) * pow(10.0, p[P_LOGTR]);   // T_X
+            s_T[tid] = jx_press(p, r) / jx_ne_pc(p, pc, r, c.ne_mode) * pow(10.0, p[P_LOGTR]);   // T_X
         }
         __syncthreads();
         const int nba = c.nband * c.nann;
