@@ -612,10 +612,10 @@ int jx_finalize(jx_ctx* ctx) {
     // ---- chunk capacity and work buffers
     const size_t per_walker = (ctx->conv_mode == 1)
         ? sizeof(double) * ((size_t)P * P * 2 + (size_t)P * ctx->Ph * 2 + (size_t)S * ctx->Sh * 2)
-        : sizeof(double) * ((d.quad ? (size_t)d.q_nb * (d.q_na + 3) : (size_t)S * S) + (size_t)(ctx->cv.NU + ctx->cv.CROWS) * ctx->cv.fir_ld + (size_t)ctx->cv.NJ * 28 + (size_t)ctx->cv.nblk3 * ctx->Sh * 2);
+        : sizeof(double) * ((d.quad ? (size_t)d.q_nb * (d.q_na + 16) : (size_t)S * S) + (size_t)(ctx->cv.NU + ctx->cv.CROWS) * ctx->cv.fir_ld + (size_t)ctx->cv.NJ * 28 + (size_t)ctx->cv.nblk3 * ctx->Sh * 2);
     d.img_ld = (ctx->conv_mode == 1) ? P : S;
     d.img_ws = (ctx->conv_mode == 1) ? (long long)P * P : (long long)S * S;
-    if (d.quad) { d.img_ld = (d.q_na + 3) & ~1; d.img_ws = (long long)d.q_nb * d.img_ld; }     // even stride, >= 1 spare column
+    if (d.quad) { d.img_ld = (d.q_na + 16) & ~15; d.img_ws = (long long)d.q_nb * d.img_ld; }   // rows start on cache lines, >= 1 spare column
     int chunk = c.max_batch > 0 ? c.max_batch : 1024;   // >= 4 map blocks per CU: launches desynchronise, stores overlap compute
     if (const char* e = getenv("JOXSZ_CHUNK")) { int v = atoi(e); if (v > 0) chunk = v; }
     const size_t budget = (size_t)24 << 30;
