@@ -786,11 +786,11 @@ static int launch_fused_conv(jx_ctx* ctx, int n, EvSet* es) {
         const size_t lds = (size_t)ntr * ctx->fused_bucket * 64 * sizeof(double);
         const long long tW = ctx->tW, KU = ctx->tKU, RP = 16LL * ntr, nt = cv.o + 1;
         (void)ntile;
-#define JX_LR_GO(K, T) if (ctx->fused_bucket == K && ntr == T) { \
-            hipLaunchKernelGGL((jx_lowrank_kernel<K, T>), dim3(ctx->num_cu), dim3(512), lds, st, lr, ctx->d_Rt, 0LL, tW, 1LL, \
-                               ctx->d_Ct, 0LL, 1LL, (long long)cv.Ph * 64, ncols, 1, cv.Ph, RP * KU, KU * tW, 64LL); \
-            hipLaunchKernelGGL((jx_lowrank_kernel<K, T>), dim3(ctx->num_cu), dim3(512), lds, st, ctx->lrf0, ctx->d_x0t, 0LL, tW, 1LL, \
-                               ctx->d_Ct0, 0LL, 1LL, 32LL * 64, ncols, 1, (int)nt, RP * KU, 0LL, 64LL); }
+        // one launch: the kx batches of the row spectra, then the output-column batches of the column-0 terms
+        const JxGemmSeg s0{lr.U, ctx->d_Rt, ctx->d_Ct, RP * KU, KU * tW, 64LL, (long long)cv.Ph * 64, cv.Ph};
+        const JxGemmSeg s1{ctx->lrf0.U, ctx->d_x0t, ctx->d_Ct0, RP * KU, 0LL, 64LL, 32LL * 64, (int)nt};
+#define JX_LR_GO(K, T) if (ctx->fused_bucket == K && ntr == T) \
+            hipLaunchKernelGGL((jx_lowrank_kernel<K, T>), dim3(ctx->num_cu), dim3(512), lds, st, lr, s0, s1, 0LL, tW, 1LL, 0LL, 1LL, ncols, 1);
         JX_LR_KINDS(JX_LR_GO)
 #undef JX_LR_GO
     }
@@ -840,12 +840,15 @@ static int launch_custom_conv(jx_ctx* ctx, int n, double* tap_convjobs, EvSet* e
         const size_t lds = (size_t)ntr * ctx->lr_bucket * 64 * sizeof(double);
         const dim3 blocks(ctx->num_cu);
         const long long ld = cv.fir_ld, nt = cv.o + 1;
+        const JxGemmSeg none{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0};
+        const JxGemmSeg sr{lr.U, reinterpret_cast<const double*>(ctx->d_C), ctx->d_Clr, 0, 0, 0, 1LL, 1};
+        const JxGemmSeg sc{lr.U, cv.col0, ctx->d_col0lr, 0, 0, 0, (long long)lr.r, 1};
 #define JX_LR_GO(K, T) if (ctx->lr_bucket == K && ntr == T) { \
-            hipLaunchKernelGGL((jx_lowrank_kernel<K, T>), blocks, dim3(threads), lds, st, lr, reinterpret_cast<const double*>(ctx->d_C), \
-                               (long long)cv.CROWS * ld, ld, 1LL, ctx->d_Clr, (long long)lr.r * ld, ld, 1LL, cv.xsym ? cv.Ph : 2 * cv.Ph, n, 1, 0LL, 0LL, 0LL); \
+            hipLaunchKernelGGL((jx_lowrank_kernel<K, T>), blocks, dim3(threads), lds, st, lr, sr, none, (long long)cv.CROWS * ld, ld, 1LL, \
+                               (long long)lr.r * ld, ld, cv.xsym ? cv.Ph : 2 * cv.Ph, n); \
             if (cv.xsym) \
-                hipLaunchKernelGGL((jx_lowrank_kernel<K, T>), blocks, dim3(threads), lds, st, lr, cv.col0, nt * cv.NJ, 1LL, (long long)cv.NJ, \
-                                   ctx->d_col0lr, nt * lr.r, 1LL, (long long)lr.r, (int)nt, n, 1, 0LL, 0LL, 0LL); }
+                hipLaunchKernelGGL((jx_lowrank_kernel<K, T>), blocks, dim3(threads), lds, st, lr, sc, none, nt * cv.NJ, 1LL, (long long)cv.NJ, \
+                                   nt * lr.r, 1LL, (int)nt, n); }
         JX_LR_KINDS(JX_LR_GO)
 #undef JX_LR_GO
     }

@@ -809,8 +809,13 @@ jx_beamfir_reg_kernel(JxConv c, const int* __restrict__ runs, int nrun, int nwal
 // ------------------------------------------------------------------------------------
 #define JX_LR_KS 72                 // k-steps per task, B values of all of them in flight at once: jobs <= 4 * JX_LR_KS
 #define JX_LR_LDS_MAX (150 * 1024)  // the U fragments of every rho tile live in LDS
+struct JxGemmSeg {                  // one run of batches of the GEMM kernel: matrices, operands, results and their strides
+    const double* A; const double* B; double* D;
+    long long a_batch, b_batch, d_batch, dj;                          // per-batch steps; step between result columns
+    int nbatch;
+};
 struct JxLowrank {
-    const double* U;                // [RP][KQ] sigma u, zero padded (RP multiple of 16, KQ = 4 ks)
+    const double* U;                // [RP][KQ] sigma u, zero padded (RP multiple of 16, KQ = 4 ks) -- host-side handle, the kernel takes JxGemmSeg
     int r, ks, KQ, nq;              // rank, k-steps, padded and true job count
 };
 
@@ -821,9 +826,8 @@ typedef double jx_v4d __attribute__((ext_vector_type(4)));
 // beyond lr.ks are zero): no branch inside the load and MFMA sequences, no barrier between the tasks of one A tile.
 template <int KS, int NTR>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 2)))
-jx_lowrank_kernel(JxLowrank lr, const double* __restrict__ B, long long bws, long long bq, long long bj,
-                  double* __restrict__ D, long long dws, long long dr, long long dj, int ncols, int nwalk,
-                  int nbatch, long long a_batch, long long b_batch, long long d_batch) {
+jx_lowrank_kernel(JxLowrank lr, JxGemmSeg sg0, JxGemmSeg sg1, long long bws, long long bq, long long bj,
+                  long long dws, long long dr, int ncols, int nwalk) {
     extern __shared__ __attribute__((aligned(16))) double s_a[];      // [NTR][KS][64]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
     const int li = lane & 15, lk = lane >> 4;
@@ -832,6 +836,7 @@ jx_lowrank_kernel(JxLowrank lr, const double* __restrict__ B, long long bws, lon
     // units (walker, 16-column tile); a group = nwave consecutive units of one batch, one per wave.  Persistent blocks
     // take CONTIGUOUS ranges of groups, so a block changes its A tile (refill of the LDS copy, two barriers) rarely.
     const int ntile = (ncols + 15) >> 4, nunit = ntile * nwalk, gpb = (nunit + nwave - 1) / nwave;
+    const int nbatch = sg0.nbatch + sg1.nbatch;                       // batches of the second segment follow the first's
     const long long G = (long long)nbatch * gpb;
     const int g0 = (int)(G * blockIdx.x / gridDim.x), g1 = (int)(G * (blockIdx.x + 1) / gridDim.x);
     if (g0 >= g1) return;
@@ -842,7 +847,9 @@ jx_lowrank_kernel(JxLowrank lr, const double* __restrict__ B, long long bws, lon
     auto bptr = [&](int g) {
         const int batch = g / gpb, unit = min((g - batch * gpb) * nwave + wave, nunit - 1);
         const int w = unit / ntile, jt = unit - w * ntile;
-        return B + (size_t)batch * b_batch + (size_t)w * bws + (size_t)min(jt * 16 + li, ncols - 1) * bj + (size_t)lk * bq;
+        const bool second = batch >= sg0.nbatch;                      // wave-uniform
+        const double* Bb = second ? sg1.B + (size_t)(batch - sg0.nbatch) * sg1.b_batch : sg0.B + (size_t)batch * sg0.b_batch;
+        return Bb + (size_t)w * bws + (size_t)min(jt * 16 + li, ncols - 1) * bj + (size_t)lk * bq;
     };
     // one LDS base per rho tile: the k-step offsets then fit the 16-bit immediate of ds_read (a single base would need an
     // address register for every (tile, step) past 64 KB)
@@ -862,7 +869,7 @@ jx_lowrank_kernel(JxLowrank lr, const double* __restrict__ B, long long bws, lon
         const int batch = g / gpb;
         if (batch != cur) {                                           // block-uniform
             if (cur >= 0) __syncthreads();                            // every wave is done with the old tile
-            const double* Ab = lr.U + (size_t)batch * a_batch;
+            const double* Ab = batch >= sg0.nbatch ? sg1.A + (size_t)(batch - sg0.nbatch) * sg1.a_batch : sg0.A + (size_t)batch * sg0.a_batch;
             for (int e = threadIdx.x; e < NTR * KS * 64; e += blockDim.x) {
                 const int l = e & 63, s = (e >> 6) % KS, t = (e >> 6) / KS;
                 s_a[e] = (s < lr.ks) ? Ab[(size_t)(t * 16 + (l & 15)) * lr.KQ + 4 * s + (l >> 4)] : 0.0;
@@ -896,7 +903,9 @@ jx_lowrank_kernel(JxLowrank lr, const double* __restrict__ B, long long bws, lon
         const int unit = (g - batch * gpb) * nwave + wave;
         const int w = unit / ntile, jt = unit - w * ntile;
         if (unit < nunit && jt * 16 + li < ncols) {
-            double* Dp = D + (size_t)batch * d_batch + (size_t)w * dws + (size_t)(jt * 16 + li) * dj;
+            const bool second = batch >= sg0.nbatch;
+            double* Dp = (second ? sg1.D + (size_t)(batch - sg0.nbatch) * sg1.d_batch : sg0.D + (size_t)batch * sg0.d_batch)
+                         + (size_t)w * dws + (size_t)(jt * 16 + li) * (second ? sg1.dj : sg0.dj);
 #pragma unroll
             for (int t = 0; t < NTR; ++t)
 #pragma unroll
