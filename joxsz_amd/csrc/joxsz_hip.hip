@@ -927,7 +927,6 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
         }
         if (tm) HIPCHK(ctx, hipEventRecord(es.e[4], st));
     } else {
-        const JxConv& cv = ctx->cv;
         int rc2 = use_fused(ctx, t.conv) ? launch_fused_conv(ctx, n, tm ? &es : nullptr) : launch_custom_conv(ctx, n, t.conv, tm ? &es : nullptr);
         if (rc2) return rc2;
         zpart = ctx->d_part;

@@ -831,7 +831,6 @@ jx_lowrank_kernel(JxLowrank lr, JxGemmSeg sg0, JxGemmSeg sg1, long long bws, lon
     extern __shared__ __attribute__((aligned(16))) double s_a[];      // [NTR][KS][64]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
     const int li = lane & 15, lk = lane >> 4;
-    const double* sa = s_a + lane;
     // Work: batches (each with its own A matrix and B / D base: the fused FIR + combination has one per column kx) of
     // units (walker, 16-column tile); a group = nwave consecutive units of one batch, one per wave.  Persistent blocks
     // take CONTIGUOUS ranges of groups, so a block changes its A tile (refill of the LDS copy, two barriers) rarely.
