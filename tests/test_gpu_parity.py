@@ -313,6 +313,31 @@ def test_lowrank_weights_against_full_weights(monkeypatch):
         assert _relerr(res['fused'][0][0], st['map_row']) < RTOL_STAGE
 
 
+def test_rough_transfer_function_falls_back_to_one_row_per_job():
+    """A transfer function whose weights are not low-rank (here: multiplied by uncorrelated noise, symmetrised) must
+    switch the low-rank / fused routes off by itself and still match the oracle."""
+    from joxsz_amd import datasets
+    pb = datasets.synthetic_problem(S=128, N=150, seed=21)
+    rng = np.random.default_rng(21)
+    noise = 1.0 + 0.5 * rng.random((pb.S, pb.S))
+    idx = (-np.arange(pb.S)) % pb.S
+    noise = 0.5 * (noise + noise[idx][:, idx])               # keep the filter symmetric under k -> -k (real weights)
+    pb.filtering = np.ascontiguousarray(pb.filtering * noise)
+    th = datasets.walker_ball(pb, 5, spread=0.04, seed=21)
+    post = _post(pb, conv='custom')
+    lay = post.ctx.conv_layout
+    assert lay['rank'] == 0 and lay['fused'] == 0 and lay['xsym'] == 1
+    got = post.log_prob(th)
+    row = post.stage(th[:1], 'map_row')[0]
+    post.close()
+    want = orc.log_posterior_batch(pb, th)
+    assert np.array_equal(np.isfinite(got), np.isfinite(want)) and np.isfinite(want).sum() >= 3
+    fin = np.isfinite(want)
+    np.testing.assert_allclose(got[fin], want[fin], rtol=RTOL)
+    st = orc.sz_stages(pb, orc.pars_dict(pb, th[0]))
+    assert _relerr(row, st['map_row']) < RTOL_STAGE
+
+
 def test_largest_config_shape():
     """BASELINE configs[4] shape (S=1024, N=1000): two walkers against the oracle, both back ends."""
     from joxsz_amd import datasets
