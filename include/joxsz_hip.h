@@ -181,7 +181,7 @@ int  jx_get_conv_mode(jx_ctx* ctx);
  * img_rows x img_ld quadrant of distinct pixels per walker instead of the S x S map; NU distinct map rows, NJ
  * convolution jobs, P padded transform length; rank > 0: the transfer-function weights are applied in their
  * low-rank form and pass 3 transforms `rank` combined rows per walker instead of NJ (JOXSZ_LOWRANK=0 turns it
- * off, JOXSZ_LOWRANK_TOL sets the singular-value cut, default 1e-13); fused = 1: the FIR along rows and that
+ * off, JOXSZ_LOWRANK_TOL sets the singular-value cut relative to the largest one, default 1e-10); fused = 1: the FIR along rows and that
  * combination run as one matrix product per column kx on walker-minor row spectra (JOXSZ_FUSED=0: separate kernels).  JX_ERR_UNSUPPORTED with the rocFFT back end. */
 int  jx_get_conv_layout(jx_ctx* ctx, int32_t out[12]);
 /* Test hook (hand-written convolution only): device address and geometry of a work buffer, holding the last

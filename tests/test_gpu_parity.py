@@ -287,7 +287,9 @@ def test_lowrank_weights_against_full_weights(monkeypatch):
     'lowrank' = FIR kernel, then the combination (JOXSZ_FUSED=0), 'full' = one pass-3 row per job
     (JOXSZ_LOWRANK=0).  All three against each other and against the oracle; ragged walker counts included."""
     from joxsz_amd import datasets
-    modes = {'fused': {}, 'lowrank': {'JOXSZ_FUSED': '0'}, 'full': {'JOXSZ_LOWRANK': '0'}}
+    # 'tight': every singular value above rounding (1e-13); the default cut is 1e-10
+    modes = {'fused': {}, 'tight': {'JOXSZ_LOWRANK_TOL': '1e-13'}, 'lowrank': {'JOXSZ_FUSED': '0', 'JOXSZ_LOWRANK_TOL': '1e-13'},
+             'full': {'JOXSZ_LOWRANK': '0'}}
     for S, N, nw in ((256, 300, 6), (512, 500, 37)):
         pb = datasets.synthetic_problem(S=S, N=N, seed=11)
         th = datasets.walker_ball(pb, nw, spread=0.05, seed=11)
@@ -298,15 +300,19 @@ def test_lowrank_weights_against_full_weights(monkeypatch):
             post = _post(pb, conv='custom')
             lay = post.ctx.conv_layout
             assert (lay['rank'] > 0) == (mode != 'full') and lay['rank'] < lay['NJ'] // 2
-            assert bool(lay['fused']) == (mode == 'fused')
-            res[mode] = (post.stage(th, 'map_row'), post.stage(th, 'bright'), post.log_prob(th))
+            assert bool(lay['fused']) == (mode in ('fused', 'tight'))
+            res[mode] = (post.stage(th, 'map_row'), post.stage(th, 'bright'), post.log_prob(th), lay['rank'])
             post.close()
             for k in env:
                 monkeypatch.delenv(k)
-        for mode in ('fused', 'lowrank'):
+        for mode in ('tight', 'lowrank'):
             for a, b in zip(res[mode][:2], res['full'][:2]):
                 np.testing.assert_allclose(a, b, rtol=1e-10, atol=1e-11 * np.abs(b).max(), err_msg=mode)
             np.testing.assert_allclose(res[mode][2], res['full'][2], rtol=1e-9, err_msg=mode)
+        for a, b in zip(res['fused'][:2], res['full'][:2]):               # default cut: 1e-10 of the largest singular value
+            np.testing.assert_allclose(a, b, rtol=1e-7, atol=1e-8 * np.abs(b).max())
+        np.testing.assert_allclose(res['fused'][2], res['full'][2], rtol=1e-9)
+        assert res['fused'][3] <= res['tight'][3]
         want = orc.log_posterior_batch(pb, th[:8])
         np.testing.assert_allclose(res['fused'][2][:8], want, rtol=RTOL)
         st = orc.sz_stages(pb, orc.pars_dict(pb, th[0]))
