@@ -188,10 +188,14 @@ def main():
         lp_ptr = ctx.dev_alloc(8 * W)
         ctx.h2d(th_ptr, theta)
 
+    if torch is not None:
+        # the library enqueues on torch's current stream: RCCL orders the gather behind the evaluation by itself and
+        # the host never waits inside a step
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+
     def step():
         ctx.eval_device(th_ptr, W, lp_ptr)
         if dist is not None:
-            ctx.sync()                                   # logp complete before RCCL reads it
             dist.all_gather_into_tensor(all_t, lp_t)
 
     def fence():

@@ -151,6 +151,10 @@ int  jx_eval(jx_ctx* ctx, const double* theta_host, int nwalkers, double* logp_h
  * once the work is enqueued on the context's stream; pair with jx_sync. */
 int  jx_eval_device(jx_ctx* ctx, const double* theta_dev, int nwalkers, double* logp_dev);
 int  jx_sync(jx_ctx* ctx);
+/* Enqueue everything that follows on the caller's HIP stream (a hipStream_t, e.g. the one the caller's collective
+ * library orders its work against) instead of the context's own; NULL goes back to the own stream.  The context never
+ * destroys a stream it was handed.  Pending work on the previous stream is waited for first. */
+int  jx_set_stream(jx_ctx* ctx, void* hip_stream);
 /* Parity/debug tap: evaluates and copies one intermediate quantity to host. */
 int  jx_eval_stage(jx_ctx* ctx, const double* theta_host, int nwalkers, int stage_id,
                    double* out_host, size_t nbytes);

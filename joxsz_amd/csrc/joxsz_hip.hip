@@ -38,6 +38,7 @@ struct jx_ctx {
     std::string err;
     std::string devname;
     hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;  // created by jx_create; `stream` may point at a caller's stream instead (jx_set_stream)
 
     // host copies of the uploaded tensors
     std::vector<std::vector<unsigned char>> host;
@@ -238,6 +239,7 @@ int jx_create(const jx_config* cfg, jx_ctx** out) {
     ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     ctx->devname = std::string(prop.name[0] ? prop.name : "AMD GPU") + " (" + prop.gcnArchName + ", " + std::to_string(prop.multiProcessorCount) + " CUs)";
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return JX_ERR_HIP; }
+    ctx->own_stream = ctx->stream;
     if (g_rocfft_refs++ == 0) rocfft_setup();
     *out = ctx;
     return JX_OK;
@@ -967,6 +969,15 @@ int jx_eval_device(jx_ctx* ctx, const double* theta_dev, int nwalkers, double* l
     return JX_OK;
 }
 
+int jx_set_stream(jx_ctx* ctx, void* hip_stream) {
+    if (!ctx) return JX_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    if (ctx->info) FFTCHK(ctx, rocfft_execution_info_set_stream(ctx->info, ctx->stream));
+    return JX_OK;
+}
+
 int jx_sync(jx_ctx* ctx) {
     if (!ctx) return JX_ERR_INVALID;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1204,7 +1215,7 @@ void jx_destroy(jx_ctx* ctx) {
     if (ctx->d_work) (void)hipFree(ctx->d_work);
     if (ctx->d_theta) (void)hipFree(ctx->d_theta);
     if (ctx->d_logp) (void)hipFree(ctx->d_logp);
-    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     if (--g_rocfft_refs == 0) rocfft_cleanup();
     delete ctx;
 }

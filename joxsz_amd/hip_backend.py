@@ -14,7 +14,7 @@ ABI_VERSION = 1
 
 # must list every function include/joxsz_hip.h declares (tests/test_abi.py checks this)
 EXPORTS = (
-    'jx_create', 'jx_upload', 'jx_finalize', 'jx_eval', 'jx_eval_device', 'jx_sync', 'jx_eval_stage',
+    'jx_create', 'jx_upload', 'jx_finalize', 'jx_eval', 'jx_eval_device', 'jx_sync', 'jx_set_stream', 'jx_eval_stage',
     'jx_set_par_vals', 'jx_dev_alloc', 'jx_dev_free', 'jx_memcpy_h2d', 'jx_memcpy_d2h',
     'jx_timing_reset', 'jx_timing_enable', 'jx_timing_get', 'jx_get_info', 'jx_get_conv_mode', 'jx_get_conv_layout', 'jx_debug_workspace', 'jx_device_count',
     'jx_device_name', 'jx_strerror', 'jx_last_error', 'jx_destroy',
@@ -69,6 +69,7 @@ def load_library(path=None):
     lib.jx_eval.argtypes = [vp, dp, ci, dp]
     lib.jx_eval_device.argtypes = [vp, vp, ci, vp]
     lib.jx_sync.argtypes = [vp]
+    lib.jx_set_stream.argtypes = [vp, vp]
     lib.jx_eval_stage.argtypes = [vp, dp, ci, ci, dp, cs]
     lib.jx_set_par_vals.argtypes = [vp, dp, ci]
     lib.jx_dev_alloc.argtypes = [vp, cs, ctypes.POINTER(vp)]
@@ -252,6 +253,11 @@ class HipContext:
 
     def eval_device(self, theta_ptr, nwalkers, logp_ptr):
         self._chk(self.lib.jx_eval_device(self._h, ctypes.c_void_p(theta_ptr), nwalkers, ctypes.c_void_p(logp_ptr)), 'jx_eval_device')
+
+    def set_stream(self, hip_stream):
+        """Enqueue on the caller's hipStream_t (integer handle, e.g. ``torch.cuda.current_stream().cuda_stream``);
+        ``None`` or 0 returns to the context's own stream."""
+        self._chk(self.lib.jx_set_stream(self._h, ctypes.c_void_p(hip_stream or 0)), 'jx_set_stream')
 
     def sync(self):
         self._chk(self.lib.jx_sync(self._h), 'jx_sync')

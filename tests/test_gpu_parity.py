@@ -344,6 +344,29 @@ def test_rough_transfer_function_falls_back_to_one_row_per_job():
     assert _relerr(row, st['map_row']) < RTOL_STAGE
 
 
+def test_caller_stream(golden_tiny):
+    """jx_set_stream: the evaluation is enqueued on a stream of the caller (here a torch stream, as bench.py does for
+    the RCCL gather) and gives the same numbers; NULL returns to the context's own stream."""
+    torch = pytest.importorskip('torch')
+    from joxsz_amd import datasets
+    pb = datasets.synthetic_problem(S=64, N=80, seed=2)
+    th = datasets.walker_ball(pb, 9, spread=0.03, seed=2)
+    post = _post(pb)
+    ctx = post.ctx
+    want = post.log_prob(th)
+    side = torch.cuda.Stream()
+    ctx.set_stream(side.cuda_stream)
+    th_t = torch.from_numpy(th).cuda()
+    lp_t = torch.full((len(th),), float('nan'), dtype=torch.float64, device='cuda')
+    torch.cuda.synchronize()
+    ctx.eval_device(th_t.data_ptr(), len(th), lp_t.data_ptr())
+    side.synchronize()
+    np.testing.assert_array_equal(lp_t.cpu().numpy(), want)
+    ctx.set_stream(None)
+    np.testing.assert_array_equal(post.log_prob(th), want)
+    post.close()
+
+
 def test_largest_config_shape():
     """BASELINE configs[4] shape (S=1024, N=1000): two walkers against the oracle, both back ends."""
     from joxsz_amd import datasets
