@@ -1,5 +1,7 @@
 """Parity of the HIP path (through the C-ABI) against the CPU oracle and against
 the reference's golden vectors.  Needs an MI355X: run with -m gpu."""
+import os
+
 import numpy as np
 import pytest
 
@@ -344,27 +346,43 @@ def test_rough_transfer_function_falls_back_to_one_row_per_job():
     assert _relerr(row, st['map_row']) < RTOL_STAGE
 
 
-def test_caller_stream(golden_tiny):
+_CALLER_STREAM_SCRIPT = r"""
+import sys, numpy as np
+import torch                                   # first: torch brings its own HIP runtime and must initialise it itself
+torch.cuda.init()
+sys.path.insert(0, sys.argv[1])
+from joxsz_amd import datasets
+from joxsz_amd.posterior import JoxszPosterior
+pb = datasets.synthetic_problem(S=64, N=80, seed=2)
+th = datasets.walker_ball(pb, 9, spread=0.03, seed=2)
+post = JoxszPosterior(pb, device=0)
+ctx = post.ctx
+want = post.log_prob(th)
+side = torch.cuda.Stream()
+ctx.set_stream(side.cuda_stream)
+th_t = torch.from_numpy(th).cuda()
+lp_t = torch.full((len(th),), float('nan'), dtype=torch.float64, device='cuda')
+torch.cuda.synchronize()
+ctx.eval_device(th_t.data_ptr(), len(th), lp_t.data_ptr())
+side.synchronize()
+assert np.array_equal(lp_t.cpu().numpy(), want), 'caller stream'
+ctx.set_stream(None)
+assert np.array_equal(post.log_prob(th), want), 'own stream again'
+post.close()
+print('ok')
+"""
+
+
+def test_caller_stream():
     """jx_set_stream: the evaluation is enqueued on a stream of the caller (here a torch stream, as bench.py does for
-    the RCCL gather) and gives the same numbers; NULL returns to the context's own stream."""
-    torch = pytest.importorskip('torch')
-    from joxsz_amd import datasets
-    pb = datasets.synthetic_problem(S=64, N=80, seed=2)
-    th = datasets.walker_ball(pb, 9, spread=0.03, seed=2)
-    post = _post(pb)
-    ctx = post.ctx
-    want = post.log_prob(th)
-    side = torch.cuda.Stream()
-    ctx.set_stream(side.cuda_stream)
-    th_t = torch.from_numpy(th).cuda()
-    lp_t = torch.full((len(th),), float('nan'), dtype=torch.float64, device='cuda')
-    torch.cuda.synchronize()
-    ctx.eval_device(th_t.data_ptr(), len(th), lp_t.data_ptr())
-    side.synchronize()
-    np.testing.assert_array_equal(lp_t.cpu().numpy(), want)
-    ctx.set_stream(None)
-    np.testing.assert_array_equal(post.log_prob(th), want)
-    post.close()
+    the RCCL gather) and gives the same numbers; NULL returns to the context's own stream.  In a child process: torch
+    has to initialise its HIP runtime before this library is loaded, as in bench.py."""
+    pytest.importorskip('torch')
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-c', _CALLER_STREAM_SCRIPT, root], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith('ok'), r.stderr[-2000:]
 
 
 def test_largest_config_shape():
