@@ -385,6 +385,25 @@ def test_caller_stream():
     assert r.returncode == 0 and r.stdout.strip().endswith('ok'), r.stderr[-2000:]
 
 
+def test_fused_route_chunking():
+    """Walker counts that are no multiple of the GEMM's 16-walker tiles, split over several launch sequences of
+    different sizes, give the numbers of one launch sequence, walker by walker."""
+    from joxsz_amd import datasets
+    pb = datasets.synthetic_problem(S=128, N=150, seed=13)
+    th = datasets.walker_ball(pb, 77, spread=0.04, seed=13)
+    post = _post(pb, conv='custom')
+    assert post.ctx.conv_layout['fused'] == 1
+    one = post.log_prob(th)
+    post.close()
+    for mb in (16, 20, 50):
+        post = _post(pb, conv='custom', max_batch=mb)
+        got = post.log_prob(th)
+        post.close()
+        np.testing.assert_array_equal(got, one, err_msg='max_batch=%d' % mb)
+    want = orc.log_posterior_batch(pb, th[:6])
+    np.testing.assert_allclose(one[:6], want, rtol=RTOL)
+
+
 def test_largest_config_shape():
     """BASELINE configs[4] shape (S=1024, N=1000): two walkers against the oracle, both back ends."""
     from joxsz_amd import datasets
