@@ -180,13 +180,15 @@ int  jx_get_info(jx_ctx* ctx, int32_t* fft_pad, int32_t* chunk, int32_t* spline_
 /* 1 = rocFFT, 2 = hand-written passes (what `conv_mode` resolved to); <0 on error */
 int  jx_get_conv_mode(jx_ctx* ctx);
 /* Layout the library chose for the hand-written convolution: out = {xsym, quad, NU, NJ, ld, img_rows, img_ld, P,
- * rank, fused, 0, 0}.
+ * rank, fused, kact, 0}.
  * xsym: row spectra travel as one real array (ld doubles per row); quad: the Abel+map kernel stores only the
  * img_rows x img_ld quadrant of distinct pixels per walker instead of the S x S map; NU distinct map rows, NJ
  * convolution jobs, P padded transform length; rank > 0: the transfer-function weights are applied in their
  * low-rank form and pass 3 transforms `rank` combined rows per walker instead of NJ (JOXSZ_LOWRANK=0 turns it
  * off, JOXSZ_LOWRANK_TOL sets the singular-value cut relative to the largest one, default 1e-10); fused = 1: the FIR along rows and that
- * combination run as one matrix product per column kx on walker-minor row spectra (JOXSZ_FUSED=0: separate kernels).  JX_ERR_UNSUPPORTED with the rocFFT back end. */
+ * combination run as one matrix product per column kx on walker-minor row spectra (JOXSZ_FUSED=0: separate kernels),
+ * for the kact columns below the beam's band limit (every tap beyond is under a tenth of the singular-value cut, relative to the largest; JOXSZ_BANDLIMIT=0
+ * keeps all P/2+1).  JX_ERR_UNSUPPORTED with the rocFFT back end. */
 int  jx_get_conv_layout(jx_ctx* ctx, int32_t out[12]);
 /* Test hook (hand-written convolution only): device address and geometry of a work buffer, holding the last
  * evaluated chunk.  which: 0 Compton-y maps [chunk][S][S] (geom[3] = 0) or their quadrant of

@@ -68,7 +68,8 @@ struct jx_ctx {
     // fused FIR + job combination (one GEMM per column, walker-minor row spectra): tables, buffers, launch copy of JxConv
     JxLowrank lrf, lrf0;               // lrf.r == 0: not available.  A = Wk [Ph][RP][KU] / V0 [o+1][RP][KU]
     JxConv cv_f;
-    int fused_bucket = 0, tW = 0, tKU = 0;
+    int fused_bucket = 0, tW = 0, tKU = 0, kact = 0;
+    double lr_tol = 1e-10;             // singular-value cut in use
     double *d_Rt = nullptr, *d_Ct = nullptr, *d_Ct0 = nullptr, *d_x0t = nullptr;
     std::vector<double> h_L, h_taps;   // finalize scratch: U [r][NJ], FIR taps [o+1][Ph]
     jxt::ConvRows h_rows;
@@ -484,6 +485,7 @@ int jx_finalize(jx_ctx* ctx) {
             bool want = true;
             if (const char* e = getenv("JOXSZ_LOWRANK")) { if (atoi(e) == 0) want = false; }
             if (const char* e = getenv("JOXSZ_LOWRANK_TOL")) { const double v2 = atof(e); if (v2 > 0.0 && v2 < 1e-6) tol = v2; }
+            ctx->lr_tol = tol;
             double maxre = 0.0, maxim = 0.0;
             for (size_t e = 0; e < hyc.size(); e += 2) { maxre = std::max(maxre, std::fabs(hyc[e])); maxim = std::max(maxim, std::fabs(hyc[e + 1])); }
             if (want && cv.NJ <= 4 * JX_LR_KS && cv.NJ >= 32 && maxim <= 1e-15 * maxre) {
@@ -681,7 +683,24 @@ int jx_finalize(jx_ctx* ctx) {
 #undef JX_LR_PICK
             if (fuse && fb && (size_t)(RP / 16) * fb * 64 * sizeof(double) <= JX_LR_LDS_MAX) {
                 std::vector<double> Wk, V0, bc((size_t)nt * JX_COL0_LD, 0.0);
-                jxt::fused_row_operator(ctx->h_L, r, ctx->h_rows, S, cv.o, ctx->h_taps.data(), cv.Ph, cv.Ph, RP, KU, Wk);
+                // band limit of the beam: past the last column with a tap above band_tol (a tenth of the singular-value cut:
+                // 1e-11 by default) of the largest one the combined rows are dropped like the small singular values are;
+                // those columns are neither stored by pass 1 nor multiplied (Ct stays at its zero fill)
+                int kact = cv.Ph;
+                {
+                    const double band_tol = 0.1 * ctx->lr_tol;
+                    double tmax = 0.0;
+                    for (double v2 : ctx->h_taps) tmax = std::max(tmax, std::fabs(v2));
+                    while (kact > 1) {
+                        double m = 0.0;
+                        for (int t = 0; t < nt; ++t) m = std::max(m, std::fabs(ctx->h_taps[(size_t)t * cv.Ph + kact - 1]));
+                        if (m > band_tol * tmax) break;
+                        --kact;
+                    }
+                    if (const char* e = getenv("JOXSZ_BANDLIMIT")) { if (atoi(e) == 0) kact = cv.Ph; }
+                }
+                ctx->kact = kact;
+                jxt::fused_row_operator(ctx->h_L, r, ctx->h_rows, S, cv.o, ctx->h_taps.data(), kact, cv.Ph, RP, KU, Wk);
                 for (int t = 0; t < nt; ++t)
                     for (int x = 0; x < nt; ++x) bc[(size_t)t * JX_COL0_LD + x] = c.step * c.step * beam_h[(size_t)(cv.o + t) * B + cv.o + x];
                 jxt::fused_row_operator(ctx->h_L, r, ctx->h_rows, S, cv.o, bc.data(), nt, JX_COL0_LD, RP, KU, V0);
@@ -697,7 +716,7 @@ int jx_finalize(jx_ctx* ctx) {
                 if ((rc = dev_new(ctx, tW * 32 * 64 + 64, &ctx->d_Ct0, true))) return rc;
                 if ((rc = dev_new(ctx, ((size_t)KU + slack_rows) * tW, &ctx->d_x0t, true))) return rc;
                 ctx->cv_f = ctx->cv_lr;
-                ctx->cv_f.tmode = 1; ctx->cv_f.tW = ctx->tW; ctx->cv_f.tKU = KU; ctx->cv_f.ct0 = ctx->d_Ct0;
+                ctx->cv_f.tmode = 1; ctx->cv_f.tW = ctx->tW; ctx->cv_f.tKU = KU; ctx->cv_f.ct0 = ctx->d_Ct0; ctx->cv_f.kact = kact;
             }
             ctx->h_L.clear(); ctx->h_taps.clear();
         }
@@ -789,7 +808,7 @@ static int launch_fused_conv(jx_ctx* ctx, int n, EvSet* es) {
         const long long tW = ctx->tW, KU = ctx->tKU, RP = 16LL * ntr, nt = cv.o + 1;
         (void)ntile;
         // one launch: the kx batches of the row spectra, then the output-column batches of the column-0 terms
-        const JxGemmSeg s0{lr.U, ctx->d_Rt, ctx->d_Ct, RP * KU, KU * tW, 64LL, (long long)cv.Ph * 64, cv.Ph};
+        const JxGemmSeg s0{lr.U, ctx->d_Rt, ctx->d_Ct, RP * KU, KU * tW, 64LL, (long long)cv.Ph * 64, ctx->kact};
         const JxGemmSeg s1{ctx->lrf0.U, ctx->d_x0t, ctx->d_Ct0, RP * KU, 0LL, 64LL, 32LL * 64, (int)nt};
 #define JX_LR_GO(K, T) if (ctx->fused_bucket == K && ntr == T) \
             hipLaunchKernelGGL((jx_lowrank_kernel<K, T>), dim3(ctx->num_cu), dim3(512), lds, st, lr, s0, s1, 0LL, tW, 1LL, 0LL, 1LL, ncols, 1);
@@ -1163,7 +1182,7 @@ int jx_get_conv_layout(jx_ctx* ctx, int32_t out[12]) {
     const JxConv& cv = ctx->cv;
     out[0] = cv.xsym; out[1] = ctx->d.quad; out[2] = cv.NU; out[3] = cv.NJ; out[4] = cv.fir_ld;
     out[5] = ctx->d.quad ? ctx->d.q_nb : cv.S; out[6] = (int32_t)ctx->d.img_ld; out[7] = cv.P;
-    out[8] = ctx->lr.r; out[9] = ctx->lrf.r > 0 ? 1 : 0; out[10] = out[11] = 0;
+    out[8] = ctx->lr.r; out[9] = ctx->lrf.r > 0 ? 1 : 0; out[10] = ctx->lrf.r > 0 ? ctx->kact : 0; out[11] = 0;
     return JX_OK;
 }
 

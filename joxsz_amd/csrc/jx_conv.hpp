@@ -58,6 +58,7 @@ struct JxConv {
     // fused FIR + job combination (JxFused): pass 1 writes its rows walker-minor, pass 3 reads rho-minor
     int tmode;                      // 1: pass 1 -> Rt[k][tKU][tW] (block = distinct row x walker group); pass 3 <- Ct[w][Ph][64], Ct0[w][32][64]
     int tW, tKU, tn;                // walker stride (multiple of 16), padded distinct-row count, walkers in this launch
+    int kact;                       // columns kx < kact are kept: beyond, every beam tap is below a tenth of the singular-value cut
     const double* ct0;              // [tW][32][64] column-0 terms of the combined rows
     int quad;                       // 1: the map arrives as its quadrant [S/2+1][img_ld] of distinct pixels (|iy-c|, |ix-c|)
     const cplx* zab;                // [LP][2] pass-3 pre-process factors: Z[k] = zab[k][0] Rc[k] + zab[k][1] Rc[LP-k]   (xsym)
@@ -233,7 +234,7 @@ jx_rowfft2_kernel(JxConv c, const double* __restrict__ img, size_t img_ld, size_
     if (c.tmode) {
         // walker-minor output Rt[k][u][w]: consecutive lanes take consecutive walkers of the same k
         double* Rt = reinterpret_cast<double*>(Y);
-        for (int e = tid; e < nrows * Ph; e += nth) {
+        for (int e = tid; e < nrows * c.kact; e += nth) {             // (columns past the beam's band limit are never read)
             const int k = e / nrows, row = e - k * nrows;
             const cplx zk = M[row * RS + (k == LP ? 0 : k)];
             const cplx zc = c_conj(M[row * RS + (k == 0 ? 0 : LP - k)]);
@@ -352,8 +353,8 @@ jx_rowtf2_kernel(JxConv c, const cplx* __restrict__ C, cplx* __restrict__ part, 
 #pragma unroll
         for (int i = 0; i < NTRIP; ++i) {
             const int e = min(tid + i * 256, NPAIR * NSUB - 1), k = e >> LSUB, sub = min(e & (NSUB - 1), HR - 1);
-            ra[i] = *reinterpret_cast<const double2*>(Cw + (size_t)k * 64 + 2 * sub);
-            rb[i] = *reinterpret_cast<const double2*>(Cw + (size_t)(LP - k) * 64 + 2 * sub);
+            ra[i] = k < c.kact ? *reinterpret_cast<const double2*>(Cw + (size_t)k * 64 + 2 * sub) : make_double2(0.0, 0.0);
+            rb[i] = LP - k < c.kact ? *reinterpret_cast<const double2*>(Cw + (size_t)(LP - k) * 64 + 2 * sub) : make_double2(0.0, 0.0);
         }
 #pragma unroll
         for (int i = 0; i < NTRIP; ++i) {

@@ -160,7 +160,7 @@ class HipContext:
         if self.conv == 'custom':
             lay = (ctypes.c_int32 * 12)()
             self._chk(self.lib.jx_get_conv_layout(self._h, lay), 'jx_get_conv_layout')
-            self.conv_layout = dict(zip(('xsym', 'quad', 'NU', 'NJ', 'ld', 'img_rows', 'img_ld', 'P', 'rank', 'fused'), [int(v) for v in lay]))
+            self.conv_layout = dict(zip(('xsym', 'quad', 'NU', 'NJ', 'ld', 'img_rows', 'img_ld', 'P', 'rank', 'fused', 'kact'), [int(v) for v in lay]))
 
     # -- plumbing --
     def _chk(self, rc, what):

@@ -206,6 +206,7 @@ def test_custom_conv_with_and_without_row_symmetry(monkeypatch):
     spectra (JOXSZ_CONV_XSYM=0) and the default (both symmetries) against each other and the oracle."""
     from joxsz_amd import datasets
     modes = {'full': {}, 'rows_only': {'JOXSZ_CONV_XSYM': '0'}, 'none': {'JOXSZ_CONV_NOSYM': '1'}}
+    monkeypatch.setenv('JOXSZ_LOWRANK_TOL', '1e-13')          # bookkeeping test: no truncation beyond rounding in any mode
     for S, N, fwhm in ((64, 80, 18.5), (256, 300, 18.5), (512, 300, 9.0)):
         pb = datasets.synthetic_problem(S=S, N=N, seed=9, fwhm=fwhm)
         th = datasets.walker_ball(pb, 4, spread=0.04, seed=9)
