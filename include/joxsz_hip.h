@@ -195,7 +195,7 @@ int  jx_get_conv_layout(jx_ctx* ctx, int32_t out[12]);
  * distinct pixels [chunk][S/2+1][ld], entry (|iy-c|, |ix-c|) (geom[3] = 1), 1 pass-1 row spectra [chunk][NU][ld], 2 FIR output
  * [chunk][NJ+1][ld], 3 column-0 terms [chunk][o+1][NJ] (doubles); 4 conv row of each job [NJ], 5 distinct-row index
  * of each map row [S] (int32); fused route: 6 walker-minor row spectra [Ph][KU][tW], 7 combined rows [tW][Ph][64],
- * 8 their column-0 terms [tW][32][64], 9 walker-minor map column 0 [KU][tW]; low-rank route with separate kernels: 10 combined rows
+ * 8 their column-0 terms [tW][40][64], 9 walker-minor map column 0 [KU][tW]; low-rank route with separate kernels: 10 combined rows
  * [chunk][rank][ld], 11 their column-0 terms [chunk][o+1][rank] (geom[3] = rank).  geom = {chunk, rows, ld, xsym}: ld doubles per row, xsym = 1 when rows 1 and 2 hold
  * the real array R of  Y(kx) = x0 + e^{-2 pi i kx (S/2)/P} R(kx),  0 when they hold (re, im) pairs. */
 int  jx_debug_workspace(jx_ctx* ctx, int which, void** dev, int32_t geom[4]);

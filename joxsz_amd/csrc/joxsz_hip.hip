@@ -536,7 +536,7 @@ int jx_finalize(jx_ctx* ctx) {
         }
         // x-symmetric rows: one real array per row between the passes (needs the mirror structure of d_mat, which makes
         // every map row symmetric about column S/2, and the register-window FIR)
-        cv.xsym = (use_mirror && ctx->fir_reg && S <= 1024 && o < JX_XSYM_MAXT) ? 1 : 0;
+        cv.xsym = (use_mirror && S <= 1024 && o < JX_XSYM_MAXT) ? 1 : 0;       // (beam widths without a register FIR: jx_beamfir_real_kernel)
         if (const char* e = getenv("JOXSZ_CONV_XSYM")) { if (atoi(e) == 0) cv.xsym = 0; }
         cv.fir_ld = cv.xsym ? ((cv.Ph + 15) & ~15) : 2 * cv.Ph;
         if (cv.xsym) {
@@ -713,7 +713,7 @@ int jx_finalize(jx_ctx* ctx) {
                 const size_t tW = ctx->tW, slack_rows = (size_t)4 * fb - KU + 4;
                 if ((rc = dev_new(ctx, ((size_t)cv.Ph * KU + slack_rows) * tW, &ctx->d_Rt, true))) return rc;
                 if ((rc = dev_new(ctx, tW * cv.Ph * 64 + 64, &ctx->d_Ct, true))) return rc;
-                if ((rc = dev_new(ctx, tW * 32 * 64 + 64, &ctx->d_Ct0, true))) return rc;
+                if ((rc = dev_new(ctx, tW * JX_CT0_X * 64 + 64, &ctx->d_Ct0, true))) return rc;
                 if ((rc = dev_new(ctx, ((size_t)KU + slack_rows) * tW, &ctx->d_x0t, true))) return rc;
                 ctx->cv_f = ctx->cv_lr;
                 ctx->cv_f.tmode = 1; ctx->cv_f.tW = ctx->tW; ctx->cv_f.tKU = KU; ctx->cv_f.ct0 = ctx->d_Ct0; ctx->cv_f.kact = kact;
@@ -809,7 +809,7 @@ static int launch_fused_conv(jx_ctx* ctx, int n, EvSet* es) {
         (void)ntile;
         // one launch: the kx batches of the row spectra, then the output-column batches of the column-0 terms
         const JxGemmSeg s0{lr.U, ctx->d_Rt, ctx->d_Ct, RP * KU, KU * tW, 64LL, (long long)cv.Ph * 64, ctx->kact};
-        const JxGemmSeg s1{ctx->lrf0.U, ctx->d_x0t, ctx->d_Ct0, RP * KU, 0LL, 64LL, 32LL * 64, (int)nt};
+        const JxGemmSeg s1{ctx->lrf0.U, ctx->d_x0t, ctx->d_Ct0, RP * KU, 0LL, 64LL, (long long)JX_CT0_X * 64, (int)nt};
 #define JX_LR_GO(K, T) if (ctx->fused_bucket == K && ntr == T) \
             hipLaunchKernelGGL((jx_lowrank_kernel<K, T>), dim3(ctx->num_cu), dim3(512), lds, st, lr, s0, s1, 0LL, tW, 1LL, 0LL, 1LL, ncols, 1);
         JX_LR_KINDS(JX_LR_GO)
@@ -846,6 +846,9 @@ static int launch_custom_conv(jx_ctx* ctx, int n, double* tap_convjobs, EvSet* e
 #define JX_FIRREG(Ov) if (cv.o == Ov) hipLaunchKernelGGL((jx_beamfir_reg_kernel<Ov>), g2, dim3(64), 0, st, cv, ctx->d_runs, ctx->nrun, n, ctx->d_Y, ctx->d_C);
         JX_FIR_REG_O(JX_FIRREG)
 #undef JX_FIRREG
+    } else if (cv.xsym) {
+        hipLaunchKernelGGL(jx_beamfir_real_kernel, dim3(cv.NJ, n), dim3(256), 0, st, cv, reinterpret_cast<const double*>(ctx->d_Y),
+                           reinterpret_cast<double*>(ctx->d_C));
     } else {
         const dim3 g2((cv.Ph + JX_FIR_KX - 1) / JX_FIR_KX, n);
         hipLaunchKernelGGL(jx_beamfir_kernel, g2, dim3(256), ctx->p2_lds, st, cv, ctx->d_Y, ctx->d_C);
@@ -1210,7 +1213,7 @@ int jx_debug_workspace(jx_ctx* ctx, int which, void** dev, int32_t geom[4]) {
             geom[3] = ctx->lrf.r;
             if (which == 6) { *dev = ctx->d_Rt; geom[0] = cv.Ph; geom[1] = ctx->tKU; geom[2] = ctx->tW; }
             if (which == 7) { *dev = ctx->d_Ct; geom[0] = ctx->tW; geom[1] = cv.Ph; geom[2] = 64; }
-            if (which == 8) { *dev = ctx->d_Ct0; geom[0] = ctx->tW; geom[1] = 32; geom[2] = 64; }
+            if (which == 8) { *dev = ctx->d_Ct0; geom[0] = ctx->tW; geom[1] = JX_CT0_X; geom[2] = 64; }
             if (which == 9) { *dev = ctx->d_x0t; geom[0] = 1; geom[1] = ctx->tKU; geom[2] = ctx->tW; }
             break;
         default: ctx->err = "unknown work buffer"; return JX_ERR_INVALID;

@@ -56,10 +56,10 @@ struct JxConv {
     int xsym;                       // 1: map rows are also mirror-symmetric in x: Y and C hold ONE real array per row
     int fir_ld;                     // doubles per row of Y / C: Ph rounded up to 16 (xsym: rows start on cache lines) or 2 Ph
     // fused FIR + job combination (JxFused): pass 1 writes its rows walker-minor, pass 3 reads rho-minor
-    int tmode;                      // 1: pass 1 -> Rt[k][tKU][tW] (block = distinct row x walker group); pass 3 <- Ct[w][Ph][64], Ct0[w][32][64]
+    int tmode;                      // 1: pass 1 -> Rt[k][tKU][tW] (block = distinct row x walker group); pass 3 <- Ct[w][Ph][64], Ct0[w][JX_CT0_X][64]
     int tW, tKU, tn;                // walker stride (multiple of 16), padded distinct-row count, walkers in this launch
     int kact;                       // columns kx < kact are kept: beyond, every beam tap is below a tenth of the singular-value cut
-    const double* ct0;              // [tW][32][64] column-0 terms of the combined rows
+    const double* ct0;              // [tW][JX_CT0_X][64] column-0 terms of the combined rows
     int quad;                       // 1: the map arrives as its quadrant [S/2+1][img_ld] of distinct pixels (|iy-c|, |ix-c|)
     const cplx* zab;                // [LP][2] pass-3 pre-process factors: Z[k] = zab[k][0] Rc[k] + zab[k][1] Rc[LP-k]   (xsym)
     const double* bcol;             // [o+1][JX_COL0_LD] step^2 beam[o+t][o+x], zero beyond x = o: what column 0 of a map row adds to output column x  (xsym)
@@ -81,9 +81,10 @@ struct JxConv {
 #define JX_FIR_NR 8                 // consecutive output rows per thread
 #define JX_FIR_KX 32                // kx per slab
 // beam half-widths o = (B-1)/2 with a register-window FIR instance (and an x-symmetric pass-3 pre-process)
-#define JX_XSYM_MAXT 28              // taps (o + 1) of the widest such beam
+#define JX_XSYM_MAXT 33              // taps (o + 1) of the widest beam the path takes ((B-1)/2 <= 32)
 #define JX_COL0_XG 7                // output columns per block of the column-0 kernel
-#define JX_COL0_LD 28               // row stride of its beam table (a multiple of JX_COL0_XG, >= JX_XSYM_MAXT)
+#define JX_COL0_LD 35               // row stride of its beam table (a multiple of JX_COL0_XG, >= JX_XSYM_MAXT)
+#define JX_CT0_X 40                 // output columns per walker in the rho-minor column-0 array Ct0[w][JX_CT0_X][64]
 #define JX_FIR_REG_O(X) X(4) X(5) X(13) X(27)          // all >= 4: the FIR's 8 accumulator chains need 2O+1 >= 8
 #define JX_FIR_RING 128             // LDS ring of input rows (>= JX_FIR_TILE + 2 o)
 
@@ -343,7 +344,7 @@ jx_rowtf2_kernel(JxConv c, const cplx* __restrict__ C, cplx* __restrict__ part, 
 #pragma unroll
         for (int u = 0; u < NSL; ++u) {
             const int e = min(tid + u * nth, ns - 1), row = e / nt, xo = e - row * nt;
-            cz[u] = c.ct0[((size_t)w * 32 + xo) * 64 + r0 + row];
+            cz[u] = c.ct0[((size_t)w * JX_CT0_X + xo) * 64 + r0 + row];
         }
         constexpr int HR = (ROWS + 1) / 2;                            // row pairs
         constexpr int NSUB = HR <= 4 ? 4 : (HR <= 8 ? 8 : (HR <= 16 ? 16 : 32)), LSUB = NSUB == 4 ? 2 : (NSUB == 8 ? 3 : (NSUB == 16 ? 4 : 5));
@@ -1030,6 +1031,22 @@ jx_tail_fft_kernel(JxDev c, JxConv cv, const cplx* __restrict__ zpart, int nblk,
         logp[w0 + w] = tot;
         if (tap_chisq) tap_chisq[w] = chisq;
         if (tap_parts) tap_parts[(size_t)w * 4 + 1] = ll;
+    }
+}
+
+// FIR along rows on the real row spectra for beam widths without a register-window instance.  Only the routes with
+// separate kernels get here (the beam-convolved-map tap, JOXSZ_FUSED=0): one thread per output element, plain sums.
+__global__ void __launch_bounds__(256)
+jx_beamfir_real_kernel(JxConv c, const double* __restrict__ Y, double* __restrict__ C) {
+    const int q = blockIdx.x, w = blockIdx.y, S = c.S, o = c.o, ld = c.fir_ld, r = c.jrow[q];
+    const double* Yw = Y + (size_t)w * c.NU * ld;
+    for (int k = threadIdx.x; k < c.Ph; k += blockDim.x) {
+        double a = 0.0;
+        for (int d = -o; d <= o; ++d) {
+            const int m = r + d;
+            if (m >= 0 && m < S) a = fma(c.taps[(size_t)abs(d) * c.Ph + k], Yw[(size_t)c.umap[m] * ld + k], a);
+        }
+        C[((size_t)w * c.CROWS + q) * ld + k] = a;
     }
 }
 

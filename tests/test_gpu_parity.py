@@ -421,8 +421,9 @@ def test_largest_config_shape():
 
 @pytest.mark.parametrize('fwhm,B', [(6.5, 19), (9.0, 27), (21.0, 63)])
 def test_other_beam_widths(fwhm, B):
-    """Beam half-widths without a register-window FIR instance use the LDS-ring FIR (B=19, 63);
-    B=27 has its own instance.  All against the oracle."""
+    """Beam widths with (B=27) and without (B=19, 63) a register-window FIR instance: the log-posterior goes through the
+    fused route either way, the beam-convolved-map tap through the register FIR or the plain real-array FIR.  All
+    against the oracle."""
     from joxsz_amd import datasets
     pb = datasets.synthetic_problem(S=128, N=150, seed=11, fwhm=fwhm)
     assert pb.B == B
