@@ -77,6 +77,8 @@ struct jx_ctx {
     size_t p1_lds = 0, p2_lds = 0, p3_lds = 0;
     int p13_rows = 8, p1_rows = 8;
     int lr_bucket = 0;                // k-steps compiled into the low-rank kernel in use
+    bool lr_sep = false;              // the separate combination kernel is available (else: fused route or one row per job)
+    int fused_nh = 1;                 // K halves of the fused GEMM (two launches, the second accumulating, when NU/4 exceeds the buckets)
     int last_nblk3 = 0;               // pass-3 blocks per walker of the launch sequence just queued
     int num_cu = 256;
     int* d_rowjob = nullptr;
@@ -488,7 +490,7 @@ int jx_finalize(jx_ctx* ctx) {
             ctx->lr_tol = tol;
             double maxre = 0.0, maxim = 0.0;
             for (size_t e = 0; e < hyc.size(); e += 2) { maxre = std::max(maxre, std::fabs(hyc[e])); maxim = std::max(maxim, std::fabs(hyc[e + 1])); }
-            if (want && cv.NJ <= 4 * JX_LR_KS && cv.NJ >= 32 && maxim <= 1e-15 * maxre) {
+            if (want && cv.NJ >= 32 && cv.NJ <= 600 && maxim <= 1e-15 * maxre) {
                 std::vector<double> A((size_t)cv.NJ * cv.Sh), L, Rt;
                 for (size_t e = 0; e < A.size(); ++e) A[e] = hyc[2 * e];
                 const int r = jxt::lowrank_factor(A.data(), cv.NJ, cv.Sh, tol, L, Rt);
@@ -498,7 +500,9 @@ int jx_finalize(jx_ctx* ctx) {
 #undef JX_LR_PICK
                 ctx->lr_bucket = bucket;
                 const size_t lds_need = (size_t)((r + 15) / 16) * bucket * 64 * sizeof(double);
-                if (bucket && r > 0 && 2 * r <= cv.NJ && r <= 64 && lds_need <= JX_LR_LDS_MAX) {
+                // the combination as its own kernel (behind the FIR kernel) holds the U tile for all jobs in LDS
+                ctx->lr_sep = bucket && lds_need <= JX_LR_LDS_MAX;
+                if (r > 0 && 2 * r <= cv.NJ && r <= 64) {
                     JxLowrank& lr = ctx->lr;
                     lr.r = r; lr.nq = cv.NJ; lr.ks = (cv.NJ + 3) / 4; lr.KQ = 4 * lr.ks;
                     const int RP = ((r + 15) / 16) * 16;
@@ -666,8 +670,8 @@ int jx_finalize(jx_ctx* ctx) {
         if (cv.xsym && (rc = dev_new(ctx, (size_t)chunk * cv.NJ * (cv.o + 1) + 4 * JX_LR_KS, &ctx->cv.col0, true))) return rc;
         if ((rc = dev_new(ctx, (size_t)chunk * cv.nblk3 * cv.Sh, &ctx->d_part))) return rc;
         if (ctx->lr.r > 0) {
-            if ((rc = dev_new(ctx, (size_t)chunk * ctx->lr.r * cv.fir_ld, &ctx->d_Clr))) return rc;
-            if (cv.xsym && (rc = dev_new(ctx, (size_t)chunk * (cv.o + 1) * ctx->lr.r, &ctx->d_col0lr))) return rc;
+            if (ctx->lr_sep && (rc = dev_new(ctx, (size_t)chunk * ctx->lr.r * cv.fir_ld, &ctx->d_Clr))) return rc;
+            if (ctx->lr_sep && cv.xsym && (rc = dev_new(ctx, (size_t)chunk * (cv.o + 1) * ctx->lr.r, &ctx->d_col0lr))) return rc;
             ctx->cv_lr = ctx->cv;                                  // cv is final here
             ctx->cv_lr.hy = ctx->lr_vt;
             ctx->cv_lr.col0 = ctx->d_col0lr;
@@ -676,9 +680,12 @@ int jx_finalize(jx_ctx* ctx) {
             // fused FIR + combination: needs the real row spectra and the quadrant map (walker-minor column-0 copy)
             bool fuse = cv.xsym && d.quad;
             if (const char* e = getenv("JOXSZ_FUSED")) { if (atoi(e) == 0) fuse = false; }
-            const int r = ctx->lr.r, RP = ((r + 15) / 16) * 16, KU = (cv.NU + 3) & ~3, nt = cv.o + 1;
+            const int r = ctx->lr.r, RP = ((r + 15) / 16) * 16, nt = cv.o + 1;
+            // K = distinct rows: one GEMM pass while NU/4 fits the compiled k-step buckets, else two halves (second accumulates)
+            int nh = ((cv.NU + 3) / 4 <= JX_LR_KS) ? 1 : 2;
+            const int KUh = (((cv.NU + nh - 1) / nh) + 3) & ~3, KU = nh * KUh;
             int fb = 0;
-#define JX_LR_PICK(K) if (!fb && KU / 4 <= K) fb = K;
+#define JX_LR_PICK(K) if (!fb && KUh / 4 <= K) fb = K;
             JX_LR_BUCKETS(JX_LR_PICK)
 #undef JX_LR_PICK
             if (fuse && fb && (size_t)(RP / 16) * fb * 64 * sizeof(double) <= JX_LR_LDS_MAX) {
@@ -705,12 +712,23 @@ int jx_finalize(jx_ctx* ctx) {
                     for (int x = 0; x < nt; ++x) bc[(size_t)t * JX_COL0_LD + x] = c.step * c.step * beam_h[(size_t)(cv.o + t) * B + cv.o + x];
                 jxt::fused_row_operator(ctx->h_L, r, ctx->h_rows, S, cv.o, bc.data(), nt, JX_COL0_LD, RP, KU, V0);
                 double* p2;
+                if (nh == 2) {                                     // [b][RP][KU] -> [half][b][RP][KUh]
+                    for (std::vector<double>* T : {&Wk, &V0}) {
+                        const size_t nb = T->size() / ((size_t)RP * KU);
+                        std::vector<double> H2(T->size());
+                        for (int h = 0; h < 2; ++h)
+                            for (size_t b = 0; b < nb; ++b)
+                                for (int rho = 0; rho < RP; ++rho)
+                                    memcpy(&H2[(((size_t)h * nb + b) * RP + rho) * KUh], &(*T)[((size_t)b * RP + rho) * KU + (size_t)h * KUh], sizeof(double) * KUh);
+                        T->swap(H2);
+                    }
+                }
                 if ((rc = dev_put(ctx, Wk.data(), Wk.size(), &p2))) return rc;
-                ctx->lrf.U = p2; ctx->lrf.r = r; ctx->lrf.ks = KU / 4; ctx->lrf.KQ = KU; ctx->lrf.nq = cv.NU;
+                ctx->lrf.U = p2; ctx->lrf.r = r; ctx->lrf.ks = KUh / 4; ctx->lrf.KQ = KUh; ctx->lrf.nq = cv.NU;
                 if ((rc = dev_put(ctx, V0.data(), V0.size(), &p2))) return rc;
                 ctx->lrf0 = ctx->lrf; ctx->lrf0.U = p2;
-                ctx->fused_bucket = fb; ctx->tKU = KU; ctx->tW = (chunk + 15) & ~15;
-                const size_t tW = ctx->tW, slack_rows = (size_t)4 * fb - KU + 4;
+                ctx->fused_bucket = fb; ctx->tKU = KU; ctx->tW = (chunk + 15) & ~15; ctx->fused_nh = nh;
+                const size_t tW = ctx->tW, slack_rows = (size_t)4 * fb - KUh + 4;
                 if ((rc = dev_new(ctx, ((size_t)cv.Ph * KU + slack_rows) * tW, &ctx->d_Rt, true))) return rc;
                 if ((rc = dev_new(ctx, tW * cv.Ph * 64 + 64, &ctx->d_Ct, true))) return rc;
                 if ((rc = dev_new(ctx, tW * JX_CT0_X * 64 + 64, &ctx->d_Ct0, true))) return rc;
@@ -808,12 +826,18 @@ static int launch_fused_conv(jx_ctx* ctx, int n, EvSet* es) {
         const long long tW = ctx->tW, KU = ctx->tKU, RP = 16LL * ntr, nt = cv.o + 1;
         (void)ntile;
         // one launch: the kx batches of the row spectra, then the output-column batches of the column-0 terms
-        const JxGemmSeg s0{lr.U, ctx->d_Rt, ctx->d_Ct, RP * KU, KU * tW, 64LL, (long long)cv.Ph * 64, ctx->kact};
-        const JxGemmSeg s1{ctx->lrf0.U, ctx->d_x0t, ctx->d_Ct0, RP * KU, 0LL, 64LL, (long long)JX_CT0_X * 64, (int)nt};
+        // (K split in halves for large maps: the second launch adds its half of the distinct rows to the first's results)
+        const long long KUh = KU / ctx->fused_nh;
+        for (int h = 0; h < ctx->fused_nh; ++h) {
+            const JxGemmSeg s0{lr.U + (size_t)h * ctx->kact * RP * KUh, ctx->d_Rt + (size_t)h * KUh * tW, ctx->d_Ct, RP * KUh, KU * tW, 64LL,
+                               (long long)cv.Ph * 64, ctx->kact, h};
+            const JxGemmSeg s1{ctx->lrf0.U + (size_t)h * nt * RP * KUh, ctx->d_x0t + (size_t)h * KUh * tW, ctx->d_Ct0, RP * KUh, 0LL, 64LL,
+                               (long long)JX_CT0_X * 64, (int)nt, h};
 #define JX_LR_GO(K, T) if (ctx->fused_bucket == K && ntr == T) \
             hipLaunchKernelGGL((jx_lowrank_kernel<K, T>), dim3(ctx->num_cu), dim3(512), lds, st, lr, s0, s1, 0LL, tW, 1LL, 0LL, 1LL, ncols, 1);
-        JX_LR_KINDS(JX_LR_GO)
+            JX_LR_KINDS(JX_LR_GO)
 #undef JX_LR_GO
+        }
     }
     ctx->last_nblk3 = cf.nblk3;
     done = false;
@@ -856,7 +880,7 @@ static int launch_custom_conv(jx_ctx* ctx, int n, double* tap_convjobs, EvSet* e
     if (es) HIPCHK(ctx, hipEventRecord(es->e[3], st));
     done = false;
     // the beam-convolved map is only materialised job by job (parity tap) without the low-rank combination
-    const bool lowrank = ctx->lr.r > 0 && !tap_convjobs;
+    const bool lowrank = ctx->lr.r > 0 && ctx->lr_sep && !tap_convjobs;
     ctx->last_nblk3 = lowrank ? ctx->cv_lr.nblk3 : cv.nblk3;
     if (lowrank) {
         const JxLowrank& lr = ctx->lr;
@@ -864,9 +888,9 @@ static int launch_custom_conv(jx_ctx* ctx, int n, double* tap_convjobs, EvSet* e
         const size_t lds = (size_t)ntr * ctx->lr_bucket * 64 * sizeof(double);
         const dim3 blocks(ctx->num_cu);
         const long long ld = cv.fir_ld, nt = cv.o + 1;
-        const JxGemmSeg none{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0};
-        const JxGemmSeg sr{lr.U, reinterpret_cast<const double*>(ctx->d_C), ctx->d_Clr, 0, 0, 0, 1LL, 1};
-        const JxGemmSeg sc{lr.U, cv.col0, ctx->d_col0lr, 0, 0, 0, (long long)lr.r, 1};
+        const JxGemmSeg none{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0};
+        const JxGemmSeg sr{lr.U, reinterpret_cast<const double*>(ctx->d_C), ctx->d_Clr, 0, 0, 0, 1LL, 1, 0};
+        const JxGemmSeg sc{lr.U, cv.col0, ctx->d_col0lr, 0, 0, 0, (long long)lr.r, 1, 0};
 #define JX_LR_GO(K, T) if (ctx->lr_bucket == K && ntr == T) { \
             hipLaunchKernelGGL((jx_lowrank_kernel<K, T>), blocks, dim3(threads), lds, st, lr, sr, none, (long long)cv.CROWS * ld, ld, 1LL, \
                                (long long)lr.r * ld, ld, cv.xsym ? cv.Ph : 2 * cv.Ph, n); \

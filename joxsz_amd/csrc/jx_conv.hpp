@@ -815,6 +815,7 @@ struct JxGemmSeg {                  // one run of batches of the GEMM kernel: ma
     const double* A; const double* B; double* D;
     long long a_batch, b_batch, d_batch, dj;                          // per-batch steps; step between result columns
     int nbatch;
+    int acc;                                                          // 1: D += (the second half of a K range split over two launches)
 };
 struct JxLowrank {
     const double* U;                // [RP][KQ] sigma u, zero padded (RP multiple of 16, KQ = 4 ks) -- host-side handle, the kernel takes JxGemmSeg
@@ -912,7 +913,7 @@ jx_lowrank_kernel(JxLowrank lr, JxGemmSeg sg0, JxGemmSeg sg1, long long bws, lon
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {
                     const int rho = t * 16 + lk + 4 * gq;
-                    if (rho < lr.r) Dp[(size_t)rho * dr] = acc[t][gq];
+                    if (rho < lr.r) Dp[(size_t)rho * dr] = (second ? sg1.acc : sg0.acc) ? Dp[(size_t)rho * dr] + acc[t][gq] : acc[t][gq];
                 }
         }
     }
