@@ -27,8 +27,13 @@
 // FMAs), pass 3 rebuilds Z from Rc with one precomputed complex factor per term.  What column 0 adds to
 // the convolved row is put back in real space after the inverse transform: it only reaches output
 // columns 0..o,  conv[r][x] += step^2 sum_t beam[o+t][o+x] (x0[r-t] + x0[r+t]).
-// Every pass keeps rows contiguous in memory ([row][kx], 16-byte complex), so all global
-// accesses are coalesced wave transactions and no transpose is needed.
+// Default route: the weights Hyc[q][kc] factor as sum_rho U[rho][q] v_rho[kc] (truncated SVD built at
+// jx_finalize), so the jobs are combined before pass 3, and pass 2 together with that combination is one real matrix per
+// column kx applied to the walkers as columns: jx_rowfft2_kernel (tmode: walker-minor rows) -> jx_lowrank_kernel (fp64
+// MFMA, batched over kx) -> jx_rowtf2_kernel over the r combined rows -> jx_tail_fft_kernel.  The kernels of the
+// step-by-step description above remain as the route of the beam-convolved-map tap and of the fallbacks.
+// In the step-by-step routes every pass keeps rows contiguous in memory ([row][kx]), so all global accesses are
+// coalesced wave transactions; the default route trades that for walker-minor / rho-minor arrays where a GEMM wants them.
 //
 // FFTs: a real transform of length 2L is a complex transform of length L plus the usual
 // even/odd split; the complex transform is two-level, L = L1 * L2, with both
