@@ -640,9 +640,17 @@ int jx_finalize(jx_ctx* ctx) {
         auto need = [&](int threads) {
             size_t scratch = JX_MAP_SCRATCH_DOUBLES(N);
             if (d.fast_map) scratch = std::max(scratch, (size_t)(threads / 64) * ((S + 3) & ~1));
-            const size_t dbl = JX_MAP_FIXED_DOUBLES(N) + scratch;
+            const size_t dbl = JX_MAP_FIXED_DOUBLES(N) + scratch + (d.pairw == 2 ? 4 * JX_MAP_NE(N) + 8 : 0);
             return dbl * sizeof(double);
         };
+        // quadrant map: two walkers per block share every (slot, abscissa) table entry (half the table traffic per walker),
+        // as long as two such blocks still fit a CU
+        d.pairw = 1;
+        if (d.quad) {
+            d.pairw = 2;
+            if (const char* e = getenv("JOXSZ_MAP_PAIR")) { if (atoi(e) == 0) d.pairw = 1; }
+            if (d.pairw == 2 && need(ctx->map_threads) > (LDS_MAX - 2048) / 2) d.pairw = 1;
+        }
         while (ctx->map_threads > 64 && need(ctx->map_threads) > LDS_MAX - 1024) ctx->map_threads /= 2;
         ctx->map_lds_bytes = need(ctx->map_threads);
         if (ctx->map_lds_bytes > LDS_MAX - 1024) { ctx->err = "radial grid too long for the LDS-resident spline"; return JX_ERR_UNSUPPORTED; }
@@ -936,10 +944,12 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
     if (tm) HIPCHK(ctx, hipEventRecord(es.e[1], st));
     {
         const bool vec2 = (d.S % 2 == 0) && (d.P % 2 == 0);
-        const dim3 grid(n * d.map_split), block(ctx->map_threads);
+        const int npw = (d.quad && d.pairw == 2) ? 2 : 1;
+        const dim3 grid(((n + npw - 1) / npw) * d.map_split), block(ctx->map_threads);
         if (d.fast_map) {
             const size_t sh = ctx->map_lds_bytes;
             JxDev dm = d;                                          // fused route: column 0 is copied walker-minor
+            dm.nlaunch = n;
             if (use_fused(ctx, t.conv)) { dm.xcol = ctx->d_x0t; dm.xcol_ld = ctx->tW; }
 #define JX_SYM_LAUNCH(V, NA) hipLaunchKernelGGL((jx_abel_map_sym_kernel<V, NA>), grid, block, sh, st, dm, theta_dev, w0, ctx->d_img, t.pp, t.ab, t.y)
             const int nait = (d.q_na + 63) / 64;

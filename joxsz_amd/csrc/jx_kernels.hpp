@@ -53,6 +53,7 @@ struct JxDev {
     int fast_map, q_na, q_nb;    // symmetric-map form: table sizes (|ix-c|, |iy-c|)
     double* xcol;                // quad mode: copy of the quadrant's last column (map column 0): [chunk][q_nb], or walker-minor
     long long xcol_ld;           //   [q_nb padded][xcol_ld] when xcol_ld > 0 (fused FIR path)
+    int pairw, nlaunch;          // quad mode: walkers per block (1 or 2: two coefficient sets share every table entry), walkers of this launch
     int quad;                    // 1: the image is the quadrant [q_nb][img_ld] (|iy-c|, |ix-c|) alone, nothing mirrored
     const int* q_k;              // [q_nb*q_na] coefficient slot of each quadrant radius
     const double* q_t;           // [q_nb*q_na] local abscissa within that slot
@@ -556,21 +557,31 @@ jx_abel_map_sym_kernel(JxDev c, const double* __restrict__ theta, int w0, double
     double* p = sm;
     const int Ne = (N + 1) & ~1;
     double* s_cf = sm + JX_LDS_HDR;                                   // [4(N+1)] cubic coefficients (live in phase 5)
-    double* s_r = sm + JX_MAP_FIXED_DOUBLES(N);                       // [N] knots         -- scratch from here on
+    // quad mode with two walkers per block: the second walker's coefficients sit in front of the scratch
+    const int npw = (c.quad && c.pairw == 2) ? 2 : 1;
+    double* s_cfB = sm + JX_MAP_FIXED_DOUBLES(N);
+    double* s_r = sm + JX_MAP_FIXED_DOUBLES(N) + (npw == 2 ? 4 * JX_MAP_NE(N) + 8 : 0);   // [N] knots -- scratch from here on
     double* s_pp = s_r + Ne;                                          // [N]
     double* s_y = s_pp + Ne;                                          // [N]
     double* s_M = s_y + Ne;                                           // [N]
     double2* s_rq = reinterpret_cast<double2*>(s_M + Ne);             // [N] (r^2, cj*pp)
     double2* s_ds = s_rq + Ne;                                        // [N] (dg, sp)
-    double* s_row = sm + JX_MAP_FIXED_DOUBLES(N);                     // [nwaves][row_pad] over the dead scratch
+    double* s_row = s_r;                                              // [nwaves][row_pad] over the dead scratch
 
     const int tid = threadIdx.x, nth = blockDim.x;
-    const int w = blockIdx.x / c.map_split;
-    const int part = blockIdx.x - w * c.map_split;
+    const int blk = blockIdx.x / c.map_split, part = blockIdx.x - blk * c.map_split;
+    const int w = blk * npw;
+    const bool haveB = npw == 2 && w + 1 < c.nlaunch;                 // (an odd launch: the last block has one walker)
 
     jx_load_params(c, theta, w0 + w, p);
     if (!(c.dbg & 1)) jx_profile_to_coefs(c, p, w, part == 0, s_r, s_pp, s_y, s_M, s_cf, s_rq, s_ds, tap_pp, tap_ab, tap_y);
     else { for (int k = tid; k < 4 * (N + 1); k += nth) s_cf[k] = 0.0; __syncthreads(); }
+    if (haveB) {
+        __syncthreads();
+        jx_load_params(c, theta, w0 + w + 1, p);
+        if (!(c.dbg & 1)) jx_profile_to_coefs(c, p, w + 1, part == 0, s_r, s_pp, s_y, s_M, s_cfB, s_rq, s_ds, tap_pp, tap_ab, tap_y);
+        else { for (int k = tid; k < 4 * (N + 1); k += nth) s_cfB[k] = 0.0; __syncthreads(); }
+    }
     if (c.dbg & 2) return;
 
     const int S = c.S, na = c.q_na, nb = c.q_nb, cc = c.S / 2;
@@ -581,6 +592,41 @@ jx_abel_map_sym_kernel(JxDev c, const double* __restrict__ theta, int w0, double
     const int b_per = (nb + c.map_split - 1) / c.map_split;
     const int b0 = part * b_per, b1 = min(nb, b0 + b_per);
 
+    if (c.quad && !(c.dbg & 4)) {
+        // The distinct pixels only, walked as one flat array of (slot, abscissa) entries [b0*na, b1*na): every lane has
+        // an entry in every trip (a row-wise walk leaves na mod 64 lanes idle), eight entries per lane in flight.
+        const int e_end = b1 * na;
+        constexpr int UN = 8;
+        for (int e0 = b0 * na + tid; e0 < e_end; e0 += UN * nth) {
+            int kk[UN];
+            double tt[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int e = min(e0 + u * nth, e_end - 1);
+                kk[u] = c.q_k[e];
+                tt[u] = c.q_t[e];
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int e = e0 + u * nth;
+                if (e < e_end) {
+                    const double t = tt[u];
+                    const double* cf = s_cf + 4 * kk[u];
+                    const double v = fma(t, fma(t, fma(t, cf[3], cf[2]), cf[1]), cf[0]);
+                    const int bb = e / na, a = e - bb * na;
+                    out[(size_t)bb * c.img_ld + a] = v;
+                    if (a == na - 1) c.xcol[c.xcol_ld > 0 ? (size_t)bb * c.xcol_ld + w : (size_t)w * nb + bb] = v;
+                    if (haveB) {                                      // the same table entry for the block's second walker
+                        const double* cg = s_cfB + 4 * kk[u];
+                        const double v2 = fma(t, fma(t, fma(t, cg[3], cg[2]), cg[1]), cg[0]);
+                        out[c.img_ws + (size_t)bb * c.img_ld + a] = v2;
+                        if (a == na - 1) c.xcol[c.xcol_ld > 0 ? (size_t)bb * c.xcol_ld + w + 1 : (size_t)(w + 1) * nb + bb] = v2;
+                    }
+                }
+            }
+        }
+        return;
+    }
     int kq[NAIT];
     double tq[NAIT];
     int b = b0 + wv;
@@ -617,36 +663,6 @@ jx_abel_map_sym_kernel(JxDev c, const double* __restrict__ theta, int w0, double
             kq[u] = ok ? c.q_k[(size_t)b * na + a] : N;
             tq[u] = ok ? c.q_t[(size_t)b * na + a] : 0.0;
         }
-    }
-    if (c.quad) {
-        // the distinct pixels only: row b of the quadrant, one coalesced store per 64 abscissae
-        for (; b < b1; b += nwv) {
-            double v[NAIT];
-#pragma unroll
-            for (int u = 0; u < NAIT; ++u) {
-                const double t = tq[u];
-                const double* cf = s_cf + 4 * kq[u];
-                v[u] = fma(t, fma(t, fma(t, cf[3], cf[2]), cf[1]), cf[0]);
-            }
-            const int bn = b + nwv;
-            if (bn < b1) {
-#pragma unroll
-                for (int u = 0; u < NAIT; ++u) {
-                    const int a = lane + 64 * u;
-                    const bool ok = a < na;
-                    kq[u] = ok ? c.q_k[(size_t)bn * na + a] : N;
-                    tq[u] = ok ? c.q_t[(size_t)bn * na + a] : 0.0;
-                }
-            }
-            double* orow = out + (size_t)b * c.img_ld;
-#pragma unroll
-            for (int u = 0; u < NAIT; ++u) {
-                const int a = lane + 64 * u;
-                if (a < na) orow[a] = v[u];
-                if (a == na - 1) c.xcol[c.xcol_ld > 0 ? (size_t)b * c.xcol_ld + w : (size_t)w * nb + b] = v[u];
-            }
-        }
-        return;
     }
     for (; b < b1; b += nwv) {
         // evaluate the half row and mirror it into the full row
