@@ -1,4 +1,6 @@
-cd $GRAFT_REPO_ROOT
+# usage (on the GPU box, from the repo root): bash scripts/other_shapes.sh [tag]   -> gpurun_out/<tag>_other_shapes.log
+cd ${GRAFT_REPO_ROOT:-.}
+TAG=${1:-r01}
 python -m pytest tests -m gpu -x -q > gpurun_out/t.log 2>&1; tail -2 gpurun_out/t.log
 {
 echo "# other BASELINE shapes, same library, one MI355X (bench.py --no-cpu --steps 20 --warmup 3)"
@@ -16,5 +18,5 @@ pb = datasets.synthetic_problem(S=512, N=500, seed=0)
 t = time.time(); post = JoxszPosterior(pb, device=0); print('JoxszPosterior(...) took %.2f s' % (time.time() - t)); post.close()
 t = time.time(); post = JoxszPosterior(pb, device=0); print('second context   took %.2f s' % (time.time() - t)); post.close()
 PY
-} > gpurun_out/r01c_other_shapes.log 2>&1
-cat gpurun_out/r01c_other_shapes.log
+} > gpurun_out/${TAG}_other_shapes.log 2>&1
+cat gpurun_out/${TAG}_other_shapes.log
