@@ -155,6 +155,15 @@ int  jx_sync(jx_ctx* ctx);
  * library orders its work against) instead of the context's own; NULL goes back to the own stream.  The context never
  * destroys a stream it was handed.  Pending work on the previous stream is waited for first. */
 int  jx_set_stream(jx_ctx* ctx, void* hip_stream);
+/* Device-resident affine-invariant ensemble sampler (Goodman & Weare stretch move in emcee's red/blue form: what
+ * mcmc.sample does with the reference's callable, joxsz_funcs.py:593-622): nsteps iterations of two half steps, with
+ * proposals, log-posterior evaluation, accept/reject and the chain all on the device and one copy back at the end.
+ * theta0 [nwalkers][ndim] (finite log-posterior required, nwalkers even); chain_out [nsteps][nwalkers][ndim],
+ * logp_out [nsteps][nwalkers], naccept_out [nwalkers] are host arrays and may be NULL.  Random numbers are
+ * Philox4x32-10 keyed by seed with counter (walker slot, 2 iteration + half, draw, 0): a run is reproducible and can
+ * be replayed on the host (joxsz_amd/sampler.py). */
+int  jx_sample(jx_ctx* ctx, const double* theta0_host, int nwalkers, int nsteps, double a, uint64_t seed,
+               double* chain_out, double* logp_out, int64_t* naccept_out);
 /* Parity/debug tap: evaluates and copies one intermediate quantity to host. */
 int  jx_eval_stage(jx_ctx* ctx, const double* theta_host, int nwalkers, int stage_id,
                    double* out_host, size_t nbytes);

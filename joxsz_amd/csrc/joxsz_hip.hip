@@ -1025,6 +1025,58 @@ int jx_eval_device(jx_ctx* ctx, const double* theta_dev, int nwalkers, double* l
     return JX_OK;
 }
 
+int jx_sample(jx_ctx* ctx, const double* theta0, int nwalkers, int nsteps, double a, uint64_t seed,
+              double* chain_out, double* logp_out, int64_t* naccept_out) {
+    if (!ctx || !theta0 || nwalkers < 2 || (nwalkers & 1) || nsteps < 0 || !(a > 1.0)) return JX_ERR_INVALID;
+    if (!ctx->finalized) { ctx->err = "jx_sample before jx_finalize"; return JX_ERR_STATE; }
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    const int ndim = ctx->cfg.ndim, W = nwalkers, half = W / 2;
+    hipStream_t st = ctx->stream;
+    double *x = nullptr, *lp = nullptr, *q = nullptr, *lq = nullptr, *zz = nullptr, *chain = nullptr, *lps = nullptr;
+    long long* nacc = nullptr;
+    auto cleanup = [&]() {
+        for (void* p : {(void*)x, (void*)lp, (void*)q, (void*)lq, (void*)zz, (void*)chain, (void*)lps, (void*)nacc}) if (p) (void)hipFree(p);
+    };
+#define SCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { ctx->err = std::string(#expr) + ": " + hipGetErrorString(e_); cleanup(); return JX_ERR_HIP; } } while (0)
+    SCHK(hipMalloc((void**)&x, sizeof(double) * (size_t)W * ndim));
+    SCHK(hipMalloc((void**)&lp, sizeof(double) * (size_t)W));
+    SCHK(hipMalloc((void**)&q, sizeof(double) * (size_t)half * ndim));
+    SCHK(hipMalloc((void**)&lq, sizeof(double) * (size_t)half));
+    SCHK(hipMalloc((void**)&zz, sizeof(double) * (size_t)half));
+    SCHK(hipMalloc((void**)&nacc, sizeof(long long) * (size_t)W));
+    SCHK(hipMemsetAsync(nacc, 0, sizeof(long long) * (size_t)W, st));
+    if (chain_out && nsteps) SCHK(hipMalloc((void**)&chain, sizeof(double) * (size_t)nsteps * W * ndim));
+    if (logp_out && nsteps) SCHK(hipMalloc((void**)&lps, sizeof(double) * (size_t)nsteps * W));
+    SCHK(hipMemcpyAsync(x, theta0, sizeof(double) * (size_t)W * ndim, hipMemcpyHostToDevice, st));
+    int rc = jx_eval_device(ctx, x, W, lp);
+    if (rc) { cleanup(); return rc; }
+    {
+        std::vector<double> l0(W);
+        SCHK(hipMemcpyAsync(l0.data(), lp, sizeof(double) * W, hipMemcpyDeviceToHost, st));
+        SCHK(hipStreamSynchronize(st));
+        for (double v : l0) if (!std::isfinite(v)) { ctx->err = "initial positions must have finite log-posterior"; cleanup(); return JX_ERR_INVALID; }
+    }
+    const dim3 grid((half + 255) / 256), block(256);
+    for (int it = 0; it < nsteps; ++it) {
+        for (int hs = 0; hs < 2; ++hs) {
+            const int s1 = hs * half, s2 = (1 - hs) * half;
+            hipLaunchKernelGGL(jx_sm_propose_kernel, grid, block, 0, st, x, q, zz, ndim, half, s1, s2, 2 * it + hs, a, seed);
+            if ((rc = jx_eval_device(ctx, q, half, lq))) { cleanup(); return rc; }
+            hipLaunchKernelGGL(jx_sm_accept_kernel, grid, block, 0, st, x, lp, q, lq, zz, nacc, ndim, half, s1, 2 * it + hs, seed);
+        }
+        if (chain) SCHK(hipMemcpyAsync(chain + (size_t)it * W * ndim, x, sizeof(double) * (size_t)W * ndim, hipMemcpyDeviceToDevice, st));
+        if (lps) SCHK(hipMemcpyAsync(lps + (size_t)it * W, lp, sizeof(double) * (size_t)W, hipMemcpyDeviceToDevice, st));
+    }
+    if (chain) SCHK(hipMemcpyAsync(chain_out, chain, sizeof(double) * (size_t)nsteps * W * ndim, hipMemcpyDeviceToHost, st));
+    if (lps) SCHK(hipMemcpyAsync(logp_out, lps, sizeof(double) * (size_t)nsteps * W, hipMemcpyDeviceToHost, st));
+    if (naccept_out) SCHK(hipMemcpyAsync(naccept_out, nacc, sizeof(long long) * (size_t)W, hipMemcpyDeviceToHost, st));
+    SCHK(hipStreamSynchronize(st));
+    SCHK(hipGetLastError());
+#undef SCHK
+    cleanup();
+    return JX_OK;
+}
+
 int jx_set_stream(jx_ctx* ctx, void* hip_stream) {
     if (!ctx) return JX_ERR_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->cfg.device));

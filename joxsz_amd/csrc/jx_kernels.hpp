@@ -819,3 +819,60 @@ jx_tail_kernel(JxDev c, const double2* __restrict__ tfspec, const double2* __res
         if (tap_parts) tap_parts[(size_t)w * 4 + 1] = ll;
     }
 }
+
+// ------------------------------------------------------------------------------------
+// Device-resident stretch move (the caller of the hot path, joxsz_funcs.py:593-622 through emcee's
+// red/blue StretchMove).  Random numbers: Philox4x32-10 (Salmon et al. 2011), key = seed, counter =
+// (walker slot, 2 * iteration + half, draw, 0); a uniform double is ((hi << 32 | lo) >> 11) * 2^-53.
+// The arithmetic of the proposal is written without fused multiply-adds so that a host implementation with
+// separately rounded operations (joxsz_amd/sampler.py::DeviceStretchMove.replay) reproduces it bit for bit.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ void jx_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* out) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ double jx_u01(uint32_t hi, uint32_t lo) {
+    return (double)((((uint64_t)hi << 32) | lo) >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// proposals for the `half` walkers [s1, s1 + half) against the complementary ensemble [s2, s2 + half)
+__global__ void __launch_bounds__(256)
+jx_sm_propose_kernel(const double* __restrict__ x, double* __restrict__ q, double* __restrict__ zz, int ndim, int half, int s1, int s2,
+                     int iter2, double a, uint64_t seed) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= half) return;
+    uint32_t r[4];
+    jx_philox((uint32_t)i, (uint32_t)iter2, 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    const double u1 = jx_u01(r[0], r[1]), u2 = jx_u01(r[2], r[3]);
+    const double t = __dadd_rn(__dmul_rn(a - 1.0, u1), 1.0);
+    const double z = __ddiv_rn(__dmul_rn(t, t), a);                   // ((a-1) u + 1)^2 / a
+    int j = (int)__dmul_rn(u2, (double)half);
+    j = min(j, half - 1);
+    const double* xp = x + (size_t)(s2 + j) * ndim;
+    const double* xi = x + (size_t)(s1 + i) * ndim;
+    for (int d = 0; d < ndim; ++d) q[(size_t)i * ndim + d] = __dsub_rn(xp[d], __dmul_rn(__dsub_rn(xp[d], xi[d]), z));
+    zz[i] = z;
+}
+
+__global__ void __launch_bounds__(256)
+jx_sm_accept_kernel(double* __restrict__ x, double* __restrict__ lp, const double* __restrict__ q, const double* __restrict__ lq,
+                    const double* __restrict__ zz, long long* __restrict__ nacc, int ndim, int half, int s1, int iter2, uint64_t seed) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= half) return;
+    uint32_t r[4];
+    jx_philox((uint32_t)i, (uint32_t)iter2, 1u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    const double u3 = jx_u01(r[0], r[1]);
+    const double lnew = lq[i];
+    const double lnpdiff = __dadd_rn(__dmul_rn((double)(ndim - 1), log(zz[i])), __dsub_rn(lnew, lp[s1 + i]));
+    if (isfinite(lnew) && log(u3) < lnpdiff) {
+        for (int d = 0; d < ndim; ++d) x[(size_t)(s1 + i) * ndim + d] = q[(size_t)i * ndim + d];
+        lp[s1 + i] = lnew;
+        nacc[s1 + i] += 1;
+    }
+}

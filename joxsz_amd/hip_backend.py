@@ -14,7 +14,7 @@ ABI_VERSION = 1
 
 # must list every function include/joxsz_hip.h declares (tests/test_abi.py checks this)
 EXPORTS = (
-    'jx_create', 'jx_upload', 'jx_finalize', 'jx_eval', 'jx_eval_device', 'jx_sync', 'jx_set_stream', 'jx_eval_stage',
+    'jx_create', 'jx_upload', 'jx_finalize', 'jx_eval', 'jx_eval_device', 'jx_sync', 'jx_set_stream', 'jx_sample', 'jx_eval_stage',
     'jx_set_par_vals', 'jx_dev_alloc', 'jx_dev_free', 'jx_memcpy_h2d', 'jx_memcpy_d2h',
     'jx_timing_reset', 'jx_timing_enable', 'jx_timing_get', 'jx_get_info', 'jx_get_conv_mode', 'jx_get_conv_layout', 'jx_debug_workspace', 'jx_device_count',
     'jx_device_name', 'jx_strerror', 'jx_last_error', 'jx_destroy',
@@ -70,6 +70,7 @@ def load_library(path=None):
     lib.jx_eval_device.argtypes = [vp, vp, ci, vp]
     lib.jx_sync.argtypes = [vp]
     lib.jx_set_stream.argtypes = [vp, vp]
+    lib.jx_sample.argtypes = [vp, dp, ci, ci, ctypes.c_double, ctypes.c_uint64, dp, dp, ctypes.POINTER(ctypes.c_int64)]
     lib.jx_eval_stage.argtypes = [vp, dp, ci, ci, dp, cs]
     lib.jx_set_par_vals.argtypes = [vp, dp, ci]
     lib.jx_dev_alloc.argtypes = [vp, cs, ctypes.POINTER(vp)]
@@ -253,6 +254,17 @@ class HipContext:
 
     def eval_device(self, theta_ptr, nwalkers, logp_ptr):
         self._chk(self.lib.jx_eval_device(self._h, ctypes.c_void_p(theta_ptr), nwalkers, ctypes.c_void_p(logp_ptr)), 'jx_eval_device')
+
+    def sample(self, theta0, nsteps, a=2.0, seed=0):
+        """Device-resident stretch-move run (``jx_sample``): returns (chain[nsteps, W, ndim], logp[nsteps, W], naccept[W])."""
+        th = np.ascontiguousarray(theta0, dtype=np.float64)
+        W, ndim = th.shape
+        chain = np.empty((nsteps, W, ndim)); lps = np.empty((nsteps, W)); nacc = np.zeros(W, np.int64)
+        dp = ctypes.POINTER(ctypes.c_double)
+        self._chk(self.lib.jx_sample(self._h, th.ctypes.data_as(dp), W, int(nsteps), float(a), int(seed) & (2 ** 64 - 1),
+                                     chain.ctypes.data_as(dp), lps.ctypes.data_as(dp),
+                                     nacc.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))), 'jx_sample')
+        return chain, lps, nacc
 
     def set_stream(self, hip_stream):
         """Enqueue on the caller's hipStream_t (integer handle, e.g. ``torch.cuda.current_stream().cuda_stream``);

@@ -87,6 +87,12 @@ class JoxszPosterior:
         """Batched parity tap (see ``hip_backend.STAGES``)."""
         return self.ctx.eval_stage(theta, name)
 
+    def sample(self, p0, nsteps, a=2.0, seed=0):
+        """Device-resident stretch-move run from the start positions ``p0[W, ndim]`` (``jx_sample``; what ``mcmc.sample``
+        does with the reference's callable, joxsz_funcs.py:593-622, without a host round trip per step).
+        Returns (chain[nsteps, W, ndim], log_prob[nsteps, W], naccepted[W]) in emcee's chain layout."""
+        return self.ctx.sample(p0, nsteps, a, seed)
+
     def pool(self):
         return WalkerPool(self)
 

@@ -69,3 +69,68 @@ class StretchMoveSampler:
                 chain.append(x.copy())
                 lps.append(lp.copy())
         return np.array(chain), np.array(lps)
+
+
+# ---------------------------------------------------------------------------------------
+# Device-resident variant (jx_sample) and its host replay
+# ---------------------------------------------------------------------------------------
+_M0, _M1, _W0, _W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
+_MASK = 0xFFFFFFFF
+
+
+def philox4x32(c0, c1, c2, c3, seed):
+    """Philox4x32-10 on arrays of 32-bit counters, key = (seed & 0xffffffff, seed >> 32): the generator of jx_sample."""
+    c0, c1, c2, c3 = (np.asarray(v, dtype=np.uint64) & _MASK for v in np.broadcast_arrays(c0, c1, c2, c3))
+    k0, k1 = np.uint64(seed & _MASK), np.uint64((seed >> 32) & _MASK)
+    for _ in range(10):
+        p0, p1 = np.uint64(_M0) * c0, np.uint64(_M1) * c2
+        c0, c1, c2, c3 = ((p1 >> np.uint64(32)) ^ c1 ^ k0) & _MASK, p1 & _MASK, ((p0 >> np.uint64(32)) ^ c3 ^ k1) & _MASK, p0 & _MASK
+        k0, k1 = (k0 + np.uint64(_W0)) & np.uint64(_MASK), (k1 + np.uint64(_W1)) & np.uint64(_MASK)
+    return c0, c1, c2, c3
+
+
+def _u01(hi, lo):
+    return ((((hi << np.uint64(32)) | lo) >> np.uint64(11)).astype(np.float64)) * (1.0 / 9007199254740992.0)
+
+
+class DeviceStretchMove:
+    """The stretch move with the whole loop on the device (``JoxszPosterior.sample`` -> ``jx_sample``): proposals,
+    evaluation, accept/reject and the chain never leave the GPU.  ``replay`` runs the same algorithm on the host with
+    the same counter-based random numbers and any batched ``log_prob``: with the device's own ``log_prob`` it
+    reproduces the device chain exactly, which is how the test checks the kernels."""
+
+    def __init__(self, posterior, a=2.0, seed=0):
+        self.post, self.a, self.seed = posterior, float(a), int(seed)
+
+    def run(self, p0, nsteps):
+        return self.post.ctx.sample(p0, nsteps, self.a, self.seed)
+
+    def replay(self, p0, nsteps, log_prob=None):
+        log_prob = self.post.log_prob if log_prob is None else log_prob
+        x = np.array(p0, dtype=np.float64)
+        W, ndim = x.shape
+        half = W // 2
+        lp = np.asarray(log_prob(x), dtype=np.float64)
+        nacc = np.zeros(W, np.int64)
+        chain, lps = np.empty((nsteps, W, ndim)), np.empty((nsteps, W))
+        i = np.arange(half)
+        for it in range(nsteps):
+            for hs in (0, 1):
+                s1, s2 = hs * half, (1 - hs) * half
+                r = philox4x32(i, 2 * it + hs, 0, 0, self.seed)
+                u1, u2 = _u01(r[0], r[1]), _u01(r[2], r[3])
+                t = (self.a - 1.0) * u1 + 1.0
+                z = (t * t) / self.a
+                j = np.minimum((u2 * half).astype(np.int64), half - 1)
+                xp, xi = x[s2 + j], x[s1:s1 + half]
+                q = xp - (xp - xi) * z[:, None]
+                lq = np.asarray(log_prob(q), dtype=np.float64)
+                u3 = _u01(*philox4x32(i, 2 * it + hs, 1, 0, self.seed)[:2])
+                with np.errstate(invalid='ignore'):
+                    lnpdiff = (ndim - 1) * np.log(z) + (lq - lp[s1:s1 + half])
+                    acc = np.isfinite(lq) & (np.log(u3) < lnpdiff)
+                x[s1:s1 + half][acc] = q[acc]
+                lp[s1:s1 + half][acc] = lq[acc]
+                nacc[s1:s1 + half][acc] += 1
+            chain[it], lps[it] = x, lp
+        return chain, lps, nacc

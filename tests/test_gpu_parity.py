@@ -405,6 +405,29 @@ def test_fused_route_chunking():
     np.testing.assert_allclose(one[:6], want, rtol=RTOL)
 
 
+def test_device_sampler_against_host_replay():
+    """jx_sample (proposals, evaluation, accept/reject and chain on the device) against the same stretch move replayed
+    on the host with the same Philox counters and the device's own log-posterior: identical chain and acceptances."""
+    from joxsz_amd import datasets
+    from joxsz_amd.sampler import DeviceStretchMove, initial_ball
+    pb = datasets.synthetic_problem(S=64, N=80, seed=3)
+    p0f = orc.pars_dict(pb, datasets.fiducial_theta(pb))
+    datasets.fill_data(pb, orc.sz_stages(pb, p0f)['bright'], orc.calc_profiles(pb, p0f), seed=3)
+    post = _post(pb)
+    p0 = initial_ball(post.log_prob, datasets.fiducial_theta(pb), 28, spread=0.01, rng=np.random.default_rng(3))
+    sm = DeviceStretchMove(post, a=2.0, seed=1234)
+    chain, lps, nacc = sm.run(p0, 12)
+    rchain, rlps, rnacc = sm.replay(p0, 12)
+    post.close()
+    assert chain.shape == (12, 28, pb.ndim) and np.isfinite(lps).all()
+    assert 0 < nacc.sum() < 12 * 28                            # some proposals accepted, some rejected
+    np.testing.assert_array_equal(nacc, rnacc)
+    np.testing.assert_allclose(chain, rchain, rtol=1e-13, atol=0)
+    np.testing.assert_allclose(lps, rlps, rtol=1e-12)
+    # a different seed gives a different chain, the same seed the same one
+    assert not np.array_equal(chain, DeviceStretchMove(_post(pb), seed=99).run(p0, 12)[0])
+
+
 def test_largest_config_shape():
     """BASELINE configs[4] shape (S=1024, N=1000): two walkers against the oracle, both back ends."""
     from joxsz_amd import datasets

@@ -53,3 +53,27 @@ def test_config0_gpu_chain_equals_cpu_chain(golden_bundled):
     post.close()
     np.testing.assert_allclose(out['gpu'][0], out['cpu'][0], rtol=1e-12)      # same accept decisions, same chain
     np.testing.assert_allclose(out['gpu'][1], out['cpu'][1], rtol=1e-6)
+
+
+def test_philox_known_answers():
+    """The counter-based generator of the device sampler against the Random123 known-answer vectors for Philox4x32-10."""
+    from joxsz_amd.sampler import philox4x32
+    assert [int(v) for v in philox4x32(0, 0, 0, 0, 0)] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    m = 0xffffffff
+    assert [int(v) for v in philox4x32(m, m, m, m, 0xffffffffffffffff)] == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    r = philox4x32(np.arange(5), 3, 1, 0, 42)
+    assert all(a.shape == (5,) for a in r) and len({int(v) for v in r[0]}) == 5
+
+
+def test_device_sampler_replay_on_a_gaussian():
+    """The host replay of the device sampler's algorithm samples a Gaussian correctly (moments), with any log_prob."""
+    from joxsz_amd.sampler import DeviceStretchMove
+    ndim, W = 3, 40
+    sig = np.array([1.0, 0.5, 2.0])
+    sm = DeviceStretchMove(None, a=2.0, seed=7)
+    rng = np.random.default_rng(0)
+    chain, lps, nacc = sm.replay(rng.normal(size=(W, ndim)), 600, log_prob=lambda x: -0.5 * np.sum((x / sig) ** 2, axis=1))
+    flat = chain[200:].reshape(-1, ndim)
+    assert np.all(np.abs(flat.mean(axis=0)) < 0.15 * sig)
+    np.testing.assert_allclose(flat.std(axis=0), sig, rtol=0.12)
+    assert 0.2 < nacc.mean() / 600 < 0.8
