@@ -196,7 +196,7 @@ int  jx_get_conv_mode(jx_ctx* ctx);
  * low-rank form and pass 3 transforms `rank` combined rows per walker instead of NJ (JOXSZ_LOWRANK=0 turns it
  * off, JOXSZ_LOWRANK_TOL sets the singular-value cut relative to the largest one, default 1e-10); fused = 1: the FIR along rows and that
  * combination run as one matrix product per column kx on walker-minor row spectra (JOXSZ_FUSED=0: separate kernels),
- * for the kact columns below the beam's band limit (every tap beyond is under a tenth of the singular-value cut, relative to the largest; JOXSZ_BANDLIMIT=0
+ * for the kact columns below the beam's band limit (every tap beyond is under 0.03 of the singular-value cut, relative to the largest; JOXSZ_BANDLIMIT=0
  * keeps all P/2+1).  JX_ERR_UNSUPPORTED with the rocFFT back end. */
 int  jx_get_conv_layout(jx_ctx* ctx, int32_t out[12]);
 /* Test hook (hand-written convolution only): device address and geometry of a work buffer, holding the last

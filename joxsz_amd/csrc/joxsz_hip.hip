@@ -698,12 +698,12 @@ int jx_finalize(jx_ctx* ctx) {
 #undef JX_LR_PICK
             if (fuse && fb && (size_t)(RP / 16) * fb * 64 * sizeof(double) <= JX_LR_LDS_MAX) {
                 std::vector<double> Wk, V0, bc((size_t)nt * JX_COL0_LD, 0.0);
-                // band limit of the beam: past the last column with a tap above band_tol (a tenth of the singular-value cut:
-                // 1e-11 by default) of the largest one the combined rows are dropped like the small singular values are;
+                // band limit of the beam: past the last column with a tap above band_tol (0.03 of the singular-value cut:
+                // 3e-12 by default) of the largest one the combined rows are dropped like the small singular values are;
                 // those columns are neither stored by pass 1 nor multiplied (Ct stays at its zero fill)
                 int kact = cv.Ph;
                 {
-                    const double band_tol = 0.1 * ctx->lr_tol;
+                    const double band_tol = 0.03 * ctx->lr_tol;
                     double tmax = 0.0;
                     for (double v2 : ctx->h_taps) tmax = std::max(tmax, std::fabs(v2));
                     while (kact > 1) {

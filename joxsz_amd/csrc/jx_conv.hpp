@@ -63,7 +63,7 @@ struct JxConv {
     // fused FIR + job combination (JxFused): pass 1 writes its rows walker-minor, pass 3 reads rho-minor
     int tmode;                      // 1: pass 1 -> Rt[k][tKU][tW] (block = distinct row x walker group); pass 3 <- Ct[w][Ph][64], Ct0[w][JX_CT0_X][64]
     int tW, tKU, tn;                // walker stride (multiple of 16), padded distinct-row count, walkers in this launch
-    int kact;                       // columns kx < kact are kept: beyond, every beam tap is below a tenth of the singular-value cut
+    int kact;                       // columns kx < kact are kept: beyond, every beam tap is below 0.03 of the singular-value cut
     const double* ct0;              // [tW][JX_CT0_X][64] column-0 terms of the combined rows
     int quad;                       // 1: the map arrives as its quadrant [S/2+1][img_ld] of distinct pixels (|iy-c|, |ix-c|)
     const cplx* zab;                // [LP][2] pass-3 pre-process factors: Z[k] = zab[k][0] Rc[k] + zab[k][1] Rc[LP-k]   (xsym)
