@@ -266,6 +266,9 @@ def main():
             'cpu_baseline': cpu,
             'stage_ms_per_step': {k: tm[k] / args.steps for k in
                                   ('prep_ms', 'abel_map_ms', 'beam_fft_ms', 'tf_fft_ms', 'tail_ms', 'total_ms')},
+            'stage_kernels': ({'prep_ms': 'jx_prep_kernel', 'abel_map_ms': 'jx_abel_map_sym_kernel (graded)', 'beam_fft_ms': 'jx_rowfft2_kernel (pass 1)',
+                               'tf_fft_ms': 'jx_lowrank_kernel (fp64 MFMA GEMM) + jx_rowtf2_kernel (pass 3)', 'tail_ms': 'jx_tail_fft_kernel'}
+                              if (ctx.conv_layout or {}).get('fused') else None),
             'parity_max_rel_err': parity,
         }
         print(json.dumps(out))
