@@ -6,6 +6,6 @@ plus rocFFT, reached through the C-ABI declared in ``include/joxsz_hip.h``
 fallback: constructing ``JoxszPosterior`` without the built library raises.
 """
 from .problem import Problem, default_par_table, PAR_SLOTS  # noqa: F401
-from . import datasets, setup_host  # noqa: F401
+from . import datasets, setup_host, chain, profiles  # noqa: F401
 
-__all__ = ['Problem', 'default_par_table', 'PAR_SLOTS', 'datasets', 'setup_host']
+__all__ = ['Problem', 'default_par_table', 'PAR_SLOTS', 'datasets', 'setup_host', 'chain', 'profiles']

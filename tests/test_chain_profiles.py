@@ -1,0 +1,133 @@
+"""The callers either side of the log-posterior: chain layouts and storage, the MCMC run, and
+the batched chain summaries, each against a per-sample loop over the oracle (what the reference's plotting code does)."""
+import numpy as np
+import pytest
+from scipy import optimize
+
+from joxsz_amd import chain as ch, datasets, profiles as pr
+from oracle import joxsz_oracle as orc
+
+
+def test_chain_layouts_and_storage(tmp_path):
+    rng = np.random.default_rng(0)
+    c = rng.normal(size=(7, 6, 3))                                   # [nsteps, W, ndim]
+    cube = ch.cube_chain(c)
+    assert cube.shape == (6, 7, 3) and np.array_equal(cube[4, 2], c[2, 4])
+    flat = ch.flat_chain(cube)
+    assert flat.shape == (42, 3)
+    assert np.array_equal(flat[:6], c[0]) and np.array_equal(flat[6 + 1], c[1, 1])     # walker index fastest
+    lp = rng.normal(size=(7, 6))
+    path = tmp_path / 'run_chain.npz'
+    ch.save_chain(path, c, lp, ['log(n_0)', r'\beta', 'P_0'], burn=500, thin=5, accepted=np.arange(6))
+    back = ch.load_chain(path)
+    assert np.array_equal(back['chain'], c) and np.array_equal(back['log_prob'], lp)
+    assert back['param_names'] == ['log(n_0)', r'\beta', 'P_0'] and (back['burn'], back['thin']) == (500, 5)
+    assert np.array_equal(back['accepted'], np.arange(6))
+    with pytest.raises(ValueError):
+        ch.save_chain(path, c, lp[:, :5], ['a', 'b', 'c'], 0, 1)
+
+
+def test_equal_tailed_and_subset():
+    rng = np.random.default_rng(1)
+    data = rng.normal(size=(2001, 4))
+    lo, med, up = ch.equal_tailed(data, ci=90)
+    s = np.sort(data, axis=0)
+    np.testing.assert_allclose(med, s[1000])
+    np.testing.assert_allclose(lo, s[100])
+    np.testing.assert_allclose(up, s[1900])
+    cube = rng.normal(size=(5, 8, 3))
+    a, b = ch.chain_subset(cube, 12, seed=3), ch.chain_subset(cube, 12, seed=3)
+    assert np.array_equal(a, b) and a.shape == (12, 3)
+    rows = {tuple(r) for r in cube.reshape(-1, 3)}
+    assert all(tuple(r) in rows for r in a) and len({tuple(r) for r in a}) == 12     # without replacement
+    assert {tuple(r) for r in ch.chain_subset(cube, 'all', seed=0)} == rows
+
+
+def test_mcmc_run_on_a_gaussian():
+    sig = np.array([1., 2., 0.5])
+    logp = lambda t: -0.5 * np.sum(((np.atleast_2d(t) - 5.) / sig) ** 2, axis=1)
+    out = ch.mcmc_run(logp, 24, nburn=100, nsteps=600, nthin=2, theta0=np.full(3, 5.), seed=4, prelim_iters=50, max_prelim=3)
+    assert out['chain'].shape == (300, 24, 3) and out['log_prob'].shape == (300, 24)
+    flat = ch.flat_chain(ch.cube_chain(out['chain']))
+    np.testing.assert_allclose(flat.std(axis=0), sig, rtol=0.2)
+    np.testing.assert_allclose(flat.mean(axis=0), 5., atol=0.4)
+    assert 0.2 < out['acceptance_fraction'] < 0.9 and 1 <= out['prelim_blocks'] <= 3
+    # a stored position has the stored log-posterior
+    np.testing.assert_allclose(logp(out['chain'][-1]), out['log_prob'][-1])
+
+
+@pytest.mark.parametrize('ne_mode', ['single', 'double'])
+def test_profiles_against_per_sample_loop(ne_mode):
+    pb = datasets.synthetic_problem(S=32, N=40, seed=7, ne_mode=ne_mode)
+    thetas = datasets.walker_ball(pb, 9, spread=0.05, seed=1)
+    got = pr.thermodynamic_profs(pb, thetas)
+    p = pr.par_table(pb, thetas)
+    mass = pr.hydrostatic_mass(pb, p, pb.r_pp)
+    for i, th in enumerate(thetas):
+        q = orc.pars_dict(pb, th)
+        dens, press = orc.vikh_function(q, pb.r_pp, ne_mode), orc.press_fun(q, pb.r_pp)
+        np.testing.assert_allclose(got['dens'][i], dens, rtol=1e-13)
+        np.testing.assert_allclose(got['press'][i], press, rtol=1e-13)
+        np.testing.assert_allclose(got['temp'][i], orc.temp_fun(q, pb.r_pp, ne_mode, getT_SZ=True), rtol=1e-13)
+        np.testing.assert_allclose(got['tempx'][i], orc.temp_fun(q, pb.r_pp, ne_mode), rtol=1e-13)
+        np.testing.assert_allclose(got['entr'][i], (press / dens) / dens ** (2 / 3), rtol=1e-13)
+        np.testing.assert_allclose(mass[i], orc.mass_fun(q, pb.r_pp, ne_mode), rtol=1e-12)
+        # cumulative gas mass: shell by shell (joxsz_plots.py:208-217)
+        edg = np.append(pb.r_pp[0] / 2, pb.r_pp + pb.r_pp[0] / 2) * pr.kpc_cm
+        shell = dens * pr.mu_e * pr.mu_g / pr.solar_mass_g * 4 / 3 * np.pi * (edg[1:] ** 3 - edg[:-1] ** 3)
+        want = np.array([shell[:k].sum() + shell[k] * pr.inner_fraction(edg)[k] for k in range(pb.N)])
+        np.testing.assert_allclose(got['cmgas'][i], want, rtol=1e-12)
+    cube = thetas.reshape(3, 3, -1)
+    summ = pr.comp_rad_profs(cube, pb, ci=80)
+    assert summ['dens'].shape == (3, pb.N) and np.all(summ['dens'][0] <= summ['dens'][1]) and np.all(summ['dens'][1] <= summ['dens'][2])
+    fg = pr.frac_gas_prof(cube, pb)
+    assert fg.shape == (3, pb.N) and np.all(np.isfinite(fg))
+
+
+def test_overdensity_radius_against_scipy_newton():
+    pb = datasets.synthetic_problem(S=32, N=40, seed=7)
+    thetas = datasets.walker_ball(pb, 6, spread=0.03, seed=2)
+    cosmo = dict(z=0.89, H0=67.32, WM=0.3158, WV=0.6842)            # joxsz_main.py:26-31
+    r_d, m_d = pr.overdensity_radius(pb, thetas, cosmo)
+    found = 0
+    for i, th in enumerate(thetas):
+        q = orc.pars_dict(pb, th)
+        try:
+            with np.errstate(all='ignore'):
+                want = optimize.newton(lambda r: orc.mass_fun(q, r) - pr.critical_mass(r, **cosmo), 700.)
+        except RuntimeError:                                         # the secant walk left the positive radii
+            assert np.isnan(r_d[i])
+            continue
+        found += 1
+        np.testing.assert_allclose(r_d[i], want, rtol=1e-7)
+        np.testing.assert_allclose(m_d[i], orc.mass_fun(q, want), rtol=1e-6)
+        np.testing.assert_allclose(m_d[i], pr.critical_mass(r_d[i], **cosmo), rtol=1e-6)
+    assert found >= 3
+    cube = thetas.reshape(2, 3, -1)
+    mass, rd, md = pr.comp_mass_prof(cube, pb, cosmo)
+    assert mass.shape == (3, pb.N) and rd.shape == (3, 1) and md.shape == (3, 1)
+    assert pr.comp_mass_prof(cube, pb, overdens=False).shape == (3, pb.N)
+
+
+@pytest.mark.gpu
+def test_best_fit_prof_and_device_run():
+    """``best_fit_prof`` over a chain the device sampler produced, against one oracle call per sample."""
+    from joxsz_amd.posterior import JoxszPosterior
+    pb = datasets.synthetic_problem(S=64, N=80, seed=3)
+    post = JoxszPosterior(pb, device=0)
+    pb.par_vals[pb.thawed_idx] = datasets.fiducial_theta(pb)
+    post.updateThawed(datasets.fiducial_theta(pb))
+    out = ch.mcmc_run(post, 32, nburn=6, nsteps=8, nthin=2, initspread=0.01, seed=2, prelim_iters=5, max_prelim=2)
+    assert out['chain'].shape == (4, 32, pb.ndim) and np.all(np.isfinite(out['log_prob']))
+    np.testing.assert_allclose(post.log_prob(out['chain'][-1]), out['log_prob'][-1], rtol=1e-12)
+    cube = ch.cube_chain(out['chain'])
+    px, ps = ch.best_fit_prof(cube, post, num=10, seed=5, ci=80, batch=4)
+    thetas = ch.chain_subset(cube, 10, seed=5)
+    wx, ws = [], []
+    for th in thetas:
+        q = orc.pars_dict(pb, th)
+        wx.append(orc.calc_profiles(pb, q))
+        ws.append(orc.get_sz_like(pb, q, output='bright'))
+    np.testing.assert_allclose(px, ch.equal_tailed(np.array(wx), 80), rtol=1e-9)
+    np.testing.assert_allclose(ps, ch.equal_tailed(np.array(ws), 80), rtol=1e-7, atol=1e-9 * np.abs(np.array(ws)).max())
+    post.close()
