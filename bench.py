@@ -110,6 +110,8 @@ def main():
     ap.add_argument('--sz-only', action='store_true')
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
+    ap.add_argument('--route', choices=('map', 'operator'), default='map',
+                    help="'map': the reference's sequence of steps per walker (the BASELINE metric); 'operator': the collapsed route (jx_set_route)")
     ap.add_argument('--fwhm', type=float, default=18.5, help='beam FWHM in arcsec (B = 2*floor(3*fwhm/step)+1)')
     args = ap.parse_args()
 
@@ -151,6 +153,8 @@ def main():
     # parity spot-check of the CPU sample on the very same problem tensors
     parity = None
     if cpu_sample is not None:
+        if args.route != 'map':
+            ctx.set_route(args.route)
         got = ctx.eval(cpu_sample)
         fin = np.isfinite(cpu_logp)
         if not np.array_equal(np.isfinite(got), fin) and not os.environ.get('JOXSZ_DBG'):
@@ -168,6 +172,8 @@ def main():
     datasets.fill_data(pb, bright, xprofs, seed=0)
     post = JoxszPosterior(pb, device=local_rank)
     ctx = post.ctx
+    if args.route != 'map':
+        ctx.set_route(args.route)
     cand = datasets.walker_ball(pb, 4 * W, spread=0.02, seed=100 + rank)
     lp = ctx.eval(cand)
     good = cand[np.isfinite(lp)]
@@ -253,7 +259,7 @@ def main():
                                    % (W, S, S, args.N, 'SZ-only' if pb.sz_only else 'joint X-ray+SZ',
                                       ' (BASELINE configs[2])' if (W, S, args.N, pb.sz_only) == (1024, 512, 500, False) else ''),
                        'walkers_per_gpu': W, 'S': S, 'N': args.N, 'B': pb.B, 'fft_pad': ctx.fft_pad,
-                       'chunk': ctx.chunk, 'conv': ctx.conv, 'conv_layout': ctx.conv_layout, 'parallelism': 'walkers sharded x%d' % world, 'device': ctx.device_name},
+                       'chunk': ctx.chunk, 'route': ctx.route, 'conv': ctx.conv, 'conv_layout': ctx.conv_layout, 'parallelism': 'walkers sharded x%d' % world, 'device': ctx.device_name},
             'roofline': {'kernel': 'jx_abel_map_sym_kernel', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': pmc_traffic('jx_abel_map', walkers_per_launch, S),

@@ -164,6 +164,22 @@ int  jx_set_stream(jx_ctx* ctx, void* hip_stream);
  * be replayed on the host (joxsz_amd/sampler.py). */
 int  jx_sample(jx_ctx* ctx, const double* theta0_host, int nwalkers, int nsteps, double a, uint64_t seed,
                double* chain_out, double* logp_out, int64_t* naccept_out);
+/* Route of jx_eval / jx_eval_device / jx_sample for the SZ side of the log-posterior.
+ *   JX_ROUTE_MAP (default): the reference's own sequence, joxsz_funcs.py:453-472 -- profile, Abel integral, Compton-y
+ *       map, beam convolution, transfer function, central row -- every walker, every call.
+ *   JX_ROUTE_OPERATOR: those steps are linear in the pressure profile with constant coefficients, so the row is
+ *       G pp with one constant nrow x N matrix.  Switching to this route builds G once by sending the N unit profiles
+ *       through the MAP route's kernels (a few launches); afterwards a walker costs press_fun + one nrow x N
+ *       matrix-vector product on the SZ side.  Same results to rounding (the operator inherits the MAP route's own
+ *       truncation, see jx_get_conv_layout); works for every map size, odd sides included.
+ * jx_eval_stage always runs the MAP route (the intermediate stages do not exist on the other one).  The data tensors
+ * G depends on (r_pp, d_mat, beam_2d, filtering, step, constants) are fixed at jx_finalize, so G never goes stale. */
+enum { JX_ROUTE_MAP = 0, JX_ROUTE_OPERATOR = 1 };
+int  jx_set_route(jx_ctx* ctx, int route);
+int  jx_get_route(jx_ctx* ctx);
+/* Copy of G as the library holds it, out_host[N][nrow] (column j = row response of the unit profile e_j);
+ * JX_ERR_STATE before the operator route was first selected. */
+int  jx_get_operator(jx_ctx* ctx, double* out_host, size_t nbytes);
 /* Parity/debug tap: evaluates and copies one intermediate quantity to host. */
 int  jx_eval_stage(jx_ctx* ctx, const double* theta_host, int nwalkers, int stage_id,
                    double* out_host, size_t nbytes);

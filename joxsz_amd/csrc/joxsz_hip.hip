@@ -96,6 +96,11 @@ struct jx_ctx {
     double *t_pp = nullptr, *t_ab = nullptr, *t_y = nullptr, *t_row = nullptr, *t_bright = nullptr,
            *t_chisq = nullptr, *t_tprof = nullptr, *t_xprofs = nullptr, *t_parts = nullptr;
 
+    // collapsed route (jx_set_route): Gt [N][g_ld], row j = map row of the unit pressure profile e_j
+    int route = JX_ROUTE_MAP;
+    double* d_G = nullptr;
+    int g_ld = 0;
+
     std::map<int, Plan3> plans;
     rocfft_execution_info info = nullptr;
 
@@ -942,6 +947,20 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
                            ctx->d_base, ctx->d_cfac, t.tprof, t.xprofs, t.parts);
     }
     if (tm) HIPCHK(ctx, hipEventRecord(es.e[1], st));
+    if (ctx->route == JX_ROUTE_OPERATOR && !t.pp && !d.inject_pp) {
+        // collapsed route: the SZ side is one kernel (no map, no transforms); the stage events in between coincide
+        if (tm) for (int k = 2; k <= 4; ++k) HIPCHK(ctx, hipEventRecord(es.e[k], st));
+        const int N = d.N, nrow = d.nrow;
+        const size_t sh = sizeof(double) * ((size_t)JX_OP_WPB * (32 + ((N + 1) & ~1) + ((nrow + 1) & ~1)) + 8);
+        hipLaunchKernelGGL(jx_operator_kernel, dim3((n + JX_OP_WPB - 1) / JX_OP_WPB), dim3(256), sh, st, d, theta_dev, w0, n,
+                           ctx->d_G, ctx->g_ld, ctx->d_cfac, ctx->d_base, logp_dev, t.row, t.bright, t.chisq, t.parts);
+        if (tm) {
+            HIPCHK(ctx, hipEventRecord(es.e[5], st));
+            ctx->ev_inflight.push_back(es);
+        }
+        HIPCHK(ctx, hipGetLastError());
+        return JX_OK;
+    }
     {
         const bool vec2 = (d.S % 2 == 0) && (d.P % 2 == 0);
         const int npw = (d.quad && d.pairw == 2) ? 2 : 1;
@@ -1074,6 +1093,81 @@ int jx_sample(jx_ctx* ctx, const double* theta0, int nwalkers, int nsteps, doubl
     SCHK(hipGetLastError());
 #undef SCHK
     cleanup();
+    return JX_OK;
+}
+
+static int ensure_taps(jx_ctx* ctx);
+
+// G by the MAP route's own kernels: the unit profiles e_j go in as injected pressure profiles, their map rows come out
+// of the row tap.  (theta only feeds the prep kernel here; the current parameter values keep it on ordinary numbers.)
+static int build_operator(jx_ctx* ctx) {
+    const jx_config& c = ctx->cfg;
+    const int N = c.N, nrow = ctx->nrow, ld = (nrow + 15) & ~15;
+    int rc;
+    if ((rc = ensure_taps(ctx))) return rc;
+    if ((rc = ensure_batch(ctx, ctx->chunk))) return rc;
+    double* G = nullptr;
+    double* inj = nullptr;
+    if ((rc = dev_new(ctx, (size_t)N * ld, &G, true))) return rc;
+    HIPCHK(ctx, hipMalloc((void**)&inj, sizeof(double) * (size_t)ctx->chunk * N));
+    std::vector<double> th((size_t)ctx->chunk * c.ndim);
+    {
+        const std::vector<double> pv = host_vec<double>(ctx, JX_T_PAR_VALS);
+        const std::vector<int32_t> ti = host_vec<int32_t>(ctx, JX_T_THAWED_IDX);
+        for (int w = 0; w < ctx->chunk; ++w) for (int k = 0; k < c.ndim; ++k) th[(size_t)w * c.ndim + k] = pv[ti[k]];
+    }
+    hipStream_t st = ctx->stream;
+    const bool tm = ctx->timing_on;
+    auto fail = [&](int code) { (void)hipStreamSynchronize(st); ctx->d.inject_pp = nullptr; ctx->timing_on = tm; (void)hipFree(inj); return code; };
+    if (hipMemcpyAsync(ctx->d_theta, th.data(), sizeof(double) * th.size(), hipMemcpyHostToDevice, st) != hipSuccess) return fail(JX_ERR_HIP);
+    Taps t;
+    t.pp = ctx->t_pp; t.ab = ctx->t_ab; t.y = ctx->t_y; t.row = ctx->t_row; t.bright = ctx->t_bright;
+    t.chisq = ctx->t_chisq; t.tprof = ctx->t_tprof; t.xprofs = c.sz_only ? nullptr : ctx->t_xprofs; t.parts = ctx->t_parts;
+    std::vector<double> eye;
+    ctx->timing_on = false;
+    for (int j0 = 0; j0 < N; j0 += ctx->chunk) {
+        const int n = std::min(ctx->chunk, N - j0);
+        eye.assign((size_t)n * N, 0.0);
+        for (int w = 0; w < n; ++w) eye[(size_t)w * N + j0 + w] = 1.0;
+        if (hipMemcpyAsync(inj, eye.data(), sizeof(double) * eye.size(), hipMemcpyHostToDevice, st) != hipSuccess) return fail(JX_ERR_HIP);
+        ctx->d.inject_pp = inj;
+        rc = run_chunk(ctx, ctx->d_theta, ctx->d_logp, 0, n, t);
+        ctx->d.inject_pp = nullptr;
+        if (rc) return fail(rc);
+        if (hipMemcpy2DAsync(G + (size_t)j0 * ld, sizeof(double) * ld, ctx->t_row, sizeof(double) * nrow, sizeof(double) * nrow, n,
+                             hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(JX_ERR_HIP);
+        if (hipStreamSynchronize(st) != hipSuccess) return fail(JX_ERR_HIP);
+    }
+    ctx->timing_on = tm;
+    (void)hipFree(inj);
+    ctx->d_G = G;
+    ctx->g_ld = ld;
+    return JX_OK;
+}
+
+int jx_set_route(jx_ctx* ctx, int route) {
+    if (!ctx || (route != JX_ROUTE_MAP && route != JX_ROUTE_OPERATOR)) return JX_ERR_INVALID;
+    if (!ctx->finalized) { ctx->err = "jx_set_route before jx_finalize"; return JX_ERR_STATE; }
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    if (route == JX_ROUTE_OPERATOR && !ctx->d_G) {
+        const int rc = build_operator(ctx);
+        if (rc) return rc;
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->route = route;
+    return JX_OK;
+}
+
+int jx_get_route(jx_ctx* ctx) { return ctx ? ctx->route : JX_ERR_INVALID; }
+
+int jx_get_operator(jx_ctx* ctx, double* out, size_t nbytes) {
+    if (!ctx || !out) return JX_ERR_INVALID;
+    if (!ctx->d_G) { ctx->err = "jx_get_operator: the operator route was never selected"; return JX_ERR_STATE; }
+    if (nbytes != sizeof(double) * (size_t)ctx->cfg.N * ctx->nrow) { ctx->err = "jx_get_operator: wrong output size"; return JX_ERR_INVALID; }
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    HIPCHK(ctx, hipMemcpy2DAsync(out, sizeof(double) * ctx->nrow, ctx->d_G, sizeof(double) * ctx->g_ld, sizeof(double) * ctx->nrow,
+                                 ctx->cfg.N, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return JX_OK;
 }
 

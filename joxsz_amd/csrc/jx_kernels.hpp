@@ -50,6 +50,7 @@ struct JxDev {
     const double* d_mat;         // [S*S]
     long long img_ld, img_ws;    // row and walker strides (doubles) of the y-map image
     int dbg;                     // timing-only ablations (JOXSZ_DBG): 1 skip phases 1-4, 2 skip phase 5, 4 phase 5 stores only
+    const double* inject_pp;     // operator build only: [nlaunch][N] pressure profiles that replace press_fun(theta) (else null)
     int fast_map, q_na, q_nb;    // symmetric-map form: table sizes (|ix-c|, |iy-c|)
     double* xcol;                // quad mode: copy of the quadrant's last column (map column 0): [chunk][q_nb], or walker-minor
     long long xcol_ld;           //   [q_nb padded][xcol_ld] when xcol_ld > 0 (fused FIR path)
@@ -373,7 +374,7 @@ __device__ __forceinline__ void jx_profile_to_coefs(const JxDev& c, const double
         const double r = t0.x;
         s_r[j] = r;
         s_ds[j] = t1;
-        const double v = (c.dbg & 32) ? r : jx_press(p, r);
+        const double v = c.inject_pp ? c.inject_pp[(size_t)w * N + j] : ((c.dbg & 32) ? r : jx_press(p, r));
         s_pp[j] = v;
         s_rq[j] = make_double2(r * r, t0.y * v);
         if (taps && tap_pp) tap_pp[(size_t)w * N + j] = v;
@@ -817,6 +818,114 @@ jx_tail_kernel(JxDev c, const double2* __restrict__ tfspec, const double2* __res
         logp[w0 + w] = tot;
         if (tap_chisq) tap_chisq[w] = chisq;
         if (tap_parts) tap_parts[(size_t)w * 4 + 1] = ll;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Collapsed route (jx_set_route(ctx, JX_ROUTE_OPERATOR)).  Between the pressure profile and the extracted map row
+// every step of joxsz_funcs.py:457-472 is linear with constant coefficients (Abel matrix, spline through fixed knots
+// evaluated at fixed radii, beam convolution, transfer function, row extraction), so
+//     map_row[x] = sum_j G[x][j] pp[j]
+// with one constant nrow x N matrix.  G is not derived separately: jx_set_route pushes the N unit profiles through
+// the kernels above (inject_pp) and stores their rows, Gt[j][x] (row stride ldg).  This kernel is then the whole SZ
+// side of a walker: pp = press_fun(theta) -> G pp -> conversion -> data radii -> chi^2 -> total (as jx_tail_kernel).
+// One block of 256 threads for JX_OP_WPB walkers: every G entry fetched once serves all of them.
+// LDS: [JX_OP_WPB][32] parameters, [JX_OP_WPB][Ne] profiles, [JX_OP_WPB][nrow_e] rows, 8 scratch.
+// ------------------------------------------------------------------------------------
+#define JX_OP_WPB 4
+__global__ void __launch_bounds__(256)
+jx_operator_kernel(JxDev c, const double* __restrict__ theta, int w0, int n, const double* __restrict__ Gt, int ldg,
+                   const double* __restrict__ cfac, const double* __restrict__ base, double* __restrict__ logp,
+                   double* __restrict__ tap_row, double* __restrict__ tap_bright, double* __restrict__ tap_chisq,
+                   double* __restrict__ tap_parts) {
+    JX_LDS_DECL;
+    const int N = c.N, nrow = c.nrow, Ne = (N + 1) & ~1, Re = (nrow + 1) & ~1;
+    double* s_p = sm;                                   // [WPB][32]
+    double* s_pp = s_p + JX_OP_WPB * 32;                // [WPB][Ne]
+    double* s_prof = s_pp + JX_OP_WPB * Ne;             // [WPB][Re]
+    double* red = s_prof + JX_OP_WPB * Re;              // [8]
+    const int tid = threadIdx.x, nth = blockDim.x;
+    const int wb = blockIdx.x * JX_OP_WPB;
+    const int nw = min(JX_OP_WPB, n - wb);
+
+    for (int k = 0; k < JX_OP_WPB; ++k)                 // (a missing walker repeats the block's first: finite work, never stored)
+        jx_load_params(c, theta, w0 + wb + (k < nw ? k : 0), s_p + 32 * k);
+    for (int j = tid; j < N; j += nth) {
+        const double r = c.abel_tab[4 * (size_t)j];
+#pragma unroll
+        for (int k = 0; k < JX_OP_WPB; ++k) s_pp[k * Ne + j] = jx_press(s_p + 32 * k, r);
+    }
+    __syncthreads();
+
+    for (int x = tid; x < nrow; x += nth) {
+        double a[JX_OP_WPB][2];
+#pragma unroll
+        for (int k = 0; k < JX_OP_WPB; ++k) a[k][0] = a[k][1] = 0.0;
+        const double* g = Gt + x;
+        int j = 0;
+        for (; j + 1 < N; j += 2) {
+            const double g0 = g[(size_t)j * ldg], g1 = g[(size_t)(j + 1) * ldg];
+#pragma unroll
+            for (int k = 0; k < JX_OP_WPB; ++k) {
+                const double2 v = *reinterpret_cast<const double2*>(s_pp + k * Ne + j);
+                a[k][0] = fma(g0, v.x, a[k][0]);
+                a[k][1] = fma(g1, v.y, a[k][1]);
+            }
+        }
+        if (j < N) {
+            const double g0 = g[(size_t)j * ldg];
+#pragma unroll
+            for (int k = 0; k < JX_OP_WPB; ++k) a[k][0] = fma(g0, s_pp[k * Ne + j], a[k][0]);
+        }
+#pragma unroll
+        for (int k = 0; k < JX_OP_WPB; ++k) {
+            const double row = a[k][0] + a[k][1];
+            double b = 0.0;
+            if (k < nw) {
+                const size_t o = (size_t)(wb + k) * nrow + x;
+                b = row * cfac[o];
+                if (tap_row) tap_row[o] = row;
+                if (tap_bright) tap_bright[o] = b;
+            }
+            s_prof[k * Re + x] = b;
+        }
+    }
+    __syncthreads();
+
+    double part[JX_OP_WPB];
+#pragma unroll
+    for (int k = 0; k < JX_OP_WPB; ++k) part[k] = 0.0;
+    for (int d = tid; d < c.nflux; d += nth) {
+        const double* e = c.emat + (size_t)d * nrow;
+        double m[JX_OP_WPB];
+#pragma unroll
+        for (int k = 0; k < JX_OP_WPB; ++k) m[k] = 0.0;
+        for (int x = 0; x < nrow; ++x) {
+            const double ev = e[x];
+#pragma unroll
+            for (int k = 0; k < JX_OP_WPB; ++k) m[k] = fma(ev, s_prof[k * Re + x], m[k]);
+        }
+        const double f = c.flux[c.nflux + d], er = c.flux[2 * c.nflux + d];
+#pragma unroll
+        for (int k = 0; k < JX_OP_WPB; ++k) {
+            const double z = (f - m[k]) / er;
+            const double z2 = z * z;
+            if (z2 == z2) part[k] += z2;                 // np.nansum drops NaN terms
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < JX_OP_WPB; ++k) {
+        const double chisq = jx_block_sum(part[k], red);
+        if (tid == 0 && k < nw) {
+            const int w = wb + k;
+            const double ll = -chisq / 2.0;
+            const double b = base[w];
+            double tot = (b == -INFINITY) ? -INFINITY : b + ll;
+            if (tot != tot) tot = -INFINITY;             // never hand NaN to the sampler
+            logp[w0 + w] = tot;
+            if (tap_chisq) tap_chisq[w] = chisq;
+            if (tap_parts) tap_parts[(size_t)w * 4 + 1] = ll;
+        }
     }
 }
 

@@ -15,6 +15,7 @@ ABI_VERSION = 1
 # must list every function include/joxsz_hip.h declares (tests/test_abi.py checks this)
 EXPORTS = (
     'jx_create', 'jx_upload', 'jx_finalize', 'jx_eval', 'jx_eval_device', 'jx_sync', 'jx_set_stream', 'jx_sample', 'jx_eval_stage',
+    'jx_set_route', 'jx_get_route', 'jx_get_operator',
     'jx_set_par_vals', 'jx_dev_alloc', 'jx_dev_free', 'jx_memcpy_h2d', 'jx_memcpy_d2h',
     'jx_timing_reset', 'jx_timing_enable', 'jx_timing_get', 'jx_get_info', 'jx_get_conv_mode', 'jx_get_conv_layout', 'jx_debug_workspace', 'jx_device_count',
     'jx_device_name', 'jx_strerror', 'jx_last_error', 'jx_destroy',
@@ -70,6 +71,9 @@ def load_library(path=None):
     lib.jx_eval_device.argtypes = [vp, vp, ci, vp]
     lib.jx_sync.argtypes = [vp]
     lib.jx_set_stream.argtypes = [vp, vp]
+    lib.jx_set_route.argtypes = [vp, ci]
+    lib.jx_get_route.argtypes = [vp]
+    lib.jx_get_operator.argtypes = [vp, dp, cs]
     lib.jx_sample.argtypes = [vp, dp, ci, ci, ctypes.c_double, ctypes.c_uint64, dp, dp, ctypes.POINTER(ctypes.c_int64)]
     lib.jx_eval_stage.argtypes = [vp, dp, ci, ci, dp, cs]
     lib.jx_set_par_vals.argtypes = [vp, dp, ci]
@@ -103,6 +107,7 @@ def load_library(path=None):
 
 
 CONV_MODES = {'auto': 0, 'rocfft': 1, 'custom': 2}
+ROUTES = {'map': 0, 'operator': 1}
 
 
 def config_from_problem(pb, device=0, max_batch=0, fft_pad=0, map_split=0, conv='auto'):
@@ -128,7 +133,7 @@ def config_from_problem(pb, device=0, max_batch=0, fft_pad=0, map_split=0, conv=
 class HipContext:
     """Thin owner of one ``jx_ctx``: uploads a ``Problem`` and evaluates batches."""
 
-    def __init__(self, pb, device=0, max_batch=0, fft_pad=0, map_split=0, conv='auto', lib_path=None):
+    def __init__(self, pb, device=0, max_batch=0, fft_pad=0, map_split=0, conv='auto', lib_path=None, route=None):
         self._h = ctypes.c_void_p()
         self.lib = load_library(lib_path)
         pb.validate()
@@ -162,6 +167,14 @@ class HipContext:
             lay = (ctypes.c_int32 * 12)()
             self._chk(self.lib.jx_get_conv_layout(self._h, lay), 'jx_get_conv_layout')
             self.conv_layout = dict(zip(('xsym', 'quad', 'NU', 'NJ', 'ld', 'img_rows', 'img_ld', 'P', 'rank', 'fused', 'kact'), [int(v) for v in lay]))
+        self.route = 'map'
+        route = route or os.environ.get('JOXSZ_ROUTE')
+        if route and route != 'map':
+            try:
+                self.set_route(route)
+            except Exception:
+                self.close()
+                raise
 
     # -- plumbing --
     def _chk(self, rc, what):
@@ -265,6 +278,21 @@ class HipContext:
                                      chain.ctypes.data_as(dp), lps.ctypes.data_as(dp),
                                      nacc.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))), 'jx_sample')
         return chain, lps, nacc
+
+    def set_route(self, route):
+        """'map': the reference's own sequence of steps for every walker (default).  'operator': the SZ side as one
+        constant nrow x N matrix applied to the pressure profile (``jx_set_route``; built on first use by sending the
+        unit profiles through the 'map' kernels).  ``eval_stage`` always takes the 'map' route."""
+        if route not in ROUTES:
+            raise ValueError("route must be 'map' or 'operator'")
+        self._chk(self.lib.jx_set_route(self._h, ROUTES[route]), 'jx_set_route')
+        self.route = route
+
+    def operator(self):
+        """G [N, nrow]: row j is the map row (before conversion) of the unit pressure profile e_j."""
+        out = np.empty((self.pb.N, self.nrow))
+        self._chk(self.lib.jx_get_operator(self._h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), out.nbytes), 'jx_get_operator')
+        return out
 
     def set_stream(self, hip_stream):
         """Enqueue on the caller's hipStream_t (integer handle, e.g. ``torch.cuda.current_stream().cuda_stream``);
