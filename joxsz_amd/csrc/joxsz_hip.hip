@@ -28,6 +28,7 @@ struct Plan3 {
 struct EvSet {
     hipEvent_t e[6];
     int walkers;
+    bool op;                           // operator route: only e[0], e[1], e[5] were recorded
 };
 
 }  // namespace
@@ -99,6 +100,9 @@ struct jx_ctx {
     // collapsed route (jx_set_route): Gt [N][g_ld], row j = map row of the unit pressure profile e_j
     int route = JX_ROUTE_MAP;
     double* d_G = nullptr;
+    double* d_pp = nullptr;            // [op_cap][N] pressure profiles, prep kernel -> operator kernel
+    double *d_base_op = nullptr, *d_cfac_op = nullptr;   // [op_cap], [op_cap][nrow]
+    int op_cap = 0;                    // walkers per launch on the operator route
     int g_ld = 0;
 
     std::map<int, Plan3> plans;
@@ -793,8 +797,13 @@ static int drain_events(jx_ctx* ctx) {
     if (ctx->ev_inflight.empty()) return JX_OK;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     for (auto& es : ctx->ev_inflight) {
-        float ms[5], tot;
-        for (int k = 0; k < 5; ++k) HIPCHK(ctx, hipEventElapsedTime(&ms[k], es.e[k], es.e[k + 1]));
+        float ms[5] = {0, 0, 0, 0, 0}, tot;
+        if (es.op) {                                   // collapsed route: prep, then one kernel
+            HIPCHK(ctx, hipEventElapsedTime(&ms[0], es.e[0], es.e[1]));
+            HIPCHK(ctx, hipEventElapsedTime(&ms[4], es.e[1], es.e[5]));
+        } else {
+            for (int k = 0; k < 5; ++k) HIPCHK(ctx, hipEventElapsedTime(&ms[k], es.e[k], es.e[k + 1]));
+        }
         HIPCHK(ctx, hipEventElapsedTime(&tot, es.e[0], es.e[5]));
         ctx->acc.prep_ms += ms[0]; ctx->acc.abel_map_ms += ms[1]; ctx->acc.beam_fft_ms += ms[2];
         ctx->acc.tf_fft_ms += ms[3]; ctx->acc.tail_ms += ms[4]; ctx->acc.total_ms += tot;
@@ -928,32 +937,41 @@ static int launch_custom_conv(jx_ctx* ctx, int n, double* tap_convjobs, EvSet* e
 
 // One chunk: walkers [w0, w0+n) of the batch whose thetas live at theta_dev.
 static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int w0, int n, const Taps& t) {
-    Plan3* pl = nullptr;
-    int rc = (ctx->conv_mode == 1) ? make_plans(ctx, n, &pl) : JX_OK;
-    if (rc) return rc;
     const JxDev& d = ctx->d;
+    const bool op_route = ctx->route == JX_ROUTE_OPERATOR && !t.pp && !d.inject_pp;      // stage taps and the operator build: map route
+    Plan3* pl = nullptr;
+    int rc = (ctx->conv_mode == 1 && !op_route) ? make_plans(ctx, n, &pl) : JX_OK;
+    if (rc) return rc;
     hipStream_t st = ctx->stream;
     EvSet es;
     const bool tm = ctx->timing_on;
+    // the operator route has no per-walker work buffers beyond these three, so its launches can be much larger than a chunk
+    double* base_buf = op_route ? ctx->d_base_op : ctx->d_base;
+    double* cfac_buf = op_route ? ctx->d_cfac_op : ctx->d_cfac;
     if (tm) {
         if (ctx->ev_inflight.size() > 2048 && (rc = drain_events(ctx))) return rc;
         if ((rc = get_evset(ctx, &es))) return rc;
         es.walkers = n;
+        es.op = false;
         HIPCHK(ctx, hipEventRecord(es.e[0], st));
     }
     {
-        const size_t sh = sizeof(double) * (JX_LDS_HDR + (size_t)d.N + 2 * d.nann + (size_t)d.nband * d.nann + 8);
+        const size_t sh = sizeof(double) * (JX_LDS_HDR + (size_t)2 * d.N + 2 * d.nann + (size_t)d.nband * d.nann + 8);
         hipLaunchKernelGGL(jx_prep_kernel, dim3(n), dim3(JX_PREP_THREADS), sh, st, d, theta_dev, w0,
-                           ctx->d_base, ctx->d_cfac, t.tprof, t.xprofs, t.parts);
+                           base_buf, cfac_buf, op_route ? ctx->d_pp : (double*)nullptr, t.tprof, t.xprofs, t.parts);
     }
     if (tm) HIPCHK(ctx, hipEventRecord(es.e[1], st));
-    if (ctx->route == JX_ROUTE_OPERATOR && !t.pp && !d.inject_pp) {
-        // collapsed route: the SZ side is one kernel (no map, no transforms); the stage events in between coincide
-        if (tm) for (int k = 2; k <= 4; ++k) HIPCHK(ctx, hipEventRecord(es.e[k], st));
-        const int N = d.N, nrow = d.nrow;
-        const size_t sh = sizeof(double) * ((size_t)JX_OP_WPB * (32 + ((N + 1) & ~1) + ((nrow + 1) & ~1)) + 8);
-        hipLaunchKernelGGL(jx_operator_kernel, dim3((n + JX_OP_WPB - 1) / JX_OP_WPB), dim3(256), sh, st, d, theta_dev, w0, n,
-                           ctx->d_G, ctx->g_ld, ctx->d_cfac, ctx->d_base, logp_dev, t.row, t.bright, t.chisq, t.parts);
+    if (op_route) {
+        // collapsed route: the SZ side is one kernel (no map, no transforms)
+        es.op = true;
+        const int nrow = d.nrow, Re = (nrow + 1) & ~1;
+        int wpb = (n >= 4096) ? 16 : (n >= 2048 ? 8 : 4);                    // walkers per block x radii per LDS chunk = 2048
+        while (wpb > 4 && sizeof(double) * (2048 + (size_t)wpb * Re + 8) > 64 * 1024) wpb >>= 1;
+        const size_t sh = sizeof(double) * (2048 + (size_t)wpb * Re + 8);
+#define JX_OP_GO(WPBv) hipLaunchKernelGGL((jx_operator_kernel<WPBv, 2048 / WPBv>), dim3((n + WPBv - 1) / WPBv), dim3(256), sh, st, d, ctx->d_pp, w0, n, \
+                           ctx->d_G, ctx->g_ld, cfac_buf, base_buf, logp_dev, t.row, t.bright, t.chisq, t.parts)
+        if (wpb == 16) JX_OP_GO(16); else if (wpb == 8) JX_OP_GO(8); else JX_OP_GO(4);
+#undef JX_OP_GO
         if (tm) {
             HIPCHK(ctx, hipEventRecord(es.e[5], st));
             ctx->ev_inflight.push_back(es);
@@ -1036,8 +1054,9 @@ int jx_eval_device(jx_ctx* ctx, const double* theta_dev, int nwalkers, double* l
     if (!ctx->finalized) { ctx->err = "jx_eval before jx_finalize"; return JX_ERR_STATE; }
     HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
     Taps none;
-    for (int w0 = 0; w0 < nwalkers; w0 += ctx->chunk) {
-        const int n = std::min(ctx->chunk, nwalkers - w0);
+    const int step = (ctx->route == JX_ROUTE_OPERATOR) ? ctx->op_cap : ctx->chunk;
+    for (int w0 = 0; w0 < nwalkers; w0 += step) {
+        const int n = std::min(step, nwalkers - w0);
         int rc = run_chunk(ctx, theta_dev, logp_dev, w0, n, none);
         if (rc) return rc;
     }
@@ -1108,7 +1127,7 @@ static int build_operator(jx_ctx* ctx) {
     if ((rc = ensure_batch(ctx, ctx->chunk))) return rc;
     double* G = nullptr;
     double* inj = nullptr;
-    if ((rc = dev_new(ctx, (size_t)N * ld, &G, true))) return rc;
+    if ((rc = dev_new(ctx, (size_t)(N + 2) * ld, &G, true))) return rc;        // two zero rows behind the last: the kernel reads j in pairs
     HIPCHK(ctx, hipMalloc((void**)&inj, sizeof(double) * (size_t)ctx->chunk * N));
     std::vector<double> th((size_t)ctx->chunk * c.ndim);
     {
@@ -1140,6 +1159,10 @@ static int build_operator(jx_ctx* ctx) {
     }
     ctx->timing_on = tm;
     (void)hipFree(inj);
+    ctx->op_cap = std::max(ctx->chunk, ctx->cfg.max_batch > 0 ? ctx->chunk : 16384);      // (an explicit max_batch bounds this route too)
+    if ((rc = dev_new(ctx, (size_t)ctx->op_cap * N, &ctx->d_pp))) return rc;
+    if ((rc = dev_new(ctx, (size_t)ctx->op_cap, &ctx->d_base_op))) return rc;
+    if ((rc = dev_new(ctx, (size_t)ctx->op_cap * nrow, &ctx->d_cfac_op))) return rc;
     ctx->d_G = G;
     ctx->g_ld = ld;
     return JX_OK;

@@ -121,7 +121,7 @@ __device__ __forceinline__ void jx_ne_consts(const double* p, int mode, double* 
 }
 __device__ __forceinline__ double jx_ne_pc(const double* p, const double* pc, double r, int mode) {
     const double x = r / pc[1];
-    double res = pc[0] * pow(x, -p[P_ALPHA]) /
+    double res = pc[0] * ((p[P_ALPHA] == 0.0) ? 1.0 : pow(x, -p[P_ALPHA])) /      // (alpha is frozen at 0 by default: x^-0 == 1 exactly)
                  (pow(1.0 + x * x, 3.0 * p[P_BETA] - p[P_ALPHA] / 2.0) *
                   pow(1.0 + pow(r / pc[2], p[P_GAMMA]), p[P_EPS] / p[P_GAMMA]));
     if (mode == 1) {
@@ -192,8 +192,8 @@ __device__ __forceinline__ void jx_load_params(const JxDev& c, const double* __r
 // ------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(JX_PREP_THREADS)
 jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
-               double* __restrict__ base, double* __restrict__ cfac, double* __restrict__ tap_tprof,
-               double* __restrict__ tap_xprofs, double* __restrict__ tap_parts) {
+               double* __restrict__ base, double* __restrict__ cfac, double* __restrict__ pp_out /*[chunk][N] or null*/,
+               double* __restrict__ tap_tprof, double* __restrict__ tap_xprofs, double* __restrict__ tap_parts) {
     JX_LDS_DECL;
     double* p = sm;
     double* red = sm + 20;
@@ -202,8 +202,9 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
     const int gw = w0 + w;                    // walker within the batch
     const int tid = threadIdx.x, nth = blockDim.x;
 
-    double* s_m = sm + JX_LDS_HDR;            // [N] mass profile, then reused
-    double* s_ne = s_m + c.N;                 // [nann]
+    double* s_m = sm + JX_LDS_HDR;            // [N] mass profile
+    double* s_t = s_m + c.N;                  // [N] T_SZ on r_pp[:nt]
+    double* s_ne = s_t + c.N;                 // [nann]
     double* s_T = s_ne + c.nann;              // [nann]
     double* s_rate = s_T + c.nann;            // [nband*nann]
 
@@ -231,14 +232,26 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
     // ---- model prior: r_c <= r_s (joxsz_funcs.py:397-407) ----
     if (tid == 0 && pow(10.0, p[P_LOGRC]) > pow(10.0, p[P_LOGRS])) rej |= REJ_RCRS;
 
-    // ---- hydrostatic-mass monotonicity veto (joxsz_funcs.py:522-525, 428-437) ----
-    if (c.exclude_unphy_mass) {
-        for (int i = tid; i < c.N; i += nth) {
-            const double r = c.r_pp[i];
+    // ---- one pass over the radial grid: pressure (joxsz_funcs.py:275-287), the hydrostatic-mass profile of the
+    //      monotonicity veto (joxsz_funcs.py:522-525, 428-437) and T_SZ on r_pp[:nt] (joxsz_funcs.py:469).  The pressure
+    //      derivative (joxsz_funcs.py:289-301) is the pressure times -(c + b x^a) / (r (1 + x^a)): no powers of its own.
+    const bool veto = c.exclude_unphy_mass != 0;
+    const int nprof = (veto || pp_out) ? c.N : c.nt;
+    for (int i = tid; i < nprof; i += nth) {
+        const double r = c.r_pp[i];
+        const double x = r / p[P_RP];
+        const double xa = pow(x, p[P_A]);
+        const double press = p[P_P0] / (pow(x, p[P_C]) * pow(1.0 + xa, (p[P_B] - p[P_C]) / p[P_A]));   // == jx_press(p, r)
+        if (pp_out) pp_out[(size_t)w * c.N + i] = press;
+        if (veto || i < c.nt) {
+            const double ne = jx_ne_pc(p, pc, r, c.ne_mode);
             // positive constant factors of mass_fun cannot change the sign test
-            s_m[i] = -jx_press_deriv(p, r) * r * r / jx_ne_pc(p, pc, r, c.ne_mode);
+            if (veto) s_m[i] = press * (p[P_C] + p[P_B] * xa) / (r * (1.0 + xa)) * r * r / ne;
+            if (i < c.nt) s_t[i] = press / ne;
         }
-        __syncthreads();
+    }
+    __syncthreads();
+    if (veto) {
         for (int i = tid; i < c.N; i += nth) {
             double g;                          // np.gradient(m, 1)
             if (i == 0) g = s_m[1] - s_m[0];
@@ -246,18 +259,11 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
             else g = (s_m[i + 1] - s_m[i - 1]) / 2.0;
             if (!(g > 0.0)) rej |= REJ_MASS;
         }
-        __syncthreads();
     }
 
-    // ---- T_SZ on r_pp[:nt], h(0), conversion factors (joxsz_funcs.py:469-473) ----
-    double* s_t = s_m;                         // reuse [nt] (nt < N)
+    // ---- h(0), conversion factors (joxsz_funcs.py:470-473) ----
     double part = 0.0;
-    for (int k = tid; k < c.nt; k += nth) {
-        const double r = c.r_pp[k];
-        const double t = jx_press(p, r) / jx_ne_pc(p, pc, r, c.ne_mode);
-        s_t[k] = t;
-        part += c.hw[k] * t;
-    }
+    for (int k = tid; k < c.nt; k += nth) part += c.hw[k] * s_t[k];
     const double t0 = jx_block_sum(part, red);
     for (int k = tid; k < c.nrow; k += nth) {
         const double T = (k == 0) ? t0 : s_t[k - 1];
@@ -828,93 +834,106 @@ jx_tail_kernel(JxDev c, const double2* __restrict__ tfspec, const double2* __res
 //     map_row[x] = sum_j G[x][j] pp[j]
 // with one constant nrow x N matrix.  G is not derived separately: jx_set_route pushes the N unit profiles through
 // the kernels above (inject_pp) and stores their rows, Gt[j][x] (row stride ldg).  This kernel is then the whole SZ
-// side of a walker: pp = press_fun(theta) -> G pp -> conversion -> data radii -> chi^2 -> total (as jx_tail_kernel).
-// One block of 256 threads for JX_OP_WPB walkers: every G entry fetched once serves all of them.
-// LDS: [JX_OP_WPB][32] parameters, [JX_OP_WPB][Ne] profiles, [JX_OP_WPB][nrow_e] rows, 8 scratch.
+// side of a walker: pp (left in HBM by the prep kernel, which needs it anyway) -> G pp -> conversion -> data radii ->
+// chi^2 -> total (as jx_tail_kernel).
+// One block of 256 threads for WPB walkers (4, 8 or 16 by launch size): a G entry fetched once serves all of them --
+// every block streams the whole of G out of L2, which is what bounds this kernel, so large launches take more walkers
+// per block.  The profiles pass through LDS in chunks of JC radii (512, 256, 128: the
+// fewer walkers, the longer the chunk).  Each walker's sums run over j in the same
+// order whatever WPB is: a result does not depend on the launch it was part of.
+// LDS: [WPB][JC] profile chunk, [WPB][nrow_e] rows, 8 scratch.
 // ------------------------------------------------------------------------------------
-#define JX_OP_WPB 4
+template <int WPB, int JC>
 __global__ void __launch_bounds__(256)
-jx_operator_kernel(JxDev c, const double* __restrict__ theta, int w0, int n, const double* __restrict__ Gt, int ldg,
+jx_operator_kernel(JxDev c, const double* __restrict__ pp /*[launch][N], written by jx_prep_kernel*/, int w0, int n,
+                   const double* __restrict__ Gt /*[N+2][ldg], the last two rows zero*/, int ldg,
                    const double* __restrict__ cfac, const double* __restrict__ base, double* __restrict__ logp,
                    double* __restrict__ tap_row, double* __restrict__ tap_bright, double* __restrict__ tap_chisq,
                    double* __restrict__ tap_parts) {
     JX_LDS_DECL;
-    const int N = c.N, nrow = c.nrow, Ne = (N + 1) & ~1, Re = (nrow + 1) & ~1;
-    double* s_p = sm;                                   // [WPB][32]
-    double* s_pp = s_p + JX_OP_WPB * 32;                // [WPB][Ne]
-    double* s_prof = s_pp + JX_OP_WPB * Ne;             // [WPB][Re]
-    double* red = s_prof + JX_OP_WPB * Re;              // [8]
+    const int N = c.N, nrow = c.nrow, Re = (nrow + 1) & ~1;
+    double* s_pp = sm;                                  // [WPB][JC]
+    double* s_prof = s_pp + WPB * JC;             // [WPB][Re]
+    double* red = s_prof + WPB * Re;                    // [8]
     const int tid = threadIdx.x, nth = blockDim.x;
-    const int wb = blockIdx.x * JX_OP_WPB;
-    const int nw = min(JX_OP_WPB, n - wb);
+    const int wb = blockIdx.x * WPB;
+    const int nw = min(WPB, n - wb);
 
-    for (int k = 0; k < JX_OP_WPB; ++k)                 // (a missing walker repeats the block's first: finite work, never stored)
-        jx_load_params(c, theta, w0 + wb + (k < nw ? k : 0), s_p + 32 * k);
-    for (int j = tid; j < N; j += nth) {
-        const double r = c.abel_tab[4 * (size_t)j];
+    for (int xs = 0; xs < nrow; xs += nth) {            // slabs of 256 rows (one, up to S = 512)
+        const int x = xs + tid;
+        const bool live = x < nrow;
+        double a[WPB][2];
 #pragma unroll
-        for (int k = 0; k < JX_OP_WPB; ++k) s_pp[k * Ne + j] = jx_press(s_p + 32 * k, r);
+        for (int k = 0; k < WPB; ++k) a[k][0] = a[k][1] = 0.0;
+        for (int j0 = 0; j0 < N; j0 += JC) {
+            __syncthreads();                            // the previous chunk has been used up
+            for (int q = tid; q < WPB * JC; q += nth) {
+                const int k = q / JC, j = q - k * JC;
+                // (a missing walker repeats the block's first: finite work, never stored)
+                s_pp[q] = (j0 + j < N) ? pp[(size_t)(wb + (k < nw ? k : 0)) * N + j0 + j] : 0.0;
+            }
+            __syncthreads();
+            if (live) {
+                const int jn = min(JC, (N - j0 + 1) & ~1);          // even count: G has zero rows behind row N-1
+                const double* g = Gt + (size_t)j0 * ldg + x;
+                for (int j = 0; j < jn; j += 2) {
+                    const double g0 = g[(size_t)j * ldg], g1 = g[(size_t)(j + 1) * ldg];
+#pragma unroll
+                    for (int k = 0; k < WPB; ++k) {
+                        const double2 v = *reinterpret_cast<const double2*>(s_pp + k * JC + j);
+                        a[k][0] = fma(g0, v.x, a[k][0]);
+                        a[k][1] = fma(g1, v.y, a[k][1]);
+                    }
+                }
+            }
+        }
+        if (live) {
+#pragma unroll
+            for (int k = 0; k < WPB; ++k) {
+                const double row = a[k][0] + a[k][1];
+                double b = 0.0;
+                if (k < nw) {
+                    const size_t o = (size_t)(wb + k) * nrow + x;
+                    b = row * cfac[o];
+                    if (tap_row) tap_row[o] = row;
+                    if (tap_bright) tap_bright[o] = b;
+                }
+                s_prof[k * Re + x] = b;
+            }
+        }
     }
     __syncthreads();
 
-    for (int x = tid; x < nrow; x += nth) {
-        double a[JX_OP_WPB][2];
+    // data radii and chi^2: one data point per wave at a time, lanes along the row (emat rows are contiguous)
+    double part[WPB];
 #pragma unroll
-        for (int k = 0; k < JX_OP_WPB; ++k) a[k][0] = a[k][1] = 0.0;
-        const double* g = Gt + x;
-        int j = 0;
-        for (; j + 1 < N; j += 2) {
-            const double g0 = g[(size_t)j * ldg], g1 = g[(size_t)(j + 1) * ldg];
-#pragma unroll
-            for (int k = 0; k < JX_OP_WPB; ++k) {
-                const double2 v = *reinterpret_cast<const double2*>(s_pp + k * Ne + j);
-                a[k][0] = fma(g0, v.x, a[k][0]);
-                a[k][1] = fma(g1, v.y, a[k][1]);
-            }
-        }
-        if (j < N) {
-            const double g0 = g[(size_t)j * ldg];
-#pragma unroll
-            for (int k = 0; k < JX_OP_WPB; ++k) a[k][0] = fma(g0, s_pp[k * Ne + j], a[k][0]);
-        }
-#pragma unroll
-        for (int k = 0; k < JX_OP_WPB; ++k) {
-            const double row = a[k][0] + a[k][1];
-            double b = 0.0;
-            if (k < nw) {
-                const size_t o = (size_t)(wb + k) * nrow + x;
-                b = row * cfac[o];
-                if (tap_row) tap_row[o] = row;
-                if (tap_bright) tap_bright[o] = b;
-            }
-            s_prof[k * Re + x] = b;
-        }
-    }
-    __syncthreads();
-
-    double part[JX_OP_WPB];
-#pragma unroll
-    for (int k = 0; k < JX_OP_WPB; ++k) part[k] = 0.0;
-    for (int d = tid; d < c.nflux; d += nth) {
+    for (int k = 0; k < WPB; ++k) part[k] = 0.0;
+    const int lane = tid & 63, wv = tid >> 6, nwv = nth >> 6;
+    for (int d = wv; d < c.nflux; d += nwv) {
         const double* e = c.emat + (size_t)d * nrow;
-        double m[JX_OP_WPB];
+        double m[WPB];
 #pragma unroll
-        for (int k = 0; k < JX_OP_WPB; ++k) m[k] = 0.0;
-        for (int x = 0; x < nrow; ++x) {
+        for (int k = 0; k < WPB; ++k) m[k] = 0.0;
+        for (int x = lane; x < nrow; x += 64) {
             const double ev = e[x];
 #pragma unroll
-            for (int k = 0; k < JX_OP_WPB; ++k) m[k] = fma(ev, s_prof[k * Re + x], m[k]);
+            for (int k = 0; k < WPB; ++k) m[k] = fma(ev, s_prof[k * Re + x], m[k]);
         }
-        const double f = c.flux[c.nflux + d], er = c.flux[2 * c.nflux + d];
 #pragma unroll
-        for (int k = 0; k < JX_OP_WPB; ++k) {
-            const double z = (f - m[k]) / er;
-            const double z2 = z * z;
-            if (z2 == z2) part[k] += z2;                 // np.nansum drops NaN terms
+        for (int k = 0; k < WPB; ++k)
+            for (int off = 32; off > 0; off >>= 1) m[k] += __shfl_xor(m[k], off, 64);
+        if (lane == 0) {
+            const double f = c.flux[c.nflux + d], er = c.flux[2 * c.nflux + d];
+#pragma unroll
+            for (int k = 0; k < WPB; ++k) {
+                const double z = (f - m[k]) / er;
+                const double z2 = z * z;
+                if (z2 == z2) part[k] += z2;             // np.nansum drops NaN terms
+            }
         }
     }
 #pragma unroll
-    for (int k = 0; k < JX_OP_WPB; ++k) {
+    for (int k = 0; k < WPB; ++k) {
         const double chisq = jx_block_sum(part[k], red);
         if (tid == 0 && k < nw) {
             const int w = wb + k;
