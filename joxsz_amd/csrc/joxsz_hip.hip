@@ -580,6 +580,13 @@ int jx_finalize(jx_ctx* ctx) {
         double* p; int* q;
 #define PUTD(field, id) { std::vector<double> v = host_vec<double>(ctx, id); if ((rc = dev_put(ctx, v.data(), v.size(), &p))) return rc; d.field = p; }
 #define PUTI(field, id) { std::vector<int32_t> v = host_vec<int32_t>(ctx, id); if ((rc = dev_put(ctx, v.data(), v.size(), &q))) return rc; d.field = q; }
+        {
+            std::vector<double> lr = host_vec<double>(ctx, JX_T_R_PP);
+            for (double& v : lr) v = std::log(v);
+            if ((rc = dev_put(ctx, lr.data(), lr.size(), &p))) return rc;
+            d.lr_pp = p;
+            d.prep_pow = getenv("JOXSZ_PREP_POW") && atoi(getenv("JOXSZ_PREP_POW")) ? 1 : 0;
+        }
         PUTD(r_pp, JX_T_R_PP) PUTD(d_mat, JX_T_D_MAT) PUTD(conv_T, JX_T_CONV_T) PUTD(conv_v, JX_T_CONV_V)
         PUTD(par_vals, JX_T_PAR_VALS) PUTD(par_min, JX_T_PAR_MIN) PUTD(par_max, JX_T_PAR_MAX)
         PUTD(par_mu, JX_T_PAR_MU) PUTD(par_sigma, JX_T_PAR_SIGMA)

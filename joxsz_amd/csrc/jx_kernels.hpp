@@ -50,6 +50,8 @@ struct JxDev {
     const double* d_mat;         // [S*S]
     long long img_ld, img_ws;    // row and walker strides (doubles) of the y-map image
     int dbg;                     // timing-only ablations (JOXSZ_DBG): 1 skip phases 1-4, 2 skip phase 5, 4 phase 5 stores only
+    int prep_pow;                // 1 (JOXSZ_PREP_POW=1): the prep kernel evaluates the profiles with pow() as written in the reference
+    const double* lr_pp;         // [N] log(r_pp)
     const double* inject_pp;     // operator build only: [nlaunch][N] pressure profiles that replace press_fun(theta) (else null)
     int fast_map, q_na, q_nb;    // symmetric-map form: table sizes (|ix-c|, |iy-c|)
     double* xcol;                // quad mode: copy of the quadrant's last column (map column 0): [chunk][q_nb], or walker-minor
@@ -127,6 +129,44 @@ __device__ __forceinline__ double jx_ne_pc(const double* p, const double* pc, do
     if (mode == 1) {
         const double x2 = r / pc[4];
         res += pc[3] / pow(1.0 + x2 * x2, 3.0 * p[P_BETA2]);
+    }
+    return sqrt(res);
+}
+
+// The two profiles in log form.  Every power in joxsz_funcs.py:275-287 and :375-395 has a positive base, so
+//     press = P0 exp(-(c lx + ((b-c)/a) log(1 + x^a))),   x^a = exp(a lx),   lx = log r - log r_p
+//     ne^2  = n0^2 exp(-(alpha lc + (3 beta - alpha/2) log(1 + (r/rc)^2) + (eps/gamma) log(1 + exp(gamma (log r - log r_s)))))
+// (+ the second beta term): three log() and four exp() per radius instead of six pow(), which is what the prep kernel's
+// time goes into.  The exponents are O(10) and carry an absolute error of a few 1e-16 each, so the values agree with
+// the pow() forms to ~1e-14 relative (the pow() forms stay available: JOXSZ_PREP_POW=1).
+// pl = {log r_p, (b-c)/a, log r_c, r_c, log r_s, 3 beta - alpha/2, eps/gamma, n0^2, n02^2, r_c2}
+__device__ __forceinline__ void jx_prof_consts(const double* p, int mode, double* pl) {
+    const double ln10 = 2.30258509299404568402;
+    pl[0] = log(p[P_RP]);
+    pl[1] = (p[P_B] - p[P_C]) / p[P_A];
+    pl[2] = p[P_LOGRC] * ln10;
+    pl[3] = exp(pl[2]);
+    pl[4] = p[P_LOGRS] * ln10;
+    pl[5] = 3.0 * p[P_BETA] - p[P_ALPHA] / 2.0;
+    pl[6] = p[P_EPS] / p[P_GAMMA];
+    pl[7] = exp(2.0 * ln10 * p[P_LOGN0]);
+    pl[8] = (mode == 1) ? exp(2.0 * ln10 * p[P_LOGN02]) : 0.0;
+    pl[9] = (mode == 1) ? exp(ln10 * p[P_LOGRC2]) : 1.0;
+}
+// pressure and x^a at radius r (lr = log r)
+__device__ __forceinline__ double jx_press_log(const double* p, const double* pl, double lr, double* xa_out) {
+    const double lx = lr - pl[0];
+    const double xa = exp(p[P_A] * lx);
+    *xa_out = xa;
+    return p[P_P0] * exp(-(p[P_C] * lx + pl[1] * log(1.0 + xa)));
+}
+__device__ __forceinline__ double jx_ne_log(const double* p, const double* pl, double r, double lr, int mode) {
+    const double x = r / pl[3];
+    const double u = exp(p[P_GAMMA] * (lr - pl[4]));
+    double res = pl[7] * exp(-(p[P_ALPHA] * (lr - pl[2]) + pl[5] * log(1.0 + x * x) + pl[6] * log(1.0 + u)));
+    if (mode == 1) {
+        const double x2 = r / pl[9];
+        res += pl[8] * exp(-3.0 * p[P_BETA2] * log(1.0 + x2 * x2));
     }
     return sqrt(res);
 }
@@ -209,8 +249,8 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
     double* s_rate = s_T + c.nann;            // [nband*nann]
 
     jx_load_params(c, theta, gw, p);
-    double pc[5];                             // radius-independent factors of the density (every thread its own copy)
-    jx_ne_consts(p, c.ne_mode, pc);
+    double pc[5] = {0, 1, 1, 0, 1};           // radius-independent factors of the density (every thread its own copy)
+    if (c.prep_pow) jx_ne_consts(p, c.ne_mode, pc);
 
     // ---- priors on every parameter (joxsz_funcs.py:518) ----
     double pr = 0.0;
@@ -230,21 +270,28 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
     const double parprior = jx_block_sum(pr, red);
 
     // ---- model prior: r_c <= r_s (joxsz_funcs.py:397-407) ----
-    if (tid == 0 && pow(10.0, p[P_LOGRC]) > pow(10.0, p[P_LOGRS])) rej |= REJ_RCRS;
+    if (tid == 0 && (c.prep_pow ? (pow(10.0, p[P_LOGRC]) > pow(10.0, p[P_LOGRS])) : (p[P_LOGRC] > p[P_LOGRS]))) rej |= REJ_RCRS;   // 10^x is monotonic
 
     // ---- one pass over the radial grid: pressure (joxsz_funcs.py:275-287), the hydrostatic-mass profile of the
     //      monotonicity veto (joxsz_funcs.py:522-525, 428-437) and T_SZ on r_pp[:nt] (joxsz_funcs.py:469).  The pressure
     //      derivative (joxsz_funcs.py:289-301) is the pressure times -(c + b x^a) / (r (1 + x^a)): no powers of its own.
     const bool veto = c.exclude_unphy_mass != 0;
     const int nprof = (veto || pp_out) ? c.N : c.nt;
+    const bool logform = !c.prep_pow;
+    double pl[10];
+    jx_prof_consts(p, c.ne_mode, pl);
     for (int i = tid; i < nprof; i += nth) {
         const double r = c.r_pp[i];
-        const double x = r / p[P_RP];
-        const double xa = pow(x, p[P_A]);
-        const double press = p[P_P0] / (pow(x, p[P_C]) * pow(1.0 + xa, (p[P_B] - p[P_C]) / p[P_A]));   // == jx_press(p, r)
+        double xa, press;
+        if (logform) press = jx_press_log(p, pl, c.lr_pp[i], &xa);
+        else {
+            const double x = r / p[P_RP];
+            xa = pow(x, p[P_A]);
+            press = p[P_P0] / (pow(x, p[P_C]) * pow(1.0 + xa, (p[P_B] - p[P_C]) / p[P_A]));               // == jx_press(p, r)
+        }
         if (pp_out) pp_out[(size_t)w * c.N + i] = press;
         if (veto || i < c.nt) {
-            const double ne = jx_ne_pc(p, pc, r, c.ne_mode);
+            const double ne = logform ? jx_ne_log(p, pl, r, c.lr_pp[i], c.ne_mode) : jx_ne_pc(p, pc, r, c.ne_mode);
             // positive constant factors of mass_fun cannot change the sign test
             if (veto) s_m[i] = press * (p[P_C] + p[P_B] * xa) / (r * (1.0 + xa)) * r * r / ne;
             if (i < c.nt) s_t[i] = press / ne;
@@ -276,9 +323,16 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
     double xlike = 0.0;
     if (!c.sz_only) {
         if (tid < c.nann) {
-            s_ne[tid] = jx_ne_pc(p, pc, c.x_r_ne[tid], c.ne_mode);
-            const double r = c.x_r_T[tid];
-            s_T[tid] = jx_press(p, r) / jx_ne_pc(p, pc, r, c.ne_mode) * pow(10.0, p[P_LOGTR]);   // T_X
+            const double rn = c.x_r_ne[tid], r = c.x_r_T[tid];
+            if (logform) {
+                double xa;
+                const double lr = log(r);
+                s_ne[tid] = jx_ne_log(p, pl, rn, (rn == r) ? lr : log(rn), c.ne_mode);
+                s_T[tid] = jx_press_log(p, pl, lr, &xa) / jx_ne_log(p, pl, r, lr, c.ne_mode) * exp(2.30258509299404568402 * p[P_LOGTR]);   // T_X
+            } else {
+                s_ne[tid] = jx_ne_pc(p, pc, rn, c.ne_mode);
+                s_T[tid] = jx_press(p, r) / jx_ne_pc(p, pc, r, c.ne_mode) * pow(10.0, p[P_LOGTR]);   // T_X
+            }
         }
         __syncthreads();
         const int nba = c.nband * c.nann;
@@ -876,7 +930,8 @@ jx_operator_kernel(JxDev c, const double* __restrict__ pp /*[launch][N], written
             if (live) {
                 const int jn = min(JC, (N - j0 + 1) & ~1);          // even count: G has zero rows behind row N-1
                 const double* g = Gt + (size_t)j0 * ldg + x;
-                for (int j = 0; j < jn; j += 2) {
+#pragma unroll 4
+                for (int j = 0; j < jn; j += 2) {           // (unrolled: eight G loads in flight per lane)
                     const double g0 = g[(size_t)j * ldg], g1 = g[(size_t)(j + 1) * ldg];
 #pragma unroll
                     for (int k = 0; k < WPB; ++k) {

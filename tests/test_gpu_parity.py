@@ -487,3 +487,32 @@ def test_full_size_determinism_and_permutation():
     d = small.log_prob(th[:300])
     small.close()
     np.testing.assert_array_equal(d, a[:300])
+
+
+def test_prep_log_form_against_pow_form(monkeypatch):
+    """The prep kernel evaluates the pressure and density profiles through exp/log of their exponents (default) or with
+    the pow() calls of joxsz_funcs.py:275-287, 375-395 (JOXSZ_PREP_POW=1): same T profile, X-ray profiles, veto and
+    log-posterior, both density modes."""
+    from joxsz_amd import datasets
+    for kw in (dict(), dict(ne_mode='double')):
+        pb = datasets.synthetic_problem(S=64, N=80, seed=6, **kw)
+        p0 = orc.pars_dict(pb, datasets.fiducial_theta(pb))
+        datasets.fill_data(pb, orc.sz_stages(pb, p0)['bright'], orc.calc_profiles(pb, p0), seed=6)
+        th = datasets.walker_ball(pb, 40, spread=0.08, seed=6)
+        out = {}
+        for form in ('log', 'pow'):
+            if form == 'pow':
+                monkeypatch.setenv('JOXSZ_PREP_POW', '1')
+            else:
+                monkeypatch.delenv('JOXSZ_PREP_POW', raising=False)
+            post = _post(pb)
+            out[form] = (post.log_prob(th), post.stage(th, 'tprof'), post.stage(th, 'xprofs'), post.stage(th, 'parts'))
+            post.close()
+        monkeypatch.delenv('JOXSZ_PREP_POW', raising=False)
+        fin = np.isfinite(out['pow'][0])
+        assert fin.sum() > 10 and (~fin).sum() > 0                       # the wide ball has vetoed walkers too
+        assert np.array_equal(np.isfinite(out['log'][0]), fin)
+        np.testing.assert_array_equal(out['log'][3][:, 3], out['pow'][3][:, 3])      # same rejection reasons
+        np.testing.assert_allclose(out['log'][0][fin], out['pow'][0][fin], rtol=1e-11)
+        np.testing.assert_allclose(out['log'][1][fin], out['pow'][1][fin], rtol=1e-12)
+        np.testing.assert_allclose(out['log'][2][fin], out['pow'][2][fin], rtol=1e-12)
