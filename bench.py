@@ -224,30 +224,6 @@ def main():
     tm = ctx.timing()
     ctx.timing_enable(False)
 
-    # the same batch on the collapsed route (DESIGN 5.6), outside the timed region of the metric: reported beside it
-    also = None
-    if dist is None and args.route == 'map':
-        lp_map = np.empty(W)
-        ctx.d2h(lp_map, lp_ptr)
-        ctx.set_route('operator')
-        for _ in range(args.warmup):
-            step()
-        fence()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        fence()
-        dt = time.perf_counter() - t1
-        lp_op = np.empty(W)
-        ctx.d2h(lp_op, lp_ptr)
-        fin = np.isfinite(lp_map)
-        also = {'route': 'operator', 'value': W * args.steps / dt, 'unit': 'walker-likelihoods/s', 'ms_per_step': 1e3 * dt / args.steps,
-                'max_rel_diff_vs_map_route': (float(np.max(np.abs(lp_op[fin] - lp_map[fin]) / np.abs(lp_map[fin]))) if fin.any() else None),
-                'same_rejections': bool(np.array_equal(np.isfinite(lp_op), fin)),
-                'note': 'same walkers, same library, jx_set_route(JX_ROUTE_OPERATOR): the SZ side as one constant nrow x N matrix '
-                        'applied to the pressure profile; not the BASELINE metric (no Abel+map kernel runs per step)'}
-        ctx.set_route('map')
-
     if dist is not None:
         e = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
         dist.all_reduce(e, op=dist.ReduceOp.MAX)
@@ -258,6 +234,33 @@ def main():
         ctx.d2h(final, lp_ptr)
     if not np.all(np.isfinite(final)) and not os.environ.get('JOXSZ_DBG'):
         raise SystemExit('bench: non-finite log-probabilities in the timed batch')
+
+    # the same batch on the collapsed route (DESIGN 5.6), outside the timed region of the metric: reported beside it
+    also = None
+    if dist is None and args.route == 'map':
+        try:
+            lp_map = final
+            ctx.set_route('operator')
+            for _ in range(args.warmup):
+                step()
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            fence()
+            dt = time.perf_counter() - t1
+            lp_op = np.empty(W)
+            ctx.d2h(lp_op, lp_ptr)
+            fin = np.isfinite(lp_map)
+            also = {'route': 'operator', 'value': W * args.steps / dt, 'unit': 'walker-likelihoods/s', 'ms_per_step': 1e3 * dt / args.steps,
+                    'max_rel_diff_vs_map_route': (float(np.max(np.abs(lp_op[fin] - lp_map[fin]) / np.abs(lp_map[fin]))) if fin.any() else None),
+                    'same_rejections': bool(np.array_equal(np.isfinite(lp_op), fin)),
+                    'note': 'same walkers, same library, jx_set_route(JX_ROUTE_OPERATOR): the SZ side as one constant nrow x N matrix '
+                            'applied to the pressure profile; not the BASELINE metric (no Abel+map kernel runs per step)'}
+            ctx.set_route('map')
+        except Exception as exc:                                  # never let the side measurement take the metric down
+            also = {'route': 'operator', 'error': str(exc)}
+
 
     if rank == 0:
         S = args.S

@@ -186,17 +186,15 @@ def nrow_of(S):
     return S - S // 2
 
 
-def sz_stages(pb, p, abel=None):
-    """All intermediate quantities of ``get_sz_like`` (funcs:453-479) in a dict."""
+def row_chain(pb, pp, abel=None):
+    """funcs:457-467 and the row of funcs:472 for a GIVEN pressure profile ``pp`` on ``r_pp``: Abel integral, Compton y,
+    mirrored cubic spline onto the pixel radii, beam convolution, transfer function, central row.  Every step is linear
+    in ``pp`` with constant coefficients (which ``sz_operator`` tabulates)."""
     if abel is None:
         abel = pyabel_direct.direct_transform_forward
     r_pp = pb.r_pp
     S = pb.d_mat.shape[0]
-    nrow = nrow_of(S)
-    nt = nrow - 1                                    # == sep for odd S
     out = {}
-    pp = press_fun(p, r_pp)                          # funcs:453
-    out['pp'] = pp
     ab = abel(pp, r_pp)                              # funcs:457
     out['ab'] = ab
     y = pb.kpc_cm * pb.sigma_T / pb.m_e * ab         # funcs:459
@@ -210,6 +208,27 @@ def sz_stages(pb, p, abel=None):
     FT_map_in = fft2(conv_2d)                        # funcs:466
     map_out = np.real(ifft2(FT_map_in * pb.filtering))   # funcs:467
     out['map_row'] = map_out[S // 2, S // 2:].copy()
+    return out
+
+
+def sz_operator(pb, abel=None):
+    """G [N, nrow]: row j = ``row_chain`` of the unit profile e_j, so that map_row = pp @ G for every pp (the matrix the
+    HIP library's operator route builds with its own kernels, ``jx_set_route``)."""
+    N = pb.r_pp.size
+    eye = np.eye(N)
+    return np.array([row_chain(pb, eye[j], abel)['map_row'] for j in range(N)])
+
+
+def sz_stages(pb, p, abel=None):
+    """All intermediate quantities of ``get_sz_like`` (funcs:453-479) in a dict."""
+    r_pp = pb.r_pp
+    S = pb.d_mat.shape[0]
+    nrow = nrow_of(S)
+    nt = nrow - 1                                    # == sep for odd S
+    pp = press_fun(p, r_pp)                          # funcs:453
+    out = {'pp': pp}
+    out.update(row_chain(pb, pp, abel))
+    map_row = out['map_row']
     t_prof = temp_fun(p, r_pp[:nt], pb.ne_mode, getT_SZ=True)   # funcs:469
     out['t_prof'] = t_prof
     h = interp1d(np.append(-r_pp[:nt], r_pp[:nt]), np.append(t_prof, t_prof), 'cubic',
@@ -217,7 +236,7 @@ def sz_stages(pb, p, abel=None):
     t0 = h(0.)
     out['t0'] = float(t0)
     convert = interp1d(pb.conv_T, pb.conv_v, 'linear', fill_value='extrapolate')   # main:109
-    map_prof = map_out[S // 2, S // 2:] * convert(np.append(t0, t_prof)) * p['calibration']   # funcs:472-473
+    map_prof = map_row * convert(np.append(t0, t_prof)) * p['calibration']   # funcs:472-473
     out['bright'] = map_prof
     g = interp1d(pb.radius[S // 2:], map_prof, 'cubic', fill_value='extrapolate')   # funcs:476
     model = g(pb.flux_data[0])

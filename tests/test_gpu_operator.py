@@ -51,6 +51,19 @@ def test_random_walkers_vs_oracle_operator_route(S, N, kw):
     assert np.max(np.abs(got[fin] - want[fin]) / np.abs(want[fin])) < 1e-8
 
 
+@pytest.mark.parametrize('S,N', [(31, 40), (64, 80)])
+def test_operator_matrix_against_the_oracle_operator(S, N):
+    """The matrix the library builds with its kernels against the one tabulated from the oracle's own chain
+    (``orc.sz_operator``: numpy/scipy steps of funcs:457-472 on the unit profiles), entry by entry."""
+    from joxsz_amd import datasets
+    pb = datasets.synthetic_problem(S=S, N=N, seed=S)
+    post = _post(pb, route='operator')
+    G = post.ctx.operator()
+    post.close()
+    want = orc.sz_operator(pb)
+    np.testing.assert_allclose(G, want, rtol=0, atol=1e-9 * np.abs(want).max())
+
+
 def test_operator_is_the_map_route_applied_to_unit_profiles():
     """G pp against the row the map route extracts for the same walkers; both routes on the same batch."""
     from joxsz_amd import datasets

@@ -92,3 +92,18 @@ def test_count_rate_interpolation_clamps():
     np.testing.assert_allclose(lo, edge, rtol=1e-14)
     mid = mbp.count_rate(lnT, z0, z1, np.array([3.0]), 0.0, np.array([2e-3]))
     np.testing.assert_allclose(mid, np.exp(-150. + 0.5 * math.log(3.0)) * 4e-6, rtol=1e-12)
+
+
+def test_sz_row_is_linear_in_the_pressure_profile(golden_tiny):
+    """funcs:457-472 between ``press_fun`` and the extracted row: linear with constant coefficients.  The operator
+    tabulated from unit profiles reproduces the row of every golden parameter vector, and superposition holds."""
+    pb, ref = golden_tiny
+    G = orc.sz_operator(pb)
+    assert G.shape == (pb.N, pb.nrow)
+    rng = np.random.default_rng(0)
+    for th in ref['thetas'][np.isfinite(ref['ref_logp'])][:4]:
+        st = orc.sz_stages(pb, orc.pars_dict(pb, th))
+        np.testing.assert_allclose(st['pp'] @ G, st['map_row'], rtol=0, atol=1e-12 * np.abs(st['map_row']).max())
+    a, b = rng.random(pb.N), rng.random(pb.N)
+    ra, rb, rab = (orc.row_chain(pb, v)['map_row'] for v in (a, b, 2.5 * a - 0.5 * b))
+    np.testing.assert_allclose(rab, 2.5 * ra - 0.5 * rb, rtol=0, atol=1e-12 * np.abs(rab).max())
