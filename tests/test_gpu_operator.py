@@ -133,3 +133,21 @@ def test_operator_route_full_size():
     fin = np.isfinite(lp_map)
     assert fin.sum() > 200 and np.array_equal(np.isfinite(lp_op), fin)
     np.testing.assert_allclose(lp_op[fin], lp_map[fin], rtol=1e-9)
+
+
+@pytest.mark.parametrize('S,N', [(512, 500), (171, 313)])
+def test_operator_route_large_launch_equals_small_launch(S, N):
+    """The operator kernel takes 4, 8 or 16 walkers per block by launch size; a walker's sums run in the same order in
+    all three, so its log-posterior is the same bit pattern whichever launch it was part of."""
+    from joxsz_amd import datasets
+    pb = datasets.synthetic_problem(S=S, N=N, seed=0)
+    th = datasets.walker_ball(pb, 4500, spread=0.03, seed=8)       # 16 walkers per block, a ragged last block
+    th[7, 1] = 9.0
+    post = _post(pb, route='operator')
+    big = post.log_prob(th)
+    mid = np.concatenate([post.log_prob(th[k:k + 2250]) for k in range(0, 4500, 2250)])      # 8 per block
+    small = np.concatenate([post.log_prob(th[k:k + 500]) for k in range(0, 4500, 500)])      # 4 per block
+    post.close()
+    assert np.isfinite(big).sum() > 4000 and big[7] == -np.inf
+    np.testing.assert_array_equal(big, mid)
+    np.testing.assert_array_equal(big, small)
