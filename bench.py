@@ -145,6 +145,11 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group('nccl', rank=rank, world_size=world,
                                 device_id=torch.device('cuda', local_rank))
+        # an explicit stream for the whole run: the library is handed this stream (jx_set_stream) and RCCL orders its
+        # collectives against torch's CURRENT stream, so evaluation and gather are ordered without a host wait.  (torch's
+        # default stream has handle 0, which jx_set_stream reads as "back to the library's own stream".)
+        bench_stream = torch.cuda.Stream(device=local_rank)
+        torch.cuda.set_stream(bench_stream)
 
     from joxsz_amd.posterior import JoxszPosterior
     post = JoxszPosterior(pb, device=local_rank)
@@ -197,7 +202,8 @@ def main():
     if torch is not None:
         # the library enqueues on torch's current stream: RCCL orders the gather behind the evaluation by itself and
         # the host never waits inside a step
-        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        assert torch.cuda.current_stream().cuda_stream == bench_stream.cuda_stream != 0
+        ctx.set_stream(bench_stream.cuda_stream)
 
     def step():
         ctx.eval_device(th_ptr, W, lp_ptr)

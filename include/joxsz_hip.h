@@ -153,7 +153,8 @@ int  jx_eval_device(jx_ctx* ctx, const double* theta_dev, int nwalkers, double* 
 int  jx_sync(jx_ctx* ctx);
 /* Enqueue everything that follows on the caller's HIP stream (a hipStream_t, e.g. the one the caller's collective
  * library orders its work against) instead of the context's own; NULL goes back to the own stream.  The context never
- * destroys a stream it was handed.  Pending work on the previous stream is waited for first. */
+ * destroys a stream it was handed.  Pending work on the previous stream is waited for first.  (NULL is NOT the legacy
+ * default stream here: a caller whose work sits on that stream, e.g. torch's default stream, creates a stream for it.) */
 int  jx_set_stream(jx_ctx* ctx, void* hip_stream);
 /* Device-resident affine-invariant ensemble sampler (Goodman & Weare stretch move in emcee's red/blue form: what
  * mcmc.sample does with the reference's callable, joxsz_funcs.py:593-622): nsteps iterations of two half steps, with
