@@ -194,6 +194,22 @@ __device__ __forceinline__ double jx_interp_clamped(const double* xp, const doub
     return slope * (x - xp[lo]) + fp[lo];
 }
 
+// the same for two tables on one grid: identical arithmetic per table, one interval search
+__device__ __forceinline__ void jx_interp_clamped2(const double* xp, const double* f0, const double* f1, int n, double x,
+                                                   double* o0, double* o1) {
+    if (x != x) { *o0 = x; *o1 = x; return; }
+    if (x <= xp[0]) { *o0 = f0[0]; *o1 = f1[0]; return; }
+    if (x >= xp[n - 1]) { *o0 = f0[n - 1]; *o1 = f1[n - 1]; return; }
+    int lo = 0, hi = n - 1;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (xp[mid] <= x) lo = mid; else hi = mid;
+    }
+    const double dx = xp[hi] - xp[lo], t = x - xp[lo];
+    *o0 = (f0[hi] - f0[lo]) / dx * t + f0[lo];
+    *o1 = (f1[hi] - f1[lo]) / dx * t + f1[lo];
+}
+
 __device__ __forceinline__ double jx_block_sum(double v, double* red /*[>=4]*/) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -322,7 +338,20 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
     // ---- X-ray: calcProfiles + Cash (joxsz_funcs.py:527-532, 495-505) ----
     double xlike = 0.0;
     if (!c.sz_only) {
-        if (tid < c.nann) {
+        if (logform && c.nann <= 64 && nth >= 192) {
+            // three waves side by side: density at the n_e radii, pressure at the T radii, density at the T radii (only
+            // where the two radii differ), then T_X = P / n_e * 10^log(T_X/T_SZ)
+            double* s_x = s_m;                 // (the mass profile is dead: two block reductions since its last read)
+            const int grp = tid >> 6, k = tid & 63;
+            if (k < c.nann && grp < 3) {
+                const double rn = c.x_r_ne[k], r = c.x_r_T[k];
+                if (grp == 0) s_ne[k] = jx_ne_log(p, pl, rn, log(rn), c.ne_mode);
+                else if (grp == 1) { double xa; s_T[k] = jx_press_log(p, pl, log(r), &xa) * exp(2.30258509299404568402 * p[P_LOGTR]); }
+                else s_x[k] = (rn == r) ? 0.0 : jx_ne_log(p, pl, r, log(r), c.ne_mode);
+            }
+            __syncthreads();
+            if (tid < c.nann) s_T[tid] = s_T[tid] / ((c.x_r_ne[tid] == c.x_r_T[tid]) ? s_ne[tid] : s_x[tid]);   // T_X
+        } else if (tid < c.nann) {
             const double rn = c.x_r_ne[tid], r = c.x_r_T[tid];
             if (logform) {
                 double xa;
@@ -340,8 +369,9 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
             const int b = q / c.nann, j = q - b * c.nann;
             const double lt = log(s_T[j]);
             const double* tab = c.lnrate + (size_t)b * 2 * c.ntab;
-            const double z0 = exp(jx_interp_clamped(c.lnT, tab, c.ntab, lt));
-            const double z1 = exp(jx_interp_clamped(c.lnT, tab + c.ntab, c.ntab, lt));
+            double i0, i1;                     // one search of the temperature grid serves both metallicity tables
+            jx_interp_clamped2(c.lnT, tab, tab + c.ntab, c.ntab, lt, &i0, &i1);
+            const double z0 = exp(i0), z1 = exp(i1);
             s_rate[q] = (z0 + (z1 - z0) * p[P_Z]) * s_ne[j] * s_ne[j];
         }
         __syncthreads();
