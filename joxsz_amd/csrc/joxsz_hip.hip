@@ -590,6 +590,12 @@ int jx_finalize(jx_ctx* ctx) {
         PUTD(r_pp, JX_T_R_PP) PUTD(d_mat, JX_T_D_MAT) PUTD(conv_T, JX_T_CONV_T) PUTD(conv_v, JX_T_CONV_V)
         PUTD(par_vals, JX_T_PAR_VALS) PUTD(par_min, JX_T_PAR_MIN) PUTD(par_max, JX_T_PAR_MAX)
         PUTD(par_mu, JX_T_PAR_MU) PUTD(par_sigma, JX_T_PAR_SIGMA)
+        {   // -log(sqrt(2 pi)) - log(sigma) of the Gaussian priors, once
+            std::vector<double> sg = host_vec<double>(ctx, JX_T_PAR_SIGMA);
+            for (double& v : sg) v = (v > 0.0) ? -0.5 * std::log(2.0 * 3.14159265358979323846) - std::log(v) : 0.0;
+            if ((rc = dev_put(ctx, sg.data(), sg.size(), &p))) return rc;
+            d.par_lnorm = p;
+        }
         PUTI(par_kind, JX_T_PAR_KIND) PUTI(thawed_idx, JX_T_THAWED_IDX)
         ctx->d_par_vals = const_cast<double*>(d.par_vals);
         if (!c.sz_only) {

@@ -71,7 +71,8 @@ struct JxDev {
     const double* flux;          // [3*nflux]
     const double* conv_T; const double* conv_v;   // [nconv]
     const double* par_vals; const double* par_min; const double* par_max;
-    const double* par_mu; const double* par_sigma; const int* par_kind; const int* thawed_idx;
+    const double* par_mu; const double* par_sigma; const double* par_lnorm;   // par_lnorm = -log(sqrt(2 pi) sigma)
+    const int* par_kind; const int* thawed_idx;
     const double* x_r_ne; const double* x_r_T; const double* projvols; const double* cts;
     const double* areascales; const double* exposures; const double* backrates;
     const double* geomarea; const double* lnT; const double* lnrate;
@@ -278,7 +279,7 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
             if (sg <= 0.0) { rej |= REJ_BOX; }
             else {
                 const double z = (v - c.par_mu[tid]) / sg;
-                pr = -0.5 * log(2.0 * 3.14159265358979323846) - log(sg) - 0.5 * z * z;
+                pr = c.par_lnorm[tid] - 0.5 * z * z;
             }
         } else if (v < c.par_min[tid] || v > c.par_max[tid]) rej |= REJ_BOX;
         if (v != v) rej |= REJ_BOX;           // NaN parameter: reject (emcee cannot use NaN)
@@ -389,7 +390,7 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
             if (ct == ct) lk += ct * log(model) - model;
         }
         xlike = jx_block_sum(lk, red);
-        if (jx_block_or(bad, &redi)) rej |= REJ_XRAY;
+        if (bad) rej |= REJ_XRAY;              // (the block-wide OR of rej below carries it to everybody)
         // cashLogLikelihood returns -inf for a non-finite sum; per band in the reference,
         // a non-finite band makes the total non-finite as well
         if (!(fabs(xlike) <= 1.79769313486231570e308)) rej |= REJ_XRAY;
