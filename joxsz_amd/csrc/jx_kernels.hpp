@@ -297,21 +297,38 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
     const bool logform = !c.prep_pow;
     double pl[10];
     jx_prof_consts(p, c.ne_mode, pl);
-    for (int i = tid; i < nprof; i += nth) {
-        const double r = c.r_pp[i];
-        double xa, press;
-        if (logform) press = jx_press_log(p, pl, c.lr_pp[i], &xa);
-        else {
-            const double x = r / p[P_RP];
-            xa = pow(x, p[P_A]);
-            press = p[P_P0] / (pow(x, p[P_C]) * pow(1.0 + xa, (p[P_B] - p[P_C]) / p[P_A]));               // == jx_press(p, r)
-        }
-        if (pp_out) pp_out[(size_t)w * c.N + i] = press;
-        if (veto || i < c.nt) {
-            const double ne = logform ? jx_ne_log(p, pl, r, c.lr_pp[i], c.ne_mode) : jx_ne_pc(p, pc, r, c.ne_mode);
+    const int N_ = c.N, nt_ = c.nt, mode_ = c.ne_mode;
+    if (logform) {
+        // Two radii per trip, straight-line: the evaluations are chains of dependent fp64 operations, and two independent
+        // chains in flight per lane are what keeps the SIMD issuing when few waves are resident.  (The second index is
+        // clamped instead of branched on, the density is evaluated for every radius, and the stores come after both.)
+        for (int i = tid; i < nprof; i += 2 * nth) {
+            const int i2 = min(i + nth, nprof - 1);
+            const bool two = i + nth < nprof;
+            const double ra = c.r_pp[i], rb = c.r_pp[i2], lra = c.lr_pp[i], lrb = c.lr_pp[i2];
+            double xaa, xab;
+            const double pa = jx_press_log(p, pl, lra, &xaa), pb = jx_press_log(p, pl, lrb, &xab);
+            const double na = jx_ne_log(p, pl, ra, lra, mode_), nb = jx_ne_log(p, pl, rb, lrb, mode_);
             // positive constant factors of mass_fun cannot change the sign test
-            if (veto) s_m[i] = press * (p[P_C] + p[P_B] * xa) / (r * (1.0 + xa)) * r * r / ne;
-            if (i < c.nt) s_t[i] = press / ne;
+            const double ma = pa * (p[P_C] + p[P_B] * xaa) / (ra * (1.0 + xaa)) * ra * ra / na;
+            const double mb = pb * (p[P_C] + p[P_B] * xab) / (rb * (1.0 + xab)) * rb * rb / nb;
+            if (pp_out) { pp_out[(size_t)w * N_ + i] = pa; if (two) pp_out[(size_t)w * N_ + i2] = pb; }
+            if (veto) { s_m[i] = ma; if (two) s_m[i2] = mb; }
+            if (i < nt_) s_t[i] = pa / na;
+            if (two && i2 < nt_) s_t[i2] = pb / nb;
+        }
+    } else {
+        for (int i = tid; i < nprof; i += nth) {
+            const double r = c.r_pp[i];
+            const double x = r / p[P_RP];
+            const double xa = pow(x, p[P_A]);
+            const double press = p[P_P0] / (pow(x, p[P_C]) * pow(1.0 + xa, (p[P_B] - p[P_C]) / p[P_A]));   // == jx_press(p, r)
+            if (pp_out) pp_out[(size_t)w * N_ + i] = press;
+            if (veto || i < nt_) {
+                const double ne = jx_ne_pc(p, pc, r, mode_);
+                if (veto) s_m[i] = press * (p[P_C] + p[P_B] * xa) / (r * (1.0 + xa)) * r * r / ne;
+                if (i < nt_) s_t[i] = press / ne;
+            }
         }
     }
     __syncthreads();
