@@ -660,7 +660,7 @@ int jx_finalize(jx_ctx* ctx) {
     {
         const size_t LDS_MAX = 160 * 1024;
         auto need = [&](int threads) {
-            size_t scratch = JX_MAP_SCRATCH_DOUBLES(N);
+            size_t scratch = (d.pairw == 2) ? JX_MAP_SCRATCH2_DOUBLES(N) : JX_MAP_SCRATCH_DOUBLES(N);
             if (d.fast_map) scratch = std::max(scratch, (size_t)(threads / 64) * ((S + 3) & ~1));
             const size_t dbl = JX_MAP_FIXED_DOUBLES(N) + scratch + (d.pairw == 2 ? 4 * JX_MAP_NE(N) + 8 : 0);
             return dbl * sizeof(double);

@@ -573,6 +573,156 @@ __device__ __forceinline__ void jx_profile_to_coefs(const JxDev& c, const double
     __syncthreads();
 }
 
+// The same four phases for TWO walkers at once (quadrant mode, two walkers per block).  What the two share is computed
+// once -- the Abel weights 1/sqrt(r_j^2 - r_i^2) of phase 2, the loads of the banded spline operator in phase 3 -- and
+// the rest gives every lane two independent dependency chains instead of one.  Each walker's sums run over the same
+// terms in the same order as in jx_profile_to_coefs: the results are the same bit patterns.
+__device__ __forceinline__ void jx_abel_row2(const double2* s_rq, const double* s_qB, double ri2, int j0, int N, double* oA, double* oB) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
+    int j = j0;
+    for (; j + 12 < N; j += 16) {
+        const double2 q0 = s_rq[j], q1 = s_rq[j + 4], q2 = s_rq[j + 8], q3 = s_rq[j + 12];
+        const double u0 = s_qB[j], u1 = s_qB[j + 4], u2 = s_qB[j + 8], u3 = s_qB[j + 12];
+        const double t0 = jx_rsqrt(q0.x - ri2), t1 = jx_rsqrt(q1.x - ri2), t2 = jx_rsqrt(q2.x - ri2), t3 = jx_rsqrt(q3.x - ri2);
+        a0 = fma(q0.y, t0, a0); a1 = fma(q1.y, t1, a1); a2 = fma(q2.y, t2, a2); a3 = fma(q3.y, t3, a3);
+        b0 = fma(u0, t0, b0); b1 = fma(u1, t1, b1); b2 = fma(u2, t2, b2); b3 = fma(u3, t3, b3);
+    }
+    for (; j < N; j += 4) {
+        const double2 q0 = s_rq[j];
+        const double t0 = jx_rsqrt(q0.x - ri2);
+        a0 = fma(q0.y, t0, a0);
+        b0 = fma(s_qB[j], t0, b0);
+    }
+    *oA = (a0 + a1) + (a2 + a3);
+    *oB = (b0 + b1) + (b2 + b3);
+}
+
+// scratch (doubles, Ne = N rounded up to even): s_r[Ne] s_ppA[Ne] s_ppB[Ne] s_yA[Ne] s_yB[Ne] s_qB[Ne] s_rq[2 Ne] s_ds[2 Ne];
+// the spline moments of phase 3 go where s_rq was (dead after phase 2).
+#define JX_MAP_SCRATCH2_DOUBLES(N) (10 * JX_MAP_NE(N) + JX_LDS_HDR)
+__device__ __forceinline__ void jx_profile_to_coefs2(const JxDev& c, const double* pA, const double* pB, int w, bool taps,
+                                                     double* scratch, double* s_cfA, double* s_cfB,
+                                                     double* tap_pp, double* tap_ab, double* tap_y) {
+    const int N = c.N, tid = threadIdx.x, nth = blockDim.x, Ne = (N + 1) & ~1;
+    double* s_r = scratch;
+    double* s_ppA = s_r + Ne;
+    double* s_ppB = s_ppA + Ne;
+    double* s_yA = s_ppB + Ne;
+    double* s_yB = s_yA + Ne;
+    double* s_qB = s_yB + Ne;
+    double2* s_rq = reinterpret_cast<double2*>(s_qB + Ne);
+    double2* s_ds = s_rq + Ne;
+    double* s_MA = reinterpret_cast<double*>(s_rq);
+    double* s_MB = s_MA + Ne;
+
+    // Phase 1
+    for (int j = tid; j < N; j += nth) {
+        const double2 t0 = *reinterpret_cast<const double2*>(c.abel_tab + 4 * (size_t)j);
+        const double2 t1 = *reinterpret_cast<const double2*>(c.abel_tab + 4 * (size_t)j + 2);
+        const double r = t0.x;
+        s_r[j] = r;
+        s_ds[j] = t1;
+        const double vA = c.inject_pp ? c.inject_pp[(size_t)w * N + j] : ((c.dbg & 32) ? r : jx_press(pA, r));
+        const double vB = c.inject_pp ? c.inject_pp[(size_t)(w + 1) * N + j] : ((c.dbg & 32) ? r : jx_press(pB, r));
+        s_ppA[j] = vA;
+        s_ppB[j] = vB;
+        s_rq[j] = make_double2(r * r, t0.y * vA);
+        s_qB[j] = t0.y * vB;
+        if (taps && tap_pp) { tap_pp[(size_t)w * N + j] = vA; tap_pp[(size_t)(w + 1) * N + j] = vB; }
+    }
+    __syncthreads();
+
+    // Phase 2
+    const int npair = (N + 1) >> 1;
+    for (int p0 = 0; p0 < npair; p0 += (nth >> 2)) {
+        const int pr = p0 + (tid >> 2), sub = tid & 3;
+        double a1 = 0.0, a2 = 0.0, b1 = 0.0, b2 = 0.0;
+        const int i1 = pr, i2 = N - 1 - pr;
+        if (pr < npair && !(c.dbg & 8)) {
+            jx_abel_row2(s_rq, s_qB, s_rq[i1].x, i1 + 2 + sub, N, &a1, &b1);
+            if (i2 != i1) jx_abel_row2(s_rq, s_qB, s_rq[i2].x, i2 + 2 + sub, N, &a2, &b2);
+        }
+        a1 += __shfl_xor(a1, 1, 64); a1 += __shfl_xor(a1, 2, 64);
+        a2 += __shfl_xor(a2, 1, 64); a2 += __shfl_xor(a2, 2, 64);
+        b1 += __shfl_xor(b1, 1, 64); b1 += __shfl_xor(b1, 2, 64);
+        b2 += __shfl_xor(b2, 1, 64); b2 += __shfl_xor(b2, 2, 64);
+        if (pr < npair && sub == 0) {
+            const double2 ds1 = s_ds[i1];
+            double abA = fma(ds1.x, s_ppA[i1], a1), abB = fma(ds1.x, s_ppB[i1], b1);
+            if (i1 + 1 < N) { abA = fma(ds1.y, s_ppA[i1 + 1], abA); abB = fma(ds1.y, s_ppB[i1 + 1], abB); }
+            s_yA[i1] = c.y_scale * abA;
+            s_yB[i1] = c.y_scale * abB;
+            if (taps && tap_ab) { tap_ab[(size_t)w * N + i1] = abA; tap_ab[(size_t)(w + 1) * N + i1] = abB; }
+            if (i2 != i1) {
+                const double2 ds2 = s_ds[i2];
+                double ab2A = fma(ds2.x, s_ppA[i2], a2), ab2B = fma(ds2.x, s_ppB[i2], b2);
+                if (i2 + 1 < N) { ab2A = fma(ds2.y, s_ppA[i2 + 1], ab2A); ab2B = fma(ds2.y, s_ppB[i2 + 1], ab2B); }
+                s_yA[i2] = c.y_scale * ab2A;
+                s_yB[i2] = c.y_scale * ab2B;
+                if (taps && tap_ab) { tap_ab[(size_t)w * N + i2] = ab2A; tap_ab[(size_t)(w + 1) * N + i2] = ab2B; }
+            }
+        }
+    }
+    __syncthreads();
+    if (taps && tap_y) for (int i = tid; i < N; i += nth) { tap_y[(size_t)w * N + i] = s_yA[i]; tap_y[(size_t)(w + 1) * N + i] = s_yB[i]; }
+
+    // Phase 3
+    const int K = c.K;
+    for (int i0 = 0; i0 < N; i0 += (nth >> 1)) {
+        const int i = i0 + (tid >> 1), hsel = tid & 1;
+        double m0 = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0, n0 = 0.0, n1 = 0.0, n2 = 0.0, n3 = 0.0;
+        if (i < N && !(c.dbg & 16)) {
+            const int k0 = max(-K, -i), k1 = min(K, N - 1 - i);
+            const int km = (k0 + k1 + 1) >> 1;
+            const int ka = hsel ? km : k0, kb = hsel ? k1 + 1 : km;      // [ka, kb)
+            int k = ka;
+            for (; k + 3 < kb; k += 4) {
+                const double g0 = c.gband[(size_t)(k + K) * N + i], g1 = c.gband[(size_t)(k + 1 + K) * N + i],
+                             g2 = c.gband[(size_t)(k + 2 + K) * N + i], g3 = c.gband[(size_t)(k + 3 + K) * N + i];
+                m0 = fma(g0, s_yA[i + k], m0);     m1 = fma(g1, s_yA[i + k + 1], m1);
+                m2 = fma(g2, s_yA[i + k + 2], m2); m3 = fma(g3, s_yA[i + k + 3], m3);
+                n0 = fma(g0, s_yB[i + k], n0);     n1 = fma(g1, s_yB[i + k + 1], n1);
+                n2 = fma(g2, s_yB[i + k + 2], n2); n3 = fma(g3, s_yB[i + k + 3], n3);
+            }
+            for (; k < kb; ++k) {
+                const double g = c.gband[(size_t)(k + K) * N + i];
+                m0 = fma(g, s_yA[i + k], m0);
+                n0 = fma(g, s_yB[i + k], n0);
+            }
+        }
+        double m = (m0 + m1) + (m2 + m3), n = (n0 + n1) + (n2 + n3);
+        m += __shfl_xor(m, 1, 64);
+        n += __shfl_xor(n, 1, 64);
+        if (i < N && hsel == 0) { s_MA[i] = m; s_MB[i] = n; }
+    }
+    __syncthreads();
+
+    // Phase 4
+    for (int k = tid; k < 2 * (N + 1); k += nth) {
+        const bool isB = k >= N + 1;
+        const int kk = isB ? k - (N + 1) : k;
+        const double* s_y = isB ? s_yB : s_yA;
+        const double* s_M = isB ? s_MB : s_MA;
+        double* s_cf = isB ? s_cfB : s_cfA;
+        double c0, c1, c2, c3;
+        if (kk < N - 1) {
+            const double h = s_r[kk + 1] - s_r[kk];
+            const double y0 = s_y[kk], y1 = s_y[kk + 1], m0 = s_M[kk], m1 = s_M[kk + 1];
+            c0 = y0;
+            c1 = (y1 - y0) / h - h * (2.0 * m0 + m1) / 6.0;
+            c2 = 0.5 * m0;
+            c3 = (m1 - m0) / (6.0 * h);
+        } else if (kk == N - 1) {                           // centre: y_0 + M_0 (x^2 - r_0^2)/2
+            c0 = s_y[0] - 0.5 * s_M[0] * s_r[0] * s_r[0];
+            c1 = 0.0; c2 = 0.5 * s_M[0]; c3 = 0.0;
+        } else {
+            c0 = c1 = c2 = c3 = 0.0;                        // outside [-r_N, r_N]: fill value 0
+        }
+        s_cf[4 * kk + 0] = c0; s_cf[4 * kk + 1] = c1; s_cf[4 * kk + 2] = c2; s_cf[4 * kk + 3] = c3;
+    }
+    __syncthreads();
+}
+
 // LDS doubles needed by the profile-to-coefficients phases
 // LDS layout of the map kernels (doubles): [header][cubic coefficients 4(N+1)] then the phase-1-4 scratch
 // (knots, pp, y, M, (r^2,q), (dg,sp) = 8 N), which the symmetric kernel re-uses for its per-wave row buffers
@@ -682,10 +832,18 @@ jx_abel_map_sym_kernel(JxDev c, const double* __restrict__ theta, int w0, double
     const int w = blk * npw;
     const bool haveB = npw == 2 && w + 1 < c.nlaunch;                 // (an odd launch: the last block has one walker)
 
+    const bool fused2 = haveB && !(c.dbg & (1 | 256));                // both walkers through phases 1-4 together (256: one after the other)
+    if (fused2) {
+        double* pB = s_r + 10 * JX_MAP_NE(N);
+        jx_load_params(c, theta, w0 + w, p);
+        jx_load_params(c, theta, w0 + w + 1, pB);
+        jx_profile_to_coefs2(c, p, pB, w, part == 0, s_r, s_cf, s_cfB, tap_pp, tap_ab, tap_y);
+    } else {
     jx_load_params(c, theta, w0 + w, p);
     if (!(c.dbg & 1)) jx_profile_to_coefs(c, p, w, part == 0, s_r, s_pp, s_y, s_M, s_cf, s_rq, s_ds, tap_pp, tap_ab, tap_y);
     else { for (int k = tid; k < 4 * (N + 1); k += nth) s_cf[k] = 0.0; __syncthreads(); }
-    if (haveB) {
+    }
+    if (haveB && !fused2) {
         __syncthreads();
         jx_load_params(c, theta, w0 + w + 1, p);
         if (!(c.dbg & 1)) jx_profile_to_coefs(c, p, w + 1, part == 0, s_r, s_pp, s_y, s_M, s_cfB, s_rq, s_ds, tap_pp, tap_ab, tap_y);
