@@ -171,7 +171,8 @@ int  jx_sample(jx_ctx* ctx, const double* theta0_host, int nwalkers, int nsteps,
  *   JX_ROUTE_OPERATOR: those steps are linear in the pressure profile with constant coefficients, so the row is
  *       G pp with one constant nrow x N matrix.  Switching to this route builds G once by sending the N unit profiles
  *       through the MAP route's kernels (a few launches); afterwards a walker costs press_fun + one nrow x N
- *       matrix-vector product on the SZ side.  Same results to rounding (the operator inherits the MAP route's own
+ *       matrix-vector product on the SZ side (launches of 4096 walkers and more: one product on the fp64 matrix cores;
+ *       JOXSZ_OP_NARROW=1 keeps the small-launch kernel).  Same results to rounding (the operator inherits the MAP route's own
  *       truncation, see jx_get_conv_layout); works for every map size, odd sides included.
  * jx_eval_stage always runs the MAP route (the intermediate stages do not exist on the other one).  The data tensors
  * G depends on (r_pp, d_mat, beam_2d, filtering, step, constants) are fixed at jx_finalize, so G never goes stale. */

@@ -102,6 +102,7 @@ struct jx_ctx {
     double* d_G = nullptr;
     double* d_pp = nullptr;            // [op_cap][N] pressure profiles, prep kernel -> operator kernel
     double *d_base_op = nullptr, *d_cfac_op = nullptr;   // [op_cap], [op_cap][nrow]
+    double* d_rows = nullptr;          // [op_cap / 32][nrow][32] G pp of large launches (jx_operator_mfma_kernel)
     int op_cap = 0;                    // walkers per launch on the operator route
     int g_ld = 0;
 
@@ -978,11 +979,22 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
         // collapsed route: the SZ side is one kernel (no map, no transforms)
         es.op = true;
         const int nrow = d.nrow, Re = (nrow + 1) & ~1;
+        // large launches: G pp on the fp64 matrix cores (G fetched once per 32 walkers), the rest in the kernel behind it
+        const int mt = (nrow + 63) / 64;                                     // row tiles per wave
+        const bool wide = n >= 4096 && (mt == 1 || mt == 2 || mt == 4 || mt == 8) && !getenv("JOXSZ_OP_NARROW");
+        if (wide) {
+            const size_t shw = sizeof(double) * JX_OPM_JC * 33;
+#define JX_OPM_GO(MTv) hipLaunchKernelGGL((jx_operator_mfma_kernel<MTv>), dim3((n + 31) / 32), dim3(256), shw, st, ctx->d_pp, n, d.N, nrow, \
+                           ctx->d_G, ctx->g_ld, ctx->d_rows)
+            if (mt == 1) JX_OPM_GO(1); else if (mt == 2) JX_OPM_GO(2); else if (mt == 4) JX_OPM_GO(4); else JX_OPM_GO(8);
+#undef JX_OPM_GO
+        }
+        const double* rows_t = wide ? ctx->d_rows : nullptr;
         int wpb = (n >= 4096) ? 16 : (n >= 2048 ? 8 : 4);                    // walkers per block x radii per LDS chunk = 2048
         while (wpb > 4 && sizeof(double) * (2048 + (size_t)wpb * Re + 8) > 64 * 1024) wpb >>= 1;
         const size_t sh = sizeof(double) * (2048 + (size_t)wpb * Re + 8);
 #define JX_OP_GO(WPBv) hipLaunchKernelGGL((jx_operator_kernel<WPBv, 2048 / WPBv>), dim3((n + WPBv - 1) / WPBv), dim3(256), sh, st, d, ctx->d_pp, w0, n, \
-                           ctx->d_G, ctx->g_ld, cfac_buf, base_buf, logp_dev, t.row, t.bright, t.chisq, t.parts)
+                           ctx->d_G, ctx->g_ld, rows_t, cfac_buf, base_buf, logp_dev, t.row, t.bright, t.chisq, t.parts)
         if (wpb == 16) JX_OP_GO(16); else if (wpb == 8) JX_OP_GO(8); else JX_OP_GO(4);
 #undef JX_OP_GO
         if (tm) {
@@ -1140,7 +1152,7 @@ static int build_operator(jx_ctx* ctx) {
     if ((rc = ensure_batch(ctx, ctx->chunk))) return rc;
     double* G = nullptr;
     double* inj = nullptr;
-    if ((rc = dev_new(ctx, (size_t)(N + 2) * ld, &G, true))) return rc;        // two zero rows behind the last: the kernel reads j in pairs
+    if ((rc = dev_new(ctx, (size_t)(N + 4) * ld, &G, true))) return rc;        // zero rows behind the last: the kernels read j in pairs / fours
     HIPCHK(ctx, hipMalloc((void**)&inj, sizeof(double) * (size_t)ctx->chunk * N));
     std::vector<double> th((size_t)ctx->chunk * c.ndim);
     {
@@ -1176,6 +1188,7 @@ static int build_operator(jx_ctx* ctx) {
     if ((rc = dev_new(ctx, (size_t)ctx->op_cap * N, &ctx->d_pp))) return rc;
     if ((rc = dev_new(ctx, (size_t)ctx->op_cap, &ctx->d_base_op))) return rc;
     if ((rc = dev_new(ctx, (size_t)ctx->op_cap * nrow, &ctx->d_cfac_op))) return rc;
+    if ((rc = dev_new(ctx, ((size_t)ctx->op_cap + 32) * nrow, &ctx->d_rows))) return rc;
     ctx->d_G = G;
     ctx->g_ld = ld;
     return JX_OK;

@@ -1106,7 +1106,8 @@ jx_tail_kernel(JxDev c, const double2* __restrict__ tfspec, const double2* __res
 template <int WPB, int JC>
 __global__ void __launch_bounds__(256)
 jx_operator_kernel(JxDev c, const double* __restrict__ pp /*[launch][N], written by jx_prep_kernel*/, int w0, int n,
-                   const double* __restrict__ Gt /*[N+2][ldg], the last two rows zero*/, int ldg,
+                   const double* __restrict__ Gt /*[N+4][ldg], the last four rows zero*/, int ldg,
+                   const double* __restrict__ rows_t /*[launch / 32][nrow][32] G pp from jx_operator_mfma_kernel; or null*/,
                    const double* __restrict__ cfac, const double* __restrict__ base, double* __restrict__ logp,
                    double* __restrict__ tap_row, double* __restrict__ tap_bright, double* __restrict__ tap_chisq,
                    double* __restrict__ tap_parts) {
@@ -1114,7 +1115,6 @@ jx_operator_kernel(JxDev c, const double* __restrict__ pp /*[launch][N], written
     const int N = c.N, nrow = c.nrow, Re = (nrow + 1) & ~1;
     double* s_pp = sm;                                  // [WPB][JC]
     double* s_prof = s_pp + WPB * JC;             // [WPB][Re]
-    double* red = s_prof + WPB * Re;                    // [8]
     const int tid = threadIdx.x, nth = blockDim.x;
     const int wb = blockIdx.x * WPB;
     const int nw = min(WPB, n - wb);
@@ -1125,7 +1125,15 @@ jx_operator_kernel(JxDev c, const double* __restrict__ pp /*[launch][N], written
         double a[WPB][2];
 #pragma unroll
         for (int k = 0; k < WPB; ++k) a[k][0] = a[k][1] = 0.0;
-        for (int j0 = 0; j0 < N; j0 += JC) {
+        if (rows_t && live) {
+#pragma unroll
+            for (int k = 0; k < WPB; ++k) {             // [walker / 32][x][walker % 32]: WPB divides 32, so one 32-block per thread block
+                const int wq = wb + (k < nw ? k : 0);
+                a[k][0] = rows_t[((size_t)(wq >> 5) * nrow + x) * 32 + (wq & 31)];
+                a[k][1] = 0.0;
+            }
+        }
+        for (int j0 = 0; j0 < (rows_t ? 0 : N); j0 += JC) {
             __syncthreads();                            // the previous chunk has been used up
             for (int q = tid; q < WPB * JC; q += nth) {
                 const int k = q / JC, j = q - k * JC;
@@ -1193,18 +1201,100 @@ jx_operator_kernel(JxDev c, const double* __restrict__ pp /*[launch][N], written
             }
         }
     }
+    // lane 0 of every wave holds its share of each walker's chi^2: one pass through LDS adds the (at most four) shares
+    __syncthreads();                                    // s_pp is free now
+    double* s_part = s_pp;                              // [nwv][WPB]
+    if (lane == 0) {
 #pragma unroll
-    for (int k = 0; k < WPB; ++k) {
-        const double chisq = jx_block_sum(part[k], red);
-        if (tid == 0 && k < nw) {
-            const int w = wb + k;
-            const double ll = -chisq / 2.0;
-            const double b = base[w];
-            double tot = (b == -INFINITY) ? -INFINITY : b + ll;
-            if (tot != tot) tot = -INFINITY;             // never hand NaN to the sampler
-            logp[w0 + w] = tot;
-            if (tap_chisq) tap_chisq[w] = chisq;
-            if (tap_parts) tap_parts[(size_t)w * 4 + 1] = ll;
+        for (int k = 0; k < WPB; ++k) s_part[wv * WPB + k] = part[k];
+    }
+    __syncthreads();
+    if (tid < nw) {
+        double chisq = 0.0;
+        for (int v = 0; v < nwv; ++v) chisq += s_part[v * WPB + tid];
+        const int w = wb + tid;
+        const double ll = -chisq / 2.0;
+        const double b = base[w];
+        double tot = (b == -INFINITY) ? -INFINITY : b + ll;
+        if (tot != tot) tot = -INFINITY;                 // never hand NaN to the sampler
+        logp[w0 + w] = tot;
+        if (tap_chisq) tap_chisq[w] = chisq;
+        if (tap_parts) tap_parts[(size_t)w * 4 + 1] = ll;
+    }
+}
+
+// G pp of large launches on the fp64 matrix cores (v_mfma_f64_16x16x4; operand layouts as in jx_lowrank_kernel: A lane l
+// = A[l & 15][4 s + (l >> 4)], B lane l = B[4 s + (l >> 4)][l & 15], D lane l register g = D[(l >> 4) + 4 g][l & 15]).
+// A = G (rows x, K = radii j; read straight from L2, 128 contiguous bytes per k-row of a tile), B = the pressure
+// profiles of 32 walkers (two 16-walker tiles sharing every A fragment), staged through LDS radius-major.  A block of
+// four waves covers all rows: wave v owns the row tiles [v MT, (v+1) MT).  G is fetched once per 32 walkers.
+// Output per block, walker-minor: rows_t[block][x][32 walkers] (64 KB contiguous per block).  (The sums run in the matrix core's order, not in jx_operator_kernel's: the
+// two agree to rounding, not bit for bit.)
+// LDS: [JX_OPM_JC][33] profile chunk.
+#define JX_OPM_JC 128
+typedef double jx_op_v4d __attribute__((ext_vector_type(4)));
+template <int MT>
+__global__ void __launch_bounds__(256)
+jx_operator_mfma_kernel(const double* __restrict__ pp /*[launch][N]*/, int n, int N, int nrow,
+                        const double* __restrict__ Gt /*[N+4][ldg]*/, int ldg, double* __restrict__ rows_t /*[launch / 32][nrow][32]*/) {
+    JX_LDS_DECL;
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wb = blockIdx.x * 32;
+    const int ntile = (nrow + 15) >> 4;
+    jx_op_v4d acc[MT][2];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) { acc[t][0] = jx_op_v4d{0.0, 0.0, 0.0, 0.0}; acc[t][1] = jx_op_v4d{0.0, 0.0, 0.0, 0.0}; }
+    // A fragments two k-steps ahead of their use (register ring of three): an L2 round trip is longer than the eight
+    // matrix instructions of one k-step
+    int toff[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) toff[t] = min(wv * MT + t, ntile - 1) * 16;   // (a tile past the last repeats it: never stored)
+    const int ktot = (N + 3) >> 2;                                             // G has zero rows behind row N-1
+    const double* gb = Gt + (size_t)lk * ldg + li;
+    double a0[MT], a1[MT], a2[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        a0[t] = gb[toff[t]];
+        a1[t] = (ktot > 1) ? gb[(size_t)4 * ldg + toff[t]] : 0.0;
+        a2[t] = 0.0;
+    }
+    int kg = 0;                                                                // global k-step
+    for (int j0 = 0; j0 < N; j0 += JX_OPM_JC) {
+        __syncthreads();
+        for (int q = tid; q < 32 * JX_OPM_JC; q += 256) {
+            const int l = q / JX_OPM_JC, j = q - l * JX_OPM_JC;                  // consecutive threads: consecutive radii of one walker
+            sm[j * 33 + l] = (wb + l < n && j0 + j < N) ? pp[(size_t)(wb + l) * N + j0 + j] : 0.0;
+        }
+        __syncthreads();
+        const int ksteps = min(JX_OPM_JC, (N - j0 + 3) & ~3) >> 2;
+        for (int s = 0; s < ksteps; ++s, ++kg) {
+            if (kg + 2 < ktot) {
+                const double* gs = gb + (size_t)(4 * (kg + 2)) * ldg;
+#pragma unroll
+                for (int t = 0; t < MT; ++t) a2[t] = gs[toff[t]];
+            }
+            const double b0 = sm[(4 * s + lk) * 33 + li], b1 = sm[(4 * s + lk) * 33 + 16 + li];
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                acc[t][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[t], b0, acc[t][0], 0, 0, 0);
+                acc[t][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[t], b1, acc[t][1], 0, 0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < MT; ++t) { a0[t] = a1[t]; a1[t] = a2[t]; }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        const int tile = wv * MT + t;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int w = wb + nt * 16 + li;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int x = tile * 16 + lk + 4 * g;
+                if (tile < ntile && x < nrow && w < n) rows_t[((size_t)blockIdx.x * nrow + x) * 32 + nt * 16 + li] = acc[t][nt][g];
+            }
         }
     }
 }

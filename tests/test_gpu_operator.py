@@ -135,19 +135,27 @@ def test_operator_route_full_size():
     np.testing.assert_allclose(lp_op[fin], lp_map[fin], rtol=1e-9)
 
 
-@pytest.mark.parametrize('S,N', [(512, 500), (171, 313)])
-def test_operator_route_large_launch_equals_small_launch(S, N):
-    """The operator kernel takes 4, 8 or 16 walkers per block by launch size; a walker's sums run in the same order in
-    all three, so its log-posterior is the same bit pattern whichever launch it was part of."""
+@pytest.mark.parametrize('S,N', [(512, 500), (171, 313), (256, 300)])
+def test_operator_route_large_launch_equals_small_launch(S, N, monkeypatch):
+    """Launches of 4096 walkers and more take G pp from the matrix-core kernel (32 walkers per block), smaller ones from
+    the 4/8/16-walkers-per-block kernel.  Within each of the two a walker's log-posterior is the same bit pattern
+    whichever launch it was part of; between them the sums run in different orders and agree to rounding."""
     from joxsz_amd import datasets
     pb = datasets.synthetic_problem(S=S, N=N, seed=0)
-    th = datasets.walker_ball(pb, 4500, spread=0.03, seed=8)       # 16 walkers per block, a ragged last block
+    th = datasets.walker_ball(pb, 9000, spread=0.03, seed=8)       # ragged last blocks of 32 and of 16
     th[7, 1] = 9.0
     post = _post(pb, route='operator')
-    big = post.log_prob(th)
-    mid = np.concatenate([post.log_prob(th[k:k + 2250]) for k in range(0, 4500, 2250)])      # 8 per block
-    small = np.concatenate([post.log_prob(th[k:k + 500]) for k in range(0, 4500, 500)])      # 4 per block
+    big = post.log_prob(th)                                                                   # matrix cores
+    mid = np.concatenate([post.log_prob(th[k:k + 4500]) for k in range(0, 9000, 4500)])      # matrix cores, other blocks
+    small = np.concatenate([post.log_prob(th[k:k + 500]) for k in range(0, 9000, 500)])      # 4 walkers per block
+    tiny = np.concatenate([post.log_prob(th[k:k + 3000]) for k in range(0, 9000, 3000)])     # 8 per block
     post.close()
-    assert np.isfinite(big).sum() > 4000 and big[7] == -np.inf
+    fin = np.isfinite(big)
+    assert fin.sum() > 8000 and big[7] == -np.inf and np.array_equal(np.isfinite(small), fin)
     np.testing.assert_array_equal(big, mid)
-    np.testing.assert_array_equal(big, small)
+    np.testing.assert_array_equal(small, tiny)
+    np.testing.assert_allclose(big[fin], small[fin], rtol=1e-12)
+    monkeypatch.setenv('JOXSZ_OP_NARROW', '1')                      # the small-launch kernel on the large launch (16 per block)
+    post = _post(pb, route='operator')
+    np.testing.assert_array_equal(post.log_prob(th), small)
+    post.close()
