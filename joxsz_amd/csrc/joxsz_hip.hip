@@ -990,7 +990,8 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
 #undef JX_OPM_GO
         }
         const double* rows_t = wide ? ctx->d_rows : nullptr;
-        int wpb = (n >= 4096) ? 16 : (n >= 2048 ? 8 : 4);                    // walkers per block x radii per LDS chunk = 2048
+        // walkers per block (x radii per LDS chunk = 2048): more of them spare G traffic; behind the matrix-core product there is none to spare
+        int wpb = wide ? 4 : ((n >= 4096) ? 16 : (n >= 2048 ? 8 : 4));
         while (wpb > 4 && sizeof(double) * (2048 + (size_t)wpb * Re + 8) > 64 * 1024) wpb >>= 1;
         const size_t sh = sizeof(double) * (2048 + (size_t)wpb * Re + 8);
 #define JX_OP_GO(WPBv) hipLaunchKernelGGL((jx_operator_kernel<WPBv, 2048 / WPBv>), dim3((n + WPBv - 1) / WPBv), dim3(256), sh, st, d, ctx->d_pp, w0, n, \

@@ -1173,35 +1173,82 @@ jx_operator_kernel(JxDev c, const double* __restrict__ pp /*[launch][N], written
     }
     __syncthreads();
 
-    // data radii and chi^2: one data point per wave at a time, lanes along the row (emat rows are contiguous)
+    // data radii and chi^2: one data point per wave at a time, lanes along the row (emat rows are contiguous).  Every
+    // emat entry a wave will need is requested before the first is used (one L2 round trip instead of one per use).
     double part[WPB];
 #pragma unroll
     for (int k = 0; k < WPB; ++k) part[k] = 0.0;
     const int lane = tid & 63, wv = tid >> 6, nwv = nth >> 6;
-    for (int d = wv; d < c.nflux; d += nwv) {
-        const double* e = c.emat + (size_t)d * nrow;
-        double m[WPB];
+    constexpr int NXM = 4, NDM = 8;                     // up to 256 row entries per lane set, 8 data points per wave
+    if (nrow <= 64 * NXM && c.nflux <= nwv * NDM) {
+        double ev[NDM][NXM], fv[NDM], erv[NDM];
 #pragma unroll
-        for (int k = 0; k < WPB; ++k) m[k] = 0.0;
-        for (int x = lane; x < nrow; x += 64) {
-            const double ev = e[x];
+        for (int dd = 0; dd < NDM; ++dd) {
+            const int d = wv + dd * nwv;
+            fv[dd] = (d < c.nflux) ? c.flux[c.nflux + d] : 0.0;
+            erv[dd] = (d < c.nflux) ? c.flux[2 * c.nflux + d] : 1.0;
 #pragma unroll
-            for (int k = 0; k < WPB; ++k) m[k] = fma(ev, s_prof[k * Re + x], m[k]);
+            for (int i = 0; i < NXM; ++i) {
+                const int x = lane + 64 * i;
+                ev[dd][i] = (d < c.nflux && x < nrow) ? c.emat[(size_t)d * nrow + x] : 0.0;
+            }
         }
+        double pv[WPB][NXM];
 #pragma unroll
         for (int k = 0; k < WPB; ++k)
-            for (int off = 32; off > 0; off >>= 1) m[k] += __shfl_xor(m[k], off, 64);
-        if (lane == 0) {
-            const double f = c.flux[c.nflux + d], er = c.flux[2 * c.nflux + d];
 #pragma unroll
-            for (int k = 0; k < WPB; ++k) {
-                const double z = (f - m[k]) / er;
-                const double z2 = z * z;
-                if (z2 == z2) part[k] += z2;             // np.nansum drops NaN terms
+            for (int i = 0; i < NXM; ++i) { const int x = lane + 64 * i; pv[k][i] = (x < nrow) ? s_prof[k * Re + x] : 0.0; }
+#pragma unroll
+        for (int dd = 0; dd < NDM; ++dd) {
+            const int d = wv + dd * nwv;
+            if (d < c.nflux) {                          // (wave-uniform)
+                double m[WPB];
+#pragma unroll
+                for (int k = 0; k < WPB; ++k) {
+                    m[k] = 0.0;
+#pragma unroll
+                    for (int i = 0; i < NXM; ++i) if (lane + 64 * i < nrow) m[k] = fma(ev[dd][i], pv[k][i], m[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < WPB; ++k)
+                    for (int off = 32; off > 0; off >>= 1) m[k] += __shfl_xor(m[k], off, 64);
+                if (lane == 0) {
+#pragma unroll
+                    for (int k = 0; k < WPB; ++k) {
+                        const double z = (fv[dd] - m[k]) / erv[dd];
+                        const double z2 = z * z;
+                        if (z2 == z2) part[k] += z2;     // np.nansum drops NaN terms
+                    }
+                }
+            }
+        }
+    } else {
+        for (int d = wv; d < c.nflux; d += nwv) {
+            const double* e = c.emat + (size_t)d * nrow;
+            double m[WPB];
+#pragma unroll
+            for (int k = 0; k < WPB; ++k) m[k] = 0.0;
+            for (int x = lane; x < nrow; x += 64) {
+                const double ev = e[x];
+#pragma unroll
+                for (int k = 0; k < WPB; ++k) m[k] = fma(ev, s_prof[k * Re + x], m[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < WPB; ++k)
+                for (int off = 32; off > 0; off >>= 1) m[k] += __shfl_xor(m[k], off, 64);
+            if (lane == 0) {
+                const double f = c.flux[c.nflux + d], er = c.flux[2 * c.nflux + d];
+#pragma unroll
+                for (int k = 0; k < WPB; ++k) {
+                    const double z = (f - m[k]) / er;
+                    const double z2 = z * z;
+                    if (z2 == z2) part[k] += z2;         // np.nansum drops NaN terms
+                }
             }
         }
     }
     // lane 0 of every wave holds its share of each walker's chi^2: one pass through LDS adds the (at most four) shares
+    const double base_pre = (tid < nw) ? base[wb + tid] : 0.0;      // (requested ahead of the two barriers)
     __syncthreads();                                    // s_pp is free now
     double* s_part = s_pp;                              // [nwv][WPB]
     if (lane == 0) {
@@ -1214,7 +1261,7 @@ jx_operator_kernel(JxDev c, const double* __restrict__ pp /*[launch][N], written
         for (int v = 0; v < nwv; ++v) chisq += s_part[v * WPB + tid];
         const int w = wb + tid;
         const double ll = -chisq / 2.0;
-        const double b = base[w];
+        const double b = base_pre;
         double tot = (b == -INFINITY) ? -INFINITY : b + ll;
         if (tot != tot) tot = -INFINITY;                 // never hand NaN to the sampler
         logp[w0 + w] = tot;
