@@ -26,17 +26,23 @@ def main():
     datasets.fill_data(pb, bright, xprofs, seed=0)
     post = JoxszPosterior(pb, device=0)
     p0 = initial_ball(post.log_prob, datasets.fiducial_theta(pb), W, spread=0.01, rng=np.random.default_rng(1))
+    for route in ('map', 'operator'):
+        post.ctx.set_route(route)
+        run(post, pb, p0, W, steps, route)
+    post.close()
+
+
+def run(post, pb, p0, W, steps, route):
     post.sample(p0, 2)                                           # warm-up
     t = time.perf_counter(); chain, lps, nacc = post.sample(p0, steps, seed=5); td = time.perf_counter() - t
     sm = StretchMoveSampler(W, pb.ndim, post.log_prob, seed=5)
     sm.run(p0, 2)
     t = time.perf_counter(); sm.run(p0, steps); th = time.perf_counter() - t
-    print('%d walkers, %d steps (2 half steps each) at 512^2 / 500' % (W, steps))
+    print('%d walkers, %d steps (2 half steps each) at 512^2 / 500, route %s' % (W, steps, route))
     print('device-resident loop (jx_sample): %.2f ms per step, %.0f walker-updates/s, acceptance %.2f'
           % (1e3 * td / steps, W * steps / td, nacc.mean() / steps))
     print('host loop (numpy proposals + log_prob per half step): %.2f ms per step, %.0f walker-updates/s, acceptance %.2f'
           % (1e3 * th / steps, W * steps / th, sm.acceptance_fraction.mean()))
-    post.close()
 
 
 if __name__ == '__main__':
