@@ -31,7 +31,7 @@ def test_golden_logp_operator_route(golden):
 
 
 @pytest.mark.parametrize('S,N,kw', [(31, 40, {}), (64, 80, {}), (48, 60, dict(sz_only=True)), (48, 60, dict(ne_mode='double')),
-                                    (171, 313, {}), (256, 300, {})])
+                                    (171, 313, {}), (256, 300, {}), (513, 500, {})])
 def test_random_walkers_vs_oracle_operator_route(S, N, kw):
     """Odd (reference-shaped, rocFFT underneath) and even (hand-written passes underneath) sides."""
     from joxsz_amd import datasets

@@ -76,7 +76,8 @@ def test_stage_by_stage_vs_oracle(golden_tiny):
 
 
 @pytest.mark.parametrize('S,N,conv', [(31, 40, 'rocfft'), (32, 40, 'rocfft'), (64, 80, 'rocfft'), (64, 80, 'custom'),
-                                      (48, 60, 'custom'), (171, 313, 'auto'), (256, 300, 'rocfft'), (256, 300, 'custom')])
+                                      (48, 60, 'custom'), (171, 313, 'auto'), (256, 300, 'rocfft'), (256, 300, 'custom'),
+                                      (257, 300, 'auto'), (513, 500, 'auto')])
 def test_random_walkers_vs_oracle(S, N, conv):
     """Odd (reference-shaped) and even (BASELINE-shaped) map sides, seeded walkers, both
     convolution back ends (rocFFT sequence / hand-written mixed-domain passes)."""
