@@ -285,6 +285,7 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
         if (v != v) rej |= REJ_BOX;           // NaN parameter: reject (emcee cannot use NaN)
     }
     const double parprior = jx_block_sum(pr, red);
+    if (!(fabs(parprior) <= 1.79769313486231570e308)) rej |= REJ_BOX;     // joxsz_funcs.py:519-520: a non-finite prior returns -inf at once
 
     // ---- model prior: r_c <= r_s (joxsz_funcs.py:397-407) ----
     if (tid == 0 && (c.prep_pow ? (pow(10.0, p[P_LOGRC]) > pow(10.0, p[P_LOGRS])) : (p[P_LOGRC] > p[P_LOGRS]))) rej |= REJ_RCRS;   // 10^x is monotonic

@@ -1,0 +1,250 @@
+"""BASELINE.json configs as stated, through the C-ABI on the GPU, with stage-level parity at full size.
+
+configs[1]: 256 walkers, 256^2 map, 300-pt grid, SZ-only likelihood.
+configs[2]/[3]: 512^2 map, 500-pt grid, joint likelihood; a 512-walker shard (what one of 8 ranks holds of configs[3]).
+configs[4]: 1024^2 map, 1000-pt grid; a 1024-walker shard (what one of 8 ranks holds), fp64 leg.
+
+The log-posterior of these problems is ~1e4 and dominated by the Cash term while chi^2/2 of the SZ side is ~10, so a
+relative bound on the log-posterior alone is a weak statement about the SZ path (joxsz_funcs.py:472-479).  Every case
+therefore also holds the extracted row, the surface-brightness profile and chi^2 to the oracle, chi^2/2 ABSOLUTELY.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+from oracle import joxsz_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-6              # north_star: relative, on the log-posterior
+RTOL_STAGE = 1e-9        # rows and profiles, relative to their largest entry
+ATOL_HALF_CHISQ = 1e-6   # |chi^2/2 (GPU) - chi^2/2 (oracle)|, absolute
+
+
+def _post(pb, **kw):
+    from joxsz_amd.posterior import JoxszPosterior
+    return JoxszPosterior(pb, device=0, **kw)
+
+
+def _problem(S, N, seed, **kw):
+    """Synthetic problem whose observations are the model at the fiducial vector plus noise (chi^2 ~ nflux)."""
+    from joxsz_amd import datasets
+    pb = datasets.synthetic_problem(S=S, N=N, seed=seed, **kw)
+    p0 = orc.pars_dict(pb, datasets.fiducial_theta(pb))
+    datasets.fill_data(pb, orc.sz_stages(pb, p0)['bright'], None if pb.sz_only else orc.calc_profiles(pb, p0), seed=seed)
+    return pb
+
+
+def _check_stages(pb, post, th, nref):
+    """map_row / bright / chisq / logp of the first nref walkers against one oracle call per walker."""
+    rows = post.stage(th[:nref], 'map_row')
+    bright = post.stage(th[:nref], 'bright')
+    chisq = post.stage(th[:nref], 'chisq')
+    logp = post.log_prob(th[:nref])
+    want_lp = orc.log_posterior_batch(pb, th[:nref])
+    worst = dict(row=0.0, bright=0.0, half_chisq=0.0, logp=0.0)
+    nfin = 0
+    for k in range(nref):
+        st = orc.sz_stages(pb, orc.pars_dict(pb, th[k]))
+        worst['row'] = max(worst['row'], np.abs(rows[k] - st['map_row']).max() / np.abs(st['map_row']).max())
+        worst['bright'] = max(worst['bright'], np.abs(bright[k] - st['bright']).max() / np.abs(st['bright']).max())
+        worst['half_chisq'] = max(worst['half_chisq'], abs(chisq[k] - st['chisq']) / 2)
+        assert np.isfinite(want_lp[k]) == np.isfinite(logp[k])
+        if np.isfinite(want_lp[k]):
+            nfin += 1
+            worst['logp'] = max(worst['logp'], abs(logp[k] - want_lp[k]) / abs(want_lp[k]))
+            # the parts add up to the total the way joxsz_funcs.py:538 adds them
+    assert nfin >= nref // 2, 'too few finite walkers in the reference sample'
+    assert worst['row'] < RTOL_STAGE, worst
+    assert worst['bright'] < RTOL_STAGE, worst
+    assert worst['half_chisq'] < ATOL_HALF_CHISQ, worst
+    assert worst['logp'] < RTOL, worst
+    return worst
+
+
+def test_config1_sz_only_256():
+    """configs[1] exactly: sz_only, S=256, N=300, 256 walkers; 16 of them against the oracle stage by stage, all of them
+    twice (bitwise), and split over ragged launches (bitwise)."""
+    from joxsz_amd import datasets
+    pb = _problem(256, 300, seed=1, sz_only=True)
+    th = datasets.walker_ball(pb, 256, spread=0.03, seed=1)
+    post = _post(pb)
+    assert post.ctx.conv == 'custom' and post.ctx.conv_layout['fused'] == 1
+    a = post.log_prob(th)
+    b = post.log_prob(th)
+    np.testing.assert_array_equal(a, b)
+    assert np.isfinite(a).sum() >= 200
+    _check_stages(pb, post, th, 16)
+    # SZ-only: the total is prior + sz_like, no X-ray term
+    parts = post.stage(th[:16], 'parts')
+    fin = np.isfinite(a[:16])
+    np.testing.assert_allclose(parts[fin, 0], 0.0)
+    np.testing.assert_allclose(a[:16][fin], parts[fin, 1] + parts[fin, 2], rtol=1e-14)
+    post.close()
+    small = _post(pb, max_batch=100)
+    np.testing.assert_array_equal(small.log_prob(th), a)
+    small.close()
+
+
+def test_config3_shard_512_walkers():
+    """One rank's share of configs[3] (4096 walkers over 8 ranks = 512 walkers at 512^2 / 500-pt, joint likelihood):
+    16 walkers against the oracle with the absolute chi^2/2 bound, all 512 for determinism and rejections."""
+    from joxsz_amd import datasets
+    from joxsz_amd.dist import shard_bounds
+    pb = _problem(512, 500, seed=2)
+    full = datasets.walker_ball(pb, 4096, spread=0.03, seed=2)
+    lo, hi = shard_bounds(4096, 8, 3)
+    assert hi - lo == 512
+    th = np.ascontiguousarray(full[lo:hi])
+    post = _post(pb)
+    assert post.ctx.conv == 'custom' and post.ctx.conv_layout['fused'] == 1
+    a = post.log_prob(th)
+    np.testing.assert_array_equal(a, post.log_prob(th))
+    assert np.isfinite(a).sum() >= 400
+    worst = _check_stages(pb, post, th, 16)
+    parts = post.stage(th[:64], 'parts')
+    fin = np.isfinite(a[:64])
+    np.testing.assert_allclose(a[:64][fin], parts[fin, 0] + parts[fin, 1] + parts[fin, 2], rtol=1e-14)
+    assert np.all(parts[~fin, 3] != 0)
+    post.close()
+    print('config3 shard worst errors', worst)
+
+
+def test_config4_shard_1024_walkers_fp64():
+    """One rank's share of configs[4] (8192 walkers over 8 ranks = 1024 walkers at 1024^2 / 1000-pt), fp64: 6 walkers
+    against the oracle stage by stage (absolute chi^2/2 bound), all 1024 evaluated twice (bitwise)."""
+    from joxsz_amd import datasets
+    pb = _problem(1024, 1000, seed=4)
+    th = datasets.walker_ball(pb, 1024, spread=0.02, seed=4)
+    post = _post(pb)
+    assert post.ctx.conv == 'custom'
+    a = post.log_prob(th)
+    np.testing.assert_array_equal(a, post.log_prob(th))
+    assert np.isfinite(a).sum() >= 900
+    worst = _check_stages(pb, post, th, 6)
+    post.close()
+    print('config4 shard worst errors', worst)
+
+
+def test_headline_stage_parity_32_walkers():
+    """configs[2] (the headline shape): 32 walkers spread wider around the fiducial vector, stage by stage."""
+    from joxsz_amd import datasets
+    pb = _problem(512, 500, seed=0)
+    th = datasets.walker_ball(pb, 32, spread=0.06, seed=5)
+    post = _post(pb)
+    worst = _check_stages(pb, post, th, 32)
+    post.close()
+    print('headline worst errors', worst)
+
+
+def test_nan_and_inf_parameters_are_rejections():
+    """NaN / +-inf in any thawed parameter gives -inf (never NaN, never an exception): joxsz_funcs.py:519-520 for the box
+    priors, and emcee cannot take NaN from a log-probability function."""
+    from joxsz_amd import datasets
+    pb = _problem(64, 80, seed=7)
+    t0 = datasets.fiducial_theta(pb)
+    ok = _post(pb)
+    base = ok.log_prob(t0[None, :])[0]
+    assert np.isfinite(base)
+    bad = []
+    for k in range(pb.ndim):
+        for v in (np.nan, np.inf, -np.inf):
+            t = t0.copy(); t[k] = v
+            bad.append(t)
+    bad = np.array(bad)
+    th = np.vstack((t0[None, :], bad, t0[None, :]))
+    for route in ('map', 'operator'):
+        ok.ctx.set_route(route)
+        got = ok.log_prob(th)
+        assert got[0] == base or route == 'operator'
+        assert np.isfinite(got[0]) and np.isfinite(got[-1])
+        assert np.all(got[1:-1] == -np.inf), (route, got)
+        assert not np.isnan(got).any()
+    ok.ctx.set_route('map')
+    parts = ok.stage(bad, 'parts')
+    assert np.all(parts[:, 3] != 0)
+    assert ok.getLikelihood(bad[0]) == -np.inf
+    ok.close()
+
+
+def test_c_abi_error_codes():
+    """Every misuse returns its negative jx_status (include/joxsz_hip.h) and leaves the context usable or cleanly dead."""
+    from joxsz_amd import datasets, hip_backend as hb
+    lib = hb.load_library()
+    pb = datasets.synthetic_problem(S=64, N=80, seed=3)
+    vp, dp = ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)
+    INVALID, STATE, MISSING, NODEVICE, UNSUPPORTED = -1, -2, -3, -7, -8
+
+    def make(**over):
+        cfg = hb.config_from_problem(pb, **{k: v for k, v in over.items() if k in ('device', 'conv', 'max_batch')})
+        for k, v in over.items():
+            if k not in ('device', 'conv', 'max_batch'):
+                setattr(cfg, k, v)
+        h = vp()
+        return lib.jx_create(ctypes.byref(cfg), ctypes.byref(h)), h
+
+    def upload_all(h, skip=()):
+        for tid, name in enumerate(hb.TENSORS):
+            if name in skip:
+                continue
+            a = pb.thawed_idx if name == 'thawed_idx' else getattr(pb, name)
+            a = np.ascontiguousarray(a, dtype=np.int32 if name in ('par_kind', 'thawed_idx') else np.float64)
+            assert lib.jx_upload(h, tid, a.ctypes.data_as(vp), a.nbytes) == 0, name
+
+    # jx_create
+    assert make(abi_version=99)[0] == INVALID
+    assert make(B=4)[0] == INVALID                                   # even beam side
+    assert make(npar=17)[0] == INVALID
+    assert make(device=63)[0] == NODEVICE
+    assert make(N=5000)[0] == UNSUPPORTED                            # beyond the LDS-resident spline
+    assert lib.jx_create(None, None) == INVALID
+
+    rc, h = make()
+    assert rc == 0
+    th = np.ascontiguousarray(datasets.walker_ball(pb, 4, spread=0.01, seed=1))
+    out = np.empty(4)
+    # before finalize
+    assert lib.jx_eval(h, th.ctypes.data_as(dp), 4, out.ctypes.data_as(dp)) == STATE
+    assert lib.jx_set_route(h, 1) == STATE
+    assert lib.jx_get_conv_mode(h) == STATE
+    assert lib.jx_finalize(h) == MISSING
+    assert b'missing' in lib.jx_last_error(h)
+    a = np.zeros(5)
+    assert lib.jx_upload(h, 0, a.ctypes.data_as(vp), a.nbytes) == INVALID          # wrong size for r_pp
+    assert lib.jx_upload(h, 999, a.ctypes.data_as(vp), a.nbytes) == INVALID
+    assert lib.jx_upload(h, 0, None, 0) == INVALID
+    upload_all(h, skip=('lnrate',))
+    assert lib.jx_finalize(h) == MISSING
+    upload_all(h)
+    assert lib.jx_finalize(h) == 0
+    assert lib.jx_finalize(h) == STATE
+    r = np.ascontiguousarray(pb.r_pp)
+    assert lib.jx_upload(h, 0, r.ctypes.data_as(vp), r.nbytes) == STATE             # upload after finalize
+    # evaluation arguments
+    assert lib.jx_eval(h, th.ctypes.data_as(dp), -1, out.ctypes.data_as(dp)) == INVALID
+    assert lib.jx_eval(h, None, 4, out.ctypes.data_as(dp)) == INVALID
+    assert lib.jx_eval(h, None, 0, None) == 0                                       # an empty batch is fine
+    assert lib.jx_eval_stage(h, th.ctypes.data_as(dp), 4, 99, out.ctypes.data_as(dp), out.nbytes) == INVALID
+    assert lib.jx_eval_stage(h, th.ctypes.data_as(dp), 4, 7, out.ctypes.data_as(dp), 8) == INVALID   # chisq: 4 doubles expected
+    assert lib.jx_set_route(h, 5) == INVALID
+    big = np.empty((pb.N, pb.nrow))
+    assert lib.jx_get_operator(h, big.ctypes.data_as(dp), big.nbytes) == STATE      # operator route never selected
+    assert lib.jx_sample(h, th.ctypes.data_as(dp), 3, 1, 2.0, 0, None, None, None) == INVALID       # odd ensemble
+    assert lib.jx_sample(h, th.ctypes.data_as(dp), 4, 1, 1.0, 0, None, None, None) == INVALID       # a must exceed 1
+    assert lib.jx_set_par_vals(h, th.ctypes.data_as(dp), 3) == INVALID
+    # still usable after all of that
+    assert lib.jx_eval(h, th.ctypes.data_as(dp), 4, out.ctypes.data_as(dp)) == 0
+    want = orc.log_posterior_batch(pb, th)
+    fin = np.isfinite(want)
+    np.testing.assert_allclose(out[fin], want[fin], rtol=RTOL)
+    lib.jx_destroy(h)
+    lib.jx_destroy(None)                                              # no-op
+
+    # a non-increasing radial grid is refused at finalize
+    rc, h = make()
+    upload_all(h)
+    bad = np.ascontiguousarray(pb.r_pp[::-1])
+    assert lib.jx_upload(h, 0, bad.ctypes.data_as(vp), bad.nbytes) == 0
+    assert lib.jx_finalize(h) == INVALID
+    lib.jx_destroy(h)
