@@ -16,6 +16,7 @@
 #include "../../include/joxsz_hip.h"
 #include "jx_kernels.hpp"
 #include "jx_conv.hpp"
+#include "jx_dct.hpp"
 #include "jx_tables.hpp"
 
 namespace {
@@ -81,6 +82,11 @@ struct jx_ctx {
     bool lr_sep = false;              // the separate combination kernel is available (else: fused route or one row per job)
     int fused_nh = 1;                 // K halves of the fused GEMM (two launches, the second accumulating, when NU/4 exceeds the buckets)
     int last_nblk3 = 0;               // pass-3 blocks per walker of the launch sequence just queued
+    // pass 1 from the spline coefficients (jx_rowdct_kernel): no Compton-y map in HBM on the default route
+    bool dct_ok = false;
+    JxDct dct{};
+    double* d_cf = nullptr;           // [chunk][cf_ws] cubic coefficients, Abel kernel -> jx_rowdct_kernel
+    size_t dct_lds = 0;
     int num_cu = 256;
     int* d_rowjob = nullptr;
     int* d_runs = nullptr;
@@ -121,6 +127,10 @@ static int g_rocfft_refs = 0;
 
 // two-level (register-blocked) forms: (LP, LS, rows per block in pass 1, rows per block in pass 3)
 #define JX_CONV2_PAIRS(X) X(18, 16, 42, 42) X(48, 24, 32, 32) X(48, 32, 32, 32) X(96, 64, 21, 21) X(144, 128, 21, 16) X(288, 256, 14, 14) X(576, 512, 10, 8)
+
+// coefficient-fed pass 1 (jx_rowdct_kernel): (LP = padded length / 2, NS =
+// samples per distinct row, threads per block: 16 walkers x max(L1, L2) FFT tasks + one wave without one)
+#define JX_DCT_SIZES(X) X(48, 24, 192) X(48, 32, 192) X(96, 64, 192) X(144, 128, 256) X(288, 256, 256) X(576, 512, 384)
 
 #define HIPCHK(ctx, call)                                                                          \
     do {                                                                                           \
@@ -768,6 +778,44 @@ int jx_finalize(jx_ctx* ctx) {
                 ctx->cv_f.tmode = 1; ctx->cv_f.tW = ctx->tW; ctx->cv_f.tKU = KU; ctx->cv_f.ct0 = ctx->d_Ct0; ctx->cv_f.kact = kact;
             }
             ctx->h_L.clear(); ctx->h_taps.clear();
+            // pass 1 straight from the spline coefficients: needs the fused route (walker-minor rows) and the quadrant table
+            bool want_dct = ctx->lrf.r > 0 && d.quad;
+            if (const char* e = getenv("JOXSZ_DCT")) { if (atoi(e) == 0) want_dct = false; }
+            if (want_dct) {
+                std::vector<int32_t> qk((size_t)d.q_nb * d.q_na);
+                std::vector<double> qt((size_t)d.q_nb * d.q_na);
+                HIPCHK(ctx, hipMemcpy(qk.data(), d.q_k, qk.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+                HIPCHK(ctx, hipMemcpy(qt.data(), d.q_t, qt.size() * sizeof(double), hipMemcpyDeviceToHost));
+                jxt::DctTables dt;
+                bool have_kernel = false;
+#define JX_DCT_HAS(LPv, NSv, NTv) if (cv.LP == LPv && cv.LS == NSv && S % 2 == 0) have_kernel = true;
+                JX_DCT_SIZES(JX_DCT_HAS)
+#undef JX_DCT_HAS
+                if (have_kernel && jxt::dct_tables(qk, qt, d.q_na, d.q_nb, S, N, cv.LP, dt) && dt.amax + 1 == cv.LS &&
+                    (unsigned long long)cv.LP * ctx->tKU * ctx->tW * 8ull < (1ull << 32)) {
+                    JxDct& dc = ctx->dct;
+                    memset(&dc, 0, sizeof(dc));
+                    dc.NU = cv.NU; dc.kact = ctx->kact; dc.gl = dt.gl; dc.na4 = dt.na4; dc.has_x0 = dt.has_x0; dc.N = N;
+                    dc.cf_ws = (4 * ((long long)N + 1) + 15) & ~15LL;
+                    dc.tW = ctx->tW; dc.tKU = ctx->tKU;
+                    int* qi; double* qd;
+                    if ((rc = dev_put(ctx, dt.dk.data(), dt.dk.size(), &qi))) return rc; dc.dk = qi;
+                    if ((rc = dev_put(ctx, dt.dt.data(), dt.dt.size(), &qd))) return rc; dc.dt = qd;
+                    if ((rc = dev_put(ctx, dt.x0k.data(), dt.x0k.size(), &qi))) return rc; dc.x0k = qi;
+                    if ((rc = dev_put(ctx, dt.x0t.data(), dt.x0t.size(), &qd))) return rc; dc.x0t_t = qd;
+                    if ((rc = dev_put(ctx, dt.pk.data(), dt.pk.size(), &qd))) return rc; dc.pk = qd;
+                    std::vector<double> tq;
+                    jxt::twiddles(cv.LP / 2, cv.LP / 2, tq);
+                    if ((rc = dev_put(ctx, tq.data(), tq.size(), &qd))) return rc; dc.tw_q = (const cplx*)qd;
+                    if ((rc = dev_new(ctx, (size_t)chunk * dc.cf_ws, &ctx->d_cf, true))) return rc;
+#define JX_DCT_ATTR(LPv, NSv, NTv) if (cv.LP == LPv && cv.LS == NSv) { \
+                        ctx->dct_lds = sizeof(cplx) * ((size_t)16 * jx_dct_lay<LPv / 2>::RS + LPv / 2) + sizeof(double) * (4 * (LPv / 4 + 1) + 16 * 64 + 16); \
+                        HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_rowdct_kernel<LPv, NSv, 16, NTv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->dct_lds)); }
+                    JX_DCT_SIZES(JX_DCT_ATTR)
+#undef JX_DCT_ATTR
+                    ctx->dct_ok = true;
+                }
+            }
         }
 #define JX_ATTR2(LPv, LSv, R1v, R3v) if (cv.LP == LPv && cv.LS == LSv) { \
             constexpr int rs1 = jx_lay<LPv>::RS, rs3 = jx_lay<LPv>::RS > jx_lay<LSv>::RS ? jx_lay<LPv>::RS : jx_lay<LSv>::RS; \
@@ -831,6 +879,7 @@ static int drain_events(jx_ctx* ctx) {
 struct Taps {
     double *pp = nullptr, *ab = nullptr, *y = nullptr, *row = nullptr, *bright = nullptr, *chisq = nullptr,
            *tprof = nullptr, *xprofs = nullptr, *parts = nullptr, *conv = nullptr;
+    bool need_img = false;            // the Compton-y map itself is wanted (y_2d tap, work-buffer hook): map kernel + pass 1 from the image
 };
 
 
@@ -840,13 +889,28 @@ static bool use_fused(const jx_ctx* ctx, const double* tap_convjobs) {
 }
 
 // map -> pass 1 (walker-minor rows) -> one GEMM per column (FIR + job combination) -> pass 3 over the combined rows
-static int launch_fused_conv(jx_ctx* ctx, int n, EvSet* es) {
+static int launch_fused_conv(jx_ctx* ctx, int n, EvSet* es, bool dct) {
     const JxConv& cv = ctx->cv;
     const JxDev& d = ctx->d;
     hipStream_t st = ctx->stream;
     JxConv cf = ctx->cv_f;
     cf.tn = n;
     bool done = false;
+    if (dct) {
+        JxDct dc = ctx->dct;
+        dc.n = n;
+        const int ngroups = (n + 15) / 16, gp8 = (ngroups + 7) / 8;
+        // row classes: enough blocks to fill the device a few times over, at least ~8 rows per block when there are many
+        int nrc = std::max(1, std::min(dc.NU, (8 * ctx->num_cu + 8 * gp8 - 1) / (8 * gp8)));
+        if (const char* e = getenv("JOXSZ_DCT_NRC")) { int v = atoi(e); if (v > 0) nrc = std::min(v, dc.NU); }
+        dc.nrc = nrc;
+        const dim3 gd((unsigned)(8 * gp8 * nrc));
+#define JX_DCT_GO(LPv, NSv, NTv) if (!done && cv.LP == LPv && cv.LS == NSv) { \
+            hipLaunchKernelGGL((jx_rowdct_kernel<LPv, NSv, 16, NTv>), gd, dim3(NTv), ctx->dct_lds, st, dc, ctx->d_cf, ctx->d_Rt, ctx->d_x0t); done = true; }
+        JX_DCT_SIZES(JX_DCT_GO)
+#undef JX_DCT_GO
+        if (!done) { ctx->err = "no coefficient-fed pass-1 kernel for this size"; return JX_ERR_UNSUPPORTED; }
+    }
     const dim3 g1(cv.NU, (n + ctx->p1_rows - 1) / ctx->p1_rows);
 #define JX_P1(LPv, LSv, R1v, R3v) if (!done && cv.LP == LPv && cv.LS == LSv) { \
         hipLaunchKernelGGL((jx_rowfft2_kernel<LPv, R1v>), g1, dim3(256), ctx->p1_lds, st, cf, ctx->d_img, (size_t)d.img_ld, (size_t)d.img_ws, \
@@ -1005,15 +1069,19 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
         HIPCHK(ctx, hipGetLastError());
         return JX_OK;
     }
+    // default route: the map rows are evaluated inside pass 1 from the coefficients (no image), unless the image is asked for
+    const bool dct = !op_route && use_fused(ctx, t.conv) && ctx->dct_ok && !t.need_img;
     {
         const bool vec2 = (d.S % 2 == 0) && (d.P % 2 == 0);
         const int npw = (d.quad && d.pairw == 2) ? 2 : 1;
-        const dim3 grid(((n + npw - 1) / npw) * d.map_split), block(ctx->map_threads);
+        const dim3 grid0(((n + npw - 1) / npw) * d.map_split), block(ctx->map_threads);
         if (d.fast_map) {
             const size_t sh = ctx->map_lds_bytes;
             JxDev dm = d;                                          // fused route: column 0 is copied walker-minor
             dm.nlaunch = n;
             if (use_fused(ctx, t.conv)) { dm.xcol = ctx->d_x0t; dm.xcol_ld = ctx->tW; }
+            if (dct) { dm.cf_out = ctx->d_cf; dm.cf_ws = ctx->dct.cf_ws; dm.map_split = 1; }   // phases 1-4 only: coefficients out
+            const dim3 grid(dct ? (unsigned)((n + npw - 1) / npw) : grid0.x);
 #define JX_SYM_LAUNCH(V, NA) hipLaunchKernelGGL((jx_abel_map_sym_kernel<V, NA>), grid, block, sh, st, dm, theta_dev, w0, ctx->d_img, t.pp, t.ab, t.y)
             const int nait = (d.q_na + 63) / 64;
             if (vec2) { if (nait <= 3) JX_SYM_LAUNCH(true, 3); else if (nait <= 5) JX_SYM_LAUNCH(true, 5); else JX_SYM_LAUNCH(true, 9); }
@@ -1021,8 +1089,8 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
 #undef JX_SYM_LAUNCH
         } else {
             const size_t sh = ctx->map_lds_bytes;
-            if (vec2) hipLaunchKernelGGL(jx_abel_map_kernel<true>, grid, block, sh, st, d, theta_dev, w0, ctx->d_img, t.pp, t.ab, t.y);
-            else hipLaunchKernelGGL(jx_abel_map_kernel<false>, grid, block, sh, st, d, theta_dev, w0, ctx->d_img, t.pp, t.ab, t.y);
+            if (vec2) hipLaunchKernelGGL(jx_abel_map_kernel<true>, grid0, block, sh, st, d, theta_dev, w0, ctx->d_img, t.pp, t.ab, t.y);
+            else hipLaunchKernelGGL(jx_abel_map_kernel<false>, grid0, block, sh, st, d, theta_dev, w0, ctx->d_img, t.pp, t.ab, t.y);
         }
     }
     if (tm) HIPCHK(ctx, hipEventRecord(es.e[2], st));
@@ -1048,7 +1116,7 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
         }
         if (tm) HIPCHK(ctx, hipEventRecord(es.e[4], st));
     } else {
-        int rc2 = use_fused(ctx, t.conv) ? launch_fused_conv(ctx, n, tm ? &es : nullptr) : launch_custom_conv(ctx, n, t.conv, tm ? &es : nullptr);
+        int rc2 = use_fused(ctx, t.conv) ? launch_fused_conv(ctx, n, tm ? &es : nullptr, dct) : launch_custom_conv(ctx, n, t.conv, tm ? &es : nullptr);
         if (rc2) return rc2;
         zpart = ctx->d_part;
         nblk = ctx->last_nblk3;
@@ -1298,6 +1366,7 @@ int jx_eval_stage(jx_ctx* ctx, const double* theta, int nwalkers, int stage, dou
     Taps t;
     t.pp = ctx->t_pp; t.ab = ctx->t_ab; t.y = ctx->t_y; t.row = ctx->t_row; t.bright = ctx->t_bright;
     t.conv = (stage == JX_STAGE_CONV2D) ? ctx->t_convjobs : nullptr;
+    t.need_img = (stage == JX_STAGE_Y2D);
     t.chisq = ctx->t_chisq; t.tprof = ctx->t_tprof; t.xprofs = c.sz_only ? nullptr : ctx->t_xprofs; t.parts = ctx->t_parts;
     for (int w0 = 0; w0 < nwalkers; w0 += ctx->chunk) {
         const int n = std::min(ctx->chunk, nwalkers - w0);

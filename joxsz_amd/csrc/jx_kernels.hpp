@@ -58,6 +58,8 @@ struct JxDev {
     long long xcol_ld;           //   [q_nb padded][xcol_ld] when xcol_ld > 0 (fused FIR path)
     int pairw, nlaunch;          // quad mode: walkers per block (1 or 2: two coefficient sets share every table entry), walkers of this launch
     int quad;                    // 1: the image is the quadrant [q_nb][img_ld] (|iy-c|, |ix-c|) alone, nothing mirrored
+    double* cf_out;              // not null: the kernel stops after phase 4 and leaves the cubic coefficients [nlaunch][cf_ws] here
+    long long cf_ws;             //   (4 doubles per interval slot, slots 0..N; jx_rowdct_kernel evaluates the map rows from them)
     const int* q_k;              // [q_nb*q_na] coefficient slot of each quadrant radius
     const double* q_t;           // [q_nb*q_na] local abscissa within that slot
     const double* abel_tab;      // [N][4] (r_j, cj_j, dg_j, sp_j):  A[i][j] = cj_j / sqrt(r_j^2 - r_i^2) for j >= i+2,
@@ -849,6 +851,19 @@ jx_abel_map_sym_kernel(JxDev c, const double* __restrict__ theta, int w0, double
         jx_load_params(c, theta, w0 + w + 1, p);
         if (!(c.dbg & 1)) jx_profile_to_coefs(c, p, w + 1, part == 0, s_r, s_pp, s_y, s_M, s_cfB, s_rq, s_ds, tap_pp, tap_ab, tap_y);
         else { for (int k = tid; k < 4 * (N + 1); k += nth) s_cfB[k] = 0.0; __syncthreads(); }
+    }
+    if (c.cf_out) {
+        // coefficient sets to global memory, 16 bytes per lane (the LDS copies are 16-byte aligned)
+        const int n2 = 2 * (N + 1);
+        double2* oA = reinterpret_cast<double2*>(c.cf_out + (size_t)w * c.cf_ws);
+        const double2* sA = reinterpret_cast<const double2*>(s_cf);
+        for (int k = tid; k < n2; k += nth) oA[k] = sA[k];
+        if (haveB) {
+            double2* oB = reinterpret_cast<double2*>(c.cf_out + (size_t)(w + 1) * c.cf_ws);
+            const double2* sB = reinterpret_cast<const double2*>(s_cfB);
+            for (int k = tid; k < n2; k += nth) oB[k] = sB[k];
+        }
+        return;
     }
     if (c.dbg & 2) return;
 

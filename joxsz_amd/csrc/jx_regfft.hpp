@@ -130,6 +130,6 @@ template <bool INV> struct jx_regfft<1, INV> { static JX_HD void run(jx_c*) {} }
 template <int L> struct jx_plan2;
 #define JX_PLAN2(L, A, B) template <> struct jx_plan2<L> { static constexpr int L1 = A, L2 = B; };
 JX_PLAN2(16, 4, 4) JX_PLAN2(18, 3, 6) JX_PLAN2(24, 4, 6) JX_PLAN2(32, 4, 8) JX_PLAN2(48, 6, 8) JX_PLAN2(64, 8, 8)
-JX_PLAN2(96, 8, 12) JX_PLAN2(128, 8, 16) JX_PLAN2(144, 12, 12) JX_PLAN2(256, 16, 16) JX_PLAN2(288, 16, 18)
+JX_PLAN2(72, 8, 9) JX_PLAN2(96, 8, 12) JX_PLAN2(128, 8, 16) JX_PLAN2(144, 12, 12) JX_PLAN2(256, 16, 16) JX_PLAN2(288, 16, 18)
 JX_PLAN2(512, 16, 32) JX_PLAN2(576, 24, 24)
 #undef JX_PLAN2

@@ -587,6 +587,50 @@ inline void fused_row_operator(const std::vector<double>& U /*[r][NJ]*/, int r, 
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Tables of jx_rowdct_kernel (jx_dct.hpp): per distinct row u the (interval slot, local abscissa) of the samples
+// a = 0..amax of the quadrant table, as byte offsets into a walker's coefficient set (32 bytes per slot) and padded with
+// the zero slot N to 256 entries per pass; the unpaired column a = S/2 of an even-sided map separately; and the
+// constants of the real-even split.  Returns false when the sizes do not fit the kernel's index ranges.
+// ---------------------------------------------------------------------------------------
+struct DctTables {
+    std::vector<int> dk, x0k;
+    std::vector<double> dt, x0t, pk;
+    int gl = 0, na4 = 0, has_x0 = 0, amax = 0;
+};
+
+inline bool dct_tables(const std::vector<int32_t>& qk, const std::vector<double>& qt, int na, int nb, int S, int N, int LP,
+                       DctTables& t) {
+    const int c = S / 2, Q = LP / 2, P = 2 * LP;
+    if (LP % 2) return false;
+    t.has_x0 = (S % 2 == 0) ? 1 : 0;
+    t.amax = t.has_x0 ? c - 1 : c;
+    if (na < c + 1 || t.amax < 3) return false;
+    t.gl = t.amax / 4;
+    if (t.gl + 2 > Q / 2) return false;                      // z[g], z[Q-g] of g = 0..gl+1 must stay in their own halves
+    const int npass = (t.gl + 1 + 63) / 64;
+    t.na4 = 256 * npass;
+    t.dk.assign((size_t)nb * t.na4, N * 32);
+    t.dt.assign((size_t)nb * t.na4, 0.0);
+    t.x0k.assign(nb, N * 32);
+    t.x0t.assign(nb, 0.0);
+    for (int u = 0; u < nb; ++u) {
+        for (int a = 0; a <= t.amax; ++a) {
+            t.dk[(size_t)u * t.na4 + a] = qk[(size_t)u * na + a] * 32;
+            t.dt[(size_t)u * t.na4 + a] = qt[(size_t)u * na + a];
+        }
+        if (t.has_x0) { t.x0k[u] = qk[(size_t)u * na + c] * 32; t.x0t[u] = qt[(size_t)u * na + c]; }
+    }
+    t.pk.assign((size_t)(Q / 2 + 1) * 4, 0.0);
+    for (int k = 0; k <= Q / 2; ++k) {
+        t.pk[4 * k] = 0.5 * std::cos(2.0 * kPi * k / LP);
+        t.pk[4 * k + 1] = -0.5 * std::sin(2.0 * kPi * k / LP);
+        t.pk[4 * k + 2] = k ? 1.0 / (2.0 * std::sin(2.0 * kPi * k / P)) : 0.0;
+        t.pk[4 * k + 3] = 1.0 / (2.0 * std::sin(2.0 * kPi * (Q - k) / P));
+    }
+    return true;
+}
+
 // supported (LS = S/2, LP = P/2) pairs of the hand-written convolution
 inline int custom_conv_lp(int S, int o) {
     static const int pairs[][2] = {{16, 18}, {24, 48}, {32, 48}, {64, 96}, {128, 144}, {256, 288}, {512, 576}};
