@@ -360,6 +360,7 @@ int jx_finalize(jx_ctx* ctx) {
     ctx->Ph = P / 2 + 1;
 
     std::vector<double> r = host_vec<double>(ctx, JX_T_R_PP);
+    const std::vector<double>& r_grid = r;
     for (int i = 0; i < N; ++i) {
         if (!(r[i] > 0) || (i && !(r[i] > r[i - 1]))) { ctx->err = "r_pp must be positive and increasing"; return JX_ERR_INVALID; }
     }
@@ -782,34 +783,30 @@ int jx_finalize(jx_ctx* ctx) {
             bool want_dct = ctx->lrf.r > 0 && d.quad;
             if (const char* e = getenv("JOXSZ_DCT")) { if (atoi(e) == 0) want_dct = false; }
             if (want_dct) {
-                std::vector<int32_t> qk((size_t)d.q_nb * d.q_na);
-                std::vector<double> qt((size_t)d.q_nb * d.q_na);
-                HIPCHK(ctx, hipMemcpy(qk.data(), d.q_k, qk.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
-                HIPCHK(ctx, hipMemcpy(qt.data(), d.q_t, qt.size() * sizeof(double), hipMemcpyDeviceToHost));
                 jxt::DctTables dt;
                 bool have_kernel = false;
 #define JX_DCT_HAS(LPv, NSv, NTv) if (cv.LP == LPv && cv.LS == NSv && S % 2 == 0) have_kernel = true;
                 JX_DCT_SIZES(JX_DCT_HAS)
 #undef JX_DCT_HAS
-                if (have_kernel && jxt::dct_tables(qk, qt, d.q_na, d.q_nb, S, N, cv.LP, dt) && dt.amax + 1 == cv.LS &&
+                if (have_kernel && jxt::dct_tables(Qtab, qn, qn, r_grid, S, cv.LP, dt) && dt.amax + 1 == cv.LS &&
                     (unsigned long long)cv.LP * ctx->tKU * ctx->tW * 8ull < (1ull << 32)) {
                     JxDct& dc = ctx->dct;
                     memset(&dc, 0, sizeof(dc));
                     dc.NU = cv.NU; dc.kact = ctx->kact; dc.gl = dt.gl; dc.na4 = dt.na4; dc.has_x0 = dt.has_x0; dc.N = N;
-                    dc.cf_ws = (4 * ((long long)N + 1) + 15) & ~15LL;
+                    dc.cf_ws = (2 * ((long long)N + 2) + 15) & ~15LL;          // (y, M) pairs + two zero entries behind the last knot
                     dc.tW = ctx->tW; dc.tKU = ctx->tKU;
                     int* qi; double* qd;
                     if ((rc = dev_put(ctx, dt.dk.data(), dt.dk.size(), &qi))) return rc; dc.dk = qi;
-                    if ((rc = dev_put(ctx, dt.dt.data(), dt.dt.size(), &qd))) return rc; dc.dt = qd;
+                    if ((rc = dev_put(ctx, dt.dw.data(), dt.dw.size(), &qd))) return rc; dc.dw = qd;
                     if ((rc = dev_put(ctx, dt.x0k.data(), dt.x0k.size(), &qi))) return rc; dc.x0k = qi;
-                    if ((rc = dev_put(ctx, dt.x0t.data(), dt.x0t.size(), &qd))) return rc; dc.x0t_t = qd;
+                    if ((rc = dev_put(ctx, dt.x0w.data(), dt.x0w.size(), &qd))) return rc; dc.x0w = qd;
                     if ((rc = dev_put(ctx, dt.pk.data(), dt.pk.size(), &qd))) return rc; dc.pk = qd;
                     std::vector<double> tq;
                     jxt::twiddles(cv.LP / 2, cv.LP / 2, tq);
                     if ((rc = dev_put(ctx, tq.data(), tq.size(), &qd))) return rc; dc.tw_q = (const cplx*)qd;
                     if ((rc = dev_new(ctx, (size_t)chunk * dc.cf_ws, &ctx->d_cf, true))) return rc;
 #define JX_DCT_ATTR(LPv, NSv, NTv) if (cv.LP == LPv && cv.LS == NSv) { \
-                        ctx->dct_lds = sizeof(cplx) * ((size_t)16 * jx_dct_lay<LPv / 2>::RS + LPv / 2) + sizeof(double) * (4 * (LPv / 4 + 1) + 16 * 64 + 16); \
+                        ctx->dct_lds = sizeof(cplx) * ((size_t)16 * jx_dct_lay<LPv / 2, NSv>::RS + LPv / 2) + sizeof(double) * (4 * (LPv / 4 + 1) + 16 * 64 + 16); \
                         HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_rowdct_kernel<LPv, NSv, 16, NTv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->dct_lds)); }
                     JX_DCT_SIZES(JX_DCT_ATTR)
 #undef JX_DCT_ATTR
@@ -905,11 +902,27 @@ static int launch_fused_conv(jx_ctx* ctx, int n, EvSet* es, bool dct) {
         if (const char* e = getenv("JOXSZ_DCT_NRC")) { int v = atoi(e); if (v > 0) nrc = std::min(v, dc.NU); }
         dc.nrc = nrc;
         const dim3 gd((unsigned)(8 * gp8 * nrc));
+        static unsigned long long* stamp_buf = nullptr;
+        if (getenv("JOXSZ_DCT_STAMPS")) {
+            if (!stamp_buf) HIPCHK(ctx, hipMalloc((void**)&stamp_buf, sizeof(unsigned long long) * 8 * 65536));
+            HIPCHK(ctx, hipMemsetAsync(stamp_buf, 0, sizeof(unsigned long long) * 8 * gd.x, st));
+            if (gd.x <= 65536) dc.stamps = stamp_buf;
+        }
 #define JX_DCT_GO(LPv, NSv, NTv) if (!done && cv.LP == LPv && cv.LS == NSv) { \
             hipLaunchKernelGGL((jx_rowdct_kernel<LPv, NSv, 16, NTv>), gd, dim3(NTv), ctx->dct_lds, st, dc, ctx->d_cf, ctx->d_Rt, ctx->d_x0t); done = true; }
         JX_DCT_SIZES(JX_DCT_GO)
 #undef JX_DCT_GO
         if (!done) { ctx->err = "no coefficient-fed pass-1 kernel for this size"; return JX_ERR_UNSUPPORTED; }
+        if (dc.stamps) {                                        // diagnostic: mean cycles per phase of wave 0, over the blocks
+            std::vector<unsigned long long> h((size_t)gd.x * 8);
+            HIPCHK(ctx, hipStreamSynchronize(st));
+            HIPCHK(ctx, hipMemcpy(h.data(), dc.stamps, h.size() * 8, hipMemcpyDeviceToHost));
+            double acc[6] = {0, 0, 0, 0, 0, 0};
+            for (unsigned b = 0; b < gd.x; ++b) for (int i = 0; i < 6; ++i) acc[i] += (double)h[(size_t)b * 8 + i];
+            const double rows = (double)dc.NU * ngroups;
+            fprintf(stderr, "[dct stamps] cycles per (row, 16 walkers), wave 0: E %.0f | x0+barrier %.0f | stepA %.0f | barrier+stepB %.0f | barrier+post %.0f | barrier %.0f\n",
+                    acc[0] / rows, acc[1] / rows, acc[2] / rows, acc[3] / rows, acc[4] / rows, acc[5] / rows);
+        }
     }
     const dim3 g1(cv.NU, (n + ctx->p1_rows - 1) / ctx->p1_rows);
 #define JX_P1(LPv, LSv, R1v, R3v) if (!done && cv.LP == LPv && cv.LS == LSv) { \

@@ -1,5 +1,5 @@
-// Pass 1 of the default route, second form: the Compton-y map is never written.  A block takes the cubic-spline
-// coefficients of NW walkers (left in HBM/L2 by the Abel kernel, 32 bytes per radial interval), evaluates ONE distinct
+// Pass 1 of the default route, second form: the Compton-y map is never written.  A block takes the spline ordinates
+// and moments (y_k, M_k) of NW walkers (left in HBM/L2 by the Abel kernel, 16 bytes per knot), evaluates ONE distinct
 // map row u of each of them straight into LDS (joxsz_funcs.py:460-462), and turns it into the real cosine spectrum
 // the beam convolution needs (joxsz_funcs.py:464) with a QUARTER-length complex FFT:
 //
@@ -13,9 +13,11 @@
 //   beside the FFT by the wave that has no FFT task.  scripts/proto/dct_quarter.py is the numpy statement of the steps.
 //
 // Work layout (Q = L1 L2, two-level FFT with both factors in registers, jx_regfft.hpp; TPR = max(L1, L2)):
-//   E     every wave takes the block's walkers in turn; lane g owns the four samples a = 4g..4g+3 of the row (table
-//         entries in registers, reused for all walkers; coefficient address = scalar walker base + per-lane offset),
-//         gets its left neighbour's last three by a one-lane DPP shift, and writes z[g] and z[Q-g] (16-byte LDS stores).
+//   E     every wave takes the block's walkers in turn.  Lane l evaluates the samples a = l, l + 64, l + 128, l + 192 (so
+//         that one load instruction of the wave covers 64 neighbouring samples, i.e. a few cache lines of the walker's
+//         (y, M) array: the vector-memory pipe, not arithmetic, bounds this phase); table entries live in registers
+//         and serve all walkers; address = scalar walker base + per-lane offset.  The samples pass through the
+//         walker's own (still unused) LDS row to the lane that owns the group a = 4g..4g+3, which writes z[g], z[Q-g].
 //   A/B   thread (walker, n2) / (walker, k1): the two FFT levels, in place in the walker's LDS row.
 //   post  lane = (4 consecutive k) x (16 walkers): Y[k], Y[Q-k] from Z[k], Z[Q-k]; up to four outputs per pair, stored
 //         walker-minor Rt[k][u][w] (128-byte runs) for the GEMM.
@@ -36,58 +38,53 @@ struct JxDct {
     int N;                          // radial grid points (slot N = zero outside the grid)
     long long cf_ws;                // doubles per walker in cf
     long long tW, tKU;              // walker stride / padded row count of Rt
-    const int* dk;                  // [NU][na4] byte offset (slot * 32) of each sample's interval
-    const double* dt;               // [NU][na4] local abscissa
-    const int* x0k; const double* x0t_t;   // [NU] the same for column 0
+    const int* dk;                  // [NU][na4] byte offset (16 k) of each sample's interval in a walker's (y, M) array
+    const double* dw;               // [NU][na4][4] weights of y_k, y_{k+1}, M_k, M_{k+1}
+    const int* x0k; const double* x0w;     // [NU], [NU][4] the same for column 0
     const cplx* tw_q;               // [Q] e^{-2 pi i n / Q}
+    unsigned long long* stamps;     // diagnostic build only (JOXSZ_DCT_STAMPS=1): [blocks][8] cycle counts of the phases of wave 0
     const double* pk;               // [Q/2 + 1][4]: cos/2, -sin/2 of 2 pi k / LP; 1/(2 sin(2 pi k/P)) (0 for k = 0); 1/(2 sin(2 pi (Q-k)/P))
 };
 
-template <int Q> struct jx_dct_lay {
+// geometry of the evaluation phase for NS = amax + 1 samples per row
+template <int Q, int NS> struct jx_dct_geo {
+    static constexpr int AMAX = NS - 1, GL = AMAX / 4;
+    static constexpr int NPASS = (GL + 1 + 63) / 64;
+    static constexpr int GW = (64 * NPASS - 1 < Q / 2) ? 64 * NPASS - 1 : Q / 2;    // last group written by its own lane
+    static constexpr bool TAIL = (GL == GW) && (GW < Q / 2);                          // group GW + 1 is written by lane GW
+    static constexpr int ZLO = TAIL ? GW + 2 : GW + 1, NZFILL = Q - 2 * ZLO + 1;      // slots ZLO .. Q - ZLO stay zero
+    static constexpr int NEV = 4 * GW + 4;                                            // samples a < NEV are evaluated (zero weights past amax)
+    static_assert(GL <= GW, "every group with samples has a lane");
+    static_assert(GL + 2 <= Q / 2, "z[g] and z[Q-g] of g = 0..GL+1 stay in their own halves");
+};
+
+template <int Q, int NS> struct jx_dct_lay {
     static constexpr int L1 = jx_plan2<Q>::L1, L2 = jx_plan2<Q>::L2, L2P = L2 | 1;
     static constexpr int TPR = L1 > L2 ? L1 : L2;
     static constexpr int BASE = L1 * L2P > Q ? L1 * L2P : Q;
     // the dump slot of lanes with nothing to store: the padding slot (n1 = 0, n2 = L2) when the inner stride is padded, else one more
     static constexpr bool PAD = L2P != L2;
-    static constexpr int DUMP = PAD ? L2 : BASE, SPAN = PAD ? BASE : BASE + 1;
+    static constexpr int DUMP = PAD ? L2 : BASE, SPAN0 = PAD ? BASE : BASE + 1;
+    // the row also holds the walker's NEV samples (8 bytes each) during the evaluation
+    static constexpr int NEVS = (jx_dct_geo<Q, NS>::NEV + 1) / 2, SPAN = SPAN0 > NEVS ? SPAN0 : NEVS;
     // row stride (16-byte slots) congruent to TPR modulo 16: with thread = walker * TPR + i the slot index of every
     // access below is thread + const (mod 16), i.e. no two lanes of a 16-lane group share a bank
     static constexpr int RS = SPAN + ((TPR - SPAN) % 16 + 16) % 16;
     static constexpr int zslot(int j) { return (j / L2) * L2P + (j % L2); }
 };
 
-// geometry of the evaluation phase for AMAX + 1 samples per row (compile time: LS2 = AMAX + 1)
-template <int Q, int NS> struct jx_dct_geo {
-    static constexpr int AMAX = NS - 1, GL = AMAX / 4;
-    static constexpr int NPASS = (GL + 1 + 63) / 64;
-    static constexpr int GW = (64 * NPASS - 1 < Q / 2) ? 64 * NPASS - 1 : Q / 2;    // last group written by its own lane
-    static constexpr bool TAIL = (GL == GW) && (GW < Q / 2);                          // group GW + 1 is written by lane GW
-    static constexpr int ZLO = TAIL ? GW + 2 : GW + 1, NZFILL = Q - 2 * ZLO + 1;       // slots ZLO .. Q - ZLO stay zero
-    static_assert(GL <= GW, "every group with samples has a lane");
-    static_assert(GL + 2 <= Q / 2, "z[g] and z[Q-g] of g = 0..GL+1 stay in their own halves");
-};
-
-__device__ __forceinline__ double jx_cubic(const char* cfw, unsigned koff, double t) {
-    const double2 c0 = *reinterpret_cast<const double2*>(cfw + koff);
-    const double2 c1 = *reinterpret_cast<const double2*>(cfw + koff + 16);
-    return fma(t, fma(t, fma(t, c1.y, c1.x), c0.y), c0.x);
-}
-
-// lane i gets `src` of lane i-1; lane 0 keeps `own0` (DPP wave_shr:1 without bound control leaves the destination alone)
-__device__ __forceinline__ double jx_shr1(double own0, double src) {
-    const int lo = __builtin_amdgcn_update_dpp(__double2loint(own0), __double2loint(src), 0x138, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(own0), __double2hiint(src), 0x138, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double jx_lane63(double v) {
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+// f = A y_k + B y_{k+1} + C M_k + D M_{k+1} from the walker's (y, M) pairs
+__device__ __forceinline__ double jx_spline4(const char* ym, unsigned koff, double A, double B, double C, double D) {
+    const double2 p0 = *reinterpret_cast<const double2*>(ym + koff);
+    const double2 p1 = *reinterpret_cast<const double2*>(ym + koff + 16);
+    return fma(D, p1.y, fma(C, p0.y, fma(B, p1.x, A * p0.x)));
 }
 
 template <int LP, int NS, int NW, int NT>
 __global__ void __launch_bounds__(NT)
 jx_rowdct_kernel(JxDct d, const double* __restrict__ cf, double* __restrict__ Rt, double* __restrict__ x0t) {
     constexpr int Q = LP / 2;
-    typedef jx_dct_lay<Q> Lay;
+    typedef jx_dct_lay<Q, NS> Lay;
     typedef jx_dct_geo<Q, NS> Geo;
     constexpr int L1 = Lay::L1, L2 = Lay::L2, L2P = Lay::L2P, TPR = Lay::TPR, RS = Lay::RS;
     constexpr int NWAVE = NT / 64, NPASS = Geo::NPASS, WPW = (NW + NWAVE - 1) / NWAVE;
@@ -145,30 +142,65 @@ jx_rowdct_kernel(JxDct d, const double* __restrict__ cf, double* __restrict__ Rt
     char* Rw = reinterpret_cast<char*>(Rt + w0 + pw);
     const cplx* Mw_post = M + pw * RS;
 
+    unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_t = 0;
+    const bool stamping = d.stamps != nullptr;
+#define JX_STAMP(i) if (stamping) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_t; st_t = t_; }
+    if (stamping) st_t = __builtin_amdgcn_s_memtime();
     for (int u = rc; u < d.NU; u += d.nrc) {
         // ---------------- E: evaluate the row of every walker, build z ----------------
-        int4 kb[NPASS];
-        double tq[NPASS][4];
+        int kb[NPASS][4];
+        double wt[NPASS][4][4];
 #pragma unroll
-        for (int p = 0; p < NPASS; ++p) {
-            const size_t e = (size_t)u * d.na4 + 4 * (lane + 64 * p);
-            kb[p] = *reinterpret_cast<const int4*>(d.dk + e);
-            const double2 ta = *reinterpret_cast<const double2*>(d.dt + e), tb = *reinterpret_cast<const double2*>(d.dt + e + 2);
-            tq[p][0] = ta.x; tq[p][1] = ta.y; tq[p][2] = tb.x; tq[p][3] = tb.y;
-        }
+        for (int p = 0; p < NPASS; ++p)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (256 * p + 64 * j < Geo::NEV) {
+                const size_t e = (size_t)u * d.na4 + 256 * p + 64 * j + lane;
+                kb[p][j] = d.dk[e];
+                const double2 wa = *reinterpret_cast<const double2*>(d.dw + 4 * e), wb = *reinterpret_cast<const double2*>(d.dw + 4 * e + 2);
+                wt[p][j][0] = wa.x; wt[p][j][1] = wa.y; wt[p][j][2] = wb.x; wt[p][j][3] = wb.y;
+            }
+        // the (y, M) requests of walker i + 1 go out before walker i is worked on: two walkers' loads in flight
+        double2 ld[2][NPASS][4][2];
+#define JX_DCT_REQ(i_) \
+        _Pragma("unroll") for (int p = 0; p < NPASS; ++p) \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) if (256 * p + 64 * j < Geo::NEV) { \
+            ld[(i_) & 1][p][j][0] = *reinterpret_cast<const double2*>(cfb[i_] + (unsigned)kb[p][j]); \
+            ld[(i_) & 1][p][j][1] = *reinterpret_cast<const double2*>(cfb[i_] + (unsigned)kb[p][j] + 16); }
+        JX_DCT_REQ(0)
 #pragma unroll
         for (int i = 0; i < WPW; ++i) {
             const int w = wq + NWAVE * i;                     // wave-uniform
-            if (w < NW) {
+            if (i + 1 < WPW) { JX_DCT_REQ(i + 1) }
+            __builtin_amdgcn_sched_barrier(0);
+            if (NW % NWAVE == 0 || w < NW) {
                 char* Mw = reinterpret_cast<char*>(M + w * RS);
-                double bs = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;    // carry: samples of lane 63 of the previous pass
+                double* qa = reinterpret_cast<double*>(Mw);   // the walker's row as scratch: q[a], a < NEV
+#pragma unroll
+                for (int p = 0; p < NPASS; ++p)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (256 * p + 64 * j < Geo::NEV) {
+                            const double2 p0 = ld[i & 1][p][j][0], p1 = ld[i & 1][p][j][1];
+                            const double v = fma(wt[p][j][3], p1.y, fma(wt[p][j][2], p0.y, fma(wt[p][j][1], p1.x, wt[p][j][0] * p0.x)));
+                            if (256 * p + 64 * j + 64 <= Geo::NEV || 256 * p + 64 * j + lane < Geo::NEV) qa[256 * p + 64 * j + lane] = v;
+                        }
+                // (LDS operations of one wave complete in order: the reads below see every lane's stores)
+                double2 qv[NPASS][3];
+                double q3[NPASS];
 #pragma unroll
                 for (int p = 0; p < NPASS; ++p) {
-                    const double v0 = jx_cubic(cfb[i], (unsigned)kb[p].x, tq[p][0]), v1 = jx_cubic(cfb[i], (unsigned)kb[p].y, tq[p][1]);
-                    const double v2 = jx_cubic(cfb[i], (unsigned)kb[p].z, tq[p][2]), v3 = jx_cubic(cfb[i], (unsigned)kb[p].w, tq[p][3]);
-                    // left neighbour's last three samples q[4g-1], q[4g-2], q[4g-3]; q[-a] = q[a] at the centre
-                    const double m1 = jx_shr1(p == 0 ? v1 : c3, v3), m2 = jx_shr1(p == 0 ? v2 : c2, v2), m3 = jx_shr1(p == 0 ? v3 : c1, v1);
-                    if (p + 1 < NPASS) { c1 = jx_lane63(v1); c2 = jx_lane63(v2); c3 = jx_lane63(v3); }
+                    const int g = min(lane + 64 * p, Geo::GW), gm = max(g, 1);
+                    qv[p][0] = *reinterpret_cast<const double2*>(qa + 4 * g);          // q[4g], q[4g+1]
+                    qv[p][1] = *reinterpret_cast<const double2*>(qa + 4 * g + 2);      // q[4g+2], q[4g+3]
+                    qv[p][2] = *reinterpret_cast<const double2*>(qa + 4 * gm - 2);     // q[4g-2], q[4g-1]
+                    q3[p] = qa[4 * gm - 3];                                             // q[4g-3]
+                }
+                double bs = 0.0;
+#pragma unroll
+                for (int p = 0; p < NPASS; ++p) {
+                    const double v0 = qv[p][0].x, v1 = qv[p][0].y, v2 = qv[p][1].x, v3 = qv[p][1].y;
+                    const bool centre = (p == 0) && lane == 0;                          // q[-a] = q[a]
+                    const double m1 = centre ? v1 : qv[p][2].y, m2 = centre ? v2 : qv[p][2].x, m3 = centre ? v3 : q3[p];
                     bs += v1 + v3;
                     if (e_on[p]) {
                         *reinterpret_cast<double2*>(Mw + e_j1[p]) = make_double2(v0 + v1 - m1, v2 + v3 - v1);
@@ -187,9 +219,12 @@ jx_rowdct_kernel(JxDct d, const double* __restrict__ cf, double* __restrict__ Rt
                 s_bs[w * 64 + lane] = bs;
             }
         }
+        JX_STAMP(0)
         if (d.has_x0 && tid < NW && w0 + tid < d.n)
-            x0t[(size_t)u * d.tW + w0 + tid] = jx_cubic(reinterpret_cast<const char*>(cf + (size_t)(w0 + tid) * d.cf_ws), (unsigned)d.x0k[u], d.x0t_t[u]);
+            x0t[(size_t)u * d.tW + w0 + tid] = jx_spline4(reinterpret_cast<const char*>(cf + (size_t)(w0 + tid) * d.cf_ws), (unsigned)d.x0k[u],
+                                                          d.x0w[4 * u], d.x0w[4 * u + 1], d.x0w[4 * u + 2], d.x0w[4 * u + 3]);
         __syncthreads();
+        JX_STAMP(1)
 
         // ---------------- FFT of length Q, two levels, in place; the last wave sums B[0] meanwhile ----------------
         if (actA) {
@@ -209,6 +244,7 @@ jx_rowdct_kernel(JxDct d, const double* __restrict__ cf, double* __restrict__ Rt
             a += __shfl_xor(a, 2, 64);
             if ((lane & 3) == 0) s_b0[lane >> 2] = 2.0 * a;
         }
+        JX_STAMP(2)
         __syncthreads();
         {
             jx_c y[L2];
@@ -219,6 +255,7 @@ jx_rowdct_kernel(JxDct d, const double* __restrict__ cf, double* __restrict__ Rt
                 for (int k2 = 0; k2 < L2; ++k2) jx_st(Mrow + fidx + L1 * k2, y[k2]);
             }
         }
+        JX_STAMP(3)
         __syncthreads();
 
         // ---------------- split, R(k) = A + B, walker-minor stores ----------------
@@ -247,6 +284,11 @@ jx_rowdct_kernel(JxDct d, const double* __restrict__ cf, double* __restrict__ Rt
                 }
             }
         }
+        JX_STAMP(4)
         __syncthreads();                                        // the rows are free for the next u
+        JX_STAMP(5)
     }
+    if (stamping && tid == 0) for (int i = 0; i < 6; ++i) d.stamps[(size_t)blockIdx.x * 8 + i] = st_acc[i];
+#undef JX_STAMP
+#undef JX_DCT_REQ
 }

@@ -58,8 +58,8 @@ struct JxDev {
     long long xcol_ld;           //   [q_nb padded][xcol_ld] when xcol_ld > 0 (fused FIR path)
     int pairw, nlaunch;          // quad mode: walkers per block (1 or 2: two coefficient sets share every table entry), walkers of this launch
     int quad;                    // 1: the image is the quadrant [q_nb][img_ld] (|iy-c|, |ix-c|) alone, nothing mirrored
-    double* cf_out;              // not null: the kernel stops after phase 4 and leaves the cubic coefficients [nlaunch][cf_ws] here
-    long long cf_ws;             //   (4 doubles per interval slot, slots 0..N; jx_rowdct_kernel evaluates the map rows from them)
+    double* cf_out;              // not null: the kernel stops after phase 3 and leaves the spline ordinates and moments (y_k, M_k),
+    long long cf_ws;             //   k < N, here: [nlaunch][cf_ws] doubles (jx_rowdct_kernel evaluates the map rows from them)
     const int* q_k;              // [q_nb*q_na] coefficient slot of each quadrant radius
     const double* q_t;           // [q_nb*q_na] local abscissa within that slot
     const double* abel_tab;      // [N][4] (r_j, cj_j, dg_j, sp_j):  A[i][j] = cj_j / sqrt(r_j^2 - r_i^2) for j >= i+2,
@@ -554,6 +554,11 @@ __device__ __forceinline__ void jx_profile_to_coefs(const JxDev& c, const double
         if (i < N && hsel == 0) s_M[i] = m;
     }
     __syncthreads();
+    if (c.cf_out) {                                         // (y_k, M_k) pairs out: jx_rowdct_kernel evaluates the map rows from them
+        double2* o = reinterpret_cast<double2*>(c.cf_out + (size_t)w * c.cf_ws);
+        for (int k = tid; k < N; k += nth) o[k] = make_double2(s_y[k], s_M[k]);
+        return;
+    }
 
     // Phase 4: cubic coefficients
     for (int k = tid; k < N + 1; k += nth) {
@@ -699,6 +704,12 @@ __device__ __forceinline__ void jx_profile_to_coefs2(const JxDev& c, const doubl
         if (i < N && hsel == 0) { s_MA[i] = m; s_MB[i] = n; }
     }
     __syncthreads();
+    if (c.cf_out) {                                         // (y_k, M_k) pairs out: jx_rowdct_kernel evaluates the map rows from them
+        double2* oA = reinterpret_cast<double2*>(c.cf_out + (size_t)w * c.cf_ws);
+        double2* oB = reinterpret_cast<double2*>(c.cf_out + (size_t)(w + 1) * c.cf_ws);
+        for (int k = tid; k < N; k += nth) { oA[k] = make_double2(s_yA[k], s_MA[k]); oB[k] = make_double2(s_yB[k], s_MB[k]); }
+        return;
+    }
 
     // Phase 4
     for (int k = tid; k < 2 * (N + 1); k += nth) {
@@ -852,19 +863,7 @@ jx_abel_map_sym_kernel(JxDev c, const double* __restrict__ theta, int w0, double
         if (!(c.dbg & 1)) jx_profile_to_coefs(c, p, w + 1, part == 0, s_r, s_pp, s_y, s_M, s_cfB, s_rq, s_ds, tap_pp, tap_ab, tap_y);
         else { for (int k = tid; k < 4 * (N + 1); k += nth) s_cfB[k] = 0.0; __syncthreads(); }
     }
-    if (c.cf_out) {
-        // coefficient sets to global memory, 16 bytes per lane (the LDS copies are 16-byte aligned)
-        const int n2 = 2 * (N + 1);
-        double2* oA = reinterpret_cast<double2*>(c.cf_out + (size_t)w * c.cf_ws);
-        const double2* sA = reinterpret_cast<const double2*>(s_cf);
-        for (int k = tid; k < n2; k += nth) oA[k] = sA[k];
-        if (haveB) {
-            double2* oB = reinterpret_cast<double2*>(c.cf_out + (size_t)(w + 1) * c.cf_ws);
-            const double2* sB = reinterpret_cast<const double2*>(s_cfB);
-            for (int k = tid; k < n2; k += nth) oB[k] = sB[k];
-        }
-        return;
-    }
+    if (c.cf_out) return;                                   // phases 1-3 only: the spline ordinates and moments are in HBM
     if (c.dbg & 2) return;
 
     const int S = c.S, na = c.q_na, nb = c.q_nb, cc = c.S / 2;

@@ -588,18 +588,36 @@ inline void fused_row_operator(const std::vector<double>& U /*[r][NJ]*/, int r, 
 }
 
 // ---------------------------------------------------------------------------------------
-// Tables of jx_rowdct_kernel (jx_dct.hpp): per distinct row u the (interval slot, local abscissa) of the samples
-// a = 0..amax of the quadrant table, as byte offsets into a walker's coefficient set (32 bytes per slot) and padded with
-// the zero slot N to 256 entries per pass; the unpaired column a = S/2 of an even-sided map separately; and the
-// constants of the real-even split.  Returns false when the sizes do not fit the kernel's index ranges.
+// Tables of jx_rowdct_kernel (jx_dct.hpp).  Per distinct row u and sample a = 0..amax of the quadrant (radius
+// Q[u][a] = d_mat at (|iy-c|, |ix-c|) = (u, a)): the byte offset 16 k of the spline interval in a walker's (y_k, M_k)
+// array and the four weights of
+//     f(x) = A y_k + B y_{k+1} + C M_k + D M_{k+1}
+// (interp1d(..., 'cubic') of joxsz_funcs.py:460 on [r_k, r_{k+1}]: A = 1 - t/h, B = t/h, C = (A^3 - A) h^2/6,
+// D = (B^3 - B) h^2/6; centre interval |x| < r_0 of the mirrored knots: y_0 + M_0 (x^2 - r_0^2)/2; fill value 0 outside
+// r_{N-1}; a NaN radius gives NaN).  Padded with zero weights to 256 entries per pass of 64 lanes x 4 samples.  The
+// unpaired column a = S/2 of an even-sided map comes separately, and the constants of the real-even split.
+// Returns false when the sizes do not fit the kernel's index ranges.
 // ---------------------------------------------------------------------------------------
 struct DctTables {
     std::vector<int> dk, x0k;
-    std::vector<double> dt, x0t, pk;
+    std::vector<double> dw, x0w, pk;       // dw [nb][na4][4], x0w [nb][4]
     int gl = 0, na4 = 0, has_x0 = 0, amax = 0;
 };
 
-inline bool dct_tables(const std::vector<int32_t>& qk, const std::vector<double>& qt, int na, int nb, int S, int N, int LP,
+inline void spline_sample_weights(const std::vector<double>& r, double x, int* k16, double* w4) {
+    const int N = (int)r.size();
+    *k16 = 0; w4[0] = w4[1] = w4[2] = w4[3] = 0.0;
+    if (x != x) { w4[0] = w4[1] = w4[2] = w4[3] = x; return; }
+    if (!(x <= r[N - 1])) return;                                     // fill value
+    if (x < r[0]) { w4[0] = 1.0; w4[2] = 0.5 * (x * x - r[0] * r[0]); return; }
+    int k = (int)(std::upper_bound(r.begin(), r.end(), x) - r.begin()) - 1;
+    k = std::max(0, std::min(N - 2, k));
+    const double h = r[k + 1] - r[k], B = (x - r[k]) / h, A = 1.0 - B;
+    *k16 = 16 * k;
+    w4[0] = A; w4[1] = B; w4[2] = (A * A * A - A) * h * h / 6.0; w4[3] = (B * B * B - B) * h * h / 6.0;
+}
+
+inline bool dct_tables(const std::vector<double>& Qrad /*[nb][na] radii*/, int na, int nb, const std::vector<double>& r, int S, int LP,
                        DctTables& t) {
     const int c = S / 2, Q = LP / 2, P = 2 * LP;
     if (LP % 2) return false;
@@ -610,16 +628,14 @@ inline bool dct_tables(const std::vector<int32_t>& qk, const std::vector<double>
     if (t.gl + 2 > Q / 2) return false;                      // z[g], z[Q-g] of g = 0..gl+1 must stay in their own halves
     const int npass = (t.gl + 1 + 63) / 64;
     t.na4 = 256 * npass;
-    t.dk.assign((size_t)nb * t.na4, N * 32);
-    t.dt.assign((size_t)nb * t.na4, 0.0);
-    t.x0k.assign(nb, N * 32);
-    t.x0t.assign(nb, 0.0);
+    t.dk.assign((size_t)nb * t.na4, 0);
+    t.dw.assign((size_t)nb * t.na4 * 4, 0.0);
+    t.x0k.assign(nb, 0);
+    t.x0w.assign((size_t)nb * 4, 0.0);
     for (int u = 0; u < nb; ++u) {
-        for (int a = 0; a <= t.amax; ++a) {
-            t.dk[(size_t)u * t.na4 + a] = qk[(size_t)u * na + a] * 32;
-            t.dt[(size_t)u * t.na4 + a] = qt[(size_t)u * na + a];
-        }
-        if (t.has_x0) { t.x0k[u] = qk[(size_t)u * na + c] * 32; t.x0t[u] = qt[(size_t)u * na + c]; }
+        for (int a = 0; a <= t.amax; ++a)
+            spline_sample_weights(r, Qrad[(size_t)u * na + a], &t.dk[(size_t)u * t.na4 + a], &t.dw[((size_t)u * t.na4 + a) * 4]);
+        if (t.has_x0) spline_sample_weights(r, Qrad[(size_t)u * na + c], &t.x0k[u], &t.x0w[(size_t)u * 4]);
     }
     t.pk.assign((size_t)(Q / 2 + 1) * 4, 0.0);
     for (int k = 0; k <= Q / 2; ++k) {
