@@ -12,9 +12,14 @@ vectors already resident in HBM when the timed region starts.  For N>1 every
 rank evaluates its own 1024 walkers (weak scaling, walkers are independent) and
 the log-probabilities are all-gathered over RCCL inside the timed region.
 
-Prints ONE JSON line (rank 0) with the `roofline` of the fused Abel+map kernel
-(algorithmic bytes S*S*8 per walker / HIP-event duration of that kernel) and a
-`cpu_baseline` (the numpy/scipy oracle on this box's host cores).
+Prints ONE JSON line (rank 0) with
+  `roofline`       the time-dominant kernel of the step on the bytes it must move (HIP-event duration on the library's
+                   stream), with SURVEY 8(d)'s S*S*8 B/walker figure beside it and the rocprofv3 PMC traffic of the committed
+                   profile;
+  `roofline_step`  the whole step: measured HBM bytes / ms_per_step against the 8 TB/s peak;
+  `north_star_abel_map_kernel`  the fused profile->Abel->spline->map kernel storing the full S x S map (the kernel the
+                   north_star's ">= 60 % of the HBM roofline" is about), measured beside the metric;
+  `cpu_baseline`   the numpy/scipy oracle on this box's host cores.
 """
 import argparse
 import json
@@ -30,25 +35,54 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def pmc_traffic(kernel, walkers_per_launch, S):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC measurement
-    (scripts/measure_traffic.py -> profiles/*_pmc_traffic.json), rescaled to this launch size.
-    The counters cannot be read from inside the benchmark process; None when no file is there."""
+def pmc_file(S):
+    """Latest committed rocprofv3 PMC measurement (scripts/measure_traffic.py -> profiles/*_pmc_traffic.json) of this map
+    side, or None.  The counters cannot be read from inside the benchmark process."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json')))
-    if not files:
-        return None
-    try:
-        j = json.load(open(files[-1]))
-        for name, d in j['kernels'].items():
-            if kernel in name:
-                per_walker = d['total_bytes'] / j.get('walkers_per_launch', 1024)
-                if j.get('S', 512) != S:
-                    return None
-                return per_walker * walkers_per_launch
-    except Exception:
-        return None
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json')), reverse=True):
+        try:
+            j = json.load(open(f))
+            if j.get('S', 512) == S:
+                return j
+        except Exception:
+            pass
     return None
+
+
+def pmc_traffic(j, kernel, walkers_per_launch):
+    """HBM bytes per launch of `kernel` from that file, rescaled to this launch size."""
+    if not j:
+        return None
+    for name, d in j['kernels'].items():
+        if kernel in name:
+            return d['total_bytes'] / j.get('walkers_per_launch', 1024) * walkers_per_launch
+    return None
+
+
+def must_move_bytes(ctx, pb, lay, W):
+    """Bytes every kernel of the default route has to move per launch of W walkers whatever its implementation (its
+    inputs read once + its outputs written once; walker-independent tables excluded), from the layout the library chose.
+    The reference's S x S map (S^2 * 8 B per walker written, read once) is never materialised on this route."""
+    N, S = pb.N, pb.S
+    nrow = ctx.nrow
+    if not lay or not lay.get('fused'):
+        return None
+    NU, kact, r = lay['NU'], lay['kact'], lay['rank']
+    P = lay['P']
+    coef = 16.0 * N                                   # (y_k, M_k) per knot
+    rows_t = 8.0 * kact * NU + 8.0 * NU               # real row spectra below the band limit + column 0
+    ct = 8.0 * kact * r + 8.0 * 40 * r                # combined rows + their column-0 terms
+    zp = 16.0 * (S // 2 + 1) * ((r + 13) // 14)       # partial Z per pass-3 block
+    small = 8.0 * (pb.ndim + nrow + 2)
+    per = {
+        'jx_prep_kernel': small,
+        'jx_abel_map_sym_kernel': 8.0 * pb.ndim + coef,
+        'jx_rowdct_kernel': coef + rows_t,
+        'jx_lowrank_kernel': rows_t + ct,
+        'jx_rowtf2_kernel': ct + zp,
+        'jx_tail_fft_kernel': zp + small,
+    }
+    return {k: v * W for k, v in per.items()}
 
 
 def _cpu_worker(args):
@@ -110,6 +144,7 @@ def main():
     ap.add_argument('--sz-only', action='store_true')
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
+    ap.add_argument('--no-full-map', action='store_true', help='skip the side measurement of the full-map Abel kernel')
     ap.add_argument('--route', choices=('map', 'operator'), default='map',
                     help="'map': the reference's sequence of steps per walker (the BASELINE metric); 'operator': the collapsed route (jx_set_route)")
     ap.add_argument('--fwhm', type=float, default=18.5, help='beam FWHM in arcsec (B = 2*floor(3*fwhm/step)+1)')
@@ -268,24 +303,71 @@ def main():
             also = {'route': 'operator', 'error': str(exc)}
 
 
+    # the kernel that meets north_star's "Abel+map kernel at >= 60 % of the HBM roofline": the same fused kernel storing the
+    # reference's full S x S map (JOXSZ_FULL_MAP=1), measured beside the metric (the default route never stores a map)
+    full_map = None
+    if rank == 0 and dist is None and args.route == 'map' and not args.no_full_map:
+        try:
+            os.environ['JOXSZ_FULL_MAP'] = '1'
+            p2 = JoxszPosterior(pb, device=local_rank)
+            os.environ.pop('JOXSZ_FULL_MAP')
+            c2 = p2.ctx
+            for _ in range(2):
+                c2.eval(theta)
+            c2.timing_enable(True); c2.timing_reset()
+            for _ in range(5):
+                c2.eval(theta)
+            t2 = c2.timing()
+            ms = t2['abel_map_ms'] / max(1, t2['launches'])
+            wl = t2['walkers'] / max(1, t2['launches'])
+            full_map = {'kernel': 'jx_abel_map_sym_kernel (JOXSZ_FULL_MAP=1: profile -> Abel -> spline -> full S x S map)',
+                        'launch_ms': ms, 'bytes_per_launch': wl * args.S * args.S * 8.0,
+                        'achieved_GBps': wl * args.S * args.S * 8.0 / (ms * 1e-3) / 1e9,
+                        'frac_of_hbm_peak': wl * args.S * args.S * 8.0 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            p2.close()
+        except Exception as exc:
+            os.environ.pop('JOXSZ_FULL_MAP', None)
+            full_map = {'error': str(exc)}
+
     if rank == 0:
         S = args.S
         launches = max(1, tm['launches'])
-        k_ms = tm['abel_map_ms'] / launches                  # mean duration of one Abel+map launch
         walkers_per_launch = tm['walkers'] / launches
-        alg_bytes = walkers_per_launch * S * S * 8.0          # S^2*E written per walker
-        achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         lay = ctx.conv_layout or {}
-        quad = bool(lay.get('quad'))
-        # what the kernel really stores: with the x-symmetric convolution only the distinct pixels (|iy-c|, |ix-c|)
-        stored_bytes = walkers_per_launch * (lay['img_rows'] * lay['img_ld'] + lay['img_rows']) * 8.0 if quad else alg_bytes
-        stored_rate = stored_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        stage_ms = {k: tm[k] / launches for k in ('prep_ms', 'abel_map_ms', 'beam_fft_ms', 'tf_fft_ms', 'tail_ms')}
+        if tm.get('gemm_ms', 0.0) > 0.0:                      # the matrix products and pass 3 are timed apart on the default route
+            stage_ms['gemm_ms'] = tm['gemm_ms'] / launches
+            stage_ms['pass3_ms'] = stage_ms.pop('tf_fft_ms') - stage_ms['gemm_ms']
+        dct = bool(lay.get('fused')) and not os.environ.get('JOXSZ_DCT') == '0'
+        stage_kernels = {'prep_ms': 'jx_prep_kernel',
+                         'abel_map_ms': 'jx_abel_map_sym_kernel (profile -> Abel -> spline moments)' if dct else 'jx_abel_map_sym_kernel',
+                         'beam_fft_ms': ('jx_rowdct_kernel (map rows evaluated from the spline + real-even row transform)' if dct
+                                         else 'jx_rowfft2_kernel (pass 1)'),
+                         'tf_fft_ms': 'jx_lowrank_kernel (fp64 MFMA GEMM) + jx_rowtf2_kernel (pass 3)', 'tail_ms': 'jx_tail_fft_kernel',
+                         'gemm_ms': 'jx_lowrank_kernel (FIR + job combination as fp64 MFMA matrix products)',
+                         'pass3_ms': 'jx_rowtf2_kernel (inverse row transform, crop, forward transform, transfer-function weights)'}
+        dom = max(stage_ms, key=stage_ms.get)
+        dom_kernel = stage_kernels[dom].split(' ')[0]
+        k_ms = stage_ms[dom]
+        mm = must_move_bytes(ctx, pb, lay, walkers_per_launch) if dct else None
+        pj = pmc_file(S)
+        survey_bytes = walkers_per_launch * S * S * 8.0       # the reference's map, S^2 * 8 B per walker
+        dom_bytes = (mm or {}).get(dom_kernel)
+        if dom_bytes is None:
+            dom_bytes = survey_bytes
+        achieved = dom_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         value = W * world * args.steps / elapsed
+        ms_step = 1e3 * elapsed / args.steps
+        step_must = sum(mm.values()) * (W / walkers_per_launch) if mm else None
+        step_pmc = None
+        if pj:
+            step_pmc = sum(d['total_bytes'] for n, d in pj['kernels'].items() if n.startswith(('jx_', 'void jx_')) and 'operator' not in n) \
+                / pj.get('walkers_per_launch', 1024) * W
         out = {
             'metric': 'walker-likelihoods/sec at 512^2 map, 500-pt grid' if (S, args.N) == (512, 500)
                       else 'walker-likelihoods/sec at %d^2 map, %d-pt grid' % (S, args.N),
             'value': value, 'unit': 'walker-likelihoods/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
+            'warmup': args.warmup, 'ms_per_step': ms_step, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': '%d walkers/GPU, %dx%d SZ map, %d-pt radial grid, %s likelihood, '
                                    'synthetic CL J1226.9+3332-shaped inputs%s'
@@ -293,21 +375,30 @@ def main():
                                       ' (BASELINE configs[2])' if (W, S, args.N, pb.sz_only) == (1024, 512, 500, False) else ''),
                        'walkers_per_gpu': W, 'S': S, 'N': args.N, 'B': pb.B, 'fft_pad': ctx.fft_pad,
                        'chunk': ctx.chunk, 'route': ctx.route, 'conv': ctx.conv, 'conv_layout': ctx.conv_layout, 'parallelism': 'walkers sharded x%d' % world, 'device': ctx.device_name},
-            'roofline': {'kernel': 'jx_abel_map_sym_kernel', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
+            # the time-dominant kernel of the step, on the bytes it has to move (inputs once + outputs once)
+            'roofline': {'kernel': dom_kernel, 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': pmc_traffic('jx_abel_map', walkers_per_launch, S),
-                         'launch_ms': k_ms, 'bytes_per_launch': alg_bytes,
-                         'stored_bytes_per_launch': stored_bytes, 'stored_GBps': stored_rate, 'stored_frac': stored_rate / HBM_PEAK_GBS,
-                         'note': ('achieved/frac use SURVEY 8(d)\'s algorithmic figure, S^2*8 B per walker; the kernel stores only the '
-                                  '(S/2+1)^2 distinct pixels of the mirror-symmetric map (stored_*), so frac can exceed 1 and the '
-                                  'kernel is bound by fp64 issue, not by HBM; JOXSZ_FULL_MAP=1 stores the full map') if quad
-                                 else 'full S x S map stored'},
+                         'traffic': pmc_traffic(pj, dom_kernel, walkers_per_launch),
+                         'launch_ms': k_ms, 'bytes_per_launch': dom_bytes, 'share_of_step': k_ms / max(1e-12, sum(stage_ms.values())),
+                         'survey_8d_bytes_per_launch': survey_bytes,
+                         'survey_8d_GBps': survey_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0,
+                         'note': 'achieved = bytes this kernel must move (walker inputs read once, outputs written once: DESIGN 5) / its '
+                                 'HIP-event duration; survey_8d_* = SURVEY 8(d)\'s S^2*8 B per walker for the map stage, which this route '
+                                 'never writes (the rows are evaluated from the spline inside this kernel). The kernel is bound by fp64 '
+                                 'issue and LDS, not by HBM: see profiles/ SQ counters'},
+            # the whole step against the HBM roofline: measured bytes (rocprofv3 PMC, profiles/*_pmc_traffic.json) and compulsory bytes
+            'roofline_step': {'bound': 'hbm', 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'ms_per_step': ms_step,
+                              'traffic_bytes_per_step': step_pmc,
+                              'achieved': (step_pmc / (ms_step * 1e-3) / 1e9) if step_pmc else None,
+                              'frac': (step_pmc / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS) if step_pmc else None,
+                              'must_move_bytes_per_step': step_must,
+                              'survey_8d_bytes_per_step': 2.0 * W * S * S * 8.0,
+                              'time_dominant_kernel': dom_kernel},
+            'north_star_abel_map_kernel': full_map,
             'cpu_baseline': cpu,
             'stage_ms_per_step': {k: tm[k] / args.steps for k in
-                                  ('prep_ms', 'abel_map_ms', 'beam_fft_ms', 'tf_fft_ms', 'tail_ms', 'total_ms')},
-            'stage_kernels': ({'prep_ms': 'jx_prep_kernel', 'abel_map_ms': 'jx_abel_map_sym_kernel (graded)', 'beam_fft_ms': 'jx_rowfft2_kernel (pass 1)',
-                               'tf_fft_ms': 'jx_lowrank_kernel (fp64 MFMA GEMM) + jx_rowtf2_kernel (pass 3)', 'tail_ms': 'jx_tail_fft_kernel'}
-                              if (ctx.conv_layout or {}).get('fused') else None),
+                                  ('prep_ms', 'abel_map_ms', 'beam_fft_ms', 'tf_fft_ms', 'gemm_ms', 'tail_ms', 'total_ms')},
+            'stage_kernels': stage_kernels if lay.get('fused') else None,
             'parity_max_rel_err': parity,
             'operator_route': also,
         }

@@ -128,12 +128,13 @@ typedef enum jx_stage {
 typedef struct jx_timing {
     double prep_ms;       /* priors, mass veto, T profile, X-ray Cash      */
     double abel_map_ms;   /* fused profile -> Abel -> spline -> y map      */
-    double beam_fft_ms;   /* beam convolution: rocFFT R2C + multiply + C2R, or hand-written passes 1+2 */
-    double tf_fft_ms;     /* rocFFT R2C of the S x S window, or hand-written pass 3                    */
+    double beam_fft_ms;   /* beam convolution: rocFFT R2C + multiply + C2R, or hand-written pass 1 (+ FIR on the routes with separate kernels) */
+    double tf_fft_ms;     /* rocFFT R2C of the S x S window, or the matrix products + hand-written pass 3   */
     double tail_ms;       /* filter + central row + conversion + chi^2     */
     double total_ms;      /* first event to last event of each launch      */
     int64_t launches;     /* internal chunks timed                         */
     int64_t walkers;      /* walkers those chunks processed                */
+    double gemm_ms;       /* part of tf_fft_ms: the FIR + job-combination matrix products of the default route (0 elsewhere) */
 } jx_timing;
 
 int  jx_create(const jx_config* cfg, jx_ctx** out);

@@ -27,9 +27,10 @@ struct Plan3 {
 };
 
 struct EvSet {
-    hipEvent_t e[6];
+    hipEvent_t e[7];
     int walkers;
     bool op;                           // operator route: only e[0], e[1], e[5] were recorded
+    bool gemm;                         // e[6] (behind the FIR + combination GEMM of the fused route) was recorded
 };
 
 }  // namespace
@@ -85,8 +86,20 @@ struct jx_ctx {
     // pass 1 from the spline coefficients (jx_rowdct_kernel): no Compton-y map in HBM on the default route
     bool dct_ok = false;
     JxDct dct{};
-    double* d_cf = nullptr;           // [chunk][cf_ws] cubic coefficients, Abel kernel -> jx_rowdct_kernel
+    double* d_cf = nullptr;           // [chunk][cf_ws] spline ordinates and moments, Abel kernel -> jx_rowdct_kernel
     size_t dct_lds = 0;
+    // odd map sides (the reference's own shapes): the transfer-function step in real space, no transform of length S
+    bool odd = false;
+    JxDct dct3{};                      // combined rows back to real space (jx_rowdct_kernel, MODE 1)
+    size_t dct3_lds = 0;
+    JxLowrank lr2{};                   // second matrix product: real-space circular kernels x combined rows
+    int o_nmg = 0, o_bucket2 = 0, o_RPc = 0, o_ldb = 0, o_nout = 0;
+    double *d_Ctp = nullptr, *d_cc = nullptr, *d_D2 = nullptr;
+    const double* d_Kp = nullptr;
+    // beam-convolved-map tap on the odd-side route (built on first use): FIR-only operator, one row per job
+    const double* d_Wfir = nullptr;
+    double *d_Ctj = nullptr, *d_ccj = nullptr;
+    int o_RPj = 0;
     int num_cu = 256;
     int* d_rowjob = nullptr;
     int* d_runs = nullptr;
@@ -129,6 +142,8 @@ static int g_rocfft_refs = 0;
 #define JX_CONV2_PAIRS(X) X(18, 16, 42, 42) X(48, 24, 32, 32) X(48, 32, 32, 32) X(96, 64, 21, 21) X(144, 128, 21, 16) X(288, 256, 14, 14) X(576, 512, 10, 8)
 
 // coefficient-fed pass 1 (jx_rowdct_kernel): (LP = padded length / 2, NS =
+// the generic instances for odd map sides: any sample count up to LP - 4 (LP, threads per block)
+#define JX_DCT_ODD_SIZES(X) X(48, 192) X(96, 192) X(144, 256) X(288, 256) X(576, 384)
 // samples per distinct row, threads per block: 16 walkers x max(L1, L2) FFT tasks + one wave without one)
 #define JX_DCT_SIZES(X) X(48, 24, 192) X(48, 32, 192) X(96, 64, 192) X(144, 128, 256) X(288, 256, 256) X(576, 512, 384)
 
@@ -204,6 +219,72 @@ static std::vector<T> host_vec(jx_ctx* ctx, int id) {
     std::vector<T> v(b.size() / sizeof(T));
     if (!v.empty()) memcpy(v.data(), b.data(), b.size());
     return v;
+}
+
+// What the hand-written route needs for an odd map side, worked out before the route is chosen (so that `auto` can fall
+// back to the rocFFT sequence): row bookkeeping, beam taps, low-rank form of the transfer-function weights, band limit.
+struct OddPlan {
+    bool ok = false;
+    const char* why = "";
+    int LP = 0, r = 0, kact = 0;
+    jxt::ConvRows rows;
+    std::vector<double> taps, L, V;
+};
+
+static bool dmat_is_mirror(const std::vector<double>& dm, int S) {
+    const int c = S / 2;
+    for (int iy = 0; iy < S; ++iy)
+        for (int ix = 0; ix < S; ++ix) {
+            const int b = std::abs(iy - c), a = std::abs(ix - c);
+            const int jy = (c + b < S) ? c + b : c - b, jx = (c + a < S) ? c + a : c - a;
+            if (memcmp(&dm[(size_t)iy * S + ix], &dm[(size_t)jy * S + jx], sizeof(double)) != 0) return false;
+        }
+    return true;
+}
+
+static void plan_odd(const jx_config& c, const std::vector<double>& beam, const std::vector<double>& filt,
+                     const std::vector<double>& dm, double tol, OddPlan& pl) {
+    const int S = c.S, B = c.B, o = (B - 1) / 2, Sh = S / 2 + 1;
+    pl.LP = jxt::custom_conv_lp_odd(S, o);
+    if (!pl.LP) { pl.why = "no padded length for this odd side"; return; }
+    if (!jxt::beam_is_symmetric(beam, B)) { pl.why = "beam image not flip-symmetric"; return; }
+    if (!dmat_is_mirror(dm, S)) { pl.why = "d_mat lacks the mirror structure of centdistmat"; return; }
+    const int P = 2 * pl.LP, Ph = pl.LP + 1;
+    jxt::conv_row_tables(S, o, true, pl.rows);
+    jxt::beam_fir_taps(beam, B, P, c.step * c.step / (double)P, pl.taps);
+    std::vector<double> hy;
+    jxt::tf_hy_table(filt, S, hy);
+    const int NJ = pl.rows.NJ;
+    std::vector<double> A((size_t)NJ * Sh, 0.0);
+    double maxre = 0.0, maxim = 0.0;
+    for (int rr = 0; rr < S; ++rr) {
+        const size_t q = pl.rows.rowjob[rr];
+        for (int k = 0; k < Sh; ++k) {
+            A[q * Sh + k] += hy[((size_t)rr * Sh + k) * 2];
+            maxim = std::max(maxim, std::fabs(hy[((size_t)rr * Sh + k) * 2 + 1]));
+        }
+    }
+    for (double v : A) maxre = std::max(maxre, std::fabs(v));
+    if (!(maxim <= 1e-15 * maxre)) { pl.why = "transfer-function weights are not real"; return; }
+    if (NJ < 16 || NJ > 600) { pl.why = "job count outside the matrix-product kernel's range"; return; }
+    pl.r = jxt::lowrank_factor(A.data(), NJ, Sh, tol, pl.L, pl.V);
+    // (a measured transfer function can have full rank, r = NJ: the products below then run over more rows, nothing else changes)
+    if (!(pl.r > 0)) { pl.why = "transfer-function weights vanish"; return; }
+    int kact = Ph;
+    {
+        const double band_tol = 0.03 * tol;
+        double tmax = 0.0;
+        for (double v : pl.taps) tmax = std::max(tmax, std::fabs(v));
+        while (kact > 1) {
+            double m = 0.0;
+            for (int t = 0; t <= o; ++t) m = std::max(m, std::fabs(pl.taps[(size_t)t * Ph + kact - 1]));
+            if (m > band_tol * tmax) break;
+            --kact;
+        }
+    }
+    pl.kact = kact;
+    if ((S / 2 + 1 + 3) / 4 > JX_LR_KS) { pl.why = "map side beyond the second matrix product's k range"; return; }
+    pl.ok = true;
 }
 
 extern "C" {
@@ -344,13 +425,24 @@ int jx_finalize(jx_ctx* ctx) {
     }
     if (want < 0 || want > 2) { ctx->err = "conv_mode must be 0, 1 or 2"; return JX_ERR_INVALID; }
     std::vector<double> beam_h = host_vec<double>(ctx, JX_T_BEAM_2D);
-    const int lp_custom = jxt::custom_conv_lp(S, o);
+    const bool oddS = (S & 1) != 0;
+    OddPlan oplan;
+    // singular-value cut of the transfer-function weights.  Small maps (a beam image comparable with the map: the extracted
+    // row is then a small difference of large terms) keep every term above rounding, where it costs next to nothing; large
+    // maps cut at 1e-10 (rank 46 instead of 61 at 512^2), which the truncation test of tests/test_gpu_parity.py bounds
+    double lr_tol0 = (S < 400) ? 1e-13 : 1e-10;
+    if (const char* e = getenv("JOXSZ_LOWRANK_TOL")) { const double v2 = atof(e); if (v2 > 0.0 && v2 < 1e-6) lr_tol0 = v2; }
+    if (oddS && want != 1 && c.fft_pad == 0 && JX_FIR_TILE + 2 * o <= JX_FIR_RING && !getenv("JOXSZ_ODD_ROCFFT"))
+        plan_odd(c, beam_h, host_vec<double>(ctx, JX_T_FILTERING), host_vec<double>(ctx, JX_T_D_MAT), lr_tol0, oplan);
+    const int lp_custom = oddS ? (oplan.ok ? oplan.LP : 0) : jxt::custom_conv_lp(S, o);
     const size_t fir_lds = sizeof(double) * ((size_t)2 * JX_FIR_RING * JX_FIR_KX + (size_t)(o + 1) * JX_FIR_KX) + sizeof(int) * (size_t)(S + 4);
     const bool eligible = lp_custom > 0 && jxt::beam_is_symmetric(beam_h, B) && JX_FIR_TILE + 2 * o <= JX_FIR_RING && c.fft_pad == 0;
     if (want == 2 && !eligible) {
-        ctx->err = "hand-written convolution needs S/2 in {16,24,32,64,128,256,512}, a flip-symmetric beam with (B-1)/2 <= 32 and fft_pad = 0";
+        ctx->err = oddS ? std::string("hand-written convolution, odd map side: ") + (oplan.why[0] ? oplan.why : "fft_pad must be 0 and (B-1)/2 <= 32")
+                        : std::string("hand-written convolution needs S/2 in {16,24,32,64,128,256,512}, a flip-symmetric beam with (B-1)/2 <= 32 and fft_pad = 0");
         return JX_ERR_UNSUPPORTED;
     }
+    ctx->odd = oddS && eligible && want != 1;
     ctx->conv_mode = (want == 2 || (want == 0 && eligible)) ? 2 : 1;
     int P = c.fft_pad > 0 ? c.fft_pad : jxt::next_smooth_even(S + o);
     if (const char* e = getenv("JOXSZ_FFT_PAD")) { int v = atoi(e); if (v > 0 && ctx->conv_mode == 1) P = v; }
@@ -461,6 +553,20 @@ int jx_finalize(jx_ctx* ctx) {
         JxConv& cv = ctx->cv;
         memset(&cv, 0, sizeof(cv));
         cv.S = S; cv.Sh = ctx->Sh; cv.B = B; cv.o = o; cv.P = P; cv.Ph = ctx->Ph; cv.LP = P / 2; cv.LS = S / 2; cv.ntap = o + 1;
+        memset(&ctx->lr, 0, sizeof(ctx->lr));
+        memset(&ctx->lrf, 0, sizeof(ctx->lrf));
+        memset(&ctx->lrf0, 0, sizeof(ctx->lrf0));
+        if (ctx->odd) {
+            // odd side: row bookkeeping and low-rank weights come from the plan; the matrices follow with the work buffers
+            cv.NU = oplan.rows.NU; cv.NJ = oplan.rows.NJ; cv.nseg = oplan.rows.nseg; cv.CROWS = oplan.rows.NJ + 1; cv.mirror = 1;
+            cv.xsym = 1; cv.fir_ld = (cv.Ph + 15) & ~15; cv.nblk3 = 0;
+            ctx->lr_tol = lr_tol0;
+            ctx->kact = oplan.kact;
+            ctx->lr.r = oplan.r; ctx->lr.nq = cv.NJ;
+            ctx->h_rows = oplan.rows; ctx->h_taps = oplan.taps;
+            int* q;
+            if ((rc = dev_put(ctx, oplan.rows.rowjob.data(), oplan.rows.rowjob.size(), &q))) return rc; ctx->d_rowjob = q;
+        } else {
         ctx->p13_rows = ctx->p1_rows = 0;
 #define JX_SEL2(LPv, LSv, R1v, R3v) if (cv.LP == LPv && cv.LS == LSv) { ctx->p1_rows = R1v; ctx->p13_rows = R3v; }
         JX_CONV2_PAIRS(JX_SEL2)
@@ -500,14 +606,10 @@ int jx_finalize(jx_ctx* ctx) {
         }
         if ((rc = dev_put(ctx, hyc.data(), hyc.size(), &p))) return rc; cv.hy = (const cplx*)p;
         // low-rank form of the weights (see jx_lowrank_kernel): real weights, few enough jobs for the register-held U tile
-        memset(&ctx->lr, 0, sizeof(ctx->lr));
-        memset(&ctx->lrf, 0, sizeof(ctx->lrf));
-        memset(&ctx->lrf0, 0, sizeof(ctx->lrf0));
         {
-            double tol = 1e-10;             // the extracted row then agrees with the untruncated weights to ~1e-10, the log-posterior to ~1e-13
+            double tol = lr_tol0;           // (1e-10: the extracted row then agrees with the untruncated weights to ~1e-10, the log-posterior to ~1e-13)
             bool want = true;
             if (const char* e = getenv("JOXSZ_LOWRANK")) { if (atoi(e) == 0) want = false; }
-            if (const char* e = getenv("JOXSZ_LOWRANK_TOL")) { const double v2 = atof(e); if (v2 > 0.0 && v2 < 1e-6) tol = v2; }
             ctx->lr_tol = tol;
             double maxre = 0.0, maxim = 0.0;
             for (size_t e = 0; e < hyc.size(); e += 2) { maxre = std::max(maxre, std::fabs(hyc[e])); maxim = std::max(maxim, std::fabs(hyc[e + 1])); }
@@ -586,6 +688,7 @@ int jx_finalize(jx_ctx* ctx) {
                 for (int x = 0; x < nt; ++x) bc[(size_t)t * JX_COL0_LD + x] = c.step * c.step * beam_h[(size_t)(o + t) * B + o + x];
             if ((rc = dev_put(ctx, bc.data(), bc.size(), &p))) return rc; cv.bcol = p;
         }
+        }   // even side
     }
     // ---- plain copies
     {
@@ -654,6 +757,7 @@ int jx_finalize(jx_ctx* ctx) {
     // ---- chunk capacity and work buffers
     const size_t per_walker = (ctx->conv_mode == 1)
         ? sizeof(double) * ((size_t)P * P * 2 + (size_t)P * ctx->Ph * 2 + (size_t)S * ctx->Sh * 2)
+        : ctx->odd ? sizeof(double) * ((size_t)d.q_nb * (d.q_na + 16) + (size_t)ctx->Ph * (ctx->cv.NU + 4) + (size_t)(ctx->Ph + 2 * ctx->nrow + 300) * 64)
         : sizeof(double) * ((d.quad ? (size_t)d.q_nb * (d.q_na + 16) : (size_t)S * S) + (size_t)(ctx->cv.NU + ctx->cv.CROWS) * ctx->cv.fir_ld + (size_t)ctx->cv.NJ * 28 + (size_t)ctx->cv.nblk3 * ctx->Sh * 2);
     d.img_ld = (ctx->conv_mode == 1) ? P : S;
     d.img_ws = (ctx->conv_mode == 1) ? (long long)P * P : (long long)S * S;
@@ -701,6 +805,99 @@ int jx_finalize(jx_ctx* ctx) {
         if ((rc = dev_new(ctx, (size_t)chunk * P * P, &ctx->d_conv))) return rc;
         if ((rc = dev_new(ctx, (size_t)chunk * P * ctx->Ph, &ctx->d_spec))) return rc;
         if ((rc = dev_new(ctx, (size_t)chunk * S * ctx->Sh, &ctx->d_tfspec))) return rc;
+    } else if (ctx->odd) {
+        // ---- odd map side: pass 1 (rows from the spline, real-even transform) -> matrix products per column (FIR +
+        //      job combination, walker-minor result) -> inverse real-even transform of the combined rows -> matrix products
+        //      with the real-space circular kernels of the transfer function -> sum over the combined rows in the tail
+        const JxConv& cv = ctx->cv;
+        if (!d.quad) { ctx->err = "odd-side route needs the quadrant map tables"; return JX_ERR_UNSUPPORTED; }
+        if ((rc = dev_new(ctx, (size_t)chunk * d.img_ws, &ctx->d_img, true))) return rc;         // y_2d tap only
+        if ((rc = dev_new(ctx, (size_t)chunk * d.q_nb, &d.xcol))) return rc;
+        const int r = oplan.r, RP = ((r + 15) / 16) * 16, LPo = cv.LP, nout = S / 2 + 1;
+        const int KU = (cv.NU + 3) & ~3;
+        int fb = 0;
+#define JX_LR_PICK(K) if (!fb && KU / 4 <= K) fb = K;
+        JX_LR_BUCKETS(JX_LR_PICK)
+#undef JX_LR_PICK
+        const int ks2 = (nout + 3) / 4, KQ2 = 4 * ks2;
+        int fb2 = 0;
+#define JX_LR_PICK(K) if (!fb2 && ks2 <= K) fb2 = K;
+        JX_LR_BUCKETS(JX_LR_PICK)
+#undef JX_LR_PICK
+        if (!fb || !fb2) { ctx->err = "odd-side route: matrix sizes beyond the compiled k-step buckets"; return JX_ERR_UNSUPPORTED; }
+        const size_t tW = (chunk + 15) & ~15;
+        ctx->tW = (int)tW; ctx->tKU = KU; ctx->fused_bucket = fb; ctx->fused_nh = 1;
+        ctx->o_RPc = RP; ctx->o_nout = nout; ctx->o_bucket2 = fb2; ctx->o_ldb = (nout + 15) & ~15;
+        // first product: Wk [kact][RP][KU]
+        {
+            std::vector<double> Wk;
+            jxt::fused_row_operator(oplan.L, r, oplan.rows, S, cv.o, oplan.taps.data(), oplan.kact, cv.Ph, RP, KU, Wk);
+            double* p2;
+            if ((rc = dev_put(ctx, Wk.data(), Wk.size(), &p2))) return rc;
+            ctx->lrf.U = p2; ctx->lrf.r = r; ctx->lrf.ks = KU / 4; ctx->lrf.KQ = KU; ctx->lrf.nq = cv.NU;
+        }
+        // second product: K [nmg][r][64][KQ2]
+        {
+            std::vector<double> Kp;
+            jxt::odd_rowspace_operator(oplan.V, r, S, KQ2, Kp, &ctx->o_nmg);
+            double* p2;
+            if ((rc = dev_put(ctx, Kp.data(), Kp.size(), &p2))) return rc;
+            ctx->d_Kp = p2;
+            ctx->lr2.U = p2; ctx->lr2.r = 64; ctx->lr2.ks = ks2; ctx->lr2.KQ = KQ2; ctx->lr2.nq = nout;
+        }
+        const size_t slack1 = (size_t)4 * fb - KU + 4;
+        if ((rc = dev_new(ctx, ((size_t)cv.Ph * KU + slack1) * tW, &ctx->d_Rt, true))) return rc;
+        if ((rc = dev_new(ctx, (size_t)cv.Ph * RP * tW, &ctx->d_Ctp, true))) return rc;
+        if ((rc = dev_new(ctx, ((size_t)4 * fb2 + 8) * RP * tW, &ctx->d_cc, true))) return rc;
+        if ((rc = dev_new(ctx, (size_t)tW * r * ctx->o_ldb, &ctx->d_D2, true))) return rc;
+        // transforms: forward from the spline (row = distinct map row), inverse from the combined rows (row = rho)
+        jxt::DctTables dt;
+        if (!jxt::dct_tables(Qtab, qn, qn, r_grid, S, LPo, dt) || dt.amax + 1 > LPo - 4 ||
+            (unsigned long long)LPo * std::max(KU, RP) * tW * 8ull >= (1ull << 32)) {
+            ctx->err = "odd-side route: sizes outside the transform kernel's ranges"; return JX_ERR_UNSUPPORTED;
+        }
+        {
+            JxDct& dc = ctx->dct;
+            memset(&dc, 0, sizeof(dc));
+            dc.NU = cv.NU; dc.kact = oplan.kact; dc.gl = dt.gl; dc.na4 = dt.na4; dc.has_x0 = 0; dc.N = N;
+            dc.cf_ws = (2 * ((long long)N + 2) + 15) & ~15LL;
+            dc.tW = (long long)tW; dc.tKU = KU;
+            int* qi; double* qd;
+            // (the generic instance of the kernel walks 256 entries per pass of its own pass count: pad the table to it)
+            const int npass_k = ((LPo - 5) / 4 + 1 + 63) / 64, na4k = 256 * npass_k;
+            std::vector<int> dk2((size_t)cv.NU * na4k, 0);
+            std::vector<double> dw2((size_t)cv.NU * na4k * 4, 0.0);
+            for (int u = 0; u < cv.NU; ++u)
+                for (int a = 0; a < std::min(dt.na4, na4k); ++a) {
+                    dk2[(size_t)u * na4k + a] = dt.dk[(size_t)u * dt.na4 + a];
+                    for (int j = 0; j < 4; ++j) dw2[((size_t)u * na4k + a) * 4 + j] = dt.dw[((size_t)u * dt.na4 + a) * 4 + j];
+                }
+            dc.na4 = na4k;
+            if ((rc = dev_put(ctx, dk2.data(), dk2.size(), &qi))) return rc; dc.dk = qi;
+            if ((rc = dev_put(ctx, dw2.data(), dw2.size(), &qd))) return rc; dc.dw = qd;
+            if ((rc = dev_put(ctx, dt.pk.data(), dt.pk.size(), &qd))) return rc; dc.pk = qd;
+            std::vector<double> tq;
+            jxt::twiddles(LPo / 2, LPo / 2, tq);
+            if ((rc = dev_put(ctx, tq.data(), tq.size(), &qd))) return rc; dc.tw_q = (const cplx*)qd;
+            if ((rc = dev_new(ctx, (size_t)chunk * dc.cf_ws, &ctx->d_cf, true))) return rc;
+            JxDct& d3 = ctx->dct3;
+            d3 = dc;
+            d3.NU = r; d3.kact = nout; d3.tKU = RP; d3.n_in = oplan.kact; d3.s_kstr = (long long)RP * (long long)tW;
+            d3.dk = nullptr; d3.dw = nullptr;
+        }
+        bool have = false;
+#define JX_DCTO_ATTR(LPv, NTv) if (LPo == LPv) { have = true; \
+            ctx->dct_lds = sizeof(cplx) * ((size_t)16 * jx_dct_lay<LPv / 2, LPv - 4>::RS + LPv / 2) + sizeof(double) * (4 * (LPv / 4 + 1) + 16 * 64 + 16); \
+            HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_rowdct_kernel<LPv, LPv - 4, 16, NTv, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->dct_lds)); \
+            ctx->dct3_lds = sizeof(cplx) * ((size_t)16 * jx_dct_lay<LPv / 2, LPv + 1>::RS + LPv / 2) + sizeof(double) * (4 * (LPv / 4 + 1) + 16 * 64 + 16); \
+            HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_rowdct_kernel<LPv, LPv + 1, 16, NTv, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->dct3_lds)); }
+        JX_DCT_ODD_SIZES(JX_DCTO_ATTR)
+#undef JX_DCTO_ATTR
+        if (!have) { ctx->err = "odd-side route: no transform kernel for this padded length"; return JX_ERR_UNSUPPORTED; }
+#define JX_LR_ATTR(K, T) HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_lowrank_kernel<K, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)JX_LR_LDS_MAX));
+        JX_LR_KINDS(JX_LR_ATTR)
+#undef JX_LR_ATTR
+        ctx->dct_ok = true;
     } else {
         const JxConv& cv = ctx->cv;
         if ((rc = dev_new(ctx, (size_t)chunk * d.img_ws, &ctx->d_img, true))) return rc;
@@ -807,7 +1004,7 @@ int jx_finalize(jx_ctx* ctx) {
                     if ((rc = dev_new(ctx, (size_t)chunk * dc.cf_ws, &ctx->d_cf, true))) return rc;
 #define JX_DCT_ATTR(LPv, NSv, NTv) if (cv.LP == LPv && cv.LS == NSv) { \
                         ctx->dct_lds = sizeof(cplx) * ((size_t)16 * jx_dct_lay<LPv / 2, NSv>::RS + LPv / 2) + sizeof(double) * (4 * (LPv / 4 + 1) + 16 * 64 + 16); \
-                        HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_rowdct_kernel<LPv, NSv, 16, NTv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->dct_lds)); }
+                        HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_rowdct_kernel<LPv, NSv, 16, NTv, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->dct_lds)); }
                     JX_DCT_SIZES(JX_DCT_ATTR)
 #undef JX_DCT_ATTR
                     ctx->dct_ok = true;
@@ -848,7 +1045,7 @@ static int ensure_batch(jx_ctx* ctx, int n) {
 
 static int get_evset(jx_ctx* ctx, EvSet* out) {
     if (!ctx->ev_free.empty()) { *out = ctx->ev_free.back(); ctx->ev_free.pop_back(); return JX_OK; }
-    for (int k = 0; k < 6; ++k) HIPCHK(ctx, hipEventCreate(&out->e[k]));
+    for (int k = 0; k < 7; ++k) HIPCHK(ctx, hipEventCreate(&out->e[k]));
     return JX_OK;
 }
 
@@ -864,6 +1061,7 @@ static int drain_events(jx_ctx* ctx) {
             for (int k = 0; k < 5; ++k) HIPCHK(ctx, hipEventElapsedTime(&ms[k], es.e[k], es.e[k + 1]));
         }
         HIPCHK(ctx, hipEventElapsedTime(&tot, es.e[0], es.e[5]));
+        if (es.gemm && !es.op) { float g; HIPCHK(ctx, hipEventElapsedTime(&g, es.e[3], es.e[6])); ctx->acc.gemm_ms += g; }
         ctx->acc.prep_ms += ms[0]; ctx->acc.abel_map_ms += ms[1]; ctx->acc.beam_fft_ms += ms[2];
         ctx->acc.tf_fft_ms += ms[3]; ctx->acc.tail_ms += ms[4]; ctx->acc.total_ms += tot;
         ctx->acc.launches += 1; ctx->acc.walkers += es.walkers;
@@ -909,7 +1107,7 @@ static int launch_fused_conv(jx_ctx* ctx, int n, EvSet* es, bool dct) {
             if (gd.x <= 65536) dc.stamps = stamp_buf;
         }
 #define JX_DCT_GO(LPv, NSv, NTv) if (!done && cv.LP == LPv && cv.LS == NSv) { \
-            hipLaunchKernelGGL((jx_rowdct_kernel<LPv, NSv, 16, NTv>), gd, dim3(NTv), ctx->dct_lds, st, dc, ctx->d_cf, ctx->d_Rt, ctx->d_x0t); done = true; }
+            hipLaunchKernelGGL((jx_rowdct_kernel<LPv, NSv, 16, NTv, 0>), gd, dim3(NTv), ctx->dct_lds, st, dc, ctx->d_cf, ctx->d_Rt, ctx->d_x0t); done = true; }
         JX_DCT_SIZES(JX_DCT_GO)
 #undef JX_DCT_GO
         if (!done) { ctx->err = "no coefficient-fed pass-1 kernel for this size"; return JX_ERR_UNSUPPORTED; }
@@ -952,6 +1150,7 @@ static int launch_fused_conv(jx_ctx* ctx, int n, EvSet* es, bool dct) {
 #undef JX_LR_GO
         }
     }
+    if (es) { HIPCHK(ctx, hipEventRecord(es->e[6], st)); es->gemm = true; }
     ctx->last_nblk3 = cf.nblk3;
     done = false;
     const dim3 g3(cf.nblk3, n);
@@ -961,6 +1160,116 @@ static int launch_fused_conv(jx_ctx* ctx, int n, EvSet* es, bool dct) {
     JX_CONV2_PAIRS(JX_P3)
 #undef JX_P3
     if (es) HIPCHK(ctx, hipEventRecord(es->e[4], st));
+    return JX_OK;
+}
+
+// Odd map side: pass 1 -> matrix products per column -> inverse transform of the combined rows -> matrix products with
+// the real-space kernels of the transfer function.  The tail (jx_tail_odd_kernel) sums the partial rows over rho.
+static int launch_odd_conv(jx_ctx* ctx, int n, EvSet* es) {
+    const JxConv& cv = ctx->cv;
+    hipStream_t st = ctx->stream;
+    const int ngroups = (n + 15) / 16, gp8 = (ngroups + 7) / 8, ncols = (n + 15) & ~15;
+    const long long tW = ctx->tW, KU = ctx->tKU, RP = ctx->o_RPc;
+    const JxGemmSeg none{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0};
+    bool done = false;
+    {   // pass 1: rows from the spline, real-even transform
+        JxDct dc = ctx->dct;
+        dc.n = n;
+        dc.nrc = std::max(1, std::min(dc.NU, (8 * ctx->num_cu + 8 * gp8 - 1) / (8 * gp8)));
+        const dim3 gd((unsigned)(8 * gp8 * dc.nrc));
+#define JX_DCT_GO(LPv, NTv) if (!done && cv.LP == LPv) { \
+            hipLaunchKernelGGL((jx_rowdct_kernel<LPv, LPv - 4, 16, NTv, 0>), gd, dim3(NTv), ctx->dct_lds, st, dc, ctx->d_cf, ctx->d_Rt, (double*)nullptr); done = true; }
+        JX_DCT_ODD_SIZES(JX_DCT_GO)
+#undef JX_DCT_GO
+        if (!done) { ctx->err = "no pass-1 kernel for this odd size"; return JX_ERR_UNSUPPORTED; }
+    }
+    if (es) HIPCHK(ctx, hipEventRecord(es->e[3], st));
+    // FIR + job combination: Ctp[kx][rho][w] = sum_u W_kx[rho][u] Rt[kx][u][w], 64 rows rho per launch
+    for (int g0 = 0; g0 < ctx->lrf.r; g0 += 64) {
+        JxLowrank lr = ctx->lrf;
+        lr.r = std::min(64, ctx->lrf.r - g0);
+        const int ntr = (lr.r + 15) / 16;
+        const size_t lds = (size_t)ntr * ctx->fused_bucket * 64 * sizeof(double);
+        const JxGemmSeg s0{ctx->lrf.U + (size_t)g0 * KU, ctx->d_Rt, ctx->d_Ctp + (size_t)g0 * tW, RP * KU, KU * tW, RP * tW, 1LL, ctx->kact, 0};
+#define JX_LR_GO(K, T) if (ctx->fused_bucket == K && ntr == T) \
+        hipLaunchKernelGGL((jx_lowrank_kernel<K, T>), dim3(ctx->num_cu), dim3(512), lds, st, lr, s0, none, 0LL, tW, 1LL, 0LL, tW, ncols, 1);
+        JX_LR_KINDS(JX_LR_GO)
+#undef JX_LR_GO
+    }
+    if (es) { HIPCHK(ctx, hipEventRecord(es->e[6], st)); es->gemm = true; }
+    {   // combined rows back to real space: cc[a][rho][w], a = 0..S/2 (offset from the centre column)
+        JxDct d3 = ctx->dct3;
+        d3.n = n;
+        d3.nrc = std::max(1, std::min(d3.NU, (4 * ctx->num_cu + 8 * gp8 - 1) / (8 * gp8)));
+        const dim3 gd((unsigned)(8 * gp8 * d3.nrc));
+        done = false;
+#define JX_DCT_GO(LPv, NTv) if (!done && cv.LP == LPv) { \
+            hipLaunchKernelGGL((jx_rowdct_kernel<LPv, LPv + 1, 16, NTv, 1>), gd, dim3(NTv), ctx->dct3_lds, st, d3, ctx->d_Ctp, ctx->d_cc, (double*)nullptr); done = true; }
+        JX_DCT_ODD_SIZES(JX_DCT_GO)
+#undef JX_DCT_GO
+    }
+    {   // D2[w][rho][b] = sum_a K[rho][b][a] cc[a][rho][w], 64 rows b per launch
+        const int r = ctx->lrf.r, nout = ctx->o_nout;
+        const long long ldb = ctx->o_ldb, KQ2 = ctx->lr2.KQ;
+        for (int mg = 0; mg < ctx->o_nmg; ++mg) {
+            JxLowrank lr = ctx->lr2;
+            lr.r = std::min(64, nout - 64 * mg);
+            const int ntr = (lr.r + 15) / 16;
+            const size_t lds = (size_t)ntr * ctx->o_bucket2 * 64 * sizeof(double);
+            const JxGemmSeg s0{ctx->d_Kp + (size_t)mg * r * 64 * KQ2, ctx->d_cc, ctx->d_D2 + 64 * mg, 64 * KQ2, tW, ldb, (long long)r * ldb, r, 0};
+#define JX_LR_GO(K, T) if (ctx->o_bucket2 == K && ntr == T) \
+            hipLaunchKernelGGL((jx_lowrank_kernel<K, T>), dim3(ctx->num_cu), dim3(512), lds, st, lr, s0, none, 0LL, RP * tW, 1LL, 0LL, 1LL, ncols, 1);
+            JX_LR_KINDS(JX_LR_GO)
+#undef JX_LR_GO
+        }
+    }
+    if (es) HIPCHK(ctx, hipEventRecord(es->e[4], st));
+    return JX_OK;
+}
+
+// Beam-convolved map (joxsz_funcs.py:464) on the odd-side route, for the parity tap only: the FIR along rows without the
+// job combination (identity in place of U), every job's row back to real space, then mirrored out to S x S.
+static int launch_odd_conv_tap(jx_ctx* ctx, int n) {
+    const JxConv& cv = ctx->cv;
+    hipStream_t st = ctx->stream;
+    const int NJ = cv.NJ, RPj = ((NJ + 15) / 16) * 16, S = cv.S, nout = S / 2 + 1;
+    const long long tW = ctx->tW, KU = ctx->tKU;
+    int rc;
+    if (!ctx->d_Wfir) {
+        std::vector<double> I((size_t)NJ * NJ, 0.0), Wf;
+        for (int q = 0; q < NJ; ++q) I[(size_t)q * NJ + q] = 1.0;
+        jxt::fused_row_operator(I, NJ, ctx->h_rows, S, cv.o, ctx->h_taps.data(), ctx->kact, cv.Ph, RPj, (int)KU, Wf);
+        double* p2;
+        if ((rc = dev_put(ctx, Wf.data(), Wf.size(), &p2))) return rc;
+        ctx->d_Wfir = p2;
+        ctx->o_RPj = RPj;
+        if ((rc = dev_new(ctx, (size_t)cv.Ph * RPj * tW, &ctx->d_Ctj, true))) return rc;
+        if ((rc = dev_new(ctx, (size_t)(nout + 8) * RPj * tW, &ctx->d_ccj, true))) return rc;
+        if ((unsigned long long)cv.LP * RPj * tW * 8ull >= (1ull << 32)) { ctx->err = "conv_2d tap: launch too large (lower max_batch)"; return JX_ERR_UNSUPPORTED; }
+    }
+    const int ncols = (n + 15) & ~15, ngroups = (n + 15) / 16, gp8 = (ngroups + 7) / 8;
+    const JxGemmSeg none{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0};
+    for (int g0 = 0; g0 < NJ; g0 += 64) {
+        JxLowrank lr = ctx->lrf;
+        lr.r = std::min(64, NJ - g0);
+        const int ntr = (lr.r + 15) / 16;
+        const size_t lds = (size_t)ntr * ctx->fused_bucket * 64 * sizeof(double);
+        const JxGemmSeg s0{ctx->d_Wfir + (size_t)g0 * KU, ctx->d_Rt, ctx->d_Ctj + (size_t)g0 * tW, (long long)RPj * KU, KU * tW, (long long)RPj * tW, 1LL, ctx->kact, 0};
+#define JX_LR_GO(K, T) if (ctx->fused_bucket == K && ntr == T) \
+        hipLaunchKernelGGL((jx_lowrank_kernel<K, T>), dim3(ctx->num_cu), dim3(512), lds, st, lr, s0, none, 0LL, tW, 1LL, 0LL, tW, ncols, 1);
+        JX_LR_KINDS(JX_LR_GO)
+#undef JX_LR_GO
+    }
+    JxDct d3 = ctx->dct3;
+    d3.n = n; d3.NU = NJ; d3.tKU = RPj; d3.s_kstr = (long long)RPj * tW;
+    d3.nrc = std::max(1, std::min(d3.NU, (4 * ctx->num_cu + 8 * gp8 - 1) / (8 * gp8)));
+    const dim3 gd((unsigned)(8 * gp8 * d3.nrc));
+    bool done = false;
+#define JX_DCT_GO(LPv, NTv) if (!done && cv.LP == LPv) { \
+        hipLaunchKernelGGL((jx_rowdct_kernel<LPv, LPv + 1, 16, NTv, 1>), gd, dim3(NTv), ctx->dct3_lds, st, d3, ctx->d_Ctj, ctx->d_ccj, (double*)nullptr); done = true; }
+    JX_DCT_ODD_SIZES(JX_DCT_GO)
+#undef JX_DCT_GO
+    hipLaunchKernelGGL(jx_expand_odd_conv_kernel, dim3(S, n), dim3(256), 0, st, ctx->d_ccj, ctx->d_rowjob, S, RPj, (long long)tW, ctx->t_conv);
     return JX_OK;
 }
 
@@ -1044,6 +1353,7 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
         if ((rc = get_evset(ctx, &es))) return rc;
         es.walkers = n;
         es.op = false;
+        es.gemm = false;
         HIPCHK(ctx, hipEventRecord(es.e[0], st));
     }
     {
@@ -1083,7 +1393,7 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
         return JX_OK;
     }
     // default route: the map rows are evaluated inside pass 1 from the coefficients (no image), unless the image is asked for
-    const bool dct = !op_route && use_fused(ctx, t.conv) && ctx->dct_ok && !t.need_img;
+    const bool dct = !op_route && ctx->dct_ok && (ctx->odd || (use_fused(ctx, t.conv) && !t.need_img));
     {
         const bool vec2 = (d.S % 2 == 0) && (d.P % 2 == 0);
         const int npw = (d.quad && d.pairw == 2) ? 2 : 1;
@@ -1092,13 +1402,19 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
             const size_t sh = ctx->map_lds_bytes;
             JxDev dm = d;                                          // fused route: column 0 is copied walker-minor
             dm.nlaunch = n;
-            if (use_fused(ctx, t.conv)) { dm.xcol = ctx->d_x0t; dm.xcol_ld = ctx->tW; }
-            if (dct) { dm.cf_out = ctx->d_cf; dm.cf_ws = ctx->dct.cf_ws; dm.map_split = 1; }   // phases 1-4 only: coefficients out
-            const dim3 grid(dct ? (unsigned)((n + npw - 1) / npw) : grid0.x);
-#define JX_SYM_LAUNCH(V, NA) hipLaunchKernelGGL((jx_abel_map_sym_kernel<V, NA>), grid, block, sh, st, dm, theta_dev, w0, ctx->d_img, t.pp, t.ab, t.y)
+            if (use_fused(ctx, t.conv) && ctx->d_x0t) { dm.xcol = ctx->d_x0t; dm.xcol_ld = ctx->tW; }   // (odd sides have no unpaired column)
             const int nait = (d.q_na + 63) / 64;
-            if (vec2) { if (nait <= 3) JX_SYM_LAUNCH(true, 3); else if (nait <= 5) JX_SYM_LAUNCH(true, 5); else JX_SYM_LAUNCH(true, 9); }
-            else      { if (nait <= 3) JX_SYM_LAUNCH(false, 3); else if (nait <= 5) JX_SYM_LAUNCH(false, 5); else JX_SYM_LAUNCH(false, 9); }
+#define JX_SYM_LAUNCH(V, NA) hipLaunchKernelGGL((jx_abel_map_sym_kernel<V, NA>), grid, block, sh, st, dm, theta_dev, w0, ctx->d_img, t.pp, t.ab, t.y)
+#define JX_SYM_PICK() { if (vec2) { if (nait <= 3) JX_SYM_LAUNCH(true, 3); else if (nait <= 5) JX_SYM_LAUNCH(true, 5); else JX_SYM_LAUNCH(true, 9); } \
+                        else      { if (nait <= 3) JX_SYM_LAUNCH(false, 3); else if (nait <= 5) JX_SYM_LAUNCH(false, 5); else JX_SYM_LAUNCH(false, 9); } }
+            if (dct && t.need_img) {                               // the Compton-y map tap on a route that does not store the map
+                const dim3 grid = grid0;
+                JX_SYM_PICK()
+            }
+            if (dct) { dm.cf_out = ctx->d_cf; dm.cf_ws = ctx->dct.cf_ws; dm.map_split = 1; }   // phases 1-3 only: spline out
+            const dim3 grid(dct ? (unsigned)((n + npw - 1) / npw) : grid0.x);
+            JX_SYM_PICK()
+#undef JX_SYM_PICK
 #undef JX_SYM_LAUNCH
         } else {
             const size_t sh = ctx->map_lds_bytes;
@@ -1129,10 +1445,24 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
         }
         if (tm) HIPCHK(ctx, hipEventRecord(es.e[4], st));
     } else {
-        int rc2 = use_fused(ctx, t.conv) ? launch_fused_conv(ctx, n, tm ? &es : nullptr, dct) : launch_custom_conv(ctx, n, t.conv, tm ? &es : nullptr);
+        if (ctx->odd && !dct) { ctx->err = "odd map side: the hand-written route needs the coefficient-fed pass 1"; return JX_ERR_UNSUPPORTED; }
+        int rc2 = ctx->odd ? launch_odd_conv(ctx, n, tm ? &es : nullptr)
+                : use_fused(ctx, t.conv) ? launch_fused_conv(ctx, n, tm ? &es : nullptr, dct) : launch_custom_conv(ctx, n, t.conv, tm ? &es : nullptr);
         if (rc2) return rc2;
         zpart = ctx->d_part;
         nblk = ctx->last_nblk3;
+    }
+    if (ctx->odd) {
+        if (t.conv && (rc = launch_odd_conv_tap(ctx, n))) return rc;
+        const size_t sh = sizeof(double) * (JX_LDS_HDR + (size_t)d.nrow + 8);
+        hipLaunchKernelGGL(jx_tail_odd_kernel, dim3(n), dim3(JX_TAIL_THREADS), sh, st, d, ctx->d_D2, ctx->lrf.r, ctx->o_ldb, ctx->d_cfac,
+                           ctx->d_base, logp_dev, w0, t.row, t.bright, t.chisq, t.parts);
+        if (tm) {
+            HIPCHK(ctx, hipEventRecord(es.e[5], st));
+            ctx->ev_inflight.push_back(es);
+        }
+        HIPCHK(ctx, hipGetLastError());
+        return JX_OK;
     }
     bool tail_done = false;
     if (ctx->conv_mode == 2 && d.nrow == ctx->cv.LS && !getenv("JOXSZ_TAIL_DFT")) {
@@ -1506,6 +1836,7 @@ int jx_debug_workspace(jx_ctx* ctx, int which, void** dev, int32_t geom[4]) {
     if (ctx->conv_mode != 2) { ctx->err = "work buffers of the hand-written convolution only"; return JX_ERR_UNSUPPORTED; }
     const JxConv& cv = ctx->cv;
     geom[0] = ctx->chunk; geom[3] = cv.xsym;
+    if (ctx->odd && which != 0 && which != 6) { ctx->err = "this work buffer does not exist on the odd-side route"; return JX_ERR_UNSUPPORTED; }
     switch (which) {
         case 0: *dev = ctx->d_img; geom[1] = ctx->d.quad ? ctx->d.q_nb : cv.S; geom[2] = (int)ctx->d.img_ld; geom[3] = ctx->d.quad; break;
         case 1: *dev = ctx->d_Y; geom[1] = cv.NU; geom[2] = cv.fir_ld; break;
@@ -1543,8 +1874,8 @@ void jx_destroy(jx_ctx* ctx) {
         if (kv.second.tf_fwd) rocfft_plan_destroy(kv.second.tf_fwd);
     }
     if (ctx->info) rocfft_execution_info_destroy(ctx->info);
-    for (auto& es : ctx->ev_inflight) for (int k = 0; k < 6; ++k) (void)hipEventDestroy(es.e[k]);
-    for (auto& es : ctx->ev_free) for (int k = 0; k < 6; ++k) (void)hipEventDestroy(es.e[k]);
+    for (auto& es : ctx->ev_inflight) for (int k = 0; k < 7; ++k) (void)hipEventDestroy(es.e[k]);
+    for (auto& es : ctx->ev_free) for (int k = 0; k < 7; ++k) (void)hipEventDestroy(es.e[k]);
     for (void* p : ctx->dev_allocs) (void)hipFree(p);
     if (ctx->d_work) (void)hipFree(ctx->d_work);
     if (ctx->d_theta) (void)hipFree(ctx->d_theta);

@@ -1074,3 +1074,12 @@ jx_expand_rows_kernel(const double* __restrict__ jobs /*[W][NJ][S]*/, const int*
     double* dst = full + ((size_t)w * S + r) * S;
     for (int x = threadIdx.x; x < S; x += blockDim.x) dst[x] = src[x];
 }
+
+// odd-side route, parity tap only: conv[w][r][x] = ccj[|x - c|][job of row r][w]
+__global__ void __launch_bounds__(256)
+jx_expand_odd_conv_kernel(const double* __restrict__ ccj /*[a][RPj][tW]*/, const int* __restrict__ rowjob /*[S]*/, int S, int RPj, long long tW,
+                          double* __restrict__ full /*[W][S][S]*/) {
+    const int r = blockIdx.x, w = blockIdx.y, c = S >> 1, q = rowjob[r];
+    double* dst = full + ((size_t)w * S + r) * S;
+    for (int x = threadIdx.x; x < S; x += blockDim.x) dst[x] = ccj[((size_t)abs(x - c) * RPj + q) * tW + w];
+}

@@ -37,6 +37,7 @@ struct JxDct {
     int has_x0;                     // even map side: the unpaired column 0 (a = S/2) goes to x0t, not into the transform
     int N;                          // radial grid points (slot N = zero outside the grid)
     long long cf_ws;                // doubles per walker in cf
+    long long s_kstr; int n_in;     // MODE 1: doubles between consecutive samples of the source array, valid samples (the rest are 0)
     long long tW, tKU;              // walker stride / padded row count of Rt
     const int* dk;                  // [NU][na4] byte offset (16 k) of each sample's interval in a walker's (y, M) array
     const double* dw;               // [NU][na4][4] weights of y_k, y_{k+1}, M_k, M_{k+1}
@@ -54,8 +55,12 @@ template <int Q, int NS> struct jx_dct_geo {
     static constexpr bool TAIL = (GL == GW) && (GW < Q / 2);                          // group GW + 1 is written by lane GW
     static constexpr int ZLO = TAIL ? GW + 2 : GW + 1, NZFILL = Q - 2 * ZLO + 1;      // slots ZLO .. Q - ZLO stay zero
     static constexpr int NEV = 4 * GW + 4;                                            // samples a < NEV are evaluated (zero weights past amax)
+    // FULL: samples up to the Nyquist index a = LP = 2Q (NS = 2Q + 1).  The last group g = Q/2 then also needs q[LP + j] =
+    // q[LP - j], j = 1..3 (the sequence is even about LP as well as about 0), which the loader provides.
+    static constexpr bool FULL = NS == 2 * Q + 1;
     static_assert(GL <= GW, "every group with samples has a lane");
-    static_assert(GL + 2 <= Q / 2, "z[g] and z[Q-g] of g = 0..GL+1 stay in their own halves");
+    static_assert(FULL || GL + 2 <= Q / 2, "z[g] and z[Q-g] of g = 0..GL+1 stay in their own halves");
+    static_assert(!FULL || Q % 2 == 0, "the full-range form assumes an even quarter length");
 };
 
 template <int Q, int NS> struct jx_dct_lay {
@@ -80,7 +85,11 @@ __device__ __forceinline__ double jx_spline4(const char* ym, unsigned koff, doub
     return fma(D, p1.y, fma(C, p0.y, fma(B, p1.x, A * p0.x)));
 }
 
-template <int LP, int NS, int NW, int NT>
+// MODE 0: the samples of row u are evaluated from the walkers' spline arrays cf (pass 1).
+// MODE 1: the samples are read from a walker-minor array cf[k][u][w] (k < n_in; row stride tW, sample stride s_kstr): the
+//         same transform taken of a band-limited real-even spectrum is its inverse (odd map sides: combined rows back to
+//         real space, joxsz_funcs.py:464-467 without a transform of the odd length S).
+template <int LP, int NS, int NW, int NT, int MODE>
 __global__ void __launch_bounds__(NT)
 jx_rowdct_kernel(JxDct d, const double* __restrict__ cf, double* __restrict__ Rt, double* __restrict__ x0t) {
     constexpr int Q = LP / 2;
@@ -147,80 +156,111 @@ jx_rowdct_kernel(JxDct d, const double* __restrict__ cf, double* __restrict__ Rt
 #define JX_STAMP(i) if (stamping) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_t; st_t = t_; }
     if (stamping) st_t = __builtin_amdgcn_s_memtime();
     for (int u = rc; u < d.NU; u += d.nrc) {
-        // ---------------- E: evaluate the row of every walker, build z ----------------
-        int kb[NPASS][4];
-        double wt[NPASS][4][4];
+        // ---------------- E: the samples of row u of every walker, then z ----------------
+        // z[g], z[Q-g] of walker w from its samples q[a] in the walker's LDS row (wave-private: LDS operations of one wave
+        // complete in order, so the reads see the stores before them and the z stores come after every read)
+        auto build_z = [&](int w) {
+            char* Mw = reinterpret_cast<char*>(M + w * RS);
+            const double* qa = reinterpret_cast<const double*>(Mw);
+            double2 qv[NPASS][3];
+            double q3[NPASS];
 #pragma unroll
-        for (int p = 0; p < NPASS; ++p)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) if (256 * p + 64 * j < Geo::NEV) {
-                const size_t e = (size_t)u * d.na4 + 256 * p + 64 * j + lane;
-                kb[p][j] = d.dk[e];
-                const double2 wa = *reinterpret_cast<const double2*>(d.dw + 4 * e), wb = *reinterpret_cast<const double2*>(d.dw + 4 * e + 2);
-                wt[p][j][0] = wa.x; wt[p][j][1] = wa.y; wt[p][j][2] = wb.x; wt[p][j][3] = wb.y;
+            for (int p = 0; p < NPASS; ++p) {
+                const int g = min(lane + 64 * p, Geo::GW), gm = max(g, 1);
+                qv[p][0] = *reinterpret_cast<const double2*>(qa + 4 * g);          // q[4g], q[4g+1]
+                qv[p][1] = *reinterpret_cast<const double2*>(qa + 4 * g + 2);      // q[4g+2], q[4g+3]
+                qv[p][2] = *reinterpret_cast<const double2*>(qa + 4 * gm - 2);     // q[4g-2], q[4g-1]
+                q3[p] = qa[4 * gm - 3];                                             // q[4g-3]
             }
-        // the (y, M) requests of walker i + 1 go out before walker i is worked on: two walkers' loads in flight
-        double2 ld[2][NPASS][4][2];
+            double bs = 0.0;
+#pragma unroll
+            for (int p = 0; p < NPASS; ++p) {
+                const double v0 = qv[p][0].x, v1 = qv[p][0].y, v2 = qv[p][1].x, v3 = qv[p][1].y;
+                const bool centre = (p == 0) && lane == 0;                          // q[-a] = q[a]
+                const double m1 = centre ? v1 : qv[p][2].y, m2 = centre ? v2 : qv[p][2].x, m3 = centre ? v3 : q3[p];
+                if (!Geo::FULL || lane + 64 * p < Q / 2) bs += v1 + v3;   // (the group at the Nyquist index holds mirror copies)
+                if (e_on[p]) {
+                    *reinterpret_cast<double2*>(Mw + e_j1[p]) = make_double2(v0 + v1 - m1, v2 + v3 - v1);
+                    *reinterpret_cast<double2*>(Mw + e_j2[p]) = make_double2(v0 - v1 + m1, m2 - m1 + m3);
+                }
+                if (Geo::TAIL && p == NPASS - 1 && e_tail) {   // the group behind the last one has no samples of its own
+                    *reinterpret_cast<double2*>(Mw + e_j1t) = make_double2(-v3, 0.0);
+                    *reinterpret_cast<double2*>(Mw + e_j2t) = make_double2(v3, v2 - v3 + v1);
+                }
+            }
+#pragma unroll
+            for (int e0 = 0; e0 < Geo::NZFILL; e0 += 64) {
+                const int j = Geo::ZLO + e0 + lane;
+                if (j <= Q - Geo::ZLO) *reinterpret_cast<double2*>(Mw + 16 * ((j / L2) * L2P + (j % L2))) = make_double2(0.0, 0.0);
+            }
+            s_bs[w * 64 + lane] = bs;
+        };
+        if constexpr (MODE == 0) {
+            int kb[NPASS][4];
+            double wt[NPASS][4][4];
+#pragma unroll
+            for (int p = 0; p < NPASS; ++p)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (256 * p + 64 * j < Geo::NEV) {
+                    const size_t e = (size_t)u * d.na4 + 256 * p + 64 * j + lane;
+                    kb[p][j] = d.dk[e];
+                    const double2 wa = *reinterpret_cast<const double2*>(d.dw + 4 * e), wb = *reinterpret_cast<const double2*>(d.dw + 4 * e + 2);
+                    wt[p][j][0] = wa.x; wt[p][j][1] = wa.y; wt[p][j][2] = wb.x; wt[p][j][3] = wb.y;
+                }
+            // the (y, M) requests of walker i + 1 go out before walker i is worked on: two walkers' loads in flight
+            double2 ld[2][NPASS][4][2];
 #define JX_DCT_REQ(i_) \
-        _Pragma("unroll") for (int p = 0; p < NPASS; ++p) \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) if (256 * p + 64 * j < Geo::NEV) { \
-            ld[(i_) & 1][p][j][0] = *reinterpret_cast<const double2*>(cfb[i_] + (unsigned)kb[p][j]); \
-            ld[(i_) & 1][p][j][1] = *reinterpret_cast<const double2*>(cfb[i_] + (unsigned)kb[p][j] + 16); }
-        JX_DCT_REQ(0)
+            _Pragma("unroll") for (int p = 0; p < NPASS; ++p) \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) if (256 * p + 64 * j < Geo::NEV) { \
+                ld[(i_) & 1][p][j][0] = *reinterpret_cast<const double2*>(cfb[i_] + (unsigned)kb[p][j]); \
+                ld[(i_) & 1][p][j][1] = *reinterpret_cast<const double2*>(cfb[i_] + (unsigned)kb[p][j] + 16); }
+            JX_DCT_REQ(0)
 #pragma unroll
-        for (int i = 0; i < WPW; ++i) {
-            const int w = wq + NWAVE * i;                     // wave-uniform
-            if (i + 1 < WPW) { JX_DCT_REQ(i + 1) }
-            __builtin_amdgcn_sched_barrier(0);
-            if (NW % NWAVE == 0 || w < NW) {
-                char* Mw = reinterpret_cast<char*>(M + w * RS);
-                double* qa = reinterpret_cast<double*>(Mw);   // the walker's row as scratch: q[a], a < NEV
+            for (int i = 0; i < WPW; ++i) {
+                const int w = wq + NWAVE * i;                     // wave-uniform
+                if (i + 1 < WPW) { JX_DCT_REQ(i + 1) }
+                __builtin_amdgcn_sched_barrier(0);
+                if (NW % NWAVE == 0 || w < NW) {
+                    double* qa = reinterpret_cast<double*>(M + w * RS);   // the walker's row as scratch: q[a], a < NEV
 #pragma unroll
-                for (int p = 0; p < NPASS; ++p)
+                    for (int p = 0; p < NPASS; ++p)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (256 * p + 64 * j < Geo::NEV) {
-                            const double2 p0 = ld[i & 1][p][j][0], p1 = ld[i & 1][p][j][1];
-                            const double v = fma(wt[p][j][3], p1.y, fma(wt[p][j][2], p0.y, fma(wt[p][j][1], p1.x, wt[p][j][0] * p0.x)));
-                            if (256 * p + 64 * j + 64 <= Geo::NEV || 256 * p + 64 * j + lane < Geo::NEV) qa[256 * p + 64 * j + lane] = v;
-                        }
-                // (LDS operations of one wave complete in order: the reads below see every lane's stores)
-                double2 qv[NPASS][3];
-                double q3[NPASS];
-#pragma unroll
-                for (int p = 0; p < NPASS; ++p) {
-                    const int g = min(lane + 64 * p, Geo::GW), gm = max(g, 1);
-                    qv[p][0] = *reinterpret_cast<const double2*>(qa + 4 * g);          // q[4g], q[4g+1]
-                    qv[p][1] = *reinterpret_cast<const double2*>(qa + 4 * g + 2);      // q[4g+2], q[4g+3]
-                    qv[p][2] = *reinterpret_cast<const double2*>(qa + 4 * gm - 2);     // q[4g-2], q[4g-1]
-                    q3[p] = qa[4 * gm - 3];                                             // q[4g-3]
+                        for (int j = 0; j < 4; ++j)
+                            if (256 * p + 64 * j < Geo::NEV) {
+                                const double2 p0 = ld[i & 1][p][j][0], p1 = ld[i & 1][p][j][1];
+                                const double v = fma(wt[p][j][3], p1.y, fma(wt[p][j][2], p0.y, fma(wt[p][j][1], p1.x, wt[p][j][0] * p0.x)));
+                                if (256 * p + 64 * j + 64 <= Geo::NEV || 256 * p + 64 * j + lane < Geo::NEV) qa[256 * p + 64 * j + lane] = v;
+                            }
+                    build_z(w);
                 }
-                double bs = 0.0;
+            }
+#undef JX_DCT_REQ
+        } else {
+            // lanes = 16 walkers x NT/16 samples: 128-byte runs of the walker-minor source
+            constexpr int KPT = NT / 16, NLD = (Geo::NEV + KPT - 1) / KPT;
+            const int sw = tid & 15, sk = tid >> 4;
+            const double* sp = cf + (size_t)u * d.tW + min(w0 + sw, d.n - 1);
+            double sv[NLD];
 #pragma unroll
-                for (int p = 0; p < NPASS; ++p) {
-                    const double v0 = qv[p][0].x, v1 = qv[p][0].y, v2 = qv[p][1].x, v3 = qv[p][1].y;
-                    const bool centre = (p == 0) && lane == 0;                          // q[-a] = q[a]
-                    const double m1 = centre ? v1 : qv[p][2].y, m2 = centre ? v2 : qv[p][2].x, m3 = centre ? v3 : q3[p];
-                    bs += v1 + v3;
-                    if (e_on[p]) {
-                        *reinterpret_cast<double2*>(Mw + e_j1[p]) = make_double2(v0 + v1 - m1, v2 + v3 - v1);
-                        *reinterpret_cast<double2*>(Mw + e_j2[p]) = make_double2(v0 - v1 + m1, m2 - m1 + m3);
-                    }
-                    if (Geo::TAIL && p == NPASS - 1 && e_tail) {   // the group behind the last one has no samples of its own
-                        *reinterpret_cast<double2*>(Mw + e_j1t) = make_double2(-v3, 0.0);
-                        *reinterpret_cast<double2*>(Mw + e_j2t) = make_double2(v3, v2 - v3 + v1);
-                    }
-                }
+            for (int i = 0; i < NLD; ++i) {
+                const int k = sk + KPT * i, km = (Geo::FULL && k > LP) ? 2 * LP - k : k;     // even about the Nyquist index
+                sv[i] = sp[(size_t)min(km, d.n_in - 1) * d.s_kstr];
+            }
+            double* qa = reinterpret_cast<double*>(M + sw * RS);
 #pragma unroll
-                for (int e0 = 0; e0 < Geo::NZFILL; e0 += 64) {
-                    const int j = Geo::ZLO + e0 + lane;
-                    if (j <= Q - Geo::ZLO) *reinterpret_cast<double2*>(Mw + 16 * ((j / L2) * L2P + (j % L2))) = make_double2(0.0, 0.0);
-                }
-                s_bs[w * 64 + lane] = bs;
+            for (int i = 0; i < NLD; ++i) {
+                const int k = sk + KPT * i, km = (Geo::FULL && k > LP) ? 2 * LP - k : k;
+                if (k < Geo::NEV) qa[k] = (km < d.n_in) ? sv[i] : 0.0;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < WPW; ++i) {
+                const int w = wq + NWAVE * i;
+                if (NW % NWAVE == 0 || w < NW) build_z(w);
             }
         }
         JX_STAMP(0)
-        if (d.has_x0 && tid < NW && w0 + tid < d.n)
+        if (MODE == 0 && d.has_x0 && tid < NW && w0 + tid < d.n)
             x0t[(size_t)u * d.tW + w0 + tid] = jx_spline4(reinterpret_cast<const char*>(cf + (size_t)(w0 + tid) * d.cf_ws), (unsigned)d.x0k[u],
                                                           d.x0w[4 * u], d.x0w[4 * u + 1], d.x0w[4 * u + 2], d.x0w[4 * u + 3]);
         __syncthreads();
@@ -290,5 +330,4 @@ jx_rowdct_kernel(JxDct d, const double* __restrict__ cf, double* __restrict__ Rt
     }
     if (stamping && tid == 0) for (int i = 0; i < 6; ++i) d.stamps[(size_t)blockIdx.x * 8 + i] = st_acc[i];
 #undef JX_STAMP
-#undef JX_DCT_REQ
 }

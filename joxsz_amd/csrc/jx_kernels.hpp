@@ -1103,6 +1103,59 @@ jx_tail_kernel(JxDev c, const double2* __restrict__ tfspec, const double2* __res
 }
 
 // ------------------------------------------------------------------------------------
+// Tail of the odd-side route: the extracted row arrives as r partial rows (one per term of the low-rank transfer
+// function), D2[w][rho][b]; they are added in a fixed order, then conversion, data radii, chi^2 and total as above
+// (joxsz_funcs.py:472-479, 538).
+// ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(JX_TAIL_THREADS)
+jx_tail_odd_kernel(JxDev c, const double* __restrict__ D2, int r, int ldb, const double* __restrict__ cfac,
+                   const double* __restrict__ base, double* __restrict__ logp, int w0,
+                   double* __restrict__ tap_row, double* __restrict__ tap_bright, double* __restrict__ tap_chisq,
+                   double* __restrict__ tap_parts) {
+    JX_LDS_DECL;
+    double* red = sm + 20;
+    const int nrow = c.nrow;
+    double* s_prof = sm + JX_LDS_HDR;  // [nrow]
+    const int w = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
+    const double* Dw = D2 + (size_t)w * r * ldb;
+    for (int k = tid; k < nrow; k += nth) {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int rho = 0;
+        for (; rho + 3 < r; rho += 4) {
+            a0 += Dw[(size_t)rho * ldb + k]; a1 += Dw[(size_t)(rho + 1) * ldb + k];
+            a2 += Dw[(size_t)(rho + 2) * ldb + k]; a3 += Dw[(size_t)(rho + 3) * ldb + k];
+        }
+        for (; rho < r; ++rho) a0 += Dw[(size_t)rho * ldb + k];
+        const double acc = (a0 + a1) + (a2 + a3);
+        if (tap_row) tap_row[(size_t)w * nrow + k] = acc;
+        const double b = acc * cfac[(size_t)w * nrow + k];
+        s_prof[k] = b;
+        if (tap_bright) tap_bright[(size_t)w * nrow + k] = b;
+    }
+    __syncthreads();
+    double part = 0.0;
+    for (int dd = tid >> 3; dd < c.nflux; dd += nth >> 3) {         // eight lanes per flux point
+        const double* e = c.emat + (size_t)dd * nrow;
+        double m = 0.0;
+        for (int k = tid & 7; k < nrow; k += 8) m = fma(e[k], s_prof[k], m);
+        m += __shfl_xor(m, 1, 64); m += __shfl_xor(m, 2, 64); m += __shfl_xor(m, 4, 64);
+        const double z = (c.flux[c.nflux + dd] - m) / c.flux[2 * c.nflux + dd];
+        const double z2 = z * z;
+        if ((tid & 7) == 0 && z2 == z2) part += z2;                  // np.nansum drops NaN terms
+    }
+    const double chisq = jx_block_sum(part, red);
+    if (tid == 0) {
+        const double ll = -chisq / 2.0;
+        const double b = base[w];
+        double tot = (b == -INFINITY) ? -INFINITY : b + ll;
+        if (tot != tot) tot = -INFINITY;             // never hand NaN to the sampler
+        logp[w0 + w] = tot;
+        if (tap_chisq) tap_chisq[w] = chisq;
+        if (tap_parts) tap_parts[(size_t)w * 4 + 1] = ll;
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // Collapsed route (jx_set_route(ctx, JX_ROUTE_OPERATOR)).  Between the pressure profile and the extracted map row
 // every step of joxsz_funcs.py:457-472 is linear with constant coefficients (Abel matrix, spline through fixed knots
 // evaluated at fixed radii, beam convolution, transfer function, row extraction), so

@@ -656,6 +656,47 @@ inline int custom_conv_lp(int S, int o) {
     return 0;
 }
 
+// Odd map sides (the only kind the reference itself builds, joxsz_main.py:100-105): half the padded length for the
+// hand-written route.  The rows need 2 LP >= S + o, and the quarter-length transforms (jx_dct.hpp) need the centre offset
+// c = S/2 <= LP - 5 samples.
+inline int custom_conv_lp_odd(int S, int o) {
+    static const int lps[] = {48, 96, 144, 288, 576};
+    if (S % 2 == 0) return 0;
+    for (int lp : lps)
+        if (2 * lp >= S + o && S / 2 <= lp - 5) return lp;
+    return 0;
+}
+
+// Real-space form of the transfer-function step for odd S.  With the weights in low-rank form, Hy[job][kc] =
+// sum_rho U[rho][job] v_rho[kc], the extracted row is (joxsz_funcs.py:466-467, 472)
+//     row[c + b] = sum_rho sum_{x'} k_rho[(c + b - x') mod S] cc_rho[x'],   k_rho[j] = sum_kc v_rho[kc] cos(2 pi kc j / S),
+// cc_rho the combined rows in real space.  They are symmetric about the centre column, cc_rho[c + a] = cc_rho[c - a], so
+//     row[c + b] = sum_rho sum_{a = 0..c} K[rho][b][a] cc_rho[c + a],   K[rho][b][a] = k_rho[b - a] + (a > 0) k_rho[b + a].
+// Output: for every group mg of 64 rows b and every rho one matrix [64][KQ] (zero padded): out[(mg r + rho) 64 KQ + ...].
+inline void odd_rowspace_operator(const std::vector<double>& V /*[r][Sh] right singular vectors*/, int r, int S, int KQ,
+                                  std::vector<double>& out, int* nmg_out) {
+    const int c = S / 2, Sh = S / 2 + 1, nout = c + 1, nmg = (nout + 63) / 64;
+    *nmg_out = nmg;
+    out.assign((size_t)nmg * r * 64 * KQ, 0.0);
+    std::vector<double> cs(S), k(S);
+    for (int j = 0; j < S; ++j) cs[j] = std::cos(2.0 * kPi * j / S);
+    for (int rho = 0; rho < r; ++rho) {
+        for (int j = 0; j < S; ++j) {
+            double a = 0.0;
+            for (int kc = 0; kc < Sh; ++kc) a += V[(size_t)rho * Sh + kc] * cs[(int)(((long long)kc * j) % S)];
+            k[j] = a;
+        }
+        for (int b = 0; b < nout; ++b) {
+            double* row = &out[(((size_t)(b / 64) * r + rho) * 64 + (b % 64)) * KQ];
+            for (int a = 0; a < nout; ++a) {
+                double v = k[((b - a) % S + S) % S];
+                if (a > 0) v += k[(b + a) % S];
+                row[a] = v;
+            }
+        }
+    }
+}
+
 // smallest even 2^a 3^b 5^c >= n
 inline int next_smooth_even(int n) {
     for (int m = std::max(2, n + (n & 1));; m += 2) {

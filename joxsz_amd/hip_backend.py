@@ -46,7 +46,7 @@ class JxConfig(ctypes.Structure):
 class JxTiming(ctypes.Structure):
     _fields_ = [(n, ctypes.c_double) for n in (
         'prep_ms', 'abel_map_ms', 'beam_fft_ms', 'tf_fft_ms', 'tail_ms', 'total_ms')] + \
-        [('launches', ctypes.c_int64), ('walkers', ctypes.c_int64)]
+        [('launches', ctypes.c_int64), ('walkers', ctypes.c_int64), ('gemm_ms', ctypes.c_double)]
 
 
 _lib = None

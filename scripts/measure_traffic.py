@@ -23,7 +23,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def collect(counter, outdir):
     cmd = ['rocprofv3', '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', outdir, '--',
-           sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '1', '--no-cpu']
+           sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '1', '--no-cpu', '--no-full-map']
     env = dict(os.environ, TMPDIR='/tmp')
     res = subprocess.run(cmd, check=True, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
     collect.bench = json.loads(res.stdout.strip().splitlines()[-1])
@@ -40,7 +40,7 @@ def collect(counter, outdir):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+    tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
     scratch = os.path.join(ROOT, 'gpurun_out', 'traffic_' + tag)
     fetch = collect('FETCH_SIZE', scratch + '_fetch')
     write = collect('WRITE_SIZE', scratch + '_write')

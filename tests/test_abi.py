@@ -39,7 +39,7 @@ def test_config_struct_layout():
     # 20 int32 then 5 doubles, no implicit padding (the header keeps the doubles 8-byte aligned)
     assert ctypes.sizeof(hip_backend.JxConfig) == 20 * 4 + 5 * 8
     assert hip_backend.JxConfig.step.offset == 80
-    assert ctypes.sizeof(hip_backend.JxTiming) == 6 * 8 + 2 * 8
+    assert ctypes.sizeof(hip_backend.JxTiming) == 6 * 8 + 2 * 8 + 8
 
 
 def test_strerror_and_bad_config(lib):

@@ -28,6 +28,7 @@ def test_golden_logp(golden):
     """The reference's own log-posteriors (tests/golden) on identical parameter vectors."""
     pb, ref = golden
     post = _post(pb)
+    assert post.ctx.conv == 'custom'                  # the reference's odd sides run on the hand-written route
     got = post.log_prob(ref['thetas'])
     want = ref['ref_logp']
     post.close()
@@ -89,7 +90,8 @@ def test_random_walkers_vs_oracle(S, N, conv):
     th = datasets.walker_ball(pb, W, spread=0.05, seed=S)
     th[1, 1] = 9.0                                    # one rejected walker in the batch
     post = _post(pb, conv=conv)
-    assert post.ctx.conv == ('rocfft' if conv == 'auto' else conv)      # odd S: only rocFFT is eligible
+    # odd sides take the hand-written route as well (real-space transfer-function step) once the padded length fits
+    assert post.ctx.conv == ('custom' if conv == 'auto' else conv)
     got = post.log_prob(th)
     post.close()
     want = orc.log_posterior_batch(pb, th)
@@ -195,10 +197,65 @@ def test_custom_conv_stages(S, N, step, fwhm):
 
 
 def test_custom_conv_refuses_what_it_cannot_do(golden_tiny):
+    """The hand-written route needs a flip-symmetric beam image (what mybeam builds, joxsz_funcs.py:46-76) and the
+    library's own padded length: asked for explicitly with anything else it refuses, on 'auto' it takes the rocFFT
+    sequence -- and that one still matches the oracle."""
+    import copy
     from joxsz_amd.hip_backend import JoxszHipError
-    pb, _ = golden_tiny                                # S = 31: odd side
+    pb, ref = golden_tiny
+    pb = copy.deepcopy(pb)
+    pb.beam_2d = pb.beam_2d.copy()
+    o = pb.B // 2
+    pb.beam_2d[o, o + 1] *= 1.5                        # no longer symmetric under the flips
     with pytest.raises(JoxszHipError):
         _post(pb, conv='custom')
+    with pytest.raises(JoxszHipError):
+        _post(golden_tiny[0], conv='custom', fft_pad=64)
+    post = _post(pb)
+    assert post.ctx.conv == 'rocfft'
+    got = post.log_prob(ref['thetas'][:4])
+    post.close()
+    want = orc.log_posterior_batch(pb, ref['thetas'][:4])
+    np.testing.assert_allclose(got, want, rtol=RTOL)
+
+
+@pytest.mark.parametrize('S,N', [(65, 80), (171, 313), (257, 300), (513, 500)])
+def test_odd_side_custom_route(S, N):
+    """Odd map sides -- the only kind the reference itself can run (joxsz_main.py:100-105, joxsz_funcs.py:472-473) -- on
+    the hand-written route: rows from the spline, FIR + job combination as matrix products, combined rows back to real
+    space, transfer function as real-space circular kernels.  Stage by stage against the oracle and against the rocFFT
+    sequence; ragged launches bitwise."""
+    from joxsz_amd import datasets
+    pb = datasets.synthetic_problem(S=S, N=N, seed=S + 1)
+    p0 = orc.pars_dict(pb, datasets.fiducial_theta(pb))
+    datasets.fill_data(pb, orc.sz_stages(pb, p0)['bright'], orc.calc_profiles(pb, p0), seed=S)
+    th = datasets.walker_ball(pb, 21, spread=0.04, seed=S)
+    th[3, 1] = 9.0
+    post = _post(pb, conv='custom')
+    lay = post.ctx.conv_layout
+    assert post.ctx.conv == 'custom' and lay['fused'] == 1 and lay['rank'] > 0
+    got = post.log_prob(th)
+    rows, bright, chisq, y2d, conv = (post.stage(th[:6], s) for s in ('map_row', 'bright', 'chisq', 'y_2d', 'conv_2d'))
+    assert np.array_equal(post.log_prob(th), got)
+    post.close()
+    small = _post(pb, conv='custom', max_batch=8)
+    np.testing.assert_array_equal(small.log_prob(th), got)
+    small.close()
+    ref = _post(pb, conv='rocfft')
+    want_fft = ref.log_prob(th)
+    ref.close()
+    want = orc.log_posterior_batch(pb, th)
+    fin = np.isfinite(want)
+    assert fin.sum() >= 15 and np.array_equal(np.isfinite(got), fin)
+    np.testing.assert_allclose(got[fin], want[fin], rtol=1e-9)
+    np.testing.assert_allclose(got[fin], want_fft[fin], rtol=1e-9)
+    for k in range(6):
+        st = orc.sz_stages(pb, orc.pars_dict(pb, th[k]))
+        assert _relerr(y2d[k], st['y_2d']) < RTOL_STAGE
+        assert _relerr(conv[k], st['conv_2d']) < RTOL_STAGE
+        assert _relerr(rows[k], st['map_row']) < RTOL_STAGE
+        assert _relerr(bright[k], st['bright']) < RTOL_STAGE
+        assert abs(chisq[k] - st['chisq']) / 2 < 1e-6 * max(1.0, 1e-3 * st['chisq'])      # absolute near the mode, relative far from it
 
 
 def test_custom_conv_with_and_without_row_symmetry(monkeypatch):
