@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define JX_ABI_VERSION 1
+#define JX_ABI_VERSION 2
 
 typedef struct jx_ctx jx_ctx;
 
@@ -68,12 +68,16 @@ typedef struct jx_config {
     int32_t fft_pad;          /* padded side of the beam convolution (0 = library default)     */
     int32_t map_split;        /* row slabs per walker in the Abel+map kernel (0 = default)     */
     int32_t conv_mode;        /* beam+TF convolution: 0 auto, 1 rocFFT, 2 hand-written passes  */
-    int32_t reserved0;        /* keep the doubles 8-byte aligned; must be 0                    */
+    int32_t dtype;            /* arithmetic of the map / transform stages: 0 = f64 (the reference's), 1 = f32 storage and transforms */
+    int32_t calc_integ;       /* SZ_data.calc_integ: integrated-Compton term (joxsz_funcs.py:480-484, joxsz_main.py:65) */
+    int32_t reserved1;        /* keeps the doubles 8-byte aligned; must be 0                   */
     double step;              /* arcsec                                   (joxsz_main.py:21)   */
     double kpc_as;            /* kpc per arcsec                           (joxsz_main.py:96)   */
     double m_e;               /* keV                                      (joxsz_main.py:22)   */
     double sigma_T;           /* cm^2                                     (joxsz_main.py:23)   */
     double kpc_cm;            /* mbproj2.physconstants.kpc_cm             (joxsz_funcs.py:6)   */
+    double integ_mu;          /* SZ_data.integ_mu                         (joxsz_main.py:66)   */
+    double integ_sig;         /* SZ_data.integ_sig                        (joxsz_main.py:67)   */
 } jx_config;
 
 /* Constant tensors, all float64 row-major unless noted. */
@@ -103,6 +107,8 @@ typedef enum jx_tensor {
     JX_T_GEOMAREA,        /* [nann]   arcmin^2: annuli.geomarea_arcmin2                     */
     JX_T_LNT,             /* [ntab]   CountRate.Tlogvals                                    */
     JX_T_LNRATE,          /* [nband,2,ntab] ln(rate) at Z=0 and Z=1 (joxsz_funcs.py:680)    */
+    JX_T_INTEG_W,         /* [N+1] only with calc_integ: weights w of  cint = sum_j w_j v_j,  v = [f(0), y_0 .. y_{N-1}]  --
+                             the Simpson rule of joxsz_funcs.py:481-483 on its arcmin grid, times the radius, times 2 pi */
     JX_T_COUNT
 } jx_tensor;
 
@@ -120,6 +126,7 @@ typedef enum jx_stage {
     JX_STAGE_TPROF,       /* [W,nrow]   [h(0), t_prof]              joxsz_funcs.py:469-473 */
     JX_STAGE_XPROFS,      /* [W,nband,nann] calcProfiles()          joxsz_funcs.py:527 */
     JX_STAGE_PARTS,       /* [W,4]      xray like, sz like, prior, reject mask (bit0 box, bit1 mass, bit2 r_c>r_s, bit3 xray<=0) */
+    JX_STAGE_INTEG,       /* [W]        output='integ' (calc_integ only)  joxsz_funcs.py:481-487 */
     JX_STAGE_COUNT
 } jx_stage;
 

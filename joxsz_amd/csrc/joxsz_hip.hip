@@ -59,6 +59,7 @@ struct jx_ctx {
 
     // work buffers (chunk capacity)
     double *d_base = nullptr, *d_cfac = nullptr;
+    double *d_sz0 = nullptr, *d_sz0_op = nullptr, *t_integ = nullptr;   // integrated-Compton term per walker (calc_integ), its tap
     double *d_img = nullptr, *d_conv = nullptr;
     double2 *d_spec = nullptr, *d_tfspec = nullptr;
     // hand-written convolution (conv_mode 2)
@@ -185,6 +186,7 @@ static size_t tensor_bytes(const jx_config& c, int id) {
             return f * (size_t)c.nband * c.nann;
         case JX_T_LNT: return f * c.ntab;
         case JX_T_LNRATE: return f * (size_t)c.nband * 2 * c.ntab;
+        case JX_T_INTEG_W: return f * ((size_t)c.N + 1);
     }
     return 0;
 }
@@ -327,6 +329,8 @@ int jx_create(const jx_config* cfg, jx_ctx** out) {
     if (c.N < c.S - c.S / 2) return JX_ERR_INVALID;       // r_pp[:nrow-1] must exist (joxsz_funcs.py:469)
     if (!(c.step > 0) || !(c.kpc_as > 0) || !(c.m_e > 0) || !(c.sigma_T > 0) || !(c.kpc_cm > 0)) return JX_ERR_INVALID;
     if (c.nann > 64 || c.nband > 64 || c.N > 4096 || c.S > 4096) return JX_ERR_UNSUPPORTED;
+    if (c.dtype != 0 && c.dtype != 1) return JX_ERR_INVALID;
+    if (c.calc_integ && !(c.integ_sig > 0)) return JX_ERR_INVALID;
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return JX_ERR_NODEVICE;
@@ -409,6 +413,7 @@ int jx_finalize(jx_ctx* ctx) {
     const jx_config& c = ctx->cfg;
     for (int id = 0; id < JX_T_COUNT; ++id) {
         if (c.sz_only && tensor_is_xray(id)) continue;
+        if (id == JX_T_INTEG_W && !c.calc_integ) continue;
         if (!ctx->have[id]) { ctx->err = "tensor " + std::to_string(id) + " missing"; return JX_ERR_MISSING; }
     }
     HIPCHK(ctx, hipSetDevice(c.device));
@@ -493,6 +498,20 @@ int jx_finalize(jx_ctx* ctx) {
                 if (j >= 0 && j < N) band[(size_t)(k + K) * N + i] = G[(size_t)i * N + j];
             }
         double* p; if ((rc = dev_put(ctx, band.data(), band.size(), &p))) return rc; d.gband = p;
+        if (c.calc_integ) {
+            // cint = w . [f(0), y],  f(0) = y_0 - r_0^2/2 * (G y)_0 (value at 0 of the mirrored spline),  y = y_scale * A pp:
+            // one weight per radius of the pressure profile
+            std::vector<double> w = host_vec<double>(ctx, JX_T_INTEG_W), wy(N), A, wp(N, 0.0);
+            for (int j = 0; j < N; ++j) wy[j] = w[j + 1] - w[0] * 0.5 * r[0] * r[0] * G[j];
+            wy[0] += w[0];
+            jxt::abel_matrix(r, A);
+            for (int i = 0; i < N; ++i) {
+                const double f = d.y_scale * wy[i];
+                for (int j = i; j < N; ++j) wp[j] += f * A[(size_t)i * N + j];
+            }
+            if ((rc = dev_put(ctx, wp.data(), wp.size(), &p))) return rc;
+            d.integ_wp = p; d.calc_integ = 1; d.integ_mu = c.integ_mu; d.integ_sig = c.integ_sig;
+        }
     }
     // ---- h(0) weights: spline through (+-r_pp[:nt], t) evaluated at 0 (joxsz_funcs.py:470-473)
     {
@@ -800,6 +819,7 @@ int jx_finalize(jx_ctx* ctx) {
 
     if ((rc = dev_new(ctx, (size_t)chunk, &ctx->d_base))) return rc;
     if ((rc = dev_new(ctx, (size_t)chunk * ctx->nrow, &ctx->d_cfac))) return rc;
+    if (c.calc_integ && (rc = dev_new(ctx, (size_t)chunk, &ctx->d_sz0, true))) return rc;
     if (ctx->conv_mode == 1) {
         if ((rc = dev_new(ctx, (size_t)chunk * P * P, &ctx->d_img, true))) return rc;     // padding stays zero for ever
         if ((rc = dev_new(ctx, (size_t)chunk * P * P, &ctx->d_conv))) return rc;
@@ -1073,7 +1093,7 @@ static int drain_events(jx_ctx* ctx) {
 
 struct Taps {
     double *pp = nullptr, *ab = nullptr, *y = nullptr, *row = nullptr, *bright = nullptr, *chisq = nullptr,
-           *tprof = nullptr, *xprofs = nullptr, *parts = nullptr, *conv = nullptr;
+           *tprof = nullptr, *xprofs = nullptr, *parts = nullptr, *conv = nullptr, *integ = nullptr;
     bool need_img = false;            // the Compton-y map itself is wanted (y_2d tap, work-buffer hook): map kernel + pass 1 from the image
 };
 
@@ -1348,6 +1368,7 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
     // the operator route has no per-walker work buffers beyond these three, so its launches can be much larger than a chunk
     double* base_buf = op_route ? ctx->d_base_op : ctx->d_base;
     double* cfac_buf = op_route ? ctx->d_cfac_op : ctx->d_cfac;
+    double* sz0_buf = op_route ? ctx->d_sz0_op : ctx->d_sz0;           // null unless calc_integ
     if (tm) {
         if (ctx->ev_inflight.size() > 2048 && (rc = drain_events(ctx))) return rc;
         if ((rc = get_evset(ctx, &es))) return rc;
@@ -1359,7 +1380,7 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
     {
         const size_t sh = sizeof(double) * (JX_LDS_HDR + (size_t)2 * d.N + 2 * d.nann + (size_t)d.nband * d.nann + 8);
         hipLaunchKernelGGL(jx_prep_kernel, dim3(n), dim3(JX_PREP_THREADS), sh, st, d, theta_dev, w0,
-                           base_buf, cfac_buf, op_route ? ctx->d_pp : (double*)nullptr, t.tprof, t.xprofs, t.parts);
+                           base_buf, cfac_buf, op_route ? ctx->d_pp : (double*)nullptr, sz0_buf, t.tprof, t.xprofs, t.parts, t.integ);
     }
     if (tm) HIPCHK(ctx, hipEventRecord(es.e[1], st));
     if (op_route) {
@@ -1382,7 +1403,7 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
         while (wpb > 4 && sizeof(double) * (2048 + (size_t)wpb * Re + 8) > 64 * 1024) wpb >>= 1;
         const size_t sh = sizeof(double) * (2048 + (size_t)wpb * Re + 8);
 #define JX_OP_GO(WPBv) hipLaunchKernelGGL((jx_operator_kernel<WPBv, 2048 / WPBv>), dim3((n + WPBv - 1) / WPBv), dim3(256), sh, st, d, ctx->d_pp, w0, n, \
-                           ctx->d_G, ctx->g_ld, rows_t, cfac_buf, base_buf, logp_dev, t.row, t.bright, t.chisq, t.parts)
+                           ctx->d_G, ctx->g_ld, rows_t, cfac_buf, sz0_buf, base_buf, logp_dev, t.row, t.bright, t.chisq, t.parts)
         if (wpb == 16) JX_OP_GO(16); else if (wpb == 8) JX_OP_GO(8); else JX_OP_GO(4);
 #undef JX_OP_GO
         if (tm) {
@@ -1455,7 +1476,7 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
     if (ctx->odd) {
         if (t.conv && (rc = launch_odd_conv_tap(ctx, n))) return rc;
         const size_t sh = sizeof(double) * (JX_LDS_HDR + (size_t)d.nrow + 8);
-        hipLaunchKernelGGL(jx_tail_odd_kernel, dim3(n), dim3(JX_TAIL_THREADS), sh, st, d, ctx->d_D2, ctx->lrf.r, ctx->o_ldb, ctx->d_cfac,
+        hipLaunchKernelGGL(jx_tail_odd_kernel, dim3(n), dim3(JX_TAIL_THREADS), sh, st, d, ctx->d_D2, ctx->lrf.r, ctx->o_ldb, ctx->d_cfac, ctx->d_sz0,
                            ctx->d_base, logp_dev, w0, t.row, t.bright, t.chisq, t.parts);
         if (tm) {
             HIPCHK(ctx, hipEventRecord(es.e[5], st));
@@ -1468,14 +1489,14 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
     if (ctx->conv_mode == 2 && d.nrow == ctx->cv.LS && !getenv("JOXSZ_TAIL_DFT")) {
         const JxConv& cv = ctx->cv;
 #define JX_TAILF(LPv, LSv, R1v, R3v) if (!tail_done && cv.LP == LPv && cv.LS == LSv) { \
-            hipLaunchKernelGGL((jx_tail_fft_kernel<LSv>), dim3(n), dim3(256), 0, st, d, cv, zpart, nblk, ctx->d_cfac, ctx->d_base, logp_dev, w0, \
+            hipLaunchKernelGGL((jx_tail_fft_kernel<LSv>), dim3(n), dim3(256), 0, st, d, cv, zpart, nblk, ctx->d_cfac, ctx->d_sz0, ctx->d_base, logp_dev, w0, \
                                t.row, t.bright, t.chisq, t.parts); tail_done = true; }
         JX_CONV2_PAIRS(JX_TAILF)
 #undef JX_TAILF
     }
     if (!tail_done) {
         const size_t sh = sizeof(double) * (JX_LDS_HDR + (size_t)2 * d.Sh + d.nrow + 8);
-        hipLaunchKernelGGL(jx_tail_kernel, dim3(n), dim3(JX_TAIL_THREADS), sh, st, d, ctx->d_tfspec, zpart, nblk, ctx->d_cfac,
+        hipLaunchKernelGGL(jx_tail_kernel, dim3(n), dim3(JX_TAIL_THREADS), sh, st, d, ctx->d_tfspec, zpart, nblk, ctx->d_cfac, ctx->d_sz0,
                            ctx->d_base, logp_dev, w0, t.row, t.bright, t.chisq, t.parts);
     }
     if (tm) {
@@ -1600,6 +1621,7 @@ static int build_operator(jx_ctx* ctx) {
     if ((rc = dev_new(ctx, (size_t)ctx->op_cap * N, &ctx->d_pp))) return rc;
     if ((rc = dev_new(ctx, (size_t)ctx->op_cap, &ctx->d_base_op))) return rc;
     if ((rc = dev_new(ctx, (size_t)ctx->op_cap * nrow, &ctx->d_cfac_op))) return rc;
+    if (c.calc_integ && (rc = dev_new(ctx, (size_t)ctx->op_cap, &ctx->d_sz0_op, true))) return rc;
     if ((rc = dev_new(ctx, ((size_t)ctx->op_cap + 32) * nrow, &ctx->d_rows))) return rc;
     ctx->d_G = G;
     ctx->g_ld = ld;
@@ -1675,6 +1697,7 @@ static int ensure_taps(jx_ctx* ctx) {
     if ((rc = dev_new(ctx, C, &ctx->t_chisq))) return rc;
     if ((rc = dev_new(ctx, C * std::max(1, c.nband * c.nann), &ctx->t_xprofs, true))) return rc;
     if ((rc = dev_new(ctx, C * 4, &ctx->t_parts, true))) return rc;
+    if ((rc = dev_new(ctx, C, &ctx->t_integ, true))) return rc;
     return JX_OK;
 }
 
@@ -1692,7 +1715,9 @@ int jx_eval_stage(jx_ctx* ctx, const double* theta, int nwalkers, int stage, dou
         case JX_STAGE_CHISQ: per = 1; break;
         case JX_STAGE_XPROFS: per = (size_t)c.nband * c.nann; break;
         case JX_STAGE_PARTS: per = 4; break;
+        case JX_STAGE_INTEG: per = 1; break;
     }
+    if (stage == JX_STAGE_INTEG && !c.calc_integ) { ctx->err = "the 'integ' output needs calc_integ"; return JX_ERR_INVALID; }
     if (stage == JX_STAGE_XPROFS && c.sz_only) { ctx->err = "no X-ray profiles in sz_only mode"; return JX_ERR_INVALID; }
     if (nbytes != per * sizeof(double) * (size_t)nwalkers) { ctx->err = "jx_eval_stage: wrong output size"; return JX_ERR_INVALID; }
     HIPCHK(ctx, hipSetDevice(c.device));
@@ -1711,6 +1736,7 @@ int jx_eval_stage(jx_ctx* ctx, const double* theta, int nwalkers, int stage, dou
     t.conv = (stage == JX_STAGE_CONV2D) ? ctx->t_convjobs : nullptr;
     t.need_img = (stage == JX_STAGE_Y2D);
     t.chisq = ctx->t_chisq; t.tprof = ctx->t_tprof; t.xprofs = c.sz_only ? nullptr : ctx->t_xprofs; t.parts = ctx->t_parts;
+    t.integ = ctx->t_integ;
     for (int w0 = 0; w0 < nwalkers; w0 += ctx->chunk) {
         const int n = std::min(ctx->chunk, nwalkers - w0);
         if ((rc = run_chunk(ctx, ctx->d_theta, ctx->d_logp, w0, n, t))) return rc;
@@ -1726,6 +1752,7 @@ int jx_eval_stage(jx_ctx* ctx, const double* theta, int nwalkers, int stage, dou
             case JX_STAGE_CHISQ: src = ctx->t_chisq; break;
             case JX_STAGE_XPROFS: src = ctx->t_xprofs; break;
             case JX_STAGE_PARTS: src = ctx->t_parts; break;
+            case JX_STAGE_INTEG: src = ctx->t_integ; break;
             default: break;
         }
         if (src) {

@@ -939,7 +939,7 @@ jx_lowrank_kernel(JxLowrank lr, JxGemmSeg sg0, JxGemmSeg sg1, long long bws, lon
 // ------------------------------------------------------------------------------------
 template <int LS>
 __global__ void __launch_bounds__(256)
-jx_tail_fft_kernel(JxDev c, JxConv cv, const cplx* __restrict__ zpart, int nblk, const double* __restrict__ cfac,
+jx_tail_fft_kernel(JxDev c, JxConv cv, const cplx* __restrict__ zpart, int nblk, const double* __restrict__ cfac, const double* __restrict__ sz0,
                    const double* __restrict__ base, double* __restrict__ logp, int w0,
                    double* __restrict__ tap_row, double* __restrict__ tap_bright, double* __restrict__ tap_chisq,
                    double* __restrict__ tap_parts) {
@@ -1030,7 +1030,7 @@ jx_tail_fft_kernel(JxDev c, JxConv cv, const cplx* __restrict__ zpart, int nblk,
     }
     const double chisq = jx_block_sum(part, s_red);
     if (tid == 0) {
-        const double ll = -chisq / 2.0;
+        const double ll = -chisq / 2.0 + (sz0 ? sz0[w] : 0.0);
         const double b = base[w];
         double tot = (b == -INFINITY) ? -INFINITY : b + ll;
         if (tot != tot) tot = -INFINITY;                             // never hand NaN to the sampler

@@ -58,6 +58,9 @@ struct JxDev {
     long long xcol_ld;           //   [q_nb padded][xcol_ld] when xcol_ld > 0 (fused FIR path)
     int pairw, nlaunch;          // quad mode: walkers per block (1 or 2: two coefficient sets share every table entry), walkers of this launch
     int quad;                    // 1: the image is the quadrant [q_nb][img_ld] (|iy-c|, |ix-c|) alone, nothing mirrored
+    int calc_integ;              // joxsz_funcs.py:480-484: cint = integ_wp . press_fun(r_pp) (Simpson rule, spline value at 0, Compton
+    const double* integ_wp;      //   scaling and Abel integral folded into one weight per radius); chi^2 term ((cint - mu)/sig)^2
+    double integ_mu, integ_sig;
     double* cf_out;              // not null: the kernel stops after phase 3 and leaves the spline ordinates and moments (y_k, M_k),
     long long cf_ws;             //   k < N, here: [nlaunch][cf_ws] doubles (jx_rowdct_kernel evaluates the map rows from them)
     const int* q_k;              // [q_nb*q_na] coefficient slot of each quadrant radius
@@ -252,7 +255,8 @@ __device__ __forceinline__ void jx_load_params(const JxDev& c, const double* __r
 __global__ void __launch_bounds__(JX_PREP_THREADS)
 jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
                double* __restrict__ base, double* __restrict__ cfac, double* __restrict__ pp_out /*[chunk][N] or null*/,
-               double* __restrict__ tap_tprof, double* __restrict__ tap_xprofs, double* __restrict__ tap_parts) {
+               double* __restrict__ sz0 /*[chunk] integrated-Compton term of the SZ log-likelihood, or null*/,
+               double* __restrict__ tap_tprof, double* __restrict__ tap_xprofs, double* __restrict__ tap_parts, double* __restrict__ tap_integ) {
     JX_LDS_DECL;
     double* p = sm;
     double* red = sm + 20;
@@ -296,7 +300,8 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
     //      monotonicity veto (joxsz_funcs.py:522-525, 428-437) and T_SZ on r_pp[:nt] (joxsz_funcs.py:469).  The pressure
     //      derivative (joxsz_funcs.py:289-301) is the pressure times -(c + b x^a) / (r (1 + x^a)): no powers of its own.
     const bool veto = c.exclude_unphy_mass != 0;
-    const int nprof = (veto || pp_out) ? c.N : c.nt;
+    const int nprof = (veto || pp_out || c.calc_integ) ? c.N : c.nt;
+    double ci = 0.0;                          // this thread's share of integ_wp . pp
     const bool logform = !c.prep_pow;
     double pl[10];
     jx_prof_consts(p, c.ne_mode, pl);
@@ -316,6 +321,7 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
             const double ma = pa * (p[P_C] + p[P_B] * xaa) / (ra * (1.0 + xaa)) * ra * ra / na;
             const double mb = pb * (p[P_C] + p[P_B] * xab) / (rb * (1.0 + xab)) * rb * rb / nb;
             if (pp_out) { pp_out[(size_t)w * N_ + i] = pa; if (two) pp_out[(size_t)w * N_ + i2] = pb; }
+            if (c.calc_integ) { ci = fma(c.integ_wp[i], pa, ci); if (two) ci = fma(c.integ_wp[i2], pb, ci); }
             if (veto) { s_m[i] = ma; if (two) s_m[i2] = mb; }
             if (i < nt_) s_t[i] = pa / na;
             if (two && i2 < nt_) s_t[i2] = pb / nb;
@@ -327,6 +333,7 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
             const double xa = pow(x, p[P_A]);
             const double press = p[P_P0] / (pow(x, p[P_C]) * pow(1.0 + xa, (p[P_B] - p[P_C]) / p[P_A]));   // == jx_press(p, r)
             if (pp_out) pp_out[(size_t)w * N_ + i] = press;
+            if (c.calc_integ) ci = fma(c.integ_wp[i], press, ci);
             if (veto || i < nt_) {
                 const double ne = jx_ne_pc(p, pc, r, mode_);
                 if (veto) s_m[i] = press * (p[P_C] + p[P_B] * xa) / (r * (1.0 + xa)) * r * r / ne;
@@ -342,6 +349,17 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
             else if (i == c.N - 1) g = s_m[c.N - 1] - s_m[c.N - 2];
             else g = (s_m[i + 1] - s_m[i - 1]) / 2.0;
             if (!(g > 0.0)) rej |= REJ_MASS;
+        }
+    }
+
+    // ---- integrated Compton parameter and its chi^2 term (joxsz_funcs.py:480-484; np.nansum drops a NaN) ----
+    if (c.calc_integ) {
+        const double cint = jx_block_sum(ci, red);
+        if (tid == 0) {
+            const double z = (cint - c.integ_mu) / c.integ_sig;
+            const double z2 = z * z;
+            if (sz0) sz0[w] = (z2 == z2) ? -0.5 * z2 : 0.0;
+            if (tap_integ) tap_integ[w] = cint;
         }
     }
 
@@ -1020,7 +1038,7 @@ jx_beam_mul_kernel(double2* __restrict__ spec, const double2* __restrict__ bhat,
 // ------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(JX_TAIL_THREADS)
 jx_tail_kernel(JxDev c, const double2* __restrict__ tfspec, const double2* __restrict__ zpart, int nblk,
-               const double* __restrict__ cfac,
+               const double* __restrict__ cfac, const double* __restrict__ sz0,
                const double* __restrict__ base, double* __restrict__ logp, int w0,
                double* __restrict__ tap_row, double* __restrict__ tap_bright, double* __restrict__ tap_chisq,
                double* __restrict__ tap_parts) {
@@ -1092,7 +1110,7 @@ jx_tail_kernel(JxDev c, const double2* __restrict__ tfspec, const double2* __res
     }
     const double chisq = jx_block_sum(part, red);
     if (tid == 0) {
-        const double ll = -chisq / 2.0;
+        const double ll = -chisq / 2.0 + (sz0 ? sz0[w] : 0.0);
         const double b = base[w];
         double tot = (b == -INFINITY) ? -INFINITY : b + ll;
         if (tot != tot) tot = -INFINITY;             // never hand NaN to the sampler
@@ -1108,7 +1126,7 @@ jx_tail_kernel(JxDev c, const double2* __restrict__ tfspec, const double2* __res
 // (joxsz_funcs.py:472-479, 538).
 // ------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(JX_TAIL_THREADS)
-jx_tail_odd_kernel(JxDev c, const double* __restrict__ D2, int r, int ldb, const double* __restrict__ cfac,
+jx_tail_odd_kernel(JxDev c, const double* __restrict__ D2, int r, int ldb, const double* __restrict__ cfac, const double* __restrict__ sz0,
                    const double* __restrict__ base, double* __restrict__ logp, int w0,
                    double* __restrict__ tap_row, double* __restrict__ tap_bright, double* __restrict__ tap_chisq,
                    double* __restrict__ tap_parts) {
@@ -1145,7 +1163,7 @@ jx_tail_odd_kernel(JxDev c, const double* __restrict__ D2, int r, int ldb, const
     }
     const double chisq = jx_block_sum(part, red);
     if (tid == 0) {
-        const double ll = -chisq / 2.0;
+        const double ll = -chisq / 2.0 + (sz0 ? sz0[w] : 0.0);
         const double b = base[w];
         double tot = (b == -INFINITY) ? -INFINITY : b + ll;
         if (tot != tot) tot = -INFINITY;             // never hand NaN to the sampler
@@ -1176,7 +1194,7 @@ __global__ void __launch_bounds__(256)
 jx_operator_kernel(JxDev c, const double* __restrict__ pp /*[launch][N], written by jx_prep_kernel*/, int w0, int n,
                    const double* __restrict__ Gt /*[N+4][ldg], the last four rows zero*/, int ldg,
                    const double* __restrict__ rows_t /*[launch / 32][nrow][32] G pp from jx_operator_mfma_kernel; or null*/,
-                   const double* __restrict__ cfac, const double* __restrict__ base, double* __restrict__ logp,
+                   const double* __restrict__ cfac, const double* __restrict__ sz0, const double* __restrict__ base, double* __restrict__ logp,
                    double* __restrict__ tap_row, double* __restrict__ tap_bright, double* __restrict__ tap_chisq,
                    double* __restrict__ tap_parts) {
     JX_LDS_DECL;
@@ -1328,7 +1346,7 @@ jx_operator_kernel(JxDev c, const double* __restrict__ pp /*[launch][N], written
         double chisq = 0.0;
         for (int v = 0; v < nwv; ++v) chisq += s_part[v * WPB + tid];
         const int w = wb + tid;
-        const double ll = -chisq / 2.0;
+        const double ll = -chisq / 2.0 + (sz0 ? sz0[w] : 0.0);
         const double b = base_pre;
         double tot = (b == -INFINITY) ? -INFINITY : b + ll;
         if (tot != tot) tot = -INFINITY;                 // never hand NaN to the sampler

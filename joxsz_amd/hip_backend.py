@@ -10,7 +10,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('JOXSZ_LIB') or os.path.join(_HERE, 'csrc', 'libjoxsz_hip.so')    # JOXSZ_LIB: A/B builds
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # must list every function include/joxsz_hip.h declares (tests/test_abi.py checks this)
 EXPORTS = (
@@ -24,11 +24,11 @@ EXPORTS = (
 TENSORS = ('r_pp', 'd_mat', 'beam_2d', 'filtering', 'radius', 'flux_data', 'conv_T', 'conv_v',
            'par_vals', 'par_min', 'par_max', 'par_kind', 'par_mu', 'par_sigma', 'thawed_idx',
            'x_r_ne_kpc', 'x_r_T_kpc', 'projvols', 'cts', 'areascales', 'exposures', 'backrates',
-           'geomarea', 'lnT', 'lnrate')
+           'geomarea', 'lnT', 'lnrate', 'integ_w')
 _INT_TENSORS = ('par_kind', 'thawed_idx')
 _XRAY_FIRST = TENSORS.index('x_r_ne_kpc')
 
-STAGES = ('pp', 'ab', 'y', 'y_2d', 'conv_2d', 'map_row', 'bright', 'chisq', 'tprof', 'xprofs', 'parts')
+STAGES = ('pp', 'ab', 'y', 'y_2d', 'conv_2d', 'map_row', 'bright', 'chisq', 'tprof', 'xprofs', 'parts', 'integ')
 
 
 class JoxszHipError(RuntimeError):
@@ -39,8 +39,8 @@ class JxConfig(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
         'abi_version', 'S', 'N', 'B', 'nflux', 'nconv', 'nann', 'nband', 'ntab', 'npar', 'ndim',
         'ne_mode', 'exclude_unphy_mass', 'sz_only', 'device', 'max_batch', 'fft_pad', 'map_split',
-        'conv_mode', 'reserved0')] + \
-        [(n, ctypes.c_double) for n in ('step', 'kpc_as', 'm_e', 'sigma_T', 'kpc_cm')]
+        'conv_mode', 'dtype', 'calc_integ', 'reserved1')] + \
+        [(n, ctypes.c_double) for n in ('step', 'kpc_as', 'm_e', 'sigma_T', 'kpc_cm', 'integ_mu', 'integ_sig')]
 
 
 class JxTiming(ctypes.Structure):
@@ -110,7 +110,10 @@ CONV_MODES = {'auto': 0, 'rocfft': 1, 'custom': 2}
 ROUTES = {'map': 0, 'operator': 1}
 
 
-def config_from_problem(pb, device=0, max_batch=0, fft_pad=0, map_split=0, conv='auto'):
+DTYPES = {'f64': 0, 'f32': 1}
+
+
+def config_from_problem(pb, device=0, max_batch=0, fft_pad=0, map_split=0, conv='auto', dtype='f64'):
     cfg = JxConfig()
     cfg.abi_version = ABI_VERSION
     cfg.S, cfg.N, cfg.B = pb.S, pb.N, pb.B
@@ -125,6 +128,9 @@ def config_from_problem(pb, device=0, max_batch=0, fft_pad=0, map_split=0, conv=
     cfg.sz_only = int(bool(pb.sz_only))
     cfg.device, cfg.max_batch, cfg.fft_pad, cfg.map_split = device, max_batch, fft_pad, map_split
     cfg.conv_mode = CONV_MODES[conv]
+    cfg.dtype = DTYPES[dtype]
+    cfg.calc_integ = int(bool(getattr(pb, 'calc_integ', False)))
+    cfg.integ_mu, cfg.integ_sig = float(getattr(pb, 'integ_mu', 0.0)), float(getattr(pb, 'integ_sig', 1.0))
     cfg.step, cfg.kpc_as = float(pb.step), float(pb.kpc_as)
     cfg.m_e, cfg.sigma_T, cfg.kpc_cm = float(pb.m_e), float(pb.sigma_T), float(pb.kpc_cm)
     return cfg
@@ -133,22 +139,28 @@ def config_from_problem(pb, device=0, max_batch=0, fft_pad=0, map_split=0, conv=
 class HipContext:
     """Thin owner of one ``jx_ctx``: uploads a ``Problem`` and evaluates batches."""
 
-    def __init__(self, pb, device=0, max_batch=0, fft_pad=0, map_split=0, conv='auto', lib_path=None, route=None):
+    def __init__(self, pb, device=0, max_batch=0, fft_pad=0, map_split=0, conv='auto', lib_path=None, route=None, dtype='f64'):
         self._h = ctypes.c_void_p()
         self.lib = load_library(lib_path)
         pb.validate()
         self.pb = pb
         self.ndim = pb.ndim
-        cfg = config_from_problem(pb, device, max_batch, fft_pad, map_split, conv)
+        cfg = config_from_problem(pb, device, max_batch, fft_pad, map_split, conv, dtype)
+        self.dtype = dtype
         rc = self.lib.jx_create(ctypes.byref(cfg), ctypes.byref(self._h))
         if rc != 0:
             self._h = ctypes.c_void_p()
             raise JoxszHipError('jx_create: %s' % self.lib.jx_strerror(rc).decode())
         try:
             for tid, name in enumerate(TENSORS):
-                if pb.sz_only and tid >= _XRAY_FIRST:
+                if name == 'integ_w':
+                    if not getattr(pb, 'calc_integ', False):
+                        continue
+                    a = pb.integ_weights()
+                elif pb.sz_only and tid >= _XRAY_FIRST:
                     continue
-                a = pb.thawed_idx if name == 'thawed_idx' else getattr(pb, name)
+                else:
+                    a = pb.thawed_idx if name == 'thawed_idx' else getattr(pb, name)
                 a = np.ascontiguousarray(a, dtype=np.int32 if name in _INT_TENSORS else np.float64)
                 self._chk(self.lib.jx_upload(self._h, tid, a.ctypes.data_as(ctypes.c_void_p), a.nbytes),
                           'jx_upload(%s)' % name)
@@ -223,7 +235,7 @@ class HipContext:
         pb = self.pb
         shapes = {'pp': (W, pb.N), 'ab': (W, pb.N), 'y': (W, pb.N), 'y_2d': (W, pb.S, pb.S),
                   'conv_2d': (W, pb.S, pb.S), 'map_row': (W, self.nrow), 'bright': (W, self.nrow),
-                  'chisq': (W,), 'tprof': (W, self.nrow), 'xprofs': (W,) + tuple(pb.cts.shape), 'parts': (W, 4)}
+                  'chisq': (W,), 'tprof': (W, self.nrow), 'xprofs': (W,) + tuple(pb.cts.shape), 'parts': (W, 4), 'integ': (W,)}
         out = np.empty(shapes[stage], dtype=np.float64)
         dp = ctypes.POINTER(ctypes.c_double)
         self._chk(self.lib.jx_eval_stage(self._h, t.ctypes.data_as(dp), W, STAGES.index(stage),

@@ -19,10 +19,10 @@ from .hip_backend import HipContext
 
 
 class JoxszPosterior:
-    def __init__(self, problem, device=0, max_batch=0, fft_pad=0, map_split=0, conv='auto', route=None):
+    def __init__(self, problem, device=0, max_batch=0, fft_pad=0, map_split=0, conv='auto', route=None, dtype='f64'):
         self.problem = problem
         self.ctx = HipContext(problem, device=device, max_batch=max_batch, fft_pad=fft_pad, map_split=map_split,
-                              conv=conv, route=route)
+                              conv=conv, route=route, dtype=dtype)
         self.thawed = list(problem.thawed)                 # joxsz_main.py:179
         self.ndim = problem.ndim
         self.exclude_unphy_mass = bool(problem.exclude_unphy_mass)
@@ -75,8 +75,10 @@ class JoxszPosterior:
         if output == 'chisq':
             return float(self.ctx.eval_stage(th, 'chisq')[0])
         if output == 'll':
-            return -float(self.ctx.eval_stage(th, 'chisq')[0]) / 2
-        raise RuntimeError('Unrecognised output name (must be "ll", "chisq", "pp" or "bright")')
+            return float(self.ctx.eval_stage(th, 'parts')[0, 1])          # -chisq/2, minus the integrated-Compton term if enabled
+        if output == 'integ' and getattr(self.problem, 'calc_integ', False):
+            return float(self.ctx.eval_stage(th, 'integ')[0])
+        raise RuntimeError('Unrecognised output name (must be "ll", "chisq", "pp", "bright" or "integ")')
 
     def calcProfiles(self):
         """mbproj2 ``Fit.calcProfiles`` (joxsz_funcs.py:527): predicted counts

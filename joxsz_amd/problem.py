@@ -117,6 +117,9 @@ class Problem:
     ne_mode: str = 'single'
     exclude_unphy_mass: bool = True   # joxsz_main.py:88
     sz_only: bool = False             # build extension: skip the X-ray term (BASELINE configs[1])
+    calc_integ: bool = False          # SZ_data.calc_integ (joxsz_main.py:65): integrated-Compton term, joxsz_funcs.py:480-484
+    integ_mu: float = .94 / 1e3       # joxsz_main.py:66
+    integ_sig: float = .36 / 1e3      # joxsz_main.py:67
     meta: dict = field(default_factory=dict)
 
     # ---- derived sizes ----
@@ -155,6 +158,18 @@ class Problem:
         """mbproj2 ``Fit.thawedParVals`` (used at joxsz_funcs.py:555,585)."""
         return self.par_vals[self.thawed_idx].copy()
 
+    def integ_weights(self):
+        """w [N+1] with  cint = sum_j w_j v_j,  v = [f(0), y_0 .. y_{N-1}]: joxsz_funcs.py:481-483 is Simpson's rule over
+        the arcmin grid x = arange(0, r_pp[-1]/kpc_as/60 + step/60, step/60) of the integrand v x, times 2 pi -- a fixed
+        linear functional of v.  The rule is scipy's (``simps`` of the reference = ``scipy.integrate.simpson`` today),
+        applied here to the unit vectors, so whatever it does for an even number of samples is reproduced."""
+        from scipy.integrate import simpson
+        x = np.arange(0., self.r_pp[-1] / self.kpc_as / 60 + self.step / 60, self.step / 60)
+        if x.size != self.N + 1:
+            raise ValueError('calc_integ: the arcmin grid of joxsz_funcs.py:482 has %d points for %d samples '
+                             '(r_pp must be step*kpc_as*(1..N))' % (x.size, self.N + 1))
+        return 2 * np.pi * x * simpson(np.eye(x.size), x=x, axis=1)
+
     def validate(self):
         S = self.S
         assert self.d_mat.shape == (S, S) and self.filtering.shape == (S, S)
@@ -180,7 +195,8 @@ class Problem:
                'par_vals', 'par_min', 'par_max', 'par_frozen', 'par_kind', 'par_mu', 'par_sigma',
                'x_r_ne_kpc', 'x_r_T_kpc', 'projvols', 'cts', 'areascales', 'exposures', 'backrates',
                'geomarea', 'lnT', 'lnrate')
-    _SCALARS = ('step', 'kpc_as', 'm_e', 'sigma_T', 'kpc_cm', 'ne_mode', 'exclude_unphy_mass', 'sz_only')
+    _SCALARS = ('step', 'kpc_as', 'm_e', 'sigma_T', 'kpc_cm', 'ne_mode', 'exclude_unphy_mass', 'sz_only',
+                'calc_integ', 'integ_mu', 'integ_sig')
 
     def to_dict(self, prefix='pb_'):
         d = {prefix + k: np.asarray(getattr(self, k)) for k in self._ARRAYS}
@@ -199,6 +215,9 @@ class Problem:
         kw['ne_mode'] = str(d[prefix + 'ne_mode'])
         kw['exclude_unphy_mass'] = bool(d[prefix + 'exclude_unphy_mass'])
         kw['sz_only'] = bool(d[prefix + 'sz_only'])
+        if prefix + 'calc_integ' in d:                      # (fixtures written before the branch existed lack these)
+            kw['calc_integ'] = bool(d[prefix + 'calc_integ'])
+            kw['integ_mu'], kw['integ_sig'] = float(d[prefix + 'integ_mu']), float(d[prefix + 'integ_sig'])
         kw['par_names'] = [n.decode('utf-8') for n in d[prefix + 'par_names']]
         return cls(**kw)
 

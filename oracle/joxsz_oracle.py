@@ -19,6 +19,7 @@ from scipy.interpolate import interp1d
 from scipy.signal import fftconvolve
 from scipy.fftpack import fft2, ifft2
 from scipy.stats import norm
+from scipy.integrate import simpson
 from scipy import optimize
 
 from . import pyabel_direct
@@ -243,14 +244,23 @@ def sz_stages(pb, p, abel=None):
     out['flux_model'] = model
     chisq = np.nansum(((pb.flux_data[1] - model) / pb.flux_data[2]) ** 2)   # funcs:478
     out['chisq'] = float(chisq)
-    out['ll'] = float(-chisq / 2)                    # funcs:479
+    log_lik = -chisq / 2                             # funcs:479
+    if getattr(pb, 'calc_integ', False):             # funcs:480-484 (`simps` is today's scipy.integrate.simpson)
+        y = out['y']
+        f = interp1d(np.append(-r_pp, r_pp), np.append(y, y), 'cubic', bounds_error=False, fill_value=(0., 0.))
+        xs = np.arange(0., r_pp[-1] / pb.kpc_as / 60 + pb.step / 60, pb.step / 60)
+        cint = simpson(np.concatenate((f(0.), y), axis=None) * xs, xs) * 2 * np.pi
+        new_chi = np.nansum(((cint - pb.integ_mu) / pb.integ_sig) ** 2)
+        log_lik -= new_chi / 2
+        out['integ'] = float(cint)
+    out['ll'] = float(log_lik)
     return out
 
 
 def get_sz_like(pb, p, output='ll', abel=None):
-    """funcs:439-493 (``calc_integ`` branch, funcs:480-487, out of scope)."""
+    """funcs:439-493."""
     st = sz_stages(pb, p, abel=abel)
-    if output in ('pp', 'bright', 'chisq', 'll'):
+    if output in ('pp', 'bright', 'chisq', 'll') or (output == 'integ' and 'integ' in st):
         return st[output]
     raise RuntimeError('Unrecognised output name')
 

@@ -185,7 +185,7 @@ def build_ref_fit(ref, mb, pb):
 
     convert = interp1d(pb.conv_T, pb.conv_v, 'linear', fill_value='extrapolate')       # joxsz_main.py:109
     sz = ref.SZ_data([pb.m_e, pb.sigma_T], pb.step, pb.kpc_as, convert, pb.flux_data, pb.beam_2d,
-                     pb.radius, pb.S // 2, pb.r_pp, pb.d_mat, pb.filtering)
+                     pb.radius, pb.S // 2, pb.r_pp, pb.d_mat, pb.filtering, pb.calc_integ, pb.integ_mu, pb.integ_sig)
 
     fit = _Bag()
     fit.pars = pars
@@ -260,6 +260,8 @@ def run_case(ref, mb, pb, tag, with_stages=True):
     thetas = theta_cases(pb)
     rec = dict(thetas=thetas)
     outs = {k: [] for k in ('logp', 'pp', 'dpp', 'ne', 'tsz', 'mass', 'bright', 'chisq', 'll', 'xlike', 'densprior')}
+    if pb.calc_integ:
+        outs['integ'] = []
     for th in thetas:
         outs['logp'].append(fit.getLikelihood(th))                    # also updates fit.pars (funcs:515-516)
         P = fit.pars
@@ -271,6 +273,8 @@ def run_case(ref, mb, pb, tag, with_stages=True):
         outs['bright'].append(fit.get_sz_like(output='bright'))
         outs['chisq'].append(fit.get_sz_like(output='chisq'))
         outs['ll'].append(fit.get_sz_like(output='ll'))
+        if pb.calc_integ:
+            outs['integ'].append(fit.get_sz_like(output='integ'))          # funcs:481-487
         profs = fit.calcProfiles()
         outs['xlike'].append(fit.mylikeFromProfs(profs) if np.array(profs).min() > 0 else -np.inf)
         outs['densprior'].append(fit.model.ne_cmpt.prior(P))
@@ -283,10 +287,44 @@ def run_case(ref, mb, pb, tag, with_stages=True):
     print('  wrote', path, os.path.getsize(path) // 1024, 'KiB')
 
 
+def tiny_problem(ref, kpc_as):
+    """Tiny shape: Gaussian beam / normal-cdf transfer function branches (funcs:69-71, 100-101)."""
+    S, N = 31, 40
+    step_t = 6.
+    flux_r = np.array([3., 14., 29., 44.])
+    beam_t, _ = ref.mybeam(step_t, 0., approx=True, normalize=True, fwhm_beam=8.5)   # |rad|<=25.5 -> B=9
+    radius_t = step_t * (np.arange(S) - S // 2)
+    d_mat_t = ref.centdistmat(radius_t * kpc_as)
+    wn_t = np.linspace(0., 0.4967, 76)
+    tf_t = 0.95 * __import__('scipy.stats').stats.norm.cdf(wn_t, 0., 0.02)
+    filt_t = ref.filt_image(wn_t, tf_t, S, step_t)
+    syn = datasets.synthetic_problem(S=S, N=N, step=step_t, fwhm=8.5)
+    syn.flux_data = np.vstack((flux_r, [-1.1, -0.9, -0.5, -0.2], [0.1, 0.08, 0.07, 0.06]))
+    syn.beam_2d, syn.radius, syn.d_mat, syn.filtering = beam_t, radius_t, d_mat_t, filt_t
+    syn.cts = syn.cts.copy(); syn.cts[2, 3] = np.nan; syn.cts[5, 0] = np.nan      # missing data (funcs:504)
+    syn.validate()
+    assert syn.B == 9
+    return syn
+
+
 def main():
     mb = install_standins()
     sys.path.insert(0, REF)
     import joxsz_funcs as ref                                         # the reference module itself
+
+    if '--only-integ' in sys.argv:
+        # the calc_integ branch (funcs:480-487, off by default at joxsz_main.py:65) on the tiny shape and on an even count
+        # of Simpson samples (N = 41 -> 42 samples): a separate fixture, the older ones stay byte for byte
+        syn = tiny_problem(ref, datasets.KPC_AS_CLJ1226)
+        syn.calc_integ, syn.integ_mu, syn.integ_sig = True, 2.0e-5, 0.6e-5
+        run_case(ref, mb, syn, 'tiny_integ')
+        syn2 = datasets.synthetic_problem(S=31, N=41, step=6., fwhm=8.5)
+        syn2.flux_data = syn.flux_data
+        syn2.beam_2d, syn2.radius, syn2.d_mat, syn2.filtering = syn.beam_2d, syn.radius, syn.d_mat, syn.filtering
+        syn2.calc_integ, syn2.integ_mu, syn2.integ_sig = True, 2.0e-5, 0.6e-5
+        syn2.validate()
+        run_case(ref, mb, syn2, 'tiny_integ_even')
+        return
 
     # ---- bundled shape: every setup tensor through the reference's own setup functions ----
     d = os.path.join(REF, 'data')
@@ -324,21 +362,7 @@ def main():
                                      for b in datasets.BAND_EDGES_EV]))
 
     # ---- tiny shape: Gaussian beam / normal-cdf transfer function branches (funcs:69-71, 100-101) ----
-    S, N = 31, 40
-    step_t = 6.
-    flux_r = np.array([3., 14., 29., 44.])
-    beam_t, _ = ref.mybeam(step_t, 0., approx=True, normalize=True, fwhm_beam=8.5)   # |rad|<=25.5 -> B=9
-    radius_t = step_t * (np.arange(S) - S // 2)
-    d_mat_t = ref.centdistmat(radius_t * kpc_as)
-    wn_t = np.linspace(0., 0.4967, 76)
-    tf_t = 0.95 * __import__('scipy.stats').stats.norm.cdf(wn_t, 0., 0.02)
-    filt_t = ref.filt_image(wn_t, tf_t, S, step_t)
-    syn = datasets.synthetic_problem(S=S, N=N, step=step_t, fwhm=8.5)
-    syn.flux_data = np.vstack((flux_r, [-1.1, -0.9, -0.5, -0.2], [0.1, 0.08, 0.07, 0.06]))
-    syn.beam_2d, syn.radius, syn.d_mat, syn.filtering = beam_t, radius_t, d_mat_t, filt_t
-    syn.cts = syn.cts.copy(); syn.cts[2, 3] = np.nan; syn.cts[5, 0] = np.nan      # missing data (funcs:504)
-    syn.validate()
-    assert syn.B == 9
+    syn = tiny_problem(ref, kpc_as)
     run_case(ref, mb, syn, 'tiny')
 
 

@@ -37,3 +37,9 @@ def golden_tiny():
 @pytest.fixture(scope='session')
 def golden_bundled():
     return load_golden('bundled')
+
+
+@pytest.fixture(scope='session', params=['tiny_integ', 'tiny_integ_even'])
+def golden_integ(request):
+    """The reference run with calc_integ = True (joxsz_funcs.py:480-487): odd and even numbers of Simpson samples."""
+    return load_golden(request.param)

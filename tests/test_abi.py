@@ -36,9 +36,9 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_config_struct_layout():
-    # 20 int32 then 5 doubles, no implicit padding (the header keeps the doubles 8-byte aligned)
-    assert ctypes.sizeof(hip_backend.JxConfig) == 20 * 4 + 5 * 8
-    assert hip_backend.JxConfig.step.offset == 80
+    # 22 int32 then 7 doubles, no implicit padding (the header keeps the doubles 8-byte aligned)
+    assert ctypes.sizeof(hip_backend.JxConfig) == 22 * 4 + 7 * 8
+    assert hip_backend.JxConfig.step.offset == 88
     assert ctypes.sizeof(hip_backend.JxTiming) == 6 * 8 + 2 * 8 + 8
 
 

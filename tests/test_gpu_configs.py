@@ -186,7 +186,7 @@ def test_c_abi_error_codes():
 
     def upload_all(h, skip=()):
         for tid, name in enumerate(hb.TENSORS):
-            if name in skip:
+            if name in skip or name == 'integ_w':               # (calc_integ is off: that tensor is not wanted)
                 continue
             a = pb.thawed_idx if name == 'thawed_idx' else getattr(pb, name)
             a = np.ascontiguousarray(a, dtype=np.int32 if name in ('par_kind', 'thawed_idx') else np.float64)
@@ -248,3 +248,75 @@ def test_c_abi_error_codes():
     assert lib.jx_upload(h, 0, bad.ctypes.data_as(vp), bad.nbytes) == 0
     assert lib.jx_finalize(h) == INVALID
     lib.jx_destroy(h)
+
+
+def test_calc_integ_branch_on_the_gpu(golden_integ):
+    """The integrated-Compton term (joxsz_funcs.py:480-487, SZ_data.calc_integ) against the reference's own run of it:
+    'integ' output, 'll' with the extra chi^2 term, the total; both routes."""
+    pb, ref = golden_integ
+    th = ref['thetas']
+    fin = np.isfinite(ref['ref_logp'])
+    post = _post(pb)
+    got = post.log_prob(th)
+    integ = post.stage(th, 'integ')
+    parts = post.stage(th, 'parts')
+    assert np.array_equal(np.isfinite(got), fin)
+    np.testing.assert_allclose(got[fin], ref['ref_logp'][fin], rtol=1e-9)
+    np.testing.assert_allclose(integ[fin], ref['ref_integ'][fin], rtol=1e-11)
+    np.testing.assert_allclose(parts[fin, 1], ref['ref_ll'][fin], rtol=1e-8)
+    post.updateThawed(th[1])
+    np.testing.assert_allclose(post.get_sz_like('integ'), ref['ref_integ'][1], rtol=1e-11)
+    np.testing.assert_allclose(post.get_sz_like('ll'), ref['ref_ll'][1], rtol=1e-8)
+    post.ctx.set_route('operator')
+    got_op = post.log_prob(th)
+    post.close()
+    assert np.array_equal(np.isfinite(got_op), fin)
+    np.testing.assert_allclose(got_op[fin], ref['ref_logp'][fin], rtol=1e-9)
+    # without the switch the same problem gives the plain chi^2 likelihood
+    import copy
+    pb0 = copy.deepcopy(pb)
+    pb0.calc_integ = False
+    p0 = _post(pb0)
+    ll0 = p0.stage(th, 'parts')[:, 1]
+    p0.close()
+    assert np.all(np.abs(ll0[fin] - parts[fin, 1]) > 1e-6)
+
+
+def test_loader_tensors_through_the_hip_path(golden_bundled):
+    """The setup layer (joxsz_amd/setup_host.py + datasets.py) builds the problem tensors from the parsed
+    bundled data files alone (tests/golden/bundled_inputs.npz); the HIP path on THOSE tensors reproduces the reference's
+    log-posteriors, which it computed on tensors from its own setup functions (joxsz_funcs.py:16-134)."""
+    import os
+    from joxsz_amd import setup_host as sh, datasets
+    from joxsz_amd.problem import Problem
+    ref_pb, ref = golden_bundled
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'bundled_inputs.npz'))
+    step, kpc_as, R_b = 2., datasets.KPC_AS_CLJ1226, 5000.
+    flux_data = z['flux_data']
+    prof = sh.clip_beam_profile(z['beam_r'], z['beam_prof'])
+    beam_2d, fwhm = sh.beam_image(step, flux_data[0][-1], approx=False, profile=prof)
+    radius, sep, r_pp = sh.sz_axes(step, kpc_as, flux_data[0][-1], fwhm, R_b)
+    d_mat = sh.pixel_radius_matrix(radius * kpc_as)
+    wn, tf = sh.transfer_function(z['wn_as'], z['tf'], approx=False)
+    filtering = sh.filter_image(wn, tf, d_mat.shape[0], step)
+    geo = sh.annuli_geometry(z['edges_arcmin'], kpc_as)
+    bands = [sh.band_from_profiles(f, b) for f, b in zip(z['fg'], z['bg'])]
+    kw = {k: getattr(ref_pb, k) for k in Problem._ARRAYS + Problem._SCALARS}
+    kw.update(par_names=ref_pb.par_names, flux_data=flux_data, beam_2d=beam_2d, radius=radius, r_pp=r_pp, d_mat=d_mat,
+              filtering=filtering, conv_T=z['conv_T'], conv_v=1e3 * z['conv_jy'],
+              x_r_ne_kpc=geo['midpt_kpc'].copy(), x_r_T_kpc=geo['midpt_kpc'].copy(), projvols=geo['projvols'],
+              geomarea=geo['geomarea'], cts=np.array([b['cts'] for b in bands]),
+              areascales=np.array([b['areascales'] for b in bands]), exposures=np.array([b['exposures'] for b in bands]),
+              backrates=np.array([b['backrates'] for b in bands]))
+    pb = Problem(**kw).validate()
+    assert pb.S == ref_pb.S == 171 and pb.N == ref_pb.N and pb.B == ref_pb.B
+    post = _post(pb)
+    assert post.ctx.conv == 'custom'
+    got = post.log_prob(ref['thetas'])
+    bright = post.stage(ref['thetas'][:3], 'bright')
+    post.close()
+    want = ref['ref_logp']
+    fin = np.isfinite(want)
+    assert np.array_equal(np.isfinite(got), fin)
+    np.testing.assert_allclose(got[fin], want[fin], rtol=1e-9)
+    np.testing.assert_allclose(bright, ref['ref_bright'][:3], rtol=1e-8, atol=1e-12 * np.abs(ref['ref_bright'][:3]).max())

@@ -50,3 +50,24 @@ def test_xray_like(golden):
         p = orc.pars_dict(pb, ref['thetas'][k])
         profs = orc.calc_profiles(pb, p)
         np.testing.assert_allclose(orc.like_from_profs(pb, profs), ref['ref_xlike'][k], rtol=1e-12)
+
+
+def test_calc_integ_branch(golden_integ):
+    """joxsz_funcs.py:480-487 executed by the reference (integrated Compton parameter, its chi^2 term inside 'll' and the
+    total), and the linear-functional form of it that the HIP library uploads (``Problem.integ_weights``)."""
+    from scipy.interpolate import interp1d
+    pb, ref = golden_integ
+    assert pb.calc_integ and 'ref_integ' in ref
+    got = orc.log_posterior_batch(pb, ref['thetas'])
+    fin = np.isfinite(ref['ref_logp'])
+    assert np.array_equal(np.isfinite(got), fin)
+    np.testing.assert_allclose(got[fin], ref['ref_logp'][fin], rtol=1e-11)
+    w = pb.integ_weights()
+    for k, th in enumerate(ref['thetas']):
+        st = orc.sz_stages(pb, orc.pars_dict(pb, th))
+        np.testing.assert_allclose(st['integ'], ref['ref_integ'][k], rtol=1e-12)
+        np.testing.assert_allclose(st['ll'], ref['ref_ll'][k], rtol=1e-10)
+        assert abs(st['ll'] + st['chisq'] / 2) > 1e-3                            # the extra term is there
+        y = st['y']
+        f0 = interp1d(np.append(-pb.r_pp, pb.r_pp), np.append(y, y), 'cubic')(0.)
+        np.testing.assert_allclose(w @ np.append(f0, y), st['integ'], rtol=1e-12)
