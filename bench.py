@@ -10,7 +10,10 @@ per walker).  Workload at N=1: BASELINE.json configs[2] -- 1024 walkers, S=512,
 N=500, joint likelihood, synthetic CL J1226.9+3332-shaped inputs, parameter
 vectors already resident in HBM when the timed region starts.  For N>1 every
 rank evaluates its own 1024 walkers (weak scaling, walkers are independent) and
-the log-probabilities are all-gathered over RCCL inside the timed region.
+the log-probabilities are all-gathered over RCCL inside the timed region --
+through the library's own C-ABI (jx_comm_*, jx_allgather_logp): this program
+imports no torch; the launcher (torch.distributed.run) only sets RANK /
+LOCAL_RANK / WORLD_SIZE / MASTER_PORT.
 
 Prints ONE JSON line (rank 0) with
   `roofline`       the time-dominant kernel of the step on the bytes it must move (HIP-event duration on the library's
@@ -155,7 +158,7 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
-            raise SystemExit('--gpus %d needs a torch.distributed.run launch with that many ranks' % args.gpus)
+            raise SystemExit('--gpus %d needs a launcher that starts that many ranks (torch.distributed.run sets RANK/WORLD_SIZE/LOCAL_RANK)' % args.gpus)
         args.gpus = world
 
     from joxsz_amd import datasets
@@ -170,22 +173,7 @@ def main():
         # the data the walkers are scored against do not change the cost; use the placeholder data
         cpu, cpu_sample, cpu_logp = cpu_baseline(pb, th_cpu, args.cpu_seconds)
 
-    dist = None
-    torch = None
-    if args.gpus > 1 or os.environ.get('JOXSZ_BENCH_FORCE_DIST'):      # the env switch rehearses the N>1 plumbing at N=1
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29511')
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', rank=rank, world_size=world,
-                                device_id=torch.device('cuda', local_rank))
-        # an explicit stream for the whole run: the library is handed this stream (jx_set_stream) and RCCL orders its
-        # collectives against torch's CURRENT stream, so evaluation and gather are ordered without a host wait.  (torch's
-        # default stream has handle 0, which jx_set_stream reads as "back to the library's own stream".)
-        bench_stream = torch.cuda.Stream(device=local_rank)
-        torch.cuda.set_stream(bench_stream)
-
+    multi = args.gpus > 1 or bool(os.environ.get('JOXSZ_BENCH_FORCE_DIST'))      # the env switch rehearses the N>1 plumbing at N=1
     from joxsz_amd.posterior import JoxszPosterior
     post = JoxszPosterior(pb, device=local_rank)
     ctx = post.ctx
@@ -224,31 +212,26 @@ def main():
     theta = np.ascontiguousarray(good[:W])
 
     # ---- device-resident inputs ----
-    if torch is not None:
-        th_t = torch.from_numpy(theta).cuda()
-        lp_t = torch.empty(W, dtype=torch.float64, device='cuda')
-        all_t = torch.empty(W * world, dtype=torch.float64, device='cuda')
-        th_ptr, lp_ptr = th_t.data_ptr(), lp_t.data_ptr()
-    else:
-        th_ptr = ctx.dev_alloc(theta.nbytes)
-        lp_ptr = ctx.dev_alloc(8 * W)
-        ctx.h2d(th_ptr, theta)
-
-    if torch is not None:
-        # the library enqueues on torch's current stream: RCCL orders the gather behind the evaluation by itself and
-        # the host never waits inside a step
-        assert torch.cuda.current_stream().cuda_stream == bench_stream.cuda_stream != 0
-        ctx.set_stream(bench_stream.cuda_stream)
+    th_ptr = ctx.dev_alloc(theta.nbytes)
+    lp_ptr = ctx.dev_alloc(8 * W)
+    ctx.h2d(th_ptr, theta)
+    comm = None
+    all_ptr = None
+    if multi:
+        # RCCL through the library's own C-ABI (jx_comm_*): the gather is enqueued on the context's stream behind the
+        # evaluation, the host never waits inside a step, no torch in this process
+        from joxsz_amd.dist import RcclGather
+        comm = RcclGather(ctx, rank=rank, world=world)
+        all_ptr = ctx.dev_alloc(8 * W * world)
 
     def step():
         ctx.eval_device(th_ptr, W, lp_ptr)
-        if dist is not None:
-            dist.all_gather_into_tensor(all_t, lp_t)
+        if comm is not None:
+            comm.all_gather(lp_ptr, all_ptr, W)
 
     def fence():
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
+        if comm is not None:
+            comm.barrier()
         ctx.sync()
 
     for _ in range(args.warmup):
@@ -265,11 +248,10 @@ def main():
     tm = ctx.timing()
     ctx.timing_enable(False)
 
-    if dist is not None:
-        e = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-        dist.all_reduce(e, op=dist.ReduceOp.MAX)
-        elapsed = float(e.item())
-        final = all_t.cpu().numpy()
+    if comm is not None:
+        elapsed = comm.max_over_ranks(elapsed)
+        final = np.empty(W * world)
+        ctx.d2h(final, all_ptr)
     else:
         final = np.empty(W)
         ctx.d2h(final, lp_ptr)
@@ -278,7 +260,7 @@ def main():
 
     # the same batch on the collapsed route, outside the timed region of the metric: reported beside it
     also = None
-    if dist is None and args.route == 'map':
+    if comm is None and args.route == 'map':
         try:
             lp_map = final
             ctx.set_route('operator')
@@ -306,7 +288,7 @@ def main():
     # the kernel that meets north_star's "Abel+map kernel at >= 60 % of the HBM roofline": the same fused kernel storing the
     # reference's full S x S map (JOXSZ_FULL_MAP=1), measured beside the metric (the default route never stores a map)
     full_map = None
-    if rank == 0 and dist is None and args.route == 'map' and not args.no_full_map:
+    if rank == 0 and comm is None and args.route == 'map' and not args.no_full_map:
         try:
             os.environ['JOXSZ_FULL_MAP'] = '1'
             p2 = JoxszPosterior(pb, device=local_rank)
@@ -403,9 +385,9 @@ def main():
             'operator_route': also,
         }
         print(json.dumps(out))
+    if comm is not None:
+        comm.close()
     post.close()
-    if dist is not None:
-        dist.destroy_process_group()
 
 
 if __name__ == '__main__':

@@ -43,7 +43,8 @@ typedef enum jx_status {
     JX_ERR_ROCFFT = -5,       /* rocFFT error                                 */
     JX_ERR_NOMEM = -6,        /* host or device allocation failed             */
     JX_ERR_NODEVICE = -7,     /* no usable gfx950 device                      */
-    JX_ERR_UNSUPPORTED = -8   /* size outside what the kernels support        */
+    JX_ERR_UNSUPPORTED = -8,  /* size outside what the kernels support        */
+    JX_ERR_COMM = -9          /* RCCL error or library not loadable (jx_last_error has detail) */
 } jx_status;
 
 /* Sizes and scalars of one problem: the shapes of SZ_data (joxsz_funcs.py:157-170)
@@ -204,6 +205,24 @@ int  jx_dev_alloc(jx_ctx* ctx, size_t nbytes, void** dev_out);
 int  jx_dev_free(jx_ctx* ctx, void* dev);
 int  jx_memcpy_h2d(jx_ctx* ctx, void* dev, const void* host, size_t nbytes);
 int  jx_memcpy_d2h(jx_ctx* ctx, void* host, const void* dev, size_t nbytes);
+
+/* ---- multi-GPU: one process and one context per device, walkers sharded with no data-path collective; the only exchange
+ * is the all-gather of the log-probabilities (RCCL over xGMI), enqueued on the context's stream behind the evaluation.
+ * The reference's counterpart is multiprocessing.Pool handed to emcee (joxsz_main.py:203-208).
+ *   jx_comm_unique_id   rank 0 creates the 128-byte id (ncclGetUniqueId) and hands it to the other ranks by any means
+ *                       (joxsz_amd/dist.py: a file under the launcher's run directory; the C-ABI does not care);
+ *   jx_comm_init_rank   every rank, collectively (ncclCommInitRank on the context's device);
+ *   jx_allgather_logp   recv_dev[rank * count .. ] <- send_dev[0 .. count) of every rank (float64), asynchronous on the
+ *                       context's stream like jx_eval_device; send and receive buffers are device memory;
+ *   jx_comm_allreduce_max  in-place maximum over the ranks of `count` float64 on the device (timing, barriers);
+ *   jx_comm_destroy     collective teardown (jx_destroy does it too).
+ * librccl is loaded when the first of these is called, not before: single-GPU use never touches it. */
+#define JX_COMM_ID_BYTES 128
+int  jx_comm_unique_id(void* id_out /* JX_COMM_ID_BYTES */);
+int  jx_comm_init_rank(jx_ctx* ctx, const void* id /* JX_COMM_ID_BYTES */, int nranks, int rank);
+int  jx_allgather_logp(jx_ctx* ctx, const double* send_dev, double* recv_dev, int count);
+int  jx_comm_allreduce_max(jx_ctx* ctx, double* inout_dev, int count);
+int  jx_comm_destroy(jx_ctx* ctx);
 
 int  jx_timing_reset(jx_ctx* ctx);
 int  jx_timing_enable(jx_ctx* ctx, int on);

@@ -2,6 +2,8 @@
 // building, rocFFT plans and the per-chunk launch sequence.
 #include <hip/hip_runtime.h>
 #include <rocfft/rocfft.h>
+#include <rccl/rccl.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -125,6 +127,9 @@ struct jx_ctx {
     double* d_rows = nullptr;          // [op_cap / 32][nrow][32] G pp of large launches (jx_operator_mfma_kernel)
     int op_cap = 0;                    // walkers per launch on the operator route
     int g_ld = 0;
+
+    ncclComm_t comm = nullptr;        // RCCL communicator of this rank (jx_comm_init_rank)
+    int comm_rank = 0, comm_size = 1;
 
     std::map<int, Plan3> plans;
     rocfft_execution_info info = nullptr;
@@ -289,7 +294,91 @@ static void plan_odd(const jx_config& c, const std::vector<double>& beam, const 
     pl.ok = true;
 }
 
+// librccl, loaded on first use (dlopen): the functions of the all-gather path only
+namespace {
+struct RcclApi {
+    void* h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string err;
+};
+RcclApi g_rccl;
+
+bool rccl_load() {
+    if (g_rccl.h) return true;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        g_rccl.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (g_rccl.h) break;
+    }
+    if (!g_rccl.h) { g_rccl.err = std::string("dlopen(librccl): ") + (dlerror() ? dlerror() : "?"); return false; }
+#define JX_SYM(field, sym) *(void**)(&g_rccl.field) = dlsym(g_rccl.h, sym); if (!g_rccl.field) { g_rccl.err = std::string("librccl lacks ") + sym; g_rccl.h = nullptr; return false; }
+    JX_SYM(GetUniqueId, "ncclGetUniqueId") JX_SYM(CommInitRank, "ncclCommInitRank") JX_SYM(AllGather, "ncclAllGather")
+    JX_SYM(AllReduce, "ncclAllReduce") JX_SYM(CommDestroy, "ncclCommDestroy") JX_SYM(GetErrorString, "ncclGetErrorString")
+#undef JX_SYM
+    return true;
+}
+}  // namespace
+
+#define NCCLCHK(ctx, call)                                                                         \
+    do {                                                                                           \
+        ncclResult_t r_ = (call);                                                                  \
+        if (r_ != ncclSuccess) {                                                                   \
+            (ctx)->err = std::string(#call) + ": " + g_rccl.GetErrorString(r_);                    \
+            return JX_ERR_COMM;                                                                    \
+        }                                                                                          \
+    } while (0)
+
 extern "C" {
+
+int jx_comm_unique_id(void* id_out) {
+    if (!id_out) return JX_ERR_INVALID;
+    if (!rccl_load()) return JX_ERR_COMM;
+    ncclUniqueId id;
+    if (g_rccl.GetUniqueId(&id) != ncclSuccess) return JX_ERR_COMM;
+    static_assert(sizeof(id) == JX_COMM_ID_BYTES, "id size");
+    memcpy(id_out, &id, sizeof(id));
+    return JX_OK;
+}
+
+int jx_comm_init_rank(jx_ctx* ctx, const void* idp, int nranks, int rank) {
+    if (!ctx || !idp || nranks < 1 || rank < 0 || rank >= nranks) return JX_ERR_INVALID;
+    if (ctx->comm) { ctx->err = "jx_comm_init_rank: this context already has a communicator"; return JX_ERR_STATE; }
+    if (!rccl_load()) { ctx->err = g_rccl.err; return JX_ERR_COMM; }
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    ncclUniqueId id;
+    memcpy(&id, idp, sizeof(id));
+    NCCLCHK(ctx, g_rccl.CommInitRank(&ctx->comm, nranks, id, rank));
+    ctx->comm_rank = rank; ctx->comm_size = nranks;
+    return JX_OK;
+}
+
+int jx_allgather_logp(jx_ctx* ctx, const double* send_dev, double* recv_dev, int count) {
+    if (!ctx || !send_dev || !recv_dev || count < 0) return JX_ERR_INVALID;
+    if (!ctx->comm) { ctx->err = "jx_allgather_logp before jx_comm_init_rank"; return JX_ERR_STATE; }
+    if (count == 0) return JX_OK;
+    NCCLCHK(ctx, g_rccl.AllGather(send_dev, recv_dev, (size_t)count, ncclDouble, ctx->comm, ctx->stream));
+    return JX_OK;
+}
+
+int jx_comm_allreduce_max(jx_ctx* ctx, double* inout_dev, int count) {
+    if (!ctx || !inout_dev || count < 1) return JX_ERR_INVALID;
+    if (!ctx->comm) { ctx->err = "jx_comm_allreduce_max before jx_comm_init_rank"; return JX_ERR_STATE; }
+    NCCLCHK(ctx, g_rccl.AllReduce(inout_dev, inout_dev, (size_t)count, ncclDouble, ncclMax, ctx->comm, ctx->stream));
+    return JX_OK;
+}
+
+int jx_comm_destroy(jx_ctx* ctx) {
+    if (!ctx) return JX_ERR_INVALID;
+    if (!ctx->comm) return JX_OK;
+    (void)hipStreamSynchronize(ctx->stream);
+    NCCLCHK(ctx, g_rccl.CommDestroy(ctx->comm));
+    ctx->comm = nullptr; ctx->comm_rank = 0; ctx->comm_size = 1;
+    return JX_OK;
+}
 
 const char* jx_strerror(int s) {
     switch (s) {
@@ -302,6 +391,7 @@ const char* jx_strerror(int s) {
         case JX_ERR_NOMEM: return "out of memory";
         case JX_ERR_NODEVICE: return "no usable HIP device";
         case JX_ERR_UNSUPPORTED: return "unsupported size";
+        case JX_ERR_COMM: return "RCCL error";
     }
     return "unknown status";
 }
@@ -1895,6 +1985,7 @@ void jx_destroy(jx_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->cfg.device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->comm) (void)jx_comm_destroy(ctx);
     for (auto& kv : ctx->plans) {
         if (kv.second.beam_fwd) rocfft_plan_destroy(kv.second.beam_fwd);
         if (kv.second.beam_inv) rocfft_plan_destroy(kv.second.beam_inv);

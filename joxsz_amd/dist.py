@@ -6,10 +6,99 @@ exchange step is an all-gather of the log-probabilities -- RCCL over xGMI with
 the ``nccl`` backend on GPUs, ``gloo`` on CPUs (tests).  The message is a few
 KiB per rank: latency-bound, no data-path collective besides it.
 
-``torch.distributed`` is used as plumbing only (rendezvous + the collective);
-it is imported lazily so that single-GPU use needs no torch at all.
+Two carriers of that one exchange:
+
+* ``RcclGather`` -- the GPU path: RCCL through the library's own C-ABI (``jx_comm_*``, ``jx_allgather_logp``), device
+  buffers, enqueued on the context's stream behind the evaluation.  No torch anywhere; the 128-byte RCCL id travels from
+  rank 0 to the others through a file (one node) -- ``exchange_unique_id``.
+* ``ShardedLogProb`` -- ``torch.distributed`` with the ``gloo`` backend, for the CPU tests of the sharding logic and for
+  ranks that share one device (RCCL refuses two ranks on one GPU).  torch is imported lazily, only there.
 """
+import os
+import time
+
 import numpy as np
+
+
+def launch_env():
+    """(rank, world, local_rank) from the environment ``torch.distributed.run`` / any MPI-style launcher sets."""
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', str(rank)))
+    return rank, world, local_rank
+
+
+def exchange_unique_id(make_id, rank, world, timeout=120.0):
+    """Rank 0 calls ``make_id()`` (``jx_comm_unique_id``) and publishes the 128 bytes; the others read them.
+    One node: a file under ``JOXSZ_RDZV_DIR`` (default /tmp) named after the launcher's pid and MASTER_PORT, written
+    atomically (rename).  The ranks of one launch share their parent process, so the name is unique per launch."""
+    if world == 1:
+        return make_id()
+    d = os.environ.get('JOXSZ_RDZV_DIR', '/tmp')
+    tag = os.environ.get('JOXSZ_RDZV_TAG') or '%s_%s_%d' % (os.environ.get('TORCHELASTIC_RUN_ID', 'run'),
+                                                            os.environ.get('MASTER_PORT', '0'), os.getppid())
+    path = os.path.join(d, 'joxsz_rccl_%s.id' % tag)
+    if rank == 0:
+        uid = make_id()
+        tmp = path + '.tmp%d' % os.getpid()
+        with open(tmp, 'wb') as f:
+            f.write(uid)
+        os.replace(tmp, path)
+        return uid
+    t0 = time.time()
+    while True:
+        try:
+            with open(path, 'rb') as f:
+                uid = f.read()
+            if len(uid) == 128:
+                return uid
+        except FileNotFoundError:
+            pass
+        if time.time() - t0 > timeout:
+            raise RuntimeError('rank %d: no RCCL id from rank 0 at %s after %.0f s' % (rank, path, timeout))
+        time.sleep(0.02)
+
+
+class RcclGather:
+    """All-gather of per-rank log-probabilities over RCCL, through the C-ABI of the HIP library (no torch).
+
+    ``ctx`` is this rank's ``HipContext`` (one per process, one process per GPU).  ``all_gather(send_ptr, recv_ptr, n)``
+    takes device pointers (``ctx.dev_alloc``) and is asynchronous on the context's stream, ordered behind
+    ``ctx.eval_device``; ``barrier()`` and ``max_over_ranks(x)`` serve the timing protocol of bench.py."""
+
+    def __init__(self, ctx, rank=None, world=None):
+        env_rank, env_world, _ = launch_env()
+        self.ctx = ctx
+        self.rank = env_rank if rank is None else rank
+        self.world = env_world if world is None else world
+        uid = exchange_unique_id(ctx.comm_unique_id, self.rank, self.world)
+        ctx.comm_init_rank(uid, self.world, self.rank)
+        self._scratch = ctx.dev_alloc(8)
+        if self.rank == 0 and self.world > 1:
+            try:                                              # everybody has read the id once the communicator exists
+                d = os.environ.get('JOXSZ_RDZV_DIR', '/tmp')
+                for f in os.listdir(d):
+                    if f.startswith('joxsz_rccl_') and f.endswith('_%d.id' % os.getppid()):
+                        os.unlink(os.path.join(d, f))
+            except OSError:
+                pass
+
+    def all_gather(self, send_ptr, recv_ptr, count):
+        self.ctx.allgather_logp(send_ptr, recv_ptr, count)
+
+    def max_over_ranks(self, value):
+        buf = np.array([float(value)])
+        self.ctx.h2d(self._scratch, buf)
+        self.ctx.comm_allreduce_max(self._scratch, 1)
+        self.ctx.sync()
+        self.ctx.d2h(buf, self._scratch)
+        return float(buf[0])
+
+    def barrier(self):
+        self.max_over_ranks(0.0)
+
+    def close(self):
+        self.ctx.comm_destroy()
 
 
 def shard_bounds(nwalkers, world, rank):

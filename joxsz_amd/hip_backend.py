@@ -19,6 +19,7 @@ EXPORTS = (
     'jx_set_par_vals', 'jx_dev_alloc', 'jx_dev_free', 'jx_memcpy_h2d', 'jx_memcpy_d2h',
     'jx_timing_reset', 'jx_timing_enable', 'jx_timing_get', 'jx_get_info', 'jx_get_conv_mode', 'jx_get_conv_layout', 'jx_debug_workspace', 'jx_device_count',
     'jx_device_name', 'jx_strerror', 'jx_last_error', 'jx_destroy',
+    'jx_comm_unique_id', 'jx_comm_init_rank', 'jx_allgather_logp', 'jx_comm_allreduce_max', 'jx_comm_destroy',
 )
 
 TENSORS = ('r_pp', 'd_mat', 'beam_2d', 'filtering', 'radius', 'flux_data', 'conv_T', 'conv_v',
@@ -89,6 +90,11 @@ def load_library(path=None):
     lib.jx_get_conv_mode.argtypes = [vp]
     lib.jx_get_conv_layout.argtypes = [vp, ctypes.POINTER(ctypes.c_int32)]
     lib.jx_debug_workspace.argtypes = [vp, ci, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int32)]
+    lib.jx_comm_unique_id.argtypes = [vp]
+    lib.jx_comm_init_rank.argtypes = [vp, vp, ci, ci]
+    lib.jx_allgather_logp.argtypes = [vp, vp, vp, ci]
+    lib.jx_comm_allreduce_max.argtypes = [vp, vp, ci]
+    lib.jx_comm_destroy.argtypes = [vp]
     lib.jx_device_count.argtypes = []
     lib.jx_device_name.argtypes = [vp]
     lib.jx_device_name.restype = ctypes.c_char_p
@@ -313,6 +319,27 @@ class HipContext:
 
     def sync(self):
         self._chk(self.lib.jx_sync(self._h), 'jx_sync')
+
+    # -- RCCL through the C-ABI (no torch): see joxsz_amd/dist.py::RcclGather --
+    def comm_unique_id(self):
+        buf = ctypes.create_string_buffer(128)
+        rc = self.lib.jx_comm_unique_id(buf)
+        if rc != 0:
+            raise JoxszHipError('jx_comm_unique_id failed: %s' % self.lib.jx_strerror(rc).decode())
+        return buf.raw
+
+    def comm_init_rank(self, uid, nranks, rank):
+        assert len(uid) == 128
+        self._chk(self.lib.jx_comm_init_rank(self._h, ctypes.c_char_p(uid), nranks, rank), 'jx_comm_init_rank')
+
+    def allgather_logp(self, send_ptr, recv_ptr, count):
+        self._chk(self.lib.jx_allgather_logp(self._h, ctypes.c_void_p(send_ptr), ctypes.c_void_p(recv_ptr), count), 'jx_allgather_logp')
+
+    def comm_allreduce_max(self, ptr, count=1):
+        self._chk(self.lib.jx_comm_allreduce_max(self._h, ctypes.c_void_p(ptr), count), 'jx_comm_allreduce_max')
+
+    def comm_destroy(self):
+        self._chk(self.lib.jx_comm_destroy(self._h), 'jx_comm_destroy')
 
     # -- timing --
     def timing_enable(self, on=True):
