@@ -4,6 +4,7 @@
 #include <rocfft/rocfft.h>
 #include <rccl/rccl.h>
 #include <dlfcn.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cmath>
@@ -351,7 +352,15 @@ int jx_comm_init_rank(jx_ctx* ctx, const void* idp, int nranks, int rank) {
     HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
     ncclUniqueId id;
     memcpy(&id, idp, sizeof(id));
-    NCCLCHK(ctx, g_rccl.CommInitRank(&ctx->comm, nranks, id, rank));
+    // RCCL prints a version banner on stdout when its first communicator comes up; a caller whose stdout is a protocol
+    // (bench.py: one JSON line) must not see it, so file descriptor 1 points at stderr for the duration of the call
+    fflush(stdout);
+    const int saved = dup(1);
+    if (saved >= 0) dup2(2, 1);
+    const ncclResult_t r0 = g_rccl.CommInitRank(&ctx->comm, nranks, id, rank);
+    fflush(stdout);
+    if (saved >= 0) { dup2(saved, 1); close(saved); }
+    NCCLCHK(ctx, r0);
     ctx->comm_rank = rank; ctx->comm_size = nranks;
     return JX_OK;
 }
