@@ -151,6 +151,8 @@ def main():
     ap.add_argument('--route', choices=('map', 'operator'), default='map',
                     help="'map': the reference's sequence of steps per walker (the BASELINE metric); 'operator': the collapsed route (jx_set_route)")
     ap.add_argument('--fwhm', type=float, default=18.5, help='beam FWHM in arcsec (B = 2*floor(3*fwhm/step)+1)')
+    ap.add_argument('--dtype', choices=('f64', 'f32'), default='f64', help="'f64': the reference's arithmetic (the metric); 'f32': the fp32 variant")
+    ap.add_argument('--no-f32', action='store_true', help='skip the side measurement of the fp32 variant')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -198,7 +200,7 @@ def main():
     xprofs = None if pb.sz_only else ctx.eval_stage(t0w, 'xprofs')[0]
     post.close()
     datasets.fill_data(pb, bright, xprofs, seed=0)
-    post = JoxszPosterior(pb, device=local_rank)
+    post = JoxszPosterior(pb, device=local_rank, dtype=args.dtype)
     ctx = post.ctx
     if args.route != 'map':
         ctx.set_route(args.route)
@@ -285,6 +287,35 @@ def main():
             also = {'route': 'operator', 'error': str(exc)}
 
 
+    # the fp32 variant on the same walkers (BASELINE configs[4]'s tolerance sweep): beside the f64 metric, never instead of it
+    f32 = None
+    if rank == 0 and comm is None and args.route == 'map' and args.dtype == 'f64' and not args.no_f32:
+        try:
+            p3 = JoxszPosterior(pb, device=local_rank, dtype='f32')
+            c3 = p3.ctx
+            t3, l3 = c3.dev_alloc(theta.nbytes), c3.dev_alloc(8 * W)
+            c3.h2d(t3, theta)
+            for _ in range(args.warmup):
+                c3.eval_device(t3, W, l3)
+            c3.sync()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                c3.eval_device(t3, W, l3)
+            c3.sync()
+            dt = time.perf_counter() - t1
+            lp32 = np.empty(W)
+            c3.d2h(lp32, l3)
+            ch32, ch64 = c3.eval_stage(theta[:256], 'chisq'), ctx.eval_stage(theta[:256], 'chisq')
+            rel = np.abs(lp32 - final) / np.abs(final)
+            f32 = {'dtype': 'f32', 'value': W * args.steps / dt, 'unit': 'walker-likelihoods/s', 'ms_per_step': 1e3 * dt / args.steps,
+                   'rel_dlogp_vs_f64': {'max': float(rel.max()), 'median': float(np.median(rel))},
+                   'abs_dchisq_vs_f64': {'max': float(np.abs(ch32 - ch64).max()), 'median': float(np.median(np.abs(ch32 - ch64)))},
+                   'note': 'fp32 evaluation of the map rows + fp32 row transform + fp32 storage of row spectra and combined rows; '
+                           'matrix products, inverse transforms, tail and everything per-walker in fp64 (jx_config.dtype = 1)'}
+            p3.close()
+        except Exception as exc:
+            f32 = {'dtype': 'f32', 'error': str(exc)}
+
     # the kernel that meets north_star's "Abel+map kernel at >= 60 % of the HBM roofline": the same fused kernel storing the
     # reference's full S x S map (JOXSZ_FULL_MAP=1), measured beside the metric (the default route never stores a map)
     full_map = None
@@ -350,7 +381,7 @@ def main():
                       else 'walker-likelihoods/sec at %d^2 map, %d-pt grid' % (S, args.N),
             'value': value, 'unit': 'walker-likelihoods/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': ms_step, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': '%d walkers/GPU, %dx%d SZ map, %d-pt radial grid, %s likelihood, '
                                    'synthetic CL J1226.9+3332-shaped inputs%s'
                                    % (W, S, S, args.N, 'SZ-only' if pb.sz_only else 'joint X-ray+SZ',
@@ -377,6 +408,7 @@ def main():
                               'survey_8d_bytes_per_step': 2.0 * W * S * S * 8.0,
                               'time_dominant_kernel': dom_kernel},
             'north_star_abel_map_kernel': full_map,
+            'fp32_variant': f32,
             'cpu_baseline': cpu,
             'stage_ms_per_step': {k: tm[k] / args.steps for k in
                                   ('prep_ms', 'abel_map_ms', 'beam_fft_ms', 'tf_fft_ms', 'gemm_ms', 'tail_ms', 'total_ms')},

@@ -93,6 +93,7 @@ struct jx_ctx {
     double* d_cf = nullptr;           // [chunk][cf_ws] spline ordinates and moments, Abel kernel -> jx_rowdct_kernel
     size_t dct_lds = 0;
     // odd map sides (the reference's own shapes): the transfer-function step in real space, no transform of length S
+    bool f32 = false;                  // jx_config.dtype == 1: fp32 storage between the kernels, fp32 evaluation and pass-1 transform
     bool odd = false;
     JxDct dct3{};                      // combined rows back to real space (jx_rowdct_kernel, MODE 1)
     size_t dct3_lds = 0;
@@ -312,7 +313,7 @@ RcclApi g_rccl;
 bool rccl_load() {
     if (g_rccl.h) return true;
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-        g_rccl.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        g_rccl.h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
         if (g_rccl.h) break;
     }
     if (!g_rccl.h) { g_rccl.err = std::string("dlopen(librccl): ") + (dlerror() ? dlerror() : "?"); return false; }
@@ -1130,12 +1131,28 @@ int jx_finalize(jx_ctx* ctx) {
                 }
             }
         }
+        if (c.dtype == 1) {
+            const int ntr = (ctx->lrf.r + 15) / 16;
+            if (!ctx->dct_ok || ntr < 2) {
+                ctx->err = "dtype f32 is available on the default route of even map sides only (fused matrix products, rank >= 17)";
+                return JX_ERR_UNSUPPORTED;
+            }
+            ctx->f32 = true;
+#define JX_DCT_ATTR(LPv, NSv, NTv) if (cv.LP == LPv && cv.LS == NSv) \
+            HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_rowdct_kernel<LPv, NSv, 16, NTv, 0, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->dct_lds));
+            JX_DCT_SIZES(JX_DCT_ATTR)
+#undef JX_DCT_ATTR
+#define JX_LR_ATTR(K, T) HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_lowrank_kernel<K, T, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)JX_LR_LDS_MAX));
+            JX_LR_KINDS_F32(JX_LR_ATTR)
+#undef JX_LR_ATTR
+        }
 #define JX_ATTR2(LPv, LSv, R1v, R3v) if (cv.LP == LPv && cv.LS == LSv) { \
             constexpr int rs1 = jx_lay<LPv>::RS, rs3 = jx_lay<LPv>::RS > jx_lay<LSv>::RS ? jx_lay<LPv>::RS : jx_lay<LSv>::RS; \
             ctx->p1_lds = sizeof(cplx) * ((size_t)R1v * rs1 + 2 * LPv + 2) + sizeof(double) * R1v; \
             ctx->p3_lds = sizeof(cplx) * ((size_t)R3v * rs3 + LPv + LSv) + (cv.xsym ? sizeof(double) * R3v * (cv.o + 1) : 0); \
             HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_rowfft2_kernel<LPv, R1v>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->p1_lds)); \
-            HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_rowtf2_kernel<LPv, LSv, R3v>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->p3_lds)); }
+            HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_rowtf2_kernel<LPv, LSv, R3v>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->p3_lds)); \
+            HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_rowtf2_kernel<LPv, LSv, R3v, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->p3_lds)); }
         JX_CONV2_PAIRS(JX_ATTR2)
 #undef JX_ATTR2
         HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_beamfir_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->p2_lds));
@@ -1226,7 +1243,9 @@ static int launch_fused_conv(jx_ctx* ctx, int n, EvSet* es, bool dct) {
             if (gd.x <= 65536) dc.stamps = stamp_buf;
         }
 #define JX_DCT_GO(LPv, NSv, NTv) if (!done && cv.LP == LPv && cv.LS == NSv) { \
-            hipLaunchKernelGGL((jx_rowdct_kernel<LPv, NSv, 16, NTv, 0>), gd, dim3(NTv), ctx->dct_lds, st, dc, ctx->d_cf, ctx->d_Rt, ctx->d_x0t); done = true; }
+            if (ctx->f32) hipLaunchKernelGGL((jx_rowdct_kernel<LPv, NSv, 16, NTv, 0, float>), gd, dim3(NTv), ctx->dct_lds, st, dc, ctx->d_cf, ctx->d_Rt, ctx->d_x0t); \
+            else hipLaunchKernelGGL((jx_rowdct_kernel<LPv, NSv, 16, NTv, 0>), gd, dim3(NTv), ctx->dct_lds, st, dc, ctx->d_cf, ctx->d_Rt, ctx->d_x0t); \
+            done = true; }
         JX_DCT_SIZES(JX_DCT_GO)
 #undef JX_DCT_GO
         if (!done) { ctx->err = "no coefficient-fed pass-1 kernel for this size"; return JX_ERR_UNSUPPORTED; }
@@ -1259,13 +1278,21 @@ static int launch_fused_conv(jx_ctx* ctx, int n, EvSet* es, bool dct) {
         // (K split in halves for large maps: the second launch adds its half of the distinct rows to the first's results)
         const long long KUh = KU / ctx->fused_nh;
         for (int h = 0; h < ctx->fused_nh; ++h) {
-            const JxGemmSeg s0{lr.U + (size_t)h * ctx->kact * RP * KUh, ctx->d_Rt + (size_t)h * KUh * tW, ctx->d_Ct, RP * KUh, KU * tW, 64LL,
+            // (operand offsets in bytes: the elements are floats in the fp32 variant)
+            const size_t esz = ctx->f32 ? sizeof(float) : sizeof(double);
+            const double* Bh = reinterpret_cast<const double*>(reinterpret_cast<const char*>(ctx->d_Rt) + (size_t)h * KUh * tW * esz);
+            const double* B0h = reinterpret_cast<const double*>(reinterpret_cast<const char*>(ctx->d_x0t) + (size_t)h * KUh * tW * esz);
+            const JxGemmSeg s0{lr.U + (size_t)h * ctx->kact * RP * KUh, Bh, ctx->d_Ct, RP * KUh, KU * tW, 64LL,
                                (long long)cv.Ph * 64, ctx->kact, h};
-            const JxGemmSeg s1{ctx->lrf0.U + (size_t)h * nt * RP * KUh, ctx->d_x0t + (size_t)h * KUh * tW, ctx->d_Ct0, RP * KUh, 0LL, 64LL,
+            const JxGemmSeg s1{ctx->lrf0.U + (size_t)h * nt * RP * KUh, B0h, ctx->d_Ct0, RP * KUh, 0LL, 64LL,
                                (long long)JX_CT0_X * 64, (int)nt, h};
-#define JX_LR_GO(K, T) if (ctx->fused_bucket == K && ntr == T) \
+#define JX_LR_GO(K, T) if (ctx->fused_bucket == K && ntr == T && !ctx->f32) \
             hipLaunchKernelGGL((jx_lowrank_kernel<K, T>), dim3(ctx->num_cu), dim3(512), lds, st, lr, s0, s1, 0LL, tW, 1LL, 0LL, 1LL, ncols, 1);
             JX_LR_KINDS(JX_LR_GO)
+#undef JX_LR_GO
+#define JX_LR_GO(K, T) if (ctx->fused_bucket == K && ntr == T && ctx->f32) \
+            hipLaunchKernelGGL((jx_lowrank_kernel<K, T, float>), dim3(ctx->num_cu), dim3(512), lds, st, lr, s0, s1, 0LL, tW, 1LL, 0LL, 1LL, ncols, 1);
+            JX_LR_KINDS_F32(JX_LR_GO)
 #undef JX_LR_GO
         }
     }
@@ -1274,8 +1301,11 @@ static int launch_fused_conv(jx_ctx* ctx, int n, EvSet* es, bool dct) {
     done = false;
     const dim3 g3(cf.nblk3, n);
 #define JX_P3(LPv, LSv, R1v, R3v) if (!done && cv.LP == LPv && cv.LS == LSv) { \
-        hipLaunchKernelGGL((jx_rowtf2_kernel<LPv, LSv, R3v>), g3, dim3(256), ctx->p3_lds, st, cf, reinterpret_cast<const cplx*>(ctx->d_Ct), \
-                           ctx->d_part, (double*)nullptr); done = true; }
+        if (ctx->f32) hipLaunchKernelGGL((jx_rowtf2_kernel<LPv, LSv, R3v, float>), g3, dim3(256), ctx->p3_lds, st, cf, reinterpret_cast<const cplx*>(ctx->d_Ct), \
+                           ctx->d_part, (double*)nullptr); \
+        else hipLaunchKernelGGL((jx_rowtf2_kernel<LPv, LSv, R3v>), g3, dim3(256), ctx->p3_lds, st, cf, reinterpret_cast<const cplx*>(ctx->d_Ct), \
+                           ctx->d_part, (double*)nullptr); \
+        done = true; }
     JX_CONV2_PAIRS(JX_P3)
 #undef JX_P3
     if (es) HIPCHK(ctx, hipEventRecord(es->e[4], st));
@@ -1514,6 +1544,7 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
     }
     // default route: the map rows are evaluated inside pass 1 from the coefficients (no image), unless the image is asked for
     const bool dct = !op_route && ctx->dct_ok && (ctx->odd || (use_fused(ctx, t.conv) && !t.need_img));
+    if (ctx->f32 && !op_route && !dct) { ctx->err = "dtype f32: the map and beam-convolved-map taps exist in the f64 build of the context only"; return JX_ERR_UNSUPPORTED; }
     {
         const bool vec2 = (d.S % 2 == 0) && (d.P % 2 == 0);
         const int npw = (d.quad && d.pairw == 2) ? 2 : 1;

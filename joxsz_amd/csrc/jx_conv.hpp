@@ -104,6 +104,12 @@ struct JxConv {
 // ====================================================================================
 __device__ __forceinline__ jx_c jx_ld(const cplx* p) { const cplx v = *p; return jxc(v.x, v.y); }
 __device__ __forceinline__ void jx_st(cplx* p, jx_c v) { *p = make_double2(v.x, v.y); }
+__device__ __forceinline__ jx_cT<float> jx_ld(const float2* p) { const float2 v = *p; return jxcT<float>(v.x, v.y); }
+__device__ __forceinline__ void jx_st(float2* p, jx_cT<float> v) { *p = make_float2(v.x, v.y); }
+// LDS / memory pair type of a scalar type
+template <typename T> struct jx_pair;
+template <> struct jx_pair<double> { typedef double2 type; };
+template <> struct jx_pair<float> { typedef float2 type; };
 
 template <int L> struct jx_lay {
     static constexpr int L1 = jx_plan2<L>::L1, L2 = jx_plan2<L>::L2;
@@ -114,24 +120,24 @@ template <int L> struct jx_lay {
 };
 
 // step A on registers already loaded: x[n1] -> FFT over n1, twiddle, store to padded layout
-template <int L, bool INV>
-__device__ __forceinline__ void jx_stepA_store(jx_c* x, int n2, cplx* Mrow, const cplx* tw) {
+template <int L, bool INV, typename T, typename T2>
+__device__ __forceinline__ void jx_stepA_store(jx_cT<T>* x, int n2, T2* Mrow, const T2* tw) {
     constexpr int L1 = jx_lay<L>::L1, L2P = jx_lay<L>::L2P;
     jx_regfft<L1, INV>::run(x);
 #pragma unroll
     for (int k1 = 0; k1 < L1; ++k1) {
-        jx_c v = x[k1];
+        jx_cT<T> v = x[k1];
         if (k1 > 0) {
-            const cplx w = tw[n2 * k1];                     // e^{-2 pi i n2 k1 / L}
-            v = INV ? jxc(v.x * w.x + v.y * w.y, v.y * w.x - v.x * w.y) : jxc(v.x * w.x - v.y * w.y, v.x * w.y + v.y * w.x);
+            const T2 w = tw[n2 * k1];                       // e^{-2 pi i n2 k1 / L}
+            v = INV ? jxcT<T>(v.x * w.x + v.y * w.y, v.y * w.x - v.x * w.y) : jxcT<T>(v.x * w.x - v.y * w.y, v.x * w.y + v.y * w.x);
         }
         jx_st(Mrow + k1 * L2P + n2, v);
     }
 }
 
 // step B: read the L2 samples of (row, k1) from the padded layout, transform, leave in y
-template <int L, bool INV>
-__device__ __forceinline__ void jx_stepB_load(jx_c* y, int k1, const cplx* Mrow) {
+template <int L, bool INV, typename T, typename T2>
+__device__ __forceinline__ void jx_stepB_load(jx_cT<T>* y, int k1, const T2* Mrow) {
     constexpr int L2 = jx_lay<L>::L2, L2P = jx_lay<L>::L2P;
 #pragma unroll
     for (int n2 = 0; n2 < L2; ++n2) y[n2] = jx_ld(Mrow + k1 * L2P + n2);
@@ -309,7 +315,8 @@ jx_col0_kernel(JxConv c, const double* __restrict__ img, size_t img_ld, size_t i
     }
 }
 
-template <int LP, int LS, int ROWS>
+// TC: element type of the combined rows Ct / Ct0 in memory on the fused route (float in the fp32 variant; widened on load)
+template <int LP, int LS, int ROWS, typename TC = double>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
 jx_rowtf2_kernel(JxConv c, const cplx* __restrict__ C, cplx* __restrict__ part, double* __restrict__ tap_conv) {
     typedef jx_lay<LP> LayP;
@@ -343,13 +350,15 @@ jx_rowtf2_kernel(JxConv c, const cplx* __restrict__ C, cplx* __restrict__ part, 
         // combined rows arrive rho-minor: Ct[w][k][64], the block's rows r0.. are 16-byte pairs of that last axis.
         // Work item = (pair (k, LP-k), two rows): NSUB consecutive lanes read the block's rows of one k (a 128-byte line for
         // 14 rows).  All trips' loads first.
-        const double* Cw = reinterpret_cast<const double*>(C) + (size_t)w * Ph * 64 + r0;
+        typedef typename jx_pair<TC>::type TC2;
+        const TC* Cw = reinterpret_cast<const TC*>(C) + (size_t)w * Ph * 64 + r0;
+        const TC* ct0 = reinterpret_cast<const TC*>(c.ct0);
         const int nt = c.o + 1, ns = nrows * nt;
         double cz[NSL];
 #pragma unroll
         for (int u = 0; u < NSL; ++u) {
             const int e = min(tid + u * nth, ns - 1), row = e / nt, xo = e - row * nt;
-            cz[u] = c.ct0[((size_t)w * JX_CT0_X + xo) * 64 + r0 + row];
+            cz[u] = (double)ct0[((size_t)w * JX_CT0_X + xo) * 64 + r0 + row];
         }
         constexpr int HR = (ROWS + 1) / 2;                            // row pairs
         constexpr int NSUB = HR <= 4 ? 4 : (HR <= 8 ? 8 : (HR <= 16 ? 16 : 32)), LSUB = NSUB == 4 ? 2 : (NSUB == 8 ? 3 : (NSUB == 16 ? 4 : 5));
@@ -359,8 +368,12 @@ jx_rowtf2_kernel(JxConv c, const cplx* __restrict__ C, cplx* __restrict__ part, 
 #pragma unroll
         for (int i = 0; i < NTRIP; ++i) {
             const int e = min(tid + i * 256, NPAIR * NSUB - 1), k = e >> LSUB, sub = min(e & (NSUB - 1), HR - 1);
-            ra[i] = k < c.kact ? *reinterpret_cast<const double2*>(Cw + (size_t)k * 64 + 2 * sub) : make_double2(0.0, 0.0);
-            rb[i] = LP - k < c.kact ? *reinterpret_cast<const double2*>(Cw + (size_t)(LP - k) * 64 + 2 * sub) : make_double2(0.0, 0.0);
+            TC2 va, vb;
+            va.x = va.y = vb.x = vb.y = 0;
+            if (k < c.kact) va = *reinterpret_cast<const TC2*>(Cw + (size_t)k * 64 + 2 * sub);
+            if (LP - k < c.kact) vb = *reinterpret_cast<const TC2*>(Cw + (size_t)(LP - k) * 64 + 2 * sub);
+            ra[i] = make_double2((double)va.x, (double)va.y);
+            rb[i] = make_double2((double)vb.x, (double)vb.y);
         }
 #pragma unroll
         for (int i = 0; i < NTRIP; ++i) {
@@ -832,7 +845,9 @@ typedef double jx_v4d __attribute__((ext_vector_type(4)));
 // One wave per column tile, all NTR rho tiles of it (NTR accumulators): every B value is requested once per CU, its NTR
 // A fragments come from LDS (fragment order [tile][k-step][lane]).  KS = k-steps compiled in (>= lr.ks, the A fragments
 // beyond lr.ks are zero): no branch inside the load and MFMA sequences, no barrier between the tasks of one A tile.
-template <int KS, int NTR>
+// TB: element type of the B operand and of the result in memory (double, or float for the fp32 variant: values are widened
+// on load, the products and sums stay fp64, the result is rounded once on store).  The A matrices are always fp64.
+template <int KS, int NTR, typename TB = double>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 2)))
 jx_lowrank_kernel(JxLowrank lr, JxGemmSeg sg0, JxGemmSeg sg1, long long bws, long long bq, long long bj,
                   long long dws, long long dr, int ncols, int nwalk) {
@@ -855,7 +870,8 @@ jx_lowrank_kernel(JxLowrank lr, JxGemmSeg sg0, JxGemmSeg sg1, long long bws, lon
         const int batch = g / gpb, unit = min((g - batch * gpb) * nwave + wave, nunit - 1);
         const int w = unit / ntile, jt = unit - w * ntile;
         const bool second = batch >= sg0.nbatch;                      // wave-uniform
-        const double* Bb = second ? sg1.B + (size_t)(batch - sg0.nbatch) * sg1.b_batch : sg0.B + (size_t)batch * sg0.b_batch;
+        const TB* Bb = second ? reinterpret_cast<const TB*>(sg1.B) + (size_t)(batch - sg0.nbatch) * sg1.b_batch
+                              : reinterpret_cast<const TB*>(sg0.B) + (size_t)batch * sg0.b_batch;
         return Bb + (size_t)w * bws + (size_t)min(jt * 16 + li, ncols - 1) * bj + (size_t)lk * bq;
     };
     // one LDS base per rho tile: the k-step offsets then fit the 16-bit immediate of ds_read (a single base would need an
@@ -868,9 +884,9 @@ jx_lowrank_kernel(JxLowrank lr, JxGemmSeg sg0, JxGemmSeg sg1, long long bws, lon
     }
     constexpr int H = KS / 2;                                         // B values in flight (must divide KS): half a task ahead
     double b[H];
-    const double* pl = bptr(g0);                                       // running load pointer (no table of row addresses in registers)
+    const TB* pl = bptr(g0);                                           // running load pointer (no table of row addresses in registers)
 #pragma unroll
-    for (int u = 0; u < H; ++u) { b[u] = *pl; pl += step; }
+    for (int u = 0; u < H; ++u) { b[u] = (double)*pl; pl += step; }
     int cur = -1;
     for (int g = g0; g < g1; ++g) {
         const int batch = g / gpb;
@@ -884,7 +900,7 @@ jx_lowrank_kernel(JxLowrank lr, JxGemmSeg sg0, JxGemmSeg sg1, long long bws, lon
             __syncthreads();
             cur = batch;
         }
-        const double* pbn = bptr(min(g + 1, g1 - 1));                  // past the end: a valid address, never used
+        const TB* pbn = bptr(min(g + 1, g1 - 1));                      // past the end: a valid address, never used
         jx_v4d acc[NTR];
 #pragma unroll
         for (int t = 0; t < NTR; ++t) acc[t] = jx_v4d{0.0, 0.0, 0.0, 0.0};
@@ -902,7 +918,7 @@ jx_lowrank_kernel(JxLowrank lr, JxGemmSeg sg0, JxGemmSeg sg1, long long bws, lon
 #pragma unroll
             for (int t = 0; t < NTR; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[t], b[u % H], acc[t], 0, 0, 0);
             if (u + H == KS) pl = pbn;                               // the ring moves on to the next task's rows
-            b[u % H] = *pl; pl += step;
+            b[u % H] = (double)*pl; pl += step;
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < NTR; ++t) ac[t] = an[t];
@@ -911,14 +927,15 @@ jx_lowrank_kernel(JxLowrank lr, JxGemmSeg sg0, JxGemmSeg sg1, long long bws, lon
         const int w = unit / ntile, jt = unit - w * ntile;
         if (unit < nunit && jt * 16 + li < ncols) {
             const bool second = batch >= sg0.nbatch;
-            double* Dp = (second ? sg1.D + (size_t)(batch - sg0.nbatch) * sg1.d_batch : sg0.D + (size_t)batch * sg0.d_batch)
-                         + (size_t)w * dws + (size_t)(jt * 16 + li) * (second ? sg1.dj : sg0.dj);
+            TB* Dp = (second ? reinterpret_cast<TB*>(sg1.D) + (size_t)(batch - sg0.nbatch) * sg1.d_batch
+                             : reinterpret_cast<TB*>(sg0.D) + (size_t)batch * sg0.d_batch)
+                     + (size_t)w * dws + (size_t)(jt * 16 + li) * (second ? sg1.dj : sg0.dj);
 #pragma unroll
             for (int t = 0; t < NTR; ++t)
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {
                     const int rho = t * 16 + lk + 4 * gq;
-                    if (rho < lr.r) Dp[(size_t)rho * dr] = (second ? sg1.acc : sg0.acc) ? Dp[(size_t)rho * dr] + acc[t][gq] : acc[t][gq];
+                    if (rho < lr.r) Dp[(size_t)rho * dr] = (TB)((second ? sg1.acc : sg0.acc) ? (double)Dp[(size_t)rho * dr] + acc[t][gq] : acc[t][gq]);
                 }
         }
     }
@@ -926,6 +943,8 @@ jx_lowrank_kernel(JxLowrank lr, JxGemmSeg sg0, JxGemmSeg sg1, long long bws, lon
 #define JX_LR_BUCKETS(X) X(24) X(40) X(68) X(72)
 #define JX_LR_KINDS(X) X(24, 1) X(24, 2) X(24, 3) X(24, 4) X(40, 1) X(40, 2) X(40, 3) X(40, 4) X(68, 1) X(68, 2) X(68, 3) X(68, 4) \
     X(72, 1) X(72, 2) X(72, 3) X(72, 4)
+// the kinds instantiated for fp32 operands as well (the fused route of the even sides: rank 17..64)
+#define JX_LR_KINDS_F32(X) X(24, 2) X(24, 3) X(24, 4) X(40, 2) X(40, 3) X(40, 4) X(68, 2) X(68, 3) X(68, 4) X(72, 2) X(72, 3) X(72, 4)
 
 // ------------------------------------------------------------------------------------
 // tail of the hand-written path.  One 256-thread block per walker:

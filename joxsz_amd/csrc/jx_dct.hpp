@@ -89,9 +89,15 @@ __device__ __forceinline__ double jx_spline4(const char* ym, unsigned koff, doub
 // MODE 1: the samples are read from a walker-minor array cf[k][u][w] (k < n_in; row stride tW, sample stride s_kstr): the
 //         same transform taken of a band-limited real-even spectrum is its inverse (odd map sides: combined rows back to
 //         real space, joxsz_funcs.py:464-467 without a transform of the odd length S).
-template <int LP, int NS, int NW, int NT, int MODE>
+// T: arithmetic and storage type of the samples, the transform and the output (double: the reference's; float: the fp32
+//    variant of BASELINE configs[4] -- the spline arrays and the tables stay fp64 and are rounded as they are loaded).
+template <int LP, int NS, int NW, int NT, int MODE, typename T = double>
 __global__ void __launch_bounds__(NT)
-jx_rowdct_kernel(JxDct d, const double* __restrict__ cf, double* __restrict__ Rt, double* __restrict__ x0t) {
+jx_rowdct_kernel(JxDct d, const void* __restrict__ src_v, void* __restrict__ out_v, void* __restrict__ x0t_v) {
+    typedef typename jx_pair<T>::type T2;
+    const double* cf = reinterpret_cast<const double*>(src_v);      // MODE 0: spline arrays (always fp64)
+    T* Rt = reinterpret_cast<T*>(out_v);
+    T* x0t = reinterpret_cast<T*>(x0t_v);
     constexpr int Q = LP / 2;
     typedef jx_dct_lay<Q, NS> Lay;
     typedef jx_dct_geo<Q, NS> Geo;
@@ -102,11 +108,11 @@ jx_rowdct_kernel(JxDct d, const double* __restrict__ cf, double* __restrict__ Rt
     static_assert(NW == 16, "the post-processing lane map assumes 16 walkers per block");
     static_assert(NW * TPR <= 64 * (NWAVE - 1) || NWAVE == 1, "the last wave has no FFT task (it sums B[0])");
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    cplx* M = reinterpret_cast<cplx*>(sm);                   // [NW][RS]
-    cplx* tw = M + NW * RS;                                  // [Q]
-    double* s_pk = reinterpret_cast<double*>(tw + Q);        // [Q/2 + 1][4]
-    double* s_bs = s_pk + 4 * (Q / 2 + 1);                   // [NW][64] per-lane sums of the odd-indexed samples
-    double* s_b0 = s_bs + NW * 64;                           // [NW] B[0]
+    T2* M = reinterpret_cast<T2*>(sm);                       // [NW][RS]
+    T2* tw = M + NW * RS;                                    // [Q]
+    T* s_pk = reinterpret_cast<T*>(tw + Q);                  // [Q/2 + 1][4]
+    T* s_bs = s_pk + 4 * (Q / 2 + 1);                        // [NW][64] per-lane sums of the odd-indexed samples
+    T* s_b0 = s_bs + NW * 64;                                // [NW] B[0]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wq = __builtin_amdgcn_readfirstlane(tid >> 6);
 
@@ -117,8 +123,8 @@ jx_rowdct_kernel(JxDct d, const double* __restrict__ cf, double* __restrict__ Rt
     if (grp >= ngroups) return;
     const int w0 = grp * NW;
 
-    for (int i = tid; i < Q; i += NT) tw[i] = d.tw_q[i];
-    for (int i = tid; i < 4 * (Q / 2 + 1); i += NT) s_pk[i] = d.pk[i];
+    for (int i = tid; i < Q; i += NT) { const cplx t = d.tw_q[i]; T2 v; v.x = (T)t.x; v.y = (T)t.y; tw[i] = v; }
+    for (int i = tid; i < 4 * (Q / 2 + 1); i += NT) s_pk[i] = (T)d.pk[i];
 
     // ---- per-thread constants of the evaluation: LDS byte offsets (within a walker's row) of this lane's outputs
     unsigned e_j1[NPASS], e_j2[NPASS];
@@ -128,10 +134,10 @@ jx_rowdct_kernel(JxDct d, const double* __restrict__ cf, double* __restrict__ Rt
         const int g = lane + 64 * p;
         e_on[p] = g <= Geo::GW;
         const int gc = min(g, Geo::GW), gq = Q - gc;
-        e_j1[p] = 16u * (unsigned)((2 * gc < Q) ? Lay::zslot(gc) : DUMP);           // first kind: j = g <= (Q-1)/2
-        e_j2[p] = 16u * (unsigned)((gc > 0) ? Lay::zslot(gq) : DUMP);               // second kind: j = Q - g, g >= 1
+        e_j1[p] = (unsigned)sizeof(T2) * (unsigned)((2 * gc < Q) ? Lay::zslot(gc) : DUMP);   // first kind: j = g <= (Q-1)/2
+        e_j2[p] = (unsigned)sizeof(T2) * (unsigned)((gc > 0) ? Lay::zslot(gq) : DUMP);       // second kind: j = Q - g, g >= 1
     }
-    constexpr unsigned e_j1t = 16u * Lay::zslot(Geo::GW + 1), e_j2t = 16u * Lay::zslot(Q - Geo::GW - 1);
+    constexpr unsigned e_j1t = (unsigned)sizeof(T2) * Lay::zslot(Geo::GW + 1), e_j2t = (unsigned)sizeof(T2) * Lay::zslot(Q - Geo::GW - 1);
     const bool e_tail = Geo::TAIL && lane == (Geo::GW & 63);
     // walker bases of this wave (byte pointers; a missing walker repeats the last one and is never stored)
     const char* cfb[WPW];
@@ -141,15 +147,15 @@ jx_rowdct_kernel(JxDct d, const double* __restrict__ cf, double* __restrict__ Rt
     // ---- FFT roles
     const int frow = tid / TPR, fidx = tid - frow * TPR;
     const bool actA = frow < NW && fidx < L2, actB = frow < NW && fidx < L1;
-    cplx* Mrow = M + frow * RS;
+    T2* Mrow = M + frow * RS;
 
     // ---- post-processing: 4 consecutive k x 16 walkers per wave
     constexpr int KPI = 4 * NWAVE, NIT = (Q / 2 + 1 + KPI - 1) / KPI;
     const int pkk = lane & 3, pw = lane >> 2;
     const bool wok = w0 + pw < d.n;
-    const unsigned kstr8 = (unsigned)(d.tKU * d.tW * 8);      // bytes between consecutive k of Rt (k * kstr8 < 2^32: checked on the host)
+    const unsigned kstr8 = (unsigned)(d.tKU * d.tW * sizeof(T));   // bytes between consecutive k of Rt (k * kstr8 < 2^32: checked on the host)
     char* Rw = reinterpret_cast<char*>(Rt + w0 + pw);
-    const cplx* Mw_post = M + pw * RS;
+    const T2* Mw_post = M + pw * RS;
 
     unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_t = 0;
     const bool stamping = d.stamps != nullptr;
@@ -161,43 +167,48 @@ jx_rowdct_kernel(JxDct d, const double* __restrict__ cf, double* __restrict__ Rt
         // complete in order, so the reads see the stores before them and the z stores come after every read)
         auto build_z = [&](int w) {
             char* Mw = reinterpret_cast<char*>(M + w * RS);
-            const double* qa = reinterpret_cast<const double*>(Mw);
-            double2 qv[NPASS][3];
-            double q3[NPASS];
+            const T* qa = reinterpret_cast<const T*>(Mw);
+            T2 qv[NPASS][3];
+            T q3[NPASS];
 #pragma unroll
             for (int p = 0; p < NPASS; ++p) {
                 const int g = min(lane + 64 * p, Geo::GW), gm = max(g, 1);
-                qv[p][0] = *reinterpret_cast<const double2*>(qa + 4 * g);          // q[4g], q[4g+1]
-                qv[p][1] = *reinterpret_cast<const double2*>(qa + 4 * g + 2);      // q[4g+2], q[4g+3]
-                qv[p][2] = *reinterpret_cast<const double2*>(qa + 4 * gm - 2);     // q[4g-2], q[4g-1]
-                q3[p] = qa[4 * gm - 3];                                             // q[4g-3]
+                qv[p][0] = *reinterpret_cast<const T2*>(qa + 4 * g);          // q[4g], q[4g+1]
+                qv[p][1] = *reinterpret_cast<const T2*>(qa + 4 * g + 2);      // q[4g+2], q[4g+3]
+                qv[p][2] = *reinterpret_cast<const T2*>(qa + 4 * gm - 2);     // q[4g-2], q[4g-1]
+                q3[p] = qa[4 * gm - 3];                                        // q[4g-3]
             }
-            double bs = 0.0;
+            T bs = 0;
 #pragma unroll
             for (int p = 0; p < NPASS; ++p) {
-                const double v0 = qv[p][0].x, v1 = qv[p][0].y, v2 = qv[p][1].x, v3 = qv[p][1].y;
+                const T v0 = qv[p][0].x, v1 = qv[p][0].y, v2 = qv[p][1].x, v3 = qv[p][1].y;
                 const bool centre = (p == 0) && lane == 0;                          // q[-a] = q[a]
-                const double m1 = centre ? v1 : qv[p][2].y, m2 = centre ? v2 : qv[p][2].x, m3 = centre ? v3 : q3[p];
+                const T m1 = centre ? v1 : qv[p][2].y, m2 = centre ? v2 : qv[p][2].x, m3 = centre ? v3 : q3[p];
                 if (!Geo::FULL || lane + 64 * p < Q / 2) bs += v1 + v3;   // (the group at the Nyquist index holds mirror copies)
                 if (e_on[p]) {
-                    *reinterpret_cast<double2*>(Mw + e_j1[p]) = make_double2(v0 + v1 - m1, v2 + v3 - v1);
-                    *reinterpret_cast<double2*>(Mw + e_j2[p]) = make_double2(v0 - v1 + m1, m2 - m1 + m3);
+                    T2 za, zb;
+                    za.x = v0 + v1 - m1; za.y = v2 + v3 - v1; zb.x = v0 - v1 + m1; zb.y = m2 - m1 + m3;
+                    *reinterpret_cast<T2*>(Mw + e_j1[p]) = za;
+                    *reinterpret_cast<T2*>(Mw + e_j2[p]) = zb;
                 }
                 if (Geo::TAIL && p == NPASS - 1 && e_tail) {   // the group behind the last one has no samples of its own
-                    *reinterpret_cast<double2*>(Mw + e_j1t) = make_double2(-v3, 0.0);
-                    *reinterpret_cast<double2*>(Mw + e_j2t) = make_double2(v3, v2 - v3 + v1);
+                    T2 za, zb;
+                    za.x = -v3; za.y = 0; zb.x = v3; zb.y = v2 - v3 + v1;
+                    *reinterpret_cast<T2*>(Mw + e_j1t) = za;
+                    *reinterpret_cast<T2*>(Mw + e_j2t) = zb;
                 }
             }
 #pragma unroll
             for (int e0 = 0; e0 < Geo::NZFILL; e0 += 64) {
                 const int j = Geo::ZLO + e0 + lane;
-                if (j <= Q - Geo::ZLO) *reinterpret_cast<double2*>(Mw + 16 * ((j / L2) * L2P + (j % L2))) = make_double2(0.0, 0.0);
+                T2 zz; zz.x = 0; zz.y = 0;
+                if (j <= Q - Geo::ZLO) *reinterpret_cast<T2*>(Mw + sizeof(T2) * ((j / L2) * L2P + (j % L2))) = zz;
             }
             s_bs[w * 64 + lane] = bs;
         };
         if constexpr (MODE == 0) {
             int kb[NPASS][4];
-            double wt[NPASS][4][4];
+            T wt[NPASS][4][4];
 #pragma unroll
             for (int p = 0; p < NPASS; ++p)
 #pragma unroll
@@ -205,7 +216,7 @@ jx_rowdct_kernel(JxDct d, const double* __restrict__ cf, double* __restrict__ Rt
                     const size_t e = (size_t)u * d.na4 + 256 * p + 64 * j + lane;
                     kb[p][j] = d.dk[e];
                     const double2 wa = *reinterpret_cast<const double2*>(d.dw + 4 * e), wb = *reinterpret_cast<const double2*>(d.dw + 4 * e + 2);
-                    wt[p][j][0] = wa.x; wt[p][j][1] = wa.y; wt[p][j][2] = wb.x; wt[p][j][3] = wb.y;
+                    wt[p][j][0] = (T)wa.x; wt[p][j][1] = (T)wa.y; wt[p][j][2] = (T)wb.x; wt[p][j][3] = (T)wb.y;
                 }
             // the (y, M) requests of walker i + 1 go out before walker i is worked on: two walkers' loads in flight
             double2 ld[2][NPASS][4][2];
@@ -221,14 +232,14 @@ jx_rowdct_kernel(JxDct d, const double* __restrict__ cf, double* __restrict__ Rt
                 if (i + 1 < WPW) { JX_DCT_REQ(i + 1) }
                 __builtin_amdgcn_sched_barrier(0);
                 if (NW % NWAVE == 0 || w < NW) {
-                    double* qa = reinterpret_cast<double*>(M + w * RS);   // the walker's row as scratch: q[a], a < NEV
+                    T* qa = reinterpret_cast<T*>(M + w * RS);             // the walker's row as scratch: q[a], a < NEV
 #pragma unroll
                     for (int p = 0; p < NPASS; ++p)
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
                             if (256 * p + 64 * j < Geo::NEV) {
                                 const double2 p0 = ld[i & 1][p][j][0], p1 = ld[i & 1][p][j][1];
-                                const double v = fma(wt[p][j][3], p1.y, fma(wt[p][j][2], p0.y, fma(wt[p][j][1], p1.x, wt[p][j][0] * p0.x)));
+                                const T v = fma(wt[p][j][3], (T)p1.y, fma(wt[p][j][2], (T)p0.y, fma(wt[p][j][1], (T)p1.x, wt[p][j][0] * (T)p0.x)));
                                 if (256 * p + 64 * j + 64 <= Geo::NEV || 256 * p + 64 * j + lane < Geo::NEV) qa[256 * p + 64 * j + lane] = v;
                             }
                     build_z(w);
@@ -239,18 +250,18 @@ jx_rowdct_kernel(JxDct d, const double* __restrict__ cf, double* __restrict__ Rt
             // lanes = 16 walkers x NT/16 samples: 128-byte runs of the walker-minor source
             constexpr int KPT = NT / 16, NLD = (Geo::NEV + KPT - 1) / KPT;
             const int sw = tid & 15, sk = tid >> 4;
-            const double* sp = cf + (size_t)u * d.tW + min(w0 + sw, d.n - 1);
-            double sv[NLD];
+            const T* sp = reinterpret_cast<const T*>(src_v) + (size_t)u * d.tW + min(w0 + sw, d.n - 1);
+            T sv[NLD];
 #pragma unroll
             for (int i = 0; i < NLD; ++i) {
                 const int k = sk + KPT * i, km = (Geo::FULL && k > LP) ? 2 * LP - k : k;     // even about the Nyquist index
                 sv[i] = sp[(size_t)min(km, d.n_in - 1) * d.s_kstr];
             }
-            double* qa = reinterpret_cast<double*>(M + sw * RS);
+            T* qa = reinterpret_cast<T*>(M + sw * RS);
 #pragma unroll
             for (int i = 0; i < NLD; ++i) {
                 const int k = sk + KPT * i, km = (Geo::FULL && k > LP) ? 2 * LP - k : k;
-                if (k < Geo::NEV) qa[k] = (km < d.n_in) ? sv[i] : 0.0;
+                if (k < Geo::NEV) qa[k] = (km < d.n_in) ? sv[i] : (T)0;
             }
             __syncthreads();
 #pragma unroll
@@ -261,34 +272,34 @@ jx_rowdct_kernel(JxDct d, const double* __restrict__ cf, double* __restrict__ Rt
         }
         JX_STAMP(0)
         if (MODE == 0 && d.has_x0 && tid < NW && w0 + tid < d.n)
-            x0t[(size_t)u * d.tW + w0 + tid] = jx_spline4(reinterpret_cast<const char*>(cf + (size_t)(w0 + tid) * d.cf_ws), (unsigned)d.x0k[u],
-                                                          d.x0w[4 * u], d.x0w[4 * u + 1], d.x0w[4 * u + 2], d.x0w[4 * u + 3]);
+            x0t[(size_t)u * d.tW + w0 + tid] = (T)jx_spline4(reinterpret_cast<const char*>(cf + (size_t)(w0 + tid) * d.cf_ws), (unsigned)d.x0k[u],
+                                                             d.x0w[4 * u], d.x0w[4 * u + 1], d.x0w[4 * u + 2], d.x0w[4 * u + 3]);
         __syncthreads();
         JX_STAMP(1)
 
         // ---------------- FFT of length Q, two levels, in place; the last wave sums B[0] meanwhile ----------------
         if (actA) {
-            jx_c x[L1];
+            jx_cT<T> x[L1];
 #pragma unroll
             for (int n1 = 0; n1 < L1; ++n1) x[n1] = jx_ld(Mrow + n1 * L2P + fidx);
-            jx_stepA_store<Q, false>(x, fidx, Mrow, tw);
+            jx_stepA_store<Q, false>(x, fidx, Mrow, (const T2*)tw);
         }
         if (wq == NWAVE - 1) {
             // lane = (walker, quarter): 16 partial sums each, then two exchanges inside the quad
-            const double2* bp = reinterpret_cast<const double2*>(s_bs + (lane >> 2) * 64 + (lane & 3) * 16);
-            double a0 = 0.0, a1 = 0.0;
+            const T2* bp = reinterpret_cast<const T2*>(s_bs + (lane >> 2) * 64 + (lane & 3) * 16);
+            T a0 = 0, a1 = 0;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { const double2 v = bp[i]; a0 += v.x; a1 += v.y; }
-            double a = a0 + a1;
+            for (int i = 0; i < 8; ++i) { const T2 v = bp[i]; a0 += v.x; a1 += v.y; }
+            T a = a0 + a1;
             a += __shfl_xor(a, 1, 64);
             a += __shfl_xor(a, 2, 64);
-            if ((lane & 3) == 0) s_b0[lane >> 2] = 2.0 * a;
+            if ((lane & 3) == 0) s_b0[lane >> 2] = (T)2 * a;
         }
         JX_STAMP(2)
         __syncthreads();
         {
-            jx_c y[L2];
-            if (actB) jx_stepB_load<Q, false>(y, fidx, Mrow);
+            jx_cT<T> y[L2];
+            if (actB) jx_stepB_load<Q, false>(y, fidx, (const T2*)Mrow);
             __syncthreads();
             if (actB) {
 #pragma unroll
@@ -300,25 +311,25 @@ jx_rowdct_kernel(JxDct d, const double* __restrict__ cf, double* __restrict__ Rt
 
         // ---------------- split, R(k) = A + B, walker-minor stores ----------------
         {
-            const double b0 = s_b0[pw];
-            char* Ru = Rw + (size_t)u * d.tW * 8;
+            const T b0 = s_b0[pw];
+            char* Ru = Rw + (size_t)u * d.tW * sizeof(T);
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int k = it * KPI + 4 * wq + pkk;
                 if (k <= Q / 2) {
-                    const cplx zk = Mw_post[k], zq = Mw_post[k == 0 ? 0 : Q - k];
-                    const double2 pa = *reinterpret_cast<const double2*>(s_pk + 4 * k), pb = *reinterpret_cast<const double2*>(s_pk + 4 * k + 2);
-                    const double sx = zk.x + zq.x, sy = zk.y - zq.y, dx = zk.x - zq.x, dy = zk.y + zq.y;   // s = zk + conj zq, dd = zk - conj zq
-                    const double tx = fma(pa.x, dx, -pa.y * dy), ty = fma(pa.x, dy, pa.y * dx);           // t/2 = (w_k / 2) dd
-                    const double Ak = fma(0.5, sx, ty), Aq = fma(0.5, sx, -ty), Ik = fma(0.5, sy, -tx), Iq = fma(-0.5, sy, -tx);
-                    const double bk = (k == 0) ? b0 : pb.x * Ik, bq = pb.y * Iq;
+                    const T2 zk = Mw_post[k], zq = Mw_post[k == 0 ? 0 : Q - k];
+                    const T2 pa = *reinterpret_cast<const T2*>(s_pk + 4 * k), pb = *reinterpret_cast<const T2*>(s_pk + 4 * k + 2);
+                    const T sx = zk.x + zq.x, sy = zk.y - zq.y, dx = zk.x - zq.x, dy = zk.y + zq.y;   // s = zk + conj zq, dd = zk - conj zq
+                    const T tx = fma(pa.x, dx, -pa.y * dy), ty = fma(pa.x, dy, pa.y * dx);            // t/2 = (w_k / 2) dd
+                    const T Ak = fma((T)0.5, sx, ty), Aq = fma((T)0.5, sx, -ty), Ik = fma((T)0.5, sy, -tx), Iq = fma((T)-0.5, sy, -tx);
+                    const T bk = (k == 0) ? b0 : pb.x * Ik, bq = pb.y * Iq;
                     if (wok) {
                         const unsigned ok = (unsigned)k * kstr8;
-                        if (k < d.kact) *reinterpret_cast<double*>(Ru + ok) = Ak + bk;
-                        if (LP - k < d.kact) *reinterpret_cast<double*>(Ru + (unsigned)(LP - k) * kstr8) = Ak - bk;
+                        if (k < d.kact) *reinterpret_cast<T*>(Ru + ok) = Ak + bk;
+                        if (LP - k < d.kact) *reinterpret_cast<T*>(Ru + (unsigned)(LP - k) * kstr8) = Ak - bk;
                         if (2 * k != Q) {
-                            if (Q - k < d.kact) *reinterpret_cast<double*>(Ru + (unsigned)(Q - k) * kstr8) = Aq + bq;
-                            if (k > 0 && Q + k < d.kact) *reinterpret_cast<double*>(Ru + (unsigned)(Q + k) * kstr8) = Aq - bq;
+                            if (Q - k < d.kact) *reinterpret_cast<T*>(Ru + (unsigned)(Q - k) * kstr8) = Aq + bq;
+                            if (k > 0 && Q + k < d.kact) *reinterpret_cast<T*>(Ru + (unsigned)(Q + k) * kstr8) = Aq - bq;
                         }
                     }
                 }

@@ -10,12 +10,15 @@
 #define JX_HD inline
 #endif
 
-struct jx_c { double x, y; };
+// complex number over float or double (the fp32 variant of the row transforms uses the same code)
+template <typename T> struct jx_cT { T x, y; };
+typedef jx_cT<double> jx_c;
 
-JX_HD jx_c jxc(double a, double b) { jx_c r; r.x = a; r.y = b; return r; }
-JX_HD jx_c jxc_add(jx_c a, jx_c b) { return jxc(a.x + b.x, a.y + b.y); }
-JX_HD jx_c jxc_sub(jx_c a, jx_c b) { return jxc(a.x - b.x, a.y - b.y); }
-JX_HD jx_c jxc_mul(jx_c a, jx_c b) { return jxc(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+template <typename T> JX_HD jx_cT<T> jxcT(T a, T b) { jx_cT<T> r; r.x = a; r.y = b; return r; }
+JX_HD jx_c jxc(double a, double b) { return jxcT<double>(a, b); }
+template <typename T> JX_HD jx_cT<T> jxc_add(jx_cT<T> a, jx_cT<T> b) { return jxcT<T>(a.x + b.x, a.y + b.y); }
+template <typename T> JX_HD jx_cT<T> jxc_sub(jx_cT<T> a, jx_cT<T> b) { return jxcT<T>(a.x - b.x, a.y - b.y); }
+template <typename T> JX_HD jx_cT<T> jxc_mul(jx_cT<T> a, jx_cT<T> b) { return jxcT<T>(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 
 // ---- constexpr cos/sin of 2 pi k / n (octant reduction on the integers, Taylor series on [0, pi/4]) ----
 constexpr double jx_cx_pi = 3.14159265358979323846264338327950288;
@@ -49,23 +52,23 @@ constexpr int jx_rf_radix(int n) { return (n % 4 == 0) ? 4 : ((n % 2 == 0) ? 2 :
 
 template <int R, bool INV> struct jx_bfly;
 template <bool INV> struct jx_bfly<2, INV> {
-    static JX_HD void run(jx_c* u) { const jx_c a = u[0], b = u[1]; u[0] = jxc_add(a, b); u[1] = jxc_sub(a, b); }
+    template <typename T> static JX_HD void run(jx_cT<T>* u) { const jx_cT<T> a = u[0], b = u[1]; u[0] = jxc_add(a, b); u[1] = jxc_sub(a, b); }
 };
 template <bool INV> struct jx_bfly<4, INV> {
-    static JX_HD void run(jx_c* u) {
-        const jx_c s0 = jxc_add(u[0], u[2]), d0 = jxc_sub(u[0], u[2]);
-        const jx_c s1 = jxc_add(u[1], u[3]), e = jxc_sub(u[1], u[3]);
-        const jx_c d1 = INV ? jxc(-e.y, e.x) : jxc(e.y, -e.x);              // -+ i (u1 - u3)
+    template <typename T> static JX_HD void run(jx_cT<T>* u) {
+        const jx_cT<T> s0 = jxc_add(u[0], u[2]), d0 = jxc_sub(u[0], u[2]);
+        const jx_cT<T> s1 = jxc_add(u[1], u[3]), e = jxc_sub(u[1], u[3]);
+        const jx_cT<T> d1 = INV ? jxcT<T>(-e.y, e.x) : jxcT<T>(e.y, -e.x);              // -+ i (u1 - u3)
         u[0] = jxc_add(s0, s1); u[2] = jxc_sub(s0, s1);
         u[1] = jxc_add(d0, d1); u[3] = jxc_sub(d0, d1);
     }
 };
 template <bool INV> struct jx_bfly<3, INV> {
-    static JX_HD void run(jx_c* u) {
-        const double s = INV ? 0.86602540378443864676 : -0.86602540378443864676;
-        const jx_c t = jxc_add(u[1], u[2]), d = jxc_sub(u[1], u[2]);
-        const jx_c m = jxc(u[0].x - 0.5 * t.x, u[0].y - 0.5 * t.y);
-        const jx_c q = jxc(-s * d.y, s * d.x);
+    template <typename T> static JX_HD void run(jx_cT<T>* u) {
+        const T s = (T)(INV ? 0.86602540378443864676 : -0.86602540378443864676);
+        const jx_cT<T> t = jxc_add(u[1], u[2]), d = jxc_sub(u[1], u[2]);
+        const jx_cT<T> m = jxcT<T>(u[0].x - (T)0.5 * t.x, u[0].y - (T)0.5 * t.y);
+        const jx_cT<T> q = jxcT<T>(-s * d.y, s * d.x);
         u[0] = jxc_add(u[0], t);
         u[1] = jxc_add(m, q);
         u[2] = jxc_sub(m, q);
@@ -73,58 +76,59 @@ template <bool INV> struct jx_bfly<3, INV> {
 };
 
 // multiply by W_n^{k} (forward: e^{-2 pi i k/n}; inverse: conjugate), constants folded at compile time
-template <int K, int N, bool INV>
-JX_HD jx_c jx_twmul(jx_c a) {
+template <int K, int N, bool INV, typename T>
+JX_HD jx_cT<T> jx_twmul(jx_cT<T> a) {
     constexpr int k = ((K % N) + N) % N;
     if constexpr (k == 0) return a;
-    else if constexpr (4 * k == N) return INV ? jxc(-a.y, a.x) : jxc(a.y, -a.x);
-    else if constexpr (2 * k == N) return jxc(-a.x, -a.y);
-    else if constexpr (4 * k == 3 * N) return INV ? jxc(a.y, -a.x) : jxc(-a.y, a.x);
+    else if constexpr (4 * k == N) return INV ? jxcT<T>(-a.y, a.x) : jxcT<T>(a.y, -a.x);
+    else if constexpr (2 * k == N) return jxcT<T>(-a.x, -a.y);
+    else if constexpr (4 * k == 3 * N) return INV ? jxcT<T>(a.y, -a.x) : jxcT<T>(-a.y, a.x);
     else {
-        constexpr double c = jx_cx_cos2pi(k, N);
-        constexpr double s = INV ? jx_cx_sin2pi(k, N) : -jx_cx_sin2pi(k, N);
-        return jxc(a.x * c - a.y * s, a.x * s + a.y * c);
+        constexpr T c = (T)jx_cx_cos2pi(k, N);
+        constexpr T s = (T)(INV ? jx_cx_sin2pi(k, N) : -jx_cx_sin2pi(k, N));
+        return jxcT<T>(a.x * c - a.y * s, a.x * s + a.y * c);
     }
 }
 
 // In-place, natural-order FFT of x[0..N-1] (N = 2^a 3^b), decimation in time, fully unrolled.
 template <int N, bool INV> struct jx_regfft {
-    template <int R, int M, int KK, int RR>
-    static JX_HD void tw_row(jx_c (&sub)[R][M], jx_c* u) {
+    template <int R, int M, int KK, int RR, typename T>
+    static JX_HD void tw_row(jx_cT<T> (&sub)[R][M], jx_cT<T>* u) {
         if constexpr (RR < R) {
-            u[RR] = jx_twmul<RR * KK, N, INV>(sub[RR][KK]);
-            tw_row<R, M, KK, RR + 1>(sub, u);
+            u[RR] = jx_twmul<RR * KK, N, INV, T>(sub[RR][KK]);
+            tw_row<R, M, KK, RR + 1, T>(sub, u);
         }
     }
-    template <int R, int M, int KK>
-    static JX_HD void combine(jx_c (&sub)[R][M], jx_c* x) {
+    template <int R, int M, int KK, typename T>
+    static JX_HD void combine(jx_cT<T> (&sub)[R][M], jx_cT<T>* x) {
         if constexpr (KK < M) {
-            jx_c u[R];
-            tw_row<R, M, KK, 0>(sub, u);
+            jx_cT<T> u[R];
+            tw_row<R, M, KK, 0, T>(sub, u);
             jx_bfly<R, INV>::run(u);
 #pragma unroll
             for (int q = 0; q < R; ++q) x[KK + M * q] = u[q];
-            combine<R, M, KK + 1>(sub, x);
+            combine<R, M, KK + 1, T>(sub, x);
         }
     }
-    static JX_HD void run(jx_c* x) {
+    template <typename T>
+    static JX_HD void run(jx_cT<T>* x) {
         constexpr int R = jx_rf_radix(N);
         constexpr int M = N / R;
         if constexpr (M == 1) {
             jx_bfly<R, INV>::run(x);
         } else {
-            jx_c sub[R][M];
+            jx_cT<T> sub[R][M];
 #pragma unroll
             for (int r = 0; r < R; ++r)
 #pragma unroll
                 for (int m = 0; m < M; ++m) sub[r][m] = x[r + R * m];
 #pragma unroll
             for (int r = 0; r < R; ++r) jx_regfft<M, INV>::run(sub[r]);
-            combine<R, M, 0>(sub, x);
+            combine<R, M, 0, T>(sub, x);
         }
     }
 };
-template <bool INV> struct jx_regfft<1, INV> { static JX_HD void run(jx_c*) {} };
+template <bool INV> struct jx_regfft<1, INV> { template <typename T> static JX_HD void run(jx_cT<T>*) {} };
 
 // factorisation L = L1 * L2 used by the two-level LDS FFT (both factors small enough for registers)
 template <int L> struct jx_plan2;

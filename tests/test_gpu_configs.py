@@ -320,3 +320,31 @@ def test_loader_tensors_through_the_hip_path(golden_bundled):
     assert np.array_equal(np.isfinite(got), fin)
     np.testing.assert_allclose(got[fin], want[fin], rtol=1e-9)
     np.testing.assert_allclose(bright, ref['ref_bright'][:3], rtol=1e-8, atol=1e-12 * np.abs(ref['ref_bright'][:3]).max())
+
+
+@pytest.mark.parametrize('S,N,W', [(512, 500, 512), (1024, 1000, 1024)])
+def test_fp32_variant_tolerance_sweep(S, N, W):
+    """BASELINE configs[4]: the fp32 variant (fp32 evaluation of the map rows, fp32 row transform, fp32 storage of the row
+    spectra and combined rows; matrix products, inverse transforms and the tail in fp64) against the fp64 path on the same
+    walkers around the posterior mode: relative difference of the log-posterior, absolute difference of chi^2."""
+    from joxsz_amd import datasets
+    pb = _problem(S, N, seed=S)
+    th = datasets.walker_ball(pb, W, spread=0.02, seed=S)
+    p64 = _post(pb)
+    lp64, ch64, row64 = p64.log_prob(th), p64.stage(th[:64], 'chisq'), p64.stage(th[:64], 'map_row')
+    p64.close()
+    p32 = _post(pb, dtype='f32')
+    assert p32.ctx.dtype == 'f32'
+    lp32, ch32, row32 = p32.log_prob(th), p32.stage(th[:64], 'chisq'), p32.stage(th[:64], 'map_row')
+    np.testing.assert_array_equal(lp32, p32.log_prob(th))               # deterministic too
+    p32.close()
+    fin = np.isfinite(lp64)
+    assert fin.sum() > 0.8 * W and np.array_equal(np.isfinite(lp32), fin)
+    rel = np.abs(lp32[fin] - lp64[fin]) / np.abs(lp64[fin])
+    dchi = np.abs(ch32 - ch64)
+    rrow = np.abs(row32 - row64).max(axis=1) / np.abs(row64).max(axis=1)
+    print('fp32 vs fp64 at %d^2/%d-pt, %d walkers: rel dlogp max %.3e median %.3e | abs dchi^2 max %.3e median %.3e | row max %.3e'
+          % (S, N, W, rel.max(), np.median(rel), dchi.max(), np.median(dchi), rrow.max()))
+    assert rel.max() < 1e-6 and np.median(rel) < 1e-7                   # inside the north_star's 1e-6 around the mode
+    assert rrow.max() < 1e-4
+    assert np.any(lp32[fin] != lp64[fin])                               # it really is another arithmetic
