@@ -107,3 +107,72 @@ def test_sz_row_is_linear_in_the_pressure_profile(golden_tiny):
     a, b = rng.random(pb.N), rng.random(pb.N)
     ra, rb, rab = (orc.row_chain(pb, v)['map_row'] for v in (a, b, 2.5 * a - 0.5 * b))
     np.testing.assert_allclose(rab, 2.5 * ra - 0.5 * rb, rtol=0, atol=1e-12 * np.abs(rab).max())
+
+
+# ---- behaviours of PyAbel's direct integral that the restatement relies on (source absent: these pin the restatement to
+# ---- the published algorithm case by case, they cannot pin PyAbel itself -- DESIGN.md section 3)
+
+def test_abel_last_interior_row_keeps_a_quarter_of_the_end_sample():
+    """Row i = N-2: the 'extra triangle' correction takes HALF of the two-sample trapezoid of columns {i, i+1}, and
+    column i+1 = N-1 is the last sample, whose trapezoid weight is already dx/2 -> 0.25 dx stays (interior rows: 0.5 dx)."""
+    r = 10.0 * np.arange(1, 12)
+    n, dx = r.size, 10.0
+    A = pyabel_direct.abel_weight_matrix(r)
+
+    def cell(i):                                                   # analytic end cell, coefficient of F_{i+1}
+        s = math.sqrt(r[i + 1] ** 2 - r[i] ** 2)
+        return s / dx - math.acosh(r[i + 1] / r[i]) * r[i] / dx
+
+    i = n - 2
+    want_last = (0.25 * dx / math.sqrt(r[i + 1] ** 2 - r[i] ** 2) + cell(i)) * 2 * r[i + 1]
+    assert abs(A[i, i + 1] - want_last) < 1e-13 * abs(want_last)
+    i = 3
+    want_mid = (0.5 * dx / math.sqrt(r[i + 1] ** 2 - r[i] ** 2) + cell(i)) * 2 * r[i + 1]
+    assert abs(A[i, i + 1] - want_mid) < 1e-13 * abs(want_mid)
+    # beyond the first off-diagonal: plain trapezoid weights dx (dx/2 for the last column)
+    assert abs(A[3, 7] - dx * 2 * r[7] / math.sqrt(r[7] ** 2 - r[3] ** 2)) < 1e-12
+    assert abs(A[3, n - 1] - 0.5 * dx * 2 * r[n - 1] / math.sqrt(r[n - 1] ** 2 - r[3] ** 2)) < 1e-12
+    assert np.all(A[n - 1] == 0.0) and np.all(np.tril(A, -1) == 0.0)
+
+
+def test_abel_grid_starting_at_zero_takes_the_cosh1_branch():
+    """r[0] = 0: acosh(r_1 / r_0) is replaced by acosh(cosh(1)) = 1 (the F_0 term vanishes anyway since F = 2 r f)."""
+    r = 5.0 * np.arange(0, 40)
+    f = np.exp(-(r / 60.) ** 2)
+    out = pyabel_direct.direct_transform_forward(f, r)
+    assert np.all(np.isfinite(out)) and out[-1] == 0.0
+    F = 2 * r * f
+    h = 5.0
+    trap = h * (F[2:-1] / r[2:-1]).sum() + 0.5 * h * F[-1] / r[-1] + 0.5 * h * F[1] / r[1]      # row 0, j >= 1, minus half the first cell
+    fr = (F[1] - F[0]) / h
+    want0 = trap + r[1] * fr + 1.0 * (F[0] - fr * r[0])
+    assert abs(out[0] - want0) < 1e-12 * abs(want0)
+    # and the known answer at the centre to the method's accuracy
+    assert abs(out[0] - 60. * math.sqrt(math.pi)) / (60. * math.sqrt(math.pi)) < 2e-2
+
+
+def test_abel_uniform_and_nonuniform_code_paths_give_the_same_numbers(monkeypatch):
+    """np.trapz(dx=...) and np.trapz(x=...) on one exactly uniform grid: identical to rounding, so it does not matter on
+    which side of PyAbel's 1e-13 uniformity test the reference's arange grid (joxsz_main.py:104) falls."""
+    r = 16.0 * np.arange(1, 200)
+    f = 1. / (1. + (r / 250.) ** 2) ** 1.7
+    assert pyabel_direct.is_uniform_sampling(r)
+    a = pyabel_direct.direct_transform_forward(f, r)
+    monkeypatch.setattr(pyabel_direct, 'is_uniform_sampling', lambda _r: False)
+    b = pyabel_direct.direct_transform_forward(f, r)
+    np.testing.assert_allclose(a, b, rtol=1e-13)
+
+
+def test_projection_volumes_cash_and_priors_edge_cases():
+    """mbproj2 pieces (restated, unpinned): shells wholly inside the outermost annulus project to their full volume; a
+    non-finite Cash sum is -inf; a value on a box bound is inside, a hair beyond it is -inf."""
+    e = np.array([0., 1., 2.5, 4., 7.])
+    V = mbp.projection_volume_matrix(e)
+    vol = 4. / 3. * math.pi * (e[1:] ** 3 - e[:-1] ** 3)
+    np.testing.assert_allclose(V.sum(axis=0), vol, rtol=1e-13)
+    assert np.all(np.triu(V) == V) or np.all(np.tril(V) == V)           # an annulus sees only shells at or beyond its radius
+    assert mbp.cash_log_likelihood(np.array([2., 3.]), np.array([1., np.inf])) == -np.inf
+    assert mbp.cash_log_likelihood(np.array([2., 3.]), np.array([1., np.nan])) == -np.inf
+    assert mbp.param_prior(0., 0., 1.) == 0.0 and mbp.param_prior(np.nextafter(0., -1.), 0., 1.) == -np.inf
+    # a NaN passes mbproj2's comparisons (prior 0); the reference then fails the mass-monotonicity test with it (-inf)
+    assert mbp.param_prior(np.nan, 0., 1.) == 0.0
