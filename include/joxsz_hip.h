@@ -244,6 +244,12 @@ int  jx_get_conv_mode(jx_ctx* ctx);
  * for the kact columns below the beam's band limit (every tap beyond is under 0.03 of the singular-value cut, relative to the largest; JOXSZ_BANDLIMIT=0
  * keeps all P/2+1).  JX_ERR_UNSUPPORTED with the rocFFT back end. */
 int  jx_get_conv_layout(jx_ctx* ctx, int32_t out[12]);
+/* What the truncations of the default route cost on this problem: out = {singular-value cut in use, largest difference of
+ * the extracted row between the truncated route and the route with every job and every column, relative to the row's
+ * largest entry (measured once in jx_finalize on the current parameter values; -1 where nothing is truncated), rank, 1 if
+ * jx_finalize found the first estimate above 1e-9 and rebuilt the tables with the cut at 1e-13}.
+ * JOXSZ_TRUNC_PROBE=0 skips the measurement, an explicit JOXSZ_LOWRANK_TOL is never overridden. */
+int  jx_get_truncation(jx_ctx* ctx, double out[4]);
 /* Test hook (hand-written convolution only): device address and geometry of a work buffer, holding the last
  * evaluated chunk.  which: 0 Compton-y maps [chunk][S][S] (geom[3] = 0) or their quadrant of
  * distinct pixels [chunk][S/2+1][ld], entry (|iy-c|, |ix-c|) (geom[3] = 1), 1 pass-1 row spectra [chunk][NU][ld], 2 FIR output

@@ -77,6 +77,10 @@ struct jx_ctx {
     JxConv cv_f;
     int fused_bucket = 0, tW = 0, tKU = 0, kact = 0;
     double lr_tol = 1e-10;             // singular-value cut in use
+    double lr_tol_override = 0.0;      // > 0: the cut to use (second finalize pass after the truncation probe asked for a tighter one)
+    double trunc_est = -1.0;           // probe: largest difference between the extracted row on the truncated default route and on the
+                                       //   route with every job and every column, relative to the row's largest entry (-1: not measured)
+    int trunc_retried = 0;
     double *d_Rt = nullptr, *d_Ct = nullptr, *d_Ct0 = nullptr, *d_x0t = nullptr;
     std::vector<double> h_L, h_taps;   // finalize scratch: U [r][NJ], FIR taps [o+1][Ph]
     jxt::ConvRows h_rows;
@@ -507,7 +511,7 @@ static int make_plans(jx_ctx* ctx, int batch, Plan3** out) {
     return JX_OK;
 }
 
-int jx_finalize(jx_ctx* ctx) {
+static int finalize_impl(jx_ctx* ctx) {
     if (!ctx) return JX_ERR_INVALID;
     if (ctx->finalized) { ctx->err = "jx_finalize called twice"; return JX_ERR_STATE; }
     const jx_config& c = ctx->cfg;
@@ -537,6 +541,7 @@ int jx_finalize(jx_ctx* ctx) {
     // maps cut at 1e-10 (rank 46 instead of 61 at 512^2), which the truncation test of tests/test_gpu_parity.py bounds
     double lr_tol0 = (S < 400) ? 1e-13 : 1e-10;
     if (const char* e = getenv("JOXSZ_LOWRANK_TOL")) { const double v2 = atof(e); if (v2 > 0.0 && v2 < 1e-6) lr_tol0 = v2; }
+    if (ctx->lr_tol_override > 0.0) lr_tol0 = ctx->lr_tol_override;
     if (oddS && want != 1 && c.fft_pad == 0 && JX_FIR_TILE + 2 * o <= JX_FIR_RING && !getenv("JOXSZ_ODD_ROCFFT"))
         plan_odd(c, beam_h, host_vec<double>(ctx, JX_T_FILTERING), host_vec<double>(ctx, JX_T_D_MAT), lr_tol0, oplan);
     const int lp_custom = oddS ? (oplan.ok ? oplan.LP : 0) : jxt::custom_conv_lp(S, o);
@@ -2018,6 +2023,76 @@ int jx_debug_workspace(jx_ctx* ctx, int which, void** dev, int32_t geom[4]) {
             break;
         default: ctx->err = "unknown work buffer"; return JX_ERR_INVALID;
     }
+    return JX_OK;
+}
+
+// The default route of even map sides drops the small singular values of the transfer-function weights and the columns
+// past the beam's band limit.  What that costs is measured here, once per context, on the current parameter values: the
+// extracted row (joxsz_funcs.py:472) through the truncated route against the route with every job and every column (the
+// one the beam-convolved-map tap uses).  Returns the largest difference relative to the row's largest entry.
+static int truncation_probe(jx_ctx* ctx, double* est) {
+    *est = -1.0;
+    if (ctx->conv_mode != 2 || ctx->odd || ctx->lrf.r == 0 || ctx->f32) return JX_OK;      // nothing truncated / no exact route beside it
+    const jx_config& c = ctx->cfg;
+    const int S = c.S, nrow = ctx->nrow;
+    int rc;
+    if ((rc = ensure_taps(ctx))) return rc;
+    if ((rc = ensure_batch(ctx, 1))) return rc;
+    std::vector<double> th(c.ndim);
+    {
+        const std::vector<double> pv = host_vec<double>(ctx, JX_T_PAR_VALS);
+        const std::vector<int32_t> ti = host_vec<int32_t>(ctx, JX_T_THAWED_IDX);
+        for (int k = 0; k < c.ndim; ++k) th[k] = pv[ti[k]];
+    }
+    double *tj = nullptr, *tc = nullptr;
+    HIPCHK(ctx, hipMalloc((void**)&tj, sizeof(double) * (size_t)ctx->cv.NJ * S));
+    HIPCHK(ctx, hipMalloc((void**)&tc, sizeof(double) * (size_t)S * S));
+    double* keep_conv = ctx->t_conv;
+    ctx->t_conv = tc;
+    auto done = [&](int code) { ctx->t_conv = keep_conv; (void)hipStreamSynchronize(ctx->stream); (void)hipFree(tj); (void)hipFree(tc); return code; };
+    if (hipMemcpyAsync(ctx->d_theta, th.data(), sizeof(double) * th.size(), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return done(JX_ERR_HIP);
+    Taps t;
+    t.pp = ctx->t_pp; t.ab = ctx->t_ab; t.y = ctx->t_y; t.row = ctx->t_row; t.bright = ctx->t_bright;
+    t.chisq = ctx->t_chisq; t.tprof = ctx->t_tprof; t.xprofs = c.sz_only ? nullptr : ctx->t_xprofs; t.parts = ctx->t_parts;
+    std::vector<double> ra(nrow), rb(nrow);
+    if ((rc = run_chunk(ctx, ctx->d_theta, ctx->d_logp, 0, 1, t))) return done(rc);
+    if (hipMemcpyAsync(ra.data(), ctx->t_row, sizeof(double) * nrow, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return done(JX_ERR_HIP);
+    t.conv = tj;
+    if ((rc = run_chunk(ctx, ctx->d_theta, ctx->d_logp, 0, 1, t))) return done(rc);
+    if (hipMemcpyAsync(rb.data(), ctx->t_row, sizeof(double) * nrow, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return done(JX_ERR_HIP);
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return done(JX_ERR_HIP);
+    double mx = 0.0, df = 0.0;
+    for (int k = 0; k < nrow; ++k) { mx = std::max(mx, std::fabs(rb[k])); df = std::max(df, std::fabs(ra[k] - rb[k])); }
+    if (mx > 0.0 && std::isfinite(mx) && std::isfinite(df)) *est = df / mx;
+    return done(JX_OK);
+}
+
+int jx_finalize(jx_ctx* ctx) {
+    int rc = finalize_impl(ctx);
+    if (rc) return rc;
+    if (const char* e = getenv("JOXSZ_TRUNC_PROBE")) { if (atoi(e) == 0) return JX_OK; }
+    if ((rc = truncation_probe(ctx, &ctx->trunc_est))) return rc;
+    // beyond 1e-9 of the row (a narrow beam, a rough transfer function): once more with every term above rounding kept
+    double bound = 1e-9;
+    if (const char* e = getenv("JOXSZ_TRUNC_BOUND")) { const double v = atof(e); if (v > 0.0) bound = v; }
+    if (ctx->trunc_est > bound && ctx->lr_tol > 2e-13 && !getenv("JOXSZ_LOWRANK_TOL")) {
+        jx_ctx* fresh = nullptr;
+        if ((rc = jx_create(&ctx->cfg, &fresh))) return rc;
+        fresh->host = ctx->host; fresh->have = ctx->have;
+        fresh->lr_tol_override = 1e-13;
+        fresh->trunc_retried = 1;
+        rc = finalize_impl(fresh);
+        if (!rc) rc = truncation_probe(fresh, &fresh->trunc_est);
+        if (rc) { ctx->err = "second finalize pass (tighter singular-value cut): " + fresh->err; jx_destroy(fresh); return rc; }
+        std::swap(*ctx, *fresh);                              // the caller's handle now owns the tighter build
+        jx_destroy(fresh);
+    }
+    return JX_OK;
+}
+
+int jx_get_truncation(jx_ctx* ctx, double out[4]) {
+    if (!ctx || !ctx->finalized || !out) return JX_ERR_STATE;
+    out[0] = ctx->lr_tol; out[1] = ctx->trunc_est; out[2] = (double)ctx->lr.r; out[3] = (double)ctx->trunc_retried;
     return JX_OK;
 }
 

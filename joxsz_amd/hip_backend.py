@@ -19,7 +19,7 @@ EXPORTS = (
     'jx_set_par_vals', 'jx_dev_alloc', 'jx_dev_free', 'jx_memcpy_h2d', 'jx_memcpy_d2h',
     'jx_timing_reset', 'jx_timing_enable', 'jx_timing_get', 'jx_get_info', 'jx_get_conv_mode', 'jx_get_conv_layout', 'jx_debug_workspace', 'jx_device_count',
     'jx_device_name', 'jx_strerror', 'jx_last_error', 'jx_destroy',
-    'jx_comm_unique_id', 'jx_comm_init_rank', 'jx_allgather_logp', 'jx_comm_allreduce_max', 'jx_comm_destroy',
+    'jx_get_truncation', 'jx_comm_unique_id', 'jx_comm_init_rank', 'jx_allgather_logp', 'jx_comm_allreduce_max', 'jx_comm_destroy',
 )
 
 TENSORS = ('r_pp', 'd_mat', 'beam_2d', 'filtering', 'radius', 'flux_data', 'conv_T', 'conv_v',
@@ -89,6 +89,7 @@ def load_library(path=None):
     lib.jx_get_info.argtypes = [vp, i32p, i32p, i32p, i32p, i64p]
     lib.jx_get_conv_mode.argtypes = [vp]
     lib.jx_get_conv_layout.argtypes = [vp, ctypes.POINTER(ctypes.c_int32)]
+    lib.jx_get_truncation.argtypes = [vp, dp]
     lib.jx_debug_workspace.argtypes = [vp, ci, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int32)]
     lib.jx_comm_unique_id.argtypes = [vp]
     lib.jx_comm_init_rank.argtypes = [vp, vp, ci, ci]
@@ -185,6 +186,9 @@ class HipContext:
             lay = (ctypes.c_int32 * 12)()
             self._chk(self.lib.jx_get_conv_layout(self._h, lay), 'jx_get_conv_layout')
             self.conv_layout = dict(zip(('xsym', 'quad', 'NU', 'NJ', 'ld', 'img_rows', 'img_ld', 'P', 'rank', 'fused', 'kact'), [int(v) for v in lay]))
+        tr = (ctypes.c_double * 4)()
+        self._chk(self.lib.jx_get_truncation(self._h, tr), 'jx_get_truncation')
+        self.truncation = dict(tol=tr[0], est_rel_row_err=tr[1], rank=int(tr[2]), retried=bool(tr[3]))
         self.route = 'map'
         route = route or os.environ.get('JOXSZ_ROUTE')
         if route and route != 'map':

@@ -348,3 +348,27 @@ def test_fp32_variant_tolerance_sweep(S, N, W):
     assert rel.max() < 1e-6 and np.median(rel) < 1e-7                   # inside the north_star's 1e-6 around the mode
     assert rrow.max() < 1e-4
     assert np.any(lp32[fin] != lp64[fin])                               # it really is another arithmetic
+
+
+def test_truncation_probe_and_automatic_tightening(monkeypatch):
+    """jx_finalize measures what the low-rank cut and the band limit cost on the extracted row (jx_get_truncation); above
+    the bound (1e-9; lowered here to force the case) it rebuilds the tables with every term above rounding kept."""
+    from joxsz_amd import datasets
+    pb = _problem(512, 500, seed=3)
+    th = datasets.walker_ball(pb, 24, spread=0.03, seed=3)
+    post = _post(pb)
+    tr = post.ctx.truncation
+    assert tr['tol'] == 1e-10 and not tr['retried'] and 0 <= tr['est_rel_row_err'] < 1e-9 and tr['rank'] == post.ctx.conv_layout['rank']
+    a = post.log_prob(th)
+    post.close()
+    monkeypatch.setenv('JOXSZ_TRUNC_BOUND', '1e-16')
+    post = _post(pb)
+    tr2 = post.ctx.truncation
+    assert tr2['retried'] and tr2['tol'] == 1e-13 and tr2['rank'] > tr['rank'] and 0 <= tr2['est_rel_row_err'] < 1e-12
+    b = post.log_prob(th)
+    rows = post.stage(th[:4], 'map_row')
+    post.close()
+    fin = np.isfinite(a)
+    np.testing.assert_allclose(b[fin], a[fin], rtol=1e-10)
+    st = orc.sz_stages(pb, orc.pars_dict(pb, th[0]))
+    assert np.abs(rows[0] - st['map_row']).max() / np.abs(st['map_row']).max() < 1e-12
