@@ -12,14 +12,21 @@
 //   jx_tail_kernel          extracted row of the filtered map, conversion, chi^2, total
 // The hand-written convolution passes live in jx_conv.hpp.
 //
-// JOXSZ_DBG (JxDev::dbg) holds timing-only ablation switches of the map kernel; results are
-// wrong when any is set: 1 skip phases 1-4, 2 skip phase 5, 4 phase 5 = stores only,
+// JOXSZ_DBG (JxDev::dbg; diagnostic build only, make ABLATIONS=1) holds timing-only ablation switches of the map kernel;
+// results are wrong when any is set: 1 skip phases 1-4, 2 skip phase 5, 4 phase 5 = stores only,
 // 8 skip the Abel sums, 16 skip the spline moments, 32 skip the pow() of the profile,
 // 64 non-temporal stores (with 4), 128 Abel loop without the reciprocal square root.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Timing-only ablations of the map kernel (JxDev::dbg, environment JOXSZ_DBG) exist in a diagnostic build only
+// (make ABLATIONS=1): in the shipped library JX_DBG is a compile-time false and the kernels carry none of these branches.
+#ifdef JOXSZ_ABLATIONS
+#define JX_DBG(c, bits) ((c).dbg & (bits))
+#else
+#define JX_DBG(c, bits) false
+#endif
 #define JX_MAX_PAR 19
 // All LDS lives in the dynamic region, 16-byte aligned, with 16-byte-multiple carve offsets: a static
 // __shared__ in front of it shifts the base and every ds_read/write_b128 is then replayed at ~64 cycles
@@ -503,7 +510,7 @@ __device__ __forceinline__ void jx_profile_to_coefs(const JxDev& c, const double
         const double r = t0.x;
         s_r[j] = r;
         s_ds[j] = t1;
-        const double v = c.inject_pp ? c.inject_pp[(size_t)w * N + j] : ((c.dbg & 32) ? r : jx_press(p, r));
+        const double v = c.inject_pp ? c.inject_pp[(size_t)w * N + j] : (JX_DBG(c, 32) ? r : jx_press(p, r));
         s_pp[j] = v;
         s_rq[j] = make_double2(r * r, t0.y * v);
         if (taps && tap_pp) tap_pp[(size_t)w * N + j] = v;
@@ -519,8 +526,8 @@ __device__ __forceinline__ void jx_profile_to_coefs(const JxDev& c, const double
         const int pr = p0 + (tid >> 2), sub = tid & 3;
         double acc1 = 0.0, acc2 = 0.0;
         const int i1 = pr, i2 = N - 1 - pr;
-        if (pr < npair && !(c.dbg & 8)) {
-            if (c.dbg & 128) {            // ablation: same loop without the reciprocal square root
+        if (pr < npair && !JX_DBG(c, 8)) {
+            if (JX_DBG(c, 128)) {            // ablation: same loop without the reciprocal square root
                 const double ri1 = s_rq[i1].x, ri2 = s_rq[i2].x;
                 for (int j = i1 + 2 + sub; j < N; j += 4) { const double2 q = s_rq[j]; acc1 = fma(q.y, q.x - ri1, acc1); }
                 for (int j = i2 + 2 + sub; j < N; j += 4) { const double2 q = s_rq[j]; acc2 = fma(q.y, q.x - ri2, acc2); }
@@ -554,7 +561,7 @@ __device__ __forceinline__ void jx_profile_to_coefs(const JxDev& c, const double
     for (int i0 = 0; i0 < N; i0 += (nth >> 1)) {
         const int i = i0 + (tid >> 1), hsel = tid & 1;
         double m0 = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0;
-        if (i < N && !(c.dbg & 16)) {
+        if (i < N && !JX_DBG(c, 16)) {
             const int k0 = max(-K, -i), k1 = min(K, N - 1 - i);
             const int km = (k0 + k1 + 1) >> 1;
             const int ka = hsel ? km : k0, kb = hsel ? k1 + 1 : km;      // [ka, kb)
@@ -648,8 +655,8 @@ __device__ __forceinline__ void jx_profile_to_coefs2(const JxDev& c, const doubl
         const double r = t0.x;
         s_r[j] = r;
         s_ds[j] = t1;
-        const double vA = c.inject_pp ? c.inject_pp[(size_t)w * N + j] : ((c.dbg & 32) ? r : jx_press(pA, r));
-        const double vB = c.inject_pp ? c.inject_pp[(size_t)(w + 1) * N + j] : ((c.dbg & 32) ? r : jx_press(pB, r));
+        const double vA = c.inject_pp ? c.inject_pp[(size_t)w * N + j] : (JX_DBG(c, 32) ? r : jx_press(pA, r));
+        const double vB = c.inject_pp ? c.inject_pp[(size_t)(w + 1) * N + j] : (JX_DBG(c, 32) ? r : jx_press(pB, r));
         s_ppA[j] = vA;
         s_ppB[j] = vB;
         s_rq[j] = make_double2(r * r, t0.y * vA);
@@ -664,7 +671,7 @@ __device__ __forceinline__ void jx_profile_to_coefs2(const JxDev& c, const doubl
         const int pr = p0 + (tid >> 2), sub = tid & 3;
         double a1 = 0.0, a2 = 0.0, b1 = 0.0, b2 = 0.0;
         const int i1 = pr, i2 = N - 1 - pr;
-        if (pr < npair && !(c.dbg & 8)) {
+        if (pr < npair && !JX_DBG(c, 8)) {
             jx_abel_row2(s_rq, s_qB, s_rq[i1].x, i1 + 2 + sub, N, &a1, &b1);
             if (i2 != i1) jx_abel_row2(s_rq, s_qB, s_rq[i2].x, i2 + 2 + sub, N, &a2, &b2);
         }
@@ -697,7 +704,7 @@ __device__ __forceinline__ void jx_profile_to_coefs2(const JxDev& c, const doubl
     for (int i0 = 0; i0 < N; i0 += (nth >> 1)) {
         const int i = i0 + (tid >> 1), hsel = tid & 1;
         double m0 = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0, n0 = 0.0, n1 = 0.0, n2 = 0.0, n3 = 0.0;
-        if (i < N && !(c.dbg & 16)) {
+        if (i < N && !JX_DBG(c, 16)) {
             const int k0 = max(-K, -i), k1 = min(K, N - 1 - i);
             const int km = (k0 + k1 + 1) >> 1;
             const int ka = hsel ? km : k0, kb = hsel ? k1 + 1 : km;      // [ka, kb)
@@ -864,7 +871,7 @@ jx_abel_map_sym_kernel(JxDev c, const double* __restrict__ theta, int w0, double
     const int w = blk * npw;
     const bool haveB = npw == 2 && w + 1 < c.nlaunch;                 // (an odd launch: the last block has one walker)
 
-    const bool fused2 = haveB && !(c.dbg & (1 | 256));                // both walkers through phases 1-4 together (256: one after the other)
+    const bool fused2 = haveB && !JX_DBG(c, 1 | 256);                // both walkers through phases 1-4 together (256: one after the other)
     if (fused2) {
         double* pB = s_r + 10 * JX_MAP_NE(N);
         jx_load_params(c, theta, w0 + w, p);
@@ -872,17 +879,17 @@ jx_abel_map_sym_kernel(JxDev c, const double* __restrict__ theta, int w0, double
         jx_profile_to_coefs2(c, p, pB, w, part == 0, s_r, s_cf, s_cfB, tap_pp, tap_ab, tap_y);
     } else {
     jx_load_params(c, theta, w0 + w, p);
-    if (!(c.dbg & 1)) jx_profile_to_coefs(c, p, w, part == 0, s_r, s_pp, s_y, s_M, s_cf, s_rq, s_ds, tap_pp, tap_ab, tap_y);
+    if (!JX_DBG(c, 1)) jx_profile_to_coefs(c, p, w, part == 0, s_r, s_pp, s_y, s_M, s_cf, s_rq, s_ds, tap_pp, tap_ab, tap_y);
     else { for (int k = tid; k < 4 * (N + 1); k += nth) s_cf[k] = 0.0; __syncthreads(); }
     }
     if (haveB && !fused2) {
         __syncthreads();
         jx_load_params(c, theta, w0 + w + 1, p);
-        if (!(c.dbg & 1)) jx_profile_to_coefs(c, p, w + 1, part == 0, s_r, s_pp, s_y, s_M, s_cfB, s_rq, s_ds, tap_pp, tap_ab, tap_y);
+        if (!JX_DBG(c, 1)) jx_profile_to_coefs(c, p, w + 1, part == 0, s_r, s_pp, s_y, s_M, s_cfB, s_rq, s_ds, tap_pp, tap_ab, tap_y);
         else { for (int k = tid; k < 4 * (N + 1); k += nth) s_cfB[k] = 0.0; __syncthreads(); }
     }
     if (c.cf_out) return;                                   // phases 1-3 only: the spline ordinates and moments are in HBM
-    if (c.dbg & 2) return;
+    if (JX_DBG(c, 2)) return;
 
     const int S = c.S, na = c.q_na, nb = c.q_nb, cc = c.S / 2;
     const int lane = tid & 63, wv = tid >> 6, nwv = nth >> 6;
@@ -892,7 +899,7 @@ jx_abel_map_sym_kernel(JxDev c, const double* __restrict__ theta, int w0, double
     const int b_per = (nb + c.map_split - 1) / c.map_split;
     const int b0 = part * b_per, b1 = min(nb, b0 + b_per);
 
-    if (c.quad && !(c.dbg & 4)) {
+    if (c.quad && !JX_DBG(c, 4)) {
         // The distinct pixels only, walked as one flat array of (slot, abscissa) entries [b0*na, b1*na): every lane has
         // an entry in every trip (a row-wise walk leaves na mod 64 lanes idle), eight entries per lane in flight.
         const int e_end = b1 * na;
@@ -930,7 +937,7 @@ jx_abel_map_sym_kernel(JxDev c, const double* __restrict__ theta, int w0, double
     int kq[NAIT];
     double tq[NAIT];
     int b = b0 + wv;
-    if (c.dbg & 4) {                                 // ablation: the store stream alone
+    if (JX_DBG(c, 4)) {                                 // ablation: the store stream alone
         for (int ix = lane; ix < row_pad; ix += 64) rowfull[ix] = 1.0;
         __builtin_amdgcn_wave_barrier();
         for (; b < b1; b += nwv) {
@@ -938,7 +945,7 @@ jx_abel_map_sym_kernel(JxDev c, const double* __restrict__ theta, int w0, double
             const bool do1 = iy1 < S, do2 = (b > 0) && (iy2 >= 0);
             double* orow1 = out + (size_t)iy1 * c.img_ld;
             double* orow2 = out + (size_t)iy2 * c.img_ld;
-            if (c.dbg & 64) {
+            if (JX_DBG(c, 64)) {
                 typedef double jx_d2 __attribute__((ext_vector_type(2)));
                 for (int ix = 2 * lane; ix + 1 < S; ix += 128) {
                     const jx_d2 v = *reinterpret_cast<const jx_d2*>(rowfull + ix);
