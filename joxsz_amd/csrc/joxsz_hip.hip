@@ -1129,7 +1129,7 @@ static int finalize_impl(jx_ctx* ctx) {
                     if ((rc = dev_new(ctx, (size_t)chunk * dc.cf_ws, &ctx->d_cf, true))) return rc;
 #define JX_DCT_ATTR(LPv, NSv, NTv) if (cv.LP == LPv && cv.LS == NSv) { \
                         ctx->dct_lds = sizeof(cplx) * ((size_t)16 * jx_dct_lay<LPv / 2, NSv>::RS + LPv / 2) + sizeof(double) * (4 * (LPv / 4 + 1) + 16 * 64 + 16); \
-                        HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_rowdct_kernel<LPv, NSv, 16, NTv, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->dct_lds)); }
+                        HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_rowdct_kernel<LPv, NSv, 16, NTv, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); }
                     JX_DCT_SIZES(JX_DCT_ATTR)
 #undef JX_DCT_ATTR
                     ctx->dct_ok = true;
@@ -1240,6 +1240,7 @@ static int launch_fused_conv(jx_ctx* ctx, int n, EvSet* es, bool dct) {
         int nrc = std::max(1, std::min(dc.NU, (8 * ctx->num_cu + 8 * gp8 - 1) / (8 * gp8)));
         if (const char* e = getenv("JOXSZ_DCT_NRC")) { int v = atoi(e); if (v > 0) nrc = std::min(v, dc.NU); }
         dc.nrc = nrc;
+        if (const char* e = getenv("JOXSZ_DCT_DBG")) dc.dbg = atoi(e);
         const dim3 gd((unsigned)(8 * gp8 * nrc));
         static unsigned long long* stamp_buf = nullptr;
         if (getenv("JOXSZ_DCT_STAMPS")) {
@@ -1247,9 +1248,11 @@ static int launch_fused_conv(jx_ctx* ctx, int n, EvSet* es, bool dct) {
             HIPCHK(ctx, hipMemsetAsync(stamp_buf, 0, sizeof(unsigned long long) * 8 * gd.x, st));
             if (gd.x <= 65536) dc.stamps = stamp_buf;
         }
+        size_t dlds = ctx->dct_lds;
+        if (const char* e = getenv("JOXSZ_DCT_LDS_KB")) dlds = std::max(dlds, (size_t)atoi(e) * 1024);     // occupancy experiments
 #define JX_DCT_GO(LPv, NSv, NTv) if (!done && cv.LP == LPv && cv.LS == NSv) { \
             if (ctx->f32) hipLaunchKernelGGL((jx_rowdct_kernel<LPv, NSv, 16, NTv, 0, float>), gd, dim3(NTv), ctx->dct_lds, st, dc, ctx->d_cf, ctx->d_Rt, ctx->d_x0t); \
-            else hipLaunchKernelGGL((jx_rowdct_kernel<LPv, NSv, 16, NTv, 0>), gd, dim3(NTv), ctx->dct_lds, st, dc, ctx->d_cf, ctx->d_Rt, ctx->d_x0t); \
+            else hipLaunchKernelGGL((jx_rowdct_kernel<LPv, NSv, 16, NTv, 0>), gd, dim3(NTv), dlds, st, dc, ctx->d_cf, ctx->d_Rt, ctx->d_x0t); \
             done = true; }
         JX_DCT_SIZES(JX_DCT_GO)
 #undef JX_DCT_GO
@@ -1258,11 +1261,12 @@ static int launch_fused_conv(jx_ctx* ctx, int n, EvSet* es, bool dct) {
             std::vector<unsigned long long> h((size_t)gd.x * 8);
             HIPCHK(ctx, hipStreamSynchronize(st));
             HIPCHK(ctx, hipMemcpy(h.data(), dc.stamps, h.size() * 8, hipMemcpyDeviceToHost));
-            double acc[6] = {0, 0, 0, 0, 0, 0};
-            for (unsigned b = 0; b < gd.x; ++b) for (int i = 0; i < 6; ++i) acc[i] += (double)h[(size_t)b * 8 + i];
+            double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (unsigned b = 0; b < gd.x; ++b) for (int i = 0; i < 8; ++i) acc[i] += (double)h[(size_t)b * 8 + i];
             const double rows = (double)dc.NU * ngroups;
             fprintf(stderr, "[dct stamps] cycles per (row, 16 walkers), wave 0: E %.0f | x0+barrier %.0f | stepA %.0f | barrier+stepB %.0f | barrier+post %.0f | barrier %.0f\n",
                     acc[0] / rows, acc[1] / rows, acc[2] / rows, acc[3] / rows, acc[4] / rows, acc[5] / rows);
+            fprintf(stderr, "[dct stamps]   inside E: evaluation %.0f | barrier %.0f | (z build = E - these)\n", acc[6] / rows, acc[7] / rows);
         }
     }
     const dim3 g1(cv.NU, (n + ctx->p1_rows - 1) / ctx->p1_rows);

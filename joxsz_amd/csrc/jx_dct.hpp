@@ -43,11 +43,15 @@ struct JxDct {
     const double* dw;               // [NU][na4][4] weights of y_k, y_{k+1}, M_k, M_{k+1}
     const int* x0k; const double* x0w;     // [NU], [NU][4] the same for column 0
     const cplx* tw_q;               // [Q] e^{-2 pi i n / Q}
+    int dbg;                        // timing experiments (JOXSZ_DCT_DBG): 1 = perfectly coalesced sample addresses (wrong results)
     unsigned long long* stamps;     // diagnostic build only (JOXSZ_DCT_STAMPS=1): [blocks][8] cycle counts of the phases of wave 0
     const double* pk;               // [Q/2 + 1][4]: cos/2, -sin/2 of 2 pi k / LP; 1/(2 sin(2 pi k/P)) (0 for k = 0); 1/(2 sin(2 pi (Q-k)/P))
 };
 
 // geometry of the evaluation phase for NS = amax + 1 samples per row
+#ifndef JX_DCT_EW
+#define JX_DCT_EW 8                // walkers whose spline requests are in flight together in the evaluation phase
+#endif
 template <int Q, int NS> struct jx_dct_geo {
     static constexpr int AMAX = NS - 1, GL = AMAX / 4;
     static constexpr int NPASS = (GL + 1 + 63) / 64;
@@ -139,11 +143,6 @@ jx_rowdct_kernel(JxDct d, const void* __restrict__ src_v, void* __restrict__ out
     }
     constexpr unsigned e_j1t = (unsigned)sizeof(T2) * Lay::zslot(Geo::GW + 1), e_j2t = (unsigned)sizeof(T2) * Lay::zslot(Q - Geo::GW - 1);
     const bool e_tail = Geo::TAIL && lane == (Geo::GW & 63);
-    // walker bases of this wave (byte pointers; a missing walker repeats the last one and is never stored)
-    const char* cfb[WPW];
-#pragma unroll
-    for (int i = 0; i < WPW; ++i) cfb[i] = reinterpret_cast<const char*>(cf + (size_t)min(w0 + min(wq + NWAVE * i, NW - 1), d.n - 1) * d.cf_ws);
-
     // ---- FFT roles
     const int frow = tid / TPR, fidx = tid - frow * TPR;
     const bool actA = frow < NW && fidx < L2, actB = frow < NW && fidx < L1;
@@ -157,7 +156,24 @@ jx_rowdct_kernel(JxDct d, const void* __restrict__ src_v, void* __restrict__ out
     char* Rw = reinterpret_cast<char*>(Rt + w0 + pw);
     const T2* Mw_post = M + pw * RS;
 
-    unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_t = 0;
+    // evaluation (MODE 0): byte offset of every walker's spline array from the group's first (wave-uniform -> scalar registers)
+    const char* cf0 = reinterpret_cast<const char*>(cf) + (size_t)w0 * d.cf_ws * 8;
+    unsigned woff[NW];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) woff[i] = (unsigned)min(i, d.n - 1 - w0) * (unsigned)(d.cf_ws * 8);   // a missing walker repeats the last one: never stored
+    constexpr int NSLT = (MODE == 0) ? (Geo::NEV + NT - 1) / NT : 1;
+    unsigned t_kb[NSLT];
+    double2 t_wa[NSLT], t_wb[NSLT];
+    if (MODE == 0 && rc < d.NU) {
+#pragma unroll
+        for (int sl = 0; sl < NSLT; ++sl) {
+            const size_t e = (size_t)rc * d.na4 + min(tid + NT * sl, Geo::NEV - 1);
+            t_kb[sl] = (unsigned)d.dk[e];
+            t_wa[sl] = *reinterpret_cast<const double2*>(d.dw + 4 * e);
+            t_wb[sl] = *reinterpret_cast<const double2*>(d.dw + 4 * e + 2);
+        }
+    }
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = 0;
     const bool stamping = d.stamps != nullptr;
 #define JX_STAMP(i) if (stamping) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_t; st_t = t_; }
     if (stamping) st_t = __builtin_amdgcn_s_memtime();
@@ -207,45 +223,58 @@ jx_rowdct_kernel(JxDct d, const void* __restrict__ src_v, void* __restrict__ out
             s_bs[w * 64 + lane] = bs;
         };
         if constexpr (MODE == 0) {
-            int kb[NPASS][4];
-            T wt[NPASS][4][4];
+            // thread = sample slot: a = tid, tid + NT, ... (one load instruction of a wave covers 64 neighbouring samples:
+            // a few cache lines of the walker's array); its table entry lives in registers and serves all NW walkers.
+            // The walkers stream through in groups of EW: the (y, M) requests of a whole group are in flight together,
+            // the next group's go out as soon as this one's registers are free.
+            constexpr int NSL = (Geo::NEV + NT - 1) / NT, EW = JX_DCT_EW;
+            static_assert(NW % EW == 0, "walker groups of the evaluation");
 #pragma unroll
-            for (int p = 0; p < NPASS; ++p)
+            for (int sl = 0; sl < NSL; ++sl) {
+                const int a = tid + NT * sl;
+                const bool live = a < Geo::NEV;
+                const unsigned kb = t_kb[sl];
+                const T w0y = (T)t_wa[sl].x, w1y = (T)t_wa[sl].y, w0m = (T)t_wb[sl].x, w1m = (T)t_wb[sl].y;
+                T* qdst = reinterpret_cast<T*>(M) + a;                        // + walker * (RS * sizeof(T2)): immediate offsets
+                double2 ld[EW][2];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) if (256 * p + 64 * j < Geo::NEV) {
-                    const size_t e = (size_t)u * d.na4 + 256 * p + 64 * j + lane;
-                    kb[p][j] = d.dk[e];
-                    const double2 wa = *reinterpret_cast<const double2*>(d.dw + 4 * e), wb = *reinterpret_cast<const double2*>(d.dw + 4 * e + 2);
-                    wt[p][j][0] = (T)wa.x; wt[p][j][1] = (T)wa.y; wt[p][j][2] = (T)wb.x; wt[p][j][3] = (T)wb.y;
-                }
-            // the (y, M) requests of walker i + 1 go out before walker i is worked on: two walkers' loads in flight
-            double2 ld[2][NPASS][4][2];
-#define JX_DCT_REQ(i_) \
-            _Pragma("unroll") for (int p = 0; p < NPASS; ++p) \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j) if (256 * p + 64 * j < Geo::NEV) { \
-                ld[(i_) & 1][p][j][0] = *reinterpret_cast<const double2*>(cfb[i_] + (unsigned)kb[p][j]); \
-                ld[(i_) & 1][p][j][1] = *reinterpret_cast<const double2*>(cfb[i_] + (unsigned)kb[p][j] + 16); }
-            JX_DCT_REQ(0)
+                for (int g0 = 0; g0 < NW; g0 += EW) {
 #pragma unroll
-            for (int i = 0; i < WPW; ++i) {
-                const int w = wq + NWAVE * i;                     // wave-uniform
-                if (i + 1 < WPW) { JX_DCT_REQ(i + 1) }
-                __builtin_amdgcn_sched_barrier(0);
-                if (NW % NWAVE == 0 || w < NW) {
-                    T* qa = reinterpret_cast<T*>(M + w * RS);             // the walker's row as scratch: q[a], a < NEV
+                    for (int i = 0; i < EW; ++i) {
+                        const unsigned off = kb + woff[g0 + i];               // scalar walker offset + per-lane slot offset (32 bits)
+                        ld[i][0] = *reinterpret_cast<const double2*>(cf0 + off);
+#ifdef JX_EXP_HALF_LOADS
+                        ld[i][1] = ld[i][0];
+#else
+                        ld[i][1] = *reinterpret_cast<const double2*>(cf0 + off + 16);
+#endif
+                    }
 #pragma unroll
-                    for (int p = 0; p < NPASS; ++p)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (256 * p + 64 * j < Geo::NEV) {
-                                const double2 p0 = ld[i & 1][p][j][0], p1 = ld[i & 1][p][j][1];
-                                const T v = fma(wt[p][j][3], (T)p1.y, fma(wt[p][j][2], (T)p0.y, fma(wt[p][j][1], (T)p1.x, wt[p][j][0] * (T)p0.x)));
-                                if (256 * p + 64 * j + 64 <= Geo::NEV || 256 * p + 64 * j + lane < Geo::NEV) qa[256 * p + 64 * j + lane] = v;
-                            }
-                    build_z(w);
+                    for (int i = 0; i < EW; ++i) {
+                        const T v = fma(w1m, (T)ld[i][1].y, fma(w0m, (T)ld[i][0].y, fma(w1y, (T)ld[i][1].x, w0y * (T)ld[i][0].x)));
+                        if (live) qdst[(g0 + i) * (RS * 2)] = v;               // (RS T2 slots = 2 RS samples per row)
+                    }
+                    __builtin_amdgcn_sched_barrier(0);            // (keeps the next group's requests behind this group's use: registers)
                 }
             }
-#undef JX_DCT_REQ
+            // the next row's table entries are requested now and arrive while this row is transformed
+            if (u + d.nrc < d.NU) {
+#pragma unroll
+                for (int sl = 0; sl < NSL; ++sl) {
+                    const size_t e = (size_t)(u + d.nrc) * d.na4 + min(tid + NT * sl, Geo::NEV - 1);
+                    t_kb[sl] = (unsigned)d.dk[e];
+                    t_wa[sl] = *reinterpret_cast<const double2*>(d.dw + 4 * e);
+                    t_wb[sl] = *reinterpret_cast<const double2*>(d.dw + 4 * e + 2);
+                }
+            }
+            JX_STAMP(6)
+            __syncthreads();
+            JX_STAMP(7)
+#pragma unroll
+            for (int i = 0; i < WPW; ++i) {
+                const int w = wq + NWAVE * i;
+                if (NW % NWAVE == 0 || w < NW) build_z(w);
+            }
         } else {
             // lanes = 16 walkers x NT/16 samples: 128-byte runs of the walker-minor source
             constexpr int KPT = NT / 16, NLD = (Geo::NEV + KPT - 1) / KPT;
@@ -323,13 +352,15 @@ jx_rowdct_kernel(JxDct d, const void* __restrict__ src_v, void* __restrict__ out
                     const T tx = fma(pa.x, dx, -pa.y * dy), ty = fma(pa.x, dy, pa.y * dx);            // t/2 = (w_k / 2) dd
                     const T Ak = fma((T)0.5, sx, ty), Aq = fma((T)0.5, sx, -ty), Ik = fma((T)0.5, sy, -tx), Iq = fma((T)-0.5, sy, -tx);
                     const T bk = (k == 0) ? b0 : pb.x * Ik, bq = pb.y * Iq;
-                    if (wok) {
+                    if (wok && !(d.dbg & 2)) {
                         const unsigned ok = (unsigned)k * kstr8;
-                        if (k < d.kact) *reinterpret_cast<T*>(Ru + ok) = Ak + bk;
-                        if (LP - k < d.kact) *reinterpret_cast<T*>(Ru + (unsigned)(LP - k) * kstr8) = Ak - bk;
+                        // (streamed out past the cache: these 0.35 GB per launch would otherwise push the walkers' spline arrays,
+                        //  which every row re-reads, out of the XCD's L2)
+                        if (k < d.kact) __builtin_nontemporal_store((T)(Ak + bk), reinterpret_cast<T*>(Ru + ok));
+                        if (LP - k < d.kact) __builtin_nontemporal_store((T)(Ak - bk), reinterpret_cast<T*>(Ru + (unsigned)(LP - k) * kstr8));
                         if (2 * k != Q) {
-                            if (Q - k < d.kact) *reinterpret_cast<T*>(Ru + (unsigned)(Q - k) * kstr8) = Aq + bq;
-                            if (k > 0 && Q + k < d.kact) *reinterpret_cast<T*>(Ru + (unsigned)(Q + k) * kstr8) = Aq - bq;
+                            if (Q - k < d.kact) __builtin_nontemporal_store((T)(Aq + bq), reinterpret_cast<T*>(Ru + (unsigned)(Q - k) * kstr8));
+                            if (k > 0 && Q + k < d.kact) __builtin_nontemporal_store((T)(Aq - bq), reinterpret_cast<T*>(Ru + (unsigned)(Q + k) * kstr8));
                         }
                     }
                 }
@@ -339,6 +370,6 @@ jx_rowdct_kernel(JxDct d, const void* __restrict__ src_v, void* __restrict__ out
         __syncthreads();                                        // the rows are free for the next u
         JX_STAMP(5)
     }
-    if (stamping && tid == 0) for (int i = 0; i < 6; ++i) d.stamps[(size_t)blockIdx.x * 8 + i] = st_acc[i];
+    if (stamping && tid == 0) for (int i = 0; i < 8; ++i) d.stamps[(size_t)blockIdx.x * 8 + i] = st_acc[i];
 #undef JX_STAMP
 }
