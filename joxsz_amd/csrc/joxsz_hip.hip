@@ -95,6 +95,11 @@ struct jx_ctx {
     bool dct_ok = false;
     JxDct dct{};
     double* d_cf = nullptr;           // [chunk][cf_ws] spline ordinates and moments, Abel kernel -> jx_rowdct_kernel
+    // the Abel kernel's phases 2-3 as one matrix product (jx_abel_gemm_kernel): operator, its geometry, the launch's pressure profiles
+    std::vector<double> h_Tm;         // host copy until the route that uses it is known
+    double* d_Tm = nullptr; int tm_ld = 0, tm_ntile = 0, tm_npair = 0;
+    double* d_ppc = nullptr;          // [chunk][N] prep kernel -> jx_abel_gemm_kernel
+    bool abel_gemm = false;
     size_t dct_lds = 0;
     // odd map sides (the reference's own shapes): the transfer-function step in real space, no transform of length S
     bool f32 = false;                  // jx_config.dtype == 1: fp32 storage between the kernels, fp32 evaluation and pass-1 transform
@@ -511,6 +516,18 @@ static int make_plans(jx_ctx* ctx, int batch, Plan3** out) {
     return JX_OK;
 }
 
+// the operator of jx_abel_gemm_kernel goes to the device once a route that evaluates the map rows from (y, M) exists
+static int setup_abel_gemm(jx_ctx* ctx, int chunk) {
+    if (ctx->h_Tm.empty() || ctx->d_Tm) return JX_OK;
+    int rc;
+    if ((rc = dev_put(ctx, ctx->h_Tm.data(), ctx->h_Tm.size(), &ctx->d_Tm))) return rc;
+    if ((rc = dev_new(ctx, (size_t)chunk * ctx->cfg.N, &ctx->d_ppc, true))) return rc;
+    std::vector<double>().swap(ctx->h_Tm);
+    const char* e = getenv("JOXSZ_ABEL_GEMM");
+    ctx->abel_gemm = !(e && atoi(e) == 0);
+    return JX_OK;
+}
+
 static int finalize_impl(jx_ctx* ctx) {
     if (!ctx) return JX_ERR_INVALID;
     if (ctx->finalized) { ctx->err = "jx_finalize called twice"; return JX_ERR_STATE; }
@@ -603,6 +620,27 @@ static int finalize_impl(jx_ctx* ctx) {
                 if (j >= 0 && j < N) band[(size_t)(k + K) * N + i] = G[(size_t)i * N + j];
             }
         double* p; if ((rc = dev_put(ctx, band.data(), band.size(), &p))) return rc; d.gband = p;
+        {
+            // Tm[j][2k] = y_scale A[k][j], Tm[j][2k+1] = sum_{|i-k|<=K} G[k][i] y_scale A[i][j]   (jx_abel_gemm_kernel)
+            std::vector<double> A;
+            jxt::abel_matrix(r, A);
+            const int rows = JX_AG_ROWS(N);
+            ctx->tm_ntile = (2 * N + 15) / 16;
+            ctx->tm_npair = (ctx->tm_ntile + 1) / 2;
+            ctx->tm_ld = 32 * ctx->tm_npair;
+            ctx->h_Tm.assign((size_t)rows * ctx->tm_ld, 0.0);
+            std::vector<long double> col(N);
+            for (int j = 0; j < N; ++j) {
+                double* row = &ctx->h_Tm[(size_t)j * ctx->tm_ld];
+                for (int k = 0; k <= j; ++k) row[2 * k] = d.y_scale * A[(size_t)k * N + j];
+                for (int k = 0; k < N; ++k) {
+                    long double m = 0.0L;
+                    const int i0 = std::max(0, k - K), i1 = std::min(std::min(N - 1, k + K), j);
+                    for (int i = i0; i <= i1; ++i) m += (long double)G[(size_t)k * N + i] * (long double)row[2 * i];
+                    row[2 * k + 1] = (double)m;
+                }
+            }
+        }
         if (c.calc_integ) {
             // cint = w . [f(0), y],  f(0) = y_0 - r_0^2/2 * (G y)_0 (value at 0 of the mirrored spline),  y = y_scale * A pp:
             // one weight per radius of the pressure profile
@@ -1005,6 +1043,7 @@ static int finalize_impl(jx_ctx* ctx) {
             jxt::twiddles(LPo / 2, LPo / 2, tq);
             if ((rc = dev_put(ctx, tq.data(), tq.size(), &qd))) return rc; dc.tw_q = (const cplx*)qd;
             if ((rc = dev_new(ctx, (size_t)chunk * dc.cf_ws, &ctx->d_cf, true))) return rc;
+            if ((rc = setup_abel_gemm(ctx, chunk))) return rc;
             JxDct& d3 = ctx->dct3;
             d3 = dc;
             d3.NU = r; d3.kact = nout; d3.tKU = RP; d3.n_in = oplan.kact; d3.s_kstr = (long long)RP * (long long)tW;
@@ -1127,6 +1166,7 @@ static int finalize_impl(jx_ctx* ctx) {
                     jxt::twiddles(cv.LP / 2, cv.LP / 2, tq);
                     if ((rc = dev_put(ctx, tq.data(), tq.size(), &qd))) return rc; dc.tw_q = (const cplx*)qd;
                     if ((rc = dev_new(ctx, (size_t)chunk * dc.cf_ws, &ctx->d_cf, true))) return rc;
+            if ((rc = setup_abel_gemm(ctx, chunk))) return rc;
 #define JX_DCT_ATTR(LPv, NSv, NTv) if (cv.LP == LPv && cv.LS == NSv) { \
                         ctx->dct_lds = sizeof(cplx) * ((size_t)16 * jx_dct_lay<LPv / 2, NSv>::RS + LPv / 2) + sizeof(double) * (4 * (LPv / 4 + 1) + 16 * 64 + 16); \
                         HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_rowdct_kernel<LPv, NSv, 16, NTv, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); }
@@ -1507,6 +1547,10 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
     double* base_buf = op_route ? ctx->d_base_op : ctx->d_base;
     double* cfac_buf = op_route ? ctx->d_cfac_op : ctx->d_cfac;
     double* sz0_buf = op_route ? ctx->d_sz0_op : ctx->d_sz0;           // null unless calc_integ
+    // default route: the map rows are evaluated inside pass 1 from the coefficients (no image), unless the image is asked for
+    const bool dct = !op_route && ctx->dct_ok && (ctx->odd || (use_fused(ctx, t.conv) && !t.need_img));
+    // ... and the coefficients come from one matrix product, unless the profile taps are asked for (they live in the Abel kernel)
+    const bool ag = dct && ctx->abel_gemm && !t.pp && !t.ab && !t.y && !d.inject_pp && !t.need_img;
     if (tm) {
         if (ctx->ev_inflight.size() > 2048 && (rc = drain_events(ctx))) return rc;
         if ((rc = get_evset(ctx, &es))) return rc;
@@ -1518,7 +1562,7 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
     {
         const size_t sh = sizeof(double) * (JX_LDS_HDR + (size_t)2 * d.N + 2 * d.nann + (size_t)d.nband * d.nann + 8);
         hipLaunchKernelGGL(jx_prep_kernel, dim3(n), dim3(JX_PREP_THREADS), sh, st, d, theta_dev, w0,
-                           base_buf, cfac_buf, op_route ? ctx->d_pp : (double*)nullptr, sz0_buf, t.tprof, t.xprofs, t.parts, t.integ);
+                           base_buf, cfac_buf, op_route ? ctx->d_pp : (ag ? ctx->d_ppc : (double*)nullptr), sz0_buf, t.tprof, t.xprofs, t.parts, t.integ);
     }
     if (tm) HIPCHK(ctx, hipEventRecord(es.e[1], st));
     if (op_route) {
@@ -1551,10 +1595,12 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
         HIPCHK(ctx, hipGetLastError());
         return JX_OK;
     }
-    // default route: the map rows are evaluated inside pass 1 from the coefficients (no image), unless the image is asked for
-    const bool dct = !op_route && ctx->dct_ok && (ctx->odd || (use_fused(ctx, t.conv) && !t.need_img));
     if (ctx->f32 && !op_route && !dct) { ctx->err = "dtype f32: the map and beam-convolved-map taps exist in the f64 build of the context only"; return JX_ERR_UNSUPPORTED; }
-    {
+    if (ag) {
+        const dim3 grid((n + 31) / 32, (ctx->tm_npair + 3) / 4);
+        hipLaunchKernelGGL((jx_abel_gemm_kernel<1>), grid, dim3(256), sizeof(double) * JX_OPM_JC * 33, st, ctx->d_ppc, n, d.N, ctx->d_Tm, ctx->tm_ld,
+                           d.K, ctx->tm_ntile, ctx->tm_npair, ctx->d_cf, ctx->dct.cf_ws);
+    } else {
         const bool vec2 = (d.S % 2 == 0) && (d.P % 2 == 0);
         const int npw = (d.quad && d.pairw == 2) ? 2 : 1;
         const dim3 grid0(((n + npw - 1) / npw) * d.map_split), block(ctx->map_threads);
@@ -1724,7 +1770,7 @@ static int build_operator(jx_ctx* ctx) {
     if ((rc = ensure_batch(ctx, ctx->chunk))) return rc;
     double* G = nullptr;
     double* inj = nullptr;
-    if ((rc = dev_new(ctx, (size_t)(N + 4) * ld, &G, true))) return rc;        // zero rows behind the last: the kernels read j in pairs / fours
+    if ((rc = dev_new(ctx, (size_t)(N + JX_OPM_GPAD) * ld, &G, true))) return rc;   // zero rows behind the last: the kernels read j in pairs / groups of 16, three k-steps ahead
     HIPCHK(ctx, hipMalloc((void**)&inj, sizeof(double) * (size_t)ctx->chunk * N));
     std::vector<double> th((size_t)ctx->chunk * c.ndim);
     {
@@ -2002,7 +2048,7 @@ int jx_debug_workspace(jx_ctx* ctx, int which, void** dev, int32_t geom[4]) {
     if (ctx->conv_mode != 2) { ctx->err = "work buffers of the hand-written convolution only"; return JX_ERR_UNSUPPORTED; }
     const JxConv& cv = ctx->cv;
     geom[0] = ctx->chunk; geom[3] = cv.xsym;
-    if (ctx->odd && which != 0 && which != 6) { ctx->err = "this work buffer does not exist on the odd-side route"; return JX_ERR_UNSUPPORTED; }
+    if (ctx->odd && which != 0 && which != 6 && which != 12) { ctx->err = "this work buffer does not exist on the odd-side route"; return JX_ERR_UNSUPPORTED; }
     switch (which) {
         case 0: *dev = ctx->d_img; geom[1] = ctx->d.quad ? ctx->d.q_nb : cv.S; geom[2] = (int)ctx->d.img_ld; geom[3] = ctx->d.quad; break;
         case 1: *dev = ctx->d_Y; geom[1] = cv.NU; geom[2] = cv.fir_ld; break;
@@ -2025,6 +2071,9 @@ int jx_debug_workspace(jx_ctx* ctx, int which, void** dev, int32_t geom[4]) {
             if (which == 8) { *dev = ctx->d_Ct0; geom[0] = ctx->tW; geom[1] = JX_CT0_X; geom[2] = 64; }
             if (which == 9) { *dev = ctx->d_x0t; geom[0] = 1; geom[1] = ctx->tKU; geom[2] = ctx->tW; }
             break;
+        case 12:
+            if (!ctx->dct_ok) { ctx->err = "no spline arrays in this mode"; return JX_ERR_UNSUPPORTED; }
+            *dev = ctx->d_cf; geom[1] = 1; geom[2] = (int)ctx->dct.cf_ws; break;
         default: ctx->err = "unknown work buffer"; return JX_ERR_INVALID;
     }
     return JX_OK;

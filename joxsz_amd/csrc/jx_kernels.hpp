@@ -1372,11 +1372,12 @@ jx_operator_kernel(JxDev c, const double* __restrict__ pp /*[launch][N], written
 // two agree to rounding, not bit for bit.)
 // LDS: [JX_OPM_JC][33] profile chunk.
 #define JX_OPM_JC 128
+#define JX_OPM_GPAD 32
 typedef double jx_op_v4d __attribute__((ext_vector_type(4)));
 template <int MT>
 __global__ void __launch_bounds__(256)
 jx_operator_mfma_kernel(const double* __restrict__ pp /*[launch][N]*/, int n, int N, int nrow,
-                        const double* __restrict__ Gt /*[N+4][ldg]*/, int ldg, double* __restrict__ rows_t /*[launch / 32][nrow][32]*/) {
+                        const double* __restrict__ Gt /*[N + JX_OPM_GPAD][ldg]*/, int ldg, double* __restrict__ rows_t /*[launch / 32][nrow][32]*/) {
     JX_LDS_DECL;
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1385,43 +1386,49 @@ jx_operator_mfma_kernel(const double* __restrict__ pp /*[launch][N]*/, int n, in
     jx_op_v4d acc[MT][2];
 #pragma unroll
     for (int t = 0; t < MT; ++t) { acc[t][0] = jx_op_v4d{0.0, 0.0, 0.0, 0.0}; acc[t][1] = jx_op_v4d{0.0, 0.0, 0.0, 0.0}; }
-    // A fragments two k-steps ahead of their use (register ring of three): an L2 round trip is longer than the eight
-    // matrix instructions of one k-step
+    // A fragments three k-steps ahead of their use in a ring of four named slots (the k loop is unrolled by four, so no
+    // value moves between registers and the waits count the requests in flight); G has JX_OPM_GPAD zero rows behind row N-1
     int toff[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) toff[t] = min(wv * MT + t, ntile - 1) * 16;   // (a tile past the last repeats it: never stored)
-    const int ktot = (N + 3) >> 2;                                             // G has zero rows behind row N-1
     const double* gb = Gt + (size_t)lk * ldg + li;
-    double a0[MT], a1[MT], a2[MT];
+    double a[4][MT];
 #pragma unroll
-    for (int t = 0; t < MT; ++t) {
-        a0[t] = gb[toff[t]];
-        a1[t] = (ktot > 1) ? gb[(size_t)4 * ldg + toff[t]] : 0.0;
-        a2[t] = 0.0;
-    }
+    for (int u = 0; u < 3; ++u)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) a[u][t] = gb[(size_t)(4 * u) * ldg + toff[t]];
+    // the profiles of the next chunk wait in registers while this chunk is multiplied
+    constexpr int NST = 32 * JX_OPM_JC / 256;
+    const int sl = tid / JX_OPM_JC, sj = tid % JX_OPM_JC;                       // consecutive threads: consecutive radii of one walker
+    double stg[NST];
+    auto fetch = [&](int j0) {
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            const int l = sl + i * (256 / JX_OPM_JC);
+            stg[i] = (wb + l < n && j0 + sj < N) ? pp[(size_t)(wb + l) * N + j0 + sj] : 0.0;
+        }
+    };
+    fetch(0);
     int kg = 0;                                                                // global k-step
     for (int j0 = 0; j0 < N; j0 += JX_OPM_JC) {
         __syncthreads();
-        for (int q = tid; q < 32 * JX_OPM_JC; q += 256) {
-            const int l = q / JX_OPM_JC, j = q - l * JX_OPM_JC;                  // consecutive threads: consecutive radii of one walker
-            sm[j * 33 + l] = (wb + l < n && j0 + j < N) ? pp[(size_t)(wb + l) * N + j0 + j] : 0.0;
-        }
+#pragma unroll
+        for (int i = 0; i < NST; ++i) sm[sj * 33 + sl + i * (256 / JX_OPM_JC)] = stg[i];
         __syncthreads();
-        const int ksteps = min(JX_OPM_JC, (N - j0 + 3) & ~3) >> 2;
-        for (int s = 0; s < ksteps; ++s, ++kg) {
-            if (kg + 2 < ktot) {
-                const double* gs = gb + (size_t)(4 * (kg + 2)) * ldg;
+        if (j0 + JX_OPM_JC < N) fetch(j0 + JX_OPM_JC);
+        const int kgroups = (min(JX_OPM_JC, N - j0) + 15) >> 4;
+        for (int sg = 0; sg < kgroups; ++sg, kg += 4) {
 #pragma unroll
-                for (int t = 0; t < MT; ++t) a2[t] = gs[toff[t]];
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int t = 0; t < MT; ++t) a[(u + 3) & 3][t] = gb[(size_t)(4 * (kg + u + 3)) * ldg + toff[t]];
+                const double b0 = sm[(4 * (4 * sg + u) + lk) * 33 + li], b1 = sm[(4 * (4 * sg + u) + lk) * 33 + 16 + li];
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    acc[t][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][t], b0, acc[t][0], 0, 0, 0);
+                    acc[t][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][t], b1, acc[t][1], 0, 0, 0);
+                }
             }
-            const double b0 = sm[(4 * s + lk) * 33 + li], b1 = sm[(4 * s + lk) * 33 + 16 + li];
-#pragma unroll
-            for (int t = 0; t < MT; ++t) {
-                acc[t][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[t], b0, acc[t][0], 0, 0, 0);
-                acc[t][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[t], b1, acc[t][1], 0, 0, 0);
-            }
-#pragma unroll
-            for (int t = 0; t < MT; ++t) { a0[t] = a1[t]; a1[t] = a2[t]; }
         }
     }
 #pragma unroll
@@ -1434,6 +1441,111 @@ jx_operator_mfma_kernel(const double* __restrict__ pp /*[launch][N]*/, int n, in
             for (int g = 0; g < 4; ++g) {
                 const int x = tile * 16 + lk + 4 * g;
                 if (tile < ntile && x < nrow && w < n) rows_t[((size_t)blockIdx.x * nrow + x) * 32 + nt * 16 + li] = acc[t][nt][g];
+            }
+        }
+    }
+}
+
+// Phases 2-3 of the Abel kernel for a whole launch as ONE matrix product on the fp64 matrix cores (default route).
+// The forward Abel transform (PyAbel direct_transform, joxsz_funcs.py:457), the Compton-y scale and the moments of the
+// mirrored cubic spline (interp1d 'cubic', joxsz_funcs.py:460) are linear in the pressure profile with constant
+// coefficients, so
+//     cf[w][2k] = y_k = sum_j Tm[j][2k] pp[w][j],     cf[w][2k+1] = M_k = sum_j Tm[j][2k+1] pp[w][j]
+// with Tm built once at jx_finalize (y_scale A and G_band y_scale A, the second accumulated in long double).  pp comes
+// from jx_prep_kernel, which evaluates the pressure on the whole grid anyway.  The kernels behind this one read cf as
+// before.  Operand layouts as in jx_lowrank_kernel; here A = the profiles of 32 walkers (two 16-walker tiles, staged
+// through LDS radius-major) and B = Tm tiles read straight from L2 two k-steps ahead of their use, so that D comes out
+// walker-major: register g of lane l = D[walker (l >> 4) + 4 g][column l & 15], i.e. 128-byte runs of a walker's array.
+// Tm is upper triangular up to the spline's band: column tile t (knots 8t .. 8t+7) has no entry above row 8t - K.  A
+// wave therefore owns NPW PAIRS of tiles (p, last - p), whose k-ranges add up to the same length for every pair, and
+// skips the matrix instructions of a tile above its first row (the fragment loads are clamped to that row instead:
+// they stay in the L1).
+#define JX_AG_R 8
+#define JX_AG_ROWS(N) ((((N) + 4 * JX_AG_R - 1) / (4 * JX_AG_R) + 1) * (4 * JX_AG_R))
+template <int NPW>
+__global__ void __launch_bounds__(256)
+jx_abel_gemm_kernel(const double* __restrict__ pp /*[launch][N]*/, int n, int N, const double* __restrict__ Tm /*[JX_AG_ROWS(N)][ldt], zero rows behind N-1*/,
+                    int ldt, int K, int ntile, int npair, double* __restrict__ cf /*[launch][cf_ws]*/, long long cf_ws) {
+    JX_LDS_DECL;
+    constexpr int NTL = 2 * NPW;
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wb = blockIdx.x * 32, grp = blockIdx.y;
+    const int ktot4 = (N + 4 * JX_AG_R - 1) / (4 * JX_AG_R) * JX_AG_R;          // k-steps, in whole groups of JX_AG_R
+    int tile[NTL], ks[NTL], toff[NTL];
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+        const int p = (grp * 4 + wv) * NPW + i;
+        tile[2 * i] = p; tile[2 * i + 1] = 2 * npair - 1 - p;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int t = tile[2 * i + h];
+            ks[2 * i + h] = (p < npair && t < ntile) ? (max(0, 8 * t - K) >> 2) : ktot4;   // first k-step with entries (ktot4: none)
+            toff[2 * i + h] = min(t, ntile - 1) * 16;
+        }
+    }
+    jx_op_v4d acc[NTL][2];
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) { acc[t][0] = jx_op_v4d{0.0, 0.0, 0.0, 0.0}; acc[t][1] = jx_op_v4d{0.0, 0.0, 0.0, 0.0}; }
+    // the block's first chunk of radii: the first row of its lowest tile
+    const int kminb = max(0, 8 * (grp * 4 * NPW) - K) >> 2;
+    const int j00 = (4 * kminb / JX_OPM_JC) * JX_OPM_JC;
+    int kg = j00 >> 2;
+    const double* gb = Tm + (size_t)lk * ldt + li;
+    // Tm fragments JX_AG_R - 1 k-steps ahead of their use in a ring of JX_AG_R named slots (the k loop is unrolled by as
+    // many, so no value is ever moved between registers and the waits count the requests still in flight): with one
+    // wave per SIMD nothing else hides the L2 round trip
+    constexpr int R = JX_AG_R;
+    double a[R][NTL];
+#pragma unroll
+    for (int u = 0; u < R - 1; ++u)
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) a[u][t] = gb[(size_t)(4 * max(kg + u, ks[t])) * ldt + toff[t]];
+    // the profiles of the next chunk wait in registers while this chunk is multiplied
+    constexpr int NST = 32 * JX_OPM_JC / 256;
+    const int sl = tid / JX_OPM_JC, sj = tid % JX_OPM_JC;                       // consecutive threads: consecutive radii of one walker
+    double stg[NST];
+    auto fetch = [&](int j0) {
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            const int l = sl + i * (256 / JX_OPM_JC);
+            stg[i] = (wb + l < n && j0 + sj < N) ? pp[(size_t)(wb + l) * N + j0 + sj] : 0.0;
+        }
+    };
+    fetch(j00);
+    for (int j0 = j00; j0 < N; j0 += JX_OPM_JC) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NST; ++i) sm[sj * 33 + sl + i * (256 / JX_OPM_JC)] = stg[i];
+        __syncthreads();
+        if (j0 + JX_OPM_JC < N) fetch(j0 + JX_OPM_JC);
+        const int kgroups = (min(JX_OPM_JC, N - j0) + 4 * R - 1) / (4 * R);
+        for (int sg = 0; sg < kgroups; ++sg, kg += R) {
+#pragma unroll
+            for (int u = 0; u < R; ++u) {
+#pragma unroll
+                for (int t = 0; t < NTL; ++t) a[(u + R - 1) % R][t] = gb[(size_t)(4 * max(kg + u + R - 1, ks[t])) * ldt + toff[t]];
+                const double p0 = sm[(4 * (R * sg + u) + lk) * 33 + li], p1 = sm[(4 * (R * sg + u) + lk) * 33 + 16 + li];
+#pragma unroll
+                for (int t = 0; t < NTL; ++t) {
+                    if (kg + u >= ks[t]) {
+                        acc[t][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(p0, a[u][t], acc[t][0], 0, 0, 0);
+                        acc[t][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(p1, a[u][t], acc[t][1], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) {
+        const long long col = (long long)tile[t] * 16 + li;
+        if (ks[t] >= ktot4 || col >= cf_ws) continue;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int w = wb + nt * 16 + lk + 4 * g;
+                if (w < n) cf[(size_t)w * cf_ws + col] = acc[t][nt][g];
             }
         }
     }

@@ -273,7 +273,7 @@ class HipContext:
     def workspace(self, which, walkers=None):
         """Test hook: copy of a work buffer of the hand-written convolution (``jx_debug_workspace``)."""
         ids = {'y_map': 0, 'row_spectra': 1, 'fir_rows': 2, 'col0': 3, 'job_rows': 4, 'row_index': 5,
-               'rows_t': 6, 'combined_t': 7, 'combined_col0_t': 8, 'x0_t': 9, 'combined': 10, 'combined_col0': 11}
+               'rows_t': 6, 'combined_t': 7, 'combined_col0_t': 8, 'x0_t': 9, 'combined': 10, 'combined_col0': 11, 'coefs': 12}
         ptr = ctypes.c_void_p()
         geom = (ctypes.c_int32 * 4)()
         self._chk(self.lib.jx_debug_workspace(self._h, ids[which], ctypes.byref(ptr), geom), 'jx_debug_workspace')
