@@ -78,8 +78,8 @@ def must_move_bytes(ctx, pb, lay, W):
     zp = 16.0 * (S // 2 + 1) * ((r + 13) // 14)       # partial Z per pass-3 block
     small = 8.0 * (pb.ndim + nrow + 2)
     per = {
-        'jx_prep_kernel': small,
-        'jx_abel_map_sym_kernel': 8.0 * pb.ndim + coef,
+        'jx_prep_kernel': small + 8.0 * N,                # (+ the pressure profile for the spline-array product)
+        'jx_abel_gemm_kernel': 8.0 * N + coef,
         'jx_rowdct_kernel': coef + rows_t,
         'jx_lowrank_kernel': rows_t + ct,
         'jx_rowtf2_kernel': ct + zp,
@@ -353,7 +353,7 @@ def main():
             stage_ms['pass3_ms'] = stage_ms.pop('tf_fft_ms') - stage_ms['gemm_ms']
         dct = bool(lay.get('fused')) and not os.environ.get('JOXSZ_DCT') == '0'
         stage_kernels = {'prep_ms': 'jx_prep_kernel',
-                         'abel_map_ms': 'jx_abel_map_sym_kernel (profile -> Abel -> spline moments)' if dct else 'jx_abel_map_sym_kernel',
+                         'abel_map_ms': 'jx_abel_gemm_kernel (Abel transform, y scale and spline moments of the launch as one fp64 MFMA product)' if dct else 'jx_abel_map_sym_kernel',
                          'beam_fft_ms': ('jx_rowdct_kernel (map rows evaluated from the spline + real-even row transform)' if dct
                                          else 'jx_rowfft2_kernel (pass 1)'),
                          'tf_fft_ms': 'jx_lowrank_kernel (fp64 MFMA GEMM) + jx_rowtf2_kernel (pass 3)', 'tail_ms': 'jx_tail_fft_kernel',

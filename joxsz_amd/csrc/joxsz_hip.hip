@@ -107,7 +107,7 @@ struct jx_ctx {
     JxDct dct3{};                      // combined rows back to real space (jx_rowdct_kernel, MODE 1)
     size_t dct3_lds = 0;
     JxLowrank lr2{};                   // second matrix product: real-space circular kernels x combined rows
-    int o_nmg = 0, o_bucket2 = 0, o_RPc = 0, o_ldb = 0, o_nout = 0;
+    int o_nmg = 0, o_bucket2 = 0, o_RPc = 0, o_ldb = 0, o_nout = 0, o_nh2 = 1;
     double *d_Ctp = nullptr, *d_cc = nullptr, *d_D2 = nullptr;
     const double* d_Kp = nullptr;
     // beam-convolved-map tap on the odd-side route (built on first use): FIR-only operator, one row per job
@@ -301,7 +301,7 @@ static void plan_odd(const jx_config& c, const std::vector<double>& beam, const 
         }
     }
     pl.kact = kact;
-    if ((S / 2 + 1 + 3) / 4 > JX_LR_KS) { pl.why = "map side beyond the second matrix product's k range"; return; }
+    if ((S / 2 + 1 + 7) / 8 > JX_LR_KS) { pl.why = "map side beyond the second matrix product's k range (two halves)"; return; }
     pl.ok = true;
 }
 
@@ -977,19 +977,20 @@ static int finalize_impl(jx_ctx* ctx) {
         if ((rc = dev_new(ctx, (size_t)chunk * d.img_ws, &ctx->d_img, true))) return rc;         // y_2d tap only
         if ((rc = dev_new(ctx, (size_t)chunk * d.q_nb, &d.xcol))) return rc;
         const int r = oplan.r, RP = ((r + 15) / 16) * 16, LPo = cv.LP, nout = S / 2 + 1;
-        const int KU = (cv.NU + 3) & ~3;
+        // K ranges beyond the largest compiled k-step bucket are split in two halves (the second launch accumulates)
+        const int nh1 = ((cv.NU + 3) / 4 > JX_LR_KS) ? 2 : 1, KU = (cv.NU + 4 * nh1 - 1) / (4 * nh1) * (4 * nh1), KUh = KU / nh1;
         int fb = 0;
-#define JX_LR_PICK(K) if (!fb && KU / 4 <= K) fb = K;
+#define JX_LR_PICK(K) if (!fb && KUh / 4 <= K) fb = K;
         JX_LR_BUCKETS(JX_LR_PICK)
 #undef JX_LR_PICK
-        const int ks2 = (nout + 3) / 4, KQ2 = 4 * ks2;
+        const int nh2 = ((nout + 3) / 4 > JX_LR_KS) ? 2 : 1, KQ2 = (nout + 4 * nh2 - 1) / (4 * nh2) * (4 * nh2), ks2 = KQ2 / nh2 / 4;
         int fb2 = 0;
 #define JX_LR_PICK(K) if (!fb2 && ks2 <= K) fb2 = K;
         JX_LR_BUCKETS(JX_LR_PICK)
 #undef JX_LR_PICK
         if (!fb || !fb2) { ctx->err = "odd-side route: matrix sizes beyond the compiled k-step buckets"; return JX_ERR_UNSUPPORTED; }
         const size_t tW = (chunk + 15) & ~15;
-        ctx->tW = (int)tW; ctx->tKU = KU; ctx->fused_bucket = fb; ctx->fused_nh = 1;
+        ctx->tW = (int)tW; ctx->tKU = KU; ctx->fused_bucket = fb; ctx->fused_nh = nh1; ctx->o_nh2 = nh2;
         ctx->o_RPc = RP; ctx->o_nout = nout; ctx->o_bucket2 = fb2; ctx->o_ldb = (nout + 15) & ~15;
         // first product: Wk [kact][RP][KU]
         {
@@ -997,7 +998,7 @@ static int finalize_impl(jx_ctx* ctx) {
             jxt::fused_row_operator(oplan.L, r, oplan.rows, S, cv.o, oplan.taps.data(), oplan.kact, cv.Ph, RP, KU, Wk);
             double* p2;
             if ((rc = dev_put(ctx, Wk.data(), Wk.size(), &p2))) return rc;
-            ctx->lrf.U = p2; ctx->lrf.r = r; ctx->lrf.ks = KU / 4; ctx->lrf.KQ = KU; ctx->lrf.nq = cv.NU;
+            ctx->lrf.U = p2; ctx->lrf.r = r; ctx->lrf.ks = KUh / 4; ctx->lrf.KQ = KU; ctx->lrf.nq = cv.NU;
         }
         // second product: K [nmg][r][64][KQ2]
         {
@@ -1008,10 +1009,10 @@ static int finalize_impl(jx_ctx* ctx) {
             ctx->d_Kp = p2;
             ctx->lr2.U = p2; ctx->lr2.r = 64; ctx->lr2.ks = ks2; ctx->lr2.KQ = KQ2; ctx->lr2.nq = nout;
         }
-        const size_t slack1 = (size_t)4 * fb - KU + 4;
+        const size_t slack1 = (size_t)4 * fb - KUh + 4;
         if ((rc = dev_new(ctx, ((size_t)cv.Ph * KU + slack1) * tW, &ctx->d_Rt, true))) return rc;
         if ((rc = dev_new(ctx, (size_t)cv.Ph * RP * tW, &ctx->d_Ctp, true))) return rc;
-        if ((rc = dev_new(ctx, ((size_t)4 * fb2 + 8) * RP * tW, &ctx->d_cc, true))) return rc;
+        if ((rc = dev_new(ctx, ((size_t)KQ2 - 4 * ks2 + 4 * fb2 + 8) * RP * tW, &ctx->d_cc, true))) return rc;
         if ((rc = dev_new(ctx, (size_t)tW * r * ctx->o_ldb, &ctx->d_D2, true))) return rc;
         // transforms: forward from the spline (row = distinct map row), inverse from the combined rows (row = rho)
         jxt::DctTables dt;
@@ -1383,17 +1384,20 @@ static int launch_odd_conv(jx_ctx* ctx, int n, EvSet* es) {
     }
     if (es) HIPCHK(ctx, hipEventRecord(es->e[3], st));
     // FIR + job combination: Ctp[kx][rho][w] = sum_u W_kx[rho][u] Rt[kx][u][w], 64 rows rho per launch
-    for (int g0 = 0; g0 < ctx->lrf.r; g0 += 64) {
-        JxLowrank lr = ctx->lrf;
-        lr.r = std::min(64, ctx->lrf.r - g0);
-        const int ntr = (lr.r + 15) / 16;
-        const size_t lds = (size_t)ntr * ctx->fused_bucket * 64 * sizeof(double);
-        const JxGemmSeg s0{ctx->lrf.U + (size_t)g0 * KU, ctx->d_Rt, ctx->d_Ctp + (size_t)g0 * tW, RP * KU, KU * tW, RP * tW, 1LL, ctx->kact, 0};
+    for (int g0 = 0; g0 < ctx->lrf.r; g0 += 64)
+        for (int h = 0; h < ctx->fused_nh; ++h) {                 // (K halves of large maps: the second launch adds to the first's results)
+            JxLowrank lr = ctx->lrf;
+            lr.r = std::min(64, ctx->lrf.r - g0);
+            const int ntr = (lr.r + 15) / 16;
+            const size_t lds = (size_t)ntr * ctx->fused_bucket * 64 * sizeof(double);
+            const long long Kh = 4LL * lr.ks;
+            const JxGemmSeg s0{ctx->lrf.U + (size_t)g0 * KU + (size_t)h * Kh, ctx->d_Rt + (size_t)h * Kh * tW, ctx->d_Ctp + (size_t)g0 * tW,
+                               RP * KU, KU * tW, RP * tW, 1LL, ctx->kact, h};
 #define JX_LR_GO(K, T) if (ctx->fused_bucket == K && ntr == T) \
-        hipLaunchKernelGGL((jx_lowrank_kernel<K, T>), dim3(ctx->num_cu), dim3(512), lds, st, lr, s0, none, 0LL, tW, 1LL, 0LL, tW, ncols, 1);
-        JX_LR_KINDS(JX_LR_GO)
+            hipLaunchKernelGGL((jx_lowrank_kernel<K, T>), dim3(ctx->num_cu), dim3(512), lds, st, lr, s0, none, 0LL, tW, 1LL, 0LL, tW, ncols, 1);
+            JX_LR_KINDS(JX_LR_GO)
 #undef JX_LR_GO
-    }
+        }
     if (es) { HIPCHK(ctx, hipEventRecord(es->e[6], st)); es->gemm = true; }
     {   // combined rows back to real space: cc[a][rho][w], a = 0..S/2 (offset from the centre column)
         JxDct d3 = ctx->dct3;
@@ -1409,17 +1413,20 @@ static int launch_odd_conv(jx_ctx* ctx, int n, EvSet* es) {
     {   // D2[w][rho][b] = sum_a K[rho][b][a] cc[a][rho][w], 64 rows b per launch
         const int r = ctx->lrf.r, nout = ctx->o_nout;
         const long long ldb = ctx->o_ldb, KQ2 = ctx->lr2.KQ;
-        for (int mg = 0; mg < ctx->o_nmg; ++mg) {
-            JxLowrank lr = ctx->lr2;
-            lr.r = std::min(64, nout - 64 * mg);
-            const int ntr = (lr.r + 15) / 16;
-            const size_t lds = (size_t)ntr * ctx->o_bucket2 * 64 * sizeof(double);
-            const JxGemmSeg s0{ctx->d_Kp + (size_t)mg * r * 64 * KQ2, ctx->d_cc, ctx->d_D2 + 64 * mg, 64 * KQ2, tW, ldb, (long long)r * ldb, r, 0};
+        for (int mg = 0; mg < ctx->o_nmg; ++mg)
+            for (int h = 0; h < ctx->o_nh2; ++h) {
+                JxLowrank lr = ctx->lr2;
+                lr.r = std::min(64, nout - 64 * mg);
+                const int ntr = (lr.r + 15) / 16;
+                const size_t lds = (size_t)ntr * ctx->o_bucket2 * 64 * sizeof(double);
+                const long long Kh = 4LL * lr.ks;
+                const JxGemmSeg s0{ctx->d_Kp + (size_t)mg * r * 64 * KQ2 + (size_t)h * Kh, ctx->d_cc + (size_t)h * Kh * RP * tW, ctx->d_D2 + 64 * mg,
+                                   64 * KQ2, tW, ldb, (long long)r * ldb, r, h};
 #define JX_LR_GO(K, T) if (ctx->o_bucket2 == K && ntr == T) \
-            hipLaunchKernelGGL((jx_lowrank_kernel<K, T>), dim3(ctx->num_cu), dim3(512), lds, st, lr, s0, none, 0LL, RP * tW, 1LL, 0LL, 1LL, ncols, 1);
-            JX_LR_KINDS(JX_LR_GO)
+                hipLaunchKernelGGL((jx_lowrank_kernel<K, T>), dim3(ctx->num_cu), dim3(512), lds, st, lr, s0, none, 0LL, RP * tW, 1LL, 0LL, 1LL, ncols, 1);
+                JX_LR_KINDS(JX_LR_GO)
 #undef JX_LR_GO
-        }
+            }
     }
     if (es) HIPCHK(ctx, hipEventRecord(es->e[4], st));
     return JX_OK;
@@ -1429,6 +1436,7 @@ static int launch_odd_conv(jx_ctx* ctx, int n, EvSet* es) {
 // job combination (identity in place of U), every job's row back to real space, then mirrored out to S x S.
 static int launch_odd_conv_tap(jx_ctx* ctx, int n) {
     const JxConv& cv = ctx->cv;
+    if (ctx->fused_nh > 1) { ctx->err = "conv_2d tap: not built for map sides whose matrix products run in two K halves (use conv = rocfft for this tap)"; return JX_ERR_UNSUPPORTED; }
     hipStream_t st = ctx->stream;
     const int NJ = cv.NJ, RPj = ((NJ + 15) / 16) * 16, S = cv.S, nout = S / 2 + 1;
     const long long tW = ctx->tW, KU = ctx->tKU;

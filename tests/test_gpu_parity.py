@@ -258,6 +258,32 @@ def test_odd_side_custom_route(S, N):
         assert abs(chisq[k] - st['chisq']) / 2 < 1e-6 * max(1.0, 1e-3 * st['chisq'])      # absolute near the mode, relative far from it
 
 
+def test_odd_side_1025():
+    """SURVEY 8(d)'s largest odd side (the odd neighbour of BASELINE configs[4]'s 1024^2 map, 1000-point grid) on the
+    hand-written route, against the oracle and the rocFFT sequence."""
+    from joxsz_amd import datasets
+    pb = datasets.synthetic_problem(S=1025, N=1000, seed=7)
+    p0 = orc.pars_dict(pb, datasets.fiducial_theta(pb))
+    datasets.fill_data(pb, orc.sz_stages(pb, p0)['bright'], orc.calc_profiles(pb, p0), seed=7)
+    th = datasets.walker_ball(pb, 6, spread=0.03, seed=7)
+    th[2, 1] = 9.0
+    post = _post(pb, conv='custom')
+    assert post.ctx.conv == 'custom' and post.ctx.conv_layout['fused'] == 1
+    got = post.log_prob(th)
+    rows = post.stage(th[:2], 'map_row')
+    post.close()
+    ref = _post(pb, conv='rocfft')
+    want_fft = ref.log_prob(th)
+    ref.close()
+    want = orc.log_posterior_batch(pb, th)
+    fin = np.isfinite(want)
+    assert fin.sum() == 5 and np.array_equal(np.isfinite(got), fin)
+    np.testing.assert_allclose(got[fin], want[fin], rtol=1e-9)
+    np.testing.assert_allclose(got[fin], want_fft[fin], rtol=1e-9)
+    for k in range(2):
+        assert _relerr(rows[k], orc.sz_stages(pb, orc.pars_dict(pb, th[k]))['map_row']) < RTOL_STAGE
+
+
 def test_custom_conv_with_and_without_row_symmetry(monkeypatch):
     """The row bookkeeping (distinct map rows, conv jobs) and the real-spectrum form of x-symmetric
     rows must not change any number: identity tables (JOXSZ_CONV_NOSYM=1), mirrored rows with complex
