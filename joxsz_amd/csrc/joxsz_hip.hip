@@ -528,6 +528,8 @@ static int setup_abel_gemm(jx_ctx* ctx, int chunk) {
     return JX_OK;
 }
 
+#define JX_LR_TOL_DEFAULT 1e-8
+#define JX_TRUNC_BOUND 2e-10
 static int finalize_impl(jx_ctx* ctx) {
     if (!ctx) return JX_ERR_INVALID;
     if (ctx->finalized) { ctx->err = "jx_finalize called twice"; return JX_ERR_STATE; }
@@ -556,7 +558,11 @@ static int finalize_impl(jx_ctx* ctx) {
     // singular-value cut of the transfer-function weights.  Small maps (a beam image comparable with the map: the extracted
     // row is then a small difference of large terms) keep every term above rounding, where it costs next to nothing; large
     // maps cut at 1e-10 (rank 46 instead of 61 at 512^2), which the truncation test of tests/test_gpu_parity.py bounds
-    double lr_tol0 = (S < 400) ? 1e-13 : 1e-10;
+    // singular-value cut of the transfer-function weights: 1e-8 of the largest leaves rank ~20 of ~290 at 512^2 and changes the
+    // extracted row by ~1e-11, chi^2/2 by < 5e-9 (scripts/tol_scan.py); small maps keep every term above rounding (there the
+    // 55-pixel beam is almost the map and the log-posterior a small difference of large terms); jx_finalize measures the
+    // effect on the caller's data and tightens the cut when it is not small enough
+    double lr_tol0 = (S < 400) ? 1e-13 : JX_LR_TOL_DEFAULT;
     if (const char* e = getenv("JOXSZ_LOWRANK_TOL")) { const double v2 = atof(e); if (v2 > 0.0 && v2 < 1e-6) lr_tol0 = v2; }
     if (ctx->lr_tol_override > 0.0) lr_tol0 = ctx->lr_tol_override;
     if (oddS && want != 1 && c.fft_pad == 0 && JX_FIR_TILE + 2 * o <= JX_FIR_RING && !getenv("JOXSZ_ODD_ROCFFT"))
@@ -2128,23 +2134,79 @@ static int truncation_probe(jx_ctx* ctx, double* est) {
     return done(JX_OK);
 }
 
+// the extracted row (joxsz_funcs.py:472) of one walker at the current parameter values, through the context's default route
+static int probe_row(jx_ctx* ctx, std::vector<double>& row) {
+    const jx_config& c = ctx->cfg;
+    int rc;
+    if ((rc = ensure_taps(ctx))) return rc;
+    if ((rc = ensure_batch(ctx, 1))) return rc;
+    std::vector<double> th(c.ndim);
+    const std::vector<double> pv = host_vec<double>(ctx, JX_T_PAR_VALS);
+    const std::vector<int32_t> ti = host_vec<int32_t>(ctx, JX_T_THAWED_IDX);
+    for (int k = 0; k < c.ndim; ++k) th[k] = pv[ti[k]];
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_theta, th.data(), sizeof(double) * th.size(), hipMemcpyHostToDevice, ctx->stream));
+    Taps t;
+    t.row = ctx->t_row; t.bright = ctx->t_bright; t.chisq = ctx->t_chisq; t.tprof = ctx->t_tprof;
+    t.xprofs = c.sz_only ? nullptr : ctx->t_xprofs; t.parts = ctx->t_parts;
+    if ((rc = run_chunk(ctx, ctx->d_theta, ctx->d_logp, 0, 1, t))) return rc;
+    row.resize(ctx->nrow);
+    HIPCHK(ctx, hipMemcpyAsync(row.data(), ctx->t_row, sizeof(double) * ctx->nrow, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return JX_OK;
+}
+
+// Odd map sides have no untruncated route inside the same context: the reference row comes from a second, small context
+// built with every singular value above rounding kept.
+static int odd_reference_row(jx_ctx* ctx, std::vector<double>& row) {
+    jx_config cfg = ctx->cfg;
+    cfg.max_batch = 16;
+    jx_ctx* ref = nullptr;
+    int rc = jx_create(&cfg, &ref);
+    if (rc) return rc;
+    ref->host = ctx->host; ref->have = ctx->have;
+    ref->lr_tol_override = 1e-13;
+    rc = finalize_impl(ref);
+    if (!rc) rc = probe_row(ref, row);
+    if (rc) ctx->err = "reference context of the truncation probe: " + ref->err;
+    jx_destroy(ref);
+    return rc;
+}
+
+static int measure_truncation(jx_ctx* ctx, const std::vector<double>& odd_ref, double* est) {
+    if (!ctx->odd) return truncation_probe(ctx, est);
+    *est = -1.0;
+    if (odd_ref.empty()) return JX_OK;
+    std::vector<double> row;
+    int rc = probe_row(ctx, row);
+    if (rc) return rc;
+    double mx = 0.0, df = 0.0;
+    for (size_t k = 0; k < row.size(); ++k) { mx = std::max(mx, std::fabs(odd_ref[k])); df = std::max(df, std::fabs(row[k] - odd_ref[k])); }
+    if (mx > 0.0 && std::isfinite(mx) && std::isfinite(df)) *est = df / mx;
+    return JX_OK;
+}
+
 int jx_finalize(jx_ctx* ctx) {
     int rc = finalize_impl(ctx);
     if (rc) return rc;
     if (const char* e = getenv("JOXSZ_TRUNC_PROBE")) { if (atoi(e) == 0) return JX_OK; }
-    if ((rc = truncation_probe(ctx, &ctx->trunc_est))) return rc;
-    // beyond 1e-9 of the row (a narrow beam, a rough transfer function): once more with every term above rounding kept
-    double bound = 1e-9;
+    // The default route drops small singular values of the transfer-function weights (and the columns past the beam's
+    // band limit).  What that costs is measured on the caller's own beam / transfer function / parameter values; beyond
+    // JX_TRUNC_BOUND of the row's largest entry the context is rebuilt with a cut a hundred times tighter, until the bound
+    // holds or every term above rounding is kept.
+    double bound = JX_TRUNC_BOUND;
     if (const char* e = getenv("JOXSZ_TRUNC_BOUND")) { const double v = atof(e); if (v > 0.0) bound = v; }
-    if (ctx->trunc_est > bound && ctx->lr_tol > 2e-13 && !getenv("JOXSZ_LOWRANK_TOL")) {
+    std::vector<double> odd_ref;
+    if (ctx->conv_mode == 2 && ctx->odd && !ctx->f32 && ctx->lr_tol > 2e-13 && (rc = odd_reference_row(ctx, odd_ref))) return rc;
+    if ((rc = measure_truncation(ctx, odd_ref, &ctx->trunc_est))) return rc;
+    while (ctx->trunc_est > bound && ctx->lr_tol > 2e-13 && !getenv("JOXSZ_LOWRANK_TOL")) {
         jx_ctx* fresh = nullptr;
         if ((rc = jx_create(&ctx->cfg, &fresh))) return rc;
         fresh->host = ctx->host; fresh->have = ctx->have;
-        fresh->lr_tol_override = 1e-13;
-        fresh->trunc_retried = 1;
+        fresh->lr_tol_override = std::max(1e-13, ctx->lr_tol * 1e-2);
+        fresh->trunc_retried = ctx->trunc_retried + 1;
         rc = finalize_impl(fresh);
-        if (!rc) rc = truncation_probe(fresh, &fresh->trunc_est);
-        if (rc) { ctx->err = "second finalize pass (tighter singular-value cut): " + fresh->err; jx_destroy(fresh); return rc; }
+        if (!rc) rc = measure_truncation(fresh, odd_ref, &fresh->trunc_est);
+        if (rc) { ctx->err = "finalize pass with a tighter singular-value cut: " + fresh->err; jx_destroy(fresh); return rc; }
         std::swap(*ctx, *fresh);                              // the caller's handle now owns the tighter build
         jx_destroy(fresh);
     }

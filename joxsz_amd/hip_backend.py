@@ -188,7 +188,7 @@ class HipContext:
             self.conv_layout = dict(zip(('xsym', 'quad', 'NU', 'NJ', 'ld', 'img_rows', 'img_ld', 'P', 'rank', 'fused', 'kact'), [int(v) for v in lay]))
         tr = (ctypes.c_double * 4)()
         self._chk(self.lib.jx_get_truncation(self._h, tr), 'jx_get_truncation')
-        self.truncation = dict(tol=tr[0], est_rel_row_err=tr[1], rank=int(tr[2]), retried=bool(tr[3]))
+        self.truncation = dict(tol=tr[0], est_rel_row_err=tr[1], rank=int(tr[2]), retried=int(tr[3]))
         self.route = 'map'
         route = route or os.environ.get('JOXSZ_ROUTE')
         if route and route != 'map':

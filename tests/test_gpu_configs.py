@@ -352,23 +352,47 @@ def test_fp32_variant_tolerance_sweep(S, N, W):
 
 def test_truncation_probe_and_automatic_tightening(monkeypatch):
     """jx_finalize measures what the low-rank cut and the band limit cost on the extracted row (jx_get_truncation); above
-    the bound (1e-9; lowered here to force the case) it rebuilds the tables with every term above rounding kept."""
+    the bound (2e-10 of the row's largest entry; lowered here to force the cases) it rebuilds the tables with a cut a
+    hundred times tighter, again and again until the bound holds or every term above rounding is kept."""
     from joxsz_amd import datasets
     pb = _problem(512, 500, seed=3)
     th = datasets.walker_ball(pb, 24, spread=0.03, seed=3)
     post = _post(pb)
     tr = post.ctx.truncation
-    assert tr['tol'] == 1e-10 and not tr['retried'] and 0 <= tr['est_rel_row_err'] < 1e-9 and tr['rank'] == post.ctx.conv_layout['rank']
+    assert tr['tol'] == 1e-8 and not tr['retried'] and 0 <= tr['est_rel_row_err'] < 2e-10 and tr['rank'] == post.ctx.conv_layout['rank']
     a = post.log_prob(th)
+    chi_a = post.stage(th, 'chisq')
     post.close()
-    monkeypatch.setenv('JOXSZ_TRUNC_BOUND', '1e-16')
+    monkeypatch.setenv('JOXSZ_TRUNC_BOUND', '1e-13')                  # one step: 1e-8 -> 1e-10 is enough for this bound
+    post = _post(pb)
+    tr1 = post.ctx.truncation
+    assert tr1['retried'] == 1 and tr1['tol'] == 1e-10 and tr1['rank'] > tr['rank'] and 0 <= tr1['est_rel_row_err'] < 1e-13
+    post.close()
+    monkeypatch.setenv('JOXSZ_TRUNC_BOUND', '1e-16')                  # never met: ends with every term above rounding
     post = _post(pb)
     tr2 = post.ctx.truncation
-    assert tr2['retried'] and tr2['tol'] == 1e-13 and tr2['rank'] > tr['rank'] and 0 <= tr2['est_rel_row_err'] < 1e-12
+    assert tr2['retried'] == 3 and tr2['tol'] == 1e-13 and tr2['rank'] > tr1['rank'] and 0 <= tr2['est_rel_row_err'] < 1e-12
     b = post.log_prob(th)
+    chi_b = post.stage(th, 'chisq')
     rows = post.stage(th[:4], 'map_row')
     post.close()
     fin = np.isfinite(a)
-    np.testing.assert_allclose(b[fin], a[fin], rtol=1e-10)
+    np.testing.assert_allclose(b[fin], a[fin], rtol=1e-9)
+    assert np.max(np.abs(chi_a[fin] - chi_b[fin])) / 2 < 1e-7         # the default cut against no cut: |d(chi^2/2)| far inside 1e-6
     st = orc.sz_stages(pb, orc.pars_dict(pb, th[0]))
     assert np.abs(rows[0] - st['map_row']).max() / np.abs(st['map_row']).max() < 1e-12
+
+
+def test_truncation_probe_odd_side(monkeypatch):
+    """Odd sides have no untruncated route inside the context: the probe compares with a second, small context built
+    with every term kept.  Same contract."""
+    pb = _problem(513, 500, seed=4)
+    post = _post(pb, conv='custom')
+    tr = post.ctx.truncation
+    assert tr['tol'] == 1e-8 and not tr['retried'] and 0 <= tr['est_rel_row_err'] < 2e-10
+    post.close()
+    monkeypatch.setenv('JOXSZ_TRUNC_BOUND', '1e-16')
+    post = _post(pb, conv='custom')
+    tr2 = post.ctx.truncation
+    assert tr2['retried'] >= 2 and tr2['tol'] <= 1e-12 and tr2['rank'] > tr['rank']      # (stops when the row equals the reference's)
+    post.close()

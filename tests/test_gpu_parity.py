@@ -162,7 +162,8 @@ def test_linearity_full_size():
     rows = post.stage(th, 'map_row')
     y2d = post.stage(th[:2], 'y_2d')
     post.close()
-    np.testing.assert_allclose(rows, rows_fft, rtol=1e-9, atol=1e-12 * np.abs(rows_fft).max())
+    # (the default route's singular-value cut moves the row by ~1e-11 of its largest entry: absolute, so relatively more in its tail)
+    np.testing.assert_allclose(rows, rows_fft, rtol=1e-9, atol=1e-10 * np.abs(rows_fft).max())
     np.testing.assert_allclose(rows[1], 2.0 * rows[0], rtol=1e-10, atol=1e-18)
     np.testing.assert_allclose(rows[2], 3.0 * rows[0], rtol=1e-10, atol=1e-18)
     np.testing.assert_allclose(y2d[1], 2.0 * y2d[0], rtol=1e-12)
@@ -254,7 +255,9 @@ def test_odd_side_custom_route(S, N):
         assert _relerr(y2d[k], st['y_2d']) < RTOL_STAGE
         assert _relerr(conv[k], st['conv_2d']) < RTOL_STAGE
         assert _relerr(rows[k], st['map_row']) < RTOL_STAGE
-        assert _relerr(bright[k], st['bright']) < RTOL_STAGE
+        # (the rejected walker's conversion factors grow by 36 orders of magnitude towards the edge, where the row has decayed by
+        #  four: what the singular-value cut leaves there, 1e-11 of the row's maximum, is then all that 'bright' shows)
+        assert _relerr(bright[k], st['bright']) < (RTOL_STAGE if fin[k] else 1e-6)
         assert abs(chisq[k] - st['chisq']) / 2 < 1e-6 * max(1.0, 1e-3 * st['chisq'])      # absolute near the mode, relative far from it
 
 
@@ -374,7 +377,7 @@ def test_lowrank_weights_against_full_weights(monkeypatch):
     'lowrank' = FIR kernel, then the combination (JOXSZ_FUSED=0), 'full' = one pass-3 row per job
     (JOXSZ_LOWRANK=0).  All three against each other and against the oracle; ragged walker counts included."""
     from joxsz_amd import datasets
-    # 'tight': every singular value above rounding (1e-13); the default cut is 1e-10
+    # 'tight': every singular value above rounding (1e-13); the default cut is 1e-8 at sides >= 400, 1e-13 below
     modes = {'fused': {}, 'tight': {'JOXSZ_LOWRANK_TOL': '1e-13'}, 'lowrank': {'JOXSZ_FUSED': '0', 'JOXSZ_LOWRANK_TOL': '1e-13'},
              'full': {'JOXSZ_LOWRANK': '0'}}
     for S, N, nw in ((256, 300, 6), (512, 500, 37)):
@@ -396,7 +399,7 @@ def test_lowrank_weights_against_full_weights(monkeypatch):
             for a, b in zip(res[mode][:2], res['full'][:2]):
                 np.testing.assert_allclose(a, b, rtol=1e-10, atol=1e-11 * np.abs(b).max(), err_msg=mode)
             np.testing.assert_allclose(res[mode][2], res['full'][2], rtol=1e-9, err_msg=mode)
-        for a, b in zip(res['fused'][:2], res['full'][:2]):               # default cut: 1e-10 of the largest singular value
+        for a, b in zip(res['fused'][:2], res['full'][:2]):               # default cut
             np.testing.assert_allclose(a, b, rtol=1e-7, atol=1e-8 * np.abs(b).max())
         np.testing.assert_allclose(res['fused'][2], res['full'][2], rtol=1e-9)
         assert res['fused'][3] <= res['tight'][3]
