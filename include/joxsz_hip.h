@@ -239,15 +239,17 @@ int  jx_get_conv_mode(jx_ctx* ctx);
  * img_rows x img_ld quadrant of distinct pixels per walker instead of the S x S map; NU distinct map rows, NJ
  * convolution jobs, P padded transform length; rank > 0: the transfer-function weights are applied in their
  * low-rank form and pass 3 transforms `rank` combined rows per walker instead of NJ (JOXSZ_LOWRANK=0 turns it
- * off, JOXSZ_LOWRANK_TOL sets the singular-value cut relative to the largest one, default 1e-10); fused = 1: the FIR along rows and that
+ * off, JOXSZ_LOWRANK_TOL sets the singular-value cut relative to the largest one, default 1e-8 at sides >= 400 and 1e-13 below,
+ * see jx_get_truncation); fused = 1: the FIR along rows and that
  * combination run as one matrix product per column kx on walker-minor row spectra (JOXSZ_FUSED=0: separate kernels),
  * for the kact columns below the beam's band limit (every tap beyond is under 0.03 of the singular-value cut, relative to the largest; JOXSZ_BANDLIMIT=0
  * keeps all P/2+1).  JX_ERR_UNSUPPORTED with the rocFFT back end. */
 int  jx_get_conv_layout(jx_ctx* ctx, int32_t out[12]);
 /* What the truncations of the default route cost on this problem: out = {singular-value cut in use, largest difference of
  * the extracted row between the truncated route and the route with every job and every column, relative to the row's
- * largest entry (measured once in jx_finalize on the current parameter values; -1 where nothing is truncated), rank, 1 if
- * jx_finalize found the first estimate above 1e-9 and rebuilt the tables with the cut at 1e-13}.
+ * largest entry (measured in jx_finalize on the current parameter values; odd sides: against a second, small context built
+ * with every term kept; -1 where nothing is truncated or nothing was measured), rank, number of times jx_finalize found the
+ * estimate above the bound (2e-10; JOXSZ_TRUNC_BOUND) and rebuilt the tables with a cut a hundred times tighter}.
  * JOXSZ_TRUNC_PROBE=0 skips the measurement, an explicit JOXSZ_LOWRANK_TOL is never overridden. */
 int  jx_get_truncation(jx_ctx* ctx, double out[4]);
 /* Test hook (hand-written convolution only): device address and geometry of a work buffer, holding the last
@@ -256,7 +258,8 @@ int  jx_get_truncation(jx_ctx* ctx, double out[4]);
  * [chunk][NJ+1][ld], 3 column-0 terms [chunk][o+1][NJ] (doubles); 4 conv row of each job [NJ], 5 distinct-row index
  * of each map row [S] (int32); fused route: 6 walker-minor row spectra [Ph][KU][tW], 7 combined rows [tW][Ph][64],
  * 8 their column-0 terms [tW][40][64], 9 walker-minor map column 0 [KU][tW]; low-rank route with separate kernels: 10 combined rows
- * [chunk][rank][ld], 11 their column-0 terms [chunk][o+1][rank] (geom[3] = rank).  geom = {chunk, rows, ld, xsym}: ld doubles per row, xsym = 1 when rows 1 and 2 hold
+ * [chunk][rank][ld], 11 their column-0 terms [chunk][o+1][rank] (geom[3] = rank); 12 spline ordinates and moments
+ * (y_k, M_k) [chunk][1][cf_ws] of the route that evaluates the map rows inside pass 1.  geom = {chunk, rows, ld, xsym}: ld doubles per row, xsym = 1 when rows 1 and 2 hold
  * the real array R of  Y(kx) = x0 + e^{-2 pi i kx (S/2)/P} R(kx),  0 when they hold (re, im) pairs. */
 int  jx_debug_workspace(jx_ctx* ctx, int which, void** dev, int32_t geom[4]);
 int  jx_device_count(void);
