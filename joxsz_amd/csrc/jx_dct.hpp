@@ -108,6 +108,7 @@ jx_rowdct_kernel(JxDct d, const void* __restrict__ src_v, void* __restrict__ out
     constexpr int L1 = Lay::L1, L2 = Lay::L2, L2P = Lay::L2P, TPR = Lay::TPR, RS = Lay::RS;
     constexpr int NWAVE = NT / 64, NPASS = Geo::NPASS, WPW = (NW + NWAVE - 1) / NWAVE;
     constexpr int DUMP = Lay::DUMP;
+    constexpr bool LEAN = LP >= 576;
     static_assert(NW * TPR <= NT, "one FFT task per thread");
     static_assert(NW == 16, "the post-processing lane map assumes 16 walkers per block");
     static_assert(NW * TPR <= 64 * (NWAVE - 1) || NWAVE == 1, "the last wave has no FFT task (it sums B[0])");
@@ -222,6 +223,71 @@ jx_rowdct_kernel(JxDct d, const void* __restrict__ src_v, void* __restrict__ out
             }
             s_bs[w * 64 + lane] = bs;
         };
+        // (two halves: all of a wave's walkers are read before any of them is written, so that the LDS round trips of the
+        //  walkers overlap; the compiler cannot see that the walkers' rows do not alias)
+        struct ZSrc { T2 qv[NPASS][3]; T q3[NPASS]; };
+        auto read_q = [&](int w, ZSrc& zs) {
+            const T* qa = reinterpret_cast<const T*>(M + w * RS);
+#pragma unroll
+            for (int p = 0; p < NPASS; ++p) {
+                const int g = min(lane + 64 * p, Geo::GW), gm = max(g, 1);
+                zs.qv[p][0] = *reinterpret_cast<const T2*>(qa + 4 * g);          // q[4g], q[4g+1]
+                zs.qv[p][1] = *reinterpret_cast<const T2*>(qa + 4 * g + 2);      // q[4g+2], q[4g+3]
+                zs.qv[p][2] = *reinterpret_cast<const T2*>(qa + 4 * gm - 2);     // q[4g-2], q[4g-1]
+                zs.q3[p] = qa[4 * gm - 3];                                        // q[4g-3]
+            }
+        };
+        auto write_z = [&](int w, const ZSrc& zs) {
+            char* Mw = reinterpret_cast<char*>(M + w * RS);
+            T bs = 0;
+#pragma unroll
+            for (int p = 0; p < NPASS; ++p) {
+                const T v0 = zs.qv[p][0].x, v1 = zs.qv[p][0].y, v2 = zs.qv[p][1].x, v3 = zs.qv[p][1].y;
+                const bool centre = (p == 0) && lane == 0;                          // q[-a] = q[a]
+                const T m1 = centre ? v1 : zs.qv[p][2].y, m2 = centre ? v2 : zs.qv[p][2].x, m3 = centre ? v3 : zs.q3[p];
+                if (!Geo::FULL || lane + 64 * p < Q / 2) bs += v1 + v3;   // (the group at the Nyquist index holds mirror copies)
+                if (e_on[p]) {
+                    T2 za, zb;
+                    za.x = v0 + v1 - m1; za.y = v2 + v3 - v1; zb.x = v0 - v1 + m1; zb.y = m2 - m1 + m3;
+                    *reinterpret_cast<T2*>(Mw + e_j1[p]) = za;
+                    *reinterpret_cast<T2*>(Mw + e_j2[p]) = zb;
+                }
+                if (Geo::TAIL && p == NPASS - 1 && e_tail) {   // the group behind the last one has no samples of its own
+                    T2 za, zb;
+                    za.x = -v3; za.y = 0; zb.x = v3; zb.y = v2 - v3 + v1;
+                    *reinterpret_cast<T2*>(Mw + e_j1t) = za;
+                    *reinterpret_cast<T2*>(Mw + e_j2t) = zb;
+                }
+            }
+#pragma unroll
+            for (int e0 = 0; e0 < Geo::NZFILL; e0 += 64) {
+                const int j = Geo::ZLO + e0 + lane;
+                T2 zz; zz.x = 0; zz.y = 0;
+                if (j <= Q - Geo::ZLO) *reinterpret_cast<T2*>(Mw + sizeof(T2) * ((j / L2) * L2P + (j % L2))) = zz;
+            }
+            s_bs[w * 64 + lane] = bs;
+        };
+        auto build_z_all = [&]() {
+            if constexpr (NPASS == 1) {
+                ZSrc zs[WPW];
+#pragma unroll
+                for (int i = 0; i < WPW; ++i) {
+                    const int w = wq + NWAVE * i;
+                    if (NW % NWAVE == 0 || w < NW) read_q(w, zs[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < WPW; ++i) {
+                    const int w = wq + NWAVE * i;
+                    if (NW % NWAVE == 0 || w < NW) write_z(w, zs[i]);
+                }
+            } else {                                             // rows with more groups per lane: one walker at a time (registers)
+#pragma unroll
+                for (int i = 0; i < WPW; ++i) {
+                    const int w = wq + NWAVE * i;
+                    if (NW % NWAVE == 0 || w < NW) build_z(w);
+                }
+            }
+        };
         if constexpr (MODE == 0) {
             // thread = sample slot: a = tid, tid + NT, ... (one load instruction of a wave covers 64 neighbouring samples:
             // a few cache lines of the walker's array); its table entry lives in registers and serves all NW walkers.
@@ -270,11 +336,7 @@ jx_rowdct_kernel(JxDct d, const void* __restrict__ src_v, void* __restrict__ out
             JX_STAMP(6)
             __syncthreads();
             JX_STAMP(7)
-#pragma unroll
-            for (int i = 0; i < WPW; ++i) {
-                const int w = wq + NWAVE * i;
-                if (NW % NWAVE == 0 || w < NW) build_z(w);
-            }
+            build_z_all();
         } else {
             // lanes = 16 walkers x NT/16 samples: 128-byte runs of the walker-minor source
             constexpr int KPT = NT / 16, NLD = (Geo::NEV + KPT - 1) / KPT;
@@ -293,11 +355,7 @@ jx_rowdct_kernel(JxDct d, const void* __restrict__ src_v, void* __restrict__ out
                 if (k < Geo::NEV) qa[k] = (km < d.n_in) ? sv[i] : (T)0;
             }
             __syncthreads();
-#pragma unroll
-            for (int i = 0; i < WPW; ++i) {
-                const int w = wq + NWAVE * i;
-                if (NW % NWAVE == 0 || w < NW) build_z(w);
-            }
+            build_z_all();
         }
         JX_STAMP(0)
         if (MODE == 0 && d.has_x0 && tid < NW && w0 + tid < d.n)
@@ -307,11 +365,14 @@ jx_rowdct_kernel(JxDct d, const void* __restrict__ src_v, void* __restrict__ out
         JX_STAMP(1)
 
         // ---------------- FFT of length Q, two levels, in place; the last wave sums B[0] meanwhile ----------------
+        T2* Mr = Mrow;
+        int fi = fidx;
+        if constexpr (LEAN) asm volatile("" : "+v"(Mr), "+v"(fi));
         if (actA) {
             jx_cT<T> x[L1];
 #pragma unroll
-            for (int n1 = 0; n1 < L1; ++n1) x[n1] = jx_ld(Mrow + n1 * L2P + fidx);
-            jx_stepA_store<Q, false>(x, fidx, Mrow, (const T2*)tw);
+            for (int n1 = 0; n1 < L1; ++n1) x[n1] = jx_ld(Mr + n1 * L2P + fi);
+            jx_stepA_store<Q, false>(x, fi, Mr, (const T2*)tw);
         }
         if (wq == NWAVE - 1) {
             // lane = (walker, quarter): 16 partial sums each, then two exchanges inside the quad
@@ -328,11 +389,11 @@ jx_rowdct_kernel(JxDct d, const void* __restrict__ src_v, void* __restrict__ out
         __syncthreads();
         {
             jx_cT<T> y[L2];
-            if (actB) jx_stepB_load<Q, false>(y, fidx, (const T2*)Mrow);
+            if (actB) jx_stepB_load<Q, false>(y, fi, (const T2*)Mr);
             __syncthreads();
             if (actB) {
 #pragma unroll
-                for (int k2 = 0; k2 < L2; ++k2) jx_st(Mrow + fidx + L1 * k2, y[k2]);
+                for (int k2 = 0; k2 < L2; ++k2) jx_st(Mr + fi + L1 * k2, y[k2]);
             }
         }
         JX_STAMP(3)
@@ -341,10 +402,15 @@ jx_rowdct_kernel(JxDct d, const void* __restrict__ src_v, void* __restrict__ out
         // ---------------- split, R(k) = A + B, walker-minor stores ----------------
         {
             const T b0 = s_b0[pw];
+            // LEAN instances (long rows): the values below that do not depend on the row are recomputed per row instead of
+            // living in registers across the whole loop -- the kernel otherwise spills (the short-row instances are faster
+            // with them hoisted: 233 registers, no spill)
+            int kb0 = 4 * wq + pkk;
+            if constexpr (LEAN) asm volatile("" : "+v"(kb0));
             char* Ru = Rw + (size_t)u * d.tW * sizeof(T);
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
-                const int k = it * KPI + 4 * wq + pkk;
+                const int k = it * KPI + kb0;
                 if (k <= Q / 2) {
                     const T2 zk = Mw_post[k], zq = Mw_post[k == 0 ? 0 : Q - k];
                     const T2 pa = *reinterpret_cast<const T2*>(s_pk + 4 * k), pb = *reinterpret_cast<const T2*>(s_pk + 4 * k + 2);
