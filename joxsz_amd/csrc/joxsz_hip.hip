@@ -627,25 +627,11 @@ static int finalize_impl(jx_ctx* ctx) {
             }
         double* p; if ((rc = dev_put(ctx, band.data(), band.size(), &p))) return rc; d.gband = p;
         {
-            // Tm[j][2k] = y_scale A[k][j], Tm[j][2k+1] = sum_{|i-k|<=K} G[k][i] y_scale A[i][j]   (jx_abel_gemm_kernel)
-            std::vector<double> A;
-            jxt::abel_matrix(r, A);
-            const int rows = JX_AG_ROWS(N);
+            // operator of jx_abel_gemm_kernel (jx_tables.hpp::abel_spline_operator)
             ctx->tm_ntile = (2 * N + 15) / 16;
             ctx->tm_npair = (ctx->tm_ntile + 1) / 2;
             ctx->tm_ld = 32 * ctx->tm_npair;
-            ctx->h_Tm.assign((size_t)rows * ctx->tm_ld, 0.0);
-            std::vector<long double> col(N);
-            for (int j = 0; j < N; ++j) {
-                double* row = &ctx->h_Tm[(size_t)j * ctx->tm_ld];
-                for (int k = 0; k <= j; ++k) row[2 * k] = d.y_scale * A[(size_t)k * N + j];
-                for (int k = 0; k < N; ++k) {
-                    long double m = 0.0L;
-                    const int i0 = std::max(0, k - K), i1 = std::min(std::min(N - 1, k + K), j);
-                    for (int i = i0; i <= i1; ++i) m += (long double)G[(size_t)k * N + i] * (long double)row[2 * i];
-                    row[2 * k + 1] = (double)m;
-                }
-            }
+            jxt::abel_spline_operator(r, G, K, d.y_scale, JX_AG_ROWS(N), ctx->tm_ld, ctx->h_Tm);
         }
         if (c.calc_integ) {
             // cint = w . [f(0), y],  f(0) = y_0 - r_0^2/2 * (G y)_0 (value at 0 of the mirrored spline),  y = y_scale * A pp:

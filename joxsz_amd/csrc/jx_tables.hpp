@@ -647,6 +647,31 @@ inline bool dct_tables(const std::vector<double>& Qrad /*[nb][na] radii*/, int n
     return true;
 }
 
+// ---------------------------------------------------------------------------------------
+// Operator of jx_abel_gemm_kernel: the spline ordinates and moments of a walker are linear in its pressure profile,
+//     y_k = sum_j Tm[j][2k] pp_j       Tm[j][2k]   = y_scale A[k][j]                          (joxsz_funcs.py:457-459)
+//     M_k = sum_j Tm[j][2k+1] pp_j     Tm[j][2k+1] = sum_{|i-k|<=K} G[k][i] y_scale A[i][j]   (joxsz_funcs.py:460)
+// A = abel_matrix(r) (upper triangular), G = mirrored_spline_op(r) restricted to its band of half-width K (what the Abel
+// kernel's own moment sums use).  The second product is accumulated in long double.  Row-major [rows][ld], zero padded.
+// ---------------------------------------------------------------------------------------
+inline void abel_spline_operator(const std::vector<double>& r, const std::vector<double>& G /*[N][N]*/, int K, double y_scale,
+                                 int rows, int ld, std::vector<double>& out) {
+    const int N = (int)r.size();
+    std::vector<double> A;
+    abel_matrix(r, A);
+    out.assign((size_t)rows * ld, 0.0);
+    for (int j = 0; j < N; ++j) {
+        double* row = &out[(size_t)j * ld];
+        for (int k = 0; k <= j; ++k) row[2 * k] = y_scale * A[(size_t)k * N + j];
+        for (int k = 0; k < N; ++k) {
+            long double m = 0.0L;
+            const int i0 = std::max(0, k - K), i1 = std::min(std::min(N - 1, k + K), j);
+            for (int i = i0; i <= i1; ++i) m += (long double)G[(size_t)k * N + i] * (long double)row[2 * i];
+            row[2 * k + 1] = (double)m;
+        }
+    }
+}
+
 // supported (LS = S/2, LP = P/2) pairs of the hand-written convolution
 inline int custom_conv_lp(int S, int o) {
     static const int pairs[][2] = {{16, 18}, {24, 48}, {32, 48}, {64, 96}, {128, 144}, {256, 288}, {512, 576}};

@@ -130,4 +130,39 @@ int jxt_custom_conv_lp(int S, int o) { return jxt::custom_conv_lp(S, o); }
 
 int jxt_next_smooth_even(int n) { return jxt::next_smooth_even(n); }
 
+// tables of jx_rowdct_kernel: dk [nb][na4], dw [nb][na4][4], x0k [nb], x0w [nb][4], pk [(LP/4 + 1)][4]; meta = {gl, na4, has_x0, amax}.
+// Call with dk == nullptr to get meta only (sizes).  Returns 0 when the sizes do not fit.
+int jxt_dct_tables(const double* Qrad, int na, int nb, const double* r, int n, int S, int LP, int* meta, int* dk, double* dw,
+                   int* x0k, double* x0w, double* pk) {
+    jxt::DctTables t;
+    if (!jxt::dct_tables(std::vector<double>(Qrad, Qrad + (size_t)na * nb), na, nb, std::vector<double>(r, r + n), S, LP, t)) return 0;
+    meta[0] = t.gl; meta[1] = t.na4; meta[2] = t.has_x0; meta[3] = t.amax;
+    if (!dk) return 1;
+    std::copy(t.dk.begin(), t.dk.end(), dk);
+    std::copy(t.dw.begin(), t.dw.end(), dw);
+    std::copy(t.x0k.begin(), t.x0k.end(), x0k);
+    std::copy(t.x0w.begin(), t.x0w.end(), x0w);
+    std::copy(t.pk.begin(), t.pk.end(), pk);
+    return 1;
+}
+
+// operator of jx_abel_gemm_kernel, [rows][ld]; G = the dense mirrored-spline operator, K = half-width of the band in use
+int jxt_abel_spline_operator(const double* r, int n, const double* G, int K, double y_scale, int rows, int ld, double* out) {
+    std::vector<double> o;
+    jxt::abel_spline_operator(std::vector<double>(r, r + n), std::vector<double>(G, G + (size_t)n * n), K, y_scale, rows, ld, o);
+    std::copy(o.begin(), o.end(), out);
+    return 0;
+}
+int jxt_band_halfwidth(const double* G, int n, double tol) { return jxt::band_halfwidth(std::vector<double>(G, G + (size_t)n * n), n, tol); }
+
+// real-space circular kernels of the odd-side route: out [nmg][r][64][KQ]; returns nmg
+int jxt_odd_rowspace_operator(const double* V, int r, int S, int KQ, double* out) {
+    std::vector<double> o;
+    int nmg = 0;
+    jxt::odd_rowspace_operator(std::vector<double>(V, V + (size_t)r * (S / 2 + 1)), r, S, KQ, o, &nmg);
+    if (out) std::copy(o.begin(), o.end(), out);
+    return nmg;
+}
+int jxt_custom_conv_lp_odd(int S, int o) { return jxt::custom_conv_lp_odd(S, o); }
+
 }  // extern "C"

@@ -292,3 +292,171 @@ def test_fused_row_operator(lib):
     got = np.einsum('bru,ub->rb', out[:, :r, :NU], R)
     np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-13)
     assert not out[:, r:].any() and not out[:, :, NU:].any()
+
+
+# ---------------------------------------------------------------------------------------
+# tables of this round's kernels: rows evaluated from the spline + quarter-length transform (jx_dct.hpp), the
+# spline-array operator (jx_abel_gemm_kernel), the real-space kernels of the odd-side route
+# ---------------------------------------------------------------------------------------
+IP = ctypes.POINTER(ctypes.c_int)
+
+
+def _dct_tables(lib, Qrad, r, S, LP):
+    nb, na = Qrad.shape
+    meta = np.zeros(4, np.int32)
+    none = ctypes.POINTER(ctypes.c_double)()
+    inone = ctypes.POINTER(ctypes.c_int)()
+    ok = lib.jxt_dct_tables(_p(Qrad), na, nb, _p(r), len(r), S, LP, meta.ctypes.data_as(IP), inone, none, inone, none, none)
+    if not ok:
+        return None
+    gl, na4, has_x0, amax = (int(v) for v in meta)
+    dk, dw = np.zeros((nb, na4), np.int32), np.zeros((nb, na4, 4))
+    x0k, x0w, pk = np.zeros(nb, np.int32), np.zeros((nb, 4)), np.zeros((LP // 4 + 1, 4))
+    assert lib.jxt_dct_tables(_p(Qrad), na, nb, _p(r), len(r), S, LP, meta.ctypes.data_as(IP), dk.ctypes.data_as(IP), _p(dw),
+                              x0k.ctypes.data_as(IP), _p(x0w), _p(pk))
+    return dict(gl=gl, na4=na4, has_x0=has_x0, amax=amax, dk=dk, dw=dw, x0k=x0k, x0w=x0w, pk=pk)
+
+
+def _mirrored_moments(lib, r, y):
+    n = len(r)
+    G = np.zeros((n, n))
+    assert lib.jxt_mirrored_spline_op(_p(r), n, _p(G)) > 0
+    return G, G @ y
+
+
+@pytest.mark.parametrize('S,LP', [(64, 48), (65, 48), (171, 144), (128, 96)])
+def test_row_sample_tables_reproduce_the_mirrored_spline(lib, S, LP):
+    """f(|x|) = A y_k + B y_{k+1} + C M_k + D M_{k+1} with the table's (interval, weights) per (row, sample) equals
+    interp1d((-r, r), (y, y), 'cubic', fill_value=(0, 0)) of joxsz_funcs.py:460-462 at the pixel radii of the quadrant."""
+    step, kpc_as = 2.0, 8.0012
+    h = step * kpc_as
+    N = int(0.8 * S)                                             # the grid ends inside the map: fill value 0 beyond it
+    r = h * np.arange(1, N + 1)
+    c = S // 2
+    a = np.arange(c + 1) * h
+    Qrad = np.ascontiguousarray(np.hypot(a[:, None], a[None, :]))      # centdistmat quadrant (joxsz_funcs.py:78-88)
+    t = _dct_tables(lib, Qrad, r, S, LP)
+    assert t is not None and t['has_x0'] == (S % 2 == 0) and t['amax'] == (c - 1 if S % 2 == 0 else c)
+    rng = np.random.default_rng(S)
+    y = np.exp(-(r / (12 * h)) ** 2) * (1 + 0.05 * rng.standard_normal(N))
+    G, M = _mirrored_moments(lib, r, y)
+    ym = np.zeros(2 * (N + 2))
+    ym[0:2 * N:2], ym[1:2 * N:2] = y, M
+    f = interp1d(np.concatenate((-r[::-1], r)), np.concatenate((y[::-1], y)), 'cubic', bounds_error=False, fill_value=(0., 0.))
+    for u in (0, 1, c // 3, c - 1, c):
+        k = t['dk'][u, :t['amax'] + 1] // 16
+        w = t['dw'][u, :t['amax'] + 1]
+        got = w[:, 0] * ym[2 * k] + w[:, 1] * ym[2 * k + 2] + w[:, 2] * ym[2 * k + 1] + w[:, 3] * ym[2 * k + 3]
+        want = f(Qrad[u, :t['amax'] + 1])
+        assert np.abs(got - want).max() < 1e-12 * np.abs(y).max(), u
+        assert np.all(t['dw'][u, t['amax'] + 1:] == 0)                                  # padding: zero weights
+        if t['has_x0']:
+            k0, w0 = t['x0k'][u] // 16, t['x0w'][u]
+            got0 = w0[0] * ym[2 * k0] + w0[1] * ym[2 * k0 + 2] + w0[2] * ym[2 * k0 + 1] + w0[3] * ym[2 * k0 + 3]
+            assert abs(got0 - f(Qrad[u, c])) < 1e-12 * np.abs(y).max()
+
+
+def _quarter_transform_with_tables(q, LP, pk):
+    """The steps of jx_rowdct_kernel in numpy: z from groups of four samples, one complex FFT of length Q = LP/2, the
+    real-even split with the kernel's own constants pk = (cos/2, -sin/2, 1/(2 sin(2 pi k/P)), 1/(2 sin(2 pi (Q-k)/P)))."""
+    Q, P = LP // 2, 2 * LP
+    amax = len(q) - 1
+    xq = lambda n: q[abs(n)] if abs(n) <= amax else 0.0
+    z = np.zeros(Q, complex)
+    for g in range(Q // 2 + 1):
+        if g <= (Q - 1) // 2:
+            z[g] = (xq(4 * g) + xq(4 * g + 1) - xq(4 * g - 1)) + 1j * (xq(4 * g + 2) + xq(4 * g + 3) - xq(4 * g + 1))
+        if g >= 1 and Q - g > (Q - 1) // 2:
+            z[Q - g] = (xq(4 * g) - xq(4 * g + 1) + xq(4 * g - 1)) + 1j * (xq(4 * g - 2) - xq(4 * g - 1) + xq(4 * g - 3))
+    Z = np.fft.fft(z)
+    R = np.zeros(LP + 1)
+    b0 = 2.0 * q[1::2].sum()
+    for k in range(Q // 2 + 1):
+        zk, zq = Z[k], Z[0 if k == 0 else Q - k]
+        sx, sy, dx, dy = zk.real + zq.real, zk.imag - zq.imag, zk.real - zq.real, zk.imag + zq.imag
+        tx, ty = pk[k, 0] * dx - pk[k, 1] * dy, pk[k, 0] * dy + pk[k, 1] * dx
+        Ak, Aq, Ik, Iq = 0.5 * sx + ty, 0.5 * sx - ty, 0.5 * sy - tx, -0.5 * sy - tx
+        bk, bq = (b0 if k == 0 else pk[k, 2] * Ik), pk[k, 3] * Iq
+        R[k], R[LP - k] = Ak + bk, Ak - bk
+        if 2 * k != Q:
+            R[Q - k] = Aq + bq
+            if k > 0:
+                R[Q + k] = Aq - bq
+    return R
+
+
+@pytest.mark.parametrize('S,LP', [(64, 48), (128, 96), (512, 288), (171, 144)])
+def test_quarter_length_real_even_transform_with_the_kernel_constants(lib, S, LP):
+    """R(k) = sum_n x[n] cos(2 pi k n / P) of an even row through one complex FFT of length P/4 (Cooley, Lewis & Welch),
+    with the split constants the library hands the kernel, against the direct cosine sum."""
+    c = S // 2
+    h = 16.0
+    a = np.arange(c + 1) * h
+    Qrad = np.ascontiguousarray(np.hypot(a[:, None], a[None, :]))
+    r = h * np.arange(1, int(0.9 * S) + 1)
+    t = _dct_tables(lib, Qrad, r, S, LP)
+    assert t is not None
+    rng = np.random.default_rng(LP)
+    amax = t['amax']
+    q = np.exp(-(np.arange(amax + 1) / (0.3 * amax)) ** 2) + 0.01 * rng.standard_normal(amax + 1)
+    n = np.arange(-amax, amax + 1)
+    want = (q[np.abs(n)][None, :] * np.cos(2 * np.pi * np.arange(LP + 1)[:, None] * n[None, :] / (2 * LP))).sum(1)
+    got = _quarter_transform_with_tables(q, LP, t['pk'])
+    assert np.abs(got - want).max() < 1e-13 * np.abs(want).max()
+
+
+@pytest.mark.parametrize('name', ['uniform', 'arange', 'ragged'])
+def test_abel_spline_operator(lib, name):
+    """Tm of jx_abel_gemm_kernel: pp @ Tm gives (y_k, M_k) = (y_scale * PyAbel forward transform, moments of the mirrored
+    cubic spline through it), i.e. joxsz_funcs.py:457-460 as one matrix."""
+    r = np.ascontiguousarray(GRIDS[name], dtype=np.float64)
+    n = len(r)
+    G = np.zeros((n, n))
+    assert lib.jxt_mirrored_spline_op(_p(r), n, _p(G)) > 0
+    lib.jxt_band_halfwidth.argtypes = [DP, ctypes.c_int, ctypes.c_double]
+    K = lib.jxt_band_halfwidth(_p(G), n, 1e-20)
+    assert 0 < K < n
+    y_scale = 3.0856776e21 * 6.6524587158e-25 / 510.9989
+    rows, ld = n + 40, 2 * n + 24
+    Tm = np.zeros((rows, ld))
+    lib.jxt_abel_spline_operator.argtypes = [DP, ctypes.c_int, DP, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int, DP]
+    lib.jxt_abel_spline_operator(_p(r), n, _p(G), K, y_scale, rows, ld, _p(Tm))
+    assert np.all(Tm[n:] == 0) and np.all(Tm[:, 2 * n:] == 0)
+    pp = 0.3 / ((r / 800.) ** 0.014 * (1 + (r / 800.) ** 1.3) ** 3.3)
+    cf = pp @ Tm[:n]
+    ab = pyabel_direct.direct_transform_forward(pp, r)
+    y = y_scale * ab
+    np.testing.assert_allclose(cf[0:2 * n:2], y, rtol=1e-12, atol=1e-14 * np.abs(y).max())
+    M = G @ y
+    assert np.abs(cf[1:2 * n:2] - M).max() < 1e-11 * np.abs(M).max()
+    # the triangle the kernel skips: column tile t (knots 8t..8t+7) has no entry above row 8t - K
+    for t in range((2 * n + 15) // 16):
+        assert np.all(Tm[:max(0, 8 * t - K), 16 * t:16 * t + 16] == 0)
+
+
+@pytest.mark.parametrize('S', [31, 65, 171])
+def test_odd_rowspace_operator(lib, S):
+    """K[rho][b][a] of the odd-side route: sum_a K[b][a] cc[c + a] equals the circular convolution of the symmetric row cc
+    with k_rho[j] = sum_kc v[kc] cos(2 pi kc j / S), read at columns c + b (joxsz_funcs.py:466-467, 472 in real space)."""
+    c, Sh, nout = S // 2, S // 2 + 1, S // 2 + 1
+    rng = np.random.default_rng(S)
+    r = 3
+    V = rng.standard_normal((r, Sh))
+    KQ = (nout + 3) // 4 * 4
+    nmg = lib.jxt_odd_rowspace_operator(_p(V), r, S, KQ, ctypes.POINTER(ctypes.c_double)())
+    out = np.zeros((nmg, r, 64, KQ))
+    assert lib.jxt_odd_rowspace_operator(_p(V), r, S, KQ, _p(out)) == nmg == (nout + 63) // 64
+    half = rng.standard_normal(nout)
+    cc = np.concatenate((half[:0:-1], half))                            # symmetric about the centre column c, length S
+    j = np.arange(S)
+    for rho in range(r):
+        k = (V[rho][None, :] * np.cos(2 * np.pi * np.arange(Sh)[None, :] * j[:, None] / S)).sum(1)
+        want = np.array([sum(k[(c + b - x) % S] * cc[x] for x in range(S)) for b in range(nout)])
+        Kb = np.concatenate([out[mg, rho] for mg in range(nmg)])[:nout, :nout]
+        got = Kb @ half
+        assert np.abs(got - want).max() < 1e-12 * np.abs(want).max()
+
+
+def test_odd_padded_lengths(lib):
+    for S, o, want in ((171, 27, 144), (31, 4, 48), (513, 27, 288), (1025, 27, 576), (65, 27, 48), (512, 27, 0), (2001, 27, 0)):
+        assert lib.jxt_custom_conv_lp_odd(S, o) == want
