@@ -101,6 +101,7 @@ struct jx_ctx {
     double* d_ppc = nullptr;          // [chunk][N] prep kernel -> jx_abel_gemm_kernel
     bool abel_gemm = false;
     size_t dct_lds = 0;
+    int dct_nw = 16;                  // walkers per block of the coefficient-fed pass 1 (8 for the longest rows: two blocks then share a CU's LDS)
     // odd map sides (the reference's own shapes): the transfer-function step in real space, no transform of length S
     bool f32 = false;                  // jx_config.dtype == 1: fp32 storage between the kernels, fp32 evaluation and pass-1 transform
     bool odd = false;
@@ -162,7 +163,11 @@ static int g_rocfft_refs = 0;
 // the generic instances for odd map sides: any sample count up to LP - 4 (LP, threads per block)
 #define JX_DCT_ODD_SIZES(X) X(48, 192) X(96, 192) X(144, 256) X(288, 256) X(576, 384)
 // samples per distinct row, threads per block: 16 walkers x max(L1, L2) FFT tasks + one wave without one)
-#define JX_DCT_SIZES(X) X(48, 24, 192) X(48, 32, 192) X(96, 64, 192) X(144, 128, 256) X(288, 256, 256) X(576, 512, 384)
+#define JX_DCT_SIZES(X) X(48, 24, 192, 16) X(48, 32, 192, 16) X(96, 64, 192, 16) X(144, 128, 256, 16) X(288, 256, 256, 16) X(576, 512, 256, 8)
+// LDS bytes of an instance: [NW][RS] complex rows + twiddles [LP/2] + split constants + per-lane odd sums + B[0]  (esz = sizeof(T))
+template <int LP, int NS> static size_t dct_lds_bytes(int nw, size_t esz) {
+    return 2 * esz * ((size_t)nw * jx_dct_lay<LP / 2, NS>::RS + LP / 2) + esz * (4 * (LP / 4 + 1) + (size_t)nw * 64 + nw);
+}
 
 #define HIPCHK(ctx, call)                                                                          \
     do {                                                                                           \
@@ -1139,7 +1144,7 @@ static int finalize_impl(jx_ctx* ctx) {
             if (want_dct) {
                 jxt::DctTables dt;
                 bool have_kernel = false;
-#define JX_DCT_HAS(LPv, NSv, NTv) if (cv.LP == LPv && cv.LS == NSv && S % 2 == 0) have_kernel = true;
+#define JX_DCT_HAS(LPv, NSv, NTv, NWv) if (cv.LP == LPv && cv.LS == NSv && S % 2 == 0) { have_kernel = true; ctx->dct_nw = NWv; }
                 JX_DCT_SIZES(JX_DCT_HAS)
 #undef JX_DCT_HAS
                 if (have_kernel && jxt::dct_tables(Qtab, qn, qn, r_grid, S, cv.LP, dt) && dt.amax + 1 == cv.LS &&
@@ -1160,9 +1165,9 @@ static int finalize_impl(jx_ctx* ctx) {
                     if ((rc = dev_put(ctx, tq.data(), tq.size(), &qd))) return rc; dc.tw_q = (const cplx*)qd;
                     if ((rc = dev_new(ctx, (size_t)chunk * dc.cf_ws, &ctx->d_cf, true))) return rc;
             if ((rc = setup_abel_gemm(ctx, chunk))) return rc;
-#define JX_DCT_ATTR(LPv, NSv, NTv) if (cv.LP == LPv && cv.LS == NSv) { \
-                        ctx->dct_lds = sizeof(cplx) * ((size_t)16 * jx_dct_lay<LPv / 2, NSv>::RS + LPv / 2) + sizeof(double) * (4 * (LPv / 4 + 1) + 16 * 64 + 16); \
-                        HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_rowdct_kernel<LPv, NSv, 16, NTv, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); }
+#define JX_DCT_ATTR(LPv, NSv, NTv, NWv) if (cv.LP == LPv && cv.LS == NSv) { \
+                        ctx->dct_lds = dct_lds_bytes<LPv, NSv>(NWv, sizeof(double)); \
+                        HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_rowdct_kernel<LPv, NSv, NWv, NTv, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); }
                     JX_DCT_SIZES(JX_DCT_ATTR)
 #undef JX_DCT_ATTR
                     ctx->dct_ok = true;
@@ -1176,8 +1181,9 @@ static int finalize_impl(jx_ctx* ctx) {
                 return JX_ERR_UNSUPPORTED;
             }
             ctx->f32 = true;
-#define JX_DCT_ATTR(LPv, NSv, NTv) if (cv.LP == LPv && cv.LS == NSv) \
-            HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_rowdct_kernel<LPv, NSv, 16, NTv, 0, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->dct_lds));
+#define JX_DCT_ATTR(LPv, NSv, NTv, NWv) if (cv.LP == LPv && cv.LS == NSv) { \
+            ctx->dct_lds = dct_lds_bytes<LPv, NSv>(NWv, sizeof(float)); \
+            HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_rowdct_kernel<LPv, NSv, NWv, NTv, 0, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->dct_lds)); }
             JX_DCT_SIZES(JX_DCT_ATTR)
 #undef JX_DCT_ATTR
 #define JX_LR_ATTR(K, T) HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_lowrank_kernel<K, T, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)JX_LR_LDS_MAX));
@@ -1268,7 +1274,7 @@ static int launch_fused_conv(jx_ctx* ctx, int n, EvSet* es, bool dct) {
     if (dct) {
         JxDct dc = ctx->dct;
         dc.n = n;
-        const int ngroups = (n + 15) / 16, gp8 = (ngroups + 7) / 8;
+        const int ngroups = (n + ctx->dct_nw - 1) / ctx->dct_nw, gp8 = (ngroups + 7) / 8;
         // row classes: enough blocks to fill the device a few times over, at least ~8 rows per block when there are many
         int nrc = std::max(1, std::min(dc.NU, (8 * ctx->num_cu + 8 * gp8 - 1) / (8 * gp8)));
         if (const char* e = getenv("JOXSZ_DCT_NRC")) { int v = atoi(e); if (v > 0) nrc = std::min(v, dc.NU); }
@@ -1283,9 +1289,9 @@ static int launch_fused_conv(jx_ctx* ctx, int n, EvSet* es, bool dct) {
         }
         size_t dlds = ctx->dct_lds;
         if (const char* e = getenv("JOXSZ_DCT_LDS_KB")) dlds = std::max(dlds, (size_t)atoi(e) * 1024);     // occupancy experiments
-#define JX_DCT_GO(LPv, NSv, NTv) if (!done && cv.LP == LPv && cv.LS == NSv) { \
-            if (ctx->f32) hipLaunchKernelGGL((jx_rowdct_kernel<LPv, NSv, 16, NTv, 0, float>), gd, dim3(NTv), ctx->dct_lds, st, dc, ctx->d_cf, ctx->d_Rt, ctx->d_x0t); \
-            else hipLaunchKernelGGL((jx_rowdct_kernel<LPv, NSv, 16, NTv, 0>), gd, dim3(NTv), dlds, st, dc, ctx->d_cf, ctx->d_Rt, ctx->d_x0t); \
+#define JX_DCT_GO(LPv, NSv, NTv, NWv) if (!done && cv.LP == LPv && cv.LS == NSv) { \
+            if (ctx->f32) hipLaunchKernelGGL((jx_rowdct_kernel<LPv, NSv, NWv, NTv, 0, float>), gd, dim3(NTv), dlds, st, dc, ctx->d_cf, ctx->d_Rt, ctx->d_x0t); \
+            else hipLaunchKernelGGL((jx_rowdct_kernel<LPv, NSv, NWv, NTv, 0>), gd, dim3(NTv), dlds, st, dc, ctx->d_cf, ctx->d_Rt, ctx->d_x0t); \
             done = true; }
         JX_DCT_SIZES(JX_DCT_GO)
 #undef JX_DCT_GO

@@ -110,7 +110,7 @@ jx_rowdct_kernel(JxDct d, const void* __restrict__ src_v, void* __restrict__ out
     constexpr int DUMP = Lay::DUMP;
     constexpr bool LEAN = LP >= 576;
     static_assert(NW * TPR <= NT, "one FFT task per thread");
-    static_assert(NW == 16, "the post-processing lane map assumes 16 walkers per block");
+    static_assert(NW == 16 || NW == 8, "the post-processing lane map: 4 k x 16 walkers or 8 k x 8 walkers per wave");
     static_assert(NW * TPR <= 64 * (NWAVE - 1) || NWAVE == 1, "the last wave has no FFT task (it sums B[0])");
     extern __shared__ __attribute__((aligned(16))) double sm[];
     T2* M = reinterpret_cast<T2*>(sm);                       // [NW][RS]
@@ -150,8 +150,9 @@ jx_rowdct_kernel(JxDct d, const void* __restrict__ src_v, void* __restrict__ out
     T2* Mrow = M + frow * RS;
 
     // ---- post-processing: 4 consecutive k x 16 walkers per wave
-    constexpr int KPI = 4 * NWAVE, NIT = (Q / 2 + 1 + KPI - 1) / KPI;
-    const int pkk = lane & 3, pw = lane >> 2;
+    constexpr int KPW = 64 / NW;                                 // consecutive k per wave and trip
+    constexpr int KPI = KPW * NWAVE, NIT = (Q / 2 + 1 + KPI - 1) / KPI;
+    const int pkk = lane & (KPW - 1), pw = lane / KPW;
     const bool wok = w0 + pw < d.n;
     const unsigned kstr8 = (unsigned)(d.tKU * d.tW * sizeof(T));   // bytes between consecutive k of Rt (k * kstr8 < 2^32: checked on the host)
     char* Rw = reinterpret_cast<char*>(Rt + w0 + pw);
@@ -338,9 +339,9 @@ jx_rowdct_kernel(JxDct d, const void* __restrict__ src_v, void* __restrict__ out
             JX_STAMP(7)
             build_z_all();
         } else {
-            // lanes = 16 walkers x NT/16 samples: 128-byte runs of the walker-minor source
-            constexpr int KPT = NT / 16, NLD = (Geo::NEV + KPT - 1) / KPT;
-            const int sw = tid & 15, sk = tid >> 4;
+            // lanes = NW walkers x NT/NW samples: 128-byte (64-byte) runs of the walker-minor source
+            constexpr int KPT = NT / NW, NLD = (Geo::NEV + KPT - 1) / KPT;
+            const int sw = tid & (NW - 1), sk = tid / NW;
             const T* sp = reinterpret_cast<const T*>(src_v) + (size_t)u * d.tW + min(w0 + sw, d.n - 1);
             T sv[NLD];
 #pragma unroll
@@ -375,15 +376,15 @@ jx_rowdct_kernel(JxDct d, const void* __restrict__ src_v, void* __restrict__ out
             jx_stepA_store<Q, false>(x, fi, Mr, (const T2*)tw);
         }
         if (wq == NWAVE - 1) {
-            // lane = (walker, quarter): 16 partial sums each, then two exchanges inside the quad
-            const T2* bp = reinterpret_cast<const T2*>(s_bs + (lane >> 2) * 64 + (lane & 3) * 16);
+            // lane = (walker, part): 64 / KPW partial sums each, then exchanges inside the group of KPW lanes
+            const T2* bp = reinterpret_cast<const T2*>(s_bs + (lane / KPW) * 64 + (lane & (KPW - 1)) * (64 / KPW));
             T a0 = 0, a1 = 0;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { const T2 v = bp[i]; a0 += v.x; a1 += v.y; }
+            for (int i = 0; i < 32 / KPW; ++i) { const T2 v = bp[i]; a0 += v.x; a1 += v.y; }
             T a = a0 + a1;
-            a += __shfl_xor(a, 1, 64);
-            a += __shfl_xor(a, 2, 64);
-            if ((lane & 3) == 0) s_b0[lane >> 2] = (T)2 * a;
+#pragma unroll
+            for (int m = 1; m < KPW; m <<= 1) a += __shfl_xor(a, m, 64);
+            if ((lane & (KPW - 1)) == 0) s_b0[lane / KPW] = (T)2 * a;
         }
         JX_STAMP(2)
         __syncthreads();
@@ -405,7 +406,7 @@ jx_rowdct_kernel(JxDct d, const void* __restrict__ src_v, void* __restrict__ out
             // LEAN instances (long rows): the values below that do not depend on the row are recomputed per row instead of
             // living in registers across the whole loop -- the kernel otherwise spills (the short-row instances are faster
             // with them hoisted: 233 registers, no spill)
-            int kb0 = 4 * wq + pkk;
+            int kb0 = KPW * wq + pkk;
             if constexpr (LEAN) asm volatile("" : "+v"(kb0));
             char* Ru = Rw + (size_t)u * d.tW * sizeof(T);
 #pragma unroll
