@@ -397,8 +397,8 @@ def main():
                          'survey_8d_GBps': survey_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0,
                          'note': 'achieved = bytes this kernel must move (walker inputs read once, outputs written once: DESIGN 5) / its '
                                  'HIP-event duration; survey_8d_* = SURVEY 8(d)\'s S^2*8 B per walker for the map stage, which this route '
-                                 'never writes (the rows are evaluated from the spline inside this kernel). The kernel is bound by fp64 '
-                                 'issue and LDS, not by HBM: see profiles/ SQ counters'},
+                                 'never writes (the rows are evaluated from the spline inside this kernel). The kernel is not HBM-bound: '
+                                 'its floor is on-chip data movement (vector-L1 return path 64 B/clk, LDS 128 B/clk; DESIGN 5.3)'},
             # the whole step against the HBM roofline: measured bytes (rocprofv3 PMC, profiles/*_pmc_traffic.json) and compulsory bytes
             'roofline_step': {'bound': 'hbm', 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'ms_per_step': ms_step,
                               'traffic_bytes_per_step': step_pmc,
