@@ -101,6 +101,8 @@ struct jx_ctx {
     double* d_ppc = nullptr;          // [chunk][N] prep kernel -> jx_abel_gemm_kernel
     bool abel_gemm = false;
     size_t dct_lds = 0;
+    void* samp_buf[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // jx_sample work buffers (grow-only)
+    size_t samp_cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int dct_nw = 16;                  // walkers per block of the coefficient-fed pass 1 (8 for the longest rows: two blocks then share a CU's LDS)
     // odd map sides (the reference's own shapes): the transfer-function step in real space, no transform of length S
     bool f32 = false;                  // jx_config.dtype == 1: fp32 storage between the kernels, fp32 evaluation and pass-1 transform
@@ -1721,19 +1723,29 @@ int jx_sample(jx_ctx* ctx, const double* theta0, int nwalkers, int nsteps, doubl
     hipStream_t st = ctx->stream;
     double *x = nullptr, *lp = nullptr, *q = nullptr, *lq = nullptr, *zz = nullptr, *chain = nullptr, *lps = nullptr;
     long long* nacc = nullptr;
-    auto cleanup = [&]() {
-        for (void* p : {(void*)x, (void*)lp, (void*)q, (void*)lq, (void*)zz, (void*)chain, (void*)lps, (void*)nacc}) if (p) (void)hipFree(p);
-    };
+    auto cleanup = [&]() {};                                     // (the work buffers stay with the context: grow-only, freed by jx_destroy)
 #define SCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { ctx->err = std::string(#expr) + ": " + hipGetErrorString(e_); cleanup(); return JX_ERR_HIP; } } while (0)
-    SCHK(hipMalloc((void**)&x, sizeof(double) * (size_t)W * ndim));
-    SCHK(hipMalloc((void**)&lp, sizeof(double) * (size_t)W));
-    SCHK(hipMalloc((void**)&q, sizeof(double) * (size_t)half * ndim));
-    SCHK(hipMalloc((void**)&lq, sizeof(double) * (size_t)half));
-    SCHK(hipMalloc((void**)&zz, sizeof(double) * (size_t)half));
-    SCHK(hipMalloc((void**)&nacc, sizeof(long long) * (size_t)W));
+    // a run re-uses the buffers of the last one when they are large enough: repeated runs (burn-in, then sampling) do not
+    // pay for device allocations of tens of megabytes each time
+    auto grab = [&](int slot, size_t bytes, void** out) -> hipError_t {
+        if (ctx->samp_cap[slot] < bytes) {
+            if (ctx->samp_buf[slot]) { (void)hipStreamSynchronize(st); (void)hipFree(ctx->samp_buf[slot]); ctx->samp_buf[slot] = nullptr; ctx->samp_cap[slot] = 0; }
+            const hipError_t e = hipMalloc(&ctx->samp_buf[slot], bytes);
+            if (e != hipSuccess) return e;
+            ctx->samp_cap[slot] = bytes;
+        }
+        *out = ctx->samp_buf[slot];
+        return hipSuccess;
+    };
+    SCHK(grab(0, sizeof(double) * (size_t)W * ndim, (void**)&x));
+    SCHK(grab(1, sizeof(double) * (size_t)W, (void**)&lp));
+    SCHK(grab(2, sizeof(double) * (size_t)half * ndim, (void**)&q));
+    SCHK(grab(3, sizeof(double) * (size_t)half, (void**)&lq));
+    SCHK(grab(4, sizeof(double) * (size_t)half, (void**)&zz));
+    SCHK(grab(5, sizeof(long long) * (size_t)W, (void**)&nacc));
     SCHK(hipMemsetAsync(nacc, 0, sizeof(long long) * (size_t)W, st));
-    if (chain_out && nsteps) SCHK(hipMalloc((void**)&chain, sizeof(double) * (size_t)nsteps * W * ndim));
-    if (logp_out && nsteps) SCHK(hipMalloc((void**)&lps, sizeof(double) * (size_t)nsteps * W));
+    if (chain_out && nsteps) SCHK(grab(6, sizeof(double) * (size_t)nsteps * W * ndim, (void**)&chain));
+    if (logp_out && nsteps) SCHK(grab(7, sizeof(double) * (size_t)nsteps * W, (void**)&lps));
     SCHK(hipMemcpyAsync(x, theta0, sizeof(double) * (size_t)W * ndim, hipMemcpyHostToDevice, st));
     int rc = jx_eval_device(ctx, x, W, lp);
     if (rc) { cleanup(); return rc; }
@@ -2225,6 +2237,7 @@ void jx_destroy(jx_ctx* ctx) {
     for (auto& es : ctx->ev_inflight) for (int k = 0; k < 7; ++k) (void)hipEventDestroy(es.e[k]);
     for (auto& es : ctx->ev_free) for (int k = 0; k < 7; ++k) (void)hipEventDestroy(es.e[k]);
     for (void* p : ctx->dev_allocs) (void)hipFree(p);
+    for (void* p : ctx->samp_buf) if (p) (void)hipFree(p);
     if (ctx->d_work) (void)hipFree(ctx->d_work);
     if (ctx->d_theta) (void)hipFree(ctx->d_theta);
     if (ctx->d_logp) (void)hipFree(ctx->d_logp);
