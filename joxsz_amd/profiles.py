@@ -20,6 +20,8 @@ mu_g = 1.6605389e-24
 G_cgs = 6.67428e-8
 solar_mass_g = 1.9891e33
 mu_e = 1.18
+ne_nH = 1.21                         # electrons per hydrogen atom (solar abundances); [MEM] of mbproj2.physconstants, unpinned
+yr_s = 31556926.0
 MU_GAS = 0.61                        # joxsz_funcs.py:428 default
 
 
@@ -87,15 +89,40 @@ def cumulative_gas_mass(r_kpc, dens):
     return mgas * inner_fraction(edg) + inside
 
 
-def thermodynamic_profs(pb, thetas, r_kpc=None):
-    """joxsz_plots.py:219-247 without the cooling time (it needs mbproj2's bolometric flux table, which is not part of
-    the problem description): dict of [M, N] arrays ``dens, temp, press, entr, cmgas, tempx``."""
+def bolometric_flux(lnT_grid, lnflux_Z0, lnflux_Z1, T_keV, Z_solar, ne_cm3):
+    """``CountRate.getFlux(T, Z, ne)`` of mbproj2 as joxsz_plots.py:243 calls it: the flux at the observer (erg cm^-2 s^-1)
+    per cm^3 of emitting plasma.  mbproj2 tabulates it with XSPEC the way it tabulates the count rates the reference's
+    ``addCountCache`` documents (joxsz_funcs.py:667-680): ln(flux) for Z = 0 and Z = 1 solar at unit density on the ln T
+    grid ``CountRate.Tlogvals``; linear in ln T (clamped to the grid ends), linear in Z, times n_e^2.  XSPEC is not
+    available here, so the two tables are inputs, like the count-rate tables of the likelihood ([MEM], unpinned)."""
+    lnT = np.log(np.asarray(T_keV, dtype=np.float64))
+    f0 = np.exp(np.interp(lnT, lnT_grid, lnflux_Z0))
+    f1 = np.exp(np.interp(lnT, lnT_grid, lnflux_Z1))
+    return (f0 + (f1 - f0) * Z_solar) * np.asarray(ne_cm3) ** 2
+
+
+def cooling_time(dens, temp, Z_solar, flux_table, D_L_Mpc):
+    """joxsz_plots.py:242-244 (years): enthalpy per volume (5/2) n_e (1 + 1/ne_nH) k T over the bolometric emissivity, the
+    latter recovered from the flux at the observer as flux * 4 pi D_L^2.  ``flux_table`` = (lnT_grid, lnflux_Z0, lnflux_Z1)."""
+    flux = bolometric_flux(flux_table[0], flux_table[1], flux_table[2], temp, Z_solar, dens)
+    return 2.5 * dens * (1. + 1. / ne_nH) * temp * keV_erg / (flux * 4. * np.pi * (D_L_Mpc * Mpc_cm) ** 2) / yr_s
+
+
+def thermodynamic_profs(pb, thetas, r_kpc=None, flux_table=None, D_L_Mpc=None):
+    """joxsz_plots.py:219-247: dict of [M, N] arrays ``dens, temp, press, entr, cmgas, tempx`` and, when the bolometric flux
+    tables (``flux_table`` = (lnT_grid, lnflux_Z0, lnflux_Z1), see ``bolometric_flux``) and the luminosity distance are
+    given, ``cool`` (the cooling time in years)."""
     r = pb.r_pp if r_kpc is None else np.asarray(r_kpc, np.float64)
     p = par_table(pb, thetas)
     dens, press = density(pb, p, r), pressure(p, r)
     temp = press / dens
-    return dict(dens=dens, temp=temp, press=press, entr=temp / dens ** (2 / 3), cmgas=cumulative_gas_mass(r, dens),
-                tempx=temp * 10 ** p['log(T_X/T_{SZ})'])
+    out = dict(dens=dens, temp=temp, press=press, entr=temp / dens ** (2 / 3), cmgas=cumulative_gas_mass(r, dens),
+               tempx=temp * 10 ** p['log(T_X/T_{SZ})'])
+    if flux_table is not None:
+        if D_L_Mpc is None:
+            raise ValueError('the cooling time needs the luminosity distance (cosmology.D_L, Mpc)')
+        out['cool'] = cooling_time(dens, temp, p['Z'], flux_table, D_L_Mpc)
+    return out
 
 
 def critical_mass(r_kpc, z, H0, WM, WV, delta=500):
@@ -141,9 +168,10 @@ def overdensity_radius(pb, thetas, cosmo, delta=500, start_opt=700., tol=1.48e-8
 
 
 # ---- chain summaries (equal-tailed intervals), joxsz_plots.py:249-273, 341-376, 451-478 ----
-def comp_rad_profs(cube, pb, num='all', seed=None, ci=95):
-    """Returns dict name -> [3, N] (lower, median, upper) for dens, temp, press, entr, cmgas, tempx."""
-    prof = thermodynamic_profs(pb, chain_subset(cube, num, seed))
+def comp_rad_profs(cube, pb, num='all', seed=None, ci=95, flux_table=None, D_L_Mpc=None):
+    """Returns dict name -> [3, N] (lower, median, upper) for dens, temp, press, entr, cmgas, tempx (and cool, given the
+    flux tables)."""
+    prof = thermodynamic_profs(pb, chain_subset(cube, num, seed), flux_table=flux_table, D_L_Mpc=D_L_Mpc)
     return {k: equal_tailed(v, ci) for k, v in prof.items()}
 
 

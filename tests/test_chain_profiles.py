@@ -84,6 +84,35 @@ def test_profiles_against_per_sample_loop(ne_mode):
     assert fg.shape == (3, pb.N) and np.all(np.isfinite(fg))
 
 
+def test_cooling_time_profile():
+    """joxsz_plots.py:242-244 with the bolometric flux tables as inputs: a per-sample loop written the way the reference
+    writes it, and a known answer (a pure bremsstrahlung table, flux ~ n_e^2 sqrt(T): t_cool ~ sqrt(T) / n_e)."""
+    pb = datasets.synthetic_problem(S=32, N=40, seed=7)
+    thetas = datasets.walker_ball(pb, 7, spread=0.05, seed=3)
+    lnT = np.log(np.geomspace(0.06, 60., 100))
+    D_L = 5900.                                                            # Mpc
+    kff = 1e-23 / (4 * np.pi * (D_L * pr.Mpc_cm) ** 2)                     # emissivity 1e-23 n_e^2 sqrt(T) erg cm^-3 s^-1
+    f0 = np.log(kff) + 0.5 * lnT
+    table = (lnT, f0, f0 + np.log(1.3))                                    # metals add 30 % at solar abundance
+    got = pr.thermodynamic_profs(pb, thetas, flux_table=table, D_L_Mpc=D_L)
+    assert got['cool'].shape == (7, pb.N) and np.all(got['cool'] > 0)
+    for i, th in enumerate(thetas):
+        q = orc.pars_dict(pb, th)
+        dens = orc.vikh_function(q, pb.r_pp, 'single')
+        temp = orc.press_fun(q, pb.r_pp) / dens
+        Z = q['Z']
+        flux = (np.exp(np.interp(np.log(temp), lnT, table[1])) * (1 - Z) + np.exp(np.interp(np.log(temp), lnT, table[2])) * Z) * dens ** 2
+        want = (5 / 2) * dens * (1. + 1 / pr.ne_nH) * temp * pr.keV_erg / (flux * 4. * np.pi * (D_L * pr.Mpc_cm) ** 2) / pr.yr_s
+        np.testing.assert_allclose(got['cool'][i], want, rtol=1e-12)
+        inside = (temp > 0.07) & (temp < 50.)                               # (the table is clamped outside its grid)
+        known = 2.5 * (1 + 1 / pr.ne_nH) * pr.keV_erg * np.sqrt(temp) / (1e-23 * (1 + 0.3 * Z) * dens) / pr.yr_s
+        np.testing.assert_allclose(got['cool'][i][inside], known[inside], rtol=2e-3)     # (ln-linear interpolation of sqrt(T))
+    summ = pr.comp_rad_profs(thetas.reshape(1, 7, -1), pb, ci=80, flux_table=table, D_L_Mpc=D_L)
+    assert summ['cool'].shape == (3, pb.N) and np.all(summ['cool'][0] <= summ['cool'][2])
+    with pytest.raises(ValueError):
+        pr.thermodynamic_profs(pb, thetas, flux_table=table)
+
+
 def test_overdensity_radius_against_scipy_newton():
     pb = datasets.synthetic_problem(S=32, N=40, seed=7)
     thetas = datasets.walker_ball(pb, 6, spread=0.03, seed=2)
