@@ -225,7 +225,8 @@ int  jx_comm_allreduce_max(jx_ctx* ctx, double* inout_dev, int count);
 int  jx_comm_destroy(jx_ctx* ctx);
 
 int  jx_timing_reset(jx_ctx* ctx);
-int  jx_timing_enable(jx_ctx* ctx, int on);
+int  jx_timing_enable(jx_ctx* ctx, int on);        /* 0 off; 1 an event behind every stage; 2 only the two events around pass 1 of the
+                                                     * hand-written route (the time-dominant kernel): beam_fft_ms, launches and walkers are filled */
 int  jx_timing_get(jx_ctx* ctx, jx_timing* out);   /* synchronises the stream */
 
 /* Introspection: derived sizes chosen by the library. */

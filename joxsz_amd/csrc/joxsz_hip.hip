@@ -34,6 +34,7 @@ struct EvSet {
     int walkers;
     bool op;                           // operator route: only e[0], e[1], e[5] were recorded
     bool gemm;                         // e[6] (behind the FIR + combination GEMM of the fused route) was recorded
+    bool p1only = false;               // timing mode 2: only e[2], e[3] (around pass 1) were recorded
 };
 
 }  // namespace
@@ -150,6 +151,7 @@ struct jx_ctx {
 
     // timing
     bool timing_on = false;
+    int timing_mode = 0;              // jx_timing_enable: 1 = every stage, 2 = only the events around pass 1 of the hand-written route
     std::vector<EvSet> ev_inflight, ev_free;
     jx_timing acc{};
 };
@@ -1236,6 +1238,13 @@ static int drain_events(jx_ctx* ctx) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     for (auto& es : ctx->ev_inflight) {
         float ms[5] = {0, 0, 0, 0, 0}, tot;
+        if (es.p1only) {                               // two events per launch sequence: the time-dominant kernel alone
+            HIPCHK(ctx, hipEventElapsedTime(&ms[2], es.e[2], es.e[3]));
+            ctx->acc.beam_fft_ms += ms[2];
+            ctx->acc.launches += 1; ctx->acc.walkers += es.walkers;
+            ctx->ev_free.push_back(es);
+            continue;
+        }
         if (es.op) {                                   // collapsed route: prep, then one kernel
             HIPCHK(ctx, hipEventElapsedTime(&ms[0], es.e[0], es.e[1]));
             HIPCHK(ctx, hipEventElapsedTime(&ms[4], es.e[1], es.e[5]));
@@ -1346,7 +1355,7 @@ static int launch_fused_conv(jx_ctx* ctx, int n, EvSet* es, bool dct) {
 #undef JX_LR_GO
         }
     }
-    if (es) { HIPCHK(ctx, hipEventRecord(es->e[6], st)); es->gemm = true; }
+    if (es && !es->p1only) { HIPCHK(ctx, hipEventRecord(es->e[6], st)); es->gemm = true; }
     ctx->last_nblk3 = cf.nblk3;
     done = false;
     const dim3 g3(cf.nblk3, n);
@@ -1358,7 +1367,7 @@ static int launch_fused_conv(jx_ctx* ctx, int n, EvSet* es, bool dct) {
         done = true; }
     JX_CONV2_PAIRS(JX_P3)
 #undef JX_P3
-    if (es) HIPCHK(ctx, hipEventRecord(es->e[4], st));
+    if (es && !es->p1only) HIPCHK(ctx, hipEventRecord(es->e[4], st));
     return JX_OK;
 }
 
@@ -1398,7 +1407,7 @@ static int launch_odd_conv(jx_ctx* ctx, int n, EvSet* es) {
             JX_LR_KINDS(JX_LR_GO)
 #undef JX_LR_GO
         }
-    if (es) { HIPCHK(ctx, hipEventRecord(es->e[6], st)); es->gemm = true; }
+    if (es && !es->p1only) { HIPCHK(ctx, hipEventRecord(es->e[6], st)); es->gemm = true; }
     {   // combined rows back to real space: cc[a][rho][w], a = 0..S/2 (offset from the centre column)
         JxDct d3 = ctx->dct3;
         d3.n = n;
@@ -1428,7 +1437,7 @@ static int launch_odd_conv(jx_ctx* ctx, int n, EvSet* es) {
 #undef JX_LR_GO
             }
     }
-    if (es) HIPCHK(ctx, hipEventRecord(es->e[4], st));
+    if (es && !es->p1only) HIPCHK(ctx, hipEventRecord(es->e[4], st));
     return JX_OK;
 }
 
@@ -1537,7 +1546,7 @@ static int launch_custom_conv(jx_ctx* ctx, int n, double* tap_convjobs, EvSet* e
 #undef JX_P3
     if (tap_convjobs)
         hipLaunchKernelGGL(jx_expand_rows_kernel, dim3(cv.S, n), dim3(256), 0, st, tap_convjobs, ctx->d_rowjob, cv.S, cv.NJ, ctx->t_conv);
-    if (es) HIPCHK(ctx, hipEventRecord(es->e[4], st));
+    if (es && !es->p1only) HIPCHK(ctx, hipEventRecord(es->e[4], st));
     return JX_OK;
 }
 
@@ -1550,7 +1559,9 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
     if (rc) return rc;
     hipStream_t st = ctx->stream;
     EvSet es;
-    const bool tm = ctx->timing_on;
+    // timing mode 2 records the two events around pass 1 only (default route of the hand-written convolution); elsewhere it records nothing
+    const bool tm = ctx->timing_on && ctx->timing_mode != 2;
+    const bool tm2 = ctx->timing_on && ctx->timing_mode == 2 && ctx->conv_mode == 2 && !op_route;
     // the operator route has no per-walker work buffers beyond these three, so its launches can be much larger than a chunk
     double* base_buf = op_route ? ctx->d_base_op : ctx->d_base;
     double* cfac_buf = op_route ? ctx->d_cfac_op : ctx->d_cfac;
@@ -1559,13 +1570,14 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
     const bool dct = !op_route && ctx->dct_ok && (ctx->odd || (use_fused(ctx, t.conv) && !t.need_img));
     // ... and the coefficients come from one matrix product, unless the profile taps are asked for (they live in the Abel kernel)
     const bool ag = dct && ctx->abel_gemm && !t.pp && !t.ab && !t.y && !d.inject_pp && !t.need_img;
-    if (tm) {
+    if (tm || tm2) {
         if (ctx->ev_inflight.size() > 2048 && (rc = drain_events(ctx))) return rc;
         if ((rc = get_evset(ctx, &es))) return rc;
         es.walkers = n;
         es.op = false;
         es.gemm = false;
-        HIPCHK(ctx, hipEventRecord(es.e[0], st));
+        es.p1only = tm2;
+        if (tm) HIPCHK(ctx, hipEventRecord(es.e[0], st));
     }
     {
         const size_t sh = sizeof(double) * (JX_LDS_HDR + (size_t)2 * d.N + 2 * d.nann + (size_t)d.nband * d.nann + 8);
@@ -1636,7 +1648,7 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
             else hipLaunchKernelGGL(jx_abel_map_kernel<false>, grid0, block, sh, st, d, theta_dev, w0, ctx->d_img, t.pp, t.ab, t.y);
         }
     }
-    if (tm) HIPCHK(ctx, hipEventRecord(es.e[2], st));
+    if (tm || tm2) HIPCHK(ctx, hipEventRecord(es.e[2], st));
     const cplx* zpart = nullptr;
     int nblk = 0;
     if (ctx->conv_mode == 1) {
@@ -1660,8 +1672,9 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
         if (tm) HIPCHK(ctx, hipEventRecord(es.e[4], st));
     } else {
         if (ctx->odd && !dct) { ctx->err = "odd map side: the hand-written route needs the coefficient-fed pass 1"; return JX_ERR_UNSUPPORTED; }
-        int rc2 = ctx->odd ? launch_odd_conv(ctx, n, tm ? &es : nullptr)
-                : use_fused(ctx, t.conv) ? launch_fused_conv(ctx, n, tm ? &es : nullptr, dct) : launch_custom_conv(ctx, n, t.conv, tm ? &es : nullptr);
+        EvSet* esp = (tm || tm2) ? &es : nullptr;
+        int rc2 = ctx->odd ? launch_odd_conv(ctx, n, esp)
+                : use_fused(ctx, t.conv) ? launch_fused_conv(ctx, n, esp, dct) : launch_custom_conv(ctx, n, t.conv, esp);
         if (rc2) return rc2;
         zpart = ctx->d_part;
         nblk = ctx->last_nblk3;
@@ -1671,10 +1684,8 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
         const size_t sh = sizeof(double) * (JX_LDS_HDR + (size_t)d.nrow + 8);
         hipLaunchKernelGGL(jx_tail_odd_kernel, dim3(n), dim3(JX_TAIL_THREADS), sh, st, d, ctx->d_D2, ctx->lrf.r, ctx->o_ldb, ctx->d_cfac, ctx->d_sz0,
                            ctx->d_base, logp_dev, w0, t.row, t.bright, t.chisq, t.parts);
-        if (tm) {
-            HIPCHK(ctx, hipEventRecord(es.e[5], st));
-            ctx->ev_inflight.push_back(es);
-        }
+        if (tm) HIPCHK(ctx, hipEventRecord(es.e[5], st));
+        if (tm || tm2) ctx->ev_inflight.push_back(es);
         HIPCHK(ctx, hipGetLastError());
         return JX_OK;
     }
@@ -1692,10 +1703,8 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
         hipLaunchKernelGGL(jx_tail_kernel, dim3(n), dim3(JX_TAIL_THREADS), sh, st, d, ctx->d_tfspec, zpart, nblk, ctx->d_cfac, ctx->d_sz0,
                            ctx->d_base, logp_dev, w0, t.row, t.bright, t.chisq, t.parts);
     }
-    if (tm) {
-        HIPCHK(ctx, hipEventRecord(es.e[5], st));
-        ctx->ev_inflight.push_back(es);
-    }
+    if (tm) HIPCHK(ctx, hipEventRecord(es.e[5], st));
+    if (tm || tm2) ctx->ev_inflight.push_back(es);
     HIPCHK(ctx, hipGetLastError());
     return JX_OK;
 }
@@ -2017,6 +2026,7 @@ int jx_memcpy_d2h(jx_ctx* ctx, void* host, const void* dev, size_t n) {
 int jx_timing_enable(jx_ctx* ctx, int on) {
     if (!ctx) return JX_ERR_INVALID;
     ctx->timing_on = on != 0;
+    ctx->timing_mode = (on == 2) ? 2 : (on ? 1 : 0);
     return JX_OK;
 }
 
