@@ -883,10 +883,11 @@ jx_lowrank_kernel(JxLowrank lr, JxGemmSeg sg0, JxGemmSeg sg1, long long bws, lon
         asm volatile("" : "+v"(sat[t]));                              // opaque: keeps the bases apart
     }
     constexpr int H = KS / 2;                                         // B values in flight (must divide KS): half a task ahead
-    double b[H];
+    TB b[H];                                                           // (kept in the storage type: a float is widened when it is USED, half a
+                                                                       //  task after its request -- widening at the request would wait for it at once)
     const TB* pl = bptr(g0);                                           // running load pointer (no table of row addresses in registers)
 #pragma unroll
-    for (int u = 0; u < H; ++u) { b[u] = (double)*pl; pl += step; }
+    for (int u = 0; u < H; ++u) { b[u] = *pl; pl += step; }
     int cur = -1;
     for (int g = g0; g < g1; ++g) {
         const int batch = g / gpb;
@@ -915,10 +916,11 @@ jx_lowrank_kernel(JxLowrank lr, JxGemmSeg sg0, JxGemmSeg sg1, long long bws, lon
 #pragma unroll
                 for (int t = 0; t < NTR; ++t) an[t] = s_a[sat[t] + (u + 1) * 64];
             }
+            const double bu = (double)b[u % H];
 #pragma unroll
-            for (int t = 0; t < NTR; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[t], b[u % H], acc[t], 0, 0, 0);
+            for (int t = 0; t < NTR; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[t], bu, acc[t], 0, 0, 0);
             if (u + H == KS) pl = pbn;                               // the ring moves on to the next task's rows
-            b[u % H] = (double)*pl; pl += step;
+            b[u % H] = *pl; pl += step;
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < NTR; ++t) ac[t] = an[t];
