@@ -354,17 +354,17 @@ jx_rowtf2_kernel(JxConv c, const cplx* __restrict__ C, cplx* __restrict__ part, 
         const TC* Cw = reinterpret_cast<const TC*>(C) + (size_t)w * Ph * 64 + r0;
         const TC* ct0 = reinterpret_cast<const TC*>(c.ct0);
         const int nt = c.o + 1, ns = nrows * nt;
-        double cz[NSL];
+        TC cz[NSL];                                                   // (storage type: widened where it is used, behind all the requests)
 #pragma unroll
         for (int u = 0; u < NSL; ++u) {
             const int e = min(tid + u * nth, ns - 1), row = e / nt, xo = e - row * nt;
-            cz[u] = (double)ct0[((size_t)w * JX_CT0_X + xo) * 64 + r0 + row];
+            cz[u] = ct0[((size_t)w * JX_CT0_X + xo) * 64 + r0 + row];
         }
         constexpr int HR = (ROWS + 1) / 2;                            // row pairs
         constexpr int NSUB = HR <= 4 ? 4 : (HR <= 8 ? 8 : (HR <= 16 ? 16 : 32)), LSUB = NSUB == 4 ? 2 : (NSUB == 8 ? 3 : (NSUB == 16 ? 4 : 5));
         static_assert(HR <= 32, "row pairs of a block share one group of lanes");
         constexpr int NPAIR = LP / 2 + 1, NTRIP = (NPAIR * NSUB + 255) / 256;
-        double2 ra[NTRIP], rb[NTRIP];
+        TC2 ra[NTRIP], rb[NTRIP];
 #pragma unroll
         for (int i = 0; i < NTRIP; ++i) {
             const int e = min(tid + i * 256, NPAIR * NSUB - 1), k = e >> LSUB, sub = min(e & (NSUB - 1), HR - 1);
@@ -372,8 +372,8 @@ jx_rowtf2_kernel(JxConv c, const cplx* __restrict__ C, cplx* __restrict__ part, 
             va.x = va.y = vb.x = vb.y = 0;
             if (k < c.kact) va = *reinterpret_cast<const TC2*>(Cw + (size_t)k * 64 + 2 * sub);
             if (LP - k < c.kact) vb = *reinterpret_cast<const TC2*>(Cw + (size_t)(LP - k) * 64 + 2 * sub);
-            ra[i] = make_double2((double)va.x, (double)va.y);
-            rb[i] = make_double2((double)vb.x, (double)vb.y);
+            ra[i] = va;
+            rb[i] = vb;
         }
 #pragma unroll
         for (int i = 0; i < NTRIP; ++i) {
@@ -382,7 +382,7 @@ jx_rowtf2_kernel(JxConv c, const cplx* __restrict__ C, cplx* __restrict__ part, 
                 const int kp = LP - k, kq = kp == LP ? 0 : kp;
                 const cplx za1 = c.zab[2 * k], zb1 = c.zab[2 * k + 1], za2 = c.zab[2 * kq], zb2 = c.zab[2 * kq + 1];
                 const int n1a = k / P2, n2a = k - n1a * P2, n1b = kq / P2, n2b = kq - n1b * P2;
-                const double r1[2] = {ra[i].x, ra[i].y}, r2[2] = {rb[i].x, rb[i].y};
+                const double r1[2] = {(double)ra[i].x, (double)ra[i].y}, r2[2] = {(double)rb[i].x, (double)rb[i].y};
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int row = 2 * sub + h;
@@ -395,7 +395,7 @@ jx_rowtf2_kernel(JxConv c, const cplx* __restrict__ C, cplx* __restrict__ part, 
             }
         }
 #pragma unroll
-        for (int u = 0; u < NSL; ++u) if (tid + u * nth < ns) s_s[tid + u * nth] = cz[u];
+        for (int u = 0; u < NSL; ++u) if (tid + u * nth < ns) s_s[tid + u * nth] = (double)cz[u];
     } else if (c.xsym) {
         // Z[k] = zab[k][0] Rc[k] + zab[k][1] Rc[LP-k], four elements per thread and trip as below
         const int ldr = c.fir_ld;                                    // row stride of the real arrays (Ph rounded up to whole cache lines)
