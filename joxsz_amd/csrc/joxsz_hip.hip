@@ -1213,6 +1213,10 @@ static int finalize_impl(jx_ctx* ctx) {
     FFTCHK(ctx, rocfft_execution_info_set_stream(ctx->info, ctx->stream));
     // the zero fills above ran on the null stream, which the context's non-blocking stream does not wait for
     HIPCHK(ctx, hipDeviceSynchronize());
+    if (c.dtype == 1 && !ctx->f32) {                             // never silently fall back to the fp64 arithmetic
+        ctx->err = "dtype f32 is available on the default route of even map sides only (hand-written convolution, fused matrix products)";
+        return JX_ERR_UNSUPPORTED;
+    }
     ctx->finalized = true;
     return JX_OK;
 }

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Randomised cross-check of the routes on the GPU: for many (map side, grid length, beam width, density mode, likelihood)
+combinations the default route's log-posteriors against the rocFFT sequence's (conv='rocfft'), the fp32 variant where it
+exists, and a few walkers against the CPU oracle.   python scripts/route_sweep.py [ncases] [seed]     (GPU box)"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from joxsz_amd import datasets
+from joxsz_amd.posterior import JoxszPosterior
+from joxsz_amd.hip_backend import JoxszHipError
+from oracle import joxsz_oracle as orc
+
+ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+sides = [32, 33, 48, 49, 64, 65, 95, 96, 128, 129, 171, 191, 255, 256, 257, 383, 511, 512, 513]
+worst = 0.0
+bad = 0
+for case in range(ncases):
+    S = int(rng.choice(sides))
+    N = int(rng.integers(max(24, S // 2 + 8), 2 * S + 40))
+    fwhm = float(rng.choice([6.5, 9.0, 12.0, 18.5]))
+    kw = dict(ne_mode=str(rng.choice(['single', 'double'])), sz_only=bool(rng.random() < 0.3))
+    W = int(rng.integers(1, 70))
+    try:
+        pb = datasets.synthetic_problem(S=S, N=N, seed=case, fwhm=fwhm, **kw)
+    except Exception as exc:
+        print('case %d S=%d N=%d fwhm=%.1f: problem not constructible (%s)' % (case, S, N, fwhm, exc)); continue
+    if pb.B > S:
+        continue
+    th = datasets.walker_ball(pb, W, spread=0.05, seed=case)
+    if W > 3:
+        th[2, 1] = 9.0
+    res = {}
+    info = {}
+    for name, args in (('default', {}), ('rocfft', dict(conv='rocfft')), ('f32', dict(dtype='f32'))):
+        try:
+            post = JoxszPosterior(pb, device=0, **args)
+            res[name] = post.log_prob(th)
+            info[name] = (post.ctx.conv, (post.ctx.conv_layout or {}).get('rank'), post.ctx.truncation.get('tol'))
+            post.close()
+        except JoxszHipError as exc:
+            info[name] = ('unsupported', str(exc)[-60:])
+    a, b = res['default'], res['rocfft']
+    fin = np.isfinite(b)
+    same = np.array_equal(np.isfinite(a), fin)
+    rel = float(np.max(np.abs(a[fin] - b[fin]) / np.abs(b[fin]))) if fin.any() else 0.0
+    nor = min(W, 3)
+    want = orc.log_posterior_batch(pb, th[:nor])
+    fo = np.isfinite(want)
+    relo = float(np.max(np.abs(a[:nor][fo] - want[fo]) / np.abs(want[fo]))) if fo.any() else 0.0
+    rel32 = None
+    if 'f32' in res:
+        rel32 = float(np.max(np.abs(res['f32'][fin] - b[fin]) / np.abs(b[fin]))) if fin.any() else 0.0
+    ok = same and rel < 1e-8 and relo < 1e-6 and np.array_equal(np.isfinite(a[:nor]), fo) and (rel32 is None or rel32 < 1e-5)
+    worst = max(worst, rel)
+    bad += 0 if ok else 1
+    print('%s case %2d S=%3d N=%4d B=%2d fwhm=%4.1f %s%s W=%2d: default %s vs rocfft rel %.2e | vs oracle %.2e | f32 %s' %
+          ('ok ' if ok else 'BAD', case, S, N, pb.B, fwhm, kw['ne_mode'], ' sz-only' if kw['sz_only'] else '', W, info['default'], rel, relo,
+           ('%.2e' % rel32) if rel32 is not None else info.get('f32', ('-',))[0]), flush=True)
+print('worst default-vs-rocfft %.3e; %d bad of %d' % (worst, bad, ncases))
+sys.exit(1 if bad else 0)

@@ -350,6 +350,16 @@ def test_fp32_variant_tolerance_sweep(S, N, W):
     assert np.any(lp32[fin] != lp64[fin])                               # it really is another arithmetic
 
 
+def test_fp32_variant_refuses_routes_it_does_not_exist_on():
+    """dtype f32 on an odd side, on the rocFFT route or on a small map must be an error, never a silent fp64 evaluation."""
+    from joxsz_amd.hip_backend import JoxszHipError
+    from joxsz_amd import datasets
+    for S, N, kw in ((513, 500, {}), (512, 500, dict(conv='rocfft')), (96, 120, {}), (64, 80, {})):
+        pb = datasets.synthetic_problem(S=S, N=N, seed=1)
+        with pytest.raises(JoxszHipError, match='unsupported'):
+            _post(pb, dtype='f32', **kw)
+
+
 def test_truncation_probe_and_automatic_tightening(monkeypatch):
     """jx_finalize measures what the low-rank cut and the band limit cost on the extracted row (jx_get_truncation); above
     the bound (2e-10 of the row's largest entry; lowered here to force the cases) it rebuilds the tables with a cut a
