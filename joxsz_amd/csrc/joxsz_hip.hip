@@ -100,6 +100,7 @@ struct jx_ctx {
     std::vector<double> h_Tm;         // host copy until the route that uses it is known
     double* d_Tm = nullptr; int tm_ld = 0, tm_ntile = 0, tm_npair = 0;
     double* d_ppc = nullptr;          // [chunk][N] prep kernel -> jx_abel_gemm_kernel
+    double* d_cf_tap = nullptr;       // fp32 contexts: fp64 spline arrays of the Abel kernel when it runs for the profile taps
     bool abel_gemm = false;
     size_t dct_lds = 0;
     void* samp_buf[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // jx_sample work buffers (grow-only)
@@ -1184,6 +1185,8 @@ static int finalize_impl(jx_ctx* ctx) {
                 ctx->err = "dtype f32 is available on the default route of even map sides only (fused matrix products, rank >= 17)";
                 return JX_ERR_UNSUPPORTED;
             }
+            if (!ctx->abel_gemm) { ctx->err = "dtype f32 takes its spline arrays from the matrix product (JOXSZ_ABEL_GEMM=0 is the f64 build's switch)"; return JX_ERR_UNSUPPORTED; }
+            if ((rc = dev_new(ctx, (size_t)chunk * ctx->dct.cf_ws, &ctx->d_cf_tap, true))) return rc;
             ctx->f32 = true;
 #define JX_DCT_ATTR(LPv, NSv, NTv, NWv) if (cv.LP == LPv && cv.LS == NSv) { \
             ctx->dct_lds = dct_lds_bytes<LPv, NSv>(NWv, sizeof(float)); \
@@ -1573,7 +1576,11 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
     // default route: the map rows are evaluated inside pass 1 from the coefficients (no image), unless the image is asked for
     const bool dct = !op_route && ctx->dct_ok && (ctx->odd || (use_fused(ctx, t.conv) && !t.need_img));
     // ... and the coefficients come from one matrix product, unless the profile taps are asked for (they live in the Abel kernel)
-    const bool ag = dct && ctx->abel_gemm && !t.pp && !t.ab && !t.y && !d.inject_pp && !t.need_img;
+    // (fp32 contexts keep the spline arrays in float and always take them from the matrix product -- from the injected profiles
+    //  when the operator is being built; the Abel kernel then runs beside it only to serve the profile taps)
+    const bool f32cf = ctx->f32 && dct;
+    const bool want_abel_taps = t.pp || t.ab || t.y || t.need_img;
+    const bool ag = dct && ctx->abel_gemm && (f32cf || (!want_abel_taps && !d.inject_pp));
     if (tm || tm2) {
         if (ctx->ev_inflight.size() > 2048 && (rc = drain_events(ctx))) return rc;
         if ((rc = get_evset(ctx, &es))) return rc;
@@ -1586,7 +1593,7 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
     {
         const size_t sh = sizeof(double) * (JX_LDS_HDR + (size_t)2 * d.N + 2 * d.nann + (size_t)d.nband * d.nann + 8);
         hipLaunchKernelGGL(jx_prep_kernel, dim3(n), dim3(JX_PREP_THREADS), sh, st, d, theta_dev, w0,
-                           base_buf, cfac_buf, op_route ? ctx->d_pp : (ag ? ctx->d_ppc : (double*)nullptr), sz0_buf, t.tprof, t.xprofs, t.parts, t.integ);
+                           base_buf, cfac_buf, op_route ? ctx->d_pp : ((ag && !d.inject_pp) ? ctx->d_ppc : (double*)nullptr), sz0_buf, t.tprof, t.xprofs, t.parts, t.integ);
     }
     if (tm) HIPCHK(ctx, hipEventRecord(es.e[1], st));
     if (op_route) {
@@ -1622,9 +1629,13 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
     if (ctx->f32 && !op_route && !dct) { ctx->err = "dtype f32: the map and beam-convolved-map taps exist in the f64 build of the context only"; return JX_ERR_UNSUPPORTED; }
     if (ag) {
         const dim3 grid((n + 31) / 32, (ctx->tm_npair + 3) / 4);
-        hipLaunchKernelGGL((jx_abel_gemm_kernel<1>), grid, dim3(256), sizeof(double) * JX_OPM_JC * 33, st, ctx->d_ppc, n, d.N, ctx->d_Tm, ctx->tm_ld,
-                           d.K, ctx->tm_ntile, ctx->tm_npair, ctx->d_cf, ctx->dct.cf_ws);
-    } else {
+        const double* pp_src = d.inject_pp ? d.inject_pp : ctx->d_ppc;
+        if (f32cf) hipLaunchKernelGGL((jx_abel_gemm_kernel<1, float>), grid, dim3(256), sizeof(double) * JX_OPM_JC * 33, st, pp_src, n, d.N, ctx->d_Tm, ctx->tm_ld,
+                                      d.K, ctx->tm_ntile, ctx->tm_npair, reinterpret_cast<float*>(ctx->d_cf), ctx->dct.cf_ws);
+        else hipLaunchKernelGGL((jx_abel_gemm_kernel<1>), grid, dim3(256), sizeof(double) * JX_OPM_JC * 33, st, pp_src, n, d.N, ctx->d_Tm, ctx->tm_ld,
+                                d.K, ctx->tm_ntile, ctx->tm_npair, ctx->d_cf, ctx->dct.cf_ws);
+    }
+    if (!ag || (f32cf && want_abel_taps)) {
         const bool vec2 = (d.S % 2 == 0) && (d.P % 2 == 0);
         const int npw = (d.quad && d.pairw == 2) ? 2 : 1;
         const dim3 grid0(((n + npw - 1) / npw) * d.map_split), block(ctx->map_threads);
@@ -1641,7 +1652,7 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
                 const dim3 grid = grid0;
                 JX_SYM_PICK()
             }
-            if (dct) { dm.cf_out = ctx->d_cf; dm.cf_ws = ctx->dct.cf_ws; dm.map_split = 1; }   // phases 1-3 only: spline out
+            if (dct) { dm.cf_out = f32cf ? ctx->d_cf_tap : ctx->d_cf; dm.cf_ws = ctx->dct.cf_ws; dm.map_split = 1; }   // phases 1-3 only: spline out (fp32 contexts: to a scratch array, for the taps' sake)
             const dim3 grid(dct ? (unsigned)((n + npw - 1) / npw) : grid0.x);
             JX_SYM_PICK()
 #undef JX_SYM_PICK

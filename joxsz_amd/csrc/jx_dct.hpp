@@ -83,23 +83,28 @@ template <int Q, int NS> struct jx_dct_lay {
 };
 
 // f = A y_k + B y_{k+1} + C M_k + D M_{k+1} from the walker's (y, M) pairs
+// (TS: storage type of the pairs; koff is the byte offset of knot k in an fp64 array, 16 k)
+template <typename TS>
 __device__ __forceinline__ double jx_spline4(const char* ym, unsigned koff, double A, double B, double C, double D) {
-    const double2 p0 = *reinterpret_cast<const double2*>(ym + koff);
-    const double2 p1 = *reinterpret_cast<const double2*>(ym + koff + 16);
-    return fma(D, p1.y, fma(C, p0.y, fma(B, p1.x, A * p0.x)));
+    typedef typename jx_pair<TS>::type S2;
+    const unsigned ko = koff / (16 / (unsigned)sizeof(S2));
+    const S2 p0 = *reinterpret_cast<const S2*>(ym + ko);
+    const S2 p1 = *reinterpret_cast<const S2*>(ym + ko + sizeof(S2));
+    return fma(D, (double)p1.y, fma(C, (double)p0.y, fma(B, (double)p1.x, A * (double)p0.x)));
 }
 
 // MODE 0: the samples of row u are evaluated from the walkers' spline arrays cf (pass 1).
 // MODE 1: the samples are read from a walker-minor array cf[k][u][w] (k < n_in; row stride tW, sample stride s_kstr): the
 //         same transform taken of a band-limited real-even spectrum is its inverse (odd map sides: combined rows back to
 //         real space, joxsz_funcs.py:464-467 without a transform of the odd length S).
-// T: arithmetic and storage type of the samples, the transform and the output (double: the reference's; float: the fp32
-//    variant of BASELINE configs[4] -- the spline arrays and the tables stay fp64 and are rounded as they are loaded).
+// T: arithmetic and storage type of the spline arrays, the samples, the transform and the output (double: the reference's;
+//    float: the fp32 variant of BASELINE configs[4] -- the tables stay fp64 and are rounded as they are loaded).  The evaluation
+//    is bound by the bytes the vector L1 returns to the registers: 32 per (sample, walker) in fp64, 16 in fp32.
 template <int LP, int NS, int NW, int NT, int MODE, typename T = double>
 __global__ void __launch_bounds__(NT)
 jx_rowdct_kernel(JxDct d, const void* __restrict__ src_v, void* __restrict__ out_v, void* __restrict__ x0t_v) {
     typedef typename jx_pair<T>::type T2;
-    const double* cf = reinterpret_cast<const double*>(src_v);      // MODE 0: spline arrays (always fp64)
+    const T* cf = reinterpret_cast<const T*>(src_v);                // MODE 0: spline arrays (y_k, M_k), stored as T
     T* Rt = reinterpret_cast<T*>(out_v);
     T* x0t = reinterpret_cast<T*>(x0t_v);
     constexpr int Q = LP / 2;
@@ -159,10 +164,10 @@ jx_rowdct_kernel(JxDct d, const void* __restrict__ src_v, void* __restrict__ out
     const T2* Mw_post = M + pw * RS;
 
     // evaluation (MODE 0): byte offset of every walker's spline array from the group's first (wave-uniform -> scalar registers)
-    const char* cf0 = reinterpret_cast<const char*>(cf) + (size_t)w0 * d.cf_ws * 8;
+    const char* cf0 = reinterpret_cast<const char*>(cf) + (size_t)w0 * d.cf_ws * sizeof(T);
     unsigned woff[NW];
 #pragma unroll
-    for (int i = 0; i < NW; ++i) woff[i] = (unsigned)min(i, d.n - 1 - w0) * (unsigned)(d.cf_ws * 8);   // a missing walker repeats the last one: never stored
+    for (int i = 0; i < NW; ++i) woff[i] = (unsigned)min(i, d.n - 1 - w0) * (unsigned)(d.cf_ws * sizeof(T));   // a missing walker repeats the last one: never stored
     constexpr int NSLT = (MODE == 0) ? (Geo::NEV + NT - 1) / NT : 1;
     unsigned t_kb[NSLT];
     double2 t_wa[NSLT], t_wb[NSLT];
@@ -300,20 +305,20 @@ jx_rowdct_kernel(JxDct d, const void* __restrict__ src_v, void* __restrict__ out
             for (int sl = 0; sl < NSL; ++sl) {
                 const int a = tid + NT * sl;
                 const bool live = a < Geo::NEV;
-                const unsigned kb = t_kb[sl];
+                const unsigned kb = t_kb[sl] / (16 / (unsigned)sizeof(T2));      // byte offset of the knot in an array of T pairs
                 const T w0y = (T)t_wa[sl].x, w1y = (T)t_wa[sl].y, w0m = (T)t_wb[sl].x, w1m = (T)t_wb[sl].y;
                 T* qdst = reinterpret_cast<T*>(M) + a;                        // + walker * (RS * sizeof(T2)): immediate offsets
-                double2 ld[EW][2];
+                T2 ld[EW][2];
 #pragma unroll
                 for (int g0 = 0; g0 < NW; g0 += EW) {
 #pragma unroll
                     for (int i = 0; i < EW; ++i) {
                         const unsigned off = kb + woff[g0 + i];               // scalar walker offset + per-lane slot offset (32 bits)
-                        ld[i][0] = *reinterpret_cast<const double2*>(cf0 + off);
+                        ld[i][0] = *reinterpret_cast<const T2*>(cf0 + off);
 #ifdef JX_EXP_HALF_LOADS
                         ld[i][1] = ld[i][0];
 #else
-                        ld[i][1] = *reinterpret_cast<const double2*>(cf0 + off + 16);
+                        ld[i][1] = *reinterpret_cast<const T2*>(cf0 + off + sizeof(T2));
 #endif
                     }
 #pragma unroll
@@ -360,7 +365,7 @@ jx_rowdct_kernel(JxDct d, const void* __restrict__ src_v, void* __restrict__ out
         }
         JX_STAMP(0)
         if (MODE == 0 && d.has_x0 && tid < NW && w0 + tid < d.n)
-            x0t[(size_t)u * d.tW + w0 + tid] = (T)jx_spline4(reinterpret_cast<const char*>(cf + (size_t)(w0 + tid) * d.cf_ws), (unsigned)d.x0k[u],
+            x0t[(size_t)u * d.tW + w0 + tid] = (T)jx_spline4<T>(reinterpret_cast<const char*>(cf + (size_t)(w0 + tid) * d.cf_ws), (unsigned)d.x0k[u],
                                                              d.x0w[4 * u], d.x0w[4 * u + 1], d.x0w[4 * u + 2], d.x0w[4 * u + 3]);
         __syncthreads();
         JX_STAMP(1)

@@ -1462,10 +1462,10 @@ jx_operator_mfma_kernel(const double* __restrict__ pp /*[launch][N]*/, int n, in
 // they stay in the L1).
 #define JX_AG_R 8
 #define JX_AG_ROWS(N) ((((N) + 4 * JX_AG_R - 1) / (4 * JX_AG_R) + 1) * (4 * JX_AG_R))
-template <int NPW>
+template <int NPW, typename TO = double>
 __global__ void __launch_bounds__(256)
 jx_abel_gemm_kernel(const double* __restrict__ pp /*[launch][N]*/, int n, int N, const double* __restrict__ Tm /*[JX_AG_ROWS(N)][ldt], zero rows behind N-1*/,
-                    int ldt, int K, int ntile, int npair, double* __restrict__ cf /*[launch][cf_ws]*/, long long cf_ws) {
+                    int ldt, int K, int ntile, int npair, TO* __restrict__ cf /*[launch][cf_ws]; float for the fp32 variant (rounded once, on store)*/, long long cf_ws) {
     JX_LDS_DECL;
     constexpr int NTL = 2 * NPW;
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
@@ -1545,7 +1545,7 @@ jx_abel_gemm_kernel(const double* __restrict__ pp /*[launch][N]*/, int n, int N,
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int w = wb + nt * 16 + lk + 4 * g;
-                if (w < n) cf[(size_t)w * cf_ws + col] = acc[t][nt][g];
+                if (w < n) cf[(size_t)w * cf_ws + col] = (TO)acc[t][nt][g];
             }
         }
     }
