@@ -393,6 +393,20 @@ def main():
         if pj:
             step_pmc = sum(d['total_bytes'] for n, d in pj['kernels'].items() if n.startswith(('jx_', 'void jx_')) and 'operator' not in n) \
                 / pj.get('walkers_per_launch', 1024) * W
+        onchip = None
+        if dct and dom_kernel == 'jx_rowdct_kernel' and k_ms > 0:
+            esz = 4.0 if args.dtype == 'f32' else 8.0
+            NUr, Q = lay['NU'], lay['P'] // 4
+            ns = S // 2 + (S % 2)                                    # samples per distinct row (the unpaired column apart)
+            l1_b = walkers_per_launch * NUr * ns * 4.0 * esz        # (y_k, M_k, y_k+1, M_k+1) per (sample, walker) returned to registers
+            lds_b = walkers_per_launch * NUr * esz * (2.75 * ns + 12.0 * Q)   # q write, z-build read (7/4) + z write, two FFT levels in place, split read
+            n_cu, clk = 256, 2.4e9
+            l1_peak, lds_peak = n_cu * 64.0 * clk / 1e9, n_cu * 128.0 * clk / 1e9
+            onchip = {'kernel': dom_kernel, 'vector_l1_return': {'bytes_per_launch': l1_b, 'achieved': l1_b / (k_ms * 1e-3) / 1e9, 'peak': l1_peak, 'unit': 'GB/s',
+                                                                'frac': l1_b / (k_ms * 1e-3) / 1e9 / l1_peak},
+                      'lds': {'bytes_per_launch': lds_b, 'achieved': lds_b / (k_ms * 1e-3) / 1e9, 'peak': lds_peak, 'unit': 'GB/s', 'frac': lds_b / (k_ms * 1e-3) / 1e9 / lds_peak},
+                      'note': 'byte model of DESIGN 5.3 (not counters); peaks = 256 CUs x 64 (128) B/clk x 2.4 GHz; the two phases alternate inside a block, '
+                              'so the sum of the two fractions is the share of the kernel time either resource is busy at best overlap'}
         out = {
             'metric': 'walker-likelihoods/sec at 512^2 map, 500-pt grid' if (S, args.N) == (512, 500)
                       else 'walker-likelihoods/sec at %d^2 map, %d-pt grid' % (S, args.N),
@@ -417,6 +431,8 @@ def main():
                                  'HIP-event duration; survey_8d_* = SURVEY 8(d)\'s S^2*8 B per walker for the map stage, which this route '
                                  'never writes (the rows are evaluated from the spline inside this kernel). The kernel is not HBM-bound: '
                                  'its floor is on-chip data movement (vector-L1 return path 64 B/clk, LDS 128 B/clk; DESIGN 5.3)'},
+            # what does bound the time-dominant kernel: on-chip data movement, priced at nominal peaks
+            'roofline_onchip': onchip,
             # the whole step against the HBM roofline: measured bytes (rocprofv3 PMC, profiles/*_pmc_traffic.json) and compulsory bytes
             'roofline_step': {'bound': 'hbm', 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'ms_per_step': ms_step,
                               'traffic_bytes_per_step': step_pmc,
