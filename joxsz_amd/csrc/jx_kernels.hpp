@@ -247,9 +247,13 @@ __device__ __forceinline__ int jx_block_or(int v, int* redi) {
 // replaced by theta (updateThawed, joxsz_funcs.py:516).  Ends with a barrier.
 __device__ __forceinline__ void jx_load_params(const JxDev& c, const double* __restrict__ theta, int gw, double* p) {
     const int tid = threadIdx.x;
-    if (tid < JX_MAX_PAR) p[tid] = (tid < c.npar) ? c.par_vals[tid] : 0.0;
+    // (all three requests first: one round trip to memory instead of two on the critical path of every per-walker kernel)
+    const double pv = (tid < c.npar) ? c.par_vals[tid] : 0.0;
+    const int ti = (tid < c.ndim) ? c.thawed_idx[tid] : -1;
+    const double tv = (tid < c.ndim) ? theta[(size_t)gw * c.ndim + tid] : 0.0;
+    if (tid < JX_MAX_PAR) p[tid] = pv;
     __syncthreads();
-    if (tid < c.ndim) p[c.thawed_idx[tid]] = theta[(size_t)gw * c.ndim + tid];
+    if (ti >= 0) p[ti] = tv;
     __syncthreads();
 }
 
@@ -278,6 +282,12 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
     double* s_T = s_ne + c.nann;              // [nann]
     double* s_rate = s_T + c.nann;            // [nband*nann]
 
+    // the constants of this thread's prior are requested before the parameters are assembled (they do not depend on them)
+    const bool has_par = tid < c.npar;
+    const int pk_kind = has_par ? c.par_kind[tid] : 0;
+    const double pk_a = has_par ? (pk_kind == 1 ? c.par_mu[tid] : c.par_min[tid]) : 0.0;
+    const double pk_b = has_par ? (pk_kind == 1 ? c.par_sigma[tid] : c.par_max[tid]) : 0.0;
+    const double pk_ln = has_par ? c.par_lnorm[tid] : 0.0;
     jx_load_params(c, theta, gw, p);
     double pc[5] = {0, 1, 1, 0, 1};           // radius-independent factors of the density (every thread its own copy)
     if (c.prep_pow) jx_ne_consts(p, c.ne_mode, pc);
@@ -285,16 +295,16 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
     // ---- priors on every parameter (joxsz_funcs.py:518) ----
     double pr = 0.0;
     int rej = 0;
-    if (tid < c.npar) {
+    if (has_par) {
         const double v = p[tid];
-        if (c.par_kind[tid] == 1) {
-            const double sg = c.par_sigma[tid];
+        if (pk_kind == 1) {
+            const double sg = pk_b;
             if (sg <= 0.0) { rej |= REJ_BOX; }
             else {
-                const double z = (v - c.par_mu[tid]) / sg;
-                pr = c.par_lnorm[tid] - 0.5 * z * z;
+                const double z = (v - pk_a) / sg;
+                pr = pk_ln - 0.5 * z * z;
             }
-        } else if (v < c.par_min[tid] || v > c.par_max[tid]) rej |= REJ_BOX;
+        } else if (v < pk_a || v > pk_b) rej |= REJ_BOX;
         if (v != v) rej |= REJ_BOX;           // NaN parameter: reject (emcee cannot use NaN)
     }
     const double parprior = jx_block_sum(pr, red);
