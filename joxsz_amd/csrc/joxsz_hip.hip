@@ -20,6 +20,7 @@
 #include "jx_kernels.hpp"
 #include "jx_conv.hpp"
 #include "jx_dct.hpp"
+#include "jx_mix.hpp"
 #include "jx_tables.hpp"
 
 namespace {
@@ -143,6 +144,17 @@ struct jx_ctx {
     double* d_rows = nullptr;          // [op_cap / 32][nrow][32] G pp of large launches (jx_operator_mfma_kernel)
     int op_cap = 0;                    // walkers per launch on the operator route
     int g_ld = 0;
+
+    // contracted route (conv_mode 3, jx_mix.hpp): sum over map rows before any transform
+    JxMix mx{};                        // stage 1 tables
+    JxOpg og{};                        // stage 2 (low-rank form) / full form
+    int mix_form = 0;                  // 0 low-rank (stage 1 + stage 2), 1 full operator on the samples
+    int mix_RT = 0, mix_nxt = 0;       // template instances in use
+    int mix_r = 0, mix_ns = 0, mix_rank_full = 0, mix_ksteps = 0;
+    long long mix_tW = 0;
+    int mix_ncol = 0;                  // columns of the walker-minor spline array stored by the matrix product: 2 (N + pad)
+    double *d_cft = nullptr, *d_Dt = nullptr, *d_Pt = nullptr;
+    double mix_beam_tol = 0.0;
 
     ncclComm_t comm = nullptr;        // RCCL communicator of this rank (jx_comm_init_rank)
     int comm_rank = 0, comm_size = 1;
@@ -538,6 +550,65 @@ static int setup_abel_gemm(jx_ctx* ctx, int chunk) {
     return JX_OK;
 }
 
+// ---- contracted route (jx_mix.hpp): host-side plan.  Built before the route is chosen, so that `auto` can fall back.
+#define JX_MIX_NS 6
+#define JX_MIX_RTS(X) X(4) X(8) X(12) X(16) X(20) X(24) X(28) X(32) X(40) X(48) X(56) X(64)
+#define JX_MIX_NXTS(X) X(1) X(2) X(3) X(4) X(5) X(6)
+#define JX_MIX_KSPLIT_MAX 64
+struct MixBuild {
+    bool ok = false;
+    std::string why;
+    int NU = 0, r = 0, ns = 0, R = 0, RT = 0, nxt = 0, ntile = 0, nog = 0, ksteps = 0;
+    size_t krows = 0;
+    jxt::MixColumns cols;
+    std::vector<double> Cm, Op;
+    int cld = 0;
+    double tol = 0.0, beam_tol = 0.0;
+};
+
+static void plan_mix(const jx_config& c, const std::vector<double>& beam, const std::vector<double>& filt, const std::vector<double>& Qtab,
+                     int qn, bool mirror, const std::vector<double>& r, double tol, MixBuild& mb) {
+    const int S = c.S, B = c.B, Sh = S / 2 + 1, nrow = S - S / 2;
+    if (!mirror) { mb.why = "d_mat lacks the mirror structure of centdistmat"; return; }
+    if (c.fft_pad != 0) { mb.why = "fft_pad is a parameter of the rocFFT sequence"; return; }
+    const int NU = std::max(S / 2, S - 1 - S / 2) + 1;
+    if (qn != NU) { mb.why = "quadrant table size"; return; }
+    if (NU > 9 * 64) { mb.why = "map side beyond the symmetric map kernel's range"; return; }
+    mb.NU = NU; mb.tol = tol; mb.beam_tol = 1e-14;
+    if (!jxt::mix_column_tables(Qtab, qn, NU, r, mb.cols)) { mb.why = "pixel radii do not grow along the columns of d_mat"; return; }
+    // transfer-function weights of the extracted row, real for a real point-symmetric filter
+    std::vector<double> hy;
+    jxt::tf_hy_table(filt, S, hy);
+    std::vector<double> A((size_t)S * Sh);
+    double maxre = 0.0, maxim = 0.0;
+    for (size_t e = 0; e < A.size(); ++e) { A[e] = hy[2 * e]; maxre = std::max(maxre, std::fabs(hy[2 * e])); maxim = std::max(maxim, std::fabs(hy[2 * e + 1])); }
+    if (!(maxim <= 1e-15 * maxre)) { mb.why = "transfer-function weights are not real"; return; }
+    std::vector<double> U, V, by, bx;
+    mb.r = jxt::lowrank_factor_qr(A.data(), S, Sh, tol, U, V);
+    if (mb.r <= 0) { mb.why = "transfer-function weights vanish"; return; }
+    mb.ns = jxt::beam_separable_terms(beam, B, c.step * c.step, mb.beam_tol, by, bx);
+    if (mb.ns <= 0) { mb.why = "beam image vanishes"; return; }
+    mb.R = mb.r * mb.ns;
+#define JX_PICK(Rv) if (!mb.RT && mb.R <= Rv) mb.RT = Rv;
+    JX_MIX_RTS(JX_PICK)
+#undef JX_PICK
+    if (!mb.RT) { mb.why = "rank of the separable form beyond the stage-1 kernel (" + std::to_string(mb.r) + " x " + std::to_string(mb.ns) + " terms)"; return; }
+    mb.cld = mb.RT;
+    jxt::mix_stage1_operator(U, mb.r, by, mb.ns, S, B, NU, mb.cols.wld, mb.cld, mb.Cm);
+    // output tiling of stage 2: the instance with the least padded work
+    const int tiles = (nrow + 15) / 16;
+    double best = 1e300;
+#define JX_PICK(Xv) { const int og = (tiles + Xv - 1) / Xv; const double cost = (double)og * Xv * (1.0 + 0.5 / Xv); if (cost < best) { best = cost; mb.nxt = Xv; mb.nog = og; } }
+    JX_MIX_NXTS(JX_PICK)
+#undef JX_PICK
+    mb.ntile = mb.nog * mb.nxt;
+    const size_t K = (size_t)NU * mb.R;
+    mb.ksteps = (int)((K + 3) / 4);
+    mb.krows = 4 * ((size_t)mb.ksteps + (size_t)JX_MIX_KSPLIT_MAX * JX_OPG_RD + JX_OPG_RD);
+    jxt::mix_stage2_operator(V, mb.r, bx, mb.ns, S, B, NU, mb.krows, mb.ntile, mb.Op);
+    mb.ok = true;
+}
+
 #define JX_LR_TOL_DEFAULT 1e-8
 #define JX_TRUNC_BOUND 2e-10
 static int finalize_impl(jx_ctx* ctx) {
@@ -556,12 +627,34 @@ static int finalize_impl(jx_ctx* ctx) {
     ctx->nt = ctx->nrow - 1;
     ctx->Sh = S / 2 + 1;
     const int o = (B - 1) / 2;
+    std::vector<double> r = host_vec<double>(ctx, JX_T_R_PP);
+    const std::vector<double>& r_grid = r;
+    for (int i = 0; i < N; ++i) {
+        if (!(r[i] > 0) || (i && !(r[i] > r[i - 1]))) { ctx->err = "r_pp must be positive and increasing"; return JX_ERR_INVALID; }
+    }
+    // ---- does d_mat have the mirror structure d_mat[iy][ix] = Q[|iy-c|][|ix-c|] (what centdistmat builds)?
+    std::vector<double> dm_h = host_vec<double>(ctx, JX_T_D_MAT);
+    const int cc0 = S / 2, qn = std::max(cc0, S - 1 - cc0) + 1;
+    std::vector<double> Qtab((size_t)qn * qn);
+    bool dmat_mirror = true;
+    {
+        for (int b = 0; b < qn; ++b)
+            for (int a = 0; a < qn; ++a) {
+                const int iy = (cc0 + b < S) ? cc0 + b : cc0 - b, ix = (cc0 + a < S) ? cc0 + a : cc0 - a;
+                Qtab[(size_t)b * qn + a] = dm_h[(size_t)iy * S + ix];
+            }
+        for (int iy = 0; iy < S && dmat_mirror; ++iy)
+            for (int ix = 0; ix < S; ++ix) {
+                const double q = Qtab[(size_t)std::abs(iy - cc0) * qn + std::abs(ix - cc0)];
+                if (memcmp(&q, &dm_h[(size_t)iy * S + ix], sizeof(double)) != 0) { dmat_mirror = false; break; }
+            }
+    }
     // ---- which convolution: rocFFT sequence or the hand-written mixed-domain passes
     int want = c.conv_mode;
     if (const char* e = getenv("JOXSZ_CONV")) {
-        if (!strcmp(e, "rocfft")) want = 1; else if (!strcmp(e, "custom")) want = 2; else if (!strcmp(e, "auto")) want = 0;
+        if (!strcmp(e, "rocfft")) want = 1; else if (!strcmp(e, "custom")) want = 2; else if (!strcmp(e, "auto")) want = 0; else if (!strcmp(e, "mix")) want = 3;
     }
-    if (want < 0 || want > 2) { ctx->err = "conv_mode must be 0, 1 or 2"; return JX_ERR_INVALID; }
+    if (want < 0 || want > 3) { ctx->err = "conv_mode must be 0, 1, 2 or 3"; return JX_ERR_INVALID; }
     std::vector<double> beam_h = host_vec<double>(ctx, JX_T_BEAM_2D);
     const bool oddS = (S & 1) != 0;
     OddPlan oplan;
@@ -575,7 +668,14 @@ static int finalize_impl(jx_ctx* ctx) {
     double lr_tol0 = (S < 400) ? 1e-13 : JX_LR_TOL_DEFAULT;
     if (const char* e = getenv("JOXSZ_LOWRANK_TOL")) { const double v2 = atof(e); if (v2 > 0.0 && v2 < 1e-6) lr_tol0 = v2; }
     if (ctx->lr_tol_override > 0.0) lr_tol0 = ctx->lr_tol_override;
-    if (oddS && want != 1 && c.fft_pad == 0 && JX_FIR_TILE + 2 * o <= JX_FIR_RING && !getenv("JOXSZ_ODD_ROCFFT"))
+    // contracted route first (jx_mix.hpp): every map side, odd ones included
+    MixBuild mixb;
+    if (want == 3 || want == 0) {
+        plan_mix(c, beam_h, host_vec<double>(ctx, JX_T_FILTERING), Qtab, qn, dmat_mirror, r, lr_tol0, mixb);
+        if (want == 3 && !mixb.ok) { ctx->err = "contracted route: " + mixb.why; return JX_ERR_UNSUPPORTED; }
+        if (mixb.ok) want = 3;
+    }
+    if (oddS && want != 1 && want != 3 && c.fft_pad == 0 && JX_FIR_TILE + 2 * o <= JX_FIR_RING && !getenv("JOXSZ_ODD_ROCFFT"))
         plan_odd(c, beam_h, host_vec<double>(ctx, JX_T_FILTERING), host_vec<double>(ctx, JX_T_D_MAT), lr_tol0, oplan);
     const int lp_custom = oddS ? (oplan.ok ? oplan.LP : 0) : jxt::custom_conv_lp(S, o);
     const size_t fir_lds = sizeof(double) * ((size_t)2 * JX_FIR_RING * JX_FIR_KX + (size_t)(o + 1) * JX_FIR_KX) + sizeof(int) * (size_t)(S + 4);
@@ -585,8 +685,8 @@ static int finalize_impl(jx_ctx* ctx) {
                         : std::string("hand-written convolution needs S/2 in {16,24,32,64,128,256,512}, a flip-symmetric beam with (B-1)/2 <= 32 and fft_pad = 0");
         return JX_ERR_UNSUPPORTED;
     }
-    ctx->odd = oddS && eligible && want != 1;
-    ctx->conv_mode = (want == 2 || (want == 0 && eligible)) ? 2 : 1;
+    ctx->odd = oddS && eligible && want != 1 && want != 3;
+    ctx->conv_mode = (want == 3) ? 3 : (want == 2 || (want == 0 && eligible)) ? 2 : 1;
     int P = c.fft_pad > 0 ? c.fft_pad : jxt::next_smooth_even(S + o);
     if (const char* e = getenv("JOXSZ_FFT_PAD")) { int v = atoi(e); if (v > 0 && ctx->conv_mode == 1) P = v; }
     if (ctx->conv_mode == 2) P = 2 * lp_custom;
@@ -594,11 +694,6 @@ static int finalize_impl(jx_ctx* ctx) {
     ctx->P = P;
     ctx->Ph = P / 2 + 1;
 
-    std::vector<double> r = host_vec<double>(ctx, JX_T_R_PP);
-    const std::vector<double>& r_grid = r;
-    for (int i = 0; i < N; ++i) {
-        if (!(r[i] > 0) || (i && !(r[i] > r[i - 1]))) { ctx->err = "r_pp must be positive and increasing"; return JX_ERR_INVALID; }
-    }
     std::vector<int32_t> thawed = host_vec<int32_t>(ctx, JX_T_THAWED_IDX);
     for (int k = 0; k < c.ndim; ++k)
         if (thawed[k] < 0 || thawed[k] >= c.npar) { ctx->err = "thawed_idx out of range"; return JX_ERR_INVALID; }
@@ -679,23 +774,6 @@ static int finalize_impl(jx_ctx* ctx) {
         double* p; if ((rc = dev_put(ctx, E.data(), E.size(), &p))) return rc; d.emat = p;
         if ((rc = dev_put(ctx, flux.data(), flux.size(), &p))) return rc; d.flux = p;
     }
-    // ---- does d_mat have the mirror structure d_mat[iy][ix] = Q[|iy-c|][|ix-c|] (what centdistmat builds)?
-    std::vector<double> dm_h = host_vec<double>(ctx, JX_T_D_MAT);
-    const int cc0 = S / 2, qn = std::max(cc0, S - 1 - cc0) + 1;
-    std::vector<double> Qtab((size_t)qn * qn);
-    bool dmat_mirror = true;
-    {
-        for (int b = 0; b < qn; ++b)
-            for (int a = 0; a < qn; ++a) {
-                const int iy = (cc0 + b < S) ? cc0 + b : cc0 - b, ix = (cc0 + a < S) ? cc0 + a : cc0 - a;
-                Qtab[(size_t)b * qn + a] = dm_h[(size_t)iy * S + ix];
-            }
-        for (int iy = 0; iy < S && dmat_mirror; ++iy)
-            for (int ix = 0; ix < S; ++ix) {
-                const double q = Qtab[(size_t)std::abs(iy - cc0) * qn + std::abs(ix - cc0)];
-                if (memcmp(&q, &dm_h[(size_t)iy * S + ix], sizeof(double)) != 0) { dmat_mirror = false; break; }
-            }
-    }
 
     // ---- twiddles of the final inverse transform of the extracted row (both modes)
     {
@@ -704,7 +782,9 @@ static int finalize_impl(jx_ctx* ctx) {
         for (int m = 0; m < S; ++m) { tw[2 * m] = std::cos(2.0 * jxt::kPi * m / S); tw[2 * m + 1] = std::sin(2.0 * jxt::kPi * m / S); }
         if ((rc = dev_put(ctx, tw.data(), tw.size(), &p))) return rc; d.twid = p;
     }
-    if (ctx->conv_mode == 1) {
+    if (ctx->conv_mode == 3) {
+        ctx->lr_tol = lr_tol0;
+    } else if (ctx->conv_mode == 1) {
         // ---- rocFFT sequence: beam spectrum and transfer-function row table
         std::vector<double> bh;
         jxt::beam_spectrum(beam_h, B, P, c.step * c.step / ((double)P * (double)P), bh);
@@ -896,7 +976,7 @@ static int finalize_impl(jx_ctx* ctx) {
         d.fast_map = sym ? 1 : 0;
         d.q_na = d.q_nb = na;
         // x-symmetric convolution + symmetric map kernel: only the quadrant of distinct pixels is ever stored
-        d.quad = (ctx->conv_mode == 2 && ctx->cv.xsym && sym && na == S / 2 + 1) ? 1 : 0;
+        d.quad = (((ctx->conv_mode == 2 && ctx->cv.xsym) || ctx->conv_mode == 3) && sym && na == S / 2 + 1) ? 1 : 0;
         if (const char* e = getenv("JOXSZ_FULL_MAP")) { if (atoi(e) > 0) d.quad = 0; }
         ctx->cv.quad = d.quad;
         if (sym) {
@@ -919,7 +999,9 @@ static int finalize_impl(jx_ctx* ctx) {
     }
 
     // ---- chunk capacity and work buffers
-    const size_t per_walker = (ctx->conv_mode == 1)
+    const size_t per_walker = (ctx->conv_mode == 3)
+        ? sizeof(double) * ((size_t)d.q_nb * (d.q_na + 16) + (size_t)mixb.krows + (size_t)(JX_MIX_KSPLIT_MAX + 1) * 16 * mixb.ntile + 4 * (size_t)N + 64)
+        : (ctx->conv_mode == 1)
         ? sizeof(double) * ((size_t)P * P * 2 + (size_t)P * ctx->Ph * 2 + (size_t)S * ctx->Sh * 2)
         : ctx->odd ? sizeof(double) * ((size_t)d.q_nb * (d.q_na + 16) + (size_t)ctx->Ph * (ctx->cv.NU + 4) + (size_t)(ctx->Ph + 2 * ctx->nrow + 300) * 64)
         : sizeof(double) * ((d.quad ? (size_t)d.q_nb * (d.q_na + 16) : (size_t)S * S) + (size_t)(ctx->cv.NU + ctx->cv.CROWS) * ctx->cv.fir_ld + (size_t)ctx->cv.NJ * 28 + (size_t)ctx->cv.nblk3 * ctx->Sh * 2);
@@ -965,7 +1047,38 @@ static int finalize_impl(jx_ctx* ctx) {
     if ((rc = dev_new(ctx, (size_t)chunk, &ctx->d_base))) return rc;
     if ((rc = dev_new(ctx, (size_t)chunk * ctx->nrow, &ctx->d_cfac))) return rc;
     if (c.calc_integ && (rc = dev_new(ctx, (size_t)chunk, &ctx->d_sz0, true))) return rc;
-    if (ctx->conv_mode == 1) {
+    if (ctx->conv_mode == 3) {
+        // ---- contracted route: spline arrays walker-minor -> stage 1 (rows mixed per column) -> stage 2 (matrix cores) -> tail
+        if (!d.quad) { ctx->err = "contracted route needs the quadrant map tables"; return JX_ERR_UNSUPPORTED; }
+        if ((rc = dev_new(ctx, (size_t)chunk * d.img_ws, &ctx->d_img, true))) return rc;         // y_2d tap only
+        if ((rc = dev_new(ctx, (size_t)chunk * d.q_nb, &d.xcol))) return rc;
+        const long long tW = ((long long)chunk + 127) & ~127LL;
+        ctx->mix_tW = tW;
+        ctx->mix_form = 0; ctx->mix_RT = mixb.RT; ctx->mix_nxt = mixb.nxt; ctx->mix_r = mixb.r; ctx->mix_ns = mixb.ns;
+        ctx->lr.r = mixb.r;                                     // (jx_get_truncation reports it)
+        JxMix& mx = ctx->mx;
+        memset(&mx, 0, sizeof(mx));
+        mx.NU = mixb.NU; mx.R = mixb.R; mx.tW = tW; mx.segld = mixb.cols.segld; mx.wld = mixb.cols.wld; mx.cld = mixb.cld;
+        int* qi; double* qd;
+        if ((rc = dev_put(ctx, mixb.cols.seg0.data(), mixb.cols.seg0.size(), &qi))) return rc; mx.seg0 = qi;
+        if ((rc = dev_put(ctx, mixb.cols.nseg.data(), mixb.cols.nseg.size(), &qi))) return rc; mx.nseg = qi;
+        if ((rc = dev_put(ctx, mixb.cols.seg.data(), mixb.cols.seg.size(), &qi))) return rc; mx.seg = qi;
+        if ((rc = dev_put(ctx, mixb.cols.w4.data(), mixb.cols.w4.size(), &qd))) return rc; mx.w4 = qd;
+        if ((rc = dev_put(ctx, mixb.Cm.data(), mixb.Cm.size(), &qd))) return rc; mx.Cm = qd;
+        JxOpg& og = ctx->og;
+        memset(&og, 0, sizeof(og));
+        og.tW = tW; og.ntile = mixb.ntile; og.nog = mixb.nog; og.ldx = 16 * mixb.ntile;
+        if ((rc = dev_put(ctx, mixb.Op.data(), mixb.Op.size(), &qd))) return rc; og.Op = qd;
+        ctx->mix_ncol = 2 * N;
+        if ((rc = dev_new(ctx, (size_t)2 * (N + JX_MIX_NS + 2) * tW, &ctx->d_cft, true))) return rc;
+        if ((rc = dev_new(ctx, mixb.krows * (size_t)tW, &ctx->d_Dt, true))) return rc;
+        og.Dt = ctx->d_Dt;
+        if ((rc = dev_new(ctx, (size_t)JX_MIX_KSPLIT_MAX * tW * og.ldx, &ctx->d_Pt))) return rc;
+        ctx->mix_ksteps = mixb.ksteps;
+        ctx->dct.cf_ws = (2 * ((long long)N + 2) + 15) & ~15LL;
+        if ((rc = dev_new(ctx, (size_t)chunk * ctx->dct.cf_ws, &ctx->d_cf, true))) return rc;    // Abel kernel's walker-major copy (profile taps)
+        if ((rc = setup_abel_gemm(ctx, chunk))) return rc;
+    } else if (ctx->conv_mode == 1) {
         if ((rc = dev_new(ctx, (size_t)chunk * P * P, &ctx->d_img, true))) return rc;     // padding stays zero for ever
         if ((rc = dev_new(ctx, (size_t)chunk * P * P, &ctx->d_conv))) return rc;
         if ((rc = dev_new(ctx, (size_t)chunk * P * ctx->Ph, &ctx->d_spec))) return rc;
@@ -1557,6 +1670,49 @@ static int launch_custom_conv(jx_ctx* ctx, int n, double* tap_convjobs, EvSet* e
     return JX_OK;
 }
 
+// Contracted route (jx_mix.hpp): spline arrays (walker-minor) -> stage 1 -> stage 2 -> tail.  es: the launch's event set or null.
+static int launch_mix(jx_ctx* ctx, int n, EvSet* es) {
+    hipStream_t st = ctx->stream;
+    const bool f32 = false;
+    (void)f32;
+    if (ctx->mix_form == 0) {
+        JxMix mx = ctx->mx;
+        mx.n = n;
+        const int ngrp = (n + 63) / 64, gpx = (ngrp + 7) / 8;
+        const dim3 g1((unsigned)(8 * gpx * mx.NU));
+        bool done = false;
+#define JX_MIX_GO(Rv) if (!done && ctx->mix_RT == Rv) { \
+            hipLaunchKernelGGL((jx_rowmix_kernel<Rv, JX_MIX_NS, double2>), g1, dim3(64), 0, st, mx, reinterpret_cast<const double2*>(ctx->d_cft), ctx->d_Dt); done = true; }
+        JX_MIX_RTS(JX_MIX_GO)
+#undef JX_MIX_GO
+        if (!done) { ctx->err = "no stage-1 kernel for this rank"; return JX_ERR_UNSUPPORTED; }
+    }
+    if (es) HIPCHK(ctx, hipEventRecord(es->e[3], st));
+    {
+        JxOpg og = ctx->og;
+        og.n = n;
+        const int nwb = (n + 127) / 128;
+        int ksplit = (2 * ctx->num_cu + nwb * og.nog - 1) / (nwb * og.nog);
+        if (const char* e = getenv("JOXSZ_MIX_KSPLIT")) { const int v = atoi(e); if (v > 0) ksplit = v; }
+        ksplit = std::max(1, std::min(std::min(ksplit, JX_MIX_KSPLIT_MAX), (ctx->mix_ksteps + 7) / 8));
+        int kper = (ctx->mix_ksteps + ksplit - 1) / ksplit;
+        kper = (kper + JX_OPG_RD - 1) / JX_OPG_RD * JX_OPG_RD;
+        ksplit = (ctx->mix_ksteps + kper - 1) / kper;
+        og.ksplit = ksplit; og.kper = kper;
+        ctx->og.ksplit = ksplit;                                  // (the tail sums this many partials)
+        const int nunit = ksplit * og.nog;
+        const dim3 g2((unsigned)(8 * nwb * ((nunit + 7) / 8)));
+        bool done = false;
+#define JX_OPG_GO(Xv) if (!done && ctx->mix_nxt == Xv) { \
+            hipLaunchKernelGGL((jx_opgemm_kernel<0, Xv, double2>), g2, dim3(256), 0, st, og, reinterpret_cast<const double2*>(ctx->d_cft), ctx->d_Pt); done = true; }
+        JX_MIX_NXTS(JX_OPG_GO)
+#undef JX_OPG_GO
+        if (!done) { ctx->err = "no stage-2 kernel for this output tiling"; return JX_ERR_UNSUPPORTED; }
+    }
+    if (es && !es->p1only) HIPCHK(ctx, hipEventRecord(es->e[4], st));
+    return JX_OK;
+}
+
 // One chunk: walkers [w0, w0+n) of the batch whose thetas live at theta_dev.
 static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int w0, int n, const Taps& t) {
     const JxDev& d = ctx->d;
@@ -1568,13 +1724,15 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
     EvSet es;
     // timing mode 2 records the two events around pass 1 only (default route of the hand-written convolution); elsewhere it records nothing
     const bool tm = ctx->timing_on && ctx->timing_mode != 2;
-    const bool tm2 = ctx->timing_on && ctx->timing_mode == 2 && ctx->conv_mode == 2 && !op_route;
+    const bool tm2 = ctx->timing_on && ctx->timing_mode == 2 && ctx->conv_mode >= 2 && !op_route;
     // the operator route has no per-walker work buffers beyond these three, so its launches can be much larger than a chunk
     double* base_buf = op_route ? ctx->d_base_op : ctx->d_base;
     double* cfac_buf = op_route ? ctx->d_cfac_op : ctx->d_cfac;
     double* sz0_buf = op_route ? ctx->d_sz0_op : ctx->d_sz0;           // null unless calc_integ
     // default route: the map rows are evaluated inside pass 1 from the coefficients (no image), unless the image is asked for
-    const bool dct = !op_route && ctx->dct_ok && (ctx->odd || (use_fused(ctx, t.conv) && !t.need_img));
+    const bool mix = !op_route && ctx->conv_mode == 3;
+    if (mix && t.conv) { ctx->err = "conv_2d tap: not available on the contracted route (use conv = rocfft for this tap)"; return JX_ERR_UNSUPPORTED; }
+    const bool dct = mix || (!op_route && ctx->dct_ok && (ctx->odd || (use_fused(ctx, t.conv) && !t.need_img)));
     // ... and the coefficients come from one matrix product, unless the profile taps are asked for (they live in the Abel kernel)
     // (fp32 contexts keep the spline arrays in float and always take them from the matrix product -- from the injected profiles
     //  when the operator is being built; the Abel kernel then runs beside it only to serve the profile taps)
@@ -1630,7 +1788,9 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
     if (ag) {
         const dim3 grid((n + 31) / 32, (ctx->tm_npair + 3) / 4);
         const double* pp_src = d.inject_pp ? d.inject_pp : ctx->d_ppc;
-        if (f32cf) hipLaunchKernelGGL((jx_abel_gemm_kernel<1, float>), grid, dim3(256), sizeof(double) * JX_OPM_JC * 33, st, pp_src, n, d.N, ctx->d_Tm, ctx->tm_ld,
+        if (mix) hipLaunchKernelGGL((jx_abel_gemm_kernel<1, double, 1>), grid, dim3(256), sizeof(double) * JX_OPM_JC * 33, st, pp_src, n, d.N, ctx->d_Tm, ctx->tm_ld,
+                                    d.K, ctx->tm_ntile, ctx->tm_npair, ctx->d_cft, ctx->mix_tW, (long long)ctx->mix_ncol);
+        else if (f32cf) hipLaunchKernelGGL((jx_abel_gemm_kernel<1, float>), grid, dim3(256), sizeof(double) * JX_OPM_JC * 33, st, pp_src, n, d.N, ctx->d_Tm, ctx->tm_ld,
                                       d.K, ctx->tm_ntile, ctx->tm_npair, reinterpret_cast<float*>(ctx->d_cf), ctx->dct.cf_ws);
         else hipLaunchKernelGGL((jx_abel_gemm_kernel<1>), grid, dim3(256), sizeof(double) * JX_OPM_JC * 33, st, pp_src, n, d.N, ctx->d_Tm, ctx->tm_ld,
                                 d.K, ctx->tm_ntile, ctx->tm_npair, ctx->d_cf, ctx->dct.cf_ws);
@@ -1653,6 +1813,9 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
                 JX_SYM_PICK()
             }
             if (dct) { dm.cf_out = f32cf ? ctx->d_cf_tap : ctx->d_cf; dm.cf_ws = ctx->dct.cf_ws; dm.map_split = 1; }   // phases 1-3 only: spline out (fp32 contexts: to a scratch array, for the taps' sake)
+            // contracted route: the Abel kernel's arrays go straight to the walker-minor array when the matrix product is off
+            // (JOXSZ_ABEL_GEMM=0, operator build), else to the walker-major scratch (only the profile taps are wanted from it)
+            if (mix && !ag) { dm.cf_out = ctx->d_cft; dm.cf_ws = ctx->mix_tW; dm.cf_tr = 1; }
             const dim3 grid(dct ? (unsigned)((n + npw - 1) / npw) : grid0.x);
             JX_SYM_PICK()
 #undef JX_SYM_PICK
@@ -1688,11 +1851,20 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
     } else {
         if (ctx->odd && !dct) { ctx->err = "odd map side: the hand-written route needs the coefficient-fed pass 1"; return JX_ERR_UNSUPPORTED; }
         EvSet* esp = (tm || tm2) ? &es : nullptr;
-        int rc2 = ctx->odd ? launch_odd_conv(ctx, n, esp)
+        int rc2 = mix ? launch_mix(ctx, n, esp) : ctx->odd ? launch_odd_conv(ctx, n, esp)
                 : use_fused(ctx, t.conv) ? launch_fused_conv(ctx, n, esp, dct) : launch_custom_conv(ctx, n, t.conv, esp);
         if (rc2) return rc2;
         zpart = ctx->d_part;
         nblk = ctx->last_nblk3;
+    }
+    if (mix) {
+        const size_t sh = sizeof(double) * (JX_LDS_HDR + (size_t)d.nrow + 8);
+        hipLaunchKernelGGL(jx_tail_row_kernel, dim3(n), dim3(JX_TAIL_THREADS), sh, st, d, ctx->d_Pt, ctx->og.ksplit, (long long)ctx->mix_tW * ctx->og.ldx, ctx->og.ldx,
+                           ctx->d_cfac, ctx->d_sz0, ctx->d_base, logp_dev, w0, t.row, t.bright, t.chisq, t.parts);
+        if (tm) HIPCHK(ctx, hipEventRecord(es.e[5], st));
+        if (tm || tm2) ctx->ev_inflight.push_back(es);
+        HIPCHK(ctx, hipGetLastError());
+        return JX_OK;
     }
     if (ctx->odd) {
         if (t.conv && (rc = launch_odd_conv_tap(ctx, n))) return rc;

@@ -70,6 +70,7 @@ struct JxDev {
     double integ_mu, integ_sig;
     double* cf_out;              // not null: the kernel stops after phase 3 and leaves the spline ordinates and moments (y_k, M_k),
     long long cf_ws;             //   k < N, here: [nlaunch][cf_ws] doubles (jx_rowdct_kernel evaluates the map rows from them)
+    int cf_tr;                   //   1: walker-minor instead, cf_out[(k * cf_ws + w) * 2 + {0, 1}] (cf_ws = walker stride; contracted route)
     const int* q_k;              // [q_nb*q_na] coefficient slot of each quadrant radius
     const double* q_t;           // [q_nb*q_na] local abscissa within that slot
     const double* abel_tab;      // [N][4] (r_j, cj_j, dg_j, sp_j):  A[i][j] = cj_j / sqrt(r_j^2 - r_i^2) for j >= i+2,
@@ -590,8 +591,9 @@ __device__ __forceinline__ void jx_profile_to_coefs(const JxDev& c, const double
     }
     __syncthreads();
     if (c.cf_out) {                                         // (y_k, M_k) pairs out: jx_rowdct_kernel evaluates the map rows from them
-        double2* o = reinterpret_cast<double2*>(c.cf_out + (size_t)w * c.cf_ws);
-        for (int k = tid; k < N; k += nth) o[k] = make_double2(s_y[k], s_M[k]);
+        double2* o = reinterpret_cast<double2*>(c.cf_out) + (c.cf_tr ? (size_t)w : (size_t)w * (c.cf_ws >> 1));
+        const size_t ks = c.cf_tr ? (size_t)c.cf_ws : 1;
+        for (int k = tid; k < N; k += nth) o[k * ks] = make_double2(s_y[k], s_M[k]);
         return;
     }
 
@@ -740,9 +742,10 @@ __device__ __forceinline__ void jx_profile_to_coefs2(const JxDev& c, const doubl
     }
     __syncthreads();
     if (c.cf_out) {                                         // (y_k, M_k) pairs out: jx_rowdct_kernel evaluates the map rows from them
-        double2* oA = reinterpret_cast<double2*>(c.cf_out + (size_t)w * c.cf_ws);
-        double2* oB = reinterpret_cast<double2*>(c.cf_out + (size_t)(w + 1) * c.cf_ws);
-        for (int k = tid; k < N; k += nth) { oA[k] = make_double2(s_yA[k], s_MA[k]); oB[k] = make_double2(s_yB[k], s_MB[k]); }
+        double2* oA = reinterpret_cast<double2*>(c.cf_out) + (c.cf_tr ? (size_t)w : (size_t)w * (c.cf_ws >> 1));
+        double2* oB = reinterpret_cast<double2*>(c.cf_out) + (c.cf_tr ? (size_t)(w + 1) : (size_t)(w + 1) * (c.cf_ws >> 1));
+        const size_t ks = c.cf_tr ? (size_t)c.cf_ws : 1;
+        for (int k = tid; k < N; k += nth) { oA[k * ks] = make_double2(s_yA[k], s_MA[k]); oB[k * ks] = make_double2(s_yB[k], s_MB[k]); }
         return;
     }
 
@@ -1472,10 +1475,13 @@ jx_operator_mfma_kernel(const double* __restrict__ pp /*[launch][N]*/, int n, in
 // they stay in the L1).
 #define JX_AG_R 8
 #define JX_AG_ROWS(N) ((((N) + 4 * JX_AG_R - 1) / (4 * JX_AG_R) + 1) * (4 * JX_AG_R))
-template <int NPW, typename TO = double>
+// TR = 1: the result goes out walker-minor for the contracted route (jx_mix.hpp): cf[(k * cf_ws + w) * 2 + {0: y_k, 1: M_k}],
+// cf_ws = walker stride; columns >= ncol are not stored.
+template <int NPW, typename TO = double, int TR = 0>
 __global__ void __launch_bounds__(256)
 jx_abel_gemm_kernel(const double* __restrict__ pp /*[launch][N]*/, int n, int N, const double* __restrict__ Tm /*[JX_AG_ROWS(N)][ldt], zero rows behind N-1*/,
-                    int ldt, int K, int ntile, int npair, TO* __restrict__ cf /*[launch][cf_ws]; float for the fp32 variant (rounded once, on store)*/, long long cf_ws) {
+                    int ldt, int K, int ntile, int npair, TO* __restrict__ cf /*[launch][cf_ws]; float for the fp32 variant (rounded once, on store)*/, long long cf_ws,
+                    long long ncol = 0) {
     JX_LDS_DECL;
     constexpr int NTL = 2 * NPW;
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
@@ -1549,13 +1555,16 @@ jx_abel_gemm_kernel(const double* __restrict__ pp /*[launch][N]*/, int n, int N,
 #pragma unroll
     for (int t = 0; t < NTL; ++t) {
         const long long col = (long long)tile[t] * 16 + li;
-        if (ks[t] >= ktot4 || col >= cf_ws) continue;
+        if (ks[t] >= ktot4 || col >= (TR ? ncol : cf_ws)) continue;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int w = wb + nt * 16 + lk + 4 * g;
-                if (w < n) cf[(size_t)w * cf_ws + col] = (TO)acc[t][nt][g];
+                if (w < n) {
+                    if (TR) cf[((size_t)(col >> 1) * cf_ws + w) * 2 + (col & 1)] = (TO)acc[t][nt][g];
+                    else cf[(size_t)w * cf_ws + col] = (TO)acc[t][nt][g];
+                }
             }
         }
     }

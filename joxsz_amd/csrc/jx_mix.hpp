@@ -1,0 +1,270 @@
+// Contracted route of the SZ side (round 3; default): the sum over map rows is taken BEFORE any transform, so no row is
+// ever transformed and no row spectrum ever reaches HBM.
+//
+// Reference lines computed (joxsz_funcs.py:462-467, row of :472):
+//     y_2d    = f(d_mat)                                     S x S samples of the mirrored cubic spline
+//     conv_2d = fftconvolve(y_2d, beam_2d, 'same') * step^2
+//     map_out = real(ifft2(fft2(conv_2d) * filtering));      out[x] = map_out[S//2, S//2 + x]
+// y_2d[m][n] = Q[|m-c|][|n-c|] (mirror structure of centdistmat), Q the NU x NU quadrant of distinct samples, and the map
+// from Q to out is linear with constant coefficients.  Two forms of it, chosen at jx_finalize by the cost of each:
+//
+//   low-rank form (separable beam image, smooth transfer function -- every BASELINE config):
+//     step^2 beam[a][b] = sum_s by_s[a] bx_s[b]   (one term for the Gaussian branch of mybeam, joxsz_funcs.py:69-71)
+//     Hy[q][kx] = sum_rho U[rho][q] v_rho[kx]     (transfer-function weights of the extracted row, truncated SVD)
+//     stage 1  jx_rowmix_kernel   D[x'][j] = sum_u C[j][u] Q[u][x'],  j = (rho, s), R = r * ns values per column
+//              -- the ONLY pass over the samples: each is evaluated from the walker's (y_k, M_k) in registers
+//              (f = A y_k + B y_k+1 + C M_k + D M_k+1, joxsz_funcs.py:460-462) and goes straight into R fused
+//              multiply-adds; the map itself is never stored
+//     stage 2  jx_opgemm_kernel<LOAD>   out[x] = sum_{x',j} G[x][(x',j)] D[x'][j]   (beam along x, circular kernel of
+//              term rho along the row, row extraction: one constant nrow x (NU R) matrix; fp64 matrix cores)
+//   full form (any beam image, any real transfer function -- the reference's measured inputs, joxsz_main.py:59-60):
+//     jx_opgemm_kernel<EVAL>   out[x] = sum_{(u,x')} Omega[x][(u,x')] Q[u][x'],  samples evaluated by the lanes that feed
+//              them to the matrix cores; exact (no truncation), cost independent of smoothness
+//   jx_tail_row_kernel  sums the K-slice partials in fixed order, conversion, data radii, chi^2, total (funcs:472-479, 538)
+//
+// Spline arrays arrive walker-minor: cft[k][w] = (y_k, M_k) of walker w as one double2 (jx_abel_gemm_kernel, TR = 1), so a
+// wave whose lanes are 64 consecutive walkers reads one knot of all of them as 1 KB contiguous.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "jx_kernels.hpp"
+
+typedef double jx_mx_v4d __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------------------------
+// Stage 1.  One wave = one column x' of the quadrant x 64 walkers (lane = walker).  The wave walks down the column,
+// u = 0 .. NU-1; the radius grows with u, so the spline interval index never decreases and a knot fetched once serves
+// every sample of its interval: the column is a list of SEGMENTS (one per knot interval, seg[j] = number of samples in
+// it) and the knots sit in a ring of NS named register slots, fetched NS-2 segments before their first use (the segment
+// loop is unrolled NS times: no value ever moves between registers and the waits count the requests in flight).
+// Everything that does not depend on the walker is wave-uniform and arrives through the scalar unit: the four spline
+// weights of the sample and the R coefficients C[u][0..R) of the row, which enter the multiply-adds as SGPR operands.
+// Per sample and walker: 4 + R fp64 FMAs and on average 0.65 x 16 B through the vector L1.
+//   cft  [N + pad][tW] double2      Dt [NU * R][tW]   (row x' * R + j, walker-minor)
+// ------------------------------------------------------------------------------------------------------------------
+struct JxMix {
+    int NU, R, n;                  // quadrant side, combined rows per column, walkers of this launch
+    long long tW;                  // walker stride of cft and Dt (multiple of 128)
+    int segld, wld, cld;           // strides: segment counts per column, samples per column (>= NU), C row (>= RT)
+    const int* seg0;               // [NU]  first knot interval of column x'
+    const int* nseg;               // [NU]  number of segments of column x'
+    const int* seg;                // [NU][segld] samples per segment
+    const double* w4;              // [NU][wld][4] weights (A, B, C, D) of sample u of column x'
+    const double* Cm;              // [wld][cld]   C[u][j], zero padded
+};
+
+template <int RT, int NS, typename TC>
+__global__ void __launch_bounds__(64)
+jx_rowmix_kernel(JxMix m, const TC* __restrict__ cft, double* __restrict__ Dt) {
+    const int lane = threadIdx.x;
+    // XCD-aware: block id % 8 is the XCD; a walker group's spline arrays (0.5 MB) are read by the blocks of one XCD only
+    const int ngrp = (m.n + 63) >> 6, gpx = (ngrp + 7) >> 3;
+    const int id = blockIdx.x, xcd = id & 7, jj = id >> 3;
+    const int grp = (jj % gpx) * 8 + xcd, xq = jj / gpx;
+    if (grp >= ngrp || xq >= m.NU) return;
+    const size_t w = (size_t)grp * 64 + lane;
+    const TC* __restrict__ cw = cft + w;
+    const size_t tW = (size_t)m.tW;
+    const int k0 = __builtin_amdgcn_readfirstlane(m.seg0[xq]), nseg = __builtin_amdgcn_readfirstlane(m.nseg[xq]);
+    const int* __restrict__ sc = m.seg + (size_t)xq * m.segld;
+    const double* __restrict__ wp = m.w4 + (size_t)xq * m.wld * 4;
+    const double* __restrict__ cp = m.Cm;
+    const int cld = m.cld;
+    double acc[RT];
+#pragma unroll
+    for (int j = 0; j < RT; ++j) acc[j] = 0.0;
+    TC q[NS];
+#pragma unroll
+    for (int i = 0; i < NS - 1; ++i) q[i] = cw[(size_t)(k0 + i) * tW];
+    int kk = k0;
+    for (int s0 = 0; s0 < nseg; s0 += NS) {
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            q[(j + NS - 1) % NS] = cw[(size_t)(kk + NS - 1) * tW];
+            const int cnt = (s0 + j < nseg) ? sc[s0 + j] : 0;
+            for (int i = 0; i < cnt; ++i) {
+                const double wa = wp[0], wb = wp[1], wc = wp[2], wd = wp[3];
+                wp += 4;
+                double f = wa * (double)q[j].x;
+                f = fma(wb, (double)q[(j + 1) % NS].x, f);
+                f = fma(wc, (double)q[j].y, f);
+                f = fma(wd, (double)q[(j + 1) % NS].y, f);
+#pragma unroll
+                for (int r = 0; r < RT; ++r) acc[r] = fma(cp[r], f, acc[r]);
+                cp += cld;
+            }
+            ++kk;
+        }
+    }
+    double* __restrict__ dp = Dt + (size_t)xq * m.R * tW + w;
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+        if (r < m.R) dp[(size_t)r * tW] = acc[r];
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Stage 2 and the full form: P[ks][w][x] = sum_{kappa in slice ks} a_kappa(w) Op[x][kappa] on v_mfma_f64_16x16x4.
+//   A operand (M = walkers): lane l holds a_kappa(w) for w = tile + (l & 15), kappa = 4 step + (l >> 4)
+//       LOAD: a = Dt[kappa][w]                         (stage-1 output, 128-byte runs)
+//       EVAL: a = the map sample kappa of walker w, evaluated here from cft (entry table in LDS)
+//   B operand (N = outputs): Op[x][kappa], stored so that a lane's NXT tiles are contiguous: Opk[step][l >> 4][l & 15][tile]
+//   D: register g of lane l = out[walker (l >> 4) + 4 g][x = l & 15]: a walker's row comes out in 128-byte runs
+// Block = 4 waves = 128 walkers (2 tiles per wave) x NXT output tiles x one K slice; operands are fetched RD k-steps ahead
+// into named register slots.  Blocks that share a K slice and an output group share an XCD (Op is read from HBM once).
+// ------------------------------------------------------------------------------------------------------------------
+struct JxSamp { long long off; double a, b, c, d; long long pad; };      // off = knot * tW (elements of cft)
+
+struct JxOpg {
+    int n; long long tW;
+    int ksplit, kper;              // K slices, k-steps per slice (multiple of the prefetch depth)
+    int ntile, nog;                // output tiles in all (multiple of NXT), output groups = ntile / NXT
+    int ldx;                       // doubles per partial row (>= 16 ntile)
+    const double* Op;              // [ksplit * kper + slack][4][16][ntile]
+    const double* Dt;              // LOAD: [4 (ksplit kper + slack)][tW]
+    const JxSamp* ent;             // EVAL: [4 (ksplit kper + slack)]
+};
+
+#define JX_OPG_RD 2
+#define JX_OPG_ECH 256             // EVAL: k-steps of entries staged in LDS at a time (256 x 4 x 48 B = 48 KB)
+
+template <int MODE /*0 LOAD, 1 EVAL*/, int NXT, typename TC>
+__global__ void __launch_bounds__(256)
+jx_opgemm_kernel(JxOpg g, const TC* __restrict__ cft, double* __restrict__ Pt) {
+    extern __shared__ __attribute__((aligned(16))) double sm_opg[];
+    constexpr int RD = JX_OPG_RD;
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwb = (g.n + 127) >> 7, nunit = g.ksplit * g.nog;
+    const int id = blockIdx.x, xcd = id & 7, jj = id >> 3;
+    const int wb = jj % nwb, unit = (jj / nwb) * 8 + xcd;
+    if (unit >= nunit) return;
+    const int ks = unit / g.nog, og = unit - ks * g.nog;
+    const size_t tW = (size_t)g.tW;
+    const size_t wbase = (size_t)wb * 128 + wv * 32 + li;
+    const int s0 = ks * g.kper, s1 = s0 + g.kper;
+    jx_mx_v4d acc[2][NXT];
+#pragma unroll
+    for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+        for (int t = 0; t < NXT; ++t) acc[mm][t] = jx_mx_v4d{0.0, 0.0, 0.0, 0.0};
+    const double* __restrict__ opb = g.Op + ((size_t)lk * 16 + li) * g.ntile + (size_t)og * NXT;
+    const size_t opstep = (size_t)64 * g.ntile;
+    double b[RD][NXT], a[RD][2];
+    TC c0[RD][2], c1[RD][2];
+    double ew[RD][4];
+    (void)c0; (void)c1; (void)ew;
+    const JxSamp* esm = reinterpret_cast<const JxSamp*>(sm_opg);
+    auto fetch = [&](int slot, int s) {
+#pragma unroll
+        for (int t = 0; t < NXT; ++t) b[slot][t] = opb[(size_t)s * opstep + t];
+        if (MODE == 0) {
+            const double* dp = g.Dt + (size_t)(4 * s + lk) * tW + wbase;
+            a[slot][0] = dp[0]; a[slot][1] = dp[16];
+        } else {
+            const JxSamp& e = esm[4 * ((s - s0) % JX_OPG_ECH) + lk];
+            const TC* cp = cft + (size_t)e.off + wbase;
+            c0[slot][0] = cp[0]; c0[slot][1] = cp[16];
+            c1[slot][0] = cp[tW]; c1[slot][1] = cp[tW + 16];
+            ew[slot][0] = e.a; ew[slot][1] = e.b; ew[slot][2] = e.c; ew[slot][3] = e.d;
+        }
+    };
+    auto stage_entries = [&](int sa) {                           // k-steps [sa, sa + ECH) of this slice into LDS
+        __syncthreads();
+        const double* src = reinterpret_cast<const double*>(g.ent + (size_t)4 * sa);
+        for (int i = tid; i < JX_OPG_ECH * 4 * 6; i += 256) sm_opg[i] = src[i];
+        __syncthreads();
+    };
+    // (EVAL: the prefetch never crosses a staging boundary: the slots are refilled after each re-staging)
+    for (int sa = s0; sa < s1; sa += JX_OPG_ECH) {
+        const int sb = (MODE == 1) ? min(s1, sa + JX_OPG_ECH) : s1;
+        if (MODE == 1) stage_entries(sa);
+#pragma unroll
+        for (int u = 0; u < RD - 1; ++u) fetch(u, min(sa + u, sb - 1));
+        for (int s = sa; s < sb; s += RD) {
+#pragma unroll
+            for (int u = 0; u < RD; ++u) {
+                fetch((u + RD - 1) % RD, min(s + u + RD - 1, sb - 1));
+                double av0, av1;
+                if (MODE == 0) { av0 = a[u][0]; av1 = a[u][1]; }
+                else {
+                    av0 = ew[u][0] * (double)c0[u][0].x; av1 = ew[u][0] * (double)c0[u][1].x;
+                    av0 = fma(ew[u][1], (double)c1[u][0].x, av0); av1 = fma(ew[u][1], (double)c1[u][1].x, av1);
+                    av0 = fma(ew[u][2], (double)c0[u][0].y, av0); av1 = fma(ew[u][2], (double)c0[u][1].y, av1);
+                    av0 = fma(ew[u][3], (double)c1[u][0].y, av0); av1 = fma(ew[u][3], (double)c1[u][1].y, av1);
+                }
+#pragma unroll
+                for (int t = 0; t < NXT; ++t) {
+                    acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av0, b[u][t], acc[0][t], 0, 0, 0);
+                    acc[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av1, b[u][t], acc[1][t], 0, 0, 0);
+                }
+            }
+        }
+        if (MODE == 0) break;
+    }
+    const size_t wrow = (size_t)wb * 128 + wv * 32 + lk;
+#pragma unroll
+    for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const size_t w = wrow + mm * 16 + 4 * gq;
+            if (w < (size_t)g.n) {
+                double* row = Pt + ((size_t)ks * tW + w) * g.ldx + (size_t)(og * NXT) * 16 + li;
+#pragma unroll
+                for (int t = 0; t < NXT; ++t) row[t * 16] = acc[mm][t][gq];
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Tail: the extracted row arrives as nks partial rows P[ks][w][ldx] (one per K slice); they are added in a fixed order
+// (a result does not depend on the launch it was part of), then conversion, data radii, chi^2 and total as in
+// jx_tail_kernel (joxsz_funcs.py:472-479, 538).  One block per walker.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(JX_TAIL_THREADS)
+jx_tail_row_kernel(JxDev c, const double* __restrict__ Pt, int nks, long long pstride /*doubles between partials*/, int ldx,
+                   const double* __restrict__ cfac, const double* __restrict__ sz0,
+                   const double* __restrict__ base, double* __restrict__ logp, int w0,
+                   double* __restrict__ tap_row, double* __restrict__ tap_bright, double* __restrict__ tap_chisq,
+                   double* __restrict__ tap_parts) {
+    JX_LDS_DECL;
+    double* red = sm + 20;
+    const int nrow = c.nrow;
+    double* s_prof = sm + JX_LDS_HDR;  // [nrow]
+    const int w = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
+    const double* Pw = Pt + (size_t)w * ldx;
+    for (int k = tid; k < nrow; k += nth) {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int ks = 0;
+        for (; ks + 3 < nks; ks += 4) {
+            a0 += Pw[(size_t)ks * pstride + k]; a1 += Pw[(size_t)(ks + 1) * pstride + k];
+            a2 += Pw[(size_t)(ks + 2) * pstride + k]; a3 += Pw[(size_t)(ks + 3) * pstride + k];
+        }
+        for (; ks < nks; ++ks) a0 += Pw[(size_t)ks * pstride + k];
+        const double acc = (a0 + a1) + (a2 + a3);
+        if (tap_row) tap_row[(size_t)w * nrow + k] = acc;
+        const double b = acc * cfac[(size_t)w * nrow + k];
+        s_prof[k] = b;
+        if (tap_bright) tap_bright[(size_t)w * nrow + k] = b;
+    }
+    __syncthreads();
+    double part = 0.0;
+    for (int dd = tid >> 3; dd < c.nflux; dd += nth >> 3) {         // eight lanes per flux point
+        const double* e = c.emat + (size_t)dd * nrow;
+        double m = 0.0;
+        for (int k = tid & 7; k < nrow; k += 8) m = fma(e[k], s_prof[k], m);
+        m += __shfl_xor(m, 1, 64); m += __shfl_xor(m, 2, 64); m += __shfl_xor(m, 4, 64);
+        const double z = (c.flux[c.nflux + dd] - m) / c.flux[2 * c.nflux + dd];
+        const double z2 = z * z;
+        if ((tid & 7) == 0 && z2 == z2) part += z2;                  // np.nansum drops NaN terms
+    }
+    const double chisq = jx_block_sum(part, red);
+    if (tid == 0) {
+        const double ll = -chisq / 2.0 + (sz0 ? sz0[w] : 0.0);
+        const double b = base[w];
+        double tot = (b == -INFINITY) ? -INFINITY : b + ll;
+        if (tot != tot) tot = -INFINITY;             // never hand NaN to the sampler
+        logp[w0 + w] = tot;
+        if (tap_chisq) tap_chisq[w] = chisq;
+        if (tap_parts) tap_parts[(size_t)w * 4 + 1] = ll;
+    }
+}

@@ -722,6 +722,213 @@ inline void odd_rowspace_operator(const std::vector<double>& V /*[r][Sh] right s
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Rank-revealing form of lowrank_factor for matrices of low numerical rank (the transfer-function weights: ~60 of 257 at
+// 512^2 above rounding): Householder QR with column pivoting, stopped when every remaining column is below 1e-17 of the
+// largest, then the one-sided Jacobi SVD of the small triangular factor.  Same output convention as lowrank_factor
+// (A ~ sum_rho L[rho][i] Rt[rho][j], L = sigma u, unit rows in Rt, sorted, r = terms above tol * sigma_max); the cost falls
+// from m n^2 per Jacobi sweep to m n k + n k^2 (k = numerical rank): 3.3 s -> 0.05 s for the 1024^2 table.
+// ---------------------------------------------------------------------------------------
+inline int lowrank_factor_qr(const double* A, int m, int n, double tol, std::vector<double>& L, std::vector<double>& Rt,
+                             std::vector<double>* sigma_out = nullptr) {
+    std::vector<double> W((size_t)n * m);                                      // column-major working copy: W[j*m + i]
+    for (int i = 0; i < m; ++i)
+        for (int j = 0; j < n; ++j) W[(size_t)j * m + i] = A[(size_t)i * n + j];
+    std::vector<int> perm(n);
+    std::vector<double> cn(n), beta;
+    for (int j = 0; j < n; ++j) {
+        perm[j] = j;
+        double a = 0.0;
+        for (int i = 0; i < m; ++i) a += W[(size_t)j * m + i] * W[(size_t)j * m + i];
+        cn[j] = a;
+    }
+    double big = 0.0;
+    for (double v : cn) big = std::max(big, v);
+    const int kmax = std::min(m, n);
+    int k = 0;
+    for (; k < kmax; ++k) {
+        int piv = k;
+        // exact remaining norms (cheap at these sizes; avoids the downdating cancellation)
+        for (int j = k; j < n; ++j) {
+            double a = 0.0;
+            for (int i = k; i < m; ++i) a += W[(size_t)j * m + i] * W[(size_t)j * m + i];
+            cn[j] = a;
+            if (a > cn[piv]) piv = j;
+        }
+        if (!(cn[piv] > big * 1e-34)) break;
+        if (piv != k) {
+            for (int i = 0; i < m; ++i) std::swap(W[(size_t)k * m + i], W[(size_t)piv * m + i]);
+            std::swap(perm[k], perm[piv]); std::swap(cn[k], cn[piv]);
+        }
+        double* x = &W[(size_t)k * m];
+        const double nrm = std::sqrt(cn[k]);
+        const double alpha = (x[k] > 0.0) ? -nrm : nrm;
+        const double v0 = x[k] - alpha;
+        // v = (v0, x[k+1..]); H = I - b v v^T, b = 2 / (v.v)
+        double vv = v0 * v0;
+        for (int i = k + 1; i < m; ++i) vv += x[i] * x[i];
+        const double b = (vv > 0.0) ? 2.0 / vv : 0.0;
+        for (int j = k + 1; j < n; ++j) {
+            double* y = &W[(size_t)j * m];
+            double d = v0 * y[k];
+            for (int i = k + 1; i < m; ++i) d += x[i] * y[i];
+            d *= b;
+            y[k] -= d * v0;
+            for (int i = k + 1; i < m; ++i) y[i] -= d * x[i];
+        }
+        x[k] = alpha;                                                           // R[k][k]; the reflector stays below it, v0 apart
+        beta.push_back(b);
+        cn[k] = v0;                                                             // (re-used as storage of v0)
+    }
+    if (k == 0) { L.clear(); Rt.clear(); if (sigma_out) sigma_out->assign(n, 0.0); return 0; }
+    // R^T as an n x k matrix (row j = permuted column j of R)
+    std::vector<double> RT((size_t)n * k, 0.0);
+    for (int j = 0; j < n; ++j)
+        for (int i = 0; i <= std::min(j, k - 1); ++i) RT[(size_t)j * k + i] = W[(size_t)j * m + i];
+    std::vector<double> L2, R2, sig;
+    const int r = lowrank_factor(RT.data(), n, k, tol, L2, R2, &sig);         // RT ~ sum L2[rho][j] R2[rho][i]
+    L.assign((size_t)r * m, 0.0);
+    Rt.assign((size_t)r * n, 0.0);
+    std::vector<double> q(m);
+    for (int rho = 0; rho < r; ++rho) {
+        const double s = sig[rho];
+        for (int j = 0; j < n; ++j) Rt[(size_t)rho * n + perm[j]] = L2[(size_t)rho * n + j] / s;
+        // u = Q (R2[rho], 0): reflectors applied last to first
+        std::fill(q.begin(), q.end(), 0.0);
+        for (int i = 0; i < k; ++i) q[i] = R2[(size_t)rho * k + i];
+        for (int h = k - 1; h >= 0; --h) {
+            const double* x = &W[(size_t)h * m];
+            const double v0 = cn[h];
+            double d = v0 * q[h];
+            for (int i = h + 1; i < m; ++i) d += x[i] * q[i];
+            d *= beta[h];
+            q[h] -= d * v0;
+            for (int i = h + 1; i < m; ++i) q[i] -= d * x[i];
+        }
+        for (int i = 0; i < m; ++i) L[(size_t)rho * m + i] = s * q[i];
+    }
+    if (sigma_out) { sigma_out->assign(n, 0.0); for (int j = 0; j < k && j < n; ++j) (*sigma_out)[j] = sig[j]; }
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------
+// Tables of the contracted route (jx_mix.hpp).  c = S/2, umap[m] = |m - c|, NU = distinct rows = distinct columns.
+// ---------------------------------------------------------------------------------------
+struct MixColumns {
+    std::vector<int> seg0, nseg, seg;      // per column x': first knot interval, segments, samples per segment [NU][segld]
+    std::vector<double> w4;                // [NU][wld][4]
+    int segld = 0, wld = 0, maxk = 0;
+};
+
+// Column x' of the quadrant, rows u = 0..NU-1: radius Q[u][x'].  Returns false when the interval index decreases along a
+// column (a d_mat that is not a centred distance matrix): the route is then not taken.
+inline bool mix_column_tables(const std::vector<double>& Qtab /*[qn][qn]: (|iy-c|, |ix-c|)*/, int qn, int NU,
+                              const std::vector<double>& r, MixColumns& t) {
+    const int N = (int)r.size();
+    t.wld = (NU + 3) & ~3;
+    t.w4.assign((size_t)NU * t.wld * 4, 0.0);
+    std::vector<int> kof((size_t)NU * NU);
+    int maxseg = 1;
+    t.seg0.assign(NU, 0); t.nseg.assign(NU, 0);
+    for (int a = 0; a < NU; ++a) {
+        int kprev = 0;
+        for (int u = 0; u < NU; ++u) {
+            int k16; double w[4];
+            const double x = Qtab[(size_t)u * qn + a];
+            spline_sample_weights(r, x, &k16, w);
+            int k = k16 / 16;
+            const bool dead = (x != x) || !(x <= r[N - 1]);                   // NaN radius / fill value: the interval does not matter
+            if (dead) k = (u == 0) ? std::max(0, N - 2) : kprev;
+            if (u > 0 && k < kprev) return false;
+            kprev = k;
+            kof[(size_t)a * NU + u] = k;
+            for (int j = 0; j < 4; ++j) t.w4[((size_t)a * t.wld + u) * 4 + j] = w[j];
+        }
+        t.seg0[a] = kof[(size_t)a * NU];
+        t.nseg[a] = kof[(size_t)a * NU + NU - 1] - t.seg0[a] + 1;
+        maxseg = std::max(maxseg, t.nseg[a]);
+        t.maxk = std::max(t.maxk, kof[(size_t)a * NU + NU - 1]);
+    }
+    t.segld = (maxseg + 3) & ~3;
+    t.seg.assign((size_t)NU * t.segld, 0);
+    for (int a = 0; a < NU; ++a)
+        for (int u = 0; u < NU; ++u) t.seg[(size_t)a * t.segld + (kof[(size_t)a * NU + u] - t.seg0[a])] += 1;
+    return true;
+}
+
+// Separable terms of the beam image, step^2 beam[a][b] ~ sum_s by[s][a] bx[s][b] (terms above tol of the largest).
+inline int beam_separable_terms(const std::vector<double>& beam, int B, double scale, double tol, std::vector<double>& by,
+                                std::vector<double>& bx, std::vector<double>* sigma = nullptr) {
+    std::vector<double> A((size_t)B * B);
+    for (size_t e = 0; e < A.size(); ++e) A[e] = beam[e] * scale;
+    return lowrank_factor(A.data(), B, B, tol, by, bx, sigma);
+}
+
+// Stage-1 operator: C[u][j], j = rho * ns + s:  C = sum_q U[rho][q] sum_{m: umap[m] = u, |q - m| <= o} by_s[q - m + o]
+// (the beam along y, 'same' crop and zero padding of joxsz_funcs.py:464, folded onto the distinct rows).  Row stride cld.
+inline void mix_stage1_operator(const std::vector<double>& U /*[r][S]*/, int r, const std::vector<double>& by /*[ns][B]*/, int ns,
+                                int S, int B, int NU, int rows_ld, int cld, std::vector<double>& Cm) {
+    const int c = S / 2, o = (B - 1) / 2;
+    Cm.assign((size_t)rows_ld * cld, 0.0);
+    std::vector<double> T((size_t)S * NU);
+    for (int s = 0; s < ns; ++s) {
+        std::fill(T.begin(), T.end(), 0.0);
+        for (int q = 0; q < S; ++q)
+            for (int m = std::max(0, q - o); m <= std::min(S - 1, q + o); ++m) T[(size_t)q * NU + std::abs(m - c)] += by[(size_t)s * B + (q - m + o)];
+        for (int rho = 0; rho < r; ++rho) {
+            const int j = rho * ns + s;
+            for (int q = 0; q < S; ++q) {
+                const double uq = U[(size_t)rho * S + q];
+                if (uq == 0.0) continue;
+                const double* tq = &T[(size_t)q * NU];
+                for (int u = 0; u < NU; ++u) if (tq[u] != 0.0) Cm[(size_t)u * cld + j] += uq * tq[u];
+            }
+        }
+    }
+}
+
+// Stage-2 operator in the matrix-core layout of jx_opgemm_kernel:  Op[(kappa * 16 + (x & 15)) * ntile + (x >> 4)],
+// kappa = x' * R + j, j = rho * ns + s:
+//   G[x][kappa] = sum_{n: |n - c| = x'} sum_{x'' in [0,S), |x'' - n| <= o} k_rho[(c + x - x'') mod S] bx_s[x'' - n + o],
+//   k_rho[d] = sum_kc V[rho][kc] cos(2 pi kc d / S)
+// (beam along x with its crop and zero padding, circular kernel of term rho along the row, extraction of the columns
+// c .. S-1; joxsz_funcs.py:464-467, 472).  Rows kappa >= NU R (padding up to krows) stay zero.
+inline void mix_stage2_operator(const std::vector<double>& V /*[r][Sh]*/, int r, const std::vector<double>& bx /*[ns][B]*/, int ns,
+                                int S, int B, int NU, size_t krows, int ntile, std::vector<double>& Op) {
+    const int c = S / 2, Sh = S / 2 + 1, o = (B - 1) / 2, nrow = S - c, R = r * ns;
+    Op.assign(krows * 16 * (size_t)ntile, 0.0);
+    std::vector<double> cs(S), kr(S), g(S);
+    for (int d = 0; d < S; ++d) cs[d] = std::cos(2.0 * kPi * d / S);
+    for (int rho = 0; rho < r; ++rho) {
+        for (int d = 0; d < S; ++d) {
+            double a = 0.0;
+            for (int kc = 0; kc < Sh; ++kc) a += V[(size_t)rho * Sh + kc] * cs[(int)(((long long)kc * d) % S)];
+            kr[d] = a;
+        }
+        for (int s = 0; s < ns; ++s) {
+            const double* b = &bx[(size_t)s * B];
+            // interior columns: g[d] = sum_t k[(d - t) mod S] b[t + o]
+            for (int d = 0; d < S; ++d) {
+                double a = 0.0;
+                for (int t = -o; t <= o; ++t) a += kr[((d - t) % S + S) % S] * b[t + o];
+                g[d] = a;
+            }
+            const int j = rho * ns + s;
+            for (int x = 0; x < nrow; ++x)
+                for (int n = 0; n < S; ++n) {
+                    double v;
+                    if (n >= o && n + o < S) v = g[((c + x - n) % S + S) % S];
+                    else {
+                        v = 0.0;
+                        for (int t = std::max(-o, -n); t <= std::min(o, S - 1 - n); ++t) v += kr[((c + x - n - t) % S + S) % S] * b[t + o];
+                    }
+                    const size_t kappa = (size_t)std::abs(n - c) * R + j;
+                    Op[(kappa * 16 + (x & 15)) * ntile + (x >> 4)] += v;
+                }
+        }
+    }
+}
+
 // smallest even 2^a 3^b 5^c >= n
 inline int next_smooth_even(int n) {
     for (int m = std::max(2, n + (n & 1));; m += 2) {

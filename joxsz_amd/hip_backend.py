@@ -113,7 +113,7 @@ def load_library(path=None):
     return lib
 
 
-CONV_MODES = {'auto': 0, 'rocfft': 1, 'custom': 2}
+CONV_MODES = {'auto': 0, 'rocfft': 1, 'custom': 2, 'mix': 3}
 ROUTES = {'map': 0, 'operator': 1}
 
 
@@ -180,7 +180,7 @@ class HipContext:
         self._chk(self.lib.jx_get_info(self._h, f, c, b, n, nb), 'jx_get_info')
         self.fft_pad, self.chunk, self.spline_band, self.nrow, self.device_bytes = f.value, c.value, b.value, n.value, nb.value
         self.device_name = self.lib.jx_device_name(self._h).decode()
-        self.conv = {1: 'rocfft', 2: 'custom'}.get(self.lib.jx_get_conv_mode(self._h), '?')
+        self.conv = {1: 'rocfft', 2: 'custom', 3: 'mix'}.get(self.lib.jx_get_conv_mode(self._h), '?')
         self.conv_layout = None
         if self.conv == 'custom':
             lay = (ctypes.c_int32 * 12)()
