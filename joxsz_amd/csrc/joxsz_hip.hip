@@ -551,7 +551,7 @@ static int setup_abel_gemm(jx_ctx* ctx, int chunk) {
 }
 
 // ---- contracted route (jx_mix.hpp): host-side plan.  Built before the route is chosen, so that `auto` can fall back.
-#define JX_MIX_NS 6
+#define JX_MIX_NS 8
 #define JX_MIX_RTS(X) X(4) X(8) X(12) X(16) X(20) X(24) X(28) X(32) X(40) X(48) X(56) X(64)
 #define JX_MIX_NXTS(X) X(1) X(2) X(3) X(4) X(5) X(6)
 #define JX_MIX_KSPLIT_MAX 64
@@ -1070,7 +1070,9 @@ static int finalize_impl(jx_ctx* ctx) {
         og.tW = tW; og.ntile = mixb.ntile; og.nog = mixb.nog; og.ldx = 16 * mixb.ntile;
         if ((rc = dev_put(ctx, mixb.Op.data(), mixb.Op.size(), &qd))) return rc; og.Op = qd;
         ctx->mix_ncol = 2 * N;
-        if ((rc = dev_new(ctx, (size_t)2 * (N + JX_MIX_NS + 2) * tW, &ctx->d_cft, true))) return rc;
+        if ((size_t)16 * (N + 2 * JX_MIX_NS + 2) * tW >= ((size_t)1 << 32)) { ctx->err = "contracted route: launch too large for 32-bit knot offsets (lower max_batch)"; return JX_ERR_UNSUPPORTED; }
+        mx.cft_bytes = (unsigned)((size_t)16 * (N + 2 * JX_MIX_NS + 2) * tW);
+        if ((rc = dev_new(ctx, (size_t)2 * (N + 2 * JX_MIX_NS + 2) * tW, &ctx->d_cft, true))) return rc;
         if ((rc = dev_new(ctx, mixb.krows * (size_t)tW, &ctx->d_Dt, true))) return rc;
         og.Dt = ctx->d_Dt;
         if ((rc = dev_new(ctx, (size_t)JX_MIX_KSPLIT_MAX * tW * og.ldx, &ctx->d_Pt))) return rc;
@@ -1678,11 +1680,19 @@ static int launch_mix(jx_ctx* ctx, int n, EvSet* es) {
     if (ctx->mix_form == 0) {
         JxMix mx = ctx->mx;
         mx.n = n;
-        const int ngrp = (n + 63) / 64, gpx = (ngrp + 7) / 8;
-        const dim3 g1((unsigned)(8 * gpx * mx.NU));
+#ifdef JOXSZ_ABLATIONS
+        if (const char* e = getenv("JOXSZ_MIX_DBG")) mx.dbg = atoi(e);
+#endif
+        int wpb = 4;                                              // waves per block: they share a column's scalar stream
+        if (const char* e = getenv("JOXSZ_MIX_WPB")) { const int v = atoi(e); if (v >= 1 && v <= 16) wpb = v; }
+        const int ngrp = (n + 63) / 64;
+        wpb = std::min(wpb, ngrp);
+        const int nq = (ngrp + wpb - 1) / wpb;
+        mx.cper = (nq <= 8 && 8 % nq == 0) ? 8 / nq : 0;
+        const dim3 g1((unsigned)(mx.cper ? 8 * ((mx.NU + mx.cper - 1) / mx.cper) : nq * mx.NU));
         bool done = false;
 #define JX_MIX_GO(Rv) if (!done && ctx->mix_RT == Rv) { \
-            hipLaunchKernelGGL((jx_rowmix_kernel<Rv, JX_MIX_NS, double2>), g1, dim3(64), 0, st, mx, reinterpret_cast<const double2*>(ctx->d_cft), ctx->d_Dt); done = true; }
+            hipLaunchKernelGGL((jx_rowmix_kernel<Rv, JX_MIX_NS, double2>), g1, dim3(64 * wpb), 0, st, mx, reinterpret_cast<const double2*>(ctx->d_cft), ctx->d_Dt); done = true; }
         JX_MIX_RTS(JX_MIX_GO)
 #undef JX_MIX_GO
         if (!done) { ctx->err = "no stage-1 kernel for this rank"; return JX_ERR_UNSUPPORTED; }

@@ -45,7 +45,10 @@ typedef double jx_mx_v4d __attribute__((ext_vector_type(4)));
 struct JxMix {
     int NU, R, n;                  // quadrant side, combined rows per column, walkers of this launch
     long long tW;                  // walker stride of cft and Dt (multiple of 128)
+    unsigned cft_bytes;            // size of cft (buffer descriptor range)
     int segld, wld, cld;           // strides: segment counts per column, samples per column (>= NU), C row (>= RT)
+    int dbg;                       // diagnostic build only (make ABLATIONS=1): timing experiments, results are wrong
+    int cper;                      // block -> (column, walker-group quad): XCDs per quad (8 / quads) when that divides, else 0
     const int* seg0;               // [NU]  first knot interval of column x'
     const int* nseg;               // [NU]  number of segments of column x'
     const int* seg;                // [NU][segld] samples per segment
@@ -53,47 +56,79 @@ struct JxMix {
     const double* Cm;              // [wld][cld]   C[u][j], zero padded
 };
 
+typedef unsigned jx_mx_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned jx_mx_u2 __attribute__((ext_vector_type(2)));
+template <typename TC> __device__ __forceinline__ TC jx_mx_ldknot(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff);
+template <> __device__ __forceinline__ double2 jx_mx_ldknot<double2>(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+    const jx_mx_u4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+    double2 r;
+    r.x = __hiloint2double((int)v.y, (int)v.x);
+    r.y = __hiloint2double((int)v.w, (int)v.z);
+    return r;
+}
+template <> __device__ __forceinline__ float2 jx_mx_ldknot<float2>(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+    const jx_mx_u2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+    return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+}
+
 template <int RT, int NS, typename TC>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(1024)
 jx_rowmix_kernel(JxMix m, const TC* __restrict__ cft, double* __restrict__ Dt) {
-    const int lane = threadIdx.x;
-    // XCD-aware: block id % 8 is the XCD; a walker group's spline arrays (0.5 MB) are read by the blocks of one XCD only
-    const int ngrp = (m.n + 63) >> 6, gpx = (ngrp + 7) >> 3;
-    const int id = blockIdx.x, xcd = id & 7, jj = id >> 3;
-    const int grp = (jj % gpx) * 8 + xcd, xq = jj / gpx;
+    static_assert(NS == 8, "one aligned 8-dword scalar load carries the sample counts of a group of NS segments");
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
+    // A block = one column x' and wpb walker groups: its waves stream the same weights and coefficients through the
+    // scalar cache (one fill serves them all).  XCD-aware: block id % 8 is the XCD; the blocks of a group quad share XCDs,
+    // so a quad's spline arrays stay in those L2s.
+    const int ngrp = (m.n + 63) >> 6, nq = (ngrp + wpb - 1) / wpb;
+    const int id = blockIdx.x;
+    int gq, xq;
+    if (m.cper > 0) { const int xcd = id & 7, jj = id >> 3; gq = xcd % nq; xq = xcd / nq + m.cper * jj; }
+    else { gq = id % nq; xq = id / nq; }
+    const int grp = gq * wpb + wv;
     if (grp >= ngrp || xq >= m.NU) return;
     const size_t w = (size_t)grp * 64 + lane;
-    const TC* __restrict__ cw = cft + w;
     const size_t tW = (size_t)m.tW;
+    // knots through a buffer descriptor: per-lane byte offset in a VGPR that never changes, the knot's offset in an SGPR
+    // -- no address arithmetic on the vector unit and no address registers for the compiler to recycle out of the ring
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<TC*>(cft), 0, m.cft_bytes, 0x00020000);
+    const unsigned loff = (unsigned)((unsigned)grp * 64u + (unsigned)lane) * (unsigned)sizeof(TC);
+    const unsigned kstride = (unsigned)(tW * sizeof(TC));
     const int k0 = __builtin_amdgcn_readfirstlane(m.seg0[xq]), nseg = __builtin_amdgcn_readfirstlane(m.nseg[xq]);
-    const int* __restrict__ sc = m.seg + (size_t)xq * m.segld;
+    const int* __restrict__ sc = m.seg + (size_t)xq * m.segld;                 // [segld], zero padded to a multiple of NS
     const double* __restrict__ wp = m.w4 + (size_t)xq * m.wld * 4;
-    const double* __restrict__ cp = m.Cm;
-    const int cld = m.cld;
+    const double* __restrict__ cp = m.Cm;                                      // rows of RT doubles
     double acc[RT];
 #pragma unroll
     for (int j = 0; j < RT; ++j) acc[j] = 0.0;
     TC q[NS];
+    unsigned kb = (unsigned)k0 * kstride;                    // (uniform) byte offset of the next knot to request
 #pragma unroll
-    for (int i = 0; i < NS - 1; ++i) q[i] = cw[(size_t)(k0 + i) * tW];
-    int kk = k0;
+    for (int i = 0; i < NS - 1; ++i) { q[i] = jx_mx_ldknot<TC>(rs, loff, kb); kb += kstride; }
     for (int s0 = 0; s0 < nseg; s0 += NS) {
+        int cnt[NS];
+#pragma unroll
+        for (int j = 0; j < NS; ++j) cnt[j] = sc[s0 + j];
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
-            q[(j + NS - 1) % NS] = cw[(size_t)(kk + NS - 1) * tW];
-            const int cnt = (s0 + j < nseg) ? sc[s0 + j] : 0;
-            for (int i = 0; i < cnt; ++i) {
+#ifdef JOXSZ_ABLATIONS
+            if (!(m.dbg & 1))                                 // timing experiment (wrong results): no knot requests in the loop
+#endif
+            q[(j + NS - 1) % NS] = jx_mx_ldknot<TC>(rs, loff, kb);
+            kb += kstride;
+            for (int i = 0; i < cnt[j]; ++i) {
                 const double wa = wp[0], wb = wp[1], wc = wp[2], wd = wp[3];
-                wp += 4;
                 double f = wa * (double)q[j].x;
                 f = fma(wb, (double)q[(j + 1) % NS].x, f);
                 f = fma(wc, (double)q[j].y, f);
                 f = fma(wd, (double)q[(j + 1) % NS].y, f);
 #pragma unroll
                 for (int r = 0; r < RT; ++r) acc[r] = fma(cp[r], f, acc[r]);
-                cp += cld;
+#ifdef JOXSZ_ABLATIONS
+                if (!(m.dbg & 2))                             // timing experiment (wrong results): the scalar streams stand still
+#endif
+                { wp += 4; cp += RT; }
             }
-            ++kk;
         }
     }
     double* __restrict__ dp = Dt + (size_t)xq * m.R * tW + w;

@@ -849,7 +849,7 @@ inline bool mix_column_tables(const std::vector<double>& Qtab /*[qn][qn]: (|iy-c
         maxseg = std::max(maxseg, t.nseg[a]);
         t.maxk = std::max(t.maxk, kof[(size_t)a * NU + NU - 1]);
     }
-    t.segld = (maxseg + 3) & ~3;
+    t.segld = (maxseg + 15) & ~7;                                             // zero padded: the kernel reads whole groups of 8
     t.seg.assign((size_t)NU * t.segld, 0);
     for (int a = 0; a < NU; ++a)
         for (int u = 0; u < NU; ++u) t.seg[(size_t)a * t.segld + (kof[(size_t)a * NU + u] - t.seg0[a])] += 1;
