@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define JX_ABI_VERSION 2
+#define JX_ABI_VERSION 3
 
 typedef struct jx_ctx jx_ctx;
 
@@ -68,8 +68,8 @@ typedef struct jx_config {
     int32_t max_batch;        /* walkers processed per internal chunk (0 = library default)    */
     int32_t fft_pad;          /* padded side of the beam convolution (0 = library default)     */
     int32_t map_split;        /* row slabs per walker in the Abel+map kernel (0 = default)     */
-    int32_t conv_mode;        /* beam+TF convolution: 0 auto, 1 rocFFT, 2 hand-written passes  */
-    int32_t dtype;            /* arithmetic of the map / transform stages: 0 = f64 (the reference's), 1 = f32 storage and transforms */
+    int32_t conv_mode;        /* beam + transfer-function step: 0 auto, 1 rocFFT sequence, 2 contracted route (hand-written kernels) */
+    int32_t dtype;            /* arithmetic of the map samples: 0 = f64 (the reference's), 1 = f32 spline arrays and sample evaluation */
     int32_t calc_integ;       /* SZ_data.calc_integ: integrated-Compton term (joxsz_funcs.py:480-484, joxsz_main.py:65) */
     int32_t reserved1;        /* keeps the doubles 8-byte aligned; must be 0                   */
     double step;              /* arcsec                                   (joxsz_main.py:21)   */
@@ -135,21 +135,24 @@ typedef enum jx_stage {
  * with HIP events on the context's stream. */
 typedef struct jx_timing {
     double prep_ms;       /* priors, mass veto, T profile, X-ray Cash      */
-    double abel_map_ms;   /* fused profile -> Abel -> spline -> y map      */
-    double beam_fft_ms;   /* beam convolution: rocFFT R2C + multiply + C2R, or hand-written pass 1 (+ FIR on the routes with separate kernels) */
-    double tf_fft_ms;     /* rocFFT R2C of the S x S window, or the matrix products + hand-written pass 3   */
+    double abel_map_ms;   /* Abel integral + spline arrays (contracted route: one matrix product) / profile -> Abel -> spline -> y map (rocFFT sequence) */
+    double beam_fft_ms;   /* contracted route: stage 1, the map samples evaluated and mixed per column (jx_rowmix_kernel); rocFFT: R2C + multiply + C2R */
+    double tf_fft_ms;     /* contracted route: stage 2 / the full form's product on the matrix cores (jx_opgemm_kernel); rocFFT: R2C of the S x S window */
     double tail_ms;       /* filter + central row + conversion + chi^2     */
     double total_ms;      /* first event to last event of each launch      */
     int64_t launches;     /* internal chunks timed                         */
     int64_t walkers;      /* walkers those chunks processed                */
-    double gemm_ms;       /* part of tf_fft_ms: the FIR + job-combination matrix products of the default route (0 elsewhere) */
+    double gemm_ms;       /* unused (0); kept so that the struct keeps its size */
 } jx_timing;
 
 int  jx_create(const jx_config* cfg, jx_ctx** out);
 int  jx_upload(jx_ctx* ctx, int tensor_id, const void* host, size_t nbytes);
-/* Build the walker-independent tables (Abel weights, spline operators, beam
- * spectrum, transfer-function reduction table), the rocFFT plans and the work
- * buffers.  Must be called once after all uploads and before jx_eval. */
+/* Build the walker-independent tables (Abel weights, spline operators, the operators of the contracted route or the beam
+ * spectrum and transfer-function table of the rocFFT sequence) and the work buffers; measure the truncation of the
+ * low-rank form (jx_get_truncation).  Must be called once after all uploads and before jx_eval.  Environment variables are
+ * read here and nowhere else: JOXSZ_CONV (auto|rocfft|custom), JOXSZ_MIX_FORM (lowrank|full), JOXSZ_LOWRANK_TOL,
+ * JOXSZ_TRUNC_PROBE, JOXSZ_TRUNC_BOUND, JOXSZ_CHUNK, JOXSZ_ABEL_GEMM, JOXSZ_PREP_POW, JOXSZ_MAP_SPLIT, JOXSZ_FFT_PAD,
+ * JOXSZ_OP_NARROW, JOXSZ_MIX_WPB, JOXSZ_MIX_KSPLIT (tuning). */
 int  jx_finalize(jx_ctx* ctx);
 
 /* theta: [nwalkers, ndim] row-major float64; logp: [nwalkers] float64.
@@ -223,51 +226,55 @@ int  jx_comm_init_rank(jx_ctx* ctx, const void* id /* JX_COMM_ID_BYTES */, int n
 int  jx_allgather_logp(jx_ctx* ctx, const double* send_dev, double* recv_dev, int count);
 int  jx_comm_allreduce_max(jx_ctx* ctx, double* inout_dev, int count);
 int  jx_comm_destroy(jx_ctx* ctx);
+/* ranks of the communicator as RCCL counts them (ncclCommCount); < 0 on error */
+int  jx_comm_count(jx_ctx* ctx);
 
 int  jx_timing_reset(jx_ctx* ctx);
-int  jx_timing_enable(jx_ctx* ctx, int on);        /* 0 off; 1 an event behind every stage; 2 only the two events around pass 1 of the
-                                                     * hand-written route (the time-dominant kernel): beam_fft_ms, launches and walkers are filled */
+int  jx_timing_enable(jx_ctx* ctx, int on);        /* 0 off; 1 an event behind every stage; 2 only the two events around stage 1 of the
+                                                     * contracted route (the time-dominant kernel): beam_fft_ms, launches and walkers are filled */
 int  jx_timing_get(jx_ctx* ctx, jx_timing* out);   /* synchronises the stream */
 
 /* Introspection: derived sizes chosen by the library. */
 int  jx_get_info(jx_ctx* ctx, int32_t* fft_pad, int32_t* chunk, int32_t* spline_band,
                  int32_t* nrow, int64_t* device_bytes);
-/* 1 = rocFFT, 2 = hand-written passes (what `conv_mode` resolved to); <0 on error */
+/* 1 = rocFFT sequence, 2 = contracted route (what `conv_mode` resolved to); <0 on error */
 int  jx_get_conv_mode(jx_ctx* ctx);
-/* Layout the library chose for the hand-written convolution: out = {xsym, quad, NU, NJ, ld, img_rows, img_ld, P,
- * rank, fused, kact, 0}.
- * xsym: row spectra travel as one real array (ld doubles per row); quad: the Abel+map kernel stores only the
- * img_rows x img_ld quadrant of distinct pixels per walker instead of the S x S map; NU distinct map rows, NJ
- * convolution jobs, P padded transform length; rank > 0: the transfer-function weights are applied in their
- * low-rank form and pass 3 transforms `rank` combined rows per walker instead of NJ (JOXSZ_LOWRANK=0 turns it
- * off, JOXSZ_LOWRANK_TOL sets the singular-value cut relative to the largest one, default 1e-8 at sides >= 400 and 1e-13 below,
- * see jx_get_truncation); fused = 1: the FIR along rows and that
- * combination run as one matrix product per column kx on walker-minor row spectra (JOXSZ_FUSED=0: separate kernels),
- * for the kact columns below the beam's band limit (every tap beyond is under 0.03 of the singular-value cut, relative to the largest; JOXSZ_BANDLIMIT=0
- * keeps all P/2+1).  JX_ERR_UNSUPPORTED with the rocFFT back end. */
+/* What the contracted route looks like on this problem: out = {form, NU, rank, beam_terms, R, RT, nxt, ntile, ksteps, tW,
+ * ldx, ksplit}.  form 0 = low-rank: the beam image in `beam_terms` separable terms, the transfer-function weights of the
+ * extracted row in `rank` singular terms (cut JOXSZ_LOWRANK_TOL relative to the largest, default 1e-8 at sides >= 400 and
+ * 1e-13 below, see jx_get_truncation), R = rank * beam_terms rows kept per map column by stage 1 (kernel instance RT >= R),
+ * stage 2 one matrix-core product with K = NU * R in `ksteps` steps of 4; form 1 = full: one operator row per distinct map
+ * sample (NU (NU + 1) / 2), no truncation, chosen when it is the cheaper one (measured beam / rough transfer function;
+ * JOXSZ_MIX_FORM=lowrank|full forces a form).  NU distinct map rows = distinct columns, nxt output tiles per block of
+ * `ntile`, tW walker stride of the work buffers, ldx doubles per partial row, ksplit K slices of the last launch.
+ * JX_ERR_UNSUPPORTED with the rocFFT back end. */
 int  jx_get_conv_layout(jx_ctx* ctx, int32_t out[12]);
-/* What the truncations of the default route cost on this problem: out = {singular-value cut in use, largest difference of
- * the extracted row between the truncated route and the route with every job and every column, relative to the row's
- * largest entry (measured in jx_finalize on the current parameter values; odd sides: against a second, small context built
- * with every term kept; -1 where nothing is truncated or nothing was measured), rank, number of times jx_finalize found the
- * estimate above the bound (2e-10; JOXSZ_TRUNC_BOUND) and rebuilt the tables with a cut a hundred times tighter}.
- * JOXSZ_TRUNC_PROBE=0 skips the measurement, an explicit JOXSZ_LOWRANK_TOL is never overridden. */
-int  jx_get_truncation(jx_ctx* ctx, double out[4]);
-/* Test hook (hand-written convolution only): device address and geometry of a work buffer, holding the last
- * evaluated chunk.  which: 0 Compton-y maps [chunk][S][S] (geom[3] = 0) or their quadrant of
- * distinct pixels [chunk][S/2+1][ld], entry (|iy-c|, |ix-c|) (geom[3] = 1), 1 pass-1 row spectra [chunk][NU][ld], 2 FIR output
- * [chunk][NJ+1][ld], 3 column-0 terms [chunk][o+1][NJ] (doubles); 4 conv row of each job [NJ], 5 distinct-row index
- * of each map row [S] (int32); fused route: 6 walker-minor row spectra [Ph][KU][tW], 7 combined rows [tW][Ph][64],
- * 8 their column-0 terms [tW][40][64], 9 walker-minor map column 0 [KU][tW]; low-rank route with separate kernels: 10 combined rows
- * [chunk][rank][ld], 11 their column-0 terms [chunk][o+1][rank] (geom[3] = rank); 12 spline ordinates and moments
- * (y_k, M_k) [chunk][1][cf_ws] of the route that evaluates the map rows inside pass 1.  geom = {chunk, rows, ld, xsym}: ld doubles per row, xsym = 1 when rows 1 and 2 hold
- * the real array R of  Y(kx) = x0 + e^{-2 pi i kx (S/2)/P} R(kx),  0 when they hold (re, im) pairs. */
+/* What the truncation of the low-rank form costs on this problem, measured in jx_finalize against the rocFFT sequence
+ * (exact, independent kernels) at the probe points: the current parameter values and the corners of the prior box in the
+ * thawed shape parameters of the pressure profile (a, b, r_p).  out = {singular-value cut in use; largest difference of the
+ * extracted row at the current parameter values, relative to the row's largest entry; rank; number of times jx_finalize
+ * found an estimate above its bound and rebuilt the tables -- in place -- with a cut ten times tighter; probe points that
+ * gave finite numbers; bound on out[1] (1e-9; JOXSZ_TRUNC_BOUND); the row difference over ALL probe points; largest
+ * difference of the SZ log-likelihood over all probe points relative to max(1, |SZ log-likelihood|), bound 1e-8}.
+ * -1 where nothing is truncated (full form, rocFFT) or nothing was measured (JOXSZ_TRUNC_PROBE=0, dtype f32); an explicit
+ * JOXSZ_LOWRANK_TOL is measured but never overridden. */
+int  jx_get_truncation(jx_ctx* ctx, double out[8]);
+/* Test hook (contracted route): device address and geometry of a work buffer holding the last evaluated chunk.
+ *   0 quadrant of the Compton-y map [chunk][NU][ld] (exists after the first y_2d tap): geom = {chunk, NU, ld, 8}
+ *   1 spline arrays, walker-minor [N][tW][2] = (y_k, M_k) of walker w at ((k tW + w) 2): geom = {N, tW, 2, element bytes}
+ *   2 stage-1 rows [NU][R][tW] (low-rank form): geom = {NU, R, tW, 8}
+ *   3 partial rows of the last launch [ksplit][tW][ldx]: geom = {ksplit, tW, ldx, 8} */
 int  jx_debug_workspace(jx_ctx* ctx, int which, void** dev, int32_t geom[4]);
+/* Duration (ms, HIP events on the context's stream, mean of `repeats` launches) of the Abel + map kernel writing the full
+ * S x S Compton-y map of `nwalkers` walkers whose parameter vectors are at theta_dev: the kernel BASELINE's metric is worded
+ * around (profile -> Abel integral -> spline -> map; S^2 * 8 bytes per walker).  The evaluation path never stores the map;
+ * this call exists for that measurement and allocates its own scratch image. */
+int  jx_map_kernel_time(jx_ctx* ctx, const double* theta_dev, int nwalkers, int repeats, double* ms_out);
 int  jx_device_count(void);
 const char* jx_device_name(jx_ctx* ctx);
 
 const char* jx_strerror(int status);
-const char* jx_last_error(jx_ctx* ctx);            /* detail of the last failure on this context */
+const char* jx_last_error(jx_ctx* ctx);            /* detail of the last failure on this context; NULL context: of the last context-free call (jx_comm_unique_id) */
 void jx_destroy(jx_ctx* ctx);
 
 #ifdef __cplusplus

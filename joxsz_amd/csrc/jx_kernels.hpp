@@ -1,16 +1,16 @@
-// Device kernels of the JoXSZ log-posterior for gfx950 (CDNA4, wave64).
+// Device kernels of the JoXSZ log-posterior for gfx950 (CDNA4, wave64).  All arithmetic is IEEE fp64 like the reference
+// (the fp32 variant of the contracted route narrows the spline arrays and the sample evaluation only).
 //
-// All arithmetic is IEEE fp64 like the reference.  No MFMA: the path is
-// memory-bound integration (HBM write of the y map, FFT/FIR passes), not a dense
-// contraction.  Kernels of this file (one launch each per chunk of walkers):
-//
-//   jx_prep_kernel          theta -> parameter vector, priors, mass veto, T_SZ profile,
+//   jx_prep_kernel          theta -> parameter vector, priors, mass veto, pressure and T_SZ profiles,
 //                           Compton->mJy/beam factors, X-ray counts + Cash likelihood
-//   jx_abel_map_sym_kernel  FUSED gNFW profile -> Abel integral -> Compton y -> cubic
-//   jx_abel_map_kernel      spline -> S x S map (symmetric d_mat / any d_mat)
-//   jx_beam_mul_kernel      spectrum *= beam spectrum (rocFFT back end only)
-//   jx_tail_kernel          extracted row of the filtered map, conversion, chi^2, total
-// The hand-written convolution passes live in jx_conv.hpp.
+//   jx_abel_gemm_kernel     Abel integral, Compton-y scale and spline moments of a launch as one fp64 matrix-core product
+//   jx_abel_map_sym_kernel  FUSED gNFW profile -> Abel integral -> Compton y -> cubic spline -> S x S map (symmetric
+//   jx_abel_map_kernel      d_mat / any d_mat): the profile taps, the y_2d tap, the rocFFT sequence, the full-map measurement
+//   jx_beam_mul_kernel      spectrum *= beam spectrum (rocFFT sequence)
+//   jx_tail_kernel          rocFFT sequence: extracted row of the filtered map, conversion, chi^2, total
+//   jx_operator_*_kernel    collapsed route (jx_set_route)
+//   jx_sm_*_kernel          device-resident stretch move
+// The contracted route's own kernels live in jx_mix.hpp.
 //
 // JOXSZ_DBG (JxDev::dbg; diagnostic build only, make ABLATIONS=1) holds timing-only ablation switches of the map kernel;
 // results are wrong when any is set: 1 skip phases 1-4, 2 skip phase 5, 4 phase 5 = stores only,
@@ -69,7 +69,7 @@ struct JxDev {
     const double* integ_wp;      //   scaling and Abel integral folded into one weight per radius); chi^2 term ((cint - mu)/sig)^2
     double integ_mu, integ_sig;
     double* cf_out;              // not null: the kernel stops after phase 3 and leaves the spline ordinates and moments (y_k, M_k),
-    long long cf_ws;             //   k < N, here: [nlaunch][cf_ws] doubles (jx_rowdct_kernel evaluates the map rows from them)
+    long long cf_ws;             //   k < N, here: [nlaunch][cf_ws] doubles (the contracted route evaluates the map samples from them)
     int cf_tr;                   //   1: walker-minor instead, cf_out[(k * cf_ws + w) * 2 + {0, 1}] (cf_ws = walker stride; contracted route)
     const int* q_k;              // [q_nb*q_na] coefficient slot of each quadrant radius
     const double* q_t;           // [q_nb*q_na] local abscissa within that slot
@@ -590,7 +590,7 @@ __device__ __forceinline__ void jx_profile_to_coefs(const JxDev& c, const double
         if (i < N && hsel == 0) s_M[i] = m;
     }
     __syncthreads();
-    if (c.cf_out) {                                         // (y_k, M_k) pairs out: jx_rowdct_kernel evaluates the map rows from them
+    if (c.cf_out) {                                         // (y_k, M_k) pairs out: the contracted route evaluates the map samples from them
         double2* o = reinterpret_cast<double2*>(c.cf_out) + (c.cf_tr ? (size_t)w : (size_t)w * (c.cf_ws >> 1));
         const size_t ks = c.cf_tr ? (size_t)c.cf_ws : 1;
         for (int k = tid; k < N; k += nth) o[k * ks] = make_double2(s_y[k], s_M[k]);
@@ -741,7 +741,7 @@ __device__ __forceinline__ void jx_profile_to_coefs2(const JxDev& c, const doubl
         if (i < N && hsel == 0) { s_MA[i] = m; s_MB[i] = n; }
     }
     __syncthreads();
-    if (c.cf_out) {                                         // (y_k, M_k) pairs out: jx_rowdct_kernel evaluates the map rows from them
+    if (c.cf_out) {                                         // (y_k, M_k) pairs out: the contracted route evaluates the map samples from them
         double2* oA = reinterpret_cast<double2*>(c.cf_out) + (c.cf_tr ? (size_t)w : (size_t)w * (c.cf_ws >> 1));
         double2* oB = reinterpret_cast<double2*>(c.cf_out) + (c.cf_tr ? (size_t)(w + 1) : (size_t)(w + 1) * (c.cf_ws >> 1));
         const size_t ks = c.cf_tr ? (size_t)c.cf_ws : 1;
@@ -1047,6 +1047,15 @@ jx_beam_mul_kernel(double2* __restrict__ spec, const double2* __restrict__ bhat,
     }
 }
 
+// mirror the quadrant of distinct pixels into the full S x S Compton-y map (parity tap only)
+__global__ void __launch_bounds__(256)
+jx_expand_quad_kernel(const double* __restrict__ quad, size_t q_ld, size_t q_ws, int S, double* __restrict__ full /*[W][S][S]*/) {
+    const int r = blockIdx.x, w = blockIdx.y, c = S >> 1;
+    const double* src = quad + (size_t)w * q_ws + (size_t)abs(r - c) * q_ld;
+    double* dst = full + ((size_t)w * S + r) * S;
+    for (int x = threadIdx.x; x < S; x += blockDim.x) dst[x] = src[abs(x - c)];
+}
+
 // ------------------------------------------------------------------------------------
 // K6+K7: transfer function, central row, conversion, chi^2, total.  One block per walker.
 //   tfspec [chunk][S][Sh] = rfft2 of the beam-convolved S x S window (unnormalised)
@@ -1057,7 +1066,7 @@ jx_beam_mul_kernel(double2* __restrict__ spec, const double2* __restrict__ bhat,
 //   chisq = nansum(((flux - model)/err)^2); logp = base - chisq/2   (joxsz_funcs.py:478-479, 538)
 // ------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(JX_TAIL_THREADS)
-jx_tail_kernel(JxDev c, const double2* __restrict__ tfspec, const double2* __restrict__ zpart, int nblk,
+jx_tail_kernel(JxDev c, const double2* __restrict__ tfspec,
                const double* __restrict__ cfac, const double* __restrict__ sz0,
                const double* __restrict__ base, double* __restrict__ logp, int w0,
                double* __restrict__ tap_row, double* __restrict__ tap_bright, double* __restrict__ tap_chisq,
@@ -1072,16 +1081,7 @@ jx_tail_kernel(JxDev c, const double2* __restrict__ tfspec, const double2* __res
     const double2* X = tfspec + (size_t)w * S * Sh;
     const double2* H = reinterpret_cast<const double2*>(c.htab);
 
-    if (zpart) {
-        // hand-written convolution: Z arrives as per-block partial sums [nblk][Sh], added in a fixed order
-        const double2* Zp = zpart + (size_t)w * nblk * Sh;
-        for (int kc = tid; kc < Sh; kc += nth) {
-            double zr = 0.0, zi = 0.0;
-            for (int b = 0; b < nblk; ++b) { const double2 v = Zp[(size_t)b * Sh + kc]; zr += v.x; zi += v.y; }
-            s_zr[kc] = zr;
-            s_zi[kc] = zi;
-        }
-    } else {
+    {
         for (int kc = tid; kc < Sh; kc += nth) {
             double zr0 = 0.0, zi0 = 0.0, zr1 = 0.0, zi1 = 0.0;
             int kr = 0;
@@ -1127,59 +1127,6 @@ jx_tail_kernel(JxDev c, const double2* __restrict__ tfspec, const double2* __res
         const double z = (c.flux[c.nflux + d] - m) / c.flux[2 * c.nflux + d];
         const double z2 = z * z;
         if (z2 == z2) part += z2;                    // np.nansum drops NaN terms
-    }
-    const double chisq = jx_block_sum(part, red);
-    if (tid == 0) {
-        const double ll = -chisq / 2.0 + (sz0 ? sz0[w] : 0.0);
-        const double b = base[w];
-        double tot = (b == -INFINITY) ? -INFINITY : b + ll;
-        if (tot != tot) tot = -INFINITY;             // never hand NaN to the sampler
-        logp[w0 + w] = tot;
-        if (tap_chisq) tap_chisq[w] = chisq;
-        if (tap_parts) tap_parts[(size_t)w * 4 + 1] = ll;
-    }
-}
-
-// ------------------------------------------------------------------------------------
-// Tail of the odd-side route: the extracted row arrives as r partial rows (one per term of the low-rank transfer
-// function), D2[w][rho][b]; they are added in a fixed order, then conversion, data radii, chi^2 and total as above
-// (joxsz_funcs.py:472-479, 538).
-// ------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(JX_TAIL_THREADS)
-jx_tail_odd_kernel(JxDev c, const double* __restrict__ D2, int r, int ldb, const double* __restrict__ cfac, const double* __restrict__ sz0,
-                   const double* __restrict__ base, double* __restrict__ logp, int w0,
-                   double* __restrict__ tap_row, double* __restrict__ tap_bright, double* __restrict__ tap_chisq,
-                   double* __restrict__ tap_parts) {
-    JX_LDS_DECL;
-    double* red = sm + 20;
-    const int nrow = c.nrow;
-    double* s_prof = sm + JX_LDS_HDR;  // [nrow]
-    const int w = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
-    const double* Dw = D2 + (size_t)w * r * ldb;
-    for (int k = tid; k < nrow; k += nth) {
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-        int rho = 0;
-        for (; rho + 3 < r; rho += 4) {
-            a0 += Dw[(size_t)rho * ldb + k]; a1 += Dw[(size_t)(rho + 1) * ldb + k];
-            a2 += Dw[(size_t)(rho + 2) * ldb + k]; a3 += Dw[(size_t)(rho + 3) * ldb + k];
-        }
-        for (; rho < r; ++rho) a0 += Dw[(size_t)rho * ldb + k];
-        const double acc = (a0 + a1) + (a2 + a3);
-        if (tap_row) tap_row[(size_t)w * nrow + k] = acc;
-        const double b = acc * cfac[(size_t)w * nrow + k];
-        s_prof[k] = b;
-        if (tap_bright) tap_bright[(size_t)w * nrow + k] = b;
-    }
-    __syncthreads();
-    double part = 0.0;
-    for (int dd = tid >> 3; dd < c.nflux; dd += nth >> 3) {         // eight lanes per flux point
-        const double* e = c.emat + (size_t)dd * nrow;
-        double m = 0.0;
-        for (int k = tid & 7; k < nrow; k += 8) m = fma(e[k], s_prof[k], m);
-        m += __shfl_xor(m, 1, 64); m += __shfl_xor(m, 2, 64); m += __shfl_xor(m, 4, 64);
-        const double z = (c.flux[c.nflux + dd] - m) / c.flux[2 * c.nflux + dd];
-        const double z2 = z * z;
-        if ((tid & 7) == 0 && z2 == z2) part += z2;                  // np.nansum drops NaN terms
     }
     const double chisq = jx_block_sum(part, red);
     if (tid == 0) {

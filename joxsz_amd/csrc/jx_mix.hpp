@@ -72,7 +72,7 @@ template <> __device__ __forceinline__ float2 jx_mx_ldknot<float2>(__amdgpu_buff
 }
 
 template <int RT, int NS, typename TC>
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(256)
 jx_rowmix_kernel(JxMix m, const TC* __restrict__ cft, double* __restrict__ Dt) {
     static_assert(NS == 8, "one aligned 8-dword scalar load carries the sample counts of a group of NS segments");
     const int lane = threadIdx.x & 63;

@@ -9,14 +9,32 @@
 //  * nak_eval_matrix      : evaluation matrix of the plain not-a-knot cubic spline with
 //                           extrapolation (joxsz_funcs.py:476) at fixed abscissae.
 //  * beam_spectrum        : half-spectrum of the zero-padded, centre-shifted beam image
-//                           for the FFT convolution of joxsz_funcs.py:464.
+//                           for the FFT convolution of joxsz_funcs.py:464 (rocFFT sequence).
 //  * tf_row_table         : transfer-function weights that collapse the inverse FFT of
-//                           joxsz_funcs.py:467 to the single row joxsz_funcs.py:472 reads.
+//                           joxsz_funcs.py:467 to the single row joxsz_funcs.py:472 reads (rocFFT sequence).
+//  * tf_hy_table, lowrank_factor(_qr), beam_separable_terms, mix_* : operators of the contracted route (jx_mix.hpp).
 #pragma once
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstring>
+#include <thread>
 #include <vector>
+
+// [0, n) in contiguous pieces on up to 16 host threads (table builds only; each piece writes its own rows)
+template <typename F>
+static inline void jx_parallel_for(int n, F&& body) {
+    int nt = (int)std::thread::hardware_concurrency();
+    nt = std::max(1, std::min(std::min(nt, 16), n));
+    if (nt == 1) { body(0, n); return; }
+    std::vector<std::thread> th;
+    const int per = (n + nt - 1) / nt;
+    for (int t = 0; t < nt; ++t) {
+        const int a = t * per, b = std::min(n, a + per);
+        if (a < b) th.emplace_back([&body, a, b]() { body(a, b); });
+    }
+    for (auto& t : th) t.join();
+}
 
 namespace jxt {
 
@@ -357,43 +375,6 @@ inline void host_fft(std::vector<double>& re, std::vector<double>& im, int sign)
     }
 }
 
-// exp(-2 pi i n / L), n = 0..count-1, interleaved re, im
-inline void twiddles(int L, int count, std::vector<double>& out) {
-    out.resize((size_t)count * 2);
-    for (int n = 0; n < count; ++n) { out[2 * n] = std::cos(2.0 * kPi * n / L); out[2 * n + 1] = -std::sin(2.0 * kPi * n / L); }
-}
-
-// Is the beam image symmetric under both flips (then its row transforms are real and
-// symmetric in the row index)?
-inline bool beam_is_symmetric(const std::vector<double>& beam, int B) {
-    double mx = 0;
-    for (double v : beam) mx = std::max(mx, std::fabs(v));
-    const double tol = 1e-14 * mx;
-    for (int u = 0; u < B; ++u)
-        for (int v = 0; v < B; ++v) {
-            const double a = beam[(size_t)u * B + v];
-            if (!(std::fabs(a - beam[(size_t)(B - 1 - u) * B + v]) <= tol)) return false;
-            if (!(std::fabs(a - beam[(size_t)u * B + (B - 1 - v)]) <= tol)) return false;
-        }
-    return true;
-}
-
-// Real FIR taps of the mixed-domain beam convolution: taps[t][kx], t = |row offset| = 0..o,
-//   taps[t][kx] = scale * sum_v beam[o - t][v] cos(2 pi kx (v - o) / P)
-inline void beam_fir_taps(const std::vector<double>& beam, int B, int P, double scale, std::vector<double>& taps) {
-    const int o = (B - 1) / 2, Ph = P / 2 + 1;
-    taps.assign((size_t)(o + 1) * Ph, 0.0);
-    for (int t = 0; t <= o; ++t)
-        for (int kx = 0; kx < Ph; ++kx) {
-            double a = 0.0;
-            for (int v = 0; v < B; ++v) {
-                long long ph = ((long long)kx * (v - o)) % P; if (ph < 0) ph += P;
-                a += beam[(size_t)(o - t) * B + v] * std::cos(2.0 * kPi * ph / P);
-            }
-            taps[(size_t)t * Ph + kx] = a * scale;
-        }
-}
-
 // Hy[r][kc] = w_kc / S^2 * sum_kr Fs[kr][kc] e^{2 pi i kr (c - r)/S}: the symmetrised transfer
 // function taken back to real space along y, at the row offset of the extracted row c = S//2.
 inline void tf_hy_table(const std::vector<double>& filt, int S, std::vector<double>& Hy) {
@@ -423,8 +404,8 @@ inline void tf_hy_table(const std::vector<double>& filt, int S, std::vector<doub
 // (Hestenes) Jacobi rotations on the columns of A: afterwards the columns are orthogonal, their norms
 // are the singular values and the accumulated rotations are the right singular vectors.  L carries
 // the singular value (L = sigma u), Rt has unit rows.  Terms are sorted by singular value; r counts
-// those above tol * sigma_max.  The transfer-function weights Hy[job][kx] have a numerical rank of a
-// few dozen, which lets pass 3 transform r combined rows per walker instead of one per job.
+// those above tol * sigma_max.  The transfer-function weights Hy[q][kx] of a smooth transfer function have a numerical
+// rank of a few dozen, which lets stage 1 of the contracted route keep r numbers per map column instead of one per row.
 // Returns r; sigma_out (optional) receives all n singular values, sorted.
 // ---------------------------------------------------------------------------------------
 inline int lowrank_factor(const double* A, int m, int n, double tol, std::vector<double>& L, std::vector<double>& Rt,
@@ -494,116 +475,11 @@ inline int lowrank_factor(const double* A, int m, int n, double tol, std::vector
 }
 
 // ---------------------------------------------------------------------------------------
-// Row bookkeeping of the hand-written convolution.
-//   mirror = true : map row m equals map row m' whenever |m - c| == |m' - c| (c = S/2), which is
-//                   what a d_mat built by centdistmat gives; otherwise every row is distinct.
-//   umap[m]  distinct-row index of map row m; urow[u] a map row carrying distinct row u.
-//   Conv row r = sum_m tap[|r-m|] * Y[umap[m]] over |r-m| <= o, 0 <= m < S.  Two conv rows are
-//   identical when their multisets of (umap[m], |r-m|) agree; each class becomes one job,
-//   represented by its largest row; jobs ascending; seg = maximal runs of consecutive rows.
-//   rowjob[r] = job of conv row r.
-// ---------------------------------------------------------------------------------------
-struct ConvRows {
-    std::vector<int> umap, urow, jrow, seg, rowjob;
-    int NU = 0, NJ = 0, nseg = 0;
-};
-
-inline void conv_row_tables(int S, int o, bool mirror, ConvRows& t) {
-    const int c = S / 2;
-    t.umap.assign(S, 0);
-    if (mirror) {
-        const int kmax = std::max(c, S - 1 - c);
-        t.NU = kmax + 1;
-        t.urow.assign(t.NU, 0);
-        for (int k = 0; k <= kmax; ++k) t.urow[k] = (c + k < S) ? c + k : c - k;
-        for (int m = 0; m < S; ++m) t.umap[m] = std::abs(m - c);
-    } else {
-        t.NU = S;
-        t.urow.resize(S);
-        for (int m = 0; m < S; ++m) { t.umap[m] = m; t.urow[m] = m; }
-    }
-    // signature of conv row r: sorted list of (u, t) pairs
-    std::vector<std::vector<long long>> sig(S);
-    for (int r = 0; r < S; ++r) {
-        for (int m = std::max(0, r - o); m <= std::min(S - 1, r + o); ++m)
-            sig[r].push_back((long long)t.umap[m] * 4096 + std::abs(r - m));
-        std::sort(sig[r].begin(), sig[r].end());
-    }
-    std::vector<int> rep(S);
-    for (int r = 0; r < S; ++r) {
-        rep[r] = r;
-        for (int r2 = S - 1; r2 > r; --r2)
-            if (sig[r2] == sig[r]) { rep[r] = r2; break; }
-    }
-    t.jrow.clear();
-    for (int r = 0; r < S; ++r) if (rep[r] == r) t.jrow.push_back(r);
-    t.NJ = (int)t.jrow.size();
-    std::vector<int> jobof(S, -1);
-    for (int q = 0; q < t.NJ; ++q) jobof[t.jrow[q]] = q;
-    t.rowjob.assign(S, 0);
-    for (int r = 0; r < S; ++r) t.rowjob[r] = jobof[rep[r]];
-    t.seg.clear();
-    for (int q = 0; q < t.NJ;) {
-        int e = q;
-        while (e + 1 < t.NJ && t.jrow[e + 1] == t.jrow[e] + 1) ++e;
-        t.seg.push_back(t.jrow[q]); t.seg.push_back(e - q + 1); t.seg.push_back(q);
-        q = e + 1;
-    }
-    t.nseg = (int)t.seg.size() / 3;
-}
-
-// ---------------------------------------------------------------------------------------
-// The FIR along map rows followed by the low-rank combination of the jobs is one linear map per
-// column b (b = kx for the row spectra, b = output column x for the column-0 terms):
-//     Ct[rho][b] = sum_q U[rho][q] sum_{m : |r_q - m| <= o} coef[|r_q - m|][b] R[umap[m]][b]
-//                = sum_u T[b][rho][u] R[u][b],
-//     T[b][rho][u] = sum_q U[rho][q] sum_{m : umap[m] = u, |r_q - m| <= o} coef[|r_q - m|][b].
-// coef is [o+1][ldc] (t major); out is [nb][RP][KU], zero padded (RP >= r rows, KU >= NU columns).
-// ---------------------------------------------------------------------------------------
-inline void fused_row_operator(const std::vector<double>& U /*[r][NJ]*/, int r, const ConvRows& rows, int S, int o,
-                               const double* coef, int nb, int ldc, int RP, int KU, std::vector<double>& out) {
-    const int NJ = rows.NJ, NU = rows.NU;
-    out.assign((size_t)nb * RP * KU, 0.0);
-    std::vector<double> g((size_t)NJ * NU);                          // G[q][u] = sum over the m of (q, u) of coef[|r_q - m|][b]
-    for (int b = 0; b < nb; ++b) {
-        std::fill(g.begin(), g.end(), 0.0);
-        for (int q = 0; q < NJ; ++q) {
-            const int rq = rows.jrow[q];
-            for (int m = std::max(0, rq - o); m <= std::min(S - 1, rq + o); ++m)
-                g[(size_t)q * NU + rows.umap[m]] += coef[(size_t)std::abs(rq - m) * ldc + b];
-        }
-        double* ob = &out[(size_t)b * RP * KU];
-        for (int rho = 0; rho < r; ++rho) {
-            double* orow = ob + (size_t)rho * KU;
-            for (int q = 0; q < NJ; ++q) {
-                const double uq = U[(size_t)rho * NJ + q];
-                const double* gq = &g[(size_t)q * NU];
-                const int rq = rows.jrow[q];                          // only |umap[m]| reachable from r_q are non-zero
-                int ulo = NU, uhi = -1;
-                for (int m = std::max(0, rq - o); m <= std::min(S - 1, rq + o); ++m) { ulo = std::min(ulo, rows.umap[m]); uhi = std::max(uhi, rows.umap[m]); }
-                for (int u = ulo; u <= uhi; ++u) orow[u] += uq * gq[u];
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------
-// Tables of jx_rowdct_kernel (jx_dct.hpp).  Per distinct row u and sample a = 0..amax of the quadrant (radius
-// Q[u][a] = d_mat at (|iy-c|, |ix-c|) = (u, a)): the byte offset 16 k of the spline interval in a walker's (y_k, M_k)
-// array and the four weights of
+// One sample of the mirrored cubic spline (interp1d(..., 'cubic') of joxsz_funcs.py:460 evaluated at radius x, funcs:462):
 //     f(x) = A y_k + B y_{k+1} + C M_k + D M_{k+1}
-// (interp1d(..., 'cubic') of joxsz_funcs.py:460 on [r_k, r_{k+1}]: A = 1 - t/h, B = t/h, C = (A^3 - A) h^2/6,
-// D = (B^3 - B) h^2/6; centre interval |x| < r_0 of the mirrored knots: y_0 + M_0 (x^2 - r_0^2)/2; fill value 0 outside
-// r_{N-1}; a NaN radius gives NaN).  Padded with zero weights to 256 entries per pass of 64 lanes x 4 samples.  The
-// unpaired column a = S/2 of an even-sided map comes separately, and the constants of the real-even split.
-// Returns false when the sizes do not fit the kernel's index ranges.
+// on [r_k, r_{k+1}]: A = 1 - t/h, B = t/h, C = (A^3 - A) h^2/6, D = (B^3 - B) h^2/6; centre interval |x| < r_0 of the mirrored
+// knots: y_0 + M_0 (x^2 - r_0^2)/2; fill value 0 outside r_{N-1}; a NaN radius gives NaN.  k16 = 16 k.
 // ---------------------------------------------------------------------------------------
-struct DctTables {
-    std::vector<int> dk, x0k;
-    std::vector<double> dw, x0w, pk;       // dw [nb][na4][4], x0w [nb][4]
-    int gl = 0, na4 = 0, has_x0 = 0, amax = 0;
-};
-
 inline void spline_sample_weights(const std::vector<double>& r, double x, int* k16, double* w4) {
     const int N = (int)r.size();
     *k16 = 0; w4[0] = w4[1] = w4[2] = w4[3] = 0.0;
@@ -615,36 +491,6 @@ inline void spline_sample_weights(const std::vector<double>& r, double x, int* k
     const double h = r[k + 1] - r[k], B = (x - r[k]) / h, A = 1.0 - B;
     *k16 = 16 * k;
     w4[0] = A; w4[1] = B; w4[2] = (A * A * A - A) * h * h / 6.0; w4[3] = (B * B * B - B) * h * h / 6.0;
-}
-
-inline bool dct_tables(const std::vector<double>& Qrad /*[nb][na] radii*/, int na, int nb, const std::vector<double>& r, int S, int LP,
-                       DctTables& t) {
-    const int c = S / 2, Q = LP / 2, P = 2 * LP;
-    if (LP % 2) return false;
-    t.has_x0 = (S % 2 == 0) ? 1 : 0;
-    t.amax = t.has_x0 ? c - 1 : c;
-    if (na < c + 1 || t.amax < 3) return false;
-    t.gl = t.amax / 4;
-    if (t.gl + 2 > Q / 2) return false;                      // z[g], z[Q-g] of g = 0..gl+1 must stay in their own halves
-    const int npass = (t.gl + 1 + 63) / 64;
-    t.na4 = 256 * npass;
-    t.dk.assign((size_t)nb * t.na4, 0);
-    t.dw.assign((size_t)nb * t.na4 * 4, 0.0);
-    t.x0k.assign(nb, 0);
-    t.x0w.assign((size_t)nb * 4, 0.0);
-    for (int u = 0; u < nb; ++u) {
-        for (int a = 0; a <= t.amax; ++a)
-            spline_sample_weights(r, Qrad[(size_t)u * na + a], &t.dk[(size_t)u * t.na4 + a], &t.dw[((size_t)u * t.na4 + a) * 4]);
-        if (t.has_x0) spline_sample_weights(r, Qrad[(size_t)u * na + c], &t.x0k[u], &t.x0w[(size_t)u * 4]);
-    }
-    t.pk.assign((size_t)(Q / 2 + 1) * 4, 0.0);
-    for (int k = 0; k <= Q / 2; ++k) {
-        t.pk[4 * k] = 0.5 * std::cos(2.0 * kPi * k / LP);
-        t.pk[4 * k + 1] = -0.5 * std::sin(2.0 * kPi * k / LP);
-        t.pk[4 * k + 2] = k ? 1.0 / (2.0 * std::sin(2.0 * kPi * k / P)) : 0.0;
-        t.pk[4 * k + 3] = 1.0 / (2.0 * std::sin(2.0 * kPi * (Q - k) / P));
-    }
-    return true;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -668,56 +514,6 @@ inline void abel_spline_operator(const std::vector<double>& r, const std::vector
             const int i0 = std::max(0, k - K), i1 = std::min(std::min(N - 1, k + K), j);
             for (int i = i0; i <= i1; ++i) m += (long double)G[(size_t)k * N + i] * (long double)row[2 * i];
             row[2 * k + 1] = (double)m;
-        }
-    }
-}
-
-// supported (LS = S/2, LP = P/2) pairs of the hand-written convolution
-inline int custom_conv_lp(int S, int o) {
-    static const int pairs[][2] = {{16, 18}, {24, 48}, {32, 48}, {64, 96}, {128, 144}, {256, 288}, {512, 576}};
-    if (S % 2) return 0;
-    for (auto& pr : pairs)
-        if (pr[0] == S / 2 && 2 * pr[1] >= S + o) return pr[1];
-    return 0;
-}
-
-// Odd map sides (the only kind the reference itself builds, joxsz_main.py:100-105): half the padded length for the
-// hand-written route.  The rows need 2 LP >= S + o, and the quarter-length transforms (jx_dct.hpp) need the centre offset
-// c = S/2 <= LP - 5 samples.
-inline int custom_conv_lp_odd(int S, int o) {
-    static const int lps[] = {48, 96, 144, 288, 576};
-    if (S % 2 == 0) return 0;
-    for (int lp : lps)
-        if (2 * lp >= S + o && S / 2 <= lp - 5) return lp;
-    return 0;
-}
-
-// Real-space form of the transfer-function step for odd S.  With the weights in low-rank form, Hy[job][kc] =
-// sum_rho U[rho][job] v_rho[kc], the extracted row is (joxsz_funcs.py:466-467, 472)
-//     row[c + b] = sum_rho sum_{x'} k_rho[(c + b - x') mod S] cc_rho[x'],   k_rho[j] = sum_kc v_rho[kc] cos(2 pi kc j / S),
-// cc_rho the combined rows in real space.  They are symmetric about the centre column, cc_rho[c + a] = cc_rho[c - a], so
-//     row[c + b] = sum_rho sum_{a = 0..c} K[rho][b][a] cc_rho[c + a],   K[rho][b][a] = k_rho[b - a] + (a > 0) k_rho[b + a].
-// Output: for every group mg of 64 rows b and every rho one matrix [64][KQ] (zero padded): out[(mg r + rho) 64 KQ + ...].
-inline void odd_rowspace_operator(const std::vector<double>& V /*[r][Sh] right singular vectors*/, int r, int S, int KQ,
-                                  std::vector<double>& out, int* nmg_out) {
-    const int c = S / 2, Sh = S / 2 + 1, nout = c + 1, nmg = (nout + 63) / 64;
-    *nmg_out = nmg;
-    out.assign((size_t)nmg * r * 64 * KQ, 0.0);
-    std::vector<double> cs(S), k(S);
-    for (int j = 0; j < S; ++j) cs[j] = std::cos(2.0 * kPi * j / S);
-    for (int rho = 0; rho < r; ++rho) {
-        for (int j = 0; j < S; ++j) {
-            double a = 0.0;
-            for (int kc = 0; kc < Sh; ++kc) a += V[(size_t)rho * Sh + kc] * cs[(int)(((long long)kc * j) % S)];
-            k[j] = a;
-        }
-        for (int b = 0; b < nout; ++b) {
-            double* row = &out[(((size_t)(b / 64) * r + rho) * 64 + (b % 64)) * KQ];
-            for (int a = 0; a < nout; ++a) {
-                double v = k[((b - a) % S + S) % S];
-                if (a > 0) v += k[(b + a) % S];
-                row[a] = v;
-            }
         }
     }
 }
@@ -927,6 +723,87 @@ inline void mix_stage2_operator(const std::vector<double>& V /*[r][Sh]*/, int r,
                 }
         }
     }
+}
+
+// Is the quadrant of pixel radii symmetric under transposition, Q[u][x'] == Q[x'][u] bit for bit (a centred distance
+// matrix on one grid for both axes)?  Then the full form keeps one operator row per unordered pair.
+inline bool quadrant_is_symmetric(const std::vector<double>& Qtab, int qn, int NU) {
+    for (int u = 0; u < NU; ++u)
+        for (int x = u + 1; x < NU; ++x)
+            if (memcmp(&Qtab[(size_t)u * qn + x], &Qtab[(size_t)x * qn + u], sizeof(double)) != 0) return false;
+    return true;
+}
+
+// Full form of the contracted route: Om[x][u][x'] = d out[x] / d Q[u][x'] for ANY beam image and any real transfer-function
+// weights Hy[q][kx] (no separability, no truncation):
+//     out[x] = sum_{q,x''} K2[q][(c + x - x'') mod S] conv[q][x''],     K2[q][d] = sum_kx Hy[q][kx] cos(2 pi kx d / S)
+//     conv[q][x''] = sum_{m,n} scale beam[q - m + o][x'' - n + o] y2d[m][n]     ('same' crop, zero padding; funcs:464)
+//     y2d[m][n] = Q[|m - c|][|n - c|]
+// Per distinct row u (independent: one thread each):  KqU[dx][j] = sum_{m in u} sum_q K2[q][j] beam[q - m + o][dx + o],
+// T[n][d] = sum_{dx: n + dx in [0,S)} KqU[dx][(d - dx) mod S]  (one table for all interior n, 2 o boundary ones), and
+// Om[x][u][x'] = sum_{n in x'} T[n][(c + x - n) mod S].
+inline void mix_full_operator(const std::vector<double>& beam, int B, double scale, const std::vector<double>& Hy /*[S][Sh] real*/,
+                              int S, int NU, std::vector<double>& Om /*[nrow][NU][NU]*/) {
+    const int c = S / 2, Sh = S / 2 + 1, o = (B - 1) / 2, nrow = S - c;
+    Om.assign((size_t)nrow * NU * NU, 0.0);
+    std::vector<double> K2((size_t)S * S);
+    {
+        std::vector<double> cs(S);
+        for (int d = 0; d < S; ++d) cs[d] = std::cos(2.0 * kPi * d / S);
+        auto rows = [&](int q0, int q1) {
+            for (int q = q0; q < q1; ++q)
+                for (int d = 0; d < S; ++d) {
+                    double a = 0.0;
+                    for (int kc = 0; kc < Sh; ++kc) a += Hy[(size_t)q * Sh + kc] * cs[(int)(((long long)kc * d) % S)];
+                    K2[(size_t)q * S + d] = a;
+                }
+        };
+        jx_parallel_for(S, rows);
+    }
+    // boundary columns (a tap would fall outside the map) get their own table each
+    std::vector<int> bidx(S, -1);
+    int nbnd = 0;
+    for (int n = 0; n < S; ++n) if (!(n >= o && n + o < S)) bidx[n] = nbnd++;
+    auto per_u = [&](int u0, int u1) {
+        std::vector<double> Kq((size_t)B * S), Tint(S), Tb((size_t)std::max(nbnd, 1) * S);
+        for (int u = u0; u < u1; ++u) {
+            std::fill(Kq.begin(), Kq.end(), 0.0);
+            for (int m = 0; m < S; ++m) {
+                if (std::abs(m - c) != u) continue;
+                for (int q = std::max(0, m - o); q <= std::min(S - 1, m + o); ++q) {
+                    const double* k2 = &K2[(size_t)q * S];
+                    for (int dx = -o; dx <= o; ++dx) {
+                        const double b = scale * beam[(size_t)(q - m + o) * B + dx + o];
+                        if (b == 0.0) continue;
+                        double* kq = &Kq[(size_t)(dx + o) * S];
+                        for (int j = 0; j < S; ++j) kq[j] += b * k2[j];
+                    }
+                }
+            }
+            // interior columns n (o <= n < S - o): every dx is inside the map
+            for (int d = 0; d < S; ++d) {
+                double a = 0.0;
+                for (int dx = -o; dx <= o; ++dx) a += Kq[(size_t)(dx + o) * S + ((d - dx) % S + S) % S];
+                Tint[d] = a;
+            }
+            for (int n = 0; n < S; ++n) {
+                if (bidx[n] < 0) continue;
+                for (int d = 0; d < S; ++d) {
+                    double a = 0.0;
+                    for (int dx = std::max(-o, -n); dx <= std::min(o, S - 1 - n); ++dx) a += Kq[(size_t)(dx + o) * S + ((d - dx) % S + S) % S];
+                    Tb[(size_t)bidx[n] * S + d] = a;
+                }
+            }
+            for (int x = 0; x < nrow; ++x) {
+                double* om = &Om[((size_t)x * NU + u) * NU];
+                for (int n = 0; n < S; ++n) {
+                    const int d = ((c + x - n) % S + S) % S;
+                    om[std::abs(n - c)] += (bidx[n] < 0) ? Tint[d] : Tb[(size_t)bidx[n] * S + d];
+                }
+            }
+        }
+    };
+    jx_parallel_for(NU, per_u);
 }
 
 // smallest even 2^a 3^b 5^c >= n

@@ -3,15 +3,6 @@
 #include <cstring>
 #include <vector>
 #include "jx_tables.hpp"
-#include "jx_regfft.hpp"
-
-// in-register FFT of every supported small length, for the host test
-template <int N> static void regfft_any(double* re, double* im, int inv) {
-    jx_c x[N];
-    for (int i = 0; i < N; ++i) x[i] = jxc(re[i], im[i]);
-    if (inv) jx_regfft<N, true>::run(x); else jx_regfft<N, false>::run(x);
-    for (int i = 0; i < N; ++i) { re[i] = x[i].x; im[i] = x[i].y; }
-}
 
 extern "C" {
 
@@ -59,14 +50,6 @@ int jxt_tf_row_table(const double* filt, int S, double* out /*[S*(S/2+1)*2]*/) {
     return 0;
 }
 
-int jxt_beam_fir_taps(const double* beam, int B, int P, double scale, double* out /*[(o+1)*(P/2+1)]*/) {
-    std::vector<double> bv(beam, beam + (size_t)B * B), t;
-    if (!jxt::beam_is_symmetric(bv, B)) return -1;
-    jxt::beam_fir_taps(bv, B, P, scale, t);
-    memcpy(out, t.data(), sizeof(double) * t.size());
-    return 0;
-}
-
 int jxt_tf_hy_table(const double* filt, int S, double* out /*[S*(S/2+1)*2]*/) {
     std::vector<double> fv(filt, filt + (size_t)S * S), H;
     jxt::tf_hy_table(fv, S, H);
@@ -82,68 +65,17 @@ int jxt_host_fft(double* re, double* im, int n, int sign) {
     return 0;
 }
 
-int jxt_regfft(int n, int inv, double* re, double* im) {
-    switch (n) {
-#define C(N) case N: regfft_any<N>(re, im, inv); return 0;
-        C(2) C(3) C(4) C(6) C(8) C(9) C(12) C(16) C(18) C(24) C(27) C(32)
-#undef C
-    }
-    return -1;
-}
-double jxt_cx_cos2pi(long long k, long long n) { return jx_cx_cos2pi(k, n); }
-double jxt_cx_sin2pi(long long k, long long n) { return jx_cx_sin2pi(k, n); }
-
-int jxt_conv_row_tables(int S, int o, int mirror, int* umap /*[S]*/, int* urow /*[S]*/, int* jrow /*[S]*/,
-                        int* rowjob /*[S]*/, int* seg /*[3*S]*/, int* counts /*[3]: NU, NJ, nseg*/) {
-    jxt::ConvRows t;
-    jxt::conv_row_tables(S, o, mirror != 0, t);
-    memcpy(umap, t.umap.data(), sizeof(int) * S);
-    memcpy(urow, t.urow.data(), sizeof(int) * t.NU);
-    memcpy(jrow, t.jrow.data(), sizeof(int) * t.NJ);
-    memcpy(rowjob, t.rowjob.data(), sizeof(int) * S);
-    memcpy(seg, t.seg.data(), sizeof(int) * t.seg.size());
-    counts[0] = t.NU; counts[1] = t.NJ; counts[2] = t.nseg;
-    return 0;
-}
+int jxt_next_smooth_even(int n) { return jxt::next_smooth_even(n); }
 
 // truncated SVD: returns the rank r; L [r][m], Rt [r][n] (caller sizes them for min(m, n) terms), sigma [n]
-int jxt_lowrank_factor(const double* A, int m, int n, double tol, double* L, double* Rt, double* sigma) {
+// qr != 0: the rank-revealing form (Householder QR with column pivoting, then Jacobi on the small factor)
+int jxt_lowrank_factor(const double* A, int m, int n, double tol, int qr, double* L, double* Rt, double* sigma) {
     std::vector<double> l, rt, sg;
-    const int r = jxt::lowrank_factor(A, m, n, tol, l, rt, &sg);
+    const int r = qr ? jxt::lowrank_factor_qr(A, m, n, tol, l, rt, &sg) : jxt::lowrank_factor(A, m, n, tol, l, rt, &sg);
     std::copy(l.begin(), l.end(), L);
     std::copy(rt.begin(), rt.end(), Rt);
     std::copy(sg.begin(), sg.end(), sigma);
     return r;
-}
-
-// fused FIR + job combination: out [nb][RP][KU] (see jx_tables.hpp fused_row_operator); mirror row structure
-int jxt_fused_row_operator(const double* U, int r, int S, int o, int mirror, const double* coef, int nb, int ldc, int RP, int KU, double* out) {
-    jxt::ConvRows rows;
-    jxt::conv_row_tables(S, o, mirror != 0, rows);
-    std::vector<double> u(U, U + (size_t)r * rows.NJ), w;
-    jxt::fused_row_operator(u, r, rows, S, o, coef, nb, ldc, RP, KU, w);
-    std::copy(w.begin(), w.end(), out);
-    return rows.NJ;
-}
-
-int jxt_custom_conv_lp(int S, int o) { return jxt::custom_conv_lp(S, o); }
-
-int jxt_next_smooth_even(int n) { return jxt::next_smooth_even(n); }
-
-// tables of jx_rowdct_kernel: dk [nb][na4], dw [nb][na4][4], x0k [nb], x0w [nb][4], pk [(LP/4 + 1)][4]; meta = {gl, na4, has_x0, amax}.
-// Call with dk == nullptr to get meta only (sizes).  Returns 0 when the sizes do not fit.
-int jxt_dct_tables(const double* Qrad, int na, int nb, const double* r, int n, int S, int LP, int* meta, int* dk, double* dw,
-                   int* x0k, double* x0w, double* pk) {
-    jxt::DctTables t;
-    if (!jxt::dct_tables(std::vector<double>(Qrad, Qrad + (size_t)na * nb), na, nb, std::vector<double>(r, r + n), S, LP, t)) return 0;
-    meta[0] = t.gl; meta[1] = t.na4; meta[2] = t.has_x0; meta[3] = t.amax;
-    if (!dk) return 1;
-    std::copy(t.dk.begin(), t.dk.end(), dk);
-    std::copy(t.dw.begin(), t.dw.end(), dw);
-    std::copy(t.x0k.begin(), t.x0k.end(), x0k);
-    std::copy(t.x0w.begin(), t.x0w.end(), x0w);
-    std::copy(t.pk.begin(), t.pk.end(), pk);
-    return 1;
 }
 
 // operator of jx_abel_gemm_kernel, [rows][ld]; G = the dense mirrored-spline operator, K = half-width of the band in use
@@ -155,14 +87,66 @@ int jxt_abel_spline_operator(const double* r, int n, const double* G, int K, dou
 }
 int jxt_band_halfwidth(const double* G, int n, double tol) { return jxt::band_halfwidth(std::vector<double>(G, G + (size_t)n * n), n, tol); }
 
-// real-space circular kernels of the odd-side route: out [nmg][r][64][KQ]; returns nmg
-int jxt_odd_rowspace_operator(const double* V, int r, int S, int KQ, double* out) {
-    std::vector<double> o;
-    int nmg = 0;
-    jxt::odd_rowspace_operator(std::vector<double>(V, V + (size_t)r * (S / 2 + 1)), r, S, KQ, o, &nmg);
-    if (out) std::copy(o.begin(), o.end(), out);
-    return nmg;
+// ---- contracted route (jx_mix.hpp) ----
+// weights of one spline sample: out = {k, A, B, C, D}
+int jxt_spline_sample(const double* r, int n, double x, double* out) {
+    int k16; double w[4];
+    jxt::spline_sample_weights(std::vector<double>(r, r + n), x, &k16, w);
+    out[0] = k16 / 16; out[1] = w[0]; out[2] = w[1]; out[3] = w[2]; out[4] = w[3];
+    return 0;
 }
-int jxt_custom_conv_lp_odd(int S, int o) { return jxt::custom_conv_lp_odd(S, o); }
+
+// column tables of stage 1: meta = {segld, wld, maxk}; call with seg0 == nullptr for the sizes.  Returns 0 when the interval
+// index decreases along a column.
+int jxt_mix_columns(const double* Qtab, int qn, int NU, const double* r, int n, int* meta, int* seg0, int* nseg, int* seg, double* w4) {
+    jxt::MixColumns t;
+    if (!jxt::mix_column_tables(std::vector<double>(Qtab, Qtab + (size_t)qn * qn), qn, NU, std::vector<double>(r, r + n), t)) return 0;
+    meta[0] = t.segld; meta[1] = t.wld; meta[2] = t.maxk;
+    if (!seg0) return 1;
+    std::copy(t.seg0.begin(), t.seg0.end(), seg0);
+    std::copy(t.nseg.begin(), t.nseg.end(), nseg);
+    std::copy(t.seg.begin(), t.seg.end(), seg);
+    std::copy(t.w4.begin(), t.w4.end(), w4);
+    return 1;
+}
+
+// Both operators of the low-rank form for a beam image and a filter: Cm [NU][R] (stage 1) and G [nrow][NU * R] (stage 2, dense,
+// kappa = x' * R + j).  Returns R = r * ns (counts[0] = r, counts[1] = ns); call with Cm == nullptr for the counts only.
+int jxt_mix_lowrank_operators(const double* beam, int B, double scale, const double* filt, int S, double tol, double beam_tol,
+                              int* counts, double* Cm, double* G) {
+    const int Sh = S / 2 + 1, c = S / 2, nrow = S - c, NU = std::max(c, S - 1 - c) + 1;
+    std::vector<double> hy, U, V, by, bx;
+    jxt::tf_hy_table(std::vector<double>(filt, filt + (size_t)S * S), S, hy);
+    std::vector<double> A((size_t)S * Sh);
+    for (size_t e = 0; e < A.size(); ++e) A[e] = hy[2 * e];
+    const int r = jxt::lowrank_factor_qr(A.data(), S, Sh, tol, U, V);
+    const int ns = jxt::beam_separable_terms(std::vector<double>(beam, beam + (size_t)B * B), B, scale, beam_tol, by, bx);
+    counts[0] = r; counts[1] = ns;
+    const int R = r * ns;
+    if (!Cm) return R;
+    std::vector<double> cm, op;
+    jxt::mix_stage1_operator(U, r, by, ns, S, B, NU, NU, R, cm);
+    std::copy(cm.begin(), cm.end(), Cm);
+    const int ntile = (nrow + 15) / 16;
+    const size_t K = (size_t)NU * R;
+    jxt::mix_stage2_operator(V, r, bx, ns, S, B, NU, K, ntile, op);
+    for (size_t k = 0; k < K; ++k)
+        for (int x = 0; x < nrow; ++x) G[(size_t)x * K + k] = op[(k * 16 + (x & 15)) * ntile + (x >> 4)];
+    return R;
+}
+
+// Full form: Om [nrow][NU][NU] for a beam image and a filter.  Returns 0, or -1 when the weights are not real.
+int jxt_mix_full_operator(const double* beam, int B, double scale, const double* filt, int S, double* Om) {
+    const int Sh = S / 2 + 1, c = S / 2, NU = std::max(c, S - 1 - c) + 1;
+    std::vector<double> hy, om;
+    jxt::tf_hy_table(std::vector<double>(filt, filt + (size_t)S * S), S, hy);
+    std::vector<double> A((size_t)S * Sh);
+    double mre = 0, mim = 0;
+    for (size_t e = 0; e < A.size(); ++e) { A[e] = hy[2 * e]; mre = std::max(mre, std::fabs(hy[2 * e])); mim = std::max(mim, std::fabs(hy[2 * e + 1])); }
+    if (!(mim <= 1e-15 * mre)) return -1;
+    jxt::mix_full_operator(std::vector<double>(beam, beam + (size_t)B * B), B, scale, A, S, NU, om);
+    std::copy(om.begin(), om.end(), Om);
+    return 0;
+}
 
 }  // extern "C"

@@ -10,7 +10,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('JOXSZ_LIB') or os.path.join(_HERE, 'csrc', 'libjoxsz_hip.so')    # JOXSZ_LIB: A/B builds
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # must list every function include/joxsz_hip.h declares (tests/test_abi.py checks this)
 EXPORTS = (
@@ -20,6 +20,7 @@ EXPORTS = (
     'jx_timing_reset', 'jx_timing_enable', 'jx_timing_get', 'jx_get_info', 'jx_get_conv_mode', 'jx_get_conv_layout', 'jx_debug_workspace', 'jx_device_count',
     'jx_device_name', 'jx_strerror', 'jx_last_error', 'jx_destroy',
     'jx_get_truncation', 'jx_comm_unique_id', 'jx_comm_init_rank', 'jx_allgather_logp', 'jx_comm_allreduce_max', 'jx_comm_destroy',
+    'jx_comm_count', 'jx_map_kernel_time',
 )
 
 TENSORS = ('r_pp', 'd_mat', 'beam_2d', 'filtering', 'radius', 'flux_data', 'conv_T', 'conv_v',
@@ -96,6 +97,8 @@ def load_library(path=None):
     lib.jx_allgather_logp.argtypes = [vp, vp, vp, ci]
     lib.jx_comm_allreduce_max.argtypes = [vp, vp, ci]
     lib.jx_comm_destroy.argtypes = [vp]
+    lib.jx_comm_count.argtypes = [vp]
+    lib.jx_map_kernel_time.argtypes = [vp, vp, ci, ci, dp]
     lib.jx_device_count.argtypes = []
     lib.jx_device_name.argtypes = [vp]
     lib.jx_device_name.restype = ctypes.c_char_p
@@ -113,7 +116,7 @@ def load_library(path=None):
     return lib
 
 
-CONV_MODES = {'auto': 0, 'rocfft': 1, 'custom': 2, 'mix': 3}
+CONV_MODES = {'auto': 0, 'rocfft': 1, 'custom': 2, 'mix': 2}        # 'custom' = 'mix': the contracted route (hand-written kernels)
 ROUTES = {'map': 0, 'operator': 1}
 
 
@@ -180,15 +183,11 @@ class HipContext:
         self._chk(self.lib.jx_get_info(self._h, f, c, b, n, nb), 'jx_get_info')
         self.fft_pad, self.chunk, self.spline_band, self.nrow, self.device_bytes = f.value, c.value, b.value, n.value, nb.value
         self.device_name = self.lib.jx_device_name(self._h).decode()
-        self.conv = {1: 'rocfft', 2: 'custom', 3: 'mix'}.get(self.lib.jx_get_conv_mode(self._h), '?')
+        self.conv = {1: 'rocfft', 2: 'custom'}.get(self.lib.jx_get_conv_mode(self._h), '?')
         self.conv_layout = None
         if self.conv == 'custom':
-            lay = (ctypes.c_int32 * 12)()
-            self._chk(self.lib.jx_get_conv_layout(self._h, lay), 'jx_get_conv_layout')
-            self.conv_layout = dict(zip(('xsym', 'quad', 'NU', 'NJ', 'ld', 'img_rows', 'img_ld', 'P', 'rank', 'fused', 'kact'), [int(v) for v in lay]))
-        tr = (ctypes.c_double * 4)()
-        self._chk(self.lib.jx_get_truncation(self._h, tr), 'jx_get_truncation')
-        self.truncation = dict(tol=tr[0], est_rel_row_err=tr[1], rank=int(tr[2]), retried=int(tr[3]))
+            self.conv_layout = self._layout()
+        self.truncation = self._truncation()
         self.route = 'map'
         route = route or os.environ.get('JOXSZ_ROUTE')
         if route and route != 'map':
@@ -197,6 +196,19 @@ class HipContext:
             except Exception:
                 self.close()
                 raise
+
+    def _layout(self):
+        lay = (ctypes.c_int32 * 12)()
+        self._chk(self.lib.jx_get_conv_layout(self._h, lay), 'jx_get_conv_layout')
+        d = dict(zip(('form', 'NU', 'rank', 'beam_terms', 'R', 'RT', 'nxt', 'ntile', 'ksteps', 'tW', 'ldx', 'ksplit'), [int(v) for v in lay]))
+        d['form'] = ('lowrank', 'full')[d['form']]
+        return d
+
+    def _truncation(self):
+        tr = (ctypes.c_double * 8)()
+        self._chk(self.lib.jx_get_truncation(self._h, tr), 'jx_get_truncation')
+        return dict(tol=tr[0], est_rel_row_err=tr[1], rank=int(tr[2]), retried=int(tr[3]), points=int(tr[4]), bound=tr[5],
+                    est_rel_row_err_box=tr[6], est_rel_sz_like_err_box=tr[7])
 
     # -- plumbing --
     def _chk(self, rc, what):
@@ -270,18 +282,18 @@ class HipContext:
         a = np.ascontiguousarray(arr)
         self._chk(self.lib.jx_memcpy_h2d(self._h, ctypes.c_void_p(ptr), a.ctypes.data_as(ctypes.c_void_p), a.nbytes), 'jx_memcpy_h2d')
 
-    def workspace(self, which, walkers=None):
-        """Test hook: copy of a work buffer of the hand-written convolution (``jx_debug_workspace``)."""
-        ids = {'y_map': 0, 'row_spectra': 1, 'fir_rows': 2, 'col0': 3, 'job_rows': 4, 'row_index': 5,
-               'rows_t': 6, 'combined_t': 7, 'combined_col0_t': 8, 'x0_t': 9, 'combined': 10, 'combined_col0': 11, 'coefs': 12}
+    def workspace(self, which):
+        """Test hook: copy of a work buffer of the contracted route (``jx_debug_workspace``), holding the last evaluated
+        chunk: 'y_map' [chunk, NU, ld] quadrant of the Compton-y map (after a y_2d tap), 'splines' [N, tW, 2] walker-minor
+        (y_k, M_k), 'stage1' [NU, R, tW] rows kept per map column, 'partials' [ksplit, tW, ldx] partial rows."""
+        ids = {'y_map': 0, 'splines': 1, 'stage1': 2, 'partials': 3}
         ptr = ctypes.c_void_p()
         geom = (ctypes.c_int32 * 4)()
         self._chk(self.lib.jx_debug_workspace(self._h, ids[which], ctypes.byref(ptr), geom), 'jx_debug_workspace')
-        n = geom[0] if walkers is None else min(walkers, geom[0])
-        out = np.empty((n, geom[1], geom[2]), np.int32 if ids[which] in (4, 5) else np.float64)
+        out = np.empty((geom[0], geom[1], geom[2]), np.float32 if geom[3] == 4 else np.float64)
         self.sync()
         self.d2h(out, ptr.value)
-        return out, bool(geom[3])
+        return out
 
     def d2h(self, arr, ptr):
         assert arr.flags['C_CONTIGUOUS']
@@ -329,7 +341,8 @@ class HipContext:
         buf = ctypes.create_string_buffer(128)
         rc = self.lib.jx_comm_unique_id(buf)
         if rc != 0:
-            raise JoxszHipError('jx_comm_unique_id failed: %s' % self.lib.jx_strerror(rc).decode())
+            detail = self.lib.jx_last_error(None).decode()
+            raise JoxszHipError('jx_comm_unique_id failed: %s%s' % (self.lib.jx_strerror(rc).decode(), (' -- ' + detail) if detail else ''))
         return buf.raw
 
     def comm_init_rank(self, uid, nranks, rank):
@@ -344,6 +357,18 @@ class HipContext:
 
     def comm_destroy(self):
         self._chk(self.lib.jx_comm_destroy(self._h), 'jx_comm_destroy')
+
+    def comm_count(self):
+        n = self.lib.jx_comm_count(self._h)
+        if n < 0:
+            self._chk(n, 'jx_comm_count')
+        return n
+
+    def map_kernel_time(self, theta_ptr, nwalkers, repeats=10):
+        """Mean duration (ms) of the Abel + map kernel writing the full S x S map of ``nwalkers`` walkers (``jx_map_kernel_time``)."""
+        ms = ctypes.c_double()
+        self._chk(self.lib.jx_map_kernel_time(self._h, ctypes.c_void_p(theta_ptr), nwalkers, repeats, ctypes.byref(ms)), 'jx_map_kernel_time')
+        return ms.value
 
     # -- timing --
     def timing_enable(self, on=True):

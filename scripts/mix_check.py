@@ -15,7 +15,7 @@ for S, N in shapes:
     pb = datasets.synthetic_problem(S=S, N=N, seed=S)
     th = datasets.walker_ball(pb, 70, spread=0.05, seed=S)
     t0 = time.time()
-    post = JoxszPosterior(pb, device=0, conv='mix')
+    post = JoxszPosterior(pb, device=0, conv='custom')
     dt = time.time() - t0
     a = post.log_prob(th)
     row_a = post.stage(th[:6], 'map_row')
@@ -34,7 +34,7 @@ for S, N in shapes:
           % (S, N, dt, tr['rank'], np.max(np.abs(a[fin] - b[fin]) / np.abs(b[fin])), np.max(np.abs(row_a - row_b)) / np.max(np.abs(row_b)),
              np.max(np.abs(chi_a[fin] - chi_b[fin])) / 2, np.max(np.abs(a[:3] - want) / np.abs(want))), flush=True)
 
-for conv in ('mix', 'custom'):
+for conv in ('custom',):
     pb = datasets.synthetic_problem(S=512, N=500, seed=0)
     post = JoxszPosterior(pb, device=0, conv=conv)
     c = post.ctx

@@ -31,7 +31,7 @@ c.timing_enable(True); c.timing_reset()
 for _ in range(20):
     c.eval_device(tp, W, lp)
 tm = c.timing()
-print('%s %s %d^2/%d x %d walkers (context %.2f s, rank %s): %.3f ms/step = %.0f /s | stages (ms): %s | env %s'
-      % (conv, dtype, S, N, W, dt, c.truncation['rank'], ms, W / ms * 1e3, {k[:-3]: round(v / 20, 4) for k, v in tm.items() if k.endswith('_ms')},
+print('%s %s %d^2/%d x %d walkers (context %.2f s, %s, %s): %.3f ms/step = %.0f /s | stages (ms): %s | env %s'
+      % (conv, dtype, S, N, W, dt, c.conv_layout, c.truncation, ms, W / ms * 1e3, {k[:-3]: round(v / 20, 4) for k, v in tm.items() if k.endswith('_ms')},
          {k: v for k, v in os.environ.items() if k.startswith('JOXSZ_')}), flush=True)
 post.close()

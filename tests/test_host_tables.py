@@ -145,40 +145,6 @@ def test_host_fft(lib):
             np.testing.assert_allclose(re + 1j * im, want, rtol=0, atol=1e-11 * max(1, np.abs(want).max()))
 
 
-@pytest.mark.parametrize('S,B,P', [(32, 9, 36), (64, 55, 96), (48, 11, 96)])
-def test_mixed_domain_tables(lib, S, B, P):
-    """Pass structure of jx_conv.hpp in numpy, fed with the C-built tables, against scipy."""
-    from oracle.joxsz_oracle import centdistmat
-    rng = np.random.default_rng(S)
-    o, Ph, Sh, c = (B - 1) // 2, P // 2 + 1, S // 2 + 1, S // 2
-    ax = np.arange(B) - o
-    beam = np.exp(-centdistmat(ax) ** 2 / (2 * (B / 5.) ** 2)) * (1 + 0.1 * np.cos(centdistmat(ax)))
-    y2d = rng.standard_normal((S, S))
-    axf = np.linspace(-S // 2 + 1, S // 2, S)
-    filt = np.roll(1 - np.exp(-np.sqrt(axf ** 2 + axf[:, None] ** 2) / 4.), S // 2 + 1, axis=(0, 1))
-    taps = np.zeros((o + 1, Ph))
-    assert lib.jxt_beam_fir_taps(_p(np.ascontiguousarray(beam)), B, P, ctypes.c_double(4.0 / P), _p(taps)) == 0
-    Hy = np.zeros((S, Sh, 2))
-    lib.jxt_tf_hy_table(_p(np.ascontiguousarray(filt)), S, _p(Hy))
-    Hy = Hy[..., 0] + 1j * Hy[..., 1]
-    Y = np.fft.rfft(np.pad(y2d, ((0, 0), (0, P - S))), axis=1)
-    C = np.zeros((S, Ph), complex)
-    for r in range(S):
-        for m in range(max(0, r - o), min(S, r + o + 1)):
-            C[r] += taps[abs(r - m)] * Y[m]
-    conv = (np.fft.irfft(C, P, axis=1) * P)[:, :S]
-    want = fftconvolve(y2d, beam, 'same') * 4.0
-    np.testing.assert_allclose(conv, want, rtol=0, atol=1e-12 * np.abs(want).max())
-    Z = (np.fft.rfft(conv, axis=1) * Hy).sum(0)
-    row = np.array([np.real(Z * np.exp(2j * np.pi * np.arange(Sh) * x / S)).sum() for x in range(c, S)])
-    want_row = np.real(ifft2(fft2(want) * filt))[c, c:]
-    np.testing.assert_allclose(row, want_row, rtol=0, atol=1e-12 * np.abs(want_row).max())
-    # an asymmetric beam is refused (the rocFFT path handles it)
-    bad = beam.copy(); bad[0, 1] *= 1.5
-    assert lib.jxt_beam_fir_taps(_p(bad), B, P, ctypes.c_double(1.0), _p(taps)) == -1
-    assert lib.jxt_custom_conv_lp(512, 27) == 288 and lib.jxt_custom_conv_lp(171, 27) == 0
-
-
 @pytest.mark.parametrize('name', list(GRIDS))
 def test_abel_onfly_tables(lib, name):
     """The kernel regenerates A[i][j] = cj[j]/sqrt(r_j^2-r_i^2) (j >= i+2) on the fly."""
@@ -197,57 +163,6 @@ def test_abel_onfly_tables(lib, name):
     np.testing.assert_allclose(A, want, rtol=1e-12, atol=1e-13 * np.abs(want).max())
 
 
-def test_constexpr_trig(lib):
-    lib.jxt_cx_cos2pi.restype = ctypes.c_double
-    lib.jxt_cx_sin2pi.restype = ctypes.c_double
-    lib.jxt_cx_cos2pi.argtypes = lib.jxt_cx_sin2pi.argtypes = [ctypes.c_longlong, ctypes.c_longlong]
-    pi = np.longdouble('3.14159265358979323846264338327950288')
-    for n in (3, 4, 7, 16, 18, 288, 576, 1152):
-        for k in list(range(-3, n + 3)) if n < 300 else (0, 1, n // 8, n // 4, n // 3, n // 2, n - 1, 5 * n + 7):
-            t = 2 * pi * np.longdouble(k % n) / np.longdouble(n)          # 80-bit reference
-            assert abs(lib.jxt_cx_cos2pi(k, n) - float(np.cos(t))) < 2.3e-16, (k, n)
-            assert abs(lib.jxt_cx_sin2pi(k, n) - float(np.sin(t))) < 2.3e-16, (k, n)
-
-
-@pytest.mark.parametrize('n', [2, 3, 4, 6, 8, 9, 12, 16, 18, 24, 27, 32])
-def test_register_fft(lib, n):
-    rng = np.random.default_rng(n)
-    x = rng.standard_normal(n) + 1j * rng.standard_normal(n)
-    for inv, want in ((0, np.fft.fft(x)), (1, np.fft.ifft(x) * n)):
-        re, im = np.ascontiguousarray(x.real), np.ascontiguousarray(x.imag)
-        assert lib.jxt_regfft(n, inv, _p(re), _p(im)) == 0
-        np.testing.assert_allclose(re + 1j * im, want, rtol=0, atol=2e-15 * n * np.abs(x).max())
-
-
-@pytest.mark.parametrize('S,o,mirror', [(31, 4, 1), (32, 4, 1), (64, 27, 1), (32, 4, 0), (171, 27, 1)])
-def test_conv_row_tables(lib, S, o, mirror):
-    """Jobs computed once must reproduce every conv row of a FIR over mirrored map rows."""
-    IP = ctypes.POINTER(ctypes.c_int)
-    umap, urow, jrow, rowjob = (np.zeros(S, np.int32) for _ in range(4))
-    seg, cnt = np.zeros(3 * S, np.int32), np.zeros(3, np.int32)
-    lib.jxt_conv_row_tables(S, o, mirror, *[a.ctypes.data_as(IP) for a in (umap, urow, jrow, rowjob, seg, cnt)])
-    NU, NJ, nseg = (int(v) for v in cnt)
-    rng = np.random.default_rng(S)
-    c = S // 2
-    if mirror:
-        base = rng.standard_normal(S)                 # one value per |m - c|
-        Y = np.array([base[abs(m - c)] for m in range(S)])
-        assert NU == max(c, S - 1 - c) + 1
-    else:
-        Y = rng.standard_normal(S)
-        assert NU == S and NJ == S and nseg == 1
-    np.testing.assert_array_equal(Y[urow[:NU]][umap], Y)             # distinct rows carry every row
-    tap = rng.standard_normal(o + 1)
-    conv = np.array([sum(tap[abs(r - m)] * Y[m] for m in range(max(0, r - o), min(S, r + o + 1))) for r in range(S)])
-    np.testing.assert_allclose(conv[jrow[:NJ]][rowjob], conv, rtol=1e-13, atol=1e-13)
-    segs = seg[:3 * nseg].reshape(-1, 3)
-    rows = np.concatenate([np.arange(a, a + n) for a, n, _ in segs])
-    np.testing.assert_array_equal(rows, jrow[:NJ])
-    assert all(q == sum(n for _, n, _ in segs[:i]) for i, (_, _, q) in enumerate(segs))
-    if mirror and S % 2 == 1:
-        assert NJ == c + 1 and nseg == 1                              # odd side: exact mirror, half the rows
-
-
 def test_lowrank_factor(lib):
     """Jacobi SVD of the host tables against numpy: singular values, reconstruction at the chosen rank."""
     rng = np.random.default_rng(5)
@@ -255,50 +170,22 @@ def test_lowrank_factor(lib):
     A = rng.standard_normal((m, true_rank)) @ np.diag(10.0 ** -np.arange(true_rank)) @ rng.standard_normal((true_rank, n))
     A += 1e-13 * rng.standard_normal((m, n))
     L = np.zeros((n, m)); Rt = np.zeros((n, n)); sg = np.zeros(n)
-    lib.jxt_lowrank_factor.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_double] + [ctypes.c_void_p] * 3
-    r = lib.jxt_lowrank_factor(_p(np.ascontiguousarray(A)), m, n, 1e-10, _p(L), _p(Rt), _p(sg))
+    lib.jxt_lowrank_factor.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int] + [ctypes.c_void_p] * 3
     want = np.linalg.svd(A, compute_uv=False)
-    assert r == int((want > 1e-10 * want[0]).sum()) == true_rank
-    np.testing.assert_allclose(sg[:true_rank], want[:true_rank], rtol=1e-12, atol=1e-14 * want[0])
-    approx = L[:r].T @ Rt[:r]
-    assert np.abs(approx - A).max() < 1e-9 * np.abs(A).max()
-    np.testing.assert_allclose(np.linalg.norm(Rt[:r], axis=1), 1.0, rtol=1e-12)
-    # full rank request reproduces the matrix to rounding
-    r2 = lib.jxt_lowrank_factor(_p(np.ascontiguousarray(A)), m, n, 0.0, _p(L), _p(Rt), _p(sg))
+    for qr in (0, 1):                 # one-sided Jacobi on the whole matrix / rank-revealing QR first, Jacobi on the small factor
+        r = lib.jxt_lowrank_factor(_p(np.ascontiguousarray(A)), m, n, 1e-10, qr, _p(L), _p(Rt), _p(sg))
+        assert r == int((want > 1e-10 * want[0]).sum()) == true_rank
+        np.testing.assert_allclose(sg[:true_rank], want[:true_rank], rtol=1e-11, atol=1e-14 * want[0])
+        approx = L[:r].T @ Rt[:r]
+        assert np.abs(approx - A).max() < 1e-9 * np.abs(A).max()
+        np.testing.assert_allclose(np.linalg.norm(Rt[:r], axis=1), 1.0, rtol=1e-12)
+    # full rank request reproduces the matrix to rounding (the QR form stops at the numerical rank: every column below 1e-17 of the largest)
+    r2 = lib.jxt_lowrank_factor(_p(np.ascontiguousarray(A)), m, n, 0.0, 0, _p(L), _p(Rt), _p(sg))
     assert r2 == n
     assert np.abs(L[:r2].T @ Rt[:r2] - A).max() < 1e-13 * np.abs(A).max()
-
-
-def test_fused_row_operator(lib):
-    """FIR along rows + job combination as one matrix per column, against the two steps done one after the other."""
-    S, o, r, nb = 32, 4, 5, 7
-    IP = ctypes.POINTER(ctypes.c_int)
-    umap = np.zeros(S, np.int32); urow = np.zeros(S, np.int32); jrow = np.zeros(S, np.int32); rowjob = np.zeros(S, np.int32)
-    seg = np.zeros(3 * S, np.int32); cnt = np.zeros(3, np.int32)
-    lib.jxt_conv_row_tables(S, o, 1, *[a.ctypes.data_as(IP) for a in (umap, urow, jrow, rowjob, seg, cnt)])
-    NU, NJ = int(cnt[0]), int(cnt[1])
-    rng = np.random.default_rng(2)
-    U = rng.standard_normal((r, NJ)); coef = rng.standard_normal((o + 1, nb)); R = rng.standard_normal((NU, nb))
-    RP, KU = 16, NU + 3
-    out = np.zeros((nb, RP, KU))
-    assert lib.jxt_fused_row_operator(_p(U), r, S, o, 1, _p(coef), nb, nb, RP, KU, _p(out)) == NJ
-    # step by step: FIR per job, then the combination
-    C = np.zeros((NJ, nb))
-    for q in range(NJ):
-        rq = jrow[q]
-        for m in range(max(0, rq - o), min(S - 1, rq + o) + 1):
-            C[q] += coef[abs(rq - m)] * R[umap[m]]
-    want = U @ C                                             # [r][nb]
-    got = np.einsum('bru,ub->rb', out[:, :r, :NU], R)
-    np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-13)
-    assert not out[:, r:].any() and not out[:, :, NU:].any()
-
-
-# ---------------------------------------------------------------------------------------
-# tables of this round's kernels: rows evaluated from the spline + quarter-length transform (jx_dct.hpp), the
-# spline-array operator (jx_abel_gemm_kernel), the real-space kernels of the odd-side route
-# ---------------------------------------------------------------------------------------
-IP = ctypes.POINTER(ctypes.c_int)
+    r3 = lib.jxt_lowrank_factor(_p(np.ascontiguousarray(A)), m, n, 1e-15, 1, _p(L), _p(Rt), _p(sg))
+    assert true_rank <= r3 <= n
+    assert np.abs(L[:r3].T @ Rt[:r3] - A).max() < 1e-12 * np.abs(A).max()
 
 
 def _dct_tables(lib, Qrad, r, S, LP):
@@ -322,38 +209,6 @@ def _mirrored_moments(lib, r, y):
     G = np.zeros((n, n))
     assert lib.jxt_mirrored_spline_op(_p(r), n, _p(G)) > 0
     return G, G @ y
-
-
-@pytest.mark.parametrize('S,LP', [(64, 48), (65, 48), (171, 144), (128, 96)])
-def test_row_sample_tables_reproduce_the_mirrored_spline(lib, S, LP):
-    """f(|x|) = A y_k + B y_{k+1} + C M_k + D M_{k+1} with the table's (interval, weights) per (row, sample) equals
-    interp1d((-r, r), (y, y), 'cubic', fill_value=(0, 0)) of joxsz_funcs.py:460-462 at the pixel radii of the quadrant."""
-    step, kpc_as = 2.0, 8.0012
-    h = step * kpc_as
-    N = int(0.8 * S)                                             # the grid ends inside the map: fill value 0 beyond it
-    r = h * np.arange(1, N + 1)
-    c = S // 2
-    a = np.arange(c + 1) * h
-    Qrad = np.ascontiguousarray(np.hypot(a[:, None], a[None, :]))      # centdistmat quadrant (joxsz_funcs.py:78-88)
-    t = _dct_tables(lib, Qrad, r, S, LP)
-    assert t is not None and t['has_x0'] == (S % 2 == 0) and t['amax'] == (c - 1 if S % 2 == 0 else c)
-    rng = np.random.default_rng(S)
-    y = np.exp(-(r / (12 * h)) ** 2) * (1 + 0.05 * rng.standard_normal(N))
-    G, M = _mirrored_moments(lib, r, y)
-    ym = np.zeros(2 * (N + 2))
-    ym[0:2 * N:2], ym[1:2 * N:2] = y, M
-    f = interp1d(np.concatenate((-r[::-1], r)), np.concatenate((y[::-1], y)), 'cubic', bounds_error=False, fill_value=(0., 0.))
-    for u in (0, 1, c // 3, c - 1, c):
-        k = t['dk'][u, :t['amax'] + 1] // 16
-        w = t['dw'][u, :t['amax'] + 1]
-        got = w[:, 0] * ym[2 * k] + w[:, 1] * ym[2 * k + 2] + w[:, 2] * ym[2 * k + 1] + w[:, 3] * ym[2 * k + 3]
-        want = f(Qrad[u, :t['amax'] + 1])
-        assert np.abs(got - want).max() < 1e-12 * np.abs(y).max(), u
-        assert np.all(t['dw'][u, t['amax'] + 1:] == 0)                                  # padding: zero weights
-        if t['has_x0']:
-            k0, w0 = t['x0k'][u] // 16, t['x0w'][u]
-            got0 = w0[0] * ym[2 * k0] + w0[1] * ym[2 * k0 + 2] + w0[2] * ym[2 * k0 + 1] + w0[3] * ym[2 * k0 + 3]
-            assert abs(got0 - f(Qrad[u, c])) < 1e-12 * np.abs(y).max()
 
 
 def _quarter_transform_with_tables(q, LP, pk):
@@ -385,26 +240,6 @@ def _quarter_transform_with_tables(q, LP, pk):
     return R
 
 
-@pytest.mark.parametrize('S,LP', [(64, 48), (128, 96), (512, 288), (171, 144)])
-def test_quarter_length_real_even_transform_with_the_kernel_constants(lib, S, LP):
-    """R(k) = sum_n x[n] cos(2 pi k n / P) of an even row through one complex FFT of length P/4 (Cooley, Lewis & Welch),
-    with the split constants the library hands the kernel, against the direct cosine sum."""
-    c = S // 2
-    h = 16.0
-    a = np.arange(c + 1) * h
-    Qrad = np.ascontiguousarray(np.hypot(a[:, None], a[None, :]))
-    r = h * np.arange(1, int(0.9 * S) + 1)
-    t = _dct_tables(lib, Qrad, r, S, LP)
-    assert t is not None
-    rng = np.random.default_rng(LP)
-    amax = t['amax']
-    q = np.exp(-(np.arange(amax + 1) / (0.3 * amax)) ** 2) + 0.01 * rng.standard_normal(amax + 1)
-    n = np.arange(-amax, amax + 1)
-    want = (q[np.abs(n)][None, :] * np.cos(2 * np.pi * np.arange(LP + 1)[:, None] * n[None, :] / (2 * LP))).sum(1)
-    got = _quarter_transform_with_tables(q, LP, t['pk'])
-    assert np.abs(got - want).max() < 1e-13 * np.abs(want).max()
-
-
 @pytest.mark.parametrize('name', ['uniform', 'arange', 'ragged'])
 def test_abel_spline_operator(lib, name):
     """Tm of jx_abel_gemm_kernel: pp @ Tm gives (y_k, M_k) = (y_scale * PyAbel forward transform, moments of the mirrored
@@ -434,29 +269,123 @@ def test_abel_spline_operator(lib, name):
         assert np.all(Tm[:max(0, 8 * t - K), 16 * t:16 * t + 16] == 0)
 
 
-@pytest.mark.parametrize('S', [31, 65, 171])
-def test_odd_rowspace_operator(lib, S):
-    """K[rho][b][a] of the odd-side route: sum_a K[b][a] cc[c + a] equals the circular convolution of the symmetric row cc
-    with k_rho[j] = sum_kc v[kc] cos(2 pi kc j / S), read at columns c + b (joxsz_funcs.py:466-467, 472 in real space)."""
-    c, Sh, nout = S // 2, S // 2 + 1, S // 2 + 1
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# contracted route (jx_mix.hpp): the tables the kernels consume, against the oracle's own chain of scipy calls
+# ------------------------------------------------------------------------------------------------------------------
+def _problem(S, N, beam=None, filt=None):
+    from joxsz_amd import datasets
+    pb = datasets.synthetic_problem(S=S, N=N, sz_only=True)
+    if beam is not None:
+        pb.beam_2d = np.ascontiguousarray(beam)
+    if filt is not None:
+        pb.filtering = np.ascontiguousarray(filt)
+    return pb
+
+
+def _quadrant(img):
+    S = img.shape[0]
+    c = S // 2
+    NU = max(c, S - 1 - c) + 1
+    iy = np.array([c + b if c + b < S else c - b for b in range(NU)])
+    return img[np.ix_(iy, iy)], NU
+
+
+def _reference_row(pb, seed=0):
+    from joxsz_amd import datasets
+    from oracle import joxsz_oracle as orc
+    th = datasets.fiducial_theta(pb)
+    par = orc.pars_dict(pb, th * (1 + 0.05 * np.random.default_rng(seed).standard_normal(th.size)))
+    return orc.row_chain(pb, orc.press_fun(par, pb.r_pp))
+
+
+@pytest.mark.parametrize('S,N', [(31, 40), (32, 40), (64, 80), (65, 80)])
+def test_mix_column_tables_reproduce_the_mirrored_spline(lib, S, N):
+    """Stage 1 walks a column of the quadrant as a list of spline intervals: the segment counts and the per-sample weights
+    (A, B, C, D) with the spline arrays (y_k, M_k) give interp1d(..., 'cubic')(d_mat) (joxsz_funcs.py:460-462)."""
+    pb = _problem(S, N)
+    ref = _reference_row(pb)
+    Q, NU = _quadrant(ref['y_2d'])
+    r = np.ascontiguousarray(pb.r_pp)
+    G = np.zeros((N, N))
+    assert lib.jxt_mirrored_spline_op(_p(r), N, _p(G)) > 0
+    y = ref['y']
+    M = G @ y
+    Qrad, _ = _quadrant(pb.d_mat)
+    Qrad = np.ascontiguousarray(Qrad)
+    meta = (ctypes.c_int * 3)()
+    IP = ctypes.POINTER(ctypes.c_int)
+    lib.jxt_mix_columns.argtypes = [DP, ctypes.c_int, ctypes.c_int, DP, ctypes.c_int, IP, IP, IP, IP, DP]
+    assert lib.jxt_mix_columns(_p(Qrad), NU, NU, _p(r), N, meta, None, None, None, None) == 1
+    segld, wld, maxk = meta[0], meta[1], meta[2]
+    seg0, nseg = np.zeros(NU, np.int32), np.zeros(NU, np.int32)
+    seg, w4 = np.zeros((NU, segld), np.int32), np.zeros((NU, wld, 4))
+    ip = lambda a: a.ctypes.data_as(IP)
+    assert lib.jxt_mix_columns(_p(Qrad), NU, NU, _p(r), N, meta, ip(seg0), ip(nseg), ip(seg), _p(w4)) == 1
+    assert segld % 8 == 0 and maxk <= N - 2
+    ypad, Mpad = np.append(y, np.zeros(4)), np.append(M, np.zeros(4))
+    for a in range(NU):
+        assert seg[a, :nseg[a]].sum() == NU and np.all(seg[a, nseg[a]:] == 0)
+        k = np.repeat(seg0[a] + np.arange(nseg[a]), seg[a, :nseg[a]])            # interval of every sample of the column
+        w = w4[a, :NU]
+        got = w[:, 0] * ypad[k] + w[:, 1] * ypad[k + 1] + w[:, 2] * Mpad[k] + w[:, 3] * Mpad[k + 1]
+        np.testing.assert_allclose(got, Q[:, a], rtol=0, atol=2e-13 * np.abs(Q).max())
+    # a radius that shrinks along a column is refused (the route then is not taken)
+    bad = Qrad.copy()
+    bad[NU // 2, 1] = bad[0, 1] * 0.5
+    if np.searchsorted(r, bad[NU // 2, 1]) < np.searchsorted(r, bad[NU // 2 - 1, 1]):
+        assert lib.jxt_mix_columns(_p(bad), NU, NU, _p(r), N, meta, None, None, None, None) == 0
+
+
+@pytest.mark.parametrize('S,N', [(31, 40), (32, 40), (64, 80), (65, 80), (128, 100)])
+def test_mix_lowrank_operators_against_the_oracle(lib, S, N):
+    """Stage 1 (C) and stage 2 (G) of the low-rank form, applied in numpy to the oracle's own Compton-y map, give the row
+    map_out[S//2, S//2:] of joxsz_funcs.py:464-472 to rounding at the tight cut, and within the cut at a loose one."""
+    pb = _problem(S, N)
+    ref = _reference_row(pb, seed=S)
+    Q, NU = _quadrant(ref['y_2d'])
+    nrow = S - S // 2
+    beam, filt = np.ascontiguousarray(pb.beam_2d), np.ascontiguousarray(pb.filtering)
+    counts = (ctypes.c_int * 2)()
+    args = [DP, ctypes.c_int, ctypes.c_double, DP, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.POINTER(ctypes.c_int), DP, DP]
+    lib.jxt_mix_lowrank_operators.argtypes = args
+    ranks = []
+    for tol, bar in ((1e-13, 1e-13), (1e-6, 1e-5)):
+        R = lib.jxt_mix_lowrank_operators(_p(beam), pb.B, pb.step ** 2, _p(filt), S, tol, 1e-14, counts, None, None)
+        assert R == counts[0] * counts[1] and counts[1] == 1            # the Gaussian beam image is one separable term
+        Cm, G = np.zeros((NU, R)), np.zeros((nrow, NU * R))
+        lib.jxt_mix_lowrank_operators(_p(beam), pb.B, pb.step ** 2, _p(filt), S, tol, 1e-14, counts, _p(Cm), _p(G))
+        D = Cm.T @ Q                                                     # [R][x']: what jx_rowmix_kernel leaves per column
+        out = G @ D.T.reshape(-1)                                        # kappa = x' * R + j
+        assert np.abs(out - ref['map_row']).max() <= bar * np.abs(ref['map_row']).max()
+        ranks.append(R)
+    assert ranks[1] < ranks[0]
+
+
+@pytest.mark.parametrize('S,N', [(31, 40), (32, 40), (64, 80)])
+def test_mix_full_operator_with_a_measured_like_beam_and_a_rough_transfer_function(lib, S, N):
+    """The full form needs no structure in the beam image (beyond nothing at all: here not even flip symmetry) and none in
+    the transfer function beyond real weights: Omega applied to the oracle's map quadrant gives the oracle's row."""
+    from oracle.joxsz_oracle import centdistmat, dist
     rng = np.random.default_rng(S)
-    r = 3
-    V = rng.standard_normal((r, Sh))
-    KQ = (nout + 3) // 4 * 4
-    nmg = lib.jxt_odd_rowspace_operator(_p(V), r, S, KQ, ctypes.POINTER(ctypes.c_double)())
-    out = np.zeros((nmg, r, 64, KQ))
-    assert lib.jxt_odd_rowspace_operator(_p(V), r, S, KQ, _p(out)) == nmg == (nout + 63) // 64
-    half = rng.standard_normal(nout)
-    cc = np.concatenate((half[:0:-1], half))                            # symmetric about the centre column c, length S
-    j = np.arange(S)
-    for rho in range(r):
-        k = (V[rho][None, :] * np.cos(2 * np.pi * np.arange(Sh)[None, :] * j[:, None] / S)).sum(1)
-        want = np.array([sum(k[(c + b - x) % S] * cc[x] for x in range(S)) for b in range(nout)])
-        Kb = np.concatenate([out[mg, rho] for mg in range(nmg)])[:nout, :nout]
-        got = Kb @ half
-        assert np.abs(got - want).max() < 1e-12 * np.abs(want).max()
-
-
-def test_odd_padded_lengths(lib):
-    for S, o, want in ((171, 27, 144), (31, 4, 48), (513, 27, 288), (1025, 27, 576), (65, 27, 48), (512, 27, 0), (2001, 27, 0)):
-        assert lib.jxt_custom_conv_lp_odd(S, o) == want
+    B = 9
+    ax = np.arange(B) - (B - 1) // 2
+    rad = centdistmat(ax)
+    beam = np.exp(-rad ** 2 / 7.) * (1 + 0.3 * np.cos(1.7 * rad)) + 0.05 * rng.random((B, B)) * np.exp(-rad / 3.)    # not separable, not symmetric
+    beam /= beam.sum() * 4.0
+    k = dist(S) / S
+    knots = np.sort(rng.random(40)) * k.max() * 1.01
+    vals = rng.random(40)
+    filt = np.interp(k, knots, vals)                                     # radial, rough from knot to knot
+    pb = _problem(S, N, beam=beam, filt=filt)
+    ref = _reference_row(pb, seed=S)
+    Q, NU = _quadrant(ref['y_2d'])
+    nrow = S - S // 2
+    Om = np.zeros((nrow, NU, NU))
+    lib.jxt_mix_full_operator.argtypes = [DP, ctypes.c_int, ctypes.c_double, DP, ctypes.c_int, DP]
+    assert lib.jxt_mix_full_operator(_p(np.ascontiguousarray(pb.beam_2d)), B, pb.step ** 2, _p(np.ascontiguousarray(pb.filtering)), S, _p(Om)) == 0
+    out = np.einsum('xuv,uv->x', Om, Q)
+    assert np.abs(out - ref['map_row']).max() <= 1e-13 * np.abs(ref['map_row']).max()
+    # weights that are not real (a filter without the symmetry in each wavenumber) are refused
+    assert lib.jxt_mix_full_operator(_p(np.ascontiguousarray(pb.beam_2d)), B, pb.step ** 2, _p(np.ascontiguousarray(rng.random((S, S)))), S, _p(Om)) == -1
