@@ -263,7 +263,9 @@ int  jx_get_truncation(jx_ctx* ctx, double out[8]);
  *   0 quadrant of the Compton-y map [chunk][NU][ld] (exists after the first y_2d tap): geom = {chunk, NU, ld, 8}
  *   1 spline arrays, walker-minor [N][tW][2] = (y_k, M_k) of walker w at ((k tW + w) 2): geom = {N, tW, 2, element bytes}
  *   2 stage-1 rows [NU][R][tW] (low-rank form): geom = {NU, R, tW, 8}
- *   3 partial rows of the last launch [ksplit][tW][ldx]: geom = {ksplit, tW, ldx, 8} */
+ *   3 partial rows of the last launch, slice ks of walker w at ks (tW ldx + 272) + w ldx: geom = {ksplit, tW, ldx, 8}
+ *   4 stage-1 operator C[u][j] (low-rank form), rows of `cld` doubles: geom = {1, wld, cld, 8}
+ *   5 operator of the matrix-core product, Op[(kappa * 16 + (x & 15)) * ntile + (x >> 4)]: geom = {4 ksteps, 16, ntile, 8} */
 int  jx_debug_workspace(jx_ctx* ctx, int which, void** dev, int32_t geom[4]);
 /* Duration (ms, HIP events on the context's stream, mean of `repeats` launches) of the Abel + map kernel writing the full
  * S x S Compton-y map of `nwalkers` walkers whose parameter vectors are at theta_dev: the kernel BASELINE's metric is worded

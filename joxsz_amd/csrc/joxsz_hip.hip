@@ -567,7 +567,8 @@ static int mix_setup(jx_ctx* ctx, const MixBuild& mb, long long tW) {
         JxSamp* qe;
         if ((rc = dev_put_l(ctx, m.allocs, mb.ent.data(), mb.ent.size(), &qe))) return rc; og.ent = qe;
     }
-    if ((rc = dev_new_l(ctx, m.allocs, (size_t)JX_MIX_KSPLIT_MAX * tW * og.ldx, &m.Pt))) return rc;
+    og.pstride = (long long)tW * og.ldx + 272;                // (not a power of two: the tail reads all slices of a walker at once)
+    if ((rc = dev_new_l(ctx, m.allocs, (size_t)JX_MIX_KSPLIT_MAX * og.pstride, &m.Pt))) return rc;
     m.bytes = ctx->device_bytes - before;
     m.ready = true;
     return JX_OK;
@@ -597,8 +598,12 @@ static int launch_mix(jx_ctx* ctx, int n, EvSet* es) {
         JxOpg og = m.og;
         og.n = n;
         const int nwb = (n + 127) / 128;
-        int ksplit = m.ksplit_force > 0 ? m.ksplit_force : (2 * ctx->num_cu + nwb * og.nog - 1) / (nwb * og.nog);
-        ksplit = std::max(1, std::min(std::min(ksplit, JX_MIX_KSPLIT_MAX), (m.ksteps + 7) / 8));
+        // K slices: a function of the problem alone (about 64 k-steps each, whole multiples of 8 slices so that a full chunk
+        // fills whole rounds of blocks), never of the launch -- a walker's sums are grouped the same way wherever it sits in
+        // whatever batch, so its result is bitwise independent of both
+        int ksplit = m.ksplit_force > 0 ? m.ksplit_force : (m.ksteps + 32) / 64;
+        if (ksplit >= 8 && m.ksplit_force <= 0) ksplit = (ksplit + 4) / 8 * 8;
+        ksplit = std::max(1, std::min(ksplit, JX_MIX_KSPLIT_MAX));
         int kper = (m.ksteps + ksplit - 1) / ksplit;
         kper = (kper + JX_OPG_RD - 1) / JX_OPG_RD * JX_OPG_RD;
         ksplit = (m.ksteps + kper - 1) / kper;
@@ -1189,7 +1194,7 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
         if (tm || tm2) HIPCHK(ctx, hipEventRecord(es.e[2], st));
         if ((rc = launch_mix(ctx, n, (tm || tm2) ? &es : nullptr))) return rc;
         const size_t sh = sizeof(double) * (JX_LDS_HDR + (size_t)d.nrow + 8);
-        hipLaunchKernelGGL(jx_tail_row_kernel, dim3(n), dim3(JX_TAIL_THREADS), sh, st, d, m.Pt, m.last_ksplit, (long long)m.tW * m.og.ldx, m.og.ldx,
+        hipLaunchKernelGGL(jx_tail_row_kernel, dim3(n), dim3(JX_TAIL_THREADS), sh, st, d, m.Pt, m.last_ksplit, m.og.pstride, m.og.ldx,
                            ctx->d_cfac, ctx->d_sz0, ctx->d_base, logp_dev, w0, t.row, t.bright, t.chisq, t.parts);
         if (tm) HIPCHK(ctx, hipEventRecord(es.e[5], st));
         if (tm || tm2) ctx->ev_inflight.push_back(es);
@@ -1730,6 +1735,9 @@ int jx_debug_workspace(jx_ctx* ctx, int which, void** dev, int32_t geom[4]) {
         case 2: if (m.form != 0) { ctx->err = "no stage-1 rows in the full form"; return JX_ERR_UNSUPPORTED; }
                 *dev = m.Dt; geom[0] = m.mx.NU; geom[1] = m.mx.R; geom[2] = (int)m.tW; geom[3] = 8; break;
         case 3: *dev = m.Pt; geom[0] = m.last_ksplit; geom[1] = (int)m.tW; geom[2] = m.og.ldx; geom[3] = 8; break;
+        case 4: if (m.form != 0) { ctx->err = "no stage-1 operator in the full form"; return JX_ERR_UNSUPPORTED; }
+                *dev = const_cast<double*>(m.mx.Cm); geom[0] = 1; geom[1] = m.mx.wld; geom[2] = m.mx.cld; geom[3] = 8; break;
+        case 5: *dev = const_cast<double*>(m.og.Op); geom[0] = 4 * m.ksteps; geom[1] = 16; geom[2] = m.og.ntile; geom[3] = 8; break;
         default: ctx->err = "unknown work buffer"; return JX_ERR_INVALID;
     }
     return JX_OK;

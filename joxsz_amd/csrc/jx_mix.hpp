@@ -154,6 +154,7 @@ struct JxOpg {
     int ksplit, kper;              // K slices, k-steps per slice (multiple of the prefetch depth)
     int ntile, nog;                // output tiles in all (multiple of NXT), output groups = ntile / NXT
     int ldx;                       // doubles per partial row (>= 16 ntile)
+    long long pstride;             // doubles between the partial rows of two K slices (>= tW ldx)
     const double* Op;              // [ksplit * kper + slack][4][16][ntile]
     const double* Dt;              // LOAD: [4 (ksplit kper + slack)][tW]
     const JxSamp* ent;             // EVAL: [4 (ksplit kper + slack)]
@@ -243,7 +244,7 @@ jx_opgemm_kernel(JxOpg g, const TC* __restrict__ cft, double* __restrict__ Pt) {
         for (int gq = 0; gq < 4; ++gq) {
             const size_t w = wrow + mm * 16 + 4 * gq;
             if (w < (size_t)g.n) {
-                double* row = Pt + ((size_t)ks * tW + w) * g.ldx + (size_t)(og * NXT) * 16 + li;
+                double* row = Pt + (size_t)ks * g.pstride + w * g.ldx + (size_t)(og * NXT) * 16 + li;
 #pragma unroll
                 for (int t = 0; t < NXT; ++t) row[t * 16] = acc[mm][t][gq];
             }

@@ -285,13 +285,19 @@ class HipContext:
     def workspace(self, which):
         """Test hook: copy of a work buffer of the contracted route (``jx_debug_workspace``), holding the last evaluated
         chunk: 'y_map' [chunk, NU, ld] quadrant of the Compton-y map (after a y_2d tap), 'splines' [N, tW, 2] walker-minor
-        (y_k, M_k), 'stage1' [NU, R, tW] rows kept per map column, 'partials' [ksplit, tW, ldx] partial rows."""
-        ids = {'y_map': 0, 'splines': 1, 'stage1': 2, 'partials': 3}
+        (y_k, M_k), 'stage1' [NU, R, tW] rows kept per map column, 'partials' [ksplit, tW, ldx] partial rows; the constant
+        operators 'stage1_op' [1, wld, cld] (C[u][j]) and 'product_op' [K, 16, ntile] (Op[kappa][x & 15][x >> 4])."""
+        ids = {'y_map': 0, 'splines': 1, 'stage1': 2, 'partials': 3, 'stage1_op': 4, 'product_op': 5}
         ptr = ctypes.c_void_p()
         geom = (ctypes.c_int32 * 4)()
         self._chk(self.lib.jx_debug_workspace(self._h, ids[which], ctypes.byref(ptr), geom), 'jx_debug_workspace')
-        out = np.empty((geom[0], geom[1], geom[2]), np.float32 if geom[3] == 4 else np.float64)
         self.sync()
+        if which == 'partials':                              # slices are 272 doubles apart beyond their [tW][ldx] rows
+            ks, tW, ldx = geom[0], geom[1], geom[2]
+            raw = np.empty(ks * (tW * ldx + 272))
+            self.d2h(raw, ptr.value)
+            return np.ascontiguousarray(raw.reshape(ks, tW * ldx + 272)[:, :tW * ldx]).reshape(ks, tW, ldx)
+        out = np.empty((geom[0], geom[1], geom[2]), np.float32 if geom[3] == 4 else np.float64)
         self.d2h(out, ptr.value)
         return out
 

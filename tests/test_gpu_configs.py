@@ -70,7 +70,7 @@ def test_config1_sz_only_256():
     pb = _problem(256, 300, seed=1, sz_only=True)
     th = datasets.walker_ball(pb, 256, spread=0.03, seed=1)
     post = _post(pb)
-    assert post.ctx.conv == 'custom' and post.ctx.conv_layout['fused'] == 1
+    assert post.ctx.conv == 'custom' and post.ctx.conv_layout['form'] == 'lowrank'
     a = post.log_prob(th)
     b = post.log_prob(th)
     np.testing.assert_array_equal(a, b)
@@ -98,7 +98,7 @@ def test_config3_shard_512_walkers():
     assert hi - lo == 512
     th = np.ascontiguousarray(full[lo:hi])
     post = _post(pb)
-    assert post.ctx.conv == 'custom' and post.ctx.conv_layout['fused'] == 1
+    assert post.ctx.conv == 'custom' and post.ctx.conv_layout['form'] == 'lowrank'
     a = post.log_prob(th)
     np.testing.assert_array_equal(a, post.log_prob(th))
     assert np.isfinite(a).sum() >= 400
@@ -324,8 +324,8 @@ def test_loader_tensors_through_the_hip_path(golden_bundled):
 
 @pytest.mark.parametrize('S,N,W', [(512, 500, 512), (1024, 1000, 1024)])
 def test_fp32_variant_tolerance_sweep(S, N, W):
-    """BASELINE configs[4]: the fp32 variant (fp32 evaluation of the map rows, fp32 row transform, fp32 storage of the row
-    spectra and combined rows; matrix products, inverse transforms and the tail in fp64) against the fp64 path on the same
+    """BASELINE configs[4]: the fp32 variant (spline arrays rounded to fp32 once, where the matrix product stores them, and
+    read as fp32 by the sample evaluation; sums, matrix-core product and tail in fp64) against the fp64 path on the same
     walkers around the posterior mode: relative difference of the log-posterior, absolute difference of chi^2."""
     from joxsz_amd import datasets
     pb = _problem(S, N, seed=S)
@@ -350,38 +350,58 @@ def test_fp32_variant_tolerance_sweep(S, N, W):
     assert np.any(lp32[fin] != lp64[fin])                               # it really is another arithmetic
 
 
-def test_fp32_variant_refuses_routes_it_does_not_exist_on():
-    """dtype f32 on an odd side, on the rocFFT route or on a small map must be an error, never a silent fp64 evaluation."""
+def test_fp32_variant_exists_on_the_contracted_route_only():
+    """dtype f32 on the rocFFT sequence must be an error, never a silent fp64 evaluation; on the contracted route it exists at
+    every side (odd and small ones included, both forms) and differs from fp64 by fp32 rounding only."""
     from joxsz_amd.hip_backend import JoxszHipError
     from joxsz_amd import datasets
-    for S, N, kw in ((513, 500, {}), (512, 500, dict(conv='rocfft')), (96, 120, {}), (64, 80, {})):
+    pb = datasets.synthetic_problem(S=512, N=500, seed=1)
+    with pytest.raises(JoxszHipError, match='unsupported'):
+        _post(pb, dtype='f32', conv='rocfft')
+    for S, N in ((513, 500), (96, 120), (171, 313)):
         pb = datasets.synthetic_problem(S=S, N=N, seed=1)
-        with pytest.raises(JoxszHipError, match='unsupported'):
-            _post(pb, dtype='f32', **kw)
+        th = datasets.walker_ball(pb, 12, spread=0.02, seed=1)
+        p64 = _post(pb)
+        a = p64.log_prob(th)
+        p64.close()
+        p32 = _post(pb, dtype='f32')
+        b = p32.log_prob(th)
+        with pytest.raises(JoxszHipError):                               # the profile taps exist in the f64 build only
+            p32.stage(th[:1], 'y')
+        p32.close()
+        fin = np.isfinite(a)
+        assert fin.sum() >= 8 and np.array_equal(np.isfinite(b), fin)
+        np.testing.assert_allclose(b[fin], a[fin], rtol=2e-5)            # (small maps: a small difference of large terms)
+        assert np.any(b[fin] != a[fin])
 
 
-def test_truncation_probe_and_automatic_tightening(monkeypatch):
-    """jx_finalize measures what the low-rank cut and the band limit cost on the extracted row (jx_get_truncation); above
-    the bound (2e-10 of the row's largest entry; lowered here to force the cases) it rebuilds the tables with a cut a
-    hundred times tighter, again and again until the bound holds or every term above rounding is kept."""
+def test_truncation_guard_and_automatic_tightening(monkeypatch):
+    """jx_finalize measures what the singular-value cut of the low-rank form costs, against the rocFFT sequence, at the
+    current parameter values and at the corners of the prior box in (a, b, r_p) (jx_get_truncation); above the bounds (row at
+    the current values 1e-9, SZ log-likelihood over the box 1e-8; lowered here to force the cases) it rebuilds the tables in
+    place with a cut ten times tighter, again and again until the bounds hold or every term above rounding is kept."""
     from joxsz_amd import datasets
     pb = _problem(512, 500, seed=3)
     th = datasets.walker_ball(pb, 24, spread=0.03, seed=3)
     post = _post(pb)
     tr = post.ctx.truncation
-    assert tr['tol'] == 1e-8 and not tr['retried'] and 0 <= tr['est_rel_row_err'] < 2e-10 and tr['rank'] == post.ctx.conv_layout['rank']
+    assert tr['tol'] == 1e-8 and not tr['retried'] and tr['points'] == 9 and tr['rank'] == post.ctx.conv_layout['rank']
+    assert 0 <= tr['est_rel_row_err'] < 1e-10 and tr['est_rel_row_err'] <= tr['est_rel_row_err_box'] < 1e-6
+    assert 0 <= tr['est_rel_sz_like_err_box'] <= 1e-8
     a = post.log_prob(th)
     chi_a = post.stage(th, 'chisq')
     post.close()
-    monkeypatch.setenv('JOXSZ_TRUNC_BOUND', '1e-13')                  # one step: 1e-8 -> 1e-10 is enough for this bound
+    monkeypatch.setenv('JOXSZ_TRUNC_BOUND', '1e-11')                  # row bound 1e-11, log-likelihood bound 1e-10 over the box
     post = _post(pb)
     tr1 = post.ctx.truncation
-    assert tr1['retried'] == 1 and tr1['tol'] == 1e-10 and tr1['rank'] > tr['rank'] and 0 <= tr1['est_rel_row_err'] < 1e-13
+    assert tr1['retried'] >= 1 and tr1['tol'] < 1e-8 and tr1['rank'] > tr['rank']
+    assert 0 <= tr1['est_rel_row_err'] <= 1e-11 and 0 <= tr1['est_rel_sz_like_err_box'] <= 1e-10
+    assert tr1['rank'] == post.ctx.conv_layout['rank']
     post.close()
-    monkeypatch.setenv('JOXSZ_TRUNC_BOUND', '1e-16')                  # never met: ends with every term above rounding
+    monkeypatch.setenv('JOXSZ_TRUNC_BOUND', '1e-18')                  # never met: ends with every term above rounding
     post = _post(pb)
     tr2 = post.ctx.truncation
-    assert tr2['retried'] == 3 and tr2['tol'] == 1e-13 and tr2['rank'] > tr1['rank'] and 0 <= tr2['est_rel_row_err'] < 1e-12
+    assert tr2['retried'] >= 5 and tr2['tol'] <= 1.01e-13 and tr2['rank'] > tr1['rank'] and 0 <= tr2['est_rel_row_err'] < 1e-12
     b = post.log_prob(th)
     chi_b = post.stage(th, 'chisq')
     rows = post.stage(th[:4], 'map_row')
@@ -391,18 +411,44 @@ def test_truncation_probe_and_automatic_tightening(monkeypatch):
     assert np.max(np.abs(chi_a[fin] - chi_b[fin])) / 2 < 1e-7         # the default cut against no cut: |d(chi^2/2)| far inside 1e-6
     st = orc.sz_stages(pb, orc.pars_dict(pb, th[0]))
     assert np.abs(rows[0] - st['map_row']).max() / np.abs(st['map_row']).max() < 1e-12
+    # an explicit cut is measured, never overridden
+    monkeypatch.setenv('JOXSZ_LOWRANK_TOL', '1e-7')
+    post = _post(pb)
+    tr3 = post.ctx.truncation
+    post.close()
+    assert tr3['tol'] == 1e-7 and tr3['retried'] == 0 and tr3['est_rel_sz_like_err_box'] > tr['est_rel_sz_like_err_box']
 
 
-def test_truncation_probe_odd_side(monkeypatch):
-    """Odd sides have no untruncated route inside the context: the probe compares with a second, small context built
-    with every term kept.  Same contract."""
+def test_truncation_guard_odd_side_and_measured_transfer_function(monkeypatch):
+    """Odd sides: same guard, same kernels.  The bundled measured transfer function (rough from one wavenumber to the next:
+    its weights have nearly full rank) leaves nothing to truncate -- the full form runs and the guard reports so."""
     pb = _problem(513, 500, seed=4)
     post = _post(pb, conv='custom')
     tr = post.ctx.truncation
-    assert tr['tol'] == 1e-8 and not tr['retried'] and 0 <= tr['est_rel_row_err'] < 2e-10
+    assert tr['tol'] == 1e-8 and not tr['retried'] and 0 <= tr['est_rel_row_err'] < 1e-10 and 0 <= tr['est_rel_sz_like_err_box'] <= 1e-8
     post.close()
-    monkeypatch.setenv('JOXSZ_TRUNC_BOUND', '1e-16')
+    monkeypatch.setenv('JOXSZ_TRUNC_BOUND', '1e-18')
     post = _post(pb, conv='custom')
     tr2 = post.ctx.truncation
-    assert tr2['retried'] >= 2 and tr2['tol'] <= 1e-12 and tr2['rank'] > tr['rank']      # (stops when the row equals the reference's)
+    assert tr2['retried'] >= 5 and tr2['tol'] <= 1.01e-13 and tr2['rank'] > tr['rank']
     post.close()
+    monkeypatch.delenv('JOXSZ_TRUNC_BOUND')
+    from joxsz_amd import datasets, setup_host as sh
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'bundled_inputs.npz'))
+    pb = datasets.synthetic_problem(S=257, N=300, seed=4)
+    wn, tf = sh.transfer_function(z['wn_as'], z['tf'], approx=False)
+    pb.filtering = np.ascontiguousarray(sh.filter_image(wn, tf, 257, 2.))
+    th = datasets.walker_ball(pb, 8, spread=0.03, seed=4)
+    post = _post(pb)
+    assert post.ctx.conv_layout['form'] == 'full'
+    tr = post.ctx.truncation
+    assert tr['est_rel_row_err'] == -1.0 and tr['rank'] == 0 and tr['retried'] == 0
+    a = post.log_prob(th)
+    post.close()
+    ref = _post(pb, conv='rocfft')
+    b = ref.log_prob(th)
+    ref.close()
+    fin = np.isfinite(b)
+    assert fin.sum() >= 6 and np.array_equal(np.isfinite(a), fin)
+    np.testing.assert_allclose(a[fin], b[fin], rtol=1e-10)

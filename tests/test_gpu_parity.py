@@ -28,7 +28,7 @@ def test_golden_logp(golden):
     """The reference's own log-posteriors (tests/golden) on identical parameter vectors."""
     pb, ref = golden
     post = _post(pb)
-    assert post.ctx.conv == 'custom'                  # the reference's odd sides run on the hand-written route
+    assert post.ctx.conv == 'custom'                  # the reference's odd sides run on the contracted route
     got = post.log_prob(ref['thetas'])
     want = ref['ref_logp']
     post.close()
@@ -81,7 +81,7 @@ def test_stage_by_stage_vs_oracle(golden_tiny):
                                       (257, 300, 'auto'), (513, 500, 'auto')])
 def test_random_walkers_vs_oracle(S, N, conv):
     """Odd (reference-shaped) and even (BASELINE-shaped) map sides, seeded walkers, both
-    convolution back ends (rocFFT sequence / hand-written mixed-domain passes)."""
+    back ends (rocFFT sequence / contracted route)."""
     from joxsz_amd import datasets
     pb = datasets.synthetic_problem(S=S, N=N, seed=S)
     p0 = orc.pars_dict(pb, datasets.fiducial_theta(pb))
@@ -90,7 +90,7 @@ def test_random_walkers_vs_oracle(S, N, conv):
     th = datasets.walker_ball(pb, W, spread=0.05, seed=S)
     th[1, 1] = 9.0                                    # one rejected walker in the batch
     post = _post(pb, conv=conv)
-    # odd sides take the hand-written route as well (real-space transfer-function step) once the padded length fits
+    # every map side with the mirror structure of centdistmat takes the contracted route
     assert post.ctx.conv == ('custom' if conv == 'auto' else conv)
     got = post.log_prob(th)
     post.close()
@@ -162,7 +162,7 @@ def test_linearity_full_size():
     rows = post.stage(th, 'map_row')
     y2d = post.stage(th[:2], 'y_2d')
     post.close()
-    # (the default route's singular-value cut moves the row by ~1e-11 of its largest entry: absolute, so relatively more in its tail)
+    # (the low-rank form's singular-value cut moves the row by ~1e-11 of its largest entry: absolute, so relatively more in its tail)
     np.testing.assert_allclose(rows, rows_fft, rtol=1e-9, atol=1e-10 * np.abs(rows_fft).max())
     np.testing.assert_allclose(rows[1], 2.0 * rows[0], rtol=1e-10, atol=1e-18)
     np.testing.assert_allclose(rows[2], 3.0 * rows[0], rtol=1e-10, atol=1e-18)
@@ -176,9 +176,9 @@ def test_linearity_full_size():
 
 
 @pytest.mark.parametrize('S,N,step,fwhm', [(32, 40, 6., 8.5), (64, 80, 2., 18.5)])
-def test_custom_conv_stages(S, N, step, fwhm):
-    """Hand-written convolution passes: beam-convolved map and extracted row against the
-    oracle, and against the rocFFT back end on the same context inputs."""
+def test_contracted_route_stages(S, N, step, fwhm):
+    """Contracted route: the Compton-y map and beam-convolved map taps (Abel + map kernel; reference facility) and the
+    extracted row against the oracle, and against the rocFFT back end on the same context inputs."""
     from joxsz_amd import datasets
     pb = datasets.synthetic_problem(S=S, N=N, seed=3, step=step, fwhm=fwhm)
     th = datasets.walker_ball(pb, 5, spread=0.04, seed=3)
@@ -197,35 +197,41 @@ def test_custom_conv_stages(S, N, step, fwhm):
         np.testing.assert_allclose(out['custom'][name], out['rocfft'][name], rtol=1e-9, atol=1e-30)
 
 
-def test_custom_conv_refuses_what_it_cannot_do(golden_tiny):
-    """The hand-written route needs a flip-symmetric beam image (what mybeam builds, joxsz_funcs.py:46-76) and the
-    library's own padded length: asked for explicitly with anything else it refuses, on 'auto' it takes the rocFFT
-    sequence -- and that one still matches the oracle."""
+def test_contracted_route_refuses_what_it_cannot_do(golden_tiny):
+    """The contracted route needs the mirror structure of a centred distance matrix (what centdistmat builds,
+    joxsz_funcs.py:78-88): asked for explicitly without it -- or with a padded length, which only the rocFFT sequence has --
+    it refuses; on 'auto' the rocFFT sequence runs, and that one still matches the oracle.  A beam image that is not
+    flip-symmetric is no obstacle (the separable terms and the full form make no use of the symmetry)."""
     import copy
     from joxsz_amd.hip_backend import JoxszHipError
     pb, ref = golden_tiny
-    pb = copy.deepcopy(pb)
-    pb.beam_2d = pb.beam_2d.copy()
-    o = pb.B // 2
-    pb.beam_2d[o, o + 1] *= 1.5                        # no longer symmetric under the flips
+    bad = copy.deepcopy(pb)
+    bad.d_mat = bad.d_mat.copy()
+    bad.d_mat[3, 5] *= 1.0001                            # one pixel off the mirror structure
     with pytest.raises(JoxszHipError):
-        _post(pb, conv='custom')
+        _post(bad, conv='custom')
     with pytest.raises(JoxszHipError):
-        _post(golden_tiny[0], conv='custom', fft_pad=64)
-    post = _post(pb)
+        _post(pb, conv='custom', fft_pad=64)
+    post = _post(bad)
     assert post.ctx.conv == 'rocfft'
     got = post.log_prob(ref['thetas'][:4])
     post.close()
-    want = orc.log_posterior_batch(pb, ref['thetas'][:4])
-    np.testing.assert_allclose(got, want, rtol=RTOL)
+    np.testing.assert_allclose(got, orc.log_posterior_batch(bad, ref['thetas'][:4]), rtol=RTOL)
+    skew = copy.deepcopy(pb)
+    skew.beam_2d = skew.beam_2d.copy()
+    o = skew.B // 2
+    skew.beam_2d[o, o + 1] *= 1.5                        # no longer symmetric under the flips
+    post = _post(skew, conv='custom')
+    got = post.log_prob(ref['thetas'][:4])
+    post.close()
+    np.testing.assert_allclose(got, orc.log_posterior_batch(skew, ref['thetas'][:4]), rtol=RTOL)
 
 
 @pytest.mark.parametrize('S,N', [(65, 80), (171, 313), (257, 300), (513, 500)])
 def test_odd_side_custom_route(S, N):
     """Odd map sides -- the only kind the reference itself can run (joxsz_main.py:100-105, joxsz_funcs.py:472-473) -- on
-    the hand-written route: rows from the spline, FIR + job combination as matrix products, combined rows back to real
-    space, transfer function as real-space circular kernels.  Stage by stage against the oracle and against the rocFFT
-    sequence; ragged launches bitwise."""
+    the contracted route (the same kernels as even sides: nothing in them depends on the parity).  Stage by stage against
+    the oracle and against the rocFFT sequence; ragged launches bitwise."""
     from joxsz_amd import datasets
     pb = datasets.synthetic_problem(S=S, N=N, seed=S + 1)
     p0 = orc.pars_dict(pb, datasets.fiducial_theta(pb))
@@ -234,7 +240,7 @@ def test_odd_side_custom_route(S, N):
     th[3, 1] = 9.0
     post = _post(pb, conv='custom')
     lay = post.ctx.conv_layout
-    assert post.ctx.conv == 'custom' and lay['fused'] == 1 and lay['rank'] > 0
+    assert post.ctx.conv == 'custom' and lay['NU'] == S // 2 + 1 and (lay['rank'] > 0) == (lay['form'] == 'lowrank')
     got = post.log_prob(th)
     rows, bright, chisq, y2d, conv = (post.stage(th[:6], s) for s in ('map_row', 'bright', 'chisq', 'y_2d', 'conv_2d'))
     assert np.array_equal(post.log_prob(th), got)
@@ -256,14 +262,14 @@ def test_odd_side_custom_route(S, N):
         assert _relerr(conv[k], st['conv_2d']) < RTOL_STAGE
         assert _relerr(rows[k], st['map_row']) < RTOL_STAGE
         # (the rejected walker's conversion factors grow by 36 orders of magnitude towards the edge, where the row has decayed by
-        #  four: what the singular-value cut leaves there, 1e-11 of the row's maximum, is then all that 'bright' shows)
+        #  four: what the singular-value cut of the low-rank form leaves there, 1e-11 of the row's maximum, is then all that 'bright' shows)
         assert _relerr(bright[k], st['bright']) < (RTOL_STAGE if fin[k] else 1e-6)
         assert abs(chisq[k] - st['chisq']) / 2 < 1e-6 * max(1.0, 1e-3 * st['chisq'])      # absolute near the mode, relative far from it
 
 
 def test_odd_side_1025():
     """SURVEY 8(d)'s largest odd side (the odd neighbour of BASELINE configs[4]'s 1024^2 map, 1000-point grid) on the
-    hand-written route, against the oracle and the rocFFT sequence."""
+    contracted route, against the oracle and the rocFFT sequence."""
     from joxsz_amd import datasets
     pb = datasets.synthetic_problem(S=1025, N=1000, seed=7)
     p0 = orc.pars_dict(pb, datasets.fiducial_theta(pb))
@@ -271,7 +277,7 @@ def test_odd_side_1025():
     th = datasets.walker_ball(pb, 6, spread=0.03, seed=7)
     th[2, 1] = 9.0
     post = _post(pb, conv='custom')
-    assert post.ctx.conv == 'custom' and post.ctx.conv_layout['fused'] == 1
+    assert post.ctx.conv == 'custom' and post.ctx.conv_layout['form'] == 'lowrank'
     got = post.log_prob(th)
     rows = post.stage(th[:2], 'map_row')
     post.close()
@@ -287,99 +293,60 @@ def test_odd_side_1025():
         assert _relerr(rows[k], orc.sz_stages(pb, orc.pars_dict(pb, th[k]))['map_row']) < RTOL_STAGE
 
 
-def test_custom_conv_with_and_without_row_symmetry(monkeypatch):
-    """The row bookkeeping (distinct map rows, conv jobs) and the real-spectrum form of x-symmetric
-    rows must not change any number: identity tables (JOXSZ_CONV_NOSYM=1), mirrored rows with complex
-    spectra (JOXSZ_CONV_XSYM=0) and the default (both symmetries) against each other and the oracle."""
+@pytest.mark.parametrize('S,N,W', [(64, 80, 3), (171, 313, 70), (512, 500, 130)])
+def test_timed_kernels_against_numpy_on_the_oracle_map(S, N, W, monkeypatch):
+    """The kernels the log-posterior is timed on, stage by stage (jx_debug_workspace), in the low-rank form: the rows stage 1
+    leaves per map column against C^T Q in numpy -- Q the quadrant of the ORACLE's Compton-y map, C the operator the device
+    holds -- and the partial rows of the matrix-core product, summed, against G D in numpy, the row tap and the oracle."""
     from joxsz_amd import datasets
-    modes = {'full': {}, 'rows_only': {'JOXSZ_CONV_XSYM': '0'}, 'none': {'JOXSZ_CONV_NOSYM': '1'}}
-    monkeypatch.setenv('JOXSZ_LOWRANK_TOL', '1e-13')          # bookkeeping test: no truncation beyond rounding in any mode
-    for S, N, fwhm in ((64, 80, 18.5), (256, 300, 18.5), (512, 300, 9.0)):
-        pb = datasets.synthetic_problem(S=S, N=N, seed=9, fwhm=fwhm)
-        th = datasets.walker_ball(pb, 4, spread=0.04, seed=9)
-        res = {}
-        for mode, env in modes.items():
-            for k, v in env.items():
-                monkeypatch.setenv(k, v)
-            post = _post(pb, conv='custom')
-            res[mode] = (post.stage(th, 'conv_2d'), post.stage(th, 'map_row'), post.log_prob(th))
-            post.close()
-            for k in env:
-                monkeypatch.delenv(k)
-        for mode in ('rows_only', 'none'):
-            for a, b in zip(res['full'][:2], res[mode][:2]):
-                np.testing.assert_allclose(a, b, rtol=1e-11, atol=1e-13 * np.abs(b).max(), err_msg=mode)
-            np.testing.assert_allclose(res['full'][2], res[mode][2], rtol=1e-9, err_msg=mode)     # chi^2 amplifies round-off
-        st = orc.sz_stages(pb, orc.pars_dict(pb, th[0]))
-        assert _relerr(res['full'][0][0], st['conv_2d']) < RTOL_STAGE
-        assert _relerr(res['full'][1][0], st['map_row']) < RTOL_STAGE
-
-
-@pytest.mark.parametrize('S,N', [(64, 80), (512, 500)])
-def test_conv_work_buffers_against_numpy(S, N, monkeypatch):
-    """Each hand-written pass on its own (jx_debug_workspace): row spectra, FIR output and the
-    column-0 terms against numpy FFTs of the Compton-y map the same evaluation produced.  (The route
-    with separate kernels, JOXSZ_FUSED=0: the fused route keeps these intermediates walker-minor.)"""
-    from joxsz_amd import datasets
-    monkeypatch.setenv('JOXSZ_FUSED', '0')
+    monkeypatch.setenv('JOXSZ_MIX_FORM', 'lowrank')
     pb = datasets.synthetic_problem(S=S, N=N, seed=5)
-    th = datasets.walker_ball(pb, 2, spread=0.03, seed=5)
-    post = _post(pb, conv='custom', max_batch=2)
-    y2d = post.stage(th, 'y_2d')
-    post.log_prob(th)
+    th = datasets.walker_ball(pb, W, spread=0.03, seed=5)
+    post = _post(pb, conv='custom')
     ctx = post.ctx
-    y, quad = ctx.workspace('y_map')
-    if quad:                                                  # only the distinct pixels (|iy-c|, |ix-c|) are stored
-        idx = np.abs(np.arange(S) - S // 2)
-        y = y[:, idx][:, :, idx]
-    np.testing.assert_array_equal(y, y2d)
-    Y, xsym = ctx.workspace('row_spectra')
-    C, _ = ctx.workspace('fir_rows')
-    jrow = ctx.workspace('job_rows')[0][0, :, 0]
-    umap = ctx.workspace('row_index')[0][0, :, 0]
-    assert xsym, 'default mode for a mirror-symmetric d_mat and this beam width'
-    col0, _ = ctx.workspace('col0')
+    lay = ctx.conv_layout
+    assert lay['form'] == 'lowrank'
+    rows = post.stage(th, 'map_row')                           # (runs the profile taps' Abel kernel for the spline arrays)
+    D_tap = ctx.workspace('stage1')[:, :, :W].copy()
+    lp = post.log_prob(th)                                      # (spline arrays from the matrix product: the timed sequence)
+    D = ctx.workspace('stage1')[:, :, :W]                       # [NU][R][walker]
+    part = ctx.workspace('partials')[:, :W, :]                  # [ksplit][walker][ldx]
+    cf = ctx.workspace('splines')[:, :W, :]                     # [N][walker][2]
+    Cm = ctx.workspace('stage1_op')[0]
+    Op = ctx.workspace('product_op')
+    y_tap = post.stage(th[:2], 'y')
     post.close()
-    P = ctx.conv_layout['P']; Ph = P // 2 + 1; c = S // 2; B = pb.B; o = (B - 1) // 2
-    Y = Y[:, :, :Ph]; C = C[:, :, :Ph]                      # rows are padded to whole cache lines
-    phase = np.exp(2j * np.pi * np.arange(Ph) * c / P)
-    beam = np.asarray(pb.beam_2d, float)
-    # beam spectrum along x per row offset d = -o..o (centred: column o is x offset 0)
-    bhat = np.fft.rfft(np.roll(np.pad(beam, ((0, 0), (0, P - B))), -o, axis=1), axis=1) * pb.step ** 2 / P
-    first = np.array([np.nonzero(umap == u)[0][0] for u in range(Y.shape[1])])
-    for w in range(2):
-        m0 = y[w].copy(); m0[:, 0] = 0.0                      # the unpaired column travels separately
-        spec = np.fft.rfft(m0, n=P, axis=1)
-        want = spec[first] * phase
-        scale = np.abs(want).max()
-        assert np.abs(want.imag).max() < 1e-13 * scale
-        assert np.abs(Y[w] - want.real).max() < 1e-13 * scale
-        conv = np.zeros((len(jrow), Ph), complex)
-        for q, r in enumerate(jrow):
-            for d in range(-o, o + 1):
-                if 0 <= r - d < S:
-                    conv[q] += bhat[o + d] * spec[r - d]
-        want_c = conv * phase
-        scale = np.abs(want_c).max()
-        assert np.abs(want_c.imag).max() < 1e-12 * scale
-        assert np.abs(C[w][:len(jrow)] - want_c.real).max() < 1e-12 * scale
-        want0 = np.zeros((len(jrow), o + 1))
-        for q, r in enumerate(jrow):
-            for d in range(-o, o + 1):
-                if 0 <= r - d < S:
-                    want0[q] += pb.step ** 2 * beam[o + d, o:] * y[w][r - d, 0]
-        assert np.abs(col0[w].T - want0).max() < 1e-13 * np.abs(want0).max()       # stored [x][job]
+    NU, R, nrow = lay['NU'], lay['R'], S - S // 2
+    Cm = Cm[:NU, :R]
+    G = np.zeros((nrow, NU * R))
+    for x in range(nrow):
+        G[x] = Op[:NU * R, x & 15, x >> 4]
+    c = S // 2
+    iy = np.array([c + b if c + b < S else c - b for b in range(NU)])
+    for w in (0, W - 1):
+        st = orc.sz_stages(pb, orc.pars_dict(pb, th[w]))
+        Q = st['y_2d'][np.ix_(iy, iy)]
+        want_D = Cm.T @ Q                                       # [R][x']
+        scale = np.abs(want_D).max()
+        assert np.abs(D[:, :, w].T - want_D).max() < 1e-12 * scale
+        assert np.abs(D_tap[:, :, w].T - want_D).max() < 1e-12 * scale
+        want_row = G @ D[:, :, w].reshape(-1)                   # kappa = x' * R + j
+        got_row = part[:, w, :nrow].sum(axis=0)
+        assert _relerr(got_row, want_row) < 1e-13
+        assert _relerr(got_row, rows[w]) < 1e-12
+        assert _relerr(got_row, st['map_row']) < RTOL_STAGE
+        if w < 2:
+            np.testing.assert_allclose(cf[:, w, 0], y_tap[w], rtol=1e-12, atol=1e-14 * np.abs(y_tap[w]).max())
+    assert np.isfinite(lp).sum() >= 0.8 * W
 
 
-def test_lowrank_weights_against_full_weights(monkeypatch):
-    """The transfer-function weights in low-rank form (truncation at 1e-13 of the largest singular value):
-    'fused' = FIR + job combination as one matrix product per column on walker-minor row spectra (default),
-    'lowrank' = FIR kernel, then the combination (JOXSZ_FUSED=0), 'full' = one pass-3 row per job
-    (JOXSZ_LOWRANK=0).  All three against each other and against the oracle; ragged walker counts included."""
+def test_lowrank_form_against_full_form(monkeypatch):
+    """The two forms of the contracted route on the same inputs: 'full' (one operator row per distinct map sample: exact),
+    'tight' (low-rank form with every singular value above rounding), 'default' (cut 1e-8 at sides >= 400) -- against each
+    other, the rocFFT sequence and the oracle; ragged walker counts included."""
     from joxsz_amd import datasets
-    # 'tight': every singular value above rounding (1e-13); the default cut is 1e-8 at sides >= 400, 1e-13 below
-    modes = {'fused': {}, 'tight': {'JOXSZ_LOWRANK_TOL': '1e-13'}, 'lowrank': {'JOXSZ_FUSED': '0', 'JOXSZ_LOWRANK_TOL': '1e-13'},
-             'full': {'JOXSZ_LOWRANK': '0'}}
+    modes = {'default': {'JOXSZ_MIX_FORM': 'lowrank'}, 'tight': {'JOXSZ_MIX_FORM': 'lowrank', 'JOXSZ_LOWRANK_TOL': '1e-13'},
+             'full': {'JOXSZ_MIX_FORM': 'full'}}
     for S, N, nw in ((256, 300, 6), (512, 500, 37)):
         pb = datasets.synthetic_problem(S=S, N=N, seed=11)
         th = datasets.walker_ball(pb, nw, spread=0.05, seed=11)
@@ -389,40 +356,44 @@ def test_lowrank_weights_against_full_weights(monkeypatch):
                 monkeypatch.setenv(k, v)
             post = _post(pb, conv='custom')
             lay = post.ctx.conv_layout
-            assert (lay['rank'] > 0) == (mode != 'full') and lay['rank'] < lay['NJ'] // 2
-            assert bool(lay['fused']) == (mode in ('fused', 'tight'))
+            assert lay['form'] == ('full' if mode == 'full' else 'lowrank') and (lay['rank'] > 0) == (mode != 'full')
             res[mode] = (post.stage(th, 'map_row'), post.stage(th, 'bright'), post.log_prob(th), lay['rank'])
             post.close()
             for k in env:
                 monkeypatch.delenv(k)
-        for mode in ('tight', 'lowrank'):
-            for a, b in zip(res[mode][:2], res['full'][:2]):
+        ref = _post(pb, conv='rocfft')
+        res['rocfft'] = (ref.stage(th, 'map_row'), ref.stage(th, 'bright'), ref.log_prob(th), 0)
+        ref.close()
+        for mode in ('tight', 'full'):
+            for a, b in zip(res[mode][:2], res['rocfft'][:2]):
                 np.testing.assert_allclose(a, b, rtol=1e-10, atol=1e-11 * np.abs(b).max(), err_msg=mode)
-            np.testing.assert_allclose(res[mode][2], res['full'][2], rtol=1e-9, err_msg=mode)
-        for a, b in zip(res['fused'][:2], res['full'][:2]):               # default cut
+            np.testing.assert_allclose(res[mode][2], res['rocfft'][2], rtol=1e-9, err_msg=mode)
+        for a, b in zip(res['default'][:2], res['full'][:2]):             # default cut
             np.testing.assert_allclose(a, b, rtol=1e-7, atol=1e-8 * np.abs(b).max())
-        np.testing.assert_allclose(res['fused'][2], res['full'][2], rtol=1e-9)
-        assert res['fused'][3] <= res['tight'][3]
+        np.testing.assert_allclose(res['default'][2], res['full'][2], rtol=1e-9)
+        assert res['default'][3] <= res['tight'][3]
         want = orc.log_posterior_batch(pb, th[:8])
-        np.testing.assert_allclose(res['fused'][2][:8], want, rtol=RTOL)
+        for mode in modes:
+            np.testing.assert_allclose(res[mode][2][:8], want, rtol=RTOL, err_msg=mode)
         st = orc.sz_stages(pb, orc.pars_dict(pb, th[0]))
-        assert _relerr(res['fused'][0][0], st['map_row']) < RTOL_STAGE
+        for mode in modes:
+            assert _relerr(res[mode][0][0], st['map_row']) < RTOL_STAGE, mode
 
 
-def test_rough_transfer_function_falls_back_to_one_row_per_job():
-    """A transfer function whose weights are not low-rank (here: multiplied by uncorrelated noise, symmetrised) must
-    switch the low-rank / fused routes off by itself and still match the oracle."""
+def test_rough_transfer_function_takes_the_full_form():
+    """A transfer function whose weights are not low-rank (here: multiplied by uncorrelated noise, symmetrised) makes the
+    low-rank form the dearer one: the library takes the full form by itself and still matches the oracle."""
     from joxsz_amd import datasets
     pb = datasets.synthetic_problem(S=128, N=150, seed=21)
     rng = np.random.default_rng(21)
     noise = 1.0 + 0.5 * rng.random((pb.S, pb.S))
     idx = (-np.arange(pb.S)) % pb.S
-    noise = 0.5 * (noise + noise[idx][:, idx])               # keep the filter symmetric under k -> -k (real weights)
+    noise = 0.25 * (noise + noise[idx][:, idx] + noise[idx] + noise[:, idx])      # symmetric in each wavenumber: real weights
     pb.filtering = np.ascontiguousarray(pb.filtering * noise)
     th = datasets.walker_ball(pb, 5, spread=0.04, seed=21)
     post = _post(pb, conv='custom')
     lay = post.ctx.conv_layout
-    assert lay['rank'] == 0 and lay['fused'] == 0 and lay['xsym'] == 1
+    assert lay['form'] == 'full' and lay['rank'] == 0 and post.ctx.truncation['est_rel_row_err'] == -1.0
     got = post.log_prob(th)
     row = post.stage(th[:1], 'map_row')[0]
     post.close()
@@ -432,6 +403,49 @@ def test_rough_transfer_function_falls_back_to_one_row_per_job():
     np.testing.assert_allclose(got[fin], want[fin], rtol=RTOL)
     st = orc.sz_stages(pb, orc.pars_dict(pb, th[0]))
     assert _relerr(row, st['map_row']) < RTOL_STAGE
+
+
+def _measured_problem(S, N):
+    """The bundled (measured) beam profile and transfer function -- the reference's own defaults, beam_approx = tf_approx =
+    False (joxsz_main.py:59-60) -- on a map of side S (tests/golden/bundled_inputs.npz holds the two data files' columns)."""
+    from joxsz_amd import datasets, setup_host as sh
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'bundled_inputs.npz'))
+    pb = datasets.synthetic_problem(S=S, N=N, seed=S)
+    prof = sh.clip_beam_profile(z['beam_r'], z['beam_prof'])
+    beam_2d, _ = sh.beam_image(2., 116.0, approx=False, profile=prof)
+    wn, tf = sh.transfer_function(z['wn_as'], z['tf'], approx=False)
+    pb.beam_2d = np.ascontiguousarray(beam_2d)
+    pb.filtering = np.ascontiguousarray(sh.filter_image(wn, tf, S, 2.))
+    return pb.validate()
+
+
+@pytest.mark.parametrize('S,N', [(512, 512), (513, 513)])
+def test_measured_beam_and_transfer_function_at_the_headline_sides(S, N):
+    """The reference's default inputs at the headline sides: the measured beam image is not separable (28 terms) and the
+    measured transfer function is rough, so the full form runs -- exact, against the oracle and the rocFFT sequence."""
+    from joxsz_amd import datasets
+    pb = _measured_problem(S, N)
+    p0 = orc.pars_dict(pb, datasets.fiducial_theta(pb))
+    datasets.fill_data(pb, orc.sz_stages(pb, p0)['bright'], orc.calc_profiles(pb, p0), seed=S)
+    th = datasets.walker_ball(pb, 20, spread=0.04, seed=S)
+    th[2, 1] = 9.0
+    post = _post(pb)
+    assert post.ctx.conv == 'custom' and post.ctx.conv_layout['form'] == 'full'
+    got = post.log_prob(th)
+    rows, chisq = post.stage(th[:4], 'map_row'), post.stage(th, 'chisq')
+    post.close()
+    ref = _post(pb, conv='rocfft')
+    want_fft, chisq_fft = ref.log_prob(th), ref.stage(th, 'chisq')
+    ref.close()
+    want = orc.log_posterior_batch(pb, th[:6])
+    fin = np.isfinite(want_fft)
+    assert fin.sum() >= 15 and np.array_equal(np.isfinite(got), fin)
+    np.testing.assert_allclose(got[fin], want_fft[fin], rtol=1e-10)
+    assert np.max(np.abs(chisq[fin] - chisq_fft[fin])) / 2 < 1e-7
+    f6 = np.isfinite(want)
+    np.testing.assert_allclose(got[:6][f6], want[f6], rtol=1e-9)
+    for k in range(2):
+        assert _relerr(rows[k], orc.sz_stages(pb, orc.pars_dict(pb, th[k]))['map_row']) < RTOL_STAGE
 
 
 _CALLER_STREAM_SCRIPT = r"""
@@ -475,14 +489,14 @@ def test_caller_stream():
     assert r.returncode == 0 and r.stdout.strip().endswith('ok'), r.stderr[-2000:]
 
 
-def test_fused_route_chunking():
-    """Walker counts that are no multiple of the GEMM's 16-walker tiles, split over several launch sequences of
-    different sizes, give the numbers of one launch sequence, walker by walker."""
+def test_contracted_route_chunking():
+    """Walker counts that are no multiple of the kernels' walker tiles (64 lanes in stage 1, 128 per block in the product),
+    split over several launch sequences of different sizes, give the numbers of one launch sequence, walker by walker."""
     from joxsz_amd import datasets
     pb = datasets.synthetic_problem(S=128, N=150, seed=13)
     th = datasets.walker_ball(pb, 77, spread=0.04, seed=13)
     post = _post(pb, conv='custom')
-    assert post.ctx.conv_layout['fused'] == 1
+    assert post.ctx.conv_layout['form'] in ('lowrank', 'full')
     one = post.log_prob(th)
     post.close()
     for mb in (16, 20, 50):
@@ -533,9 +547,8 @@ def test_largest_config_shape():
 
 @pytest.mark.parametrize('fwhm,B', [(6.5, 19), (9.0, 27), (21.0, 63)])
 def test_other_beam_widths(fwhm, B):
-    """Beam widths with (B=27) and without (B=19, 63) a register-window FIR instance: the log-posterior goes through the
-    fused route either way, the beam-convolved-map tap through the register FIR or the plain real-array FIR.  All
-    against the oracle."""
+    """Other beam widths (B = 19, 27, 63): nothing in the contracted route is specialised to one; the beam-convolved-map tap
+    goes through the context's reference facility.  All against the oracle."""
     from joxsz_amd import datasets
     pb = datasets.synthetic_problem(S=128, N=150, seed=11, fwhm=fwhm)
     assert pb.B == B
@@ -611,10 +624,10 @@ def test_prep_log_form_against_pow_form(monkeypatch):
 
 @pytest.mark.parametrize('S,N,W', [(64, 80, 5), (256, 300, 70), (171, 313, 33), (512, 500, 130)])
 def test_spline_arrays_matrix_product_against_abel_kernel(S, N, W, monkeypatch):
-    """Default route: the spline ordinates and moments (y_k, M_k) of a launch come from one matrix product on the matrix
+    """Contracted route: the spline ordinates and moments (y_k, M_k) of a launch come from one matrix product on the matrix
     cores (``jx_abel_gemm_kernel``: Abel weights, Compton-y scale and spline moments folded into one constant operator;
-    joxsz_funcs.py:457-460).  Against the Abel kernel's own phases 1-3 (JOXSZ_ABEL_GEMM=0, which also serves the
-    'ab' / 'y' stage taps that are held to the oracle above): arrays, zero padding, log-posterior, rejections."""
+    joxsz_funcs.py:457-460), walker-minor.  Against the Abel kernel's own phases 1-3 (JOXSZ_ABEL_GEMM=0, which also serves
+    the 'ab' / 'y' stage taps that are held to the oracle above): arrays, log-posterior, rejections."""
     from joxsz_amd import datasets
     pb = datasets.synthetic_problem(S=S, N=N, seed=S)
     th = datasets.walker_ball(pb, W, spread=0.03, seed=S)     # ragged: not a multiple of the 32 walkers of a block
@@ -624,10 +637,10 @@ def test_spline_arrays_matrix_product_against_abel_kernel(S, N, W, monkeypatch):
         monkeypatch.setenv('JOXSZ_ABEL_GEMM', mode)
         post = _post(pb, conv='custom')
         lp = post.log_prob(th)
-        cf, _ = post.ctx.workspace('coefs')
+        cf = post.ctx.workspace('splines')[:, :W, :]               # [N][walker][(y, M)]
         y_tap = post.stage(th, 'y')
         post.close()
-        res[mode] = (lp, cf[:W, 0, :].copy(), y_tap)
+        res[mode] = (lp, np.ascontiguousarray(cf.transpose(1, 0, 2)).reshape(W, 2 * N), y_tap)
     a, b = res['0'], res['1']
     fin = np.isfinite(a[0])
     assert not fin[1] and np.array_equal(np.isfinite(b[0]), fin)
@@ -635,5 +648,4 @@ def test_spline_arrays_matrix_product_against_abel_kernel(S, N, W, monkeypatch):
     np.testing.assert_array_equal(ya, a[2][fin])                                    # the kernel's ordinates are the 'y' tap
     assert np.max(np.abs(ya - yb) / np.abs(ya).max(axis=1, keepdims=True)) < 1e-13
     assert np.max(np.abs(ma - mb) / np.abs(ma).max(axis=1, keepdims=True)) < 5e-12  # (second differences: cancellation)
-    assert np.all(b[1][:, 2 * N:] == 0)                                             # the slots behind the last knot stay zero
     np.testing.assert_allclose(b[0][fin], a[0][fin], rtol=1e-9)
