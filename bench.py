@@ -12,21 +12,28 @@ vectors already resident in HBM when the timed region starts.  For N>1 every
 rank evaluates its own 1024 walkers (weak scaling, walkers are independent) and
 the log-probabilities are all-gathered over RCCL inside the timed region --
 through the library's own C-ABI (jx_comm_*, jx_allgather_logp): this program
-imports no torch; the launcher (torch.distributed.run) only sets RANK /
-LOCAL_RANK / WORLD_SIZE / MASTER_PORT.
+imports no torch.
+
+Ranks: under a launcher (torch.distributed.run sets RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_PORT) each process is one rank.  Without one, `--gpus N`
+with N > 1 makes THIS process the launcher: it starts N fresh child processes
+(one per GPU) before anything touches a GPU, never initialises HIP itself,
+relays rank 0's single JSON line and exits non-zero if any rank fails.
 
 Prints ONE JSON line (rank 0) with
-  `roofline`       the time-dominant kernel of the step on the bytes it must move (HIP-event duration on the library's
-                   stream), with SURVEY 8(d)'s S*S*8 B/walker figure beside it and the rocprofv3 PMC traffic of the committed
-                   profile;
-  `roofline_step`  the whole step: measured HBM bytes / ms_per_step against the 8 TB/s peak;
-  `north_star_abel_map_kernel`  the fused profile->Abel->spline->map kernel storing the full S x S map (the kernel the
-                   north_star's ">= 60 % of the HBM roofline" is about), measured beside the metric;
-  `cpu_baseline`   the numpy/scipy oracle on this box's host cores.
+  `roofline`            the time-dominant kernel of the step (stage 1 of the contracted route: fp64 vector FMAs) on its
+                        algorithmic flops over its HIP-event duration, measured inside the timed region;
+  `roofline_product`    the matrix-core product behind it, same way;
+  `roofline_step`       the whole step against the HBM roofline (rocprofv3 PMC bytes of the committed profile / ms_per_step);
+  `north_star_abel_map_kernel`  the fused profile -> Abel -> spline -> full S x S map kernel the north_star's ">= 60 % of
+                        the HBM roofline" is about (jx_map_kernel_time), against the nominal and the measured copy roofline;
+  `cpu_baseline`        the numpy/scipy oracle on this box's host cores (process pool, single process, per-stage ms);
+  `other_configs`       strong-scaling rows of BASELINE configs[3] and configs[4] (this rank's shard).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -35,7 +42,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy there; measured here per run)
+FP64_PEAK_TFLOPS = 78.6          # MI355X: fp64 vector = fp64 matrix = 256 CUs x 128 flop/clk x 2.4 GHz
+FP64_FMA_MEASURED_TFLOPS = 62.8  # scripts/ubench/fma_sgpr.hip on this chip: v_fmac_f64 with register operands, 8 waves/SIMD (profiles/r03_fma_sgpr.log)
 
 
 def pmc_file(S):
@@ -46,6 +55,7 @@ def pmc_file(S):
         try:
             j = json.load(open(f))
             if j.get('S', 512) == S:
+                j['file'] = os.path.relpath(f, ROOT)
                 return j
         except Exception:
             pass
@@ -62,32 +72,9 @@ def pmc_traffic(j, kernel, walkers_per_launch):
     return None
 
 
-def must_move_bytes(ctx, pb, lay, W):
-    """Bytes every kernel of the default route has to move per launch of W walkers whatever its implementation (its
-    inputs read once + its outputs written once; walker-independent tables excluded), from the layout the library chose.
-    The reference's S x S map (S^2 * 8 B per walker written, read once) is never materialised on this route."""
-    N, S = pb.N, pb.S
-    nrow = ctx.nrow
-    if not lay or not lay.get('fused'):
-        return None
-    NU, kact, r = lay['NU'], lay['kact'], lay['rank']
-    P = lay['P']
-    coef = 16.0 * N                                   # (y_k, M_k) per knot
-    rows_t = 8.0 * kact * NU + 8.0 * NU               # real row spectra below the band limit + column 0
-    ct = 8.0 * kact * r + 8.0 * 40 * r                # combined rows + their column-0 terms
-    zp = 16.0 * (S // 2 + 1) * ((r + 13) // 14)       # partial Z per pass-3 block
-    small = 8.0 * (pb.ndim + nrow + 2)
-    per = {
-        'jx_prep_kernel': small + 8.0 * N,                # (+ the pressure profile for the spline-array product)
-        'jx_abel_gemm_kernel': 8.0 * N + coef,
-        'jx_rowdct_kernel': coef + rows_t,
-        'jx_lowrank_kernel': rows_t + ct,
-        'jx_rowtf2_kernel': ct + zp,
-        'jx_tail_fft_kernel': zp + small,
-    }
-    return {k: v * W for k, v in per.items()}
-
-
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baseline (oracle): process pool as the reference runs it, one process, and where one call's time goes
+# ---------------------------------------------------------------------------------------------------------------------
 def _cpu_worker(args):
     pb, th = args
     from oracle import joxsz_oracle as orc
@@ -109,16 +96,51 @@ def host_cores():
     return max(1, n)
 
 
-def cpu_baseline(pb, thetas, target_s=15.0):
-    """The oracle (numpy/scipy restatement of the reference path) mapped over
-    walkers with multiprocessing.Pool on all host cores, exactly the reference's
-    parallelism (joxsz_main.py:203-206), on a bounded sample of the workload."""
+def cpu_stage_ms(pb, theta, repeats=3):
+    """Milliseconds of one oracle call by stage: the same scipy/numpy primitives the reference calls,
+    timed one after the other on one parameter vector."""
+    from scipy.interpolate import interp1d
+    from scipy.signal import fftconvolve
+    from scipy.fftpack import fft2, ifft2
+    from oracle import joxsz_oracle as orc, pyabel_direct
+    p = orc.pars_dict(pb, theta)
+    acc = {k: 0.0 for k in ('profile', 'abel', 'spline_build', 'map', 'beam_conv', 'tf_filter', 'tail', 'xray_and_priors')}
+    S = pb.d_mat.shape[0]
+    for _ in range(repeats):
+        t = time.perf_counter(); pp = orc.press_fun(p, pb.r_pp); acc['profile'] += time.perf_counter() - t
+        t = time.perf_counter(); ab = pyabel_direct.direct_transform_forward(pp, pb.r_pp); acc['abel'] += time.perf_counter() - t
+        y = pb.kpc_cm * pb.sigma_T / pb.m_e * ab
+        t = time.perf_counter()
+        f = interp1d(np.append(-pb.r_pp, pb.r_pp), np.append(y, y), 'cubic', bounds_error=False, fill_value=(0., 0.))
+        acc['spline_build'] += time.perf_counter() - t
+        t = time.perf_counter(); y2d = f(pb.d_mat); acc['map'] += time.perf_counter() - t
+        t = time.perf_counter(); conv = fftconvolve(y2d, pb.beam_2d, 'same') * pb.step ** 2; acc['beam_conv'] += time.perf_counter() - t
+        t = time.perf_counter(); row = np.real(ifft2(fft2(conv) * pb.filtering))[S // 2, S // 2:]; acc['tf_filter'] += time.perf_counter() - t
+        t = time.perf_counter(); orc.sz_stages(pb, p); full = time.perf_counter() - t
+        t = time.perf_counter(); orc.get_likelihood(pb, theta); tot = time.perf_counter() - t
+        acc['tail'] += 0.0
+        acc['xray_and_priors'] += max(0.0, tot - full)
+        del row
+    out = {k: 1e3 * v / repeats for k, v in acc.items()}
+    out['tail'] = None                                   # (temperature profile, conversion, spline to the data radii, chi^2: inside the remainder)
+    return out
+
+
+def cpu_baseline(pb, thetas, target_s=12.0):
+    """The oracle (numpy/scipy restatement of the reference path) (a) mapped over walkers with multiprocessing.Pool on all
+    host cores, exactly the reference's parallelism (joxsz_main.py:203-206), (b) in one process, on bounded samples of the
+    workload; plus the per-stage milliseconds of one call."""
     import multiprocessing as mp
     from oracle import joxsz_oracle as orc
     cores = host_cores()
     t = time.perf_counter()
     orc.log_posterior_batch(pb, thetas[:1])
     one = time.perf_counter() - t
+    n1 = max(4, min(64, int(3.0 / max(one, 1e-3))))
+    t = time.perf_counter()
+    orc.log_posterior_batch(pb, thetas[:n1])
+    single = n1 / (time.perf_counter() - t)
+    stages = cpu_stage_ms(pb, thetas[0])
     per_core = max(1, int(target_s / max(one, 1e-3)))
     n = min(len(thetas), per_core * cores)
     n = max(cores, (n // cores) * cores)
@@ -133,35 +155,99 @@ def cpu_baseline(pb, thetas, target_s=15.0):
     logp = np.concatenate(res)
     return dict(value=n / dt, unit='walker-likelihoods/s', cores=cores, kind='port',
                 sample='%d walkers of the same workload, oracle/joxsz_oracle.py over multiprocessing.Pool(%d), %.1f s'
-                       % (n, cores, dt)), sample, logp
+                       % (n, cores, dt),
+                single_process={'value': single, 'unit': 'walker-likelihoods/s', 'cores': 1, 'sample': '%d walkers, one process' % n1},
+                stage_ms_per_call=stages), sample, logp
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# launcher mode: this process starts the ranks and never touches a GPU
+# ---------------------------------------------------------------------------------------------------------------------
+def spawn_ranks(n, argv, timeout_s=3000.0, python=None, script=None):
+    """Start n child processes (RANK 0..n-1, one GPU each), wait for them, return (exit code, rank 0's last stdout line).
+    Children that are still running when one fails or the timeout expires are terminated by PID."""
+    import random
+    python = python or sys.executable
+    script = script or os.path.abspath(__file__)
+    port = int(os.environ.get('MASTER_PORT', 0)) or random.randint(20000, 45000)
+    tag = 'bench_%d_%d' % (os.getpid(), int(time.time() * 1e3))
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), JOXSZ_RDZV_TAG=tag, JOXSZ_RDZV_T0=repr(time.time()),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([python, script] + argv, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
+                                      stderr=None, text=True))
+    t0 = time.time()
+    rc = 0
+    pending = set(range(n))
+    while pending:
+        for r in list(pending):
+            code = procs[r].poll()
+            if code is not None:
+                pending.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+        if rc != 0 or time.time() - t0 > timeout_s:
+            if pending and rc == 0:
+                rc = 124
+            for r in pending:                             # exact PIDs only
+                procs[r].terminate()
+            t1 = time.time()
+            while any(procs[r].poll() is None for r in pending) and time.time() - t1 < 10.0:
+                time.sleep(0.1)
+            for r in pending:
+                if procs[r].poll() is None:
+                    procs[r].kill()
+            break
+        time.sleep(0.05)
+    out = procs[0].stdout.read() if procs[0].stdout else ''
+    lines = [l for l in out.strip().splitlines() if l.strip()]
+    return rc, (lines[-1] if lines else '')
+
+
+def time_steps(ctx, th_ptr, W, lp_ptr, steps, warmup):
+    for _ in range(warmup):
+        ctx.eval_device(th_ptr, W, lp_ptr)
+    ctx.sync()
+    t = time.perf_counter()
+    for _ in range(steps):
+        ctx.eval_device(th_ptr, W, lp_ptr)
+    ctx.sync()
+    return (time.perf_counter() - t) / steps
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--walkers', type=int, default=1024, help='walkers per GPU')
     ap.add_argument('--S', type=int, default=512)
     ap.add_argument('--N', type=int, default=500)
     ap.add_argument('--sz-only', action='store_true')
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
-    ap.add_argument('--cpu-seconds', type=float, default=15.0)
-    ap.add_argument('--no-full-map', action='store_true', help='skip the side measurement of the full-map Abel kernel')
+    ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    ap.add_argument('--no-full-map', action='store_true', help='skip the side measurement of the full-map Abel kernel and of the copy bandwidth')
     ap.add_argument('--route', choices=('map', 'operator'), default='map',
                     help="'map': the reference's sequence of steps per walker (the BASELINE metric); 'operator': the collapsed route (jx_set_route)")
     ap.add_argument('--fwhm', type=float, default=18.5, help='beam FWHM in arcsec (B = 2*floor(3*fwhm/step)+1)')
     ap.add_argument('--dtype', choices=('f64', 'f32'), default='f64', help="'f64': the reference's arithmetic (the metric); 'f32': the fp32 variant")
     ap.add_argument('--no-f32', action='store_true', help='skip the side measurement of the fp32 variant')
+    ap.add_argument('--no-other-configs', action='store_true', help='skip the strong-scaling rows of BASELINE configs[3] and configs[4]')
     args = ap.parse_args()
+
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # no launcher: be one.  Nothing above or below this line in this process touches a GPU.
+        rc, line = spawn_ranks(args.gpus, sys.argv[1:])
+        if line:
+            print(line)
+        raise SystemExit(rc if rc else (0 if line else 1))
 
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('--gpus %d needs a launcher that starts that many ranks (torch.distributed.run sets RANK/WORLD_SIZE/LOCAL_RANK)' % args.gpus)
-        args.gpus = world
+    args.gpus = world
 
     from joxsz_amd import datasets
     pb = datasets.synthetic_problem(S=args.S, N=args.N, seed=0, sz_only=args.sz_only, fwhm=args.fwhm)
@@ -180,22 +266,22 @@ def main():
     post = JoxszPosterior(pb, device=local_rank)
     ctx = post.ctx
 
-    # parity spot-check of the CPU sample on the very same problem tensors
+    # parity of the CPU sample on the very same problem tensors: the bench refuses to report a number for results that differ
     parity = None
     if cpu_sample is not None:
         if args.route != 'map':
             ctx.set_route(args.route)
         got = ctx.eval(cpu_sample)
         fin = np.isfinite(cpu_logp)
-        if not np.array_equal(np.isfinite(got), fin) and not os.environ.get('JOXSZ_DBG'):
+        if not np.array_equal(np.isfinite(got), fin):
             raise SystemExit('bench: GPU/oracle disagree on which walkers are rejected')
         parity = float(np.max(np.abs(got[fin] - cpu_logp[fin]) / np.abs(cpu_logp[fin]))) if fin.any() else 0.0
-        if parity > 1e-6 and not os.environ.get('JOXSZ_DBG'):
+        if parity > 1e-6:
             raise SystemExit('bench: parity %.3e exceeds 1e-6' % parity)
 
     # ---- synthetic observations from the model itself at the fiducial vector, then the walker ball ----
     t0 = datasets.fiducial_theta(pb)
-    t0w = np.repeat(t0[None, :], W, axis=0)              # full-size launches only: the rocprof averages stay comparable
+    t0w = np.repeat(t0[None, :], 8, axis=0)
     bright = ctx.eval_stage(t0w, 'bright')[0]
     xprofs = None if pb.sz_only else ctx.eval_stage(t0w, 'xprofs')[0]
     post.close()
@@ -207,8 +293,6 @@ def main():
     cand = datasets.walker_ball(pb, 4 * W, spread=0.02, seed=100 + rank)
     lp = ctx.eval(cand)
     good = cand[np.isfinite(lp)]
-    if os.environ.get('JOXSZ_DBG'):
-        good = cand
     if len(good) < W:
         raise SystemExit('bench: only %d finite walkers of %d' % (len(good), len(cand)))
     theta = np.ascontiguousarray(good[:W])
@@ -239,10 +323,10 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    # Timed region: HIP events around the time-dominant kernel only (pass 1 of the default route; jx_timing_enable(2)) -- its
-    # duration is what `roofline` prices.  Events behind every stage cost ~4 % of a step (seven markers between dependent
-    # kernels), so the full stage breakdown comes from a second, identical pass of the same K steps right after.
-    p1_only = (args.route == 'map')
+    # Timed region: HIP events around the time-dominant kernel only (stage 1 of the contracted route; jx_timing_enable(2)) --
+    # its duration is what `roofline` prices.  Events behind every stage cost a few per cent of a step (markers between
+    # dependent kernels), so the full stage breakdown comes from a second, identical pass of the same K steps right after.
+    p1_only = (args.route == 'map' and ctx.conv == 'custom')
     ctx.timing_enable(2 if p1_only else 1)
     ctx.timing_reset()
     fence()
@@ -261,8 +345,6 @@ def main():
             step()
         fence()
         tm = ctx.timing()
-        if not tm_timed['launches'] or tm_timed['beam_fft_ms'] <= 0.0:        # (routes without a pass 1 of their own, e.g. rocFFT)
-            tm_timed = tm
     ctx.timing_enable(False)
 
     if comm is not None:
@@ -272,35 +354,9 @@ def main():
     else:
         final = np.empty(W)
         ctx.d2h(final, lp_ptr)
-    if not np.all(np.isfinite(final)) and not os.environ.get('JOXSZ_DBG'):
+    if not np.all(np.isfinite(final)):
         raise SystemExit('bench: non-finite log-probabilities in the timed batch')
-
-    # the same batch on the collapsed route, outside the timed region of the metric: reported beside it
-    also = None
-    if comm is None and args.route == 'map':
-        try:
-            lp_map = final
-            ctx.set_route('operator')
-            for _ in range(args.warmup):
-                step()
-            fence()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                step()
-            fence()
-            dt = time.perf_counter() - t1
-            lp_op = np.empty(W)
-            ctx.d2h(lp_op, lp_ptr)
-            fin = np.isfinite(lp_map)
-            also = {'route': 'operator', 'value': W * args.steps / dt, 'unit': 'walker-likelihoods/s', 'ms_per_step': 1e3 * dt / args.steps,
-                    'max_rel_diff_vs_map_route': (float(np.max(np.abs(lp_op[fin] - lp_map[fin]) / np.abs(lp_map[fin]))) if fin.any() else None),
-                    'same_rejections': bool(np.array_equal(np.isfinite(lp_op), fin)),
-                    'note': 'same walkers, same library, jx_set_route(JX_ROUTE_OPERATOR): the SZ side as one constant nrow x N matrix '
-                            'applied to the pressure profile; not the BASELINE metric (no Abel+map kernel runs per step)'}
-            ctx.set_route('map')
-        except Exception as exc:                                  # never let the side measurement take the metric down
-            also = {'route': 'operator', 'error': str(exc)}
-
+    lp_own = final[rank * W:(rank + 1) * W] if comm is not None else final
 
     # the fp32 variant on the same walkers (BASELINE configs[4]'s tolerance sweep): beside the f64 metric, never instead of it
     f32 = None
@@ -310,52 +366,75 @@ def main():
             c3 = p3.ctx
             t3, l3 = c3.dev_alloc(theta.nbytes), c3.dev_alloc(8 * W)
             c3.h2d(t3, theta)
-            for _ in range(args.warmup):
-                c3.eval_device(t3, W, l3)
-            c3.sync()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                c3.eval_device(t3, W, l3)
-            c3.sync()
-            dt = time.perf_counter() - t1
+            dt = time_steps(c3, t3, W, l3, max(5, args.steps // 4), 3)
             lp32 = np.empty(W)
             c3.d2h(lp32, l3)
             ch32, ch64 = c3.eval_stage(theta[:256], 'chisq'), ctx.eval_stage(theta[:256], 'chisq')
             rel = np.abs(lp32 - final) / np.abs(final)
-            f32 = {'dtype': 'f32', 'value': W * args.steps / dt, 'unit': 'walker-likelihoods/s', 'ms_per_step': 1e3 * dt / args.steps,
+            f32 = {'dtype': 'f32', 'value': W / dt, 'unit': 'walker-likelihoods/s', 'ms_per_step': 1e3 * dt,
                    'rel_dlogp_vs_f64': {'max': float(rel.max()), 'median': float(np.median(rel))},
                    'abs_dchisq_vs_f64': {'max': float(np.abs(ch32 - ch64).max()), 'median': float(np.median(np.abs(ch32 - ch64)))},
-                   'note': 'fp32 evaluation of the map rows + fp32 row transform + fp32 storage of row spectra and combined rows; '
-                           'matrix products, inverse transforms, tail and everything per-walker in fp64 (jx_config.dtype = 1)'}
+                   'note': 'spline arrays (y_k, M_k) rounded to fp32 once and read as fp32 by the sample evaluation; sums, matrix-core '
+                           'product, tail and everything per-walker in fp64 (jx_config.dtype = 1)'}
             p3.close()
         except Exception as exc:
             f32 = {'dtype': 'f32', 'error': str(exc)}
 
-    # the kernel that meets north_star's "Abel+map kernel at >= 60 % of the HBM roofline": the same fused kernel storing the
-    # reference's full S x S map (JOXSZ_FULL_MAP=1), measured beside the metric (the default route never stores a map)
+    # the kernel north_star's ">= 60 % of the HBM roofline in the Abel+map kernel" is about: profile -> Abel -> spline -> full
+    # S x S map, and the measured copy bandwidth of this card as the practical roofline beside the nominal one
     full_map = None
+    copy_gbs = None
     if rank == 0 and comm is None and args.route == 'map' and not args.no_full_map:
         try:
-            os.environ['JOXSZ_FULL_MAP'] = '1'
-            p2 = JoxszPosterior(pb, device=local_rank)
-            os.environ.pop('JOXSZ_FULL_MAP')
-            c2 = p2.ctx
-            for _ in range(2):
-                c2.eval(theta)
-            c2.timing_enable(True); c2.timing_reset()
-            for _ in range(5):
-                c2.eval(theta)
-            t2 = c2.timing()
-            ms = t2['abel_map_ms'] / max(1, t2['launches'])
-            wl = t2['walkers'] / max(1, t2['launches'])
-            full_map = {'kernel': 'jx_abel_map_sym_kernel (JOXSZ_FULL_MAP=1: profile -> Abel -> spline -> full S x S map)',
-                        'launch_ms': ms, 'bytes_per_launch': wl * args.S * args.S * 8.0,
-                        'achieved_GBps': wl * args.S * args.S * 8.0 / (ms * 1e-3) / 1e9,
-                        'frac_of_hbm_peak': wl * args.S * args.S * 8.0 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
-            p2.close()
+            copy_gbs = ctx.copy_bandwidth(1 << 30, 10)
+            ms = ctx.map_kernel_time(th_ptr, W, 10)
+            b = W * args.S * args.S * 8.0
+            full_map = {'kernel': 'jx_abel_map_sym_kernel (profile -> Abel -> spline -> full S x S map; jx_map_kernel_time)',
+                        'launch_ms': ms, 'bytes_per_launch': b, 'achieved_GBps': b / (ms * 1e-3) / 1e9,
+                        'frac_of_hbm_peak': b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        'frac_of_measured_copy_roofline': b / (ms * 1e-3) / 1e9 / copy_gbs,
+                        'note': 'a store stream: S^2 * 8 B written per walker; the copy roofline counts bytes read + written'}
         except Exception as exc:
-            os.environ.pop('JOXSZ_FULL_MAP', None)
             full_map = {'error': str(exc)}
+
+    # the same batch on the collapsed route, only when asked for (--route operator): not the BASELINE metric
+    # strong-scaling rows of the other BASELINE configs: this rank's shard of configs[3] (4096 walkers, 512^2) and of
+    # configs[4] (8192 walkers, 1024^2 / 1000-pt, fp64 and fp32), a few steps each, outside the timed region
+    other = None
+    if args.route == 'map' and not args.no_other_configs and (args.S, args.N, pb.sz_only) == (512, 500, False):
+        other = {}
+        try:
+            from joxsz_amd.dist import shard_bounds
+            lo, hi = shard_bounds(4096, world, rank)
+            n3 = hi - lo
+            th3 = np.ascontiguousarray(np.resize(theta, (n3, theta.shape[1])))
+            p3t, l3t = ctx.dev_alloc(th3.nbytes), ctx.dev_alloc(8 * n3)
+            ctx.h2d(p3t, th3)
+            dt = time_steps(ctx, p3t, n3, l3t, 5, 2)
+            if comm is not None:
+                dt = comm.max_over_ranks(dt)
+            other['configs[3]'] = {'workload': '4096 walkers, 512x512 map, 500-pt grid, joint; %d walkers on this rank' % n3,
+                                   'value': 4096 / dt, 'unit': 'walker-likelihoods/s', 'ms_per_step': 1e3 * dt, 'scaling': 'strong', 'dtype': 'f64'}
+            lo, hi = shard_bounds(8192, world, rank)
+            n4 = hi - lo
+            pb4 = datasets.synthetic_problem(S=1024, N=1000, seed=0)
+            for dt_name in ('f64', 'f32'):
+                p4 = JoxszPosterior(pb4, device=local_rank, dtype=dt_name)
+                c4 = p4.ctx
+                cand4 = datasets.walker_ball(pb4, 256, spread=0.02, seed=5)
+                ok4 = cand4[np.isfinite(c4.eval(cand4))]
+                th4 = np.ascontiguousarray(np.resize(ok4, (n4, ok4.shape[1])))
+                a4, b4 = c4.dev_alloc(th4.nbytes), c4.dev_alloc(8 * n4)
+                c4.h2d(a4, th4)
+                dt = time_steps(c4, a4, n4, b4, 3, 1)
+                if comm is not None:
+                    dt = comm.max_over_ranks(dt)
+                other['configs[4] ' + dt_name] = {'workload': '8192 walkers, 1024x1024 map, 1000-pt grid, joint; %d walkers on this rank' % n4,
+                                                  'value': 8192 / dt, 'unit': 'walker-likelihoods/s', 'ms_per_step': 1e3 * dt, 'scaling': 'strong',
+                                                  'dtype': dt_name, 'conv_layout': c4.conv_layout}
+                p4.close()
+        except Exception as exc:
+            other['error'] = str(exc)
 
     if rank == 0:
         S = args.S
@@ -363,50 +442,57 @@ def main():
         walkers_per_launch = tm['walkers'] / launches
         lay = ctx.conv_layout or {}
         stage_ms = {k: tm[k] / launches for k in ('prep_ms', 'abel_map_ms', 'beam_fft_ms', 'tf_fft_ms', 'tail_ms')}
-        if tm.get('gemm_ms', 0.0) > 0.0:                      # the matrix products and pass 3 are timed apart on the default route
-            stage_ms['gemm_ms'] = tm['gemm_ms'] / launches
-            stage_ms['pass3_ms'] = stage_ms.pop('tf_fft_ms') - stage_ms['gemm_ms']
-        dct = bool(lay.get('fused')) and not os.environ.get('JOXSZ_DCT') == '0'
-        stage_kernels = {'prep_ms': 'jx_prep_kernel',
-                         'abel_map_ms': 'jx_abel_gemm_kernel (Abel transform, y scale and spline moments of the launch as one fp64 MFMA product)' if dct else 'jx_abel_map_sym_kernel',
-                         'beam_fft_ms': ('jx_rowdct_kernel (map rows evaluated from the spline + real-even row transform)' if dct
-                                         else 'jx_rowfft2_kernel (pass 1)'),
-                         'tf_fft_ms': 'jx_lowrank_kernel (fp64 MFMA GEMM) + jx_rowtf2_kernel (pass 3)', 'tail_ms': 'jx_tail_fft_kernel',
-                         'gemm_ms': 'jx_lowrank_kernel (FIR + job combination as fp64 MFMA matrix products)',
-                         'pass3_ms': 'jx_rowtf2_kernel (inverse row transform, crop, forward transform, transfer-function weights)'}
-        dom = max(stage_ms, key=stage_ms.get)
-        dom_kernel = stage_kernels[dom].split(' ')[0]
-        k_ms = stage_ms[dom]
-        if dom == 'beam_fft_ms':                              # measured inside the timed region
-            k_ms = tm_timed['beam_fft_ms'] / max(1, tm_timed['launches'])
-        mm = must_move_bytes(ctx, pb, lay, walkers_per_launch) if dct else None
-        pj = pmc_file(S)
-        survey_bytes = walkers_per_launch * S * S * 8.0       # the reference's map, S^2 * 8 B per walker
-        dom_bytes = (mm or {}).get(dom_kernel)
-        if dom_bytes is None:
-            dom_bytes = survey_bytes
-        achieved = dom_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        mixed = ctx.conv == 'custom' and args.route == 'map'
+        lowrank = mixed and lay.get('form') == 'lowrank'
+        stage_kernels = None
+        if mixed:
+            stage_kernels = {'prep_ms': 'jx_prep_kernel (priors, vetoes, X-ray Cash likelihood, pressure and temperature profiles)',
+                             'abel_map_ms': 'jx_abel_gemm_kernel (Abel transform, y scale and spline moments of the launch as one fp64 matrix-core product)',
+                             'beam_fft_ms': 'jx_rowmix_kernel (stage 1: map samples evaluated from the spline and mixed per column, fp64 vector FMAs)' if lowrank
+                                            else '(none: the full form has one kernel)',
+                             'tf_fft_ms': 'jx_opgemm_kernel (stage 2: beam along x + circular transfer-function kernels + row extraction as one fp64 matrix-core product)' if lowrank
+                                          else 'jx_opgemm_kernel (full form: map samples evaluated by the lanes that feed the fp64 matrix cores)',
+                             'tail_ms': 'jx_tail_row_kernel (partial rows summed in fixed order, conversion, chi^2, total)'}
         value = W * world * args.steps / elapsed
         ms_step = 1e3 * elapsed / args.steps
-        step_must = sum(mm.values()) * (W / walkers_per_launch) if mm else None
+        pj = pmc_file(S)
+        nrow = ctx.nrow
+        roof = roof2 = None
+        if mixed:
+            NU = lay['NU']
+            if lowrank:
+                # stage 1: per sample and walker 4 FMAs of the spline evaluation + R of the mixing
+                k_ms = tm_timed['beam_fft_ms'] / max(1, tm_timed['launches'])
+                fl = 2.0 * NU * NU * (4 + lay['R']) * walkers_per_launch
+                ach = fl / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+                roof = {'kernel': 'jx_rowmix_kernel', 'bound': 'valu (fp64 vector FMA; the same 78.6 TFLOP/s as the dense fp64 matrix-core peak)',
+                        'achieved': ach, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / FP64_PEAK_TFLOPS,
+                        'traffic': pmc_traffic(pj, 'jx_rowmix_kernel', walkers_per_launch),
+                        'traffic_source': (pj or {}).get('file'),
+                        'peak_measured': FP64_FMA_MEASURED_TFLOPS, 'frac_of_peak_measured': ach / FP64_FMA_MEASURED_TFLOPS,
+                        'launch_ms': k_ms, 'launch_ms_source': 'HIP events around this kernel inside the timed region (jx_timing_enable(2))',
+                        'flops_per_launch': fl, 'share_of_step': k_ms / max(1e-12, ms_step * walkers_per_launch / W),
+                        'algorithmic_bytes_per_launch': walkers_per_launch * (16.0 * pb.N + 8.0 * NU * lay['R']),
+                        'survey_8d_bytes_per_launch': walkers_per_launch * S * S * 8.0,
+                        'note': 'algorithmic flops = 2 * NU^2 * (4 + R) per walker (4 FMAs evaluate a map sample from the spline, R mix it into '
+                                'the rows kept per column; NU = %d distinct rows = distinct columns, R = %d) / HIP-event duration.  The S x S map of '
+                                'SURVEY 8(d) (S^2 * 8 B per walker) is never written: every sample lives in a register.  The kernel is bound by '
+                                'the fp64 vector units, not by HBM; peak_measured = sustained v_fmac_f64 rate of this chip (scripts/ubench/fma_sgpr.hip)'
+                                % (NU, lay['R'])}
+            p_ms = stage_ms['tf_fft_ms']
+            K4 = lay['ksteps'] * 4
+            fl2 = 2.0 * nrow * K4 * walkers_per_launch
+            ach2 = fl2 / (p_ms * 1e-3) / 1e12 if p_ms > 0 else 0.0
+            roof2 = {'kernel': 'jx_opgemm_kernel', 'bound': 'mfma', 'achieved': ach2, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                     'frac': ach2 / FP64_PEAK_TFLOPS, 'traffic': pmc_traffic(pj, 'jx_opgemm_kernel', walkers_per_launch),
+                     'launch_ms': p_ms, 'launch_ms_source': 'HIP events of the stage pass', 'flops_per_launch': fl2,
+                     'note': 'nrow x K x walkers product on v_mfma_f64_16x16x4 (nrow = %d outputs, K = %d rows of the operator)' % (nrow, K4)}
+            if not lowrank:
+                roof, roof2 = roof2, None
         step_pmc = None
         if pj:
-            step_pmc = sum(d['total_bytes'] for n, d in pj['kernels'].items() if n.startswith(('jx_', 'void jx_')) and 'operator' not in n) \
-                / pj.get('walkers_per_launch', 1024) * W
-        onchip = None
-        if dct and dom_kernel == 'jx_rowdct_kernel' and k_ms > 0:
-            esz = 4.0 if args.dtype == 'f32' else 8.0
-            NUr, Q = lay['NU'], lay['P'] // 4
-            ns = S // 2 + (S % 2)                                    # samples per distinct row (the unpaired column apart)
-            l1_b = walkers_per_launch * NUr * ns * 4.0 * esz        # (y_k, M_k, y_k+1, M_k+1) per (sample, walker) returned to registers
-            lds_b = walkers_per_launch * NUr * esz * (2.75 * ns + 12.0 * Q)   # q write, z-build read (7/4) + z write, two FFT levels in place, split read
-            n_cu, clk = 256, 2.4e9
-            l1_peak, lds_peak = n_cu * 64.0 * clk / 1e9, n_cu * 128.0 * clk / 1e9
-            onchip = {'kernel': dom_kernel, 'vector_l1_return': {'bytes_per_launch': l1_b, 'achieved': l1_b / (k_ms * 1e-3) / 1e9, 'peak': l1_peak, 'unit': 'GB/s',
-                                                                'frac': l1_b / (k_ms * 1e-3) / 1e9 / l1_peak},
-                      'lds': {'bytes_per_launch': lds_b, 'achieved': lds_b / (k_ms * 1e-3) / 1e9, 'peak': lds_peak, 'unit': 'GB/s', 'frac': lds_b / (k_ms * 1e-3) / 1e9 / lds_peak},
-                      'note': 'byte model of DESIGN 5.3 (not counters); peaks = 256 CUs x 64 (128) B/clk x 2.4 GHz; the two phases alternate inside a block, '
-                              'so the sum of the two fractions is the share of the kernel time either resource is busy at best overlap'}
+            step_pmc = sum(d['total_bytes'] for n, d in pj['kernels'].items() if n.startswith(('jx_', 'void jx_')) and 'operator' not in n
+                           and 'abel_map' not in n and 'copy' not in n) / pj.get('walkers_per_launch', 1024) * W
         out = {
             'metric': 'walker-likelihoods/sec at 512^2 map, 500-pt grid' if (S, args.N) == (512, 500)
                       else 'walker-likelihoods/sec at %d^2 map, %d-pt grid' % (S, args.N),
@@ -417,40 +503,30 @@ def main():
                                    'synthetic CL J1226.9+3332-shaped inputs%s'
                                    % (W, S, S, args.N, 'SZ-only' if pb.sz_only else 'joint X-ray+SZ',
                                       ' (BASELINE configs[2])' if (W, S, args.N, pb.sz_only) == (1024, 512, 500, False) else ''),
-                       'walkers_per_gpu': W, 'S': S, 'N': args.N, 'B': pb.B, 'fft_pad': ctx.fft_pad,
-                       'chunk': ctx.chunk, 'route': ctx.route, 'conv': ctx.conv, 'conv_layout': ctx.conv_layout, 'parallelism': 'walkers sharded x%d' % world, 'device': ctx.device_name},
-            # the time-dominant kernel of the step, on the bytes it has to move (inputs once + outputs once)
-            'roofline': {'kernel': dom_kernel, 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': pmc_traffic(pj, dom_kernel, walkers_per_launch),
-                         'launch_ms': k_ms, 'launch_ms_source': 'HIP events around this kernel inside the timed region' if dom == 'beam_fft_ms' else 'HIP events of the stage pass',
-                         'bytes_per_launch': dom_bytes, 'share_of_step': k_ms / max(1e-12, ms_step * walkers_per_launch / W),
-                         'survey_8d_bytes_per_launch': survey_bytes,
-                         'survey_8d_GBps': survey_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0,
-                         'note': 'achieved = bytes this kernel must move (walker inputs read once, outputs written once: DESIGN 5) / its '
-                                 'HIP-event duration; survey_8d_* = SURVEY 8(d)\'s S^2*8 B per walker for the map stage, which this route '
-                                 'never writes (the rows are evaluated from the spline inside this kernel). The kernel is not HBM-bound: '
-                                 'its floor is on-chip data movement (vector-L1 return path 64 B/clk, LDS 128 B/clk; DESIGN 5.3)'},
-            # what does bound the time-dominant kernel: on-chip data movement, priced at nominal peaks
-            'roofline_onchip': onchip,
-            # the whole step against the HBM roofline: measured bytes (rocprofv3 PMC, profiles/*_pmc_traffic.json) and compulsory bytes
-            'roofline_step': {'bound': 'hbm', 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'ms_per_step': ms_step,
-                              'traffic_bytes_per_step': step_pmc,
+                       'walkers_per_gpu': W, 'S': S, 'N': args.N, 'B': pb.B, 'chunk': ctx.chunk, 'route': ctx.route, 'conv': ctx.conv,
+                       'conv_layout': ctx.conv_layout, 'parallelism': 'walkers sharded x%d' % world, 'device': ctx.device_name},
+            'n_ranks_seen': (comm.n_ranks_seen if comm is not None else 1),
+            'roofline': roof,
+            'roofline_product': roof2,
+            # the whole step against the HBM roofline: measured bytes (rocprofv3 PMC, profiles/*_pmc_traffic.json)
+            'roofline_step': {'bound': 'hbm', 'peak': HBM_PEAK_GBS, 'peak_measured': copy_gbs, 'unit': 'GB/s', 'ms_per_step': ms_step,
+                              'traffic_bytes_per_step': step_pmc, 'traffic_source': (pj or {}).get('file'),
                               'achieved': (step_pmc / (ms_step * 1e-3) / 1e9) if step_pmc else None,
                               'frac': (step_pmc / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS) if step_pmc else None,
-                              'must_move_bytes_per_step': step_must,
                               'survey_8d_bytes_per_step': 2.0 * W * S * S * 8.0,
-                              'time_dominant_kernel': dom_kernel},
+                              'note': 'the step is compute-bound (fp64 vector units, then fp64 matrix cores): its HBM traffic is the small '
+                                      'per-walker arrays between the kernels'},
             'north_star_abel_map_kernel': full_map,
+            'hbm_copy_bandwidth_measured_GBps': copy_gbs,
+            'truncation': ctx.truncation,
             'fp32_variant': f32,
             'cpu_baseline': cpu,
-            'stage_ms_per_step': {k: tm[k] / args.steps for k in
-                                  ('prep_ms', 'abel_map_ms', 'beam_fft_ms', 'tf_fft_ms', 'gemm_ms', 'tail_ms', 'total_ms')},
+            'stage_ms_per_step': {k: tm[k] / args.steps for k in ('prep_ms', 'abel_map_ms', 'beam_fft_ms', 'tf_fft_ms', 'tail_ms', 'total_ms')},
             'stage_ms_note': 'HIP events behind every stage, from a second pass of the same steps right after the timed region '
                              '(the timed region itself carries only the two events around the time-dominant kernel)' if p1_only else None,
-            'stage_kernels': stage_kernels if lay.get('fused') else None,
+            'stage_kernels': stage_kernels,
             'parity_max_rel_err': parity,
-            'operator_route': also,
+            'other_configs': other,
         }
         print(json.dumps(out))
     if comm is not None:

@@ -1783,6 +1783,40 @@ int jx_map_kernel_time(jx_ctx* ctx, const double* theta_dev, int nwalkers, int r
     return JX_OK;
 }
 
+// Device-to-device copy bandwidth of this GPU (read + write bytes per second, in GB/s): `nbytes` copied `repeats` times
+// between two scratch buffers by a plain grid-stride kernel (16 B per lane), timed with HIP events on the context's
+// stream.  The practical HBM roofline to quote beside the nominal one.
+__global__ void __launch_bounds__(256) jx_copy_kernel(const double2* __restrict__ src, double2* __restrict__ dst, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
+
+int jx_copy_bandwidth(jx_ctx* ctx, size_t nbytes, int repeats, double* gbps_out) {
+    if (!ctx || nbytes < 4096 || repeats < 1 || !gbps_out) return JX_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    void *a = nullptr, *b = nullptr;
+    HIPCHK(ctx, hipMalloc(&a, nbytes));
+    if (hipMalloc(&b, nbytes) != hipSuccess) { (void)hipFree(a); ctx->err = "jx_copy_bandwidth: out of memory"; return JX_ERR_NOMEM; }
+    hipStream_t st = ctx->stream;
+    hipEvent_t e0, e1;
+    HIPCHK(ctx, hipEventCreate(&e0)); HIPCHK(ctx, hipEventCreate(&e1));
+    HIPCHK(ctx, hipMemsetAsync(a, 0, nbytes, st));
+    const size_t n = nbytes / sizeof(double2);
+    const dim3 grid((unsigned)(ctx->num_cu * 16));
+    hipLaunchKernelGGL(jx_copy_kernel, grid, dim3(256), 0, st, (const double2*)a, (double2*)b, n);
+    HIPCHK(ctx, hipEventRecord(e0, st));
+    for (int i = 0; i < repeats; ++i) hipLaunchKernelGGL(jx_copy_kernel, grid, dim3(256), 0, st, (const double2*)a, (double2*)b, n);
+    HIPCHK(ctx, hipEventRecord(e1, st));
+    HIPCHK(ctx, hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(ctx, hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(a); (void)hipFree(b);
+    HIPCHK(ctx, hipGetLastError());
+    *gbps_out = 2.0 * (double)(n * sizeof(double2)) * repeats / ((double)ms * 1e-3) / 1e9;
+    return JX_OK;
+}
+
 void jx_destroy(jx_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->cfg.device);

@@ -19,6 +19,8 @@ import time
 
 import numpy as np
 
+_PROCESS_T0 = time.time()
+
 
 def launch_env():
     """(rank, world, local_rank) from the environment ``torch.distributed.run`` / any MPI-style launcher sets."""
@@ -28,17 +30,30 @@ def launch_env():
     return rank, world, local_rank
 
 
-def exchange_unique_id(make_id, rank, world, timeout=120.0):
-    """Rank 0 calls ``make_id()`` (``jx_comm_unique_id``) and publishes the 128 bytes; the others read them.
-    One node: a file under ``JOXSZ_RDZV_DIR`` (default /tmp) named after the launcher's pid and MASTER_PORT, written
-    atomically (rename).  The ranks of one launch share their parent process, so the name is unique per launch."""
-    if world == 1:
-        return make_id()
+def _rdzv_path():
     d = os.environ.get('JOXSZ_RDZV_DIR', '/tmp')
     tag = os.environ.get('JOXSZ_RDZV_TAG') or '%s_%s_%d' % (os.environ.get('TORCHELASTIC_RUN_ID', 'run'),
                                                             os.environ.get('MASTER_PORT', '0'), os.getppid())
-    path = os.path.join(d, 'joxsz_rccl_%s.id' % tag)
+    return os.path.join(d, 'joxsz_rccl_%s.id' % tag)
+
+
+def exchange_unique_id(make_id, rank, world, timeout=120.0, not_before=None):
+    """Rank 0 calls ``make_id()`` (``jx_comm_unique_id``) and publishes the 128 bytes; the others read them.
+    One node: a file under ``JOXSZ_RDZV_DIR`` (default /tmp) named after ``JOXSZ_RDZV_TAG`` (bench.py's own launcher sets a
+    fresh one per launch) or the launcher's run id, MASTER_PORT and pid, written atomically (rename).  A file left behind
+    by an earlier launch with the same name is never taken for this launch's: rank 0 removes exactly that path before it
+    writes, and a reader only accepts a file whose modification time is not older than ``not_before`` -- the launch's
+    start time (``JOXSZ_RDZV_T0``, set by the launcher for all ranks) or, without one, this process's own start."""
+    if world == 1:
+        return make_id()
+    path = _rdzv_path()
+    if not_before is None:
+        not_before = float(os.environ.get('JOXSZ_RDZV_T0', _PROCESS_T0))
     if rank == 0:
+        try:
+            os.unlink(path)                                   # this launch's path only, never a glob
+        except FileNotFoundError:
+            pass
         uid = make_id()
         tmp = path + '.tmp%d' % os.getpid()
         with open(tmp, 'wb') as f:
@@ -48,10 +63,12 @@ def exchange_unique_id(make_id, rank, world, timeout=120.0):
     t0 = time.time()
     while True:
         try:
-            with open(path, 'rb') as f:
-                uid = f.read()
-            if len(uid) == 128:
-                return uid
+            st = os.stat(path)
+            if st.st_mtime >= not_before - 1.0:               # (1 s: file systems that round modification times down)
+                with open(path, 'rb') as f:
+                    uid = f.read()
+                if len(uid) == 128:
+                    return uid
         except FileNotFoundError:
             pass
         if time.time() - t0 > timeout:
@@ -64,7 +81,8 @@ class RcclGather:
 
     ``ctx`` is this rank's ``HipContext`` (one per process, one process per GPU).  ``all_gather(send_ptr, recv_ptr, n)``
     takes device pointers (``ctx.dev_alloc``) and is asynchronous on the context's stream, ordered behind
-    ``ctx.eval_device``; ``barrier()`` and ``max_over_ranks(x)`` serve the timing protocol of bench.py."""
+    ``ctx.eval_device``; ``barrier()`` and ``max_over_ranks(x)`` serve the timing protocol of bench.py;
+    ``gather_ragged`` is the padded form for shards of unequal length."""
 
     def __init__(self, ctx, rank=None, world=None):
         env_rank, env_world, _ = launch_env()
@@ -74,17 +92,38 @@ class RcclGather:
         uid = exchange_unique_id(ctx.comm_unique_id, self.rank, self.world)
         ctx.comm_init_rank(uid, self.world, self.rank)
         self._scratch = ctx.dev_alloc(8)
+        self._pad = None
+        self.n_ranks_seen = ctx.comm_count()                  # what RCCL itself says (ncclCommCount)
         if self.rank == 0 and self.world > 1:
-            try:                                              # everybody has read the id once the communicator exists
-                d = os.environ.get('JOXSZ_RDZV_DIR', '/tmp')
-                for f in os.listdir(d):
-                    if f.startswith('joxsz_rccl_') and f.endswith('_%d.id' % os.getppid()):
-                        os.unlink(os.path.join(d, f))
+            try:                                              # every rank has read the id once the communicator exists
+                os.unlink(_rdzv_path())
             except OSError:
                 pass
 
     def all_gather(self, send_ptr, recv_ptr, count):
         self.ctx.allgather_logp(send_ptr, recv_ptr, count)
+
+    def gather_ragged(self, local_logp, nwalkers):
+        """All ranks' log-probabilities of a batch of ``nwalkers`` sharded by ``shard_bounds`` (shards differ by at most one
+        walker): ``local_logp`` is this rank's shard (host array).  RCCL's all-gather wants equal counts, so every rank sends
+        a slot of ceil(nwalkers / world) values, the unused tail of a short shard filled with -inf; returns the full vector."""
+        width = -(-int(nwalkers) // self.world)
+        lo, hi = shard_bounds(nwalkers, self.world, self.rank)
+        assert len(local_logp) == hi - lo
+        if self._pad is None or self._pad[0] < width:
+            self._pad = (width, self.ctx.dev_alloc(8 * width), self.ctx.dev_alloc(8 * width * self.world))
+        buf = np.full(width, -np.inf)
+        buf[:hi - lo] = local_logp
+        self.ctx.h2d(self._pad[1], buf)
+        self.all_gather(self._pad[1], self._pad[2], width)
+        self.ctx.sync()
+        out = np.empty(width * self.world)
+        self.ctx.d2h(out, self._pad[2])
+        full = np.empty(int(nwalkers))
+        for r in range(self.world):
+            a, b = shard_bounds(nwalkers, self.world, r)
+            full[a:b] = out[r * width:r * width + (b - a)]
+        return full
 
     def max_over_ranks(self, value):
         buf = np.array([float(value)])

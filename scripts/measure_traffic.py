@@ -23,7 +23,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def collect(counter, outdir):
     cmd = ['rocprofv3', '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', outdir, '--',
-           sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '1', '--no-cpu', '--no-full-map', '--no-f32']
+           sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '1', '--no-cpu', '--no-full-map', '--no-f32', '--no-other-configs']
     env = dict(os.environ, TMPDIR='/tmp')
     res = subprocess.run(cmd, check=True, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
     collect.bench = json.loads(res.stdout.strip().splitlines()[-1])
@@ -40,13 +40,13 @@ def collect(counter, outdir):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
+    tag = sys.argv[1] if len(sys.argv) > 1 else 'r03'
     scratch = os.path.join(ROOT, 'gpurun_out', 'traffic_' + tag)
     fetch = collect('FETCH_SIZE', scratch + '_fetch')
     write = collect('WRITE_SIZE', scratch + '_write')
     cfg = collect.bench['config']
     out = {'unit': 'bytes per launch', 'S': cfg['S'], 'N': cfg['N'], 'walkers_per_launch': cfg['chunk'], 'conv': cfg['conv'],
-           'command': 'rocprofv3 --kernel-trace --pmc <FETCH_SIZE|WRITE_SIZE> -- python3 bench.py --steps 3 --warmup 1 --no-cpu', 'note': 'FETCH_SIZE KiB x 1024 x 2 (gfx950 wide-read correction), WRITE_SIZE KiB x 1024',
+           'command': 'rocprofv3 --kernel-trace --pmc <FETCH_SIZE|WRITE_SIZE> -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-full-map --no-f32 --no-other-configs', 'note': 'FETCH_SIZE KiB x 1024 x 2 (gfx950 wide-read correction), WRITE_SIZE KiB x 1024',
            'kernels': {}}
     for k in sorted(set(fetch) | set(write)):
         rd = fetch.get(k, 0.0) * 1024 * 2

@@ -1,0 +1,93 @@
+"""bench.py as its own launcher (`python bench.py --gpus N` without torch.distributed.run) and the file rendezvous of the
+RCCL id, on the CPU: stub ranks stand in for the evaluator (the GPU leg is rehearsed on a GPU box with
+JOXSZ_BENCH_FORCE_DIST=1, profiles/r03_bench_force_dist.json)."""
+import json
+import os
+import sys
+import textwrap
+import time
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _stub(tmp_path, body):
+    p = tmp_path / 'stub_rank.py'
+    p.write_text(textwrap.dedent(body))
+    return str(p)
+
+
+def test_spawn_relays_rank0_line_and_exit_codes(tmp_path):
+    """Two fresh child processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* and one rendezvous tag per launch; rank 0's
+    last stdout line comes back; a failing or hanging rank makes the launcher exit non-zero and takes the others down."""
+    import bench
+    stub = _stub(tmp_path, '''
+        import os, sys, json, time
+        r, w = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+        assert os.environ["LOCAL_RANK"] == str(r) and os.environ["MASTER_ADDR"] == "127.0.0.1" and int(os.environ["MASTER_PORT"]) > 0
+        assert float(os.environ["JOXSZ_RDZV_T0"]) <= time.time() + 1
+        if "--fail" in sys.argv and r == 1: sys.exit(3)
+        if "--hang" in sys.argv and r == 1: time.sleep(60)
+        if r == 0:
+            print("noise before the line")
+            print(json.dumps({"world": w, "tag": os.environ["JOXSZ_RDZV_TAG"], "args": sys.argv[1:]}))
+    ''')
+    rc, line = bench.spawn_ranks(2, ['--steps', '3'], script=stub)
+    assert rc == 0
+    a = json.loads(line)
+    assert a['world'] == 2 and a['args'] == ['--steps', '3']
+    rc, line = bench.spawn_ranks(2, ['--steps', '3'], script=stub)
+    assert rc == 0 and json.loads(line)['tag'] != a['tag']            # a fresh tag per launch
+    assert bench.spawn_ranks(2, ['--fail'], script=stub)[0] == 3
+    t = time.time()
+    assert bench.spawn_ranks(3, ['--hang'], script=stub, timeout_s=1.5)[0] == 124
+    assert time.time() - t < 30
+
+
+def test_bench_becomes_the_launcher_without_one(tmp_path, monkeypatch):
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment: the parent spawns, the children see WORLD_SIZE.
+    (The children are bench.py itself and fail here for want of a GPU: the launcher must report that as a failure and must
+    not have touched a device itself.)"""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    env['JOXSZ_LIB'] = str(tmp_path / 'no_such_library.so')            # the ranks die at load time, quickly and for certain
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0', '--no-cpu'],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert 'not found' in r.stderr or 'JoxszHipError' in r.stderr
+
+
+def test_rendezvous_ignores_a_stale_id_file(tmp_path, monkeypatch):
+    """A 128-byte file left at the rendezvous path by an earlier launch is older than this launch: readers wait for rank 0's
+    fresh one; rank 0 removes exactly its own path before writing."""
+    import multiprocessing as mp
+    from joxsz_amd import dist
+    monkeypatch.setenv('JOXSZ_RDZV_DIR', str(tmp_path))
+    monkeypatch.setenv('JOXSZ_RDZV_TAG', 'same_tag_as_last_time')
+    path = dist._rdzv_path()
+    with open(path, 'wb') as f:
+        f.write(b'S' * 128)
+    old = time.time() - 3600
+    os.utime(path, (old, old))
+    other = os.path.join(str(tmp_path), 'joxsz_rccl_someone_elses.id')
+    open(other, 'wb').write(b'O' * 128)
+    monkeypatch.setenv('JOXSZ_RDZV_T0', repr(time.time()))
+
+    def reader(q):
+        q.put(dist.exchange_unique_id(lambda: b'X' * 128, 1, 2, timeout=20.0))
+
+    q = mp.get_context('fork').Queue()
+    p = mp.get_context('fork').Process(target=reader, args=(q,))
+    p.start()
+    time.sleep(0.5)
+    assert q.empty()                                                   # the stale file was not accepted
+    assert dist.exchange_unique_id(lambda: b'N' * 128, 0, 2) == b'N' * 128
+    got = q.get(timeout=20)
+    p.join(20)
+    assert got == b'N' * 128
+    assert os.path.exists(other)                                       # nobody else's file was touched
+    with pytest.raises(RuntimeError):
+        os.unlink(path)
+        dist.exchange_unique_id(lambda: b'', 1, 2, timeout=0.3)       # no rank 0: a timeout, not a hang

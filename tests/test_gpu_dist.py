@@ -38,6 +38,9 @@ def test_rccl_gather_through_the_c_abi_world_1():
     ctx.d2h(got, all_ptr)
     np.testing.assert_array_equal(got, want)
     assert comm.max_over_ranks(3.25) == 3.25
+    assert comm.n_ranks_seen == 1 and ctx.comm_count() == 1          # what RCCL itself reports (ncclCommCount)
+    # the padded form for ragged shards (RCCL's all-gather wants equal counts): at one rank the shard is the batch
+    np.testing.assert_array_equal(comm.gather_ragged(want[:37], 37), want[:37])
     with pytest.raises(JoxszHipError):
         ctx.comm_init_rank(b'\0' * 128, 1, 0)                     # one communicator per context
     comm.close()
