@@ -98,6 +98,23 @@ jx_rowmix_kernel(JxMix m, const TC* __restrict__ cft, double* __restrict__ Dt) {
     const int* __restrict__ sc = m.seg + (size_t)xq * m.segld;                 // [segld], zero padded to a multiple of NS
     const double* __restrict__ wp = m.w4 + (size_t)xq * m.wld * 4;
     const double* __restrict__ cp = m.Cm;                                      // rows of RT doubles
+    // The column's weights and sample counts reach the wave through the scalar cache, which has no prefetch: the first touch of
+    // a 64-byte line there is a wave-blocking wait all the way to memory (a column's streams are read by this block and the
+    // other walker quads' blocks, on other XCDs, and by nobody before them).  One vector load with a lane per line pulls 4 KiB
+    // of a stream into this XCD's L2 long before the scalar loads come for it; the loaded words are not used.  (3 % of the
+    // kernel's time at 512^2; the rest of its scalar-side stall is the scalar cache's own latency, see DESIGN.md.)
+    int pf[5] = {0, 0, 0, 0, 0};
+    {
+        const char* wb = reinterpret_cast<const char*>(wp);
+        const int wbytes = m.wld * 32, sbytes = m.segld * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int o = lane * 64 + k * 4096;
+            if (o < wbytes) pf[k] = *reinterpret_cast<const int*>(wb + o);
+        }
+        for (int o = lane * 64 + 4 * 4096; o < wbytes; o += 4096) pf[4] |= *reinterpret_cast<const int*>(wb + o);
+        if (lane * 64 < sbytes) pf[4] |= *reinterpret_cast<const int*>(reinterpret_cast<const char*>(sc) + lane * 64);
+    }
     double acc[RT];
 #pragma unroll
     for (int j = 0; j < RT; ++j) acc[j] = 0.0;
@@ -131,6 +148,7 @@ jx_rowmix_kernel(JxMix m, const TC* __restrict__ cft, double* __restrict__ Dt) {
             }
         }
     }
+    if (m.n < 0 && (pf[0] | pf[1] | pf[2] | pf[3] | pf[4]) == 0x5a5a1234) Dt[0] = 0.0;   // (never: keeps the prefetch loads alive)
     double* __restrict__ dp = Dt + (size_t)xq * m.R * tW + w;
 #pragma unroll
     for (int r = 0; r < RT; ++r)

@@ -8,12 +8,17 @@
 #include <vector>
 #define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
-template <int R, int MODE>
+//   NW: accumulator sets per lane that share each constant (jx_rowmix_kernel's walker sets per lane)
+template <int R, int MODE, int NW>
 __global__ void __launch_bounds__(256) k(const double* __restrict__ C, double* __restrict__ out, int steps, int rows, double seed) {
-    double acc[R];
+    double acc[NW][R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = seed + r;
-    double f = seed * 0.001 + threadIdx.x * 1e-6;
+    for (int w = 0; w < NW; ++w)
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[w][r] = seed + r + w;
+    double f[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) f[w] = seed * 0.001 + threadIdx.x * 1e-6 + w;
     const double* cp = C + (size_t)(blockIdx.x % 7) * R;
     const double* cend = C + (size_t)rows * R;
     double c0[R];
@@ -22,30 +27,35 @@ __global__ void __launch_bounds__(256) k(const double* __restrict__ C, double* _
         for (int r = 0; r < R; ++r) c0[r] = cp[r];
     }
     for (int s = 0; s < steps; ++s) {
-        f = fma(f, 0.999, 1e-9);
 #pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = fma(MODE == 0 ? c0[r] : cp[r], f, acc[r]);
+        for (int w = 0; w < NW; ++w) f[w] = fma(f[w], 0.999, 1e-9);
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int w = 0; w < NW; ++w) acc[w][r] = fma(MODE == 0 ? c0[r] : cp[r], f[w], acc[w][r]);
         if (MODE == 2) { cp += R; if (cp >= cend) cp = C; }
     }
     double t = 0;
 #pragma unroll
-    for (int r = 0; r < R; ++r) t += acc[r];
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += acc[w][r];
     out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = t;
 }
 
-template <int R, int MODE>
+template <int R, int MODE, int NW = 1>
 int run(const char* name, const double* C, double* out, int wps, int rows) {
     const int steps = 2000, blocks = 256 * wps, threads = 256;        // wps blocks per CU = wps waves per SIMD
     hipEvent_t e0, e1;
     CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
-    hipLaunchKernelGGL((k<R, MODE>), dim3(blocks), dim3(threads), 0, 0, C, out, 10, rows, 1.5);
+    hipLaunchKernelGGL((k<R, MODE, NW>), dim3(blocks), dim3(threads), 0, 0, C, out, 10, rows, 1.5);
     CHK(hipEventRecord(e0));
-    hipLaunchKernelGGL((k<R, MODE>), dim3(blocks), dim3(threads), 0, 0, C, out, steps, rows, 1.5);
+    hipLaunchKernelGGL((k<R, MODE, NW>), dim3(blocks), dim3(threads), 0, 0, C, out, steps, rows, 1.5);
     CHK(hipEventRecord(e1));
     CHK(hipEventSynchronize(e1));
     float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
-    const double fma = (double)blocks * threads * steps * (R + 1);
-    printf("%-34s R=%2d %d waves/SIMD: %7.3f ms  %6.2f T FMA/s  (%.0f%% of 39.3)\n", name, R, wps, ms, fma / ms * 1e-9, fma / ms * 1e-9 / 39.3 * 100);
+    const double fma = (double)blocks * threads * steps * (R + 1) * NW;
+    printf("%-34s R=%2d NW=%d %d waves/SIMD: %7.3f ms  %6.2f T FMA/s  (%.0f%% of 39.3)\n", name, R, NW, wps, ms, fma / ms * 1e-9, fma / ms * 1e-9 / 39.3 * 100);
     return 0;
 }
 
@@ -62,6 +72,12 @@ int main() {
         run<20, 2>("streamed (160 B per step)", C, out, wps, rows);
         run<8, 2>("streamed (64 B per step)", C, out, wps, rows);
         run<32, 2>("streamed (256 B per step)", C, out, wps, rows);
+        if (wps <= 4) {
+            run<20, 0, 2>("constants in registers", C, out, wps, rows);
+            run<20, 1, 2>("re-loaded each step, same address", C, out, wps, rows);
+            run<20, 2, 2>("streamed (160 B per step)", C, out, wps, rows);
+        }
+        if (wps <= 2) run<20, 2, 3>("streamed (160 B per step)", C, out, wps, rows);
     }
     return 0;
 }
