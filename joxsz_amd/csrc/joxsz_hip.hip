@@ -610,7 +610,8 @@ static int launch_mix(jx_ctx* ctx, int n, EvSet* es) {
         og.ksplit = ksplit; og.kper = kper;
         m.last_ksplit = ksplit;                                   // (the tail sums this many partials)
         const int nunit = ksplit * og.nog;
-        const dim3 g2((unsigned)(8 * nwb * ((nunit + 7) / 8)));
+        og.kmajor = ksplit >= 8 ? 1 : 0;
+        const dim3 g2((unsigned)(og.kmajor ? 8 * nwb * og.nog * ((ksplit + 7) / 8) : 8 * nwb * ((nunit + 7) / 8)));
         const size_t lds = m.form == 1 ? (size_t)JX_OPG_ECH * 4 * sizeof(JxSamp) : 0;
         bool done = false;
 #define JX_OPG_GO(Xv) if (!done && m.nxt == Xv) { \
@@ -1175,12 +1176,17 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
         MixBack& m = ctx->mix;
         if (ctx->f32 && (want_abel_taps || t.need_img)) { ctx->err = "dtype f32: the profile and map taps exist in the f64 build of the context only"; return JX_ERR_UNSUPPORTED; }
         if (ag) {
-            const dim3 grid((n + 31) / 32, (ctx->tm_npair + 3) / 4);
+            // 32 walkers per block, or 16 when that would leave SIMDs without a wave (a walker's sums do not depend on it)
+            const int gy = (ctx->tm_npair + 3) / 4;
+            const bool narrow = (size_t)((n + 31) / 32) * gy * 4 < 1024;
+            const dim3 grid(narrow ? (n + 15) / 16 : (n + 31) / 32, gy);
             const double* pp_src = ctx->d.inject_pp ? ctx->d.inject_pp : ctx->d_ppc;
-            if (ctx->f32) hipLaunchKernelGGL((jx_abel_gemm_kernel<1, float, 1>), grid, dim3(256), sizeof(double) * JX_OPM_JC * 33, st, pp_src, n, d.N, ctx->d_Tm, ctx->tm_ld,
-                                             d.K, ctx->tm_ntile, ctx->tm_npair, reinterpret_cast<float*>(m.cft), m.tW, (long long)m.ncol);
-            else hipLaunchKernelGGL((jx_abel_gemm_kernel<1, double, 1>), grid, dim3(256), sizeof(double) * JX_OPM_JC * 33, st, pp_src, n, d.N, ctx->d_Tm, ctx->tm_ld,
-                                    d.K, ctx->tm_ntile, ctx->tm_npair, m.cft, m.tW, (long long)m.ncol);
+            const size_t shg = sizeof(double) * JX_OPM_JC * 33;
+#define JX_AG_GO(TOv, NWTv) hipLaunchKernelGGL((jx_abel_gemm_kernel<1, TOv, 1, NWTv>), grid, dim3(256), shg, st, pp_src, n, d.N, ctx->d_Tm, ctx->tm_ld, \
+                                               d.K, ctx->tm_ntile, ctx->tm_npair, reinterpret_cast<TOv*>(m.cft), m.tW, (long long)m.ncol)
+            if (ctx->f32) { if (narrow) JX_AG_GO(float, 1); else JX_AG_GO(float, 2); }
+            else { if (narrow) JX_AG_GO(double, 1); else JX_AG_GO(double, 2); }
+#undef JX_AG_GO
         } else {
             // phases 1-3 of the Abel kernel (profile, Abel integral, Compton y, spline moments): taps out, arrays walker-minor
             JxDev dm = ctx->d;

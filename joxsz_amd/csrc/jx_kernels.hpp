@@ -224,9 +224,11 @@ __device__ __forceinline__ void jx_interp_clamped2(const double* xp, const doubl
     *o1 = (f1[hi] - f1[lo]) / dx * t + f1[lo];
 }
 
-__device__ __forceinline__ double jx_block_sum(double v, double* red /*[>=4]*/) {
+// (nw: the waves that take part, the first nw of the block; every one of them must call -- two block barriers inside)
+__device__ __forceinline__ double jx_block_sum(double v, double* red /*[>=nw]*/, int nw = 0) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (nw <= 0) nw = blockDim.x >> 6;
     __syncthreads();
     if (lane == 0) red[wv] = v;
     __syncthreads();
@@ -264,7 +266,7 @@ __device__ __forceinline__ void jx_load_params(const JxDev& c, const double* __r
 //   cfac  [W, nrow]  convert([h(0), t_prof]) * calibration   (joxsz_funcs.py:473)
 //   optional taps: tprof [W,nrow], xprofs [W,nband,nann], parts [W,4]
 // ------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(JX_PREP_THREADS)
+__global__ void __launch_bounds__(JX_PREP_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
                double* __restrict__ base, double* __restrict__ cfac, double* __restrict__ pp_out /*[chunk][N] or null*/,
                double* __restrict__ sz0 /*[chunk] integrated-Compton term of the SZ log-likelihood, or null*/,
@@ -1424,7 +1426,9 @@ jx_operator_mfma_kernel(const double* __restrict__ pp /*[launch][N]*/, int n, in
 #define JX_AG_ROWS(N) ((((N) + 4 * JX_AG_R - 1) / (4 * JX_AG_R) + 1) * (4 * JX_AG_R))
 // TR = 1: the result goes out walker-minor for the contracted route (jx_mix.hpp): cf[(k * cf_ws + w) * 2 + {0: y_k, 1: M_k}],
 // cf_ws = walker stride; columns >= ncol are not stored.
-template <int NPW, typename TO = double, int TR = 0>
+// NWT = 16-walker tiles per block (2, or 1 for launches too small to give every SIMD a wave otherwise: a walker's sums are
+// the same either way).
+template <int NPW, typename TO = double, int TR = 0, int NWT = 2>
 __global__ void __launch_bounds__(256)
 jx_abel_gemm_kernel(const double* __restrict__ pp /*[launch][N]*/, int n, int N, const double* __restrict__ Tm /*[JX_AG_ROWS(N)][ldt], zero rows behind N-1*/,
                     int ldt, int K, int ntile, int npair, TO* __restrict__ cf /*[launch][cf_ws]; float for the fp32 variant (rounded once, on store)*/, long long cf_ws,
@@ -1433,7 +1437,7 @@ jx_abel_gemm_kernel(const double* __restrict__ pp /*[launch][N]*/, int n, int N,
     constexpr int NTL = 2 * NPW;
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wb = blockIdx.x * 32, grp = blockIdx.y;
+    const int wb = blockIdx.x * 16 * NWT, grp = blockIdx.y;
     const int ktot4 = (N + 4 * JX_AG_R - 1) / (4 * JX_AG_R) * JX_AG_R;          // k-steps, in whole groups of JX_AG_R
     int tile[NTL], ks[NTL], toff[NTL];
 #pragma unroll
@@ -1447,9 +1451,11 @@ jx_abel_gemm_kernel(const double* __restrict__ pp /*[launch][N]*/, int n, int N,
             toff[2 * i + h] = min(t, ntile - 1) * 16;
         }
     }
-    jx_op_v4d acc[NTL][2];
+    jx_op_v4d acc[NTL][NWT];
 #pragma unroll
-    for (int t = 0; t < NTL; ++t) { acc[t][0] = jx_op_v4d{0.0, 0.0, 0.0, 0.0}; acc[t][1] = jx_op_v4d{0.0, 0.0, 0.0, 0.0}; }
+    for (int t = 0; t < NTL; ++t)
+#pragma unroll
+        for (int nt = 0; nt < NWT; ++nt) acc[t][nt] = jx_op_v4d{0.0, 0.0, 0.0, 0.0};
     // the block's first chunk of radii: the first row of its lowest tile
     const int kminb = max(0, 8 * (grp * 4 * NPW) - K) >> 2;
     const int j00 = (4 * kminb / JX_OPM_JC) * JX_OPM_JC;
@@ -1465,7 +1471,7 @@ jx_abel_gemm_kernel(const double* __restrict__ pp /*[launch][N]*/, int n, int N,
 #pragma unroll
         for (int t = 0; t < NTL; ++t) a[u][t] = gb[(size_t)(4 * max(kg + u, ks[t])) * ldt + toff[t]];
     // the profiles of the next chunk wait in registers while this chunk is multiplied
-    constexpr int NST = 32 * JX_OPM_JC / 256;
+    constexpr int NST = 16 * NWT * JX_OPM_JC / 256;
     const int sl = tid / JX_OPM_JC, sj = tid % JX_OPM_JC;                       // consecutive threads: consecutive radii of one walker
     double stg[NST];
     auto fetch = [&](int j0) {
@@ -1484,16 +1490,21 @@ jx_abel_gemm_kernel(const double* __restrict__ pp /*[launch][N]*/, int n, int N,
         if (j0 + JX_OPM_JC < N) fetch(j0 + JX_OPM_JC);
         const int kgroups = (min(JX_OPM_JC, N - j0) + 4 * R - 1) / (4 * R);
         for (int sg = 0; sg < kgroups; ++sg, kg += R) {
+            // the group's profile fragments leave the LDS together (one wait per R k-steps, not one in front of every product)
+            double pv[R][NWT];
+#pragma unroll
+            for (int u = 0; u < R; ++u)
+#pragma unroll
+                for (int nt = 0; nt < NWT; ++nt) pv[u][nt] = sm[(4 * (R * sg + u) + lk) * 33 + nt * 16 + li];
 #pragma unroll
             for (int u = 0; u < R; ++u) {
 #pragma unroll
                 for (int t = 0; t < NTL; ++t) a[(u + R - 1) % R][t] = gb[(size_t)(4 * max(kg + u + R - 1, ks[t])) * ldt + toff[t]];
-                const double p0 = sm[(4 * (R * sg + u) + lk) * 33 + li], p1 = sm[(4 * (R * sg + u) + lk) * 33 + 16 + li];
 #pragma unroll
                 for (int t = 0; t < NTL; ++t) {
                     if (kg + u >= ks[t]) {
-                        acc[t][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(p0, a[u][t], acc[t][0], 0, 0, 0);
-                        acc[t][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(p1, a[u][t], acc[t][1], 0, 0, 0);
+#pragma unroll
+                        for (int nt = 0; nt < NWT; ++nt) acc[t][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(pv[u][nt], a[u][t], acc[t][nt], 0, 0, 0);
                     }
                 }
             }
@@ -1504,7 +1515,7 @@ jx_abel_gemm_kernel(const double* __restrict__ pp /*[launch][N]*/, int n, int N,
         const long long col = (long long)tile[t] * 16 + li;
         if (ks[t] >= ktot4 || col >= (TR ? ncol : cf_ws)) continue;
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
+        for (int nt = 0; nt < NWT; ++nt) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int w = wb + nt * 16 + lk + 4 * g;

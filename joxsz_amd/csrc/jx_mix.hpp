@@ -163,13 +163,14 @@ jx_rowmix_kernel(JxMix m, const TC* __restrict__ cft, double* __restrict__ Dt) {
 //   B operand (N = outputs): Op[x][kappa], stored so that a lane's NXT tiles are contiguous: Opk[step][l >> 4][l & 15][tile]
 //   D: register g of lane l = out[walker (l >> 4) + 4 g][x = l & 15]: a walker's row comes out in 128-byte runs
 // Block = 4 waves = 128 walkers (2 tiles per wave) x NXT output tiles x one K slice; operands are fetched RD k-steps ahead
-// into named register slots.  Blocks that share a K slice and an output group share an XCD (Op is read from HBM once).
+// into named register slots.  Blocks that share a K slice share an XCD (the slice of Dt and of Op reach one L2 only).
 // ------------------------------------------------------------------------------------------------------------------
 struct JxSamp { long long off; double a, b, c, d; long long pad; };      // off = knot * tW (elements of cft)
 
 struct JxOpg {
     int n; long long tW;
     int ksplit, kper;              // K slices, k-steps per slice (multiple of the prefetch depth)
+    int kmajor;                    // block -> unit mapping: 1 = XCD x works on the K slices x, x + 8, ... (8 or more slices), 0 = units dealt round
     int ntile, nog;                // output tiles in all (multiple of NXT), output groups = ntile / NXT
     int ldx;                       // doubles per partial row (>= 16 ntile)
     long long pstride;             // doubles between the partial rows of two K slices (>= tW ldx)
@@ -178,7 +179,9 @@ struct JxOpg {
     const JxSamp* ent;             // EVAL: [4 (ksplit kper + slack)]
 };
 
+#ifndef JX_OPG_RD
 #define JX_OPG_RD 2
+#endif
 #define JX_OPG_ECH 256             // EVAL: k-steps of entries staged in LDS at a time (256 x 4 x 48 B = 48 KB)
 
 template <int MODE /*0 LOAD, 1 EVAL*/, int NXT, typename TC>
@@ -190,9 +193,17 @@ jx_opgemm_kernel(JxOpg g, const TC* __restrict__ cft, double* __restrict__ Pt) {
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nwb = (g.n + 127) >> 7, nunit = g.ksplit * g.nog;
     const int id = blockIdx.x, xcd = id & 7, jj = id >> 3;
-    const int wb = jj % nwb, unit = (jj / nwb) * 8 + xcd;
-    if (unit >= nunit) return;
-    const int ks = unit / g.nog, og = unit - ks * g.nog;
+    const int wb = jj % nwb;
+    int ks, og;
+    if (g.kmajor) {                                  // an XCD owns whole K slices: the slice of Dt is fetched into one L2 only
+        const int lu = jj / nwb;
+        og = lu % g.nog; ks = (lu / g.nog) * 8 + xcd;
+        if (ks >= g.ksplit) return;
+    } else {
+        const int unit = (jj / nwb) * 8 + xcd;
+        if (unit >= nunit) return;
+        ks = unit / g.nog; og = unit - ks * g.nog;
+    }
     const size_t tW = (size_t)g.tW;
     const size_t wbase = (size_t)wb * 128 + wv * 32 + li;
     const int s0 = ks * g.kper, s1 = s0 + g.kper;

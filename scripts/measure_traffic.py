@@ -23,7 +23,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def collect(counter, outdir):
     cmd = ['rocprofv3', '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', outdir, '--',
-           sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '1', '--no-cpu', '--no-full-map', '--no-f32', '--no-other-configs']
+           sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '1', '--no-cpu', '--no-f32', '--no-other-configs']
     env = dict(os.environ, TMPDIR='/tmp')
     res = subprocess.run(cmd, check=True, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
     collect.bench = json.loads(res.stdout.strip().splitlines()[-1])
@@ -46,7 +46,7 @@ def main():
     write = collect('WRITE_SIZE', scratch + '_write')
     cfg = collect.bench['config']
     out = {'unit': 'bytes per launch', 'S': cfg['S'], 'N': cfg['N'], 'walkers_per_launch': cfg['chunk'], 'conv': cfg['conv'],
-           'command': 'rocprofv3 --kernel-trace --pmc <FETCH_SIZE|WRITE_SIZE> -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-full-map --no-f32 --no-other-configs', 'note': 'FETCH_SIZE KiB x 1024 x 2 (gfx950 wide-read correction), WRITE_SIZE KiB x 1024',
+           'command': 'rocprofv3 --kernel-trace --pmc <FETCH_SIZE|WRITE_SIZE> -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-f32 --no-other-configs', 'note': 'FETCH_SIZE KiB x 1024 x 2 (gfx950 wide-read correction), WRITE_SIZE KiB x 1024',
            'kernels': {}}
     for k in sorted(set(fetch) | set(write)):
         rd = fetch.get(k, 0.0) * 1024 * 2
