@@ -253,7 +253,8 @@ int  jx_get_conv_layout(jx_ctx* ctx, int32_t out[12]);
  * (exact, independent kernels) at the probe points: the current parameter values and the corners of the prior box in the
  * thawed shape parameters of the pressure profile (a, b, r_p).  out = {singular-value cut in use; largest difference of the
  * extracted row at the current parameter values, relative to the row's largest entry; rank; number of times jx_finalize
- * found an estimate above its bound and rebuilt the tables -- in place -- with a cut ten times tighter; probe points that
+ * found an estimate above its bound and rebuilt the tables -- in place -- with a cut ten times tighter (a rebuild may end
+ * in the full form, where the growing rank has made it the cheaper one: rank 0, nothing truncated); probe points that
  * gave finite numbers; bound on out[1] (1e-9; JOXSZ_TRUNC_BOUND); the row difference over ALL probe points; largest
  * difference of the SZ log-likelihood over all probe points relative to max(1, |SZ log-likelihood|), bound 1e-8}.
  * -1 where nothing is truncated (full form, rocFFT) or nothing was measured (JOXSZ_TRUNC_PROBE=0, dtype f32); an explicit

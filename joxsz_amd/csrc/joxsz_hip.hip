@@ -477,9 +477,10 @@ static void plan_mix(jx_ctx* ctx, const std::vector<double>& beam, const std::ve
             if (!mb.RT) { lowrank_ok = false; why_lr = "rank of the separable form beyond the stage-1 kernel (" + std::to_string(mb.r) + " x " + std::to_string(mb.ns) + " terms)"; }
         }
     }
-    // cost of each form in fused multiply-adds per walker (stage 1 on the vector units; the matrix cores at about the same rate)
+    // cost of each form in fused multiply-adds per walker; stage 1 runs on the vector units at about 0.6 of the rate the
+    // matrix cores reach in the product kernels (measured: 256^2 with 32 terms 0.141 ms low-rank against 0.126 ms full; 257^2 0.155 against 0.132)
     const double nsamp = (double)NU * NU;
-    mb.cost_lowrank = (lowrank_ok && mb.RT) ? nsamp * (4.0 + mb.RT) + (double)nrow * NU * mb.R : 1e300;
+    mb.cost_lowrank = (lowrank_ok && mb.RT) ? 1.6 * nsamp * (4.0 + mb.RT) + (double)nrow * NU * mb.R : 1e300;
     mb.cost_full = (double)nrow * nsamp * 0.5 + nsamp * 6.0 * mb.nog;
     int form = (mb.cost_lowrank <= mb.cost_full) ? 0 : 1;
     if (form_force == 0) { if (!lowrank_ok || !mb.RT) { mb.why = "low-rank form: " + why_lr; return; } form = 0; }

@@ -211,35 +211,6 @@ def _mirrored_moments(lib, r, y):
     return G, G @ y
 
 
-def _quarter_transform_with_tables(q, LP, pk):
-    """The steps of jx_rowdct_kernel in numpy: z from groups of four samples, one complex FFT of length Q = LP/2, the
-    real-even split with the kernel's own constants pk = (cos/2, -sin/2, 1/(2 sin(2 pi k/P)), 1/(2 sin(2 pi (Q-k)/P)))."""
-    Q, P = LP // 2, 2 * LP
-    amax = len(q) - 1
-    xq = lambda n: q[abs(n)] if abs(n) <= amax else 0.0
-    z = np.zeros(Q, complex)
-    for g in range(Q // 2 + 1):
-        if g <= (Q - 1) // 2:
-            z[g] = (xq(4 * g) + xq(4 * g + 1) - xq(4 * g - 1)) + 1j * (xq(4 * g + 2) + xq(4 * g + 3) - xq(4 * g + 1))
-        if g >= 1 and Q - g > (Q - 1) // 2:
-            z[Q - g] = (xq(4 * g) - xq(4 * g + 1) + xq(4 * g - 1)) + 1j * (xq(4 * g - 2) - xq(4 * g - 1) + xq(4 * g - 3))
-    Z = np.fft.fft(z)
-    R = np.zeros(LP + 1)
-    b0 = 2.0 * q[1::2].sum()
-    for k in range(Q // 2 + 1):
-        zk, zq = Z[k], Z[0 if k == 0 else Q - k]
-        sx, sy, dx, dy = zk.real + zq.real, zk.imag - zq.imag, zk.real - zq.real, zk.imag + zq.imag
-        tx, ty = pk[k, 0] * dx - pk[k, 1] * dy, pk[k, 0] * dy + pk[k, 1] * dx
-        Ak, Aq, Ik, Iq = 0.5 * sx + ty, 0.5 * sx - ty, 0.5 * sy - tx, -0.5 * sy - tx
-        bk, bq = (b0 if k == 0 else pk[k, 2] * Ik), pk[k, 3] * Iq
-        R[k], R[LP - k] = Ak + bk, Ak - bk
-        if 2 * k != Q:
-            R[Q - k] = Aq + bq
-            if k > 0:
-                R[Q + k] = Aq - bq
-    return R
-
-
 @pytest.mark.parametrize('name', ['uniform', 'arange', 'ragged'])
 def test_abel_spline_operator(lib, name):
     """Tm of jx_abel_gemm_kernel: pp @ Tm gives (y_k, M_k) = (y_scale * PyAbel forward transform, moments of the mirrored
