@@ -1139,8 +1139,11 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
         JxDev dp = d;
         dp.inject_pp = ctx->d.inject_pp;
         const size_t sh = sizeof(double) * (JX_LDS_HDR + (size_t)2 * d.N + 2 * d.nann + (size_t)d.nband * d.nann + 8);
-        hipLaunchKernelGGL(jx_prep_kernel, dim3(n), dim3(JX_PREP_THREADS), sh, st, dp, theta_dev, w0,
-                           base_buf, cfac_buf, op_route ? ctx->d_pp : ((ag && !ctx->d.inject_pp) ? ctx->d_ppc : (double*)nullptr), sz0_buf, t.tprof, t.xprofs, t.parts, t.integ);
+        double* pp_buf = op_route ? ctx->d_pp : ((ag && !ctx->d.inject_pp) ? ctx->d_ppc : (double*)nullptr);
+        if (d.prep_pow) hipLaunchKernelGGL(jx_prep_kernel<true>, dim3(n), dim3(JX_PREP_THREADS), sh, st, dp, theta_dev, w0,
+                                           base_buf, cfac_buf, pp_buf, sz0_buf, t.tprof, t.xprofs, t.parts, t.integ);
+        else hipLaunchKernelGGL(jx_prep_kernel<false>, dim3(n), dim3(JX_PREP_THREADS), sh, st, dp, theta_dev, w0,
+                                base_buf, cfac_buf, pp_buf, sz0_buf, t.tprof, t.xprofs, t.parts, t.integ);
     }
     if (tm) HIPCHK(ctx, hipEventRecord(es.e[1], st));
     if (op_route) {

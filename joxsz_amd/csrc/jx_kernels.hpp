@@ -266,6 +266,9 @@ __device__ __forceinline__ void jx_load_params(const JxDev& c, const double* __r
 //   cfac  [W, nrow]  convert([h(0), t_prof]) * calibration   (joxsz_funcs.py:473)
 //   optional taps: tprof [W,nrow], xprofs [W,nband,nann], parts [W,4]
 // ------------------------------------------------------------------------------------
+// POW: the profiles with pow() as written in the reference (JOXSZ_PREP_POW=1) instead of through their exponents -- a
+// compile-time choice: the code of the form not taken would be a quarter of the kernel and its registers the kernel's.
+template <bool POW>
 __global__ void __launch_bounds__(JX_PREP_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
                double* __restrict__ base, double* __restrict__ cfac, double* __restrict__ pp_out /*[chunk][N] or null*/,
@@ -293,7 +296,7 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
     const double pk_ln = has_par ? c.par_lnorm[tid] : 0.0;
     jx_load_params(c, theta, gw, p);
     double pc[5] = {0, 1, 1, 0, 1};           // radius-independent factors of the density (every thread its own copy)
-    if (c.prep_pow) jx_ne_consts(p, c.ne_mode, pc);
+    if (POW) jx_ne_consts(p, c.ne_mode, pc);
 
     // ---- priors on every parameter (joxsz_funcs.py:518) ----
     double pr = 0.0;
@@ -314,7 +317,7 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
     if (!(fabs(parprior) <= 1.79769313486231570e308)) rej |= REJ_BOX;     // joxsz_funcs.py:519-520: a non-finite prior returns -inf at once
 
     // ---- model prior: r_c <= r_s (joxsz_funcs.py:397-407) ----
-    if (tid == 0 && (c.prep_pow ? (pow(10.0, p[P_LOGRC]) > pow(10.0, p[P_LOGRS])) : (p[P_LOGRC] > p[P_LOGRS]))) rej |= REJ_RCRS;   // 10^x is monotonic
+    if (tid == 0 && (POW ? (pow(10.0, p[P_LOGRC]) > pow(10.0, p[P_LOGRS])) : (p[P_LOGRC] > p[P_LOGRS]))) rej |= REJ_RCRS;   // 10^x is monotonic
 
     // ---- one pass over the radial grid: pressure (joxsz_funcs.py:275-287), the hydrostatic-mass profile of the
     //      monotonicity veto (joxsz_funcs.py:522-525, 428-437) and T_SZ on r_pp[:nt] (joxsz_funcs.py:469).  The pressure
@@ -322,7 +325,7 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
     const bool veto = c.exclude_unphy_mass != 0;
     const int nprof = (veto || pp_out || c.calc_integ) ? c.N : c.nt;
     double ci = 0.0;                          // this thread's share of integ_wp . pp
-    const bool logform = !c.prep_pow;
+    constexpr bool logform = !POW;
     double pl[10];
     jx_prof_consts(p, c.ne_mode, pl);
     const int N_ = c.N, nt_ = c.nt, mode_ = c.ne_mode;
