@@ -101,34 +101,8 @@ __device__ __forceinline__ double jx_press(const double* p, double r) {
     return p[P_P0] / (pow(x, p[P_C]) * pow(1.0 + pow(x, p[P_A]), (p[P_B] - p[P_C]) / p[P_A]));
 }
 
-// joxsz_funcs.py:289-301
-__device__ __forceinline__ double jx_press_deriv(const double* p, double r) {
-    const double x = r / p[P_RP];
-    const double xa = pow(x, p[P_A]);
-    return -p[P_P0] * (p[P_C] + p[P_B] * xa) /
-           (p[P_RP] * pow(x, p[P_C] + 1.0) * pow(1.0 + xa, (p[P_B] - p[P_C] + p[P_A]) / p[P_A]));
-}
-
-// joxsz_funcs.py:375-395
-__device__ __forceinline__ double jx_ne(const double* p, double r, int mode) {
-    const double n0 = pow(10.0, p[P_LOGN0]);
-    const double rc = pow(10.0, p[P_LOGRC]);
-    const double rs = pow(10.0, p[P_LOGRS]);
-    const double x = r / rc;
-    double res = n0 * n0 * pow(x, -p[P_ALPHA]) /
-                 (pow(1.0 + x * x, 3.0 * p[P_BETA] - p[P_ALPHA] / 2.0) *
-                  pow(1.0 + pow(r / rs, p[P_GAMMA]), p[P_EPS] / p[P_GAMMA]));
-    if (mode == 1) {
-        const double n02 = pow(10.0, p[P_LOGN02]);
-        const double rc2 = pow(10.0, p[P_LOGRC2]);
-        const double x2 = r / rc2;
-        res += n02 * n02 / pow(1.0 + x2 * x2, 3.0 * p[P_BETA2]);
-    }
-    return sqrt(res);
-}
-
-// the same density with its radius-independent factors (five pow() of parameters only) taken out of the per-radius
-// loops: pc = {n0^2, rc, rs, n02^2, rc2}
+// joxsz_funcs.py:375-395 (mydens_vikhFunction, single and double beta) with its radius-independent factors (five pow()
+// of parameters only) taken out of the per-radius loops: pc = {n0^2, rc, rs, n02^2, rc2}
 __device__ __forceinline__ void jx_ne_consts(const double* p, int mode, double* pc) {
     const double n0 = pow(10.0, p[P_LOGN0]);
     pc[0] = n0 * n0; pc[1] = pow(10.0, p[P_LOGRC]); pc[2] = pow(10.0, p[P_LOGRS]);
@@ -194,21 +168,8 @@ __device__ __forceinline__ double jx_convert(const JxDev& c, double T) {
     return slope * (T - c.conv_T[lo]) + c.conv_v[lo];
 }
 
-// np.interp(x, xp, fp): clamped linear interpolation
-__device__ __forceinline__ double jx_interp_clamped(const double* xp, const double* fp, int n, double x) {
-    if (x != x) return x;
-    if (x <= xp[0]) return fp[0];
-    if (x >= xp[n - 1]) return fp[n - 1];
-    int lo = 0, hi = n - 1;
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (xp[mid] <= x) lo = mid; else hi = mid;
-    }
-    const double slope = (fp[hi] - fp[lo]) / (xp[hi] - xp[lo]);
-    return slope * (x - xp[lo]) + fp[lo];
-}
-
-// the same for two tables on one grid: identical arithmetic per table, one interval search
+// np.interp(x, xp, fp) -- clamped linear interpolation -- for two tables on one grid: identical arithmetic per table, one
+// interval search
 __device__ __forceinline__ void jx_interp_clamped2(const double* xp, const double* f0, const double* f1, int n, double x,
                                                    double* o0, double* o1) {
     if (x != x) { *o0 = x; *o1 = x; return; }
