@@ -118,6 +118,7 @@ struct jx_ctx {
     int trunc_retried = 0, trunc_points = 0;
     bool tol_pinned = false;           // JOXSZ_LOWRANK_TOL given: the guard measures but never overrides
     int form_force = -1;               // JOXSZ_MIX_FORM: 0 low-rank, 1 full
+    int usplit = 2;                    // pieces a map column is walked in by stage 1 (JOXSZ_MIX_USPLIT: 1, 2 or 4; a setting, never a function of the launch)
 
     // batch staging for the host-pointer API
     double *d_theta = nullptr, *d_logp = nullptr;
@@ -463,7 +464,7 @@ static void plan_mix(jx_ctx* ctx, const std::vector<double>& beam, const std::ve
     if (!(maxim <= 1e-15 * maxre)) { mb.why = "transfer-function weights are not real"; return; }
     // ---- low-rank form: separable terms of the beam x singular terms of the weights
     std::vector<double> U, V, by, bx;
-    bool lowrank_ok = jxt::mix_column_tables(ctx->h_Qtab, ctx->qn, NU, r, mb.cols);
+    bool lowrank_ok = jxt::mix_column_tables(ctx->h_Qtab, ctx->qn, NU, r, mb.cols, ctx->usplit);
     std::string why_lr = lowrank_ok ? "" : "pixel radii do not grow along the columns of d_mat";
     if (lowrank_ok && form_force != 1) {
         mb.r = jxt::lowrank_factor_qr(A.data(), S, Sh, tol, U, V);
@@ -549,6 +550,8 @@ static int mix_setup(jx_ctx* ctx, const MixBuild& mb, long long tW) {
     if (mb.form == 0) {
         mx.NU = mb.NU; mx.R = mb.R; mx.tW = tW; mx.segld = mb.cols.segld; mx.wld = mb.cols.wld; mx.cld = mb.cld;
         mx.cft_bytes = (unsigned)(2 * esz * cft_rows * tW);
+        mx.usplit = mb.cols.usplit;
+        if ((rc = dev_put_l(ctx, m.allocs, mb.cols.urange.data(), mb.cols.urange.size(), &qi))) return rc; mx.urange = qi;
         if ((rc = dev_put_l(ctx, m.allocs, mb.cols.seg0.data(), mb.cols.seg0.size(), &qi))) return rc; mx.seg0 = qi;
         if ((rc = dev_put_l(ctx, m.allocs, mb.cols.nseg.data(), mb.cols.nseg.size(), &qi))) return rc; mx.nseg = qi;
         if ((rc = dev_put_l(ctx, m.allocs, mb.cols.seg.data(), mb.cols.seg.size(), &qi))) return rc; mx.seg = qi;
@@ -582,13 +585,16 @@ static int launch_mix(jx_ctx* ctx, int n, EvSet* es) {
     if (m.form == 0) {
         JxMix mx = m.mx;
         mx.n = n;
-        const int ngrp = (n + 63) / 64, wpb = std::min(m.wpb, ngrp), nq = (ngrp + wpb - 1) / wpb;
+        // block = gpb walker groups x usplit pieces of one column (usplit: a setting of the context, never of the launch)
+        const int usp = mx.usplit, ngrp = (n + 63) / 64, gpb = std::max(1, std::min(m.wpb / usp, ngrp)), wpb = gpb * usp;
+        const int nq = (ngrp + gpb - 1) / gpb;
         mx.cper = (nq <= 8 && 8 % nq == 0) ? 8 / nq : 0;
         const dim3 g1((unsigned)(mx.cper ? 8 * ((mx.NU + mx.cper - 1) / mx.cper) : nq * mx.NU));
+        const size_t lds1 = sizeof(double) * (size_t)gpb * (usp - 1) * m.RT * 64;
         bool done = false;
 #define JX_MIX_GO(Rv) if (!done && m.RT == Rv) { \
-            if (ctx->f32) hipLaunchKernelGGL((jx_rowmix_kernel<Rv, JX_MIX_NS, float2>), g1, dim3(64 * wpb), 0, st, mx, reinterpret_cast<const float2*>(m.cft), m.Dt); \
-            else hipLaunchKernelGGL((jx_rowmix_kernel<Rv, JX_MIX_NS, double2>), g1, dim3(64 * wpb), 0, st, mx, reinterpret_cast<const double2*>(m.cft), m.Dt); \
+            if (ctx->f32) hipLaunchKernelGGL((jx_rowmix_kernel<Rv, JX_MIX_NS, float2>), g1, dim3(64 * wpb), lds1, st, mx, reinterpret_cast<const float2*>(m.cft), m.Dt); \
+            else hipLaunchKernelGGL((jx_rowmix_kernel<Rv, JX_MIX_NS, double2>), g1, dim3(64 * wpb), lds1, st, mx, reinterpret_cast<const double2*>(m.cft), m.Dt); \
             done = true; }
         JX_MIX_RTS(JX_MIX_GO)
 #undef JX_MIX_GO
@@ -829,6 +835,7 @@ static int finalize_impl(jx_ctx* ctx) {
     if (const char* e = env_str("JOXSZ_LOWRANK_TOL")) { const double v2 = atof(e); if (v2 > 0.0 && v2 < 1e-6) { lr_tol0 = v2; ctx->tol_pinned = true; } }
     if (const char* e = env_str("JOXSZ_TRUNC_BOUND")) { const double v = atof(e); if (v > 0.0) { ctx->trunc_bound = v; ctx->trunc_bound_ll = std::min(ctx->trunc_bound_ll, 10.0 * v); } }
     if (const char* e = env_str("JOXSZ_MIX_FORM")) { if (!strcmp(e, "lowrank")) ctx->form_force = 0; else if (!strcmp(e, "full")) ctx->form_force = 1; }
+    if (const char* e = env_str("JOXSZ_MIX_USPLIT")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) ctx->usplit = v; }
     if (const char* e = env_str("JOXSZ_MIX_WPB")) { const int v = atoi(e); if (v >= 1 && v <= 4) ctx->mix.wpb = v; }
     if (const char* e = env_str("JOXSZ_MIX_KSPLIT")) { const int v = atoi(e); if (v >= 1) ctx->mix.ksplit_force = v; }
     if (const char* e = env_str("JOXSZ_ABEL_GEMM")) ctx->abel_gemm = atoi(e) != 0;

@@ -48,10 +48,12 @@ struct JxMix {
     unsigned cft_bytes;            // size of cft (buffer descriptor range)
     int segld, wld, cld;           // strides: segment counts per column, samples per column (>= NU), C row (>= RT)
     int dbg;                       // diagnostic build only (make ABLATIONS=1): timing experiments, results are wrong
-    int cper;                      // block -> (column, walker-group quad): XCDs per quad (8 / quads) when that divides, else 0
-    const int* seg0;               // [NU]  first knot interval of column x'
-    const int* nseg;               // [NU]  number of segments of column x'
-    const int* seg;                // [NU][segld] samples per segment
+    int cper;                      // block -> (column, walker-group set): XCDs per set (8 / sets) when that divides, else 0
+    int usplit;                    // pieces a column is walked in, one wave each (piece v = x' * usplit + h); their sums meet in LDS
+    const int* urange;             // [NU * usplit] first row u of the piece | number of rows << 16
+    const int* seg0;               // [NU * usplit]  first knot interval of the piece
+    const int* nseg;               // [NU * usplit]  number of segments of the piece
+    const int* seg;                // [NU * usplit][segld] samples per segment
     const double* w4;              // [NU][wld][4] weights (A, B, C, D) of sample u of column x'
     const double* Cm;              // [wld][cld]   C[u][j], zero padded
 };
@@ -72,21 +74,28 @@ template <> __device__ __forceinline__ float2 jx_mx_ldknot<float2>(__amdgpu_buff
 }
 
 template <int RT, int NS, typename TC>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT <= 18 ? 6 : 1)))
 jx_rowmix_kernel(JxMix m, const TC* __restrict__ cft, double* __restrict__ Dt) {
     static_assert(NS == 8, "one aligned 8-dword scalar load carries the sample counts of a group of NS segments");
+    extern __shared__ __attribute__((aligned(16))) double sm_mix[];            // [gpb][usplit - 1][RT][64] sums of the later pieces
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
-    // A block = one column x' and wpb walker groups: its waves stream the same weights and coefficients through the
-    // scalar cache (one fill serves them all).  XCD-aware: block id % 8 is the XCD; the blocks of a group quad share XCDs,
-    // so a quad's spline arrays stay in those L2s.
-    const int ngrp = (m.n + 63) >> 6, nq = (ngrp + wpb - 1) / wpb;
+    // A block = one column x' and gpb walker groups, each group's column walked in `usplit` pieces by as many waves: what
+    // bounds a small launch is the length of a wave's walk, not the arithmetic, so the walk is cut (the pieces' sums are
+    // added in a fixed order through LDS at the end: a result does not depend on the launch).  The waves of a piece stream
+    // the same weights and coefficients through the scalar cache.  XCD-aware: block id % 8 is the XCD; the blocks of a set
+    // of walker groups share XCDs, so the set's spline arrays stay in those L2s.
+    const int usp = m.usplit, gpb = wpb / usp;
+    const int xh = wv % usp, gi = wv / usp;
+    const int ngrp = (m.n + 63) >> 6, nq = (ngrp + gpb - 1) / gpb;
     const int id = blockIdx.x;
     int gq, xq;
     if (m.cper > 0) { const int xcd = id & 7, jj = id >> 3; gq = xcd % nq; xq = xcd / nq + m.cper * jj; }
     else { gq = id % nq; xq = id / nq; }
-    const int grp = gq * wpb + wv;
-    if (grp >= ngrp || xq >= m.NU) return;
+    const int grp = gq * gpb + gi;
+    const bool active = grp < ngrp && xq < m.NU;               // (no early exit: every wave of the block meets the barrier below)
+    const int xv = min(xq, m.NU - 1) * usp + xh;               // piece
+    const int ur = __builtin_amdgcn_readfirstlane(m.urange[xv]), ubeg = ur & 0xffff, ucnt = ur >> 16;
     const size_t w = (size_t)grp * 64 + lane;
     const size_t tW = (size_t)m.tW;
     // knots through a buffer descriptor: per-lane byte offset in a VGPR that never changes, the knot's offset in an SGPR
@@ -94,26 +103,26 @@ jx_rowmix_kernel(JxMix m, const TC* __restrict__ cft, double* __restrict__ Dt) {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<TC*>(cft), 0, m.cft_bytes, 0x00020000);
     const unsigned loff = (unsigned)((unsigned)grp * 64u + (unsigned)lane) * (unsigned)sizeof(TC);
     const unsigned kstride = (unsigned)(tW * sizeof(TC));
-    const int k0 = __builtin_amdgcn_readfirstlane(m.seg0[xq]), nseg = __builtin_amdgcn_readfirstlane(m.nseg[xq]);
-    const int* __restrict__ sc = m.seg + (size_t)xq * m.segld;                 // [segld], zero padded to a multiple of NS
-    const double* __restrict__ wp = m.w4 + (size_t)xq * m.wld * 4;
-    const double* __restrict__ cp = m.Cm;                                      // rows of RT doubles
+    const int k0 = __builtin_amdgcn_readfirstlane(m.seg0[xv]), nseg = active ? __builtin_amdgcn_readfirstlane(m.nseg[xv]) : 0;
+    const int* __restrict__ sc = m.seg + (size_t)xv * m.segld;                 // [segld], zero padded to a multiple of NS
+    const double* __restrict__ wp = m.w4 + ((size_t)(xv / usp) * m.wld + ubeg) * 4;
+    const double* __restrict__ cp = m.Cm + (size_t)ubeg * RT;                  // rows of RT doubles
     // The column's weights and sample counts reach the wave through the scalar cache, which has no prefetch: the first touch of
     // a 64-byte line there is a wave-blocking wait all the way to memory (a column's streams are read by this block and the
     // other walker quads' blocks, on other XCDs, and by nobody before them).  One vector load with a lane per line pulls 4 KiB
     // of a stream into this XCD's L2 long before the scalar loads come for it; the loaded words are not used.  (3 % of the
     // kernel's time at 512^2; the rest of its scalar-side stall is the scalar cache's own latency, see DESIGN.md.)
-    int pf[5] = {0, 0, 0, 0, 0};
-    {
+    int pf[3] = {0, 0, 0};
+    if (active) {
         const char* wb = reinterpret_cast<const char*>(wp);
-        const int wbytes = m.wld * 32, sbytes = m.segld * 4;
+        const int wbytes = ucnt * 32, sbytes = m.segld * 4;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 2; ++k) {
             const int o = lane * 64 + k * 4096;
             if (o < wbytes) pf[k] = *reinterpret_cast<const int*>(wb + o);
         }
-        for (int o = lane * 64 + 4 * 4096; o < wbytes; o += 4096) pf[4] |= *reinterpret_cast<const int*>(wb + o);
-        if (lane * 64 < sbytes) pf[4] |= *reinterpret_cast<const int*>(reinterpret_cast<const char*>(sc) + lane * 64);
+        if (lane * 64 < sbytes) pf[2] = *reinterpret_cast<const int*>(reinterpret_cast<const char*>(sc) + lane * 64);
+        for (int o = lane * 64 + 2 * 4096; o < wbytes; o += 4096) pf[2] |= *reinterpret_cast<const int*>(wb + o);   // (walks beyond 256 rows)
     }
     double acc[RT];
 #pragma unroll
@@ -148,11 +157,28 @@ jx_rowmix_kernel(JxMix m, const TC* __restrict__ cft, double* __restrict__ Dt) {
             }
         }
     }
-    if (m.n < 0 && (pf[0] | pf[1] | pf[2] | pf[3] | pf[4]) == 0x5a5a1234) Dt[0] = 0.0;   // (never: keeps the prefetch loads alive)
-    double* __restrict__ dp = Dt + (size_t)xq * m.R * tW + w;
+    if (m.n < 0 && (pf[0] | pf[1] | pf[2]) == 0x5a5a1234) Dt[0] = 0.0;   // (never: keeps the prefetch loads alive)
+    if (usp > 1) {
+        if (xh > 0) {
+            double* __restrict__ sp = sm_mix + ((size_t)(gi * (usp - 1) + xh - 1) * RT) * 64 + lane;
 #pragma unroll
-    for (int r = 0; r < RT; ++r)
-        if (r < m.R) dp[(size_t)r * tW] = acc[r];
+            for (int r = 0; r < RT; ++r) sp[r * 64] = acc[r];
+        }
+        __syncthreads();
+        if (xh == 0) {
+            for (int hh = 1; hh < usp; ++hh) {                  // fixed order: piece 0 + piece 1 (+ piece 2 ...)
+                const double* __restrict__ sp = sm_mix + ((size_t)(gi * (usp - 1) + hh - 1) * RT) * 64 + lane;
+#pragma unroll
+                for (int r = 0; r < RT; ++r) acc[r] += sp[r * 64];
+            }
+        }
+    }
+    if (xh == 0 && active) {
+        double* __restrict__ dp = Dt + (size_t)xq * m.R * tW + w;
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+            if (r < m.R) dp[(size_t)r * tW] = acc[r];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------

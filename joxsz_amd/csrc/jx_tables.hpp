@@ -611,21 +611,25 @@ inline int lowrank_factor_qr(const double* A, int m, int n, double tol, std::vec
 // Tables of the contracted route (jx_mix.hpp).  c = S/2, umap[m] = |m - c|, NU = distinct rows = distinct columns.
 // ---------------------------------------------------------------------------------------
 struct MixColumns {
-    std::vector<int> seg0, nseg, seg;      // per column x': first knot interval, segments, samples per segment [NU][segld]
+    // a column x' is walked in `usplit` pieces (rows u in [ubeg, ubeg + ucnt) each): per piece v = x' * usplit + h
+    std::vector<int> seg0, nseg, seg;      // first knot interval, segments, samples per segment [NU * usplit][segld]
+    std::vector<int> urange;               // [NU * usplit] ubeg | ucnt << 16
     std::vector<double> w4;                // [NU][wld][4]
-    int segld = 0, wld = 0, maxk = 0;
+    int segld = 0, wld = 0, maxk = 0, usplit = 1;
 };
 
 // Column x' of the quadrant, rows u = 0..NU-1: radius Q[u][x'].  Returns false when the interval index decreases along a
 // column (a d_mat that is not a centred distance matrix): the route is then not taken.
 inline bool mix_column_tables(const std::vector<double>& Qtab /*[qn][qn]: (|iy-c|, |ix-c|)*/, int qn, int NU,
-                              const std::vector<double>& r, MixColumns& t) {
+                              const std::vector<double>& r, MixColumns& t, int usplit = 1) {
     const int N = (int)r.size();
+    usplit = std::max(1, std::min(usplit, NU));
+    t.usplit = usplit;
     t.wld = (NU + 3) & ~3;
     t.w4.assign((size_t)NU * t.wld * 4, 0.0);
     std::vector<int> kof((size_t)NU * NU);
     int maxseg = 1;
-    t.seg0.assign(NU, 0); t.nseg.assign(NU, 0);
+    t.seg0.assign((size_t)NU * usplit, 0); t.nseg.assign((size_t)NU * usplit, 0); t.urange.assign((size_t)NU * usplit, 0);
     for (int a = 0; a < NU; ++a) {
         int kprev = 0;
         for (int u = 0; u < NU; ++u) {
@@ -640,15 +644,22 @@ inline bool mix_column_tables(const std::vector<double>& Qtab /*[qn][qn]: (|iy-c
             kof[(size_t)a * NU + u] = k;
             for (int j = 0; j < 4; ++j) t.w4[((size_t)a * t.wld + u) * 4 + j] = w[j];
         }
-        t.seg0[a] = kof[(size_t)a * NU];
-        t.nseg[a] = kof[(size_t)a * NU + NU - 1] - t.seg0[a] + 1;
-        maxseg = std::max(maxseg, t.nseg[a]);
+        for (int h = 0; h < usplit; ++h) {
+            const int ub = (int)((long long)h * NU / usplit), ue = (int)((long long)(h + 1) * NU / usplit), v = a * usplit + h;
+            t.urange[v] = ub | ((ue - ub) << 16);
+            t.seg0[v] = kof[(size_t)a * NU + ub];
+            t.nseg[v] = kof[(size_t)a * NU + ue - 1] - t.seg0[v] + 1;
+            maxseg = std::max(maxseg, t.nseg[v]);
+        }
         t.maxk = std::max(t.maxk, kof[(size_t)a * NU + NU - 1]);
     }
     t.segld = (maxseg + 15) & ~7;                                             // zero padded: the kernel reads whole groups of 8
-    t.seg.assign((size_t)NU * t.segld, 0);
+    t.seg.assign((size_t)NU * usplit * t.segld, 0);
     for (int a = 0; a < NU; ++a)
-        for (int u = 0; u < NU; ++u) t.seg[(size_t)a * t.segld + (kof[(size_t)a * NU + u] - t.seg0[a])] += 1;
+        for (int h = 0; h < usplit; ++h) {
+            const int v = a * usplit + h, ub = t.urange[v] & 0xffff, ue = ub + (t.urange[v] >> 16);
+            for (int u = ub; u < ue; ++u) t.seg[(size_t)v * t.segld + (kof[(size_t)a * NU + u] - t.seg0[v])] += 1;
+        }
     return true;
 }
 
