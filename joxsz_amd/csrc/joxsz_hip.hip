@@ -118,7 +118,7 @@ struct jx_ctx {
     int trunc_retried = 0, trunc_points = 0;
     bool tol_pinned = false;           // JOXSZ_LOWRANK_TOL given: the guard measures but never overrides
     int form_force = -1;               // JOXSZ_MIX_FORM: 0 low-rank, 1 full
-    int usplit = 2;                    // pieces a map column is walked in by stage 1 (JOXSZ_MIX_USPLIT: 1, 2 or 4; a setting, never a function of the launch)
+    int usplit = 2;                    // pieces a map column is walked in by stage 1 (JOXSZ_MIX_USPLIT: 1..4; a setting, never a function of the launch)
 
     // batch staging for the host-pointer API
     double *d_theta = nullptr, *d_logp = nullptr;
@@ -835,7 +835,7 @@ static int finalize_impl(jx_ctx* ctx) {
     if (const char* e = env_str("JOXSZ_LOWRANK_TOL")) { const double v2 = atof(e); if (v2 > 0.0 && v2 < 1e-6) { lr_tol0 = v2; ctx->tol_pinned = true; } }
     if (const char* e = env_str("JOXSZ_TRUNC_BOUND")) { const double v = atof(e); if (v > 0.0) { ctx->trunc_bound = v; ctx->trunc_bound_ll = std::min(ctx->trunc_bound_ll, 10.0 * v); } }
     if (const char* e = env_str("JOXSZ_MIX_FORM")) { if (!strcmp(e, "lowrank")) ctx->form_force = 0; else if (!strcmp(e, "full")) ctx->form_force = 1; }
-    if (const char* e = env_str("JOXSZ_MIX_USPLIT")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) ctx->usplit = v; }
+    if (const char* e = env_str("JOXSZ_MIX_USPLIT")) { const int v = atoi(e); if (v >= 1 && v <= 4) ctx->usplit = v; }
     if (const char* e = env_str("JOXSZ_MIX_WPB")) { const int v = atoi(e); if (v >= 1 && v <= 4) ctx->mix.wpb = v; }
     if (const char* e = env_str("JOXSZ_MIX_KSPLIT")) { const int v = atoi(e); if (v >= 1) ctx->mix.ksplit_force = v; }
     if (const char* e = env_str("JOXSZ_ABEL_GEMM")) ctx->abel_gemm = atoi(e) != 0;

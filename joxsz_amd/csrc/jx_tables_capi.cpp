@@ -98,14 +98,18 @@ int jxt_spline_sample(const double* r, int n, double x, double* out) {
 
 // column tables of stage 1: meta = {segld, wld, maxk}; call with seg0 == nullptr for the sizes.  Returns 0 when the interval
 // index decreases along a column.
-int jxt_mix_columns(const double* Qtab, int qn, int NU, const double* r, int n, int* meta, int* seg0, int* nseg, int* seg, double* w4) {
+// usplit: pieces a column is walked in; seg0, nseg, urange then hold NU * usplit entries (piece v = x' * usplit + h), seg
+// NU * usplit rows; urange[v] = first row u | rows << 16 (may be null).
+int jxt_mix_columns(const double* Qtab, int qn, int NU, const double* r, int n, int usplit, int* meta, int* seg0, int* nseg, int* seg,
+                    int* urange, double* w4) {
     jxt::MixColumns t;
-    if (!jxt::mix_column_tables(std::vector<double>(Qtab, Qtab + (size_t)qn * qn), qn, NU, std::vector<double>(r, r + n), t)) return 0;
+    if (!jxt::mix_column_tables(std::vector<double>(Qtab, Qtab + (size_t)qn * qn), qn, NU, std::vector<double>(r, r + n), t, usplit)) return 0;
     meta[0] = t.segld; meta[1] = t.wld; meta[2] = t.maxk;
     if (!seg0) return 1;
     std::copy(t.seg0.begin(), t.seg0.end(), seg0);
     std::copy(t.nseg.begin(), t.nseg.end(), nseg);
     std::copy(t.seg.begin(), t.seg.end(), seg);
+    if (urange) std::copy(t.urange.begin(), t.urange.end(), urange);
     std::copy(t.w4.begin(), t.w4.end(), w4);
     return 1;
 }

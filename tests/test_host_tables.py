@@ -287,26 +287,37 @@ def test_mix_column_tables_reproduce_the_mirrored_spline(lib, S, N):
     Qrad = np.ascontiguousarray(Qrad)
     meta = (ctypes.c_int * 3)()
     IP = ctypes.POINTER(ctypes.c_int)
-    lib.jxt_mix_columns.argtypes = [DP, ctypes.c_int, ctypes.c_int, DP, ctypes.c_int, IP, IP, IP, IP, DP]
-    assert lib.jxt_mix_columns(_p(Qrad), NU, NU, _p(r), N, meta, None, None, None, None) == 1
-    segld, wld, maxk = meta[0], meta[1], meta[2]
-    seg0, nseg = np.zeros(NU, np.int32), np.zeros(NU, np.int32)
-    seg, w4 = np.zeros((NU, segld), np.int32), np.zeros((NU, wld, 4))
+    lib.jxt_mix_columns.argtypes = [DP, ctypes.c_int, ctypes.c_int, DP, ctypes.c_int, ctypes.c_int, IP, IP, IP, IP, IP, DP]
     ip = lambda a: a.ctypes.data_as(IP)
-    assert lib.jxt_mix_columns(_p(Qrad), NU, NU, _p(r), N, meta, ip(seg0), ip(nseg), ip(seg), _p(w4)) == 1
-    assert segld % 8 == 0 and maxk <= N - 2
     ypad, Mpad = np.append(y, np.zeros(4)), np.append(M, np.zeros(4))
-    for a in range(NU):
-        assert seg[a, :nseg[a]].sum() == NU and np.all(seg[a, nseg[a]:] == 0)
-        k = np.repeat(seg0[a] + np.arange(nseg[a]), seg[a, :nseg[a]])            # interval of every sample of the column
-        w = w4[a, :NU]
-        got = w[:, 0] * ypad[k] + w[:, 1] * ypad[k + 1] + w[:, 2] * Mpad[k] + w[:, 3] * Mpad[k + 1]
-        np.testing.assert_allclose(got, Q[:, a], rtol=0, atol=2e-13 * np.abs(Q).max())
+    for usplit in (1, 2, 3):                                                       # a column walked whole, or in pieces (one wave each)
+        assert lib.jxt_mix_columns(_p(Qrad), NU, NU, _p(r), N, usplit, meta, None, None, None, None, None) == 1
+        segld, wld, maxk = meta[0], meta[1], meta[2]
+        nv = NU * usplit
+        seg0, nseg, urange = np.zeros(nv, np.int32), np.zeros(nv, np.int32), np.zeros(nv, np.int32)
+        seg, w4 = np.zeros((nv, segld), np.int32), np.zeros((NU, wld, 4))
+        assert lib.jxt_mix_columns(_p(Qrad), NU, NU, _p(r), N, usplit, meta, ip(seg0), ip(nseg), ip(seg), ip(urange), _p(w4)) == 1
+        assert segld % 8 == 0 and maxk <= N - 2
+        for a in range(NU):
+            ks, nxt = [], 0
+            for h in range(usplit):
+                v = a * usplit + h
+                ub, un = urange[v] & 0xffff, urange[v] >> 16
+                assert ub == nxt and un >= 1                                       # the pieces tile the column in order
+                nxt = ub + un
+                assert seg[v, :nseg[v]].sum() == un and np.all(seg[v, nseg[v]:] == 0) and seg[v, 0] >= 1
+                ks.append(np.repeat(seg0[v] + np.arange(nseg[v]), seg[v, :nseg[v]]))    # interval of every sample of the piece
+            assert nxt == NU
+            k = np.concatenate(ks)
+            assert np.all(np.diff(k) >= 0)
+            w = w4[a, :NU]
+            got = w[:, 0] * ypad[k] + w[:, 1] * ypad[k + 1] + w[:, 2] * Mpad[k] + w[:, 3] * Mpad[k + 1]
+            np.testing.assert_allclose(got, Q[:, a], rtol=0, atol=2e-13 * np.abs(Q).max())
     # a radius that shrinks along a column is refused (the route then is not taken)
     bad = Qrad.copy()
     bad[NU // 2, 1] = bad[0, 1] * 0.5
     if np.searchsorted(r, bad[NU // 2, 1]) < np.searchsorted(r, bad[NU // 2 - 1, 1]):
-        assert lib.jxt_mix_columns(_p(bad), NU, NU, _p(r), N, meta, None, None, None, None) == 0
+        assert lib.jxt_mix_columns(_p(bad), NU, NU, _p(r), N, 1, meta, None, None, None, None, None) == 0
 
 
 @pytest.mark.parametrize('S,N', [(31, 40), (32, 40), (64, 80), (65, 80), (128, 100)])
