@@ -408,18 +408,24 @@ def main():
             lo, hi = shard_bounds(4096, world, rank)
             n3 = hi - lo
             th3 = np.ascontiguousarray(np.resize(theta, (n3, theta.shape[1])))
-            p3t, l3t = ctx.dev_alloc(th3.nbytes), ctx.dev_alloc(8 * n3)
-            ctx.h2d(p3t, th3)
-            dt = time_steps(ctx, p3t, n3, l3t, 5, 2)
+            # (a context sized for the shard: one launch sequence for all of it instead of one per 1024 walkers)
+            p3c = JoxszPosterior(pb, device=local_rank, max_batch=n3) if n3 > ctx.chunk else None
+            c3 = p3c.ctx if p3c is not None else ctx
+            p3t, l3t = c3.dev_alloc(th3.nbytes), c3.dev_alloc(8 * n3)
+            c3.h2d(p3t, th3)
+            dt = time_steps(c3, p3t, n3, l3t, 5, 2)
             if comm is not None:
                 dt = comm.max_over_ranks(dt)
             other['configs[3]'] = {'workload': '4096 walkers, 512x512 map, 500-pt grid, joint; %d walkers on this rank' % n3,
-                                   'value': 4096 / dt, 'unit': 'walker-likelihoods/s', 'ms_per_step': 1e3 * dt, 'scaling': 'strong', 'dtype': 'f64'}
+                                   'value': 4096 / dt, 'unit': 'walker-likelihoods/s', 'ms_per_step': 1e3 * dt, 'scaling': 'strong', 'dtype': 'f64',
+                                   'walkers_per_launch': c3.chunk}
+            if p3c is not None:
+                p3c.close()
             lo, hi = shard_bounds(8192, world, rank)
             n4 = hi - lo
             pb4 = datasets.synthetic_problem(S=1024, N=1000, seed=0)
             for dt_name in ('f64', 'f32'):
-                p4 = JoxszPosterior(pb4, device=local_rank, dtype=dt_name)
+                p4 = JoxszPosterior(pb4, device=local_rank, dtype=dt_name, max_batch=n4)
                 c4 = p4.ctx
                 cand4 = datasets.walker_ball(pb4, 256, spread=0.02, seed=5)
                 ok4 = cand4[np.isfinite(c4.eval(cand4))]
@@ -431,7 +437,7 @@ def main():
                     dt = comm.max_over_ranks(dt)
                 other['configs[4] ' + dt_name] = {'workload': '8192 walkers, 1024x1024 map, 1000-pt grid, joint; %d walkers on this rank' % n4,
                                                   'value': 8192 / dt, 'unit': 'walker-likelihoods/s', 'ms_per_step': 1e3 * dt, 'scaling': 'strong',
-                                                  'dtype': dt_name, 'conv_layout': c4.conv_layout}
+                                                  'dtype': dt_name, 'conv_layout': c4.conv_layout, 'walkers_per_launch': c4.chunk}
                 p4.close()
         except Exception as exc:
             other['error'] = str(exc)
