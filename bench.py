@@ -171,13 +171,14 @@ def spawn_ranks(n, argv, timeout_s=3000.0, python=None, script=None):
     script = script or os.path.abspath(__file__)
     port = int(os.environ.get('MASTER_PORT', 0)) or random.randint(20000, 45000)
     tag = 'bench_%d_%d' % (os.getpid(), int(time.time() * 1e3))
+    import tempfile
+    out0 = tempfile.TemporaryFile(mode='w+')              # rank 0's stdout: a file, so that no amount of output can block it on a full pipe
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), JOXSZ_RDZV_TAG=tag, JOXSZ_RDZV_T0=repr(time.time()),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
-        procs.append(subprocess.Popen([python, script] + argv, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
-                                      stderr=None, text=True))
+        procs.append(subprocess.Popen([python, script] + argv, env=env, stdout=out0 if r == 0 else subprocess.DEVNULL, stderr=None))
     t0 = time.time()
     rc = 0
     pending = set(range(n))
@@ -201,7 +202,9 @@ def spawn_ranks(n, argv, timeout_s=3000.0, python=None, script=None):
                     procs[r].kill()
             break
         time.sleep(0.05)
-    out = procs[0].stdout.read() if procs[0].stdout else ''
+    out0.seek(0)
+    out = out0.read()
+    out0.close()
     lines = [l for l in out.strip().splitlines() if l.strip()]
     return rc, (lines[-1] if lines else '')
 

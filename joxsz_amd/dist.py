@@ -37,18 +37,37 @@ def _rdzv_path():
     return os.path.join(d, 'joxsz_rccl_%s.id' % tag)
 
 
-def exchange_unique_id(make_id, rank, world, timeout=120.0, not_before=None):
+def _launch_start_time():
+    """A time that precedes the start of every rank of this launch and follows every earlier launch that could have used
+    the same rendezvous path: ``JOXSZ_RDZV_T0`` when the launcher sets it (bench.py's own does), else the start time of the
+    parent process -- the launcher all ranks share (torch.distributed.run's agent, mpirun, a shell), whose pid is part of the
+    default path.  NOT this process's own start: ranks come up seconds apart (a cold python import on a fresh box takes
+    a minute), and a slow rank must still accept the file rank 0 wrote before it was up."""
+    t0 = os.environ.get('JOXSZ_RDZV_T0')
+    if t0:
+        return float(t0)
+    try:
+        with open('/proc/%d/stat' % os.getppid()) as f:
+            ticks = float(f.read().rsplit(')', 1)[1].split()[19])          # field 22: start time in clock ticks since boot
+        with open('/proc/stat') as f:
+            btime = next(float(l.split()[1]) for l in f if l.startswith('btime'))
+        return btime + ticks / os.sysconf('SC_CLK_TCK')
+    except Exception:
+        return _PROCESS_T0 - 600.0                                         # no /proc: ten minutes of grace
+
+
+def exchange_unique_id(make_id, rank, world, timeout=600.0, not_before=None):
     """Rank 0 calls ``make_id()`` (``jx_comm_unique_id``) and publishes the 128 bytes; the others read them.
     One node: a file under ``JOXSZ_RDZV_DIR`` (default /tmp) named after ``JOXSZ_RDZV_TAG`` (bench.py's own launcher sets a
     fresh one per launch) or the launcher's run id, MASTER_PORT and pid, written atomically (rename).  A file left behind
     by an earlier launch with the same name is never taken for this launch's: rank 0 removes exactly that path before it
     writes, and a reader only accepts a file whose modification time is not older than ``not_before`` -- the launch's
-    start time (``JOXSZ_RDZV_T0``, set by the launcher for all ranks) or, without one, this process's own start."""
+    start time (``_launch_start_time``: ``JOXSZ_RDZV_T0`` from the launcher, or the start of the parent process)."""
     if world == 1:
         return make_id()
     path = _rdzv_path()
     if not_before is None:
-        not_before = float(os.environ.get('JOXSZ_RDZV_T0', _PROCESS_T0))
+        not_before = _launch_start_time()
     if rank == 0:
         try:
             os.unlink(path)                                   # this launch's path only, never a glob

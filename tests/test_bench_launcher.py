@@ -91,3 +91,22 @@ def test_rendezvous_ignores_a_stale_id_file(tmp_path, monkeypatch):
     with pytest.raises(RuntimeError):
         os.unlink(path)
         dist.exchange_unique_id(lambda: b'', 1, 2, timeout=0.3)       # no rank 0: a timeout, not a hang
+
+
+def test_rendezvous_accepts_the_id_a_faster_rank_0_wrote_before_this_rank_was_up(tmp_path, monkeypatch):
+    """Without a launcher-provided start time the reference is the PARENT's start (the launcher every rank shares), not the
+    reading rank's own: a rank that comes up seconds after rank 0 has already published the id must take it."""
+    from joxsz_amd import dist
+    monkeypatch.setenv('JOXSZ_RDZV_DIR', str(tmp_path))
+    monkeypatch.setenv('JOXSZ_RDZV_TAG', 'slow_rank')
+    monkeypatch.delenv('JOXSZ_RDZV_T0', raising=False)
+    t_launch = dist._launch_start_time()
+    assert t_launch <= dist._PROCESS_T0 + 1.0                             # the parent (pytest's launcher) predates this process
+    path = dist._rdzv_path()
+    with open(path, 'wb') as f:
+        f.write(b'E' * 128)
+    early = max(t_launch + 0.5, dist._PROCESS_T0 - 30.0)                  # written after the launch began, before "this rank" was up
+    if early < dist._PROCESS_T0:
+        os.utime(path, (early, early))
+    monkeypatch.setattr(dist, '_PROCESS_T0', time.time() + 5.0)           # this rank: up five seconds from now
+    assert dist.exchange_unique_id(lambda: b'', 1, 2, timeout=2.0) == b'E' * 128
