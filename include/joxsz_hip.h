@@ -276,6 +276,10 @@ int  jx_map_kernel_time(jx_ctx* ctx, const double* theta_dev, int nwalkers, int 
 /* Device-to-device copy bandwidth of this GPU in GB/s (bytes read + bytes written per second): `nbytes` copied `repeats` times
  * between two scratch buffers, HIP events on the context's stream.  The practical HBM roofline beside the nominal 8 TB/s. */
 int  jx_copy_bandwidth(jx_ctx* ctx, size_t nbytes, int repeats, double* gbps_out);
+/* The same for one kind of stream: mode 0 copy (bytes read + written), 1 read only, 2 write only (the full-map kernel of
+ * jx_map_kernel_time is a write stream).  Hand-written grid-stride kernels in the launch shapes that do best on this chip
+ * (scripts/ubench/hbm_rates.hip). */
+int  jx_stream_bandwidth(jx_ctx* ctx, int mode, size_t nbytes, int repeats, double* gbps_out);
 int  jx_device_count(void);
 const char* jx_device_name(jx_ctx* ctx);
 

@@ -1808,6 +1808,52 @@ __global__ void __launch_bounds__(256) jx_copy_kernel(const double2* __restrict_
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
 }
 
+__global__ void __launch_bounds__(256) jx_fill_kernel(double2* __restrict__ dst, size_t n, double v) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = double2{v, v};
+}
+__global__ void __launch_bounds__(256) jx_readsum_kernel(const double2* __restrict__ src, double* __restrict__ out, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    double s = 0.0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) { const double2 v = src[i]; s += v.x + v.y; }
+    if (s == 1.2345e300) out[0] = s;                       // (never: keeps the loads)
+}
+
+// mode 0: copy (bytes read + written counted), 1: read stream, 2: write stream.  Launch shapes: the best of
+// scripts/ubench/hbm_rates.hip on this chip (a write stream wants FEW blocks: one per CU sweeps memory as one compact window).
+int jx_stream_bandwidth(jx_ctx* ctx, int mode, size_t nbytes, int repeats, double* gbps_out) {
+    if (!ctx || mode < 0 || mode > 2 || nbytes < 4096 || repeats < 1 || !gbps_out) return JX_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    void *a = nullptr, *b = nullptr;
+    HIPCHK(ctx, hipMalloc(&a, nbytes));
+    if (hipMalloc(&b, nbytes) != hipSuccess) { (void)hipFree(a); ctx->err = "jx_stream_bandwidth: out of memory"; return JX_ERR_NOMEM; }
+    hipStream_t st = ctx->stream;
+    hipEvent_t e0, e1;
+    HIPCHK(ctx, hipEventCreate(&e0)); HIPCHK(ctx, hipEventCreate(&e1));
+    HIPCHK(ctx, hipMemsetAsync(a, 0, nbytes, st));
+    HIPCHK(ctx, hipMemsetAsync(b, 0, nbytes, st));
+    const size_t n = nbytes / sizeof(double2);
+    const int per_cu = mode == 2 ? 1 : 4;
+    const dim3 grid((unsigned)(ctx->num_cu * per_cu));
+    auto go = [&]() {
+        if (mode == 0) hipLaunchKernelGGL(jx_copy_kernel, grid, dim3(256), 0, st, (const double2*)a, (double2*)b, n);
+        else if (mode == 1) hipLaunchKernelGGL(jx_readsum_kernel, grid, dim3(256), 0, st, (const double2*)a, (double*)b, n);
+        else hipLaunchKernelGGL(jx_fill_kernel, grid, dim3(256), 0, st, (double2*)b, n, 1.0);
+    };
+    go();
+    HIPCHK(ctx, hipEventRecord(e0, st));
+    for (int i = 0; i < repeats; ++i) go();
+    HIPCHK(ctx, hipEventRecord(e1, st));
+    HIPCHK(ctx, hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(ctx, hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(a); (void)hipFree(b);
+    HIPCHK(ctx, hipGetLastError());
+    *gbps_out = (mode == 0 ? 2.0 : 1.0) * (double)(n * sizeof(double2)) * repeats / ((double)ms * 1e-3) / 1e9;
+    return JX_OK;
+}
+
 int jx_copy_bandwidth(jx_ctx* ctx, size_t nbytes, int repeats, double* gbps_out) {
     if (!ctx || nbytes < 4096 || repeats < 1 || !gbps_out) return JX_ERR_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->cfg.device));

@@ -20,7 +20,7 @@ EXPORTS = (
     'jx_timing_reset', 'jx_timing_enable', 'jx_timing_get', 'jx_get_info', 'jx_get_conv_mode', 'jx_get_conv_layout', 'jx_debug_workspace', 'jx_device_count',
     'jx_device_name', 'jx_strerror', 'jx_last_error', 'jx_destroy',
     'jx_get_truncation', 'jx_comm_unique_id', 'jx_comm_init_rank', 'jx_allgather_logp', 'jx_comm_allreduce_max', 'jx_comm_destroy',
-    'jx_comm_count', 'jx_map_kernel_time', 'jx_copy_bandwidth',
+    'jx_comm_count', 'jx_map_kernel_time', 'jx_copy_bandwidth', 'jx_stream_bandwidth',
 )
 
 TENSORS = ('r_pp', 'd_mat', 'beam_2d', 'filtering', 'radius', 'flux_data', 'conv_T', 'conv_v',
@@ -100,6 +100,7 @@ def load_library(path=None):
     lib.jx_comm_count.argtypes = [vp]
     lib.jx_map_kernel_time.argtypes = [vp, vp, ci, ci, dp]
     lib.jx_copy_bandwidth.argtypes = [vp, cs, ci, dp]
+    lib.jx_stream_bandwidth.argtypes = [vp, ci, cs, ci, dp]
     lib.jx_device_count.argtypes = []
     lib.jx_device_name.argtypes = [vp]
     lib.jx_device_name.restype = ctypes.c_char_p
@@ -376,6 +377,14 @@ class HipContext:
         ms = ctypes.c_double()
         self._chk(self.lib.jx_map_kernel_time(self._h, ctypes.c_void_p(theta_ptr), nwalkers, repeats, ctypes.byref(ms)), 'jx_map_kernel_time')
         return ms.value
+
+    def stream_bandwidth(self, kind, nbytes=1 << 30, repeats=10):
+        """What this GPU's HBM gives a plain stream, GB/s (``jx_stream_bandwidth``): kind 'copy' (bytes read + written), 'read'
+        or 'write'.  The full-map kernel is a write stream."""
+        g = ctypes.c_double()
+        self._chk(self.lib.jx_stream_bandwidth(self._h, {'copy': 0, 'read': 1, 'write': 2}[kind], nbytes, repeats, ctypes.byref(g)),
+                  'jx_stream_bandwidth')
+        return g.value
 
     def copy_bandwidth(self, nbytes=1 << 30, repeats=10):
         """Device-to-device copy bandwidth in GB/s, bytes read + written (``jx_copy_bandwidth``): the practical HBM roofline."""
