@@ -18,14 +18,14 @@ for S, N, W in shapes:
         os.environ['JOXSZ_ABEL_GEMM'] = mode
         post = JoxszPosterior(pb, device=0, conv='custom')
         lp = post.log_prob(th)
-        cf, _ = post.ctx.workspace('coefs')
+        cf = post.ctx.workspace('splines')                  # [N, tW, 2] walker-minor (y_k, M_k)
         post.close()
-        res[mode] = (lp, cf[:W, 0, :2 * N + 4].copy())
+        res[mode] = (lp, cf[:N, :W, :].copy())
     a, b = res['0'], res['1']
     fin = np.isfinite(a[0])
-    ya, yb = a[1][fin, 0:2 * N:2], b[1][fin, 0:2 * N:2]
-    ma, mb = a[1][fin, 1:2 * N:2], b[1][fin, 1:2 * N:2]
-    print('S=%d N=%d W=%d: y rel %.3e  M rel (of row max) %.3e  tail zeros %s  logp rel %.3e  same-inf %s'
+    ya, yb = a[1][:, fin, 0].T, b[1][:, fin, 0].T
+    ma, mb = a[1][:, fin, 1].T, b[1][:, fin, 1].T
+    print('S=%d N=%d W=%d: y rel %.3e  M rel (of row max) %.3e  logp rel %.3e  same-inf %s'
           % (S, N, W, np.max(np.abs(ya - yb) / np.abs(ya).max(axis=1, keepdims=True)),
-             np.max(np.abs(ma - mb) / np.abs(ma).max(axis=1, keepdims=True)), bool(np.all(b[1][:, 2 * N:] == 0)),
+             np.max(np.abs(ma - mb) / np.abs(ma).max(axis=1, keepdims=True)),
              np.max(np.abs(a[0][fin] - b[0][fin]) / np.abs(a[0][fin])), np.array_equal(fin, np.isfinite(b[0]))), flush=True)
