@@ -118,6 +118,7 @@ struct jx_ctx {
     int trunc_retried = 0, trunc_points = 0;
     bool tol_pinned = false;           // JOXSZ_LOWRANK_TOL given: the guard measures but never overrides
     int form_force = -1;               // JOXSZ_MIX_FORM: 0 low-rank, 1 full
+    int map_pair = 1;                  // full-map kernel: two walkers per block (JOXSZ_MAP_PAIR=0: one)
     int usplit = 2;                    // pieces a map column is walked in by stage 1 (JOXSZ_MIX_USPLIT: 1..4; a setting, never a function of the launch)
 
     // batch staging for the host-pointer API
@@ -290,13 +291,18 @@ static size_t map_lds_need(const JxDev& d, int threads) {
 }
 
 // picks pairw and the block size for `d` so that the kernel's LDS fits; returns false when the radial grid is too long
-static bool map_geometry(JxDev& d, int want_threads, int* threads_out, size_t* lds_out) {
+static bool map_geometry(JxDev& d, int want_threads, int* threads_out, size_t* lds_out, bool pair_full = false) {
     const size_t LDS_MAX = 160 * 1024;
     int threads = want_threads;
     d.pairw = 1;
     if (d.quad) {
         d.pairw = 2;                                           // two walkers per block share every table entry, while two such blocks fit a CU
         if (map_lds_need(d, threads) > (LDS_MAX - 2048) / 2) d.pairw = 1;
+    } else if (pair_full && d.fast_map) {
+        // full rows: two walkers per block take the Abel weights out of the L2 once (2 MB per walker otherwise: the stream
+        // that competes with the map's stores); one such block per CU
+        d.pairw = 2;
+        if (map_lds_need(d, threads) > LDS_MAX - 1024) d.pairw = 1;
     }
     while (threads > 64 && map_lds_need(d, threads) > LDS_MAX - 1024) threads /= 2;
     const size_t lds = map_lds_need(d, threads);
@@ -310,7 +316,7 @@ static void launch_map(hipStream_t st, const JxDev& dm_in, int threads, size_t l
     JxDev dm = dm_in;
     dm.nlaunch = n;
     const bool vec2 = (dm.S % 2 == 0) && (dm.img_ld % 2 == 0);
-    const int npw = (dm.quad && dm.pairw == 2) ? 2 : 1;
+    const int npw = (dm.pairw == 2) ? 2 : 1;
     if (coef_only) dm.map_split = 1;
     const dim3 grid(((n + npw - 1) / npw) * dm.map_split), block(threads);
     if (dm.fast_map) {
@@ -352,7 +358,7 @@ static int fft_setup(jx_ctx* ctx, FftBack& fb, int cap, int P) {
     JxDev& d = fb.d;
     d.P = P; d.Ph = fb.Ph;
     d.quad = 0; d.img_ld = P; d.img_ws = (long long)P * P; d.cf_out = nullptr; d.xcol = nullptr;
-    if (!map_geometry(d, 512, &fb.map_threads, &fb.map_lds)) { ctx->err = "radial grid too long for the LDS-resident spline"; return JX_ERR_UNSUPPORTED; }
+    if (!map_geometry(d, 512, &fb.map_threads, &fb.map_lds, ctx->map_pair != 0)) { ctx->err = "radial grid too long for the LDS-resident spline"; return JX_ERR_UNSUPPORTED; }
     {
         std::vector<double> beam = host_vec<double>(ctx, JX_T_BEAM_2D), bh, H;
         jxt::beam_spectrum(beam, B, P, c.step * c.step / ((double)P * (double)P), bh);
@@ -835,6 +841,7 @@ static int finalize_impl(jx_ctx* ctx) {
     if (const char* e = env_str("JOXSZ_LOWRANK_TOL")) { const double v2 = atof(e); if (v2 > 0.0 && v2 < 1e-6) { lr_tol0 = v2; ctx->tol_pinned = true; } }
     if (const char* e = env_str("JOXSZ_TRUNC_BOUND")) { const double v = atof(e); if (v > 0.0) { ctx->trunc_bound = v; ctx->trunc_bound_ll = std::min(ctx->trunc_bound_ll, 10.0 * v); } }
     if (const char* e = env_str("JOXSZ_MIX_FORM")) { if (!strcmp(e, "lowrank")) ctx->form_force = 0; else if (!strcmp(e, "full")) ctx->form_force = 1; }
+    if (const char* e = env_str("JOXSZ_MAP_PAIR")) ctx->map_pair = atoi(e) != 0;
     if (const char* e = env_str("JOXSZ_MIX_USPLIT")) { const int v = atoi(e); if (v >= 1 && v <= 4) ctx->usplit = v; }
     if (const char* e = env_str("JOXSZ_MIX_WPB")) { const int v = atoi(e); if (v >= 1 && v <= 4) ctx->mix.wpb = v; }
     if (const char* e = env_str("JOXSZ_MIX_KSPLIT")) { const int v = atoi(e); if (v >= 1) ctx->mix.ksplit_force = v; }
@@ -1780,7 +1787,7 @@ int jx_map_kernel_time(jx_ctx* ctx, const double* theta_dev, int nwalkers, int r
     dm.quad = 0; dm.img_ld = (long long)S; dm.img_ws = (long long)(S * S); dm.cf_out = nullptr; dm.xcol = nullptr;
     dm.map_split = std::max(dm.map_split, 2);                  // (two row slabs per walker: launches desynchronise, stores overlap compute)
     int threads; size_t lds;
-    if (!map_geometry(dm, 512, &threads, &lds)) { ctx->err = "radial grid too long for the LDS-resident spline"; return JX_ERR_UNSUPPORTED; }
+    if (!map_geometry(dm, 512, &threads, &lds, ctx->map_pair != 0)) { ctx->err = "radial grid too long for the LDS-resident spline"; return JX_ERR_UNSUPPORTED; }
     double* img = nullptr;
     HIPCHK(ctx, hipMalloc((void**)&img, sizeof(double) * (size_t)nwalkers * S * S));
     hipEvent_t e0, e1;

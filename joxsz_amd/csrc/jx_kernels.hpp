@@ -835,7 +835,7 @@ jx_abel_map_sym_kernel(JxDev c, const double* __restrict__ theta, int w0, double
     const int Ne = (N + 1) & ~1;
     double* s_cf = sm + JX_LDS_HDR;                                   // [4(N+1)] cubic coefficients (live in phase 5)
     // quad mode with two walkers per block: the second walker's coefficients sit in front of the scratch
-    const int npw = (c.quad && c.pairw == 2) ? 2 : 1;
+    const int npw = (c.pairw == 2) ? 2 : 1;
     double* s_cfB = sm + JX_MAP_FIXED_DOUBLES(N);
     double* s_r = sm + JX_MAP_FIXED_DOUBLES(N) + (npw == 2 ? 4 * JX_MAP_NE(N) + 8 : 0);   // [N] knots -- scratch from here on
     double* s_pp = s_r + Ne;                                          // [N]
@@ -913,6 +913,10 @@ jx_abel_map_sym_kernel(JxDev c, const double* __restrict__ theta, int w0, double
         }
         return;
     }
+    // (full rows: the block's walkers one after the other, each from its own coefficients)
+    for (int ww = 0; ww < (haveB ? 2 : 1); ++ww) {
+    const double* s_cfw = ww ? s_cfB : s_cf;
+    out = img + (size_t)(w + ww) * c.img_ws;
     int kq[NAIT];
     double tq[NAIT];
     int b = b0 + wv;
@@ -939,7 +943,7 @@ jx_abel_map_sym_kernel(JxDev c, const double* __restrict__ theta, int w0, double
                 }
             }
         }
-        return;
+        continue;
     }
     if (b < b1) {
 #pragma unroll
@@ -956,7 +960,7 @@ jx_abel_map_sym_kernel(JxDev c, const double* __restrict__ theta, int w0, double
         for (int u = 0; u < NAIT; ++u) {
             const int a = lane + 64 * u;
             const double t = tq[u];
-            const double* cf = s_cf + 4 * kq[u];
+            const double* cf = s_cfw + 4 * kq[u];
             const double v = fma(t, fma(t, fma(t, cf[3], cf[2]), cf[1]), cf[0]);
             if (a < na) {
                 if (cc + a < S) rowfull[cc + a] = v;
@@ -994,6 +998,7 @@ jx_abel_map_sym_kernel(JxDev c, const double* __restrict__ theta, int w0, double
             }
         }
         __builtin_amdgcn_wave_barrier();
+    }
     }
 }
 
