@@ -1,0 +1,60 @@
+"""The bench line committed with the round (profiles/r03_bench.json, written by bench.py on an MI355X) carries every field of
+the driver's contract and of SURVEY 8(d): metric / config of BASELINE.json, roofline and cpu_baseline objects, figures that
+hang together."""
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _line(name):
+    with open(os.path.join(ROOT, 'profiles', name)) as f:
+        return json.loads(f.read().strip().splitlines()[-1])
+
+
+def test_committed_bench_line_follows_the_contract():
+    d = _line('r03_bench.json')
+    base = json.load(open(os.path.join(ROOT, 'BASELINE.json')))
+    assert d['metric'].split(';')[0] == base['metric'].split(';')[0].replace('²', '^2')
+    for k in ('value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config'):
+        assert k in d, k
+    assert d['n_gpus'] == 1 and d['higher_is_better'] is True and d['scaling'] == 'weak' and d['vs_baseline'] is None
+    assert d['dtype'] == 'f64' and d['data'] == 'synthetic' and 'workload' in d['config'] and 'model' not in d['config']
+    assert '1024 walkers' in d['config']['workload'] and '512x512' in d['config']['workload']
+    # value = walkers per step / time per step
+    assert abs(d['value'] - d['config']['walkers_per_gpu'] / (d['ms_per_step'] * 1e-3)) <= 1e-6 * d['value']
+    assert d['value'] >= 10000                                            # north_star's target on one MI355X
+    r = d['roofline']
+    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'kernel', 'launch_ms'):
+        assert k in r, k
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9 and 0 < r['frac'] < 1 and r['traffic'] is not None
+    # achieved = algorithmic flops of the launch / the kernel's measured duration
+    assert abs(r['achieved'] - r['flops_per_launch'] / (r['launch_ms'] * 1e-3) / 1e12) < 1e-6 * r['achieved']
+    c = d['cpu_baseline']
+    for k in ('value', 'unit', 'cores', 'kind', 'sample'):
+        assert k in c, k
+    assert c['kind'] == 'port' and c['cores'] >= 1 and c['unit'] == d['unit'] and c['value'] > 0
+    assert 'single_process' in c and 'stage_ms_per_call' in c
+    assert d['parity_max_rel_err'] <= 1e-6                                # north_star's tolerance, checked inside the run
+    ns = d['north_star_abel_map_kernel']
+    assert ns['frac_of_hbm_peak'] >= 0.60                                 # north_star: >= 60 % of the HBM roofline in the Abel+map kernel
+    assert abs(ns['achieved_GBps'] - ns['bytes_per_launch'] / (ns['launch_ms'] * 1e-3) / 1e9) < 1e-6 * ns['achieved_GBps']
+    t = d['truncation']
+    assert t['points'] >= 9 and 0 <= t['est_rel_row_err'] <= t['bound'] and 0 <= t['est_rel_sz_like_err_box'] <= 1e-8
+    assert d['n_ranks_seen'] == 1
+
+
+def test_rocprof_kernel_statistics_agree_with_the_bench_line():
+    """profiles/r03_kernel_stats.csv (rocprofv3 --kernel-trace of the same command, full-size launches only): the dominant
+    kernel's average duration within 10 % of the HIP-event duration the roofline is computed from."""
+    import csv
+    d = _line('r03_bench.json')
+    rows = list(csv.DictReader(open(os.path.join(ROOT, 'profiles', 'r03_kernel_stats.csv'))))
+    top = rows[0]
+    assert d['roofline']['kernel'] in top['Name']
+    assert abs(float(top['AverageUs']) * 1e-3 - d['roofline']['launch_ms']) <= 0.10 * d['roofline']['launch_ms']
+    # the kernels of the step add up to the step (launch gaps excluded)
+    step_us = sum(float(r['AverageUs']) for r in rows if int(r['FullSizeCalls']) >= 100)
+    assert 0.85 * d['ms_per_step'] * 1e3 <= step_us <= 1.02 * d['ms_per_step'] * 1e3
+    f = _line('r03_bench_force_dist.json')
+    assert f['n_ranks_seen'] == 1 and abs(f['value'] - d['value']) <= 0.08 * d['value']      # the N > 1 plumbing at N = 1 costs nothing
