@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define JX_ABI_VERSION 3
+#define JX_ABI_VERSION 4
 
 typedef struct jx_ctx jx_ctx;
 
@@ -256,10 +256,13 @@ int  jx_get_conv_layout(jx_ctx* ctx, int32_t out[12]);
  * found an estimate above its bound and rebuilt the tables -- in place -- with a cut ten times tighter (a rebuild may end
  * in the full form, where the growing rank has made it the cheaper one: rank 0, nothing truncated); probe points that
  * gave finite numbers; bound on out[1] (1e-9; JOXSZ_TRUNC_BOUND); the row difference over ALL probe points; largest
- * difference of the SZ log-likelihood over all probe points relative to max(1, |SZ log-likelihood|), bound 1e-8}.
- * -1 where nothing is truncated (full form, rocFFT) or nothing was measured (JOXSZ_TRUNC_PROBE=0, dtype f32); an explicit
- * JOXSZ_LOWRANK_TOL is measured but never overridden. */
-int  jx_get_truncation(jx_ctx* ctx, double out[8]);
+ * difference of the SZ log-likelihood over all probe points relative to max(1, |SZ log-likelihood|); terms above the cut
+ * (rank < this: the rank was cut to 16 so that stage 1 fits one 16-row tile of the fp64 matrix cores -- ranks up to 20 are,
+ * and the guard takes the cap away before it tightens the cut; JOXSZ_MIX_RANKCAP=0: never cut); bound on out[7] (1e-8);
+ * 1 when stage 1 runs on the matrix cores (R <= 16; JOXSZ_MIX_MFMA=0: never); how many of the rebuilds took the cap away}.
+ * -1 where nothing is truncated (full form, rocFFT) or nothing was measured (JOXSZ_TRUNC_PROBE=0); an explicit
+ * JOXSZ_LOWRANK_TOL is measured but never overridden, and neither is an f32 context (its rounding is of the bounds' size). */
+int  jx_get_truncation(jx_ctx* ctx, double out[12]);
 /* Test hook (contracted route): device address and geometry of a work buffer holding the last evaluated chunk.
  *   0 quadrant of the Compton-y map [chunk][NU][ld] (exists after the first y_2d tap): geom = {chunk, NU, ld, 8}
  *   1 spline arrays, walker-minor [N][tW][2] = (y_k, M_k) of walker w at ((k tW + w) 2): geom = {N, tW, 2, element bytes}

@@ -62,7 +62,9 @@ struct MixBack {
     int form = 0;                      // 0 low-rank (stage 1 + stage 2), 1 full operator on the samples
     JxMix mx{};
     JxOpg og{};
-    int RT = 0, nxt = 0, r = 0, ns = 0, ksteps = 0, wpb = 4, ksplit_force = 0, last_ksplit = 1, dbg = 0;
+    int RT = 0, nxt = 0, r = 0, ns = 0, ksteps = 0, wpb = 4, wpb_force = 0, ksplit_force = 0, last_ksplit = 1, dbg = 0;
+    bool mfma = false;                 // stage 1 on the fp64 matrix cores (R <= 16: jx_rowmix_mfma_kernel)
+    int r_tol = 0;                     // terms above the singular-value cut (r < r_tol: capped to one 16-row tile)
     long long tW = 0;
     int ncol = 0;
     double tol = 0.0;
@@ -115,11 +117,14 @@ struct jx_ctx {
     // truncation guard
     double trunc_est[3] = {-1.0, -1.0, -1.0};   // measure_truncation: row at the current values, row over the probe points, SZ log-likelihood
     double trunc_bound = 1e-9, trunc_bound_ll = 1e-8;
-    int trunc_retried = 0, trunc_points = 0;
+    int trunc_retried = 0, trunc_points = 0, trunc_uncapped = 0;   // rebuilds in all; of which: the cap on the rank taken away
     bool tol_pinned = false;           // JOXSZ_LOWRANK_TOL given: the guard measures but never overrides
     int form_force = -1;               // JOXSZ_MIX_FORM: 0 low-rank, 1 full
     int map_pair = 1;                  // full-map kernel: two walkers per block (JOXSZ_MAP_PAIR=0: one)
     int usplit = 2;                    // pieces a map column is walked in by stage 1 (JOXSZ_MIX_USPLIT: 1..4; a setting, never a function of the launch)
+    int rank_cap = 16;                 // low-rank form: a rank within JX_MIX_CAP_REACH terms above this is cut to it, so that stage 1 fits one 16-row matrix-core
+                                       // tile (the guard measures the result and takes the cap away when it costs accuracy; JOXSZ_MIX_RANKCAP=0: never)
+    bool mix_mfma = false;             // JOXSZ_MIX_MFMA=1: stage 1 on the fp64 matrix cores when R <= 16 (measured slower than the vector-unit kernel: DESIGN 6.1)
 
     // batch staging for the host-pointer API
     double *d_theta = nullptr, *d_logp = nullptr;
@@ -426,10 +431,13 @@ static int fft_plans(jx_ctx* ctx, FftBack& fb, int batch, Plan3** out) {
 #define JX_MIX_NXTS(X) X(1) X(2) X(3) X(4) X(5) X(6)
 #define JX_MIX_KSPLIT_MAX 64
 #define JX_LR_TOL_DEFAULT 1e-8
+#define JX_MIX_CAP_REACH 4             // ranks up to rank_cap + this many terms are cut to rank_cap (then measured by the guard)
 struct MixBuild {
     bool ok = false;
     std::string why;
     int form = 0, NU = 0, r = 0, ns = 0, R = 0, RT = 0, nxt = 0, ntile = 0, nog = 0, ksteps = 0;
+    int r_tol = 0;                     // terms above the cut before the cap
+    bool mfma = false;
     size_t krows = 0;
     jxt::MixColumns cols;
     std::vector<double> Cm, Op;
@@ -475,8 +483,20 @@ static void plan_mix(jx_ctx* ctx, const std::vector<double>& beam, const std::ve
     if (lowrank_ok && form_force != 1) {
         mb.r = jxt::lowrank_factor_qr(A.data(), S, Sh, tol, U, V);
         mb.ns = jxt::beam_separable_terms(beam, B, c.step * c.step, mb.beam_tol, by, bx);
+        mb.r_tol = mb.r;
+        // A rank a few terms above 16 is cut to 16 (terms are sorted by singular value: the first rows of U and V): the stage-1
+        // kernel instance with 16 rows per column, stage 2 shorter by as much (and one 16-row tile of the matrix cores carries
+        // stage 1 where that kernel is asked for).  jx_finalize measures what the cut costs on the caller's data and rebuilds
+        // without the cap when it is beyond the bounds.
+        if (!ctx->tol_pinned && ctx->rank_cap > 0 && mb.ns > 0 && mb.r * mb.ns > ctx->rank_cap && ctx->rank_cap / mb.ns >= 1 &&
+            mb.r <= ctx->rank_cap / mb.ns + JX_MIX_CAP_REACH) {
+            mb.r = ctx->rank_cap / mb.ns;
+            U.resize((size_t)mb.r * S); V.resize((size_t)mb.r * Sh);
+        }
         mb.R = mb.r * mb.ns;
+        mb.mfma = ctx->mix_mfma && mb.R <= 16;
         if (mb.r <= 0 || mb.ns <= 0) { lowrank_ok = false; why_lr = "transfer-function weights or beam image vanish"; }
+        else if (mb.mfma) mb.RT = 16;
         else {
 #define JX_PICK(Rv) if (!mb.RT && mb.R <= Rv) mb.RT = Rv;
             JX_MIX_RTS(JX_PICK)
@@ -487,15 +507,17 @@ static void plan_mix(jx_ctx* ctx, const std::vector<double>& beam, const std::ve
     // cost of each form in fused multiply-adds per walker; stage 1 runs on the vector units at about 0.6 of the rate the
     // matrix cores reach in the product kernels (measured: 256^2 with 32 terms 0.141 ms low-rank against 0.126 ms full; 257^2 0.155 against 0.132)
     const double nsamp = (double)NU * NU;
-    mb.cost_lowrank = (lowrank_ok && mb.RT) ? 1.6 * nsamp * (4.0 + mb.RT) + (double)nrow * NU * mb.R : 1e300;
+    // (stage 1 on the matrix cores: 16 multiply-adds per sample there, the 4 of the evaluation beside them on the vector units)
+    mb.cost_lowrank = (lowrank_ok && mb.RT) ? (mb.mfma ? nsamp * 18.0 : 1.6 * nsamp * (4.0 + mb.RT)) + (double)nrow * NU * mb.R : 1e300;
     mb.cost_full = (double)nrow * nsamp * 0.5 + nsamp * 6.0 * mb.nog;
     int form = (mb.cost_lowrank <= mb.cost_full) ? 0 : 1;
     if (form_force == 0) { if (!lowrank_ok || !mb.RT) { mb.why = "low-rank form: " + why_lr; return; } form = 0; }
     if (form_force == 1) form = 1;
     mb.form = form;
+    if (form != 0) mb.mfma = false;
     if (form == 0) {
         mb.cld = mb.RT;
-        jxt::mix_stage1_operator(U, mb.r, by, mb.ns, S, B, NU, mb.cols.wld, mb.cld, mb.Cm);
+        jxt::mix_stage1_operator(U, mb.r, by, mb.ns, S, B, NU, (mb.cols.wld + 4 + 1) & ~1, mb.cld, mb.Cm);   // (zero rows behind the last: the matrix-core kernel reads whole groups of four)
         const size_t K = (size_t)NU * mb.R;
         mb.ksteps = (int)((K + 3) / 4);
         mb.krows = 4 * ((size_t)mb.ksteps + (size_t)JX_MIX_KSPLIT_MAX * JX_OPG_RD + JX_OPG_RD);
@@ -546,6 +568,7 @@ static int mix_setup(jx_ctx* ctx, const MixBuild& mb, long long tW) {
     const int64_t before = ctx->device_bytes;
     int rc;
     m.form = mb.form; m.RT = mb.RT; m.nxt = mb.nxt; m.r = mb.r; m.ns = mb.ns; m.ksteps = mb.ksteps; m.tW = tW; m.tol = mb.tol;
+    m.mfma = mb.mfma; m.r_tol = mb.r_tol;
     int* qi; double* qd;
     const size_t esz = ctx->f32 ? sizeof(float) : sizeof(double);
     const size_t cft_rows = (size_t)N + 2 * JX_MIX_NS + 2;
@@ -592,12 +615,29 @@ static int launch_mix(jx_ctx* ctx, int n, EvSet* es) {
         JxMix mx = m.mx;
         mx.n = n;
         // block = gpb walker groups x usplit pieces of one column (usplit: a setting of the context, never of the launch)
-        const int usp = mx.usplit, ngrp = (n + 63) / 64, gpb = std::max(1, std::min(m.wpb / usp, ngrp)), wpb = gpb * usp;
+        const int usp = mx.usplit, ngrp = (n + 63) / 64;
+        int wcap = m.wpb;
+        size_t lds_c = 0;
+        const int crows = (mx.wld + 4 + 1) & ~1;
+        if (m.mfma) {
+            // the matrix-core kernel keeps the operator in LDS: blocks of 8 waves, two per CU -- or of 16, one per CU, when the
+            // operator is too large for two copies (sides beyond ~600)
+            lds_c = sizeof(double) * (16 * (size_t)crows + 4 * (size_t)mx.wld);
+            wcap = (2 * (lds_c + sizeof(double) * JX_MXM_REGION(usp) * (8 / usp)) <= 158 * 1024) ? 8 : 16;
+            if (m.wpb_force > 0) wcap = m.wpb_force;
+        }
+        const int gpb = std::max(1, std::min(wcap / usp, ngrp)), wpb = gpb * usp;
         const int nq = (ngrp + gpb - 1) / gpb;
         mx.cper = (nq <= 8 && 8 % nq == 0) ? 8 / nq : 0;
         const dim3 g1((unsigned)(mx.cper ? 8 * ((mx.NU + mx.cper - 1) / mx.cper) : nq * mx.NU));
-        const size_t lds1 = sizeof(double) * (size_t)gpb * (usp - 1) * m.RT * 64;
+        const size_t lds1 = m.mfma ? lds_c + sizeof(double) * JX_MXM_REGION(usp) * gpb : sizeof(double) * (size_t)gpb * (usp - 1) * m.RT * 64;
+        if (lds1 > 158 * 1024) { ctx->err = "stage 1: the operator and the sample rows do not fit the LDS (lower JOXSZ_MIX_USPLIT)"; return JX_ERR_UNSUPPORTED; }
         bool done = false;
+        if (m.mfma) {
+            if (ctx->f32) hipLaunchKernelGGL((jx_rowmix_mfma_kernel<JX_MIX_NS, float2>), g1, dim3(64 * wpb), lds1, st, mx, crows, reinterpret_cast<const float2*>(m.cft), m.Dt);
+            else hipLaunchKernelGGL((jx_rowmix_mfma_kernel<JX_MIX_NS, double2>), g1, dim3(64 * wpb), lds1, st, mx, crows, reinterpret_cast<const double2*>(m.cft), m.Dt);
+            done = true;
+        }
 #define JX_MIX_GO(Rv) if (!done && m.RT == Rv) { \
             if (ctx->f32) hipLaunchKernelGGL((jx_rowmix_kernel<Rv, JX_MIX_NS, float2>), g1, dim3(64 * wpb), lds1, st, mx, reinterpret_cast<const float2*>(m.cft), m.Dt); \
             else hipLaunchKernelGGL((jx_rowmix_kernel<Rv, JX_MIX_NS, double2>), g1, dim3(64 * wpb), lds1, st, mx, reinterpret_cast<const double2*>(m.cft), m.Dt); \
@@ -843,7 +883,9 @@ static int finalize_impl(jx_ctx* ctx) {
     if (const char* e = env_str("JOXSZ_MIX_FORM")) { if (!strcmp(e, "lowrank")) ctx->form_force = 0; else if (!strcmp(e, "full")) ctx->form_force = 1; }
     if (const char* e = env_str("JOXSZ_MAP_PAIR")) ctx->map_pair = atoi(e) != 0;
     if (const char* e = env_str("JOXSZ_MIX_USPLIT")) { const int v = atoi(e); if (v >= 1 && v <= 4) ctx->usplit = v; }
-    if (const char* e = env_str("JOXSZ_MIX_WPB")) { const int v = atoi(e); if (v >= 1 && v <= 4) ctx->mix.wpb = v; }
+    if (const char* e = env_str("JOXSZ_MIX_RANKCAP")) { const int v = atoi(e); if (v >= 0 && v <= 16) ctx->rank_cap = v; }
+    if (const char* e = env_str("JOXSZ_MIX_MFMA")) ctx->mix_mfma = atoi(e) != 0;
+    if (const char* e = env_str("JOXSZ_MIX_WPB")) { const int v = atoi(e); if (v >= 1 && v <= 16) { ctx->mix.wpb_force = v; ctx->mix.wpb = std::min(v, 4); } }
     if (const char* e = env_str("JOXSZ_MIX_KSPLIT")) { const int v = atoi(e); if (v >= 1) ctx->mix.ksplit_force = v; }
     if (const char* e = env_str("JOXSZ_ABEL_GEMM")) ctx->abel_gemm = atoi(e) != 0;
     ctx->op_narrow = env_str("JOXSZ_OP_NARROW") != nullptr;
@@ -1052,6 +1094,8 @@ static int finalize_impl(jx_ctx* ctx) {
         if ((rc = mix_setup(ctx, mixb, tW2))) return rc;
         if ((rc = dev_put(ctx, h_Tm.data(), h_Tm.size(), &ctx->d_Tm))) return rc;
         if ((rc = dev_new(ctx, (size_t)chunk * N, &ctx->d_ppc, true))) return rc;
+        HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_rowmix_mfma_kernel<JX_MIX_NS, double2>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+        HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_rowmix_mfma_kernel<JX_MIX_NS, float2>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
 #define JX_OPG_ATTR(Xv) HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_opgemm_kernel<1, Xv, double2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); \
         HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_opgemm_kernel<1, Xv, float2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
         JX_MIX_NXTS(JX_OPG_ATTR)
@@ -1378,7 +1422,7 @@ int jx_finalize(jx_ctx* ctx) {
     int rc = finalize_impl(ctx);
     if (rc) return rc;
     if (const char* e = env_str("JOXSZ_TRUNC_PROBE")) { if (atoi(e) == 0) return JX_OK; }
-    if (ctx->conv_mode != 2 || ctx->mix.form != 0 || ctx->f32) return JX_OK;
+    if (ctx->conv_mode != 2 || ctx->mix.form != 0) return JX_OK;
     // The low-rank form drops the small singular values of the transfer-function weights.  What that costs is measured on the
     // caller's own beam / transfer function / prior box (measure_truncation); beyond the bounds the tables are rebuilt with
     // a cut ten times tighter -- in place: stream, communicator and every other piece of the context stay -- until the
@@ -1390,8 +1434,12 @@ int jx_finalize(jx_ctx* ctx) {
         // inside the 1e-6 the log-posterior is held to.  (An estimate that could not be taken counts as too large.)
         return !(ctx->trunc_est[0] >= 0.0 && ctx->trunc_est[0] <= ctx->trunc_bound && ctx->trunc_est[2] >= 0.0 && ctx->trunc_est[2] <= ctx->trunc_bound_ll);
     };
-    while (!ctx->tol_pinned && ctx->mix.form == 0 && ctx->mix.tol > 2e-13 && too_large()) {
-        const double tol = std::max(1e-13, ctx->mix.tol * 1e-1);
+    // (an f32 context is measured and reported but never rebuilt: the rounding of its spline arrays is of the bounds' size)
+    while (!ctx->tol_pinned && !ctx->f32 && ctx->mix.form == 0 && (ctx->mix.tol > 2e-13 || ctx->mix.r < ctx->mix.r_tol) && too_large()) {
+        // first the cap on the rank goes (the same cut, every term above it kept), then the cut tightens
+        const bool capped = ctx->mix.r < ctx->mix.r_tol;
+        if (capped) { ctx->rank_cap = 0; ctx->trunc_uncapped += 1; }
+        const double tol = capped ? ctx->mix.tol : std::max(1e-13, ctx->mix.tol * 1e-1);
         MixBuild mb;
         plan_mix(ctx, host_vec<double>(ctx, JX_T_BEAM_2D), host_vec<double>(ctx, JX_T_FILTERING), host_vec<double>(ctx, JX_T_R_PP), tol, ctx->form_force, ctx->mix.tW, mb);
         if (!mb.ok) { ctx->err = "contracted route, tighter singular-value cut: " + mb.why; return JX_ERR_UNSUPPORTED; }
@@ -1767,11 +1815,13 @@ int jx_debug_workspace(jx_ctx* ctx, int which, void** dev, int32_t geom[4]) {
     return JX_OK;
 }
 
-int jx_get_truncation(jx_ctx* ctx, double out[8]) {
+int jx_get_truncation(jx_ctx* ctx, double out[12]) {
     if (!ctx || !ctx->finalized || !out) return JX_ERR_STATE;
     const bool lr = ctx->conv_mode == 2 && ctx->mix.form == 0;
     out[0] = lr ? ctx->mix.tol : 0.0; out[1] = ctx->trunc_est[0]; out[2] = lr ? (double)ctx->mix.r : 0.0; out[3] = (double)ctx->trunc_retried;
     out[4] = (double)ctx->trunc_points; out[5] = ctx->trunc_bound; out[6] = ctx->trunc_est[1]; out[7] = ctx->trunc_est[2];
+    out[8] = lr ? (double)ctx->mix.r_tol : 0.0; out[9] = ctx->trunc_bound_ll; out[10] = (lr && ctx->mix.mfma) ? 1.0 : 0.0;
+    out[11] = (double)ctx->trunc_uncapped;
     return JX_OK;
 }
 

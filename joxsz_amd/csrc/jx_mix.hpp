@@ -182,6 +182,176 @@ jx_rowmix_kernel(JxMix m, const TC* __restrict__ cft, double* __restrict__ Dt) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Stage 1 on the fp64 matrix cores, for R <= 16 rows per column (one 16-row tile).  Same walk as jx_rowmix_kernel: one
+// wave = one piece of column x' x 64 walkers, lane = walker, knots in the ring of NS named slots, the four spline weights
+// of a sample through the scalar unit, the sample evaluated by its walker's lane (4 FMAs; joxsz_funcs.py:460-462).  What
+// changes is the mixing: instead of R scalar-operand FMAs per sample, the samples of four consecutive rows u0 .. u0+3 go
+// through four wave-private LDS rows into the B operand of v_mfma_f64_16x16x4 (lane l: row u0 + (l >> 4), walker
+// 16 t + (l & 15) of tile t), the A operand is C[u0 + (l >> 4)][l & 15] -- 512 contiguous bytes of the row-major operator,
+// which the block holds in LDS (the only vector-memory requests of the walk are then the knots, and their counted waits stay
+// exact) -- and D[j][walker] accumulates in the matrix cores' layout (register g of lane l: j = 4 g + (l >> 4), walker
+// 16 t + (l & 15)): four matrix instructions per four rows and 64 walkers.  The operands of a group are requested when its
+// fourth sample has been written and used one group later (nothing waits on the LDS round trip; LDS serves a wave's requests
+// in order, so the next group's samples may overwrite the rows at once).  The groups of four are a function of the piece
+// alone, so a walker's sums do not depend on the launch.
+//   sm: [crows][16] operator C | [wld][4] spline weights of the column | [gpb][JX_MXM_REGION(usplit)] per walker group: the sample rows of its waves (wave xh at
+//       xh * JX_MXM_RING), later the sums of the later pieces [usplit - 1][16][64]
+// ------------------------------------------------------------------------------------------------------------------
+#define JX_MXM_LD 80
+#define JX_MXM_RING (4 * JX_MXM_LD)
+#define JX_MXM_REGION(usp) ((usp) > 1 ? (((usp) - 1) * 1024 > (usp) * JX_MXM_RING ? ((usp) - 1) * 1024 : (usp) * JX_MXM_RING) : JX_MXM_RING)
+
+template <int NS, typename TC>
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4)))
+jx_rowmix_mfma_kernel(JxMix m, int crows, const TC* __restrict__ cft, double* __restrict__ Dt) {
+    static_assert(NS == 8, "one aligned 8-dword scalar load carries the sample counts of a group of NS segments");
+    extern __shared__ __attribute__((aligned(16))) double sm_mix[];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
+    const int usp = m.usplit, gpb = wpb / usp;
+    const int xh = wv % usp, gi = wv / usp;
+    const int ngrp = (m.n + 63) >> 6, nq = (ngrp + gpb - 1) / gpb;
+    const int id = blockIdx.x;
+    int gq, xq;
+    if (m.cper > 0) { const int xcd = id & 7, jj = id >> 3; gq = xcd % nq; xq = xcd / nq + m.cper * jj; }
+    else { gq = id % nq; xq = id / nq; }
+    const int grp = gq * gpb + gi;
+    const bool active = grp < ngrp && xq < m.NU;               // (no early exit: every wave of the block meets the barriers below)
+    const int xc = min(xq, m.NU - 1), xv = xc * usp + xh;      // column, piece
+    const int ur = __builtin_amdgcn_readfirstlane(m.urange[xv]), ubeg = ur & 0xffff;
+    const size_t tW = (size_t)m.tW;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<TC*>(cft), 0, m.cft_bytes, 0x00020000);
+    const unsigned loff = (unsigned)((unsigned)grp * 64u + (unsigned)lane) * (unsigned)sizeof(TC);
+    const unsigned kstride = (unsigned)(tW * sizeof(TC));
+    const int k0 = __builtin_amdgcn_readfirstlane(m.seg0[xv]), nseg = active ? __builtin_amdgcn_readfirstlane(m.nseg[xv]) : 0;
+    const int* __restrict__ sc = m.seg + (size_t)xv * m.segld;                 // [segld], zero padded: whole groups of NS, one group ahead
+    TC q[NS];
+    unsigned kb = (unsigned)k0 * kstride;
+#pragma unroll
+    for (int i = 0; i < NS - 1; ++i) { q[i] = jx_mx_ldknot<TC>(rs, loff, kb); kb += kstride; }
+    // the operator and the column's spline weights into LDS, once per block
+    double* __restrict__ wsm = sm_mix + (size_t)crows * 16;                     // [wld][4]
+    {
+        const double2* __restrict__ src = reinterpret_cast<const double2*>(m.Cm);
+        double2* dst = reinterpret_cast<double2*>(sm_mix);
+        for (int i = threadIdx.x; i < crows * 8; i += blockDim.x) dst[i] = src[i];
+        const double2* __restrict__ wsrc = reinterpret_cast<const double2*>(m.w4 + (size_t)xc * m.wld * 4);
+        double2* wdst = reinterpret_cast<double2*>(wsm);
+        for (int i = threadIdx.x; i < m.wld * 2; i += blockDim.x) wdst[i] = wsrc[i];
+    }
+    double* __restrict__ region = wsm + (size_t)m.wld * 4 + (size_t)gi * JX_MXM_REGION(usp);
+    double* __restrict__ ring = region + xh * JX_MXM_RING;
+    const double* __restrict__ bp = ring + (lane >> 4) * JX_MXM_LD + (lane & 15);   // B operand of tile t: bp[16 t]
+    const double* __restrict__ ap = sm_mix + (size_t)ubeg * 16 + lane;             // A operand of the group that starts at row ubeg + c: ap[16 c]
+    __syncthreads();
+    jx_mx_v4d acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = jx_mx_v4d{0.0, 0.0, 0.0, 0.0};
+    double bq[4] = {0.0, 0.0, 0.0, 0.0}, av = 0.0;                             // operands of the group that waits for its matrix instructions
+    int c = 0;                                                                 // samples written so far
+    auto boundary = [&]() {                                                    // c is a multiple of 4: rows c-4 .. c-1 are complete in the ring
+#ifdef JOXSZ_ABLATIONS
+        if (!(m.dbg & 4))
+#endif
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bq[t], acc[t], 0, 0, 0);
+#ifdef JOXSZ_ABLATIONS
+        if (!(m.dbg & 16))
+#endif
+        {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bq[t] = bp[16 * t];
+        av = ap[(c - 4) * 16];
+        }
+    };
+    // The four spline weights of a sample do not depend on the walker.  They wait in a window of 64 samples, one sample per
+    // lane (refilled from the LDS copy every 64 samples), and reach the multiply-adds as scalar operands through v_readlane:
+    // no memory request sits between two samples of a wave.
+    int wl[8];
+    auto refill = [&]() {
+        const int u = min(ubeg + c + lane, m.wld - 1);
+        const int4 lo = *reinterpret_cast<const int4*>(wsm + (size_t)u * 4), hi = *reinterpret_cast<const int4*>(wsm + (size_t)u * 4 + 2);
+        wl[0] = lo.x; wl[1] = lo.y; wl[2] = lo.z; wl[3] = lo.w; wl[4] = hi.x; wl[5] = hi.y; wl[6] = hi.z; wl[7] = hi.w;
+    };
+    refill();
+    int cntn[NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) cntn[j] = sc[j];
+    for (int s0 = 0; s0 < nseg; s0 += NS) {
+        int cnt[NS];
+#pragma unroll
+        for (int j = 0; j < NS; ++j) { cnt[j] = cntn[j]; cntn[j] = sc[s0 + NS + j]; }
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+#ifdef JOXSZ_ABLATIONS
+            if (!(m.dbg & 1))
+#endif
+            q[(j + NS - 1) % NS] = jx_mx_ldknot<TC>(rs, loff, kb);
+            kb += kstride;
+            for (int i = 0; i < cnt[j]; ++i) {
+                const int sl = c & 63;
+                const double wa = __hiloint2double(__builtin_amdgcn_readlane(wl[1], sl), __builtin_amdgcn_readlane(wl[0], sl));
+                const double wb = __hiloint2double(__builtin_amdgcn_readlane(wl[3], sl), __builtin_amdgcn_readlane(wl[2], sl));
+                const double wc = __hiloint2double(__builtin_amdgcn_readlane(wl[5], sl), __builtin_amdgcn_readlane(wl[4], sl));
+                const double wd = __hiloint2double(__builtin_amdgcn_readlane(wl[7], sl), __builtin_amdgcn_readlane(wl[6], sl));
+                double f = wa * (double)q[j].x;
+                f = fma(wb, (double)q[(j + 1) % NS].x, f);
+                f = fma(wc, (double)q[j].y, f);
+                f = fma(wd, (double)q[(j + 1) % NS].y, f);
+#ifdef JOXSZ_ABLATIONS
+                if (!(m.dbg & 8))
+#endif
+                ring[(c & 3) * JX_MXM_LD + lane] = f;
+                ++c;
+                if ((c & 3) == 0) {
+                    boundary();
+                    if ((c & 63) == 0) refill();
+                }
+            }
+        }
+    }
+    // the last, partial group: rows beyond the piece enter as zero samples (their operator rows are finite)
+    if (c & 3) {
+        while (c & 3) { ring[(c & 3) * JX_MXM_LD + lane] = 0.0; ++c; }
+        boundary();
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bq[t], acc[t], 0, 0, 0);
+    if (usp > 1) {
+        __syncthreads();                                        // (the sums go where the sample rows were)
+        if (xh > 0) {
+            double* __restrict__ sp = region + (size_t)(xh - 1) * 1024 + lane;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) sp[(t * 4 + g) * 64] = acc[t][g];
+        }
+        __syncthreads();
+        if (xh == 0) {
+            for (int hh = 1; hh < usp; ++hh) {                  // fixed order: piece 0 + piece 1 (+ piece 2 ...)
+                const double* __restrict__ sp = region + (size_t)(hh - 1) * 1024 + lane;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) acc[t][g] += sp[(t * 4 + g) * 64];
+            }
+        }
+    }
+    if (xh == 0 && active) {
+        const int lk = lane >> 4, li = lane & 15;
+        double* __restrict__ dp = Dt + (size_t)xq * m.R * tW + (size_t)grp * 64 + li;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int j = 4 * g + lk;
+            if (j < m.R) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) dp[(size_t)j * tW + 16 * t] = acc[t][g];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Stage 2 and the full form: P[ks][w][x] = sum_{kappa in slice ks} a_kappa(w) Op[x][kappa] on v_mfma_f64_16x16x4.
 //   A operand (M = walkers): lane l holds a_kappa(w) for w = tile + (l & 15), kappa = 4 step + (l >> 4)
 //       LOAD: a = Dt[kappa][w]                         (stage-1 output, 128-byte runs)

@@ -653,7 +653,7 @@ inline bool mix_column_tables(const std::vector<double>& Qtab /*[qn][qn]: (|iy-c
         }
         t.maxk = std::max(t.maxk, kof[(size_t)a * NU + NU - 1]);
     }
-    t.segld = (maxseg + 15) & ~7;                                             // zero padded: the kernel reads whole groups of 8
+    t.segld = (maxseg + 23) & ~7;                                             // zero padded: the kernels read whole groups of 8, one group ahead
     t.seg.assign((size_t)NU * usplit * t.segld, 0);
     for (int a = 0; a < NU; ++a)
         for (int h = 0; h < usplit; ++h) {

@@ -10,7 +10,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('JOXSZ_LIB') or os.path.join(_HERE, 'csrc', 'libjoxsz_hip.so')    # JOXSZ_LIB: A/B builds
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # must list every function include/joxsz_hip.h declares (tests/test_abi.py checks this)
 EXPORTS = (
@@ -207,10 +207,11 @@ class HipContext:
         return d
 
     def _truncation(self):
-        tr = (ctypes.c_double * 8)()
+        tr = (ctypes.c_double * 12)()
         self._chk(self.lib.jx_get_truncation(self._h, tr), 'jx_get_truncation')
         return dict(tol=tr[0], est_rel_row_err=tr[1], rank=int(tr[2]), retried=int(tr[3]), points=int(tr[4]), bound=tr[5],
-                    est_rel_row_err_box=tr[6], est_rel_sz_like_err_box=tr[7])
+                    est_rel_row_err_box=tr[6], est_rel_sz_like_err_box=tr[7], rank_above_cut=int(tr[8]), bound_sz_like=tr[9],
+                    stage1_on_matrix_cores=bool(tr[10]), cap_removed=int(tr[11]))
 
     # -- plumbing --
     def _chk(self, rc, what):
