@@ -27,6 +27,9 @@ Prints ONE JSON line (rank 0) with
   `roofline_step`       the whole step against the HBM roofline (rocprofv3 PMC bytes of the committed profile / ms_per_step);
   `north_star_abel_map_kernel`  the fused profile -> Abel -> spline -> full S x S map kernel the north_star's ">= 60 % of
                         the HBM roofline" is about (jx_map_kernel_time), against the nominal and the measured copy roofline;
+  `north_star_route`    the whole step of north_star's literal design (that kernel, then the rocFFT sequence) on the same walkers;
+  `host_pointer`        jx_eval with host pointers, one synchronisation per call: the path emcee exercises;
+  `gather_ms_per_step`  (N > 1, or JOXSZ_BENCH_FORCE_DIST=1) the all-gather's own duration on its stream;
   `cpu_baseline`        the numpy/scipy oracle on this box's host cores (process pool, single process, per-stage ms);
   `other_configs`       strong-scaling rows of BASELINE configs[3] and configs[4] (this rank's shard).
 """
@@ -171,12 +174,13 @@ def spawn_ranks(n, argv, timeout_s=3000.0, python=None, script=None):
     script = script or os.path.abspath(__file__)
     port = int(os.environ.get('MASTER_PORT', 0)) or random.randint(20000, 45000)
     tag = 'bench_%d_%d' % (os.getpid(), int(time.time() * 1e3))
+    t_launch = repr(time.time())                          # one launch start for all ranks (a reader rejects an id file older than it)
     import tempfile
     out0 = tempfile.TemporaryFile(mode='w+')              # rank 0's stdout: a file, so that no amount of output can block it on a full pipe
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), JOXSZ_RDZV_TAG=tag, JOXSZ_RDZV_T0=repr(time.time()),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), JOXSZ_RDZV_TAG=tag, JOXSZ_RDZV_T0=t_launch,
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
         procs.append(subprocess.Popen([python, script] + argv, env=env, stdout=out0 if r == 0 else subprocess.DEVNULL, stderr=None))
     t0 = time.time()
@@ -207,6 +211,17 @@ def spawn_ranks(n, argv, timeout_s=3000.0, python=None, script=None):
     out0.close()
     lines = [l for l in out.strip().splitlines() if l.strip()]
     return rc, (lines[-1] if lines else '')
+
+
+def agree_on_side_times(comm, dts):
+    """The one collective of the side measurements: element-wise maximum over the ranks of this rank's times per step (+inf where
+    the measurement failed here).  Called OUTSIDE every exception handler, after rank-local measurements that cannot raise:
+    every rank reaches it whatever happened before, so no rank is left waiting in it (a collective inside
+    try/except is a deadlock when one rank throws).  A rank that dies outright takes the launch down through the launcher."""
+    dts = [float(d) if d is not None and np.isfinite(d) else np.inf for d in dts]
+    if comm is None:
+        return dts
+    return [float(v) for v in comm.max_over_ranks(dts)]
 
 
 def time_steps(ctx, th_ptr, W, lp_ptr, steps, warmup):
@@ -305,23 +320,30 @@ def main():
     lp_ptr = ctx.dev_alloc(8 * W)
     ctx.h2d(th_ptr, theta)
     comm = None
-    all_ptr = None
+    lp_ptrs, all_ptrs = [lp_ptr], [None]
+    overlap = multi and not os.environ.get('JOXSZ_BENCH_STRICT_GATHER')
     if multi:
-        # RCCL through the library's own C-ABI (jx_comm_*): the gather is enqueued on the context's stream behind the
-        # evaluation, the host never waits inside a step, no torch in this process
+        # RCCL through the library's own C-ABI (jx_comm_*), no torch in this process.  The gather of step n runs on a second
+        # stream of the context behind an event; step n+1 writes the OTHER of two output buffers, so its kernels overlap the
+        # gather (a buffer still being sent holds back only the evaluation that would overwrite it).  The host never waits
+        # inside a step.  JOXSZ_BENCH_STRICT_GATHER=1: every collective in order on the compute stream instead.
         from joxsz_amd.dist import RcclGather
-        comm = RcclGather(ctx, rank=rank, world=world)
-        all_ptr = ctx.dev_alloc(8 * W * world)
+        comm = RcclGather(ctx, rank=rank, world=world, overlap=overlap)
+        lp_ptrs = [lp_ptr, ctx.dev_alloc(8 * W)]
+        all_ptrs = [ctx.dev_alloc(8 * W * world), ctx.dev_alloc(8 * W * world)]
+    nstep = [0]
 
     def step():
-        ctx.eval_device(th_ptr, W, lp_ptr)
+        k = nstep[0] % len(lp_ptrs)
+        ctx.eval_device(th_ptr, W, lp_ptrs[k])
         if comm is not None:
-            comm.all_gather(lp_ptr, all_ptr, W)
+            comm.all_gather(lp_ptrs[k], all_ptrs[k], W)
+        nstep[0] += 1
 
     def fence():
         if comm is not None:
             comm.barrier()
-        ctx.sync()
+        ctx.sync()                                           # (both streams of the context)
 
     for _ in range(args.warmup):
         step()
@@ -348,18 +370,44 @@ def main():
             step()
         fence()
         tm = ctx.timing()
+    gather_ms = None
+    if comm is not None:
+        gms, gn = ctx.comm_gather_time()                     # the all-gathers' own durations (events on their stream) of the stage pass
+        gather_ms = gms / max(1, gn)
     ctx.timing_enable(False)
 
+    last = (nstep[0] - 1) % len(lp_ptrs)
     if comm is not None:
         elapsed = comm.max_over_ranks(elapsed)
         final = np.empty(W * world)
-        ctx.d2h(final, all_ptr)
+        ctx.d2h(final, all_ptrs[last])
     else:
         final = np.empty(W)
         ctx.d2h(final, lp_ptr)
     if not np.all(np.isfinite(final)):
         raise SystemExit('bench: non-finite log-probabilities in the timed batch')
     lp_own = final[rank * W:(rank + 1) * W] if comm is not None else final
+    # ---- every figure of the headline is fixed from here on; nothing below can change or lose it.  The side measurements run
+    #      rank-locally inside try/except WITHOUT collectives; the ranks meet once more, in one all-reduce outside any
+    #      exception handler, to agree on the strong-scaling rows (a rank that failed contributes +inf).
+
+    # the path emcee calls (joxsz_main.py:206, vectorize=True): host theta in, host log-probabilities out, one sync per call
+    host_ptr = None
+    if rank == 0:
+        try:
+            for _ in range(3):
+                ctx.eval(theta)
+            kk = max(5, min(args.steps, 50))
+            t = time.perf_counter()
+            for _ in range(kk):
+                got_h = ctx.eval(theta)
+            dt = (time.perf_counter() - t) / kk
+            host_ptr = {'value': W / dt, 'unit': 'walker-likelihoods/s', 'ms_per_call': 1e3 * dt, 'calls': kk,
+                        'max_abs_diff_vs_device_resident': float(np.max(np.abs(got_h - lp_own))),
+                        'note': 'jx_eval: host parameter vectors in (%d B per walker over PCIe), host log-probabilities out, one stream '
+                                'synchronisation per call -- what emcee.EnsembleSampler(..., vectorize=True) exercises (joxsz_main.py:206)' % (8 * theta.shape[1])}
+        except Exception as exc:
+            host_ptr = {'error': str(exc)}
 
     # the fp32 variant on the same walkers (BASELINE configs[4]'s tolerance sweep): beside the f64 metric, never instead of it
     f32 = None
@@ -404,11 +452,40 @@ def main():
         except Exception as exc:
             full_map = {'error': str(exc)}
 
+    # north_star's literal design as a whole step: fused profile -> Abel -> map kernel, then the rocFFT sequence for the beam
+    # convolution and the transfer function (joxsz_funcs.py:460-467 executed step by step), same walkers, same problem
+    ns_route = None
+    if rank == 0 and comm is None and args.route == 'map' and not args.no_full_map and ctx.conv == 'custom':
+        try:
+            pr = JoxszPosterior(pb, device=local_rank, conv='rocfft', max_batch=W)
+            cr = pr.ctx
+            tr_, lr_ = cr.dev_alloc(theta.nbytes), cr.dev_alloc(8 * W)
+            cr.h2d(tr_, theta)
+            dt = time_steps(cr, tr_, W, lr_, 5, 2)
+            cr.timing_enable(1); cr.timing_reset()
+            for _ in range(3):
+                cr.eval_device(tr_, W, lr_)
+            tmr = cr.timing()
+            cr.timing_enable(False)
+            lpr = np.empty(W)
+            cr.d2h(lpr, lr_)
+            ns_route = {'route': 'jx_abel_map_sym_kernel -> rocFFT R2C -> jx_beam_mul_kernel -> rocFFT C2R -> rocFFT R2C of the S x S window -> jx_tail_kernel',
+                        'value': W / dt, 'unit': 'walker-likelihoods/s', 'ms_per_step': 1e3 * dt, 'walkers_per_launch': cr.chunk, 'fft_pad': cr.fft_pad,
+                        'stage_ms_per_step': {k: tmr[k] / 3 for k in ('prep_ms', 'abel_map_ms', 'beam_fft_ms', 'tf_fft_ms', 'tail_ms')},
+                        'max_rel_diff_vs_default_route': float(np.max(np.abs(lpr - lp_own) / np.abs(lp_own))),
+                        'speedup_of_default_route': None,
+                        'note': 'the same library with conv = rocfft: every map, its padded spectrum and the convolved map go through HBM'}
+            pr.close()
+        except Exception as exc:
+            ns_route = {'error': str(exc)}
+
     # the same batch on the collapsed route, only when asked for (--route operator): not the BASELINE metric
     # strong-scaling rows of the other BASELINE configs: this rank's shard of configs[3] (4096 walkers, 512^2) and of
     # configs[4] (8192 walkers, 1024^2 / 1000-pt, fp64 and fp32), a few steps each, outside the timed region
     other = None
-    if args.route == 'map' and not args.no_other_configs and (args.S, args.N, pb.sz_only) == (512, 500, False):
+    want_other = args.route == 'map' and not args.no_other_configs and (args.S, args.N, pb.sz_only) == (512, 500, False)
+    dts = [np.inf, np.inf, np.inf]                            # this rank's time per step: configs[3], configs[4] f64, configs[4] f32
+    if want_other:
         other = {}
         try:
             from joxsz_amd.dist import shard_bounds
@@ -420,18 +497,15 @@ def main():
             c3 = p3c.ctx if p3c is not None else ctx
             p3t, l3t = c3.dev_alloc(th3.nbytes), c3.dev_alloc(8 * n3)
             c3.h2d(p3t, th3)
-            dt = time_steps(c3, p3t, n3, l3t, 5, 2)
-            if comm is not None:
-                dt = comm.max_over_ranks(dt)
+            dts[0] = time_steps(c3, p3t, n3, l3t, 5, 2)
             other['configs[3]'] = {'workload': '4096 walkers, 512x512 map, 500-pt grid, joint; %d walkers on this rank' % n3,
-                                   'value': 4096 / dt, 'unit': 'walker-likelihoods/s', 'ms_per_step': 1e3 * dt, 'scaling': 'strong', 'dtype': 'f64',
-                                   'walkers_per_launch': c3.chunk}
+                                   'unit': 'walker-likelihoods/s', 'scaling': 'strong', 'dtype': 'f64', 'walkers_per_launch': c3.chunk}
             if p3c is not None:
                 p3c.close()
             lo, hi = shard_bounds(8192, world, rank)
             n4 = hi - lo
             pb4 = datasets.synthetic_problem(S=1024, N=1000, seed=0)
-            for dt_name in ('f64', 'f32'):
+            for i4, dt_name in enumerate(('f64', 'f32')):
                 p4 = JoxszPosterior(pb4, device=local_rank, dtype=dt_name, max_batch=n4)
                 c4 = p4.ctx
                 cand4 = datasets.walker_ball(pb4, 256, spread=0.02, seed=5)
@@ -439,15 +513,22 @@ def main():
                 th4 = np.ascontiguousarray(np.resize(ok4, (n4, ok4.shape[1])))
                 a4, b4 = c4.dev_alloc(th4.nbytes), c4.dev_alloc(8 * n4)
                 c4.h2d(a4, th4)
-                dt = time_steps(c4, a4, n4, b4, 3, 1)
-                if comm is not None:
-                    dt = comm.max_over_ranks(dt)
+                dts[1 + i4] = time_steps(c4, a4, n4, b4, 3, 1)
                 other['configs[4] ' + dt_name] = {'workload': '8192 walkers, 1024x1024 map, 1000-pt grid, joint; %d walkers on this rank' % n4,
-                                                  'value': 8192 / dt, 'unit': 'walker-likelihoods/s', 'ms_per_step': 1e3 * dt, 'scaling': 'strong',
+                                                  'unit': 'walker-likelihoods/s', 'scaling': 'strong',
                                                   'dtype': dt_name, 'conv_layout': c4.conv_layout, 'walkers_per_launch': c4.chunk}
                 p4.close()
         except Exception as exc:
-            other['error'] = str(exc)
+            other['error'] = '%s: %s' % (type(exc).__name__, exc)
+    if want_other:
+        dts = agree_on_side_times(comm, dts)
+    if other is not None:
+        for key, tot, dt in (('configs[3]', 4096, dts[0]), ('configs[4] f64', 8192, dts[1]), ('configs[4] f32', 8192, dts[2])):
+            if key in other:
+                if np.isfinite(dt):
+                    other[key].update(value=tot / dt, ms_per_step=1e3 * dt)
+                else:
+                    other[key] = {'error': 'not measured on every rank'}
 
     if rank == 0:
         S = args.S
@@ -481,7 +562,7 @@ def main():
                 roof = {'kernel': 'jx_rowmix_kernel', 'bound': 'valu (fp64 vector FMA; the same 78.6 TFLOP/s as the dense fp64 matrix-core peak)',
                         'achieved': ach, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / FP64_PEAK_TFLOPS,
                         'traffic': pmc_traffic(pj, 'jx_rowmix_kernel', walkers_per_launch),
-                        'traffic_source': (pj or {}).get('file'),
+                        'traffic_source': (pj or {}).get('file'), 'traffic_measured_in_this_run': False,
                         'peak_measured': FP64_FMA_MEASURED_TFLOPS, 'frac_of_peak_measured': ach / FP64_FMA_MEASURED_TFLOPS,
                         'launch_ms': k_ms, 'launch_ms_source': 'HIP events around this kernel inside the timed region (jx_timing_enable(2))',
                         'flops_per_launch': fl, 'share_of_step': k_ms / max(1e-12, ms_step * walkers_per_launch / W),
@@ -502,10 +583,16 @@ def main():
                      'note': 'nrow x K x walkers product on v_mfma_f64_16x16x4 (nrow = %d outputs, K = %d rows of the operator)' % (nrow, K4)}
             if not lowrank:
                 roof, roof2 = roof2, None
+        # HBM bytes of the step: exactly the kernels of the step (stage_kernels), nothing else the PMC file holds
+        step_names = ('jx_prep_kernel', 'jx_abel_gemm_kernel', 'jx_rowmix_kernel', 'jx_rowmix_mfma_kernel', 'jx_opgemm_kernel', 'jx_tail_row_kernel')
         step_pmc = None
-        if pj:
-            step_pmc = sum(d['total_bytes'] for n, d in pj['kernels'].items() if n.startswith(('jx_', 'void jx_')) and 'operator' not in n
-                           and 'abel_map' not in n and 'copy' not in n) / pj.get('walkers_per_launch', 1024) * W
+        step_pmc_kernels = None
+        if pj and mixed:
+            step_pmc_kernels = {n.split('<')[0].replace('void ', '').strip(): d['total_bytes'] / pj.get('walkers_per_launch', 1024) * W
+                                for n, d in pj['kernels'].items() if n.split('<')[0].replace('void ', '').strip() in step_names}
+            step_pmc = sum(step_pmc_kernels.values()) if step_pmc_kernels else None
+        if ns_route and 'ms_per_step' in ns_route:
+            ns_route['speedup_of_default_route'] = ns_route['ms_per_step'] / ms_step
         out = {
             'metric': 'walker-likelihoods/sec at 512^2 map, 500-pt grid' if (S, args.N) == (512, 500)
                       else 'walker-likelihoods/sec at %d^2 map, %d-pt grid' % (S, args.N),
@@ -517,19 +604,24 @@ def main():
                                    % (W, S, S, args.N, 'SZ-only' if pb.sz_only else 'joint X-ray+SZ',
                                       ' (BASELINE configs[2])' if (W, S, args.N, pb.sz_only) == (1024, 512, 500, False) else ''),
                        'walkers_per_gpu': W, 'S': S, 'N': args.N, 'B': pb.B, 'chunk': ctx.chunk, 'route': ctx.route, 'conv': ctx.conv,
-                       'conv_layout': ctx.conv_layout, 'parallelism': 'walkers sharded x%d' % world, 'device': ctx.device_name},
+                       'conv_layout': ctx.conv_layout, 'parallelism': 'walkers sharded x%d' % world, 'device': ctx.device_name,
+                       'gather': (('overlapped: second stream, two output buffers' if overlap else 'strict: on the compute stream') if comm is not None else None)},
             'n_ranks_seen': (comm.n_ranks_seen if comm is not None else 1),
+            'gather_ms_per_step': gather_ms,
             'roofline': roof,
             'roofline_product': roof2,
             # the whole step against the HBM roofline: measured bytes (rocprofv3 PMC, profiles/*_pmc_traffic.json)
             'roofline_step': {'bound': 'hbm', 'peak': HBM_PEAK_GBS, 'peak_measured': copy_gbs, 'unit': 'GB/s', 'ms_per_step': ms_step,
-                              'traffic_bytes_per_step': step_pmc, 'traffic_source': (pj or {}).get('file'),
+                              'traffic_bytes_per_step': step_pmc, 'traffic_by_kernel': step_pmc_kernels, 'traffic_source': (pj or {}).get('file'),
+                              'traffic_measured_in_this_run': False,
                               'achieved': (step_pmc / (ms_step * 1e-3) / 1e9) if step_pmc else None,
                               'frac': (step_pmc / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS) if step_pmc else None,
                               'survey_8d_bytes_per_step': 2.0 * W * S * S * 8.0,
                               'note': 'the step is compute-bound (fp64 vector units, then fp64 matrix cores): its HBM traffic is the small '
                                       'per-walker arrays between the kernels'},
             'north_star_abel_map_kernel': full_map,
+            'north_star_route': ns_route,
+            'host_pointer': host_ptr,
             'hbm_copy_bandwidth_measured_GBps': copy_gbs,
             'hbm_stream_bandwidth_measured_GBps': streams,
             'truncation': ctx.truncation,

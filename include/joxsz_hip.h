@@ -218,6 +218,14 @@ int  jx_memcpy_d2h(jx_ctx* ctx, void* host, const void* dev, size_t nbytes);
  *   jx_allgather_logp   recv_dev[rank * count .. ] <- send_dev[0 .. count) of every rank (float64), asynchronous on the
  *                       context's stream like jx_eval_device; send and receive buffers are device memory;
  *   jx_comm_allreduce_max  in-place maximum over the ranks of `count` float64 on the device (timing, barriers);
+ *   jx_comm_set_overlap on != 0: the communicator's collectives run on a second stream of the context, each ordered behind
+ *                       what the compute stream holds at the moment of the call; the next evaluation does NOT wait for the
+ *                       gather unless it writes the very buffer being sent (alternate two output buffers and step n+1's
+ *                       kernels overlap gather n); jx_sync waits for both streams.  0 (default): strict -- collectives on the
+ *                       compute stream, in order with everything else (what a sampler needs that proposes from the gathered
+ *                       values);
+ *   jx_comm_gather_time sum of the all-gathers' own durations (HIP events on their stream, recorded while jx_timing_enable
+ *                       is on) and their number since the last call;
  *   jx_comm_destroy     collective teardown (jx_destroy does it too).
  * librccl is loaded when the first of these is called, not before: single-GPU use never touches it. */
 #define JX_COMM_ID_BYTES 128
@@ -225,6 +233,8 @@ int  jx_comm_unique_id(void* id_out /* JX_COMM_ID_BYTES */);
 int  jx_comm_init_rank(jx_ctx* ctx, const void* id /* JX_COMM_ID_BYTES */, int nranks, int rank);
 int  jx_allgather_logp(jx_ctx* ctx, const double* send_dev, double* recv_dev, int count);
 int  jx_comm_allreduce_max(jx_ctx* ctx, double* inout_dev, int count);
+int  jx_comm_set_overlap(jx_ctx* ctx, int on);
+int  jx_comm_gather_time(jx_ctx* ctx, double* ms_total, int64_t* calls);
 int  jx_comm_destroy(jx_ctx* ctx);
 /* ranks of the communicator as RCCL counts them (ncclCommCount); < 0 on error */
 int  jx_comm_count(jx_ctx* ctx);

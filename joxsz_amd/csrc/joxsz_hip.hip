@@ -146,6 +146,15 @@ struct jx_ctx {
 
     ncclComm_t comm = nullptr;         // RCCL communicator of this rank (jx_comm_init_rank)
     int comm_rank = 0, comm_size = 1;
+    // overlapped gather (jx_comm_set_overlap): the collectives of the communicator run on a stream of their own, ordered
+    // behind the evaluation by an event; a send buffer still being gathered holds back the next evaluation that writes it
+    bool comm_overlap = false;
+    hipStream_t comm_stream = nullptr;
+    struct GatherSlot { const void* send = nullptr; hipEvent_t done = nullptr; bool busy = false; };
+    GatherSlot gslot[4];
+    hipEvent_t ev_fork = nullptr;      // compute stream -> collective stream
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> gt_inflight, gt_free;   // events around every all-gather (its own duration)
+    double gather_ms = 0.0; long long gather_calls = 0;
 
     // timing
     bool timing_on = false;
@@ -562,6 +571,8 @@ static void mix_teardown(jx_ctx* ctx, MixBack& m) {
     m.ready = false;
 }
 
+static void mix_kslices(const MixBack& m, int* ksplit_out, int* kper_out);
+
 static int mix_setup(jx_ctx* ctx, const MixBuild& mb, long long tW) {
     MixBack& m = ctx->mix;
     const int N = ctx->cfg.N;
@@ -602,9 +613,23 @@ static int mix_setup(jx_ctx* ctx, const MixBuild& mb, long long tW) {
     }
     og.pstride = (long long)tW * og.ldx + 272;                // (not a power of two: the tail reads all slices of a walker at once)
     if ((rc = dev_new_l(ctx, m.allocs, (size_t)JX_MIX_KSPLIT_MAX * og.pstride, &m.Pt))) return rc;
+    { int kp; mix_kslices(m, &m.last_ksplit, &kp); }              // (reported by jx_get_conv_layout before the first launch too)
     m.bytes = ctx->device_bytes - before;
     m.ready = true;
     return JX_OK;
+}
+
+// K slices of the matrix-core product: a function of the problem alone (about 64 k-steps each, whole multiples of 8 slices so
+// that a full chunk fills whole rounds of blocks), never of the launch -- a walker's sums are grouped the same way wherever it
+// sits in whatever batch, so its result is bitwise independent of both
+static void mix_kslices(const MixBack& m, int* ksplit_out, int* kper_out) {
+    int ksplit = m.ksplit_force > 0 ? m.ksplit_force : (m.ksteps + 32) / 64;
+    if (ksplit >= 8 && m.ksplit_force <= 0) ksplit = (ksplit + 4) / 8 * 8;
+    ksplit = std::max(1, std::min(ksplit, JX_MIX_KSPLIT_MAX));
+    int kper = (m.ksteps + ksplit - 1) / ksplit;
+    kper = (kper + JX_OPG_RD - 1) / JX_OPG_RD * JX_OPG_RD;
+    ksplit = (m.ksteps + kper - 1) / kper;
+    *ksplit_out = ksplit; *kper_out = kper;
 }
 
 // stage 1 + stage 2 (low-rank form) or the one product of the full form; es: the launch's event set or null
@@ -626,12 +651,18 @@ static int launch_mix(jx_ctx* ctx, int n, EvSet* es) {
             wcap = (2 * (lds_c + sizeof(double) * JX_MXM_REGION(usp) * (8 / usp)) <= 158 * 1024) ? 8 : 16;
             if (m.wpb_force > 0) wcap = m.wpb_force;
         }
+        if (!m.mfma && usp > 1) {                                   // walker groups per block: their hand-over (RT sums per lane and later piece) within 64 KB
+            const int fit = (int)((size_t)64 * 1024 / (sizeof(double) * (usp - 1) * m.RT * 64));
+            wcap = std::min(wcap, std::max(fit, 0) * usp);
+            if (wcap < usp) { ctx->err = "stage 1: JOXSZ_MIX_USPLIT = " + std::to_string(usp) + " pieces of " + std::to_string(m.RT) + " rows per column do not fit the LDS hand-over (lower it)"; return JX_ERR_UNSUPPORTED; }
+        }
         const int gpb = std::max(1, std::min(wcap / usp, ngrp)), wpb = gpb * usp;
         const int nq = (ngrp + gpb - 1) / gpb;
         mx.cper = (nq <= 8 && 8 % nq == 0) ? 8 / nq : 0;
         const dim3 g1((unsigned)(mx.cper ? 8 * ((mx.NU + mx.cper - 1) / mx.cper) : nq * mx.NU));
         const size_t lds1 = m.mfma ? lds_c + sizeof(double) * JX_MXM_REGION(usp) * gpb : sizeof(double) * (size_t)gpb * (usp - 1) * m.RT * 64;
-        if (lds1 > 158 * 1024) { ctx->err = "stage 1: the operator and the sample rows do not fit the LDS (lower JOXSZ_MIX_USPLIT)"; return JX_ERR_UNSUPPORTED; }
+        // (the vector-unit kernel keeps the default 64 KB limit of dynamic LDS: mix_setup clamps usplit so that a block's hand-over fits)
+        if (lds1 > (m.mfma ? (size_t)158 * 1024 : (size_t)64 * 1024)) { ctx->err = "stage 1: the hand-over of the column pieces does not fit the LDS (lower JOXSZ_MIX_USPLIT or JOXSZ_MIX_WPB)"; return JX_ERR_UNSUPPORTED; }
         bool done = false;
         if (m.mfma) {
             if (ctx->f32) hipLaunchKernelGGL((jx_rowmix_mfma_kernel<JX_MIX_NS, float2>), g1, dim3(64 * wpb), lds1, st, mx, crows, reinterpret_cast<const float2*>(m.cft), m.Dt);
@@ -651,15 +682,8 @@ static int launch_mix(jx_ctx* ctx, int n, EvSet* es) {
         JxOpg og = m.og;
         og.n = n;
         const int nwb = (n + 127) / 128;
-        // K slices: a function of the problem alone (about 64 k-steps each, whole multiples of 8 slices so that a full chunk
-        // fills whole rounds of blocks), never of the launch -- a walker's sums are grouped the same way wherever it sits in
-        // whatever batch, so its result is bitwise independent of both
-        int ksplit = m.ksplit_force > 0 ? m.ksplit_force : (m.ksteps + 32) / 64;
-        if (ksplit >= 8 && m.ksplit_force <= 0) ksplit = (ksplit + 4) / 8 * 8;
-        ksplit = std::max(1, std::min(ksplit, JX_MIX_KSPLIT_MAX));
-        int kper = (m.ksteps + ksplit - 1) / ksplit;
-        kper = (kper + JX_OPG_RD - 1) / JX_OPG_RD * JX_OPG_RD;
-        ksplit = (m.ksteps + kper - 1) / kper;
+        int ksplit, kper;
+        mix_kslices(m, &ksplit, &kper);
         og.ksplit = ksplit; og.kper = kper;
         m.last_ksplit = ksplit;                                   // (the tail sums this many partials)
         const int nunit = ksplit * og.nog;
@@ -721,18 +745,94 @@ int jx_comm_count(jx_ctx* ctx) {
     return n;
 }
 
+static int gather_drain(jx_ctx* ctx) {
+    for (auto& pr : ctx->gt_inflight) {
+        HIPCHK(ctx, hipEventSynchronize(pr.second));
+        float ms = 0.f;
+        HIPCHK(ctx, hipEventElapsedTime(&ms, pr.first, pr.second));
+        ctx->gather_ms += ms; ctx->gather_calls += 1;
+        ctx->gt_free.push_back(pr);
+    }
+    ctx->gt_inflight.clear();
+    return JX_OK;
+}
+
+// the stream the communicator's collectives run on; in overlap mode it first waits for everything enqueued on the compute stream so far
+static int comm_fork(jx_ctx* ctx, hipStream_t* out) {
+    if (!ctx->comm_overlap) { *out = ctx->stream; return JX_OK; }
+    HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->comm_stream, ctx->ev_fork, 0));
+    *out = ctx->comm_stream;
+    return JX_OK;
+}
+
+int jx_comm_set_overlap(jx_ctx* ctx, int on) {
+    if (!ctx) return JX_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->comm_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->comm_stream));
+    if (on && !ctx->comm_stream) {
+        HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+        for (auto& g : ctx->gslot) HIPCHK(ctx, hipEventCreateWithFlags(&g.done, hipEventDisableTiming));
+    }
+    for (auto& g : ctx->gslot) g.busy = false;
+    ctx->comm_overlap = on != 0;
+    return JX_OK;
+}
+
 int jx_allgather_logp(jx_ctx* ctx, const double* send_dev, double* recv_dev, int count) {
     if (!ctx || !send_dev || !recv_dev || count < 0) return JX_ERR_INVALID;
     if (!ctx->comm) { ctx->err = "jx_allgather_logp before jx_comm_init_rank"; return JX_ERR_STATE; }
     if (count == 0) return JX_OK;
-    NCCLCHK(ctx, g_rccl.AllGather(send_dev, recv_dev, (size_t)count, ncclDouble, ctx->comm, ctx->stream));
+    int rc;
+    hipStream_t cs;
+    if ((rc = comm_fork(ctx, &cs))) return rc;
+    std::pair<hipEvent_t, hipEvent_t> pr{nullptr, nullptr};
+    const bool timed = ctx->timing_on && ctx->timing_mode == 1;    // (the stage pass; the timed region of bench.py carries no events of the gather)
+    if (timed) {
+        if (ctx->gt_inflight.size() > 4096 && (rc = gather_drain(ctx))) return rc;
+        if (!ctx->gt_free.empty()) { pr = ctx->gt_free.back(); ctx->gt_free.pop_back(); }
+        else { HIPCHK(ctx, hipEventCreate(&pr.first)); HIPCHK(ctx, hipEventCreate(&pr.second)); }
+        HIPCHK(ctx, hipEventRecord(pr.first, cs));
+    }
+    NCCLCHK(ctx, g_rccl.AllGather(send_dev, recv_dev, (size_t)count, ncclDouble, ctx->comm, cs));
+    if (timed) { HIPCHK(ctx, hipEventRecord(pr.second, cs)); ctx->gt_inflight.push_back(pr); }
+    if (ctx->comm_overlap) {
+        // remember the send buffer: the next evaluation that writes it waits for this gather (run_chunk), nothing else does
+        jx_ctx::GatherSlot* slot = nullptr;
+        for (auto& g : ctx->gslot) if (g.busy && g.send == (const void*)send_dev) slot = &g;
+        if (!slot) for (auto& g : ctx->gslot) if (!g.busy) { slot = &g; break; }
+        if (!slot) {                                                 // every slot taken: retire the oldest by waiting for it on the compute stream
+            slot = &ctx->gslot[0];
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, slot->done, 0));
+        }
+        slot->send = send_dev; slot->busy = true;
+        HIPCHK(ctx, hipEventRecord(slot->done, cs));
+    }
     return JX_OK;
 }
 
 int jx_comm_allreduce_max(jx_ctx* ctx, double* inout_dev, int count) {
     if (!ctx || !inout_dev || count < 1) return JX_ERR_INVALID;
     if (!ctx->comm) { ctx->err = "jx_comm_allreduce_max before jx_comm_init_rank"; return JX_ERR_STATE; }
-    NCCLCHK(ctx, g_rccl.AllReduce(inout_dev, inout_dev, (size_t)count, ncclDouble, ncclMax, ctx->comm, ctx->stream));
+    int rc;
+    hipStream_t cs;
+    if ((rc = comm_fork(ctx, &cs))) return rc;
+    NCCLCHK(ctx, g_rccl.AllReduce(inout_dev, inout_dev, (size_t)count, ncclDouble, ncclMax, ctx->comm, cs));
+    if (ctx->comm_overlap) {                                         // the result is awaited on the compute stream, as in strict mode
+        HIPCHK(ctx, hipEventRecord(ctx->ev_fork, cs));
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_fork, 0));
+    }
+    return JX_OK;
+}
+
+int jx_comm_gather_time(jx_ctx* ctx, double* ms_total, int64_t* calls) {
+    if (!ctx || !ms_total || !calls) return JX_ERR_INVALID;
+    int rc = gather_drain(ctx);
+    if (rc) return rc;
+    *ms_total = ctx->gather_ms; *calls = ctx->gather_calls;
+    ctx->gather_ms = 0.0; ctx->gather_calls = 0;
     return JX_OK;
 }
 
@@ -740,6 +840,7 @@ int jx_comm_destroy(jx_ctx* ctx) {
     if (!ctx) return JX_ERR_INVALID;
     if (!ctx->comm) return JX_OK;
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->comm_stream) (void)hipStreamSynchronize(ctx->comm_stream);
     NCCLCHK(ctx, g_rccl.CommDestroy(ctx->comm));
     ctx->comm = nullptr; ctx->comm_rank = 0; ctx->comm_size = 1;
     return JX_OK;
@@ -890,6 +991,7 @@ static int finalize_impl(jx_ctx* ctx) {
     if (const char* e = env_str("JOXSZ_ABEL_GEMM")) ctx->abel_gemm = atoi(e) != 0;
     ctx->op_narrow = env_str("JOXSZ_OP_NARROW") != nullptr;
     ctx->f32 = c.dtype == 1;
+    if (ctx->f32 && !ctx->abel_gemm) { ctx->err = "dtype f32 takes its spline arrays from the matrix product only (JOXSZ_ABEL_GEMM=0 is an f64 setting)"; return JX_ERR_UNSUPPORTED; }
 
     int chunk = c.max_batch > 0 ? c.max_batch : 1024;
     if (const char* e = env_str("JOXSZ_CHUNK")) { int v = atoi(e); if (v > 0) chunk = v; }
@@ -1172,6 +1274,9 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
     const bool op_route = ctx->route == JX_ROUTE_OPERATOR && !t.pp && !ctx->d.inject_pp && !use_ref;   // stage taps and the operator build: map route
     int rc;
     hipStream_t st = ctx->stream;
+    if (ctx->comm_overlap)                                         // a gather still reading this output buffer: the evaluation waits for it, and only for it
+        for (auto& g : ctx->gslot)
+            if (g.busy && g.send == (const void*)logp_dev) { HIPCHK(ctx, hipStreamWaitEvent(st, g.done, 0)); g.busy = false; }
     EvSet es;
     // timing mode 2 records the two events around the time-dominant kernel only (stage 1 of the contracted route)
     const bool tm = ctx->timing_on && ctx->timing_mode != 2 && !use_ref;
@@ -1237,6 +1342,7 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
     if (mix) {
         MixBack& m = ctx->mix;
         if (ctx->f32 && (want_abel_taps || t.need_img)) { ctx->err = "dtype f32: the profile and map taps exist in the f64 build of the context only"; return JX_ERR_UNSUPPORTED; }
+        if (ctx->f32 && !ag) { ctx->err = "dtype f32 takes its spline arrays from the matrix product only (JOXSZ_ABEL_GEMM=0 is an f64 setting)"; return JX_ERR_UNSUPPORTED; }
         if (ag) {
             // 32 walkers per block, or 16 when that would leave SIMDs without a wave (a walker's sums do not depend on it)
             const int gy = (ctx->tm_npair + 3) / 4;
@@ -1622,6 +1728,7 @@ int jx_set_stream(jx_ctx* ctx, void* hip_stream) {
 int jx_sync(jx_ctx* ctx) {
     if (!ctx) return JX_ERR_INVALID;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->comm_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->comm_stream));
     return JX_OK;
 }
 
@@ -1828,6 +1935,17 @@ int jx_get_truncation(jx_ctx* ctx, double out[12]) {
 // Duration of the Abel + map kernel writing the full S x S Compton-y map of `nwalkers` walkers (the kernel BASELINE's metric
 // is worded around: profile -> Abel integral -> spline -> map, S^2 * 8 B per walker), averaged over `repeats` launches
 // between two HIP events on the context's stream.  Scratch image allocated for the call.
+namespace {
+// scratch of the measurement calls below: device buffers and events released on every path out of the call
+struct Scratch {
+    std::vector<void*> mem;
+    std::vector<hipEvent_t> ev;
+    ~Scratch() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); for (void* p : mem) (void)hipFree(p); }
+    hipError_t alloc(void** p, size_t n) { const hipError_t e = hipMalloc(p, n); if (e == hipSuccess) mem.push_back(*p); return e; }
+    hipError_t event(hipEvent_t* e) { const hipError_t r = hipEventCreate(e); if (r == hipSuccess) ev.push_back(*e); return r; }
+};
+}  // namespace
+
 int jx_map_kernel_time(jx_ctx* ctx, const double* theta_dev, int nwalkers, int repeats, double* ms_out) {
     if (!ctx || !theta_dev || nwalkers < 1 || repeats < 1 || !ms_out) return JX_ERR_INVALID;
     if (!ctx->finalized) { ctx->err = "jx_map_kernel_time before jx_finalize"; return JX_ERR_STATE; }
@@ -1838,10 +1956,11 @@ int jx_map_kernel_time(jx_ctx* ctx, const double* theta_dev, int nwalkers, int r
     dm.map_split = std::max(dm.map_split, 2);                  // (two row slabs per walker: launches desynchronise, stores overlap compute)
     int threads; size_t lds;
     if (!map_geometry(dm, 512, &threads, &lds, ctx->map_pair != 0)) { ctx->err = "radial grid too long for the LDS-resident spline"; return JX_ERR_UNSUPPORTED; }
+    Scratch sc;
     double* img = nullptr;
-    HIPCHK(ctx, hipMalloc((void**)&img, sizeof(double) * (size_t)nwalkers * S * S));
+    HIPCHK(ctx, sc.alloc((void**)&img, sizeof(double) * (size_t)nwalkers * S * S));
     hipEvent_t e0, e1;
-    HIPCHK(ctx, hipEventCreate(&e0)); HIPCHK(ctx, hipEventCreate(&e1));
+    HIPCHK(ctx, sc.event(&e0)); HIPCHK(ctx, sc.event(&e1));
     hipStream_t st = ctx->stream;
     launch_map(st, dm, threads, lds, theta_dev, 0, nwalkers, img, nullptr, nullptr, nullptr, false);       // warm-up
     HIPCHK(ctx, hipEventRecord(e0, st));
@@ -1850,8 +1969,6 @@ int jx_map_kernel_time(jx_ctx* ctx, const double* theta_dev, int nwalkers, int r
     HIPCHK(ctx, hipEventSynchronize(e1));
     float ms = 0.f;
     HIPCHK(ctx, hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    HIPCHK(ctx, hipFree(img));
     HIPCHK(ctx, hipGetLastError());
     *ms_out = (double)ms / repeats;
     return JX_OK;
@@ -1881,12 +1998,13 @@ __global__ void __launch_bounds__(256) jx_readsum_kernel(const double2* __restri
 int jx_stream_bandwidth(jx_ctx* ctx, int mode, size_t nbytes, int repeats, double* gbps_out) {
     if (!ctx || mode < 0 || mode > 2 || nbytes < 4096 || repeats < 1 || !gbps_out) return JX_ERR_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    Scratch sc;
     void *a = nullptr, *b = nullptr;
-    HIPCHK(ctx, hipMalloc(&a, nbytes));
-    if (hipMalloc(&b, nbytes) != hipSuccess) { (void)hipFree(a); ctx->err = "jx_stream_bandwidth: out of memory"; return JX_ERR_NOMEM; }
+    HIPCHK(ctx, sc.alloc(&a, nbytes));
+    HIPCHK(ctx, sc.alloc(&b, nbytes));
     hipStream_t st = ctx->stream;
     hipEvent_t e0, e1;
-    HIPCHK(ctx, hipEventCreate(&e0)); HIPCHK(ctx, hipEventCreate(&e1));
+    HIPCHK(ctx, sc.event(&e0)); HIPCHK(ctx, sc.event(&e1));
     HIPCHK(ctx, hipMemsetAsync(a, 0, nbytes, st));
     HIPCHK(ctx, hipMemsetAsync(b, 0, nbytes, st));
     const size_t n = nbytes / sizeof(double2);
@@ -1904,8 +2022,6 @@ int jx_stream_bandwidth(jx_ctx* ctx, int mode, size_t nbytes, int repeats, doubl
     HIPCHK(ctx, hipEventSynchronize(e1));
     float ms = 0.f;
     HIPCHK(ctx, hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    (void)hipFree(a); (void)hipFree(b);
     HIPCHK(ctx, hipGetLastError());
     *gbps_out = (mode == 0 ? 2.0 : 1.0) * (double)(n * sizeof(double2)) * repeats / ((double)ms * 1e-3) / 1e9;
     return JX_OK;
@@ -1914,12 +2030,13 @@ int jx_stream_bandwidth(jx_ctx* ctx, int mode, size_t nbytes, int repeats, doubl
 int jx_copy_bandwidth(jx_ctx* ctx, size_t nbytes, int repeats, double* gbps_out) {
     if (!ctx || nbytes < 4096 || repeats < 1 || !gbps_out) return JX_ERR_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    Scratch sc;
     void *a = nullptr, *b = nullptr;
-    HIPCHK(ctx, hipMalloc(&a, nbytes));
-    if (hipMalloc(&b, nbytes) != hipSuccess) { (void)hipFree(a); ctx->err = "jx_copy_bandwidth: out of memory"; return JX_ERR_NOMEM; }
+    HIPCHK(ctx, sc.alloc(&a, nbytes));
+    HIPCHK(ctx, sc.alloc(&b, nbytes));
     hipStream_t st = ctx->stream;
     hipEvent_t e0, e1;
-    HIPCHK(ctx, hipEventCreate(&e0)); HIPCHK(ctx, hipEventCreate(&e1));
+    HIPCHK(ctx, sc.event(&e0)); HIPCHK(ctx, sc.event(&e1));
     HIPCHK(ctx, hipMemsetAsync(a, 0, nbytes, st));
     const size_t n = nbytes / sizeof(double2);
     const dim3 grid((unsigned)(ctx->num_cu * 16));
@@ -1930,8 +2047,6 @@ int jx_copy_bandwidth(jx_ctx* ctx, size_t nbytes, int repeats, double* gbps_out)
     HIPCHK(ctx, hipEventSynchronize(e1));
     float ms = 0.f;
     HIPCHK(ctx, hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    (void)hipFree(a); (void)hipFree(b);
     HIPCHK(ctx, hipGetLastError());
     *gbps_out = 2.0 * (double)(n * sizeof(double2)) * repeats / ((double)ms * 1e-3) / 1e9;
     return JX_OK;
@@ -1946,6 +2061,11 @@ void jx_destroy(jx_ctx* ctx) {
     mix_teardown(ctx, ctx->mix);
     for (auto& es : ctx->ev_inflight) for (int k = 0; k < 6; ++k) (void)hipEventDestroy(es.e[k]);
     for (auto& es : ctx->ev_free) for (int k = 0; k < 6; ++k) (void)hipEventDestroy(es.e[k]);
+    for (auto& pr : ctx->gt_inflight) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (auto& pr : ctx->gt_free) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (auto& g : ctx->gslot) if (g.done) (void)hipEventDestroy(g.done);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);
     for (void* p : ctx->dev_allocs) (void)hipFree(p);
     for (void* p : ctx->samp_buf) if (p) (void)hipFree(p);
     if (ctx->d_theta) (void)hipFree(ctx->d_theta);

@@ -56,7 +56,7 @@ def synthetic_count_rate_tables(nband=10, ntab=100):
 
 
 def synthetic_problem(S=512, N=500, seed=0, sz_only=False, ne_mode='single', step=2.0,
-                      kpc_as=KPC_AS_CLJ1226, fwhm=18.5, nann=15, nband=10):
+                      kpc_as=KPC_AS_CLJ1226, fwhm=18.5, nann=15, nband=10, tf_scale=0.02, tf_c=0.95):
     """CL J1226.9+3332-shaped constants at map side ``S`` and grid length ``N``.
 
     The SZ flux values and X-ray counts are smooth placeholders of the right
@@ -72,7 +72,7 @@ def synthetic_problem(S=512, N=500, seed=0, sz_only=False, ne_mode='single', ste
     flux_r = 3.136 + 6.273 * np.arange(19)
     beam_2d, _ = sh.beam_image(step, flux_r[-1], approx=True, fwhm=fwhm)
     wn = np.linspace(0., 0.4967, 76)
-    wn, tf = sh.transfer_function(wn, None, approx=True, loc=0., scale=0.02, c=0.95)
+    wn, tf = sh.transfer_function(wn, None, approx=True, loc=0., scale=tf_scale, c=tf_c)
     filtering = sh.filter_image(wn, tf, S, step)
     flux = -2.6 * np.exp(-flux_r / 32.) + 0.02
     flux_data = np.vstack((flux_r, flux + FLUX_ERR * rng.standard_normal(19), FLUX_ERR))
@@ -94,7 +94,7 @@ def synthetic_problem(S=512, N=500, seed=0, sz_only=False, ne_mode='single', ste
                  projvols=geo['projvols'], cts=cts, areascales=areascales, exposures=exposures,
                  backrates=backrates, geomarea=geo['geomarea'], lnT=lnT, lnrate=lnrate,
                  ne_mode=ne_mode, sz_only=sz_only, **tab)
-    pb.meta = dict(kind='synthetic', seed=seed, fwhm=fwhm)
+    pb.meta = dict(kind='synthetic', seed=seed, fwhm=fwhm, tf_scale=tf_scale, tf_c=tf_c)
     return pb.validate()
 
 

@@ -32,8 +32,9 @@ def launch_env():
 
 def _rdzv_path():
     d = os.environ.get('JOXSZ_RDZV_DIR', '/tmp')
-    tag = os.environ.get('JOXSZ_RDZV_TAG') or '%s_%s_%d' % (os.environ.get('TORCHELASTIC_RUN_ID', 'run'),
-                                                            os.environ.get('MASTER_PORT', '0'), os.getppid())
+    # (the restart count: an id file left by an attempt of the same run that died between publishing and joining is not this attempt's)
+    tag = os.environ.get('JOXSZ_RDZV_TAG') or '%s_%s_%d_r%s' % (os.environ.get('TORCHELASTIC_RUN_ID', 'run'), os.environ.get('MASTER_PORT', '0'),
+                                                                os.getppid(), os.environ.get('TORCHELASTIC_RESTART_COUNT', '0'))
     return os.path.join(d, 'joxsz_rccl_%s.id' % tag)
 
 
@@ -99,20 +100,27 @@ class RcclGather:
     """All-gather of per-rank log-probabilities over RCCL, through the C-ABI of the HIP library (no torch).
 
     ``ctx`` is this rank's ``HipContext`` (one per process, one process per GPU).  ``all_gather(send_ptr, recv_ptr, n)``
-    takes device pointers (``ctx.dev_alloc``) and is asynchronous on the context's stream, ordered behind
-    ``ctx.eval_device``; ``barrier()`` and ``max_over_ranks(x)`` serve the timing protocol of bench.py;
+    takes device pointers (``ctx.dev_alloc``) and is asynchronous, ordered behind ``ctx.eval_device`` -- on the context's
+    stream (strict, default) or with ``overlap=True`` on a second stream, so that the next evaluation (into another buffer)
+    runs beside it; ``barrier()`` and ``max_over_ranks(x)`` serve the timing protocol of bench.py;
     ``gather_ragged`` is the padded form for shards of unequal length."""
 
-    def __init__(self, ctx, rank=None, world=None):
+    def __init__(self, ctx, rank=None, world=None, overlap=False):
         env_rank, env_world, _ = launch_env()
         self.ctx = ctx
+        self.overlap = bool(overlap)
         self.rank = env_rank if rank is None else rank
         self.world = env_world if world is None else world
         uid = exchange_unique_id(ctx.comm_unique_id, self.rank, self.world)
         ctx.comm_init_rank(uid, self.world, self.rank)
         self._scratch = ctx.dev_alloc(8)
+        self._scratch_n = 1
         self._pad = None
         self.n_ranks_seen = ctx.comm_count()                  # what RCCL itself says (ncclCommCount)
+        if self.overlap:
+            # the gather of step n on a second stream beside step n+1's kernels (the caller alternates two output buffers);
+            # strict mode (default) keeps every collective in order on the compute stream
+            ctx.comm_set_overlap(True)
         if self.rank == 0 and self.world > 1:
             try:                                              # every rank has read the id once the communicator exists
                 os.unlink(_rdzv_path())
@@ -145,12 +153,17 @@ class RcclGather:
         return full
 
     def max_over_ranks(self, value):
-        buf = np.array([float(value)])
+        """Maximum over the ranks of a number, or element-wise of a sequence of numbers (one collective either way)."""
+        scalar = np.ndim(value) == 0
+        buf = np.atleast_1d(np.asarray(value, dtype=np.float64)).copy()
+        if buf.size > self._scratch_n:
+            self._scratch_n = int(buf.size)
+            self._scratch = self.ctx.dev_alloc(8 * self._scratch_n)
         self.ctx.h2d(self._scratch, buf)
-        self.ctx.comm_allreduce_max(self._scratch, 1)
+        self.ctx.comm_allreduce_max(self._scratch, int(buf.size))
         self.ctx.sync()
         self.ctx.d2h(buf, self._scratch)
-        return float(buf[0])
+        return float(buf[0]) if scalar else buf
 
     def barrier(self):
         self.max_over_ranks(0.0)

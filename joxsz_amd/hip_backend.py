@@ -20,7 +20,7 @@ EXPORTS = (
     'jx_timing_reset', 'jx_timing_enable', 'jx_timing_get', 'jx_get_info', 'jx_get_conv_mode', 'jx_get_conv_layout', 'jx_debug_workspace', 'jx_device_count',
     'jx_device_name', 'jx_strerror', 'jx_last_error', 'jx_destroy',
     'jx_get_truncation', 'jx_comm_unique_id', 'jx_comm_init_rank', 'jx_allgather_logp', 'jx_comm_allreduce_max', 'jx_comm_destroy',
-    'jx_comm_count', 'jx_map_kernel_time', 'jx_copy_bandwidth', 'jx_stream_bandwidth',
+    'jx_comm_count', 'jx_comm_set_overlap', 'jx_comm_gather_time', 'jx_map_kernel_time', 'jx_copy_bandwidth', 'jx_stream_bandwidth',
 )
 
 TENSORS = ('r_pp', 'd_mat', 'beam_2d', 'filtering', 'radius', 'flux_data', 'conv_T', 'conv_v',
@@ -35,6 +35,10 @@ STAGES = ('pp', 'ab', 'y', 'y_2d', 'conv_2d', 'map_row', 'bright', 'chisq', 'tpr
 
 class JoxszHipError(RuntimeError):
     pass
+
+
+class JoxszTruncationWarning(UserWarning):
+    """The truncation guard of the low-rank form rebuilt the tables at a higher rank (slower), or sits close to its bound."""
 
 
 class JxConfig(ctypes.Structure):
@@ -98,6 +102,8 @@ def load_library(path=None):
     lib.jx_comm_allreduce_max.argtypes = [vp, vp, ci]
     lib.jx_comm_destroy.argtypes = [vp]
     lib.jx_comm_count.argtypes = [vp]
+    lib.jx_comm_set_overlap.argtypes = [vp, ci]
+    lib.jx_comm_gather_time.argtypes = [vp, dp, i64p]
     lib.jx_map_kernel_time.argtypes = [vp, vp, ci, ci, dp]
     lib.jx_copy_bandwidth.argtypes = [vp, cs, ci, dp]
     lib.jx_stream_bandwidth.argtypes = [vp, ci, cs, ci, dp]
@@ -190,6 +196,9 @@ class HipContext:
         if self.conv == 'custom':
             self.conv_layout = self._layout()
         self.truncation = self._truncation()
+        if self.truncation['warning'] and not os.environ.get('JOXSZ_QUIET'):
+            import warnings
+            warnings.warn(self.truncation['warning'], JoxszTruncationWarning, stacklevel=3)
         self.route = 'map'
         route = route or os.environ.get('JOXSZ_ROUTE')
         if route and route != 'map':
@@ -209,9 +218,32 @@ class HipContext:
     def _truncation(self):
         tr = (ctypes.c_double * 12)()
         self._chk(self.lib.jx_get_truncation(self._h, tr), 'jx_get_truncation')
-        return dict(tol=tr[0], est_rel_row_err=tr[1], rank=int(tr[2]), retried=int(tr[3]), points=int(tr[4]), bound=tr[5],
-                    est_rel_row_err_box=tr[6], est_rel_sz_like_err_box=tr[7], rank_above_cut=int(tr[8]), bound_sz_like=tr[9],
-                    stage1_on_matrix_cores=bool(tr[10]), cap_removed=int(tr[11]))
+        d = dict(tol=tr[0], est_rel_row_err=tr[1], rank=int(tr[2]), retried=int(tr[3]), points=int(tr[4]), bound=tr[5],
+                 est_rel_row_err_box=tr[6], est_rel_sz_like_err_box=tr[7], rank_above_cut=int(tr[8]), bound_sz_like=tr[9],
+                 stage1_on_matrix_cores=bool(tr[10]), cap_removed=int(tr[11]))
+        d['warning'] = self._truncation_warning(d)
+        return d
+
+    def _truncation_warning(self, d):
+        """One line when the guard changed the tables or has little room left (jx_finalize, joxsz_hip.hip): what happened and
+        what it costs.  Stages 1 and 2 of the low-rank form cost about (4 + rank) and rank multiply-adds per map sample, so
+        the step scales roughly with (4 + 2 rank) / (4 + 2 * 16) of the 16-term tables a smooth transfer function gets."""
+        if self.conv != 'custom' or d['rank'] <= 0 or d['est_rel_row_err'] < 0:
+            return None
+        rel = (4.0 + 2.0 * d['rank']) / (4.0 + 2.0 * 16)
+        msgs = []
+        if d['retried'] > d['cap_removed']:
+            msgs.append('the truncation guard tightened the singular-value cut to %.0e on this beam / transfer function: %d terms kept, '
+                        'the SZ stages cost about %.1fx those of the 16-term tables' % (d['tol'], d['rank'], rel))
+        elif d['cap_removed']:
+            msgs.append('the truncation guard took the 16-term cap away on this beam / transfer function: %d terms kept '
+                        '(SZ stages about %.2fx)' % (d['rank'], rel))
+        near = max(d['est_rel_row_err'] / d['bound'], d['est_rel_sz_like_err_box'] / d['bound_sz_like'])
+        if not msgs and near > 0.5 and self.dtype == 'f64':
+            msgs.append('the truncation of the low-rank form sits at %.0f %% of its bound (SZ log-likelihood over the prior box %.1e of %.0e): '
+                        'slightly different inputs rebuild the tables with more terms (about -35 %% throughput at 31 terms)'
+                        % (100 * near, d['est_rel_sz_like_err_box'], d['bound_sz_like']))
+        return '; '.join(msgs) if msgs else None
 
     # -- plumbing --
     def _chk(self, rc, what):
@@ -363,6 +395,16 @@ class HipContext:
 
     def comm_allreduce_max(self, ptr, count=1):
         self._chk(self.lib.jx_comm_allreduce_max(self._h, ctypes.c_void_p(ptr), count), 'jx_comm_allreduce_max')
+
+    def comm_set_overlap(self, on=True):
+        """Collectives on a second stream: the next evaluation overlaps the gather unless it writes the buffer being sent."""
+        self._chk(self.lib.jx_comm_set_overlap(self._h, int(bool(on))), 'jx_comm_set_overlap')
+
+    def comm_gather_time(self):
+        """(ms, calls): summed duration of the all-gathers on their own stream since the last call (timing must be enabled)."""
+        ms, n = ctypes.c_double(), ctypes.c_int64()
+        self._chk(self.lib.jx_comm_gather_time(self._h, ctypes.byref(ms), ctypes.byref(n)), 'jx_comm_gather_time')
+        return ms.value, n.value
 
     def comm_destroy(self):
         self._chk(self.lib.jx_comm_destroy(self._h), 'jx_comm_destroy')

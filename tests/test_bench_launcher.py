@@ -110,3 +110,56 @@ def test_rendezvous_accepts_the_id_a_faster_rank_0_wrote_before_this_rank_was_up
         os.utime(path, (early, early))
     monkeypatch.setattr(dist, '_PROCESS_T0', time.time() + 5.0)           # this rank: up five seconds from now
     assert dist.exchange_unique_id(lambda: b'', 1, 2, timeout=2.0) == b'E' * 128
+
+
+_SIDE_STUB = '''
+    import os, sys, json, time, glob
+    import numpy as np
+    sys.path.insert(0, %r)
+    import bench
+    r, w = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    d = sys.argv[sys.argv.index("--dir") + 1]
+
+    class FileComm:                                   # an all-reduce(max) through files: blocks until every rank has arrived
+        def max_over_ranks(self, vec):
+            np.save(os.path.join(d, "v%%d.npy" %% r), np.asarray(vec, float))
+            t0 = time.time()
+            while len(glob.glob(os.path.join(d, "v*.npy"))) < w:
+                if time.time() - t0 > 120: raise RuntimeError("collective timed out")
+                time.sleep(0.02)
+            time.sleep(0.2)
+            return np.max([np.load(os.path.join(d, "v%%d.npy" %% k)) for k in range(w)], axis=0)
+
+    headline = {"value": 1.0 + r}                     # fixed before the side measurements
+    dts, err = [0.5 + 0.01 * r, 0.25], None
+    try:                                              # rank-local, no collective inside
+        if "--raise" in sys.argv and r == 3: raise MemoryError("allocation failed building the 8192-walker context")
+        if "--die" in sys.argv and r == 3: os._exit(5)
+    except Exception as exc:
+        dts, err = [np.inf, 0.25], str(exc)
+    out = bench.agree_on_side_times(FileComm(), dts)  # outside the handler: every living rank gets here
+    if r == 0:
+        print(json.dumps({"headline": headline, "side": [None if not np.isfinite(v) else v for v in out]}))
+''' % ROOT
+
+
+def test_a_rank_that_throws_in_the_side_measurements_does_not_hang_the_collective(tmp_path):
+    """Eight stand-in ranks run bench.py's side-measurement protocol (rank-local measurement inside try/except, then ONE
+    collective outside it).  A rank that raises still reaches the collective: the launch ends with rank 0's line, the failed
+    row marked, the headline intact.  A rank that dies outright takes the launch down through the launcher at once -- non-zero
+    exit long before the collective's own timeout."""
+    import bench
+    stub = _stub(tmp_path, _SIDE_STUB)
+    d1 = tmp_path / 'a'; d1.mkdir()
+    t = time.time()
+    rc, line = bench.spawn_ranks(8, ['--raise', '--dir', str(d1)], script=stub, timeout_s=100)
+    assert rc == 0 and time.time() - t < 60
+    a = json.loads(line)
+    assert a['headline'] == {'value': 1.0} and a['side'][0] is None and abs(a['side'][1] - 0.25) < 1e-12
+    d2 = tmp_path / 'b'; d2.mkdir()
+    t = time.time()
+    rc, line = bench.spawn_ranks(8, ['--die', '--dir', str(d2)], script=stub, timeout_s=100)
+    assert rc == 5 and time.time() - t < 40            # the others were blocked in the collective; the launcher ended them
+    d3 = tmp_path / 'c'; d3.mkdir()
+    rc, line = bench.spawn_ranks(8, ['--dir', str(d3)], script=stub, timeout_s=100)
+    assert rc == 0 and abs(json.loads(line)['side'][0] - 0.57) < 1e-12     # the maximum over the ranks

@@ -424,6 +424,41 @@ def test_truncation_guard_and_automatic_tightening(monkeypatch):
     assert tr3['tol'] == 1e-7 and tr3['retried'] == 0 and tr3['est_rel_sz_like_err_box'] > tr['est_rel_sz_like_err_box']
 
 
+def test_truncation_guard_speaks_up_when_it_changes_the_tables():
+    """Transfer functions that sit just over the guard's bounds at the default tables (a sharper and a softer normal-cdf
+    roll-off than CL J1226.9+3332's, found with scripts/guard_scan.py): jx_finalize first takes the 16-term cap away, then --
+    for the softer one -- tightens the cut; HipContext says so once (JoxszTruncationWarning, `truncation['warning']`) with
+    the rank it ended at and what that costs; the results hold the 1e-6 bar either way.  The default inputs stay silent."""
+    import warnings
+    from joxsz_amd import datasets
+    from joxsz_amd.hip_backend import JoxszTruncationWarning
+    from joxsz_amd.posterior import JoxszPosterior
+    with warnings.catch_warnings():
+        warnings.simplefilter('error', JoxszTruncationWarning)
+        post = JoxszPosterior(datasets.synthetic_problem(S=512, N=500, seed=3), device=0)      # no warning: would raise here
+        tr0 = post.ctx.truncation
+        post.close()
+    assert tr0['warning'] is None and tr0['rank'] == 16 and tr0['rank_above_cut'] in (17, 18) and tr0['cap_removed'] == 0 and tr0['retried'] == 0
+    for scale, cap_removed, tightened in ((0.010, 1, False), (0.050, 0, True)):
+        pb = datasets.synthetic_problem(S=512, N=500, seed=3, tf_scale=scale)
+        with pytest.warns(JoxszTruncationWarning) as rec:
+            post = JoxszPosterior(pb, device=0)
+        tr = post.ctx.truncation
+        assert len(rec) == 1 and tr['warning'] == str(rec[0].message)
+        assert tr['cap_removed'] == cap_removed and (tr['retried'] > tr['cap_removed']) == tightened and tr['rank'] > 16
+        assert ('%d terms' % tr['rank']) in tr['warning']
+        assert 0 <= tr['est_rel_row_err'] <= tr['bound'] and 0 <= tr['est_rel_sz_like_err_box'] <= tr['bound_sz_like']
+        th = datasets.walker_ball(pb, 12, spread=0.03, seed=3)
+        a = post.log_prob(th)
+        post.close()
+        ref = JoxszPosterior(pb, device=0, conv='rocfft')
+        b = ref.log_prob(th)
+        ref.close()
+        fin = np.isfinite(b)
+        assert fin.sum() >= 6 and np.array_equal(np.isfinite(a), fin)
+        np.testing.assert_allclose(a[fin], b[fin], rtol=1e-8)
+
+
 def test_truncation_guard_odd_side_and_measured_transfer_function(monkeypatch):
     """Odd sides: same guard, same kernels.  The bundled measured transfer function (rough from one wavenumber to the next:
     its weights have nearly full rank) leaves nothing to truncate -- the full form runs and the guard reports so."""
