@@ -146,6 +146,11 @@ struct jx_ctx {
 
     ncclComm_t comm = nullptr;         // RCCL communicator of this rank (jx_comm_init_rank)
     int comm_rank = 0, comm_size = 1;
+    // the per-walker kernel beside the SZ chain (contracted route): second stream, joined in front of the tail
+    bool side_on = false;              // JOXSZ_SIDE_STREAM=1: the per-walker kernel on a second stream beside the SZ chain (measured: no gain, profiles/r04_side_stream_timeline.log)
+    int side_fork = 0;                 // where the side stream forks: 0 behind the profile kernel, 1 behind stage 1 (JOXSZ_SIDE_FORK)
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_side = nullptr, ev_tail = nullptr;
     // overlapped gather (jx_comm_set_overlap): the collectives of the communicator run on a stream of their own, ordered
     // behind the evaluation by an event; a send buffer still being gathered holds back the next evaluation that writes it
     bool comm_overlap = false;
@@ -633,7 +638,8 @@ static void mix_kslices(const MixBack& m, int* ksplit_out, int* kper_out) {
 }
 
 // stage 1 + stage 2 (low-rank form) or the one product of the full form; es: the launch's event set or null
-static int launch_mix(jx_ctx* ctx, int n, EvSet* es) {
+template <typename F>
+static int launch_mix(jx_ctx* ctx, int n, EvSet* es, F&& between /* called between stage 1 and the matrix-core product */) {
     MixBack& m = ctx->mix;
     hipStream_t st = ctx->stream;
     if (m.form == 0) {
@@ -678,6 +684,7 @@ static int launch_mix(jx_ctx* ctx, int n, EvSet* es) {
         if (!done) { ctx->err = "no stage-1 kernel for this rank"; return JX_ERR_UNSUPPORTED; }
     }
     if (es) HIPCHK(ctx, hipEventRecord(es->e[3], st));
+    { const int rcb = between(); if (rcb) return rcb; }
     {
         JxOpg og = m.og;
         og.n = n;
@@ -990,6 +997,8 @@ static int finalize_impl(jx_ctx* ctx) {
     if (const char* e = env_str("JOXSZ_MIX_KSPLIT")) { const int v = atoi(e); if (v >= 1) ctx->mix.ksplit_force = v; }
     if (const char* e = env_str("JOXSZ_ABEL_GEMM")) ctx->abel_gemm = atoi(e) != 0;
     ctx->op_narrow = env_str("JOXSZ_OP_NARROW") != nullptr;
+    if (const char* e = env_str("JOXSZ_SIDE_STREAM")) ctx->side_on = atoi(e) != 0;
+    if (const char* e = env_str("JOXSZ_SIDE_FORK")) ctx->side_fork = atoi(e) != 0;
     ctx->f32 = c.dtype == 1;
     if (ctx->f32 && !ctx->abel_gemm) { ctx->err = "dtype f32 takes its spline arrays from the matrix product only (JOXSZ_ABEL_GEMM=0 is an f64 setting)"; return JX_ERR_UNSUPPORTED; }
 
@@ -1194,6 +1203,11 @@ static int finalize_impl(jx_ctx* ctx) {
         }
         if ((rc = dev_new(ctx, (size_t)chunk * d.q_nb, &d.xcol))) return rc;
         if ((rc = mix_setup(ctx, mixb, tW2))) return rc;
+        if (ctx->side_on) {
+            HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+            HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_side, hipEventDisableTiming));
+            HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_tail, hipEventDisableTiming));
+        }
         if ((rc = dev_put(ctx, h_Tm.data(), h_Tm.size(), &ctx->d_Tm))) return rc;
         if ((rc = dev_new(ctx, (size_t)chunk * N, &ctx->d_ppc, true))) return rc;
         HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_rowmix_mfma_kernel<JX_MIX_NS, double2>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
@@ -1298,15 +1312,37 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
         es.p1only = tm2;
         if (tm) HIPCHK(ctx, hipEventRecord(es.e[0], st));
     }
-    {
+    // Contracted route: only the pressure profile is in the way of the SZ chain (spline arrays -> stage 1 -> stage 2); priors,
+    // vetoes, X-ray side and conversion factors feed the tail alone.  So a small kernel evaluates the profile in line, and the
+    // per-walker kernel runs on a second stream BESIDE THE MATRIX-CORE PRODUCT: forked by an event behind stage 1 (stage 1
+    // fills every wave slot of the chip, the product leaves more than half of the registers free), joined by one in front of
+    // the tail.  Everything the fork event follows on the compute stream -- the previous tail, which reads the buffers this
+    // kernel writes, and whatever produced theta -- is therefore complete when it starts.  Calls with taps stay in line.
+    const bool any_tap = t.pp || t.ab || t.y || t.row || t.bright || t.chisq || t.tprof || t.xprofs || t.parts || t.integ || t.need_img;
+    const bool side = mix && ag && ctx->side_stream && !ctx->d.inject_pp && !any_tap;
+    auto launch_prep = [&](hipStream_t ps, double* pp_buf) {
         JxDev dp = d;
         dp.inject_pp = ctx->d.inject_pp;
         const size_t sh = sizeof(double) * (JX_LDS_HDR + (size_t)2 * d.N + 2 * d.nann + (size_t)d.nband * d.nann + 8);
-        double* pp_buf = op_route ? ctx->d_pp : ((ag && !ctx->d.inject_pp) ? ctx->d_ppc : (double*)nullptr);
-        if (d.prep_pow) hipLaunchKernelGGL(jx_prep_kernel<true>, dim3(n), dim3(JX_PREP_THREADS), sh, st, dp, theta_dev, w0,
+        if (d.prep_pow) hipLaunchKernelGGL(jx_prep_kernel<true>, dim3(n), dim3(JX_PREP_THREADS), sh, ps, dp, theta_dev, w0,
                                            base_buf, cfac_buf, pp_buf, sz0_buf, t.tprof, t.xprofs, t.parts, t.integ);
-        else hipLaunchKernelGGL(jx_prep_kernel<false>, dim3(n), dim3(JX_PREP_THREADS), sh, st, dp, theta_dev, w0,
+        else hipLaunchKernelGGL(jx_prep_kernel<false>, dim3(n), dim3(JX_PREP_THREADS), sh, ps, dp, theta_dev, w0,
                                 base_buf, cfac_buf, pp_buf, sz0_buf, t.tprof, t.xprofs, t.parts, t.integ);
+    };
+    {
+        double* pp_buf = op_route ? ctx->d_pp : ((ag && !ctx->d.inject_pp) ? ctx->d_ppc : (double*)nullptr);
+        if (side) {
+            JxDev dp = d;
+            const size_t shp = sizeof(double) * (JX_LDS_HDR + 8);
+            if (d.prep_pow) hipLaunchKernelGGL(jx_pp_kernel<true>, dim3(n), dim3(128), shp, st, dp, theta_dev, w0, pp_buf);
+            else hipLaunchKernelGGL(jx_pp_kernel<false>, dim3(n), dim3(128), shp, st, dp, theta_dev, w0, pp_buf);
+            if (ctx->side_fork == 0) {                                      // fork behind the profile kernel: beside the spline-array product
+                HIPCHK(ctx, hipEventRecord(ctx->ev_tail, st));
+                HIPCHK(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->ev_tail, 0));
+                launch_prep(ctx->side_stream, nullptr);
+                HIPCHK(ctx, hipEventRecord(ctx->ev_side, ctx->side_stream));
+            }
+        } else launch_prep(st, pp_buf);
     }
     if (tm) HIPCHK(ctx, hipEventRecord(es.e[1], st));
     if (op_route) {
@@ -1366,10 +1402,20 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
             launch_map(st, ctx->d, ctx->map_threads, ctx->map_lds, theta_dev, w0, n, ctx->d_img, nullptr, nullptr, nullptr, false);
         }
         if (tm || tm2) HIPCHK(ctx, hipEventRecord(es.e[2], st));
-        if ((rc = launch_mix(ctx, n, (tm || tm2) ? &es : nullptr))) return rc;
+        auto between = [&]() -> int {
+            if (!side || ctx->side_fork != 1) return JX_OK;
+            HIPCHK(ctx, hipEventRecord(ctx->ev_tail, st));                  // ("fork": behind stage 1)
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->ev_tail, 0));
+            launch_prep(ctx->side_stream, nullptr);
+            HIPCHK(ctx, hipEventRecord(ctx->ev_side, ctx->side_stream));
+            return JX_OK;
+        };
+        if ((rc = launch_mix(ctx, n, (tm || tm2) ? &es : nullptr, between))) return rc;
         const size_t sh = sizeof(double) * (JX_LDS_HDR + (size_t)d.nrow + 8);
+        if (side) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_side, 0));
         hipLaunchKernelGGL(jx_tail_row_kernel, dim3(n), dim3(JX_TAIL_THREADS), sh, st, d, m.Pt, m.last_ksplit, m.og.pstride, m.og.ldx,
                            ctx->d_cfac, ctx->d_sz0, ctx->d_base, logp_dev, w0, t.row, t.bright, t.chisq, t.parts);
+
         if (tm) HIPCHK(ctx, hipEventRecord(es.e[5], st));
         if (tm || tm2) ctx->ev_inflight.push_back(es);
         HIPCHK(ctx, hipGetLastError());
@@ -2063,6 +2109,9 @@ void jx_destroy(jx_ctx* ctx) {
     for (auto& es : ctx->ev_free) for (int k = 0; k < 6; ++k) (void)hipEventDestroy(es.e[k]);
     for (auto& pr : ctx->gt_inflight) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto& pr : ctx->gt_free) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
+    if (ctx->ev_side) (void)hipEventDestroy(ctx->ev_side);
+    if (ctx->ev_tail) (void)hipEventDestroy(ctx->ev_tail);
     for (auto& g : ctx->gslot) if (g.done) (void)hipEventDestroy(g.done);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);

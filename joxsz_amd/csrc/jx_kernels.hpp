@@ -432,6 +432,36 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
 }
 
 // ------------------------------------------------------------------------------------
+// The pressure profile on the radial grid alone (joxsz_funcs.py:275-287, 453): what the spline-array product waits for.
+// One block per walker; the same arithmetic as the grid pass of jx_prep_kernel (which then runs beside the SZ chain on
+// a second stream: priors, vetoes, X-ray side, conversion factors are consumed by the tail only).
+// ------------------------------------------------------------------------------------
+template <bool POW>
+__global__ void __launch_bounds__(128)
+jx_pp_kernel(JxDev c, const double* __restrict__ theta, int w0, double* __restrict__ pp_out /*[chunk][N]*/) {
+    JX_LDS_DECL;
+    double* p = sm;
+    const int w = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
+    jx_load_params(c, theta, w0 + w, p);
+    const int N_ = c.N;
+    double* __restrict__ out = pp_out + (size_t)w * N_;
+    if (POW) {
+        for (int i = tid; i < N_; i += nth) out[i] = jx_press(p, c.r_pp[i]);
+    } else {
+        double pl[10];
+        jx_prof_consts(p, c.ne_mode, pl);
+        // (two radii per trip, like the grid pass of jx_prep_kernel: two independent chains per lane)
+        for (int i = tid; i < N_; i += 2 * nth) {
+            const int i2 = min(i + nth, N_ - 1);
+            double xa, xb;
+            const double pa = jx_press_log(p, pl, c.lr_pp[i], &xa), pb = jx_press_log(p, pl, c.lr_pp[i2], &xb);
+            out[i] = pa;
+            if (i + nth < N_) out[i2] = pb;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // K1: FUSED profile -> Abel -> y -> spline -> map.  grid = (chunk walkers * map_split).
 //
 // Phase 1  pp_j = gNFW(r_j)                       -> LDS            (joxsz_funcs.py:453)
