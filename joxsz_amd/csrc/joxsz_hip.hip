@@ -653,7 +653,7 @@ static int launch_mix(jx_ctx* ctx, int n, EvSet* es, F&& between /* called betwe
         if (m.mfma) {
             // the matrix-core kernel keeps the operator in LDS: blocks of 8 waves, two per CU -- or of 16, one per CU, when the
             // operator is too large for two copies (sides beyond ~600)
-            lds_c = sizeof(double) * (16 * (size_t)crows + 4 * (size_t)mx.wld);
+            lds_c = sizeof(double) * 16 * (size_t)crows;
             wcap = (2 * (lds_c + sizeof(double) * JX_MXM_REGION(usp) * (8 / usp)) <= 158 * 1024) ? 8 : 16;
             if (m.wpb_force > 0) wcap = m.wpb_force;
         }

@@ -182,7 +182,10 @@ jx_rowmix_kernel(JxMix m, const TC* __restrict__ cft, double* __restrict__ Dt) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Stage 1 on the fp64 matrix cores, for R <= 16 rows per column (one 16-row tile).  Same walk as jx_rowmix_kernel: one
+// Stage 1 on the fp64 matrix cores, for R <= 16 rows per column (one 16-row tile).  OPT-IN (JOXSZ_MIX_MFMA=1): measured at 100 us
+// per 1024 walkers at 512^2 against the 81 us of jx_rowmix_kernel -- a wave's per-sample loop costs about as many cycles per
+// instruction whatever the instruction's kind, and the staging, the group counter and the dispatch weigh as much as the 16
+// multiply-adds they replace (profiles/r04_stage1_mfma_*.log).  Same walk as jx_rowmix_kernel: one
 // wave = one piece of column x' x 64 walkers, lane = walker, knots in the ring of NS named slots, the four spline weights
 // of a sample through the scalar unit, the sample evaluated by its walker's lane (4 FMAs; joxsz_funcs.py:460-462).  What
 // changes is the mixing: instead of R scalar-operand FMAs per sample, the samples of four consecutive rows u0 .. u0+3 go
@@ -194,7 +197,7 @@ jx_rowmix_kernel(JxMix m, const TC* __restrict__ cft, double* __restrict__ Dt) {
 // fourth sample has been written and used one group later (nothing waits on the LDS round trip; LDS serves a wave's requests
 // in order, so the next group's samples may overwrite the rows at once).  The groups of four are a function of the piece
 // alone, so a walker's sums do not depend on the launch.
-//   sm: [crows][16] operator C | [wld][4] spline weights of the column | [gpb][JX_MXM_REGION(usplit)] per walker group: the sample rows of its waves (wave xh at
+//   sm: [crows][16] operator C | [gpb][JX_MXM_REGION(usplit)] per walker group: the sample rows of its waves (wave xh at
 //       xh * JX_MXM_RING), later the sums of the later pieces [usplit - 1][16][64]
 // ------------------------------------------------------------------------------------------------------------------
 #define JX_MXM_LD 80
@@ -219,6 +222,7 @@ jx_rowmix_mfma_kernel(JxMix m, int crows, const TC* __restrict__ cft, double* __
     const bool active = grp < ngrp && xq < m.NU;               // (no early exit: every wave of the block meets the barriers below)
     const int xc = min(xq, m.NU - 1), xv = xc * usp + xh;      // column, piece
     const int ur = __builtin_amdgcn_readfirstlane(m.urange[xv]), ubeg = ur & 0xffff;
+    const double* __restrict__ wp = m.w4 + ((size_t)xc * m.wld + ubeg) * 4;
     const size_t tW = (size_t)m.tW;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<TC*>(cft), 0, m.cft_bytes, 0x00020000);
     const unsigned loff = (unsigned)((unsigned)grp * 64u + (unsigned)lane) * (unsigned)sizeof(TC);
@@ -229,17 +233,24 @@ jx_rowmix_mfma_kernel(JxMix m, int crows, const TC* __restrict__ cft, double* __
     unsigned kb = (unsigned)k0 * kstride;
 #pragma unroll
     for (int i = 0; i < NS - 1; ++i) { q[i] = jx_mx_ldknot<TC>(rs, loff, kb); kb += kstride; }
-    // the operator and the column's spline weights into LDS, once per block
-    double* __restrict__ wsm = sm_mix + (size_t)crows * 16;                     // [wld][4]
-    {
+    int pf[3] = {0, 0, 0};                                                     // (L2 pre-touch of the column's scalar streams, see jx_rowmix_kernel)
+    if (active) {
+        const char* wb = reinterpret_cast<const char*>(wp);
+        const int wbytes = (ur >> 16) * 32, sbytes = m.segld * 4;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int o = lane * 64 + k * 4096;
+            if (o < wbytes) pf[k] = *reinterpret_cast<const int*>(wb + o);
+        }
+        if (lane * 64 < sbytes) pf[2] = *reinterpret_cast<const int*>(reinterpret_cast<const char*>(sc) + lane * 64);
+        for (int o = lane * 64 + 2 * 4096; o < wbytes; o += 4096) pf[2] |= *reinterpret_cast<const int*>(wb + o);
+    }
+    {   // the operator into LDS, once per block
         const double2* __restrict__ src = reinterpret_cast<const double2*>(m.Cm);
         double2* dst = reinterpret_cast<double2*>(sm_mix);
         for (int i = threadIdx.x; i < crows * 8; i += blockDim.x) dst[i] = src[i];
-        const double2* __restrict__ wsrc = reinterpret_cast<const double2*>(m.w4 + (size_t)xc * m.wld * 4);
-        double2* wdst = reinterpret_cast<double2*>(wsm);
-        for (int i = threadIdx.x; i < m.wld * 2; i += blockDim.x) wdst[i] = wsrc[i];
     }
-    double* __restrict__ region = wsm + (size_t)m.wld * 4 + (size_t)gi * JX_MXM_REGION(usp);
+    double* __restrict__ region = sm_mix + (size_t)crows * 16 + (size_t)gi * JX_MXM_REGION(usp);
     double* __restrict__ ring = region + xh * JX_MXM_RING;
     const double* __restrict__ bp = ring + (lane >> 4) * JX_MXM_LD + (lane & 15);   // B operand of tile t: bp[16 t]
     const double* __restrict__ ap = sm_mix + (size_t)ubeg * 16 + lane;             // A operand of the group that starts at row ubeg + c: ap[16 c]
@@ -264,16 +275,6 @@ jx_rowmix_mfma_kernel(JxMix m, int crows, const TC* __restrict__ cft, double* __
         av = ap[(c - 4) * 16];
         }
     };
-    // The four spline weights of a sample do not depend on the walker.  They wait in a window of 64 samples, one sample per
-    // lane (refilled from the LDS copy every 64 samples), and reach the multiply-adds as scalar operands through v_readlane:
-    // no memory request sits between two samples of a wave.
-    int wl[8];
-    auto refill = [&]() {
-        const int u = min(ubeg + c + lane, m.wld - 1);
-        const int4 lo = *reinterpret_cast<const int4*>(wsm + (size_t)u * 4), hi = *reinterpret_cast<const int4*>(wsm + (size_t)u * 4 + 2);
-        wl[0] = lo.x; wl[1] = lo.y; wl[2] = lo.z; wl[3] = lo.w; wl[4] = hi.x; wl[5] = hi.y; wl[6] = hi.z; wl[7] = hi.w;
-    };
-    refill();
     int cntn[NS];
 #pragma unroll
     for (int j = 0; j < NS; ++j) cntn[j] = sc[j];
@@ -289,11 +290,7 @@ jx_rowmix_mfma_kernel(JxMix m, int crows, const TC* __restrict__ cft, double* __
             q[(j + NS - 1) % NS] = jx_mx_ldknot<TC>(rs, loff, kb);
             kb += kstride;
             for (int i = 0; i < cnt[j]; ++i) {
-                const int sl = c & 63;
-                const double wa = __hiloint2double(__builtin_amdgcn_readlane(wl[1], sl), __builtin_amdgcn_readlane(wl[0], sl));
-                const double wb = __hiloint2double(__builtin_amdgcn_readlane(wl[3], sl), __builtin_amdgcn_readlane(wl[2], sl));
-                const double wc = __hiloint2double(__builtin_amdgcn_readlane(wl[5], sl), __builtin_amdgcn_readlane(wl[4], sl));
-                const double wd = __hiloint2double(__builtin_amdgcn_readlane(wl[7], sl), __builtin_amdgcn_readlane(wl[6], sl));
+                const double wa = wp[0], wb = wp[1], wc = wp[2], wd = wp[3];
                 double f = wa * (double)q[j].x;
                 f = fma(wb, (double)q[(j + 1) % NS].x, f);
                 f = fma(wc, (double)q[j].y, f);
@@ -302,14 +299,16 @@ jx_rowmix_mfma_kernel(JxMix m, int crows, const TC* __restrict__ cft, double* __
                 if (!(m.dbg & 8))
 #endif
                 ring[(c & 3) * JX_MXM_LD + lane] = f;
+#ifdef JOXSZ_ABLATIONS
+                if (!(m.dbg & 2))
+#endif
+                wp += 4;
                 ++c;
-                if ((c & 3) == 0) {
-                    boundary();
-                    if ((c & 63) == 0) refill();
-                }
+                if ((c & 3) == 0) boundary();
             }
         }
     }
+    if (m.n < 0 && (pf[0] | pf[1] | pf[2]) == 0x5a5a1234) Dt[0] = 0.0;   // (never: keeps the prefetch loads alive)
     // the last, partial group: rows beyond the piece enter as zero samples (their operator rows are finite)
     if (c & 3) {
         while (c & 3) { ring[(c & 3) * JX_MXM_LD + lane] = 0.0; ++c; }

@@ -653,3 +653,31 @@ def test_spline_arrays_matrix_product_against_abel_kernel(S, N, W, monkeypatch):
     assert np.max(np.abs(ya - yb) / np.abs(ya).max(axis=1, keepdims=True)) < 1e-13
     assert np.max(np.abs(ma - mb) / np.abs(ma).max(axis=1, keepdims=True)) < 5e-12  # (second differences: cancellation)
     np.testing.assert_allclose(b[0][fin], a[0][fin], rtol=1e-9)
+
+
+@pytest.mark.parametrize('S,N,usplit', [(512, 500, '2'), (512, 500, '1'), (513, 500, '3')])
+def test_stage_1_on_the_matrix_cores_against_the_vector_unit_kernel(S, N, usplit, monkeypatch):
+    """The opt-in form of stage 1 (JOXSZ_MIX_MFMA=1: jx_rowmix_mfma_kernel, the samples of four rows through LDS into
+    v_mfma_f64_16x16x4, operator in LDS) against the default jx_rowmix_kernel on the same tables: the rows kept per map column
+    (work buffer 'stage1') to rounding, the log-posterior far inside the 1e-6 bar, one, two and three pieces per column (the
+    piece lengths 257, 128 + 129, 85 + 86 + 86 exercise full and partial groups of four)."""
+    from joxsz_amd import datasets
+    pb = datasets.synthetic_problem(S=S, N=N, seed=21)
+    th = datasets.walker_ball(pb, 200, spread=0.03, seed=21)
+    monkeypatch.setenv('JOXSZ_MIX_USPLIT', usplit)
+    out = {}
+    for mfma in ('0', '1'):
+        monkeypatch.setenv('JOXSZ_MIX_MFMA', mfma)
+        post = _post(pb)
+        assert post.ctx.conv_layout['form'] == 'lowrank' and post.ctx.conv_layout['R'] <= 16
+        assert post.ctx.truncation['stage1_on_matrix_cores'] == (mfma == '1')
+        lp = post.log_prob(th)
+        d = post.ctx.workspace('stage1')[:, :post.ctx.conv_layout['R'], :200].copy()
+        out[mfma] = (lp, d, post.ctx.truncation)
+        post.close()
+    (a, da, tra), (b, db, trb) = out['0'], out['1']
+    fin = np.isfinite(a)
+    assert fin.sum() >= 150 and np.array_equal(np.isfinite(b), fin)
+    assert np.abs(db - da).max() <= 1e-12 * np.abs(da).max()
+    np.testing.assert_allclose(b[fin], a[fin], rtol=1e-10)
+    assert abs(trb['est_rel_sz_like_err_box'] - tra['est_rel_sz_like_err_box']) <= 1e-10
