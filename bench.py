@@ -250,7 +250,8 @@ def main():
     ap.add_argument('--route', choices=('map', 'operator'), default='map',
                     help="'map': the reference's sequence of steps per walker (the BASELINE metric); 'operator': the collapsed route (jx_set_route)")
     ap.add_argument('--fwhm', type=float, default=18.5, help='beam FWHM in arcsec (B = 2*floor(3*fwhm/step)+1)')
-    ap.add_argument('--dtype', choices=('f64', 'f32'), default='f64', help="'f64': the reference's arithmetic (the metric); 'f32': the fp32 variant")
+    ap.add_argument('--dtype', choices=('f64', 'f32', 'f32c'), default='f64',
+                    help="'f64': the reference's arithmetic (the metric); 'f32': fp32 spline arrays; 'f32c': fp32 arithmetic in stages 1 and 2")
     ap.add_argument('--no-f32', action='store_true', help='skip the side measurement of the fp32 variant')
     ap.add_argument('--no-other-configs', action='store_true', help='skip the strong-scaling rows of BASELINE configs[3] and configs[4]')
     args = ap.parse_args()
@@ -412,24 +413,31 @@ def main():
     # the fp32 variant on the same walkers (BASELINE configs[4]'s tolerance sweep): beside the f64 metric, never instead of it
     f32 = None
     if rank == 0 and comm is None and args.route == 'map' and args.dtype == 'f64' and not args.no_f32:
-        try:
-            p3 = JoxszPosterior(pb, device=local_rank, dtype='f32')
-            c3 = p3.ctx
-            t3, l3 = c3.dev_alloc(theta.nbytes), c3.dev_alloc(8 * W)
-            c3.h2d(t3, theta)
-            dt = time_steps(c3, t3, W, l3, max(5, args.steps // 4), 3)
-            lp32 = np.empty(W)
-            c3.d2h(lp32, l3)
-            ch32, ch64 = c3.eval_stage(theta[:256], 'chisq'), ctx.eval_stage(theta[:256], 'chisq')
-            rel = np.abs(lp32 - final) / np.abs(final)
-            f32 = {'dtype': 'f32', 'value': W / dt, 'unit': 'walker-likelihoods/s', 'ms_per_step': 1e3 * dt,
-                   'rel_dlogp_vs_f64': {'max': float(rel.max()), 'median': float(np.median(rel))},
-                   'abs_dchisq_vs_f64': {'max': float(np.abs(ch32 - ch64).max()), 'median': float(np.median(np.abs(ch32 - ch64)))},
-                   'note': 'spline arrays (y_k, M_k) rounded to fp32 once and read as fp32 by the sample evaluation; sums, matrix-core '
-                           'product, tail and everything per-walker in fp64 (jx_config.dtype = 1)'}
-            p3.close()
-        except Exception as exc:
-            f32 = {'dtype': 'f32', 'error': str(exc)}
+        f32 = {}
+        notes = {'f32': 'jx_config.dtype = 1: spline arrays (y_k, M_k) rounded to fp32 once and read as fp32 by the sample evaluation; sums, matrix-core '
+                        'product, tail and everything per-walker in fp64',
+                 'f32c': 'jx_config.dtype = 2: fp32 arithmetic -- stage 1 in packed fp32 FMAs (v_pk_fma_f32), stage 2 on v_mfma_f32_16x16x4_f32, stage-1 rows '
+                         'and partial rows in fp32, K slices added in fp64 by the tail; everything per-walker (priors, X-ray, conversion, chi^2) in fp64'}
+        ch64 = ctx.eval_stage(theta[:256], 'chisq')
+        for dt_name in ('f32', 'f32c'):
+            try:
+                p3 = JoxszPosterior(pb, device=local_rank, dtype=dt_name)
+                c3 = p3.ctx
+                t3, l3 = c3.dev_alloc(theta.nbytes), c3.dev_alloc(8 * W)
+                c3.h2d(t3, theta)
+                dt = time_steps(c3, t3, W, l3, max(5, args.steps // 4), 3)
+                lp32 = np.empty(W)
+                c3.d2h(lp32, l3)
+                ch32 = c3.eval_stage(theta[:256], 'chisq')
+                rel = np.abs(lp32 - final) / np.abs(final)
+                f32[dt_name] = {'dtype': dt_name, 'value': W / dt, 'unit': 'walker-likelihoods/s', 'ms_per_step': 1e3 * dt,
+                                'speedup_vs_f64': (elapsed / args.steps) / dt,
+                                'rel_dlogp_vs_f64': {'max': float(rel.max()), 'median': float(np.median(rel))},
+                                'abs_dchisq_half_vs_f64': {'max': float(np.abs(ch32 - ch64).max() / 2), 'median': float(np.median(np.abs(ch32 - ch64)) / 2)},
+                                'note': notes[dt_name]}
+                p3.close()
+            except Exception as exc:
+                f32[dt_name] = {'dtype': dt_name, 'error': str(exc)}
 
     # the kernel north_star's ">= 60 % of the HBM roofline in the Abel+map kernel" is about: profile -> Abel -> spline -> full
     # S x S map, and the measured copy bandwidth of this card as the practical roofline beside the nominal one
@@ -484,7 +492,7 @@ def main():
     # configs[4] (8192 walkers, 1024^2 / 1000-pt, fp64 and fp32), a few steps each, outside the timed region
     other = None
     want_other = args.route == 'map' and not args.no_other_configs and (args.S, args.N, pb.sz_only) == (512, 500, False)
-    dts = [np.inf, np.inf, np.inf]                            # this rank's time per step: configs[3], configs[4] f64, configs[4] f32
+    dts = [np.inf, np.inf, np.inf]                            # this rank's time per step: configs[3], configs[4] f64, configs[4] f32c
     if want_other:
         other = {}
         try:
@@ -505,7 +513,7 @@ def main():
             lo, hi = shard_bounds(8192, world, rank)
             n4 = hi - lo
             pb4 = datasets.synthetic_problem(S=1024, N=1000, seed=0)
-            for i4, dt_name in enumerate(('f64', 'f32')):
+            for i4, dt_name in enumerate(('f64', 'f32c')):
                 p4 = JoxszPosterior(pb4, device=local_rank, dtype=dt_name, max_batch=n4)
                 c4 = p4.ctx
                 cand4 = datasets.walker_ball(pb4, 256, spread=0.02, seed=5)
@@ -523,7 +531,7 @@ def main():
     if want_other:
         dts = agree_on_side_times(comm, dts)
     if other is not None:
-        for key, tot, dt in (('configs[3]', 4096, dts[0]), ('configs[4] f64', 8192, dts[1]), ('configs[4] f32', 8192, dts[2])):
+        for key, tot, dt in (('configs[3]', 4096, dts[0]), ('configs[4] f64', 8192, dts[1]), ('configs[4] f32c', 8192, dts[2])):
             if key in other:
                 if np.isfinite(dt):
                     other[key].update(value=tot / dt, ms_per_step=1e3 * dt)

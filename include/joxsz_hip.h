@@ -69,7 +69,8 @@ typedef struct jx_config {
     int32_t fft_pad;          /* padded side of the beam convolution (0 = library default)     */
     int32_t map_split;        /* row slabs per walker in the Abel+map kernel (0 = default)     */
     int32_t conv_mode;        /* beam + transfer-function step: 0 auto, 1 rocFFT sequence, 2 contracted route (hand-written kernels) */
-    int32_t dtype;            /* arithmetic of the map samples: 0 = f64 (the reference's), 1 = f32 spline arrays and sample evaluation */
+    int32_t dtype;            /* arithmetic of the SZ stages: 0 = f64 (the reference's); 1 = fp32 spline arrays, every sum in fp64; 2 = fp32
+                               * arithmetic in stage 1 (packed fp32 FMAs) and stage 2 (fp32 matrix cores), K slices added in fp64 (low-rank form only) */
     int32_t calc_integ;       /* SZ_data.calc_integ: integrated-Compton term (joxsz_funcs.py:480-484, joxsz_main.py:65) */
     int32_t reserved1;        /* keeps the doubles 8-byte aligned; must be 0                   */
     double step;              /* arcsec                                   (joxsz_main.py:21)   */

@@ -109,7 +109,8 @@ struct jx_ctx {
     double* d_Tm = nullptr; int tm_ld = 0, tm_ntile = 0, tm_npair = 0;
     double* d_ppc = nullptr;           // [chunk][N] prep kernel -> jx_abel_gemm_kernel
     bool abel_gemm = true;
-    bool f32 = false;                  // jx_config.dtype == 1: fp32 spline arrays, fp32 evaluation of the map samples
+    bool f32 = false;                  // jx_config.dtype >= 1: fp32 spline arrays, fp32 evaluation of the map samples
+    bool f32c = false;                 // jx_config.dtype == 2: fp32 arithmetic in stage 1 and stage 2 as well (packed fp32 FMAs, fp32 matrix cores)
 
     MixBack mix;
     FftBack fft;                       // conv_mode 1: the back end (cap = chunk); conv_mode 2: reference facility (built on first use)
@@ -603,15 +604,26 @@ static int mix_setup(jx_ctx* ctx, const MixBuild& mb, long long tW) {
         if ((rc = dev_put_l(ctx, m.allocs, mb.cols.w4.data(), mb.cols.w4.size(), &qd))) return rc; mx.w4 = qd;
         if ((rc = dev_put_l(ctx, m.allocs, mb.Cm.data(), mb.Cm.size(), &qd))) return rc; mx.Cm = qd;
     }
+    if (ctx->f32c && mb.form == 0) {                              // fp32 arithmetic: the stage-1 tables once more, rounded to fp32
+        std::vector<float> wf(mb.cols.w4.begin(), mb.cols.w4.end()), cf(mb.Cm.begin(), mb.Cm.end());
+        float* qf;
+        if ((rc = dev_put_l(ctx, m.allocs, wf.data(), wf.size(), &qf))) return rc; mx.w4f = qf;
+        if ((rc = dev_put_l(ctx, m.allocs, cf.data(), cf.size(), &qf))) return rc; mx.Cmf = qf;
+    }
     JxOpg& og = m.og;
     memset(&og, 0, sizeof(og));
     og.tW = tW; og.ntile = mb.ntile; og.nog = mb.nog; og.ldx = 16 * mb.ntile;
     if ((rc = dev_put_l(ctx, m.allocs, mb.Op.data(), mb.Op.size(), &qd))) return rc; og.Op = qd;
+    if (ctx->f32c && mb.form == 0) {
+        std::vector<float> of(mb.Op.begin(), mb.Op.end());
+        float* qf;
+        if ((rc = dev_put_l(ctx, m.allocs, of.data(), of.size(), &qf))) return rc; og.Opf = qf;
+    }
     m.ncol = 2 * N;
     if ((rc = dev_new_l(ctx, m.allocs, 2 * esz * cft_rows * tW / sizeof(double) + 1, &m.cft, true))) return rc;
     if (mb.form == 0) {
-        if ((rc = dev_new_l(ctx, m.allocs, mb.krows * (size_t)tW, &m.Dt, true))) return rc;
-        og.Dt = m.Dt;
+        if ((rc = dev_new_l(ctx, m.allocs, mb.krows * (size_t)tW, &m.Dt, true))) return rc;    // (fp32 arithmetic: the same buffer holds floats)
+        og.Dt = m.Dt; og.Dtf = reinterpret_cast<const float*>(m.Dt);
     } else {
         JxSamp* qe;
         if ((rc = dev_put_l(ctx, m.allocs, mb.ent.data(), mb.ent.size(), &qe))) return rc; og.ent = qe;
@@ -670,7 +682,15 @@ static int launch_mix(jx_ctx* ctx, int n, EvSet* es, F&& between /* called betwe
         // (the vector-unit kernel keeps the default 64 KB limit of dynamic LDS: mix_setup clamps usplit so that a block's hand-over fits)
         if (lds1 > (m.mfma ? (size_t)158 * 1024 : (size_t)64 * 1024)) { ctx->err = "stage 1: the hand-over of the column pieces does not fit the LDS (lower JOXSZ_MIX_USPLIT or JOXSZ_MIX_WPB)"; return JX_ERR_UNSUPPORTED; }
         bool done = false;
-        if (m.mfma) {
+        if (ctx->f32c) {
+            const size_t ldsf = sizeof(float) * (size_t)gpb * (usp - 1) * m.RT * 64;
+#define JX_MIXF_GO(Rv) if (!done && m.RT == Rv) { \
+            hipLaunchKernelGGL((jx_rowmix_f32_kernel<Rv, JX_MIX_NS>), g1, dim3(64 * wpb), ldsf, st, mx, reinterpret_cast<const float2*>(m.cft), reinterpret_cast<float*>(m.Dt)); \
+            done = true; }
+            JX_MIX_RTS(JX_MIXF_GO)
+#undef JX_MIXF_GO
+        }
+        if (!done && m.mfma) {
             if (ctx->f32) hipLaunchKernelGGL((jx_rowmix_mfma_kernel<JX_MIX_NS, float2>), g1, dim3(64 * wpb), lds1, st, mx, crows, reinterpret_cast<const float2*>(m.cft), m.Dt);
             else hipLaunchKernelGGL((jx_rowmix_mfma_kernel<JX_MIX_NS, double2>), g1, dim3(64 * wpb), lds1, st, mx, crows, reinterpret_cast<const double2*>(m.cft), m.Dt);
             done = true;
@@ -698,6 +718,10 @@ static int launch_mix(jx_ctx* ctx, int n, EvSet* es, F&& between /* called betwe
         const dim3 g2((unsigned)(og.kmajor ? 8 * nwb * og.nog * ((ksplit + 7) / 8) : 8 * nwb * ((nunit + 7) / 8)));
         const size_t lds = m.form == 1 ? (size_t)JX_OPG_ECH * 4 * sizeof(JxSamp) : 0;
         bool done = false;
+#define JX_OPGF_GO(Xv) if (!done && ctx->f32c && m.nxt == Xv) { \
+            hipLaunchKernelGGL((jx_opgemm_f32_kernel<Xv>), g2, dim3(256), 0, st, og, reinterpret_cast<float*>(m.Pt)); done = true; }
+        JX_MIX_NXTS(JX_OPGF_GO)
+#undef JX_OPGF_GO
 #define JX_OPG_GO(Xv) if (!done && m.nxt == Xv) { \
             if (m.form == 1 && ctx->f32) hipLaunchKernelGGL((jx_opgemm_kernel<1, Xv, float2>), g2, dim3(256), lds, st, og, reinterpret_cast<const float2*>(m.cft), m.Pt); \
             else if (m.form == 1) hipLaunchKernelGGL((jx_opgemm_kernel<1, Xv, double2>), g2, dim3(256), lds, st, og, reinterpret_cast<const double2*>(m.cft), m.Pt); \
@@ -892,7 +916,7 @@ int jx_create(const jx_config* cfg, jx_ctx** out) {
     if (c.N < c.S - c.S / 2) return JX_ERR_INVALID;       // r_pp[:nrow-1] must exist (joxsz_funcs.py:469)
     if (!(c.step > 0) || !(c.kpc_as > 0) || !(c.m_e > 0) || !(c.sigma_T > 0) || !(c.kpc_cm > 0)) return JX_ERR_INVALID;
     if (c.nann > 64 || c.nband > 64 || c.N > 4096 || c.S > 4096) return JX_ERR_UNSUPPORTED;
-    if (c.dtype != 0 && c.dtype != 1) return JX_ERR_INVALID;
+    if (c.dtype < 0 || c.dtype > 2) return JX_ERR_INVALID;
     if (c.calc_integ && !(c.integ_sig > 0)) return JX_ERR_INVALID;
 
     int ndev = 0;
@@ -999,7 +1023,8 @@ static int finalize_impl(jx_ctx* ctx) {
     ctx->op_narrow = env_str("JOXSZ_OP_NARROW") != nullptr;
     if (const char* e = env_str("JOXSZ_SIDE_STREAM")) ctx->side_on = atoi(e) != 0;
     if (const char* e = env_str("JOXSZ_SIDE_FORK")) ctx->side_fork = atoi(e) != 0;
-    ctx->f32 = c.dtype == 1;
+    ctx->f32 = c.dtype >= 1;
+    ctx->f32c = c.dtype == 2;
     if (ctx->f32 && !ctx->abel_gemm) { ctx->err = "dtype f32 takes its spline arrays from the matrix product only (JOXSZ_ABEL_GEMM=0 is an f64 setting)"; return JX_ERR_UNSUPPORTED; }
 
     int chunk = c.max_batch > 0 ? c.max_batch : 1024;
@@ -1031,6 +1056,10 @@ static int finalize_impl(jx_ctx* ctx) {
     ctx->conv_mode = mixb.ok ? 2 : 1;
     if (ctx->f32 && ctx->conv_mode != 2) {                       // never silently fall back to the fp64 arithmetic
         ctx->err = "dtype f32 is available on the contracted route only" + (mixb.why.empty() ? std::string() : " (" + mixb.why + ")");
+        return JX_ERR_UNSUPPORTED;
+    }
+    if (ctx->f32c && mixb.form != 0) {
+        ctx->err = "dtype 2 (fp32 arithmetic) exists on the low-rank form of the contracted route only; this problem takes the full form (dtype 1 keeps the arithmetic in fp64)";
         return JX_ERR_UNSUPPORTED;
     }
     int P = c.fft_pad > 0 ? c.fft_pad : jxt::next_smooth_even(S + o);
@@ -1413,8 +1442,10 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
         if ((rc = launch_mix(ctx, n, (tm || tm2) ? &es : nullptr, between))) return rc;
         const size_t sh = sizeof(double) * (JX_LDS_HDR + (size_t)d.nrow + 8);
         if (side) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_side, 0));
-        hipLaunchKernelGGL(jx_tail_row_kernel, dim3(n), dim3(JX_TAIL_THREADS), sh, st, d, m.Pt, m.last_ksplit, m.og.pstride, m.og.ldx,
-                           ctx->d_cfac, ctx->d_sz0, ctx->d_base, logp_dev, w0, t.row, t.bright, t.chisq, t.parts);
+        if (ctx->f32c) hipLaunchKernelGGL(jx_tail_row_kernel<float>, dim3(n), dim3(JX_TAIL_THREADS), sh, st, d, reinterpret_cast<const float*>(m.Pt), m.last_ksplit,
+                                          m.og.pstride, m.og.ldx, ctx->d_cfac, ctx->d_sz0, ctx->d_base, logp_dev, w0, t.row, t.bright, t.chisq, t.parts);
+        else hipLaunchKernelGGL(jx_tail_row_kernel<double>, dim3(n), dim3(JX_TAIL_THREADS), sh, st, d, m.Pt, m.last_ksplit, m.og.pstride, m.og.ldx,
+                                ctx->d_cfac, ctx->d_sz0, ctx->d_base, logp_dev, w0, t.row, t.bright, t.chisq, t.parts);
 
         if (tm) HIPCHK(ctx, hipEventRecord(es.e[5], st));
         if (tm || tm2) ctx->ev_inflight.push_back(es);
@@ -1958,8 +1989,8 @@ int jx_debug_workspace(jx_ctx* ctx, int which, void** dev, int32_t geom[4]) {
                 *dev = ctx->d_img; geom[0] = ctx->chunk; geom[1] = ctx->d.q_nb; geom[2] = (int)ctx->d.img_ld; geom[3] = 8; break;
         case 1: *dev = m.cft; geom[0] = ctx->cfg.N; geom[1] = (int)m.tW; geom[2] = 2; geom[3] = ctx->f32 ? 4 : 8; break;
         case 2: if (m.form != 0) { ctx->err = "no stage-1 rows in the full form"; return JX_ERR_UNSUPPORTED; }
-                *dev = m.Dt; geom[0] = m.mx.NU; geom[1] = m.mx.R; geom[2] = (int)m.tW; geom[3] = 8; break;
-        case 3: *dev = m.Pt; geom[0] = m.last_ksplit; geom[1] = (int)m.tW; geom[2] = m.og.ldx; geom[3] = 8; break;
+                *dev = m.Dt; geom[0] = m.mx.NU; geom[1] = m.mx.R; geom[2] = (int)m.tW; geom[3] = ctx->f32c ? 4 : 8; break;
+        case 3: *dev = m.Pt; geom[0] = m.last_ksplit; geom[1] = (int)m.tW; geom[2] = m.og.ldx; geom[3] = ctx->f32c ? 4 : 8; break;
         case 4: if (m.form != 0) { ctx->err = "no stage-1 operator in the full form"; return JX_ERR_UNSUPPORTED; }
                 *dev = const_cast<double*>(m.mx.Cm); geom[0] = 1; geom[1] = m.mx.wld; geom[2] = m.mx.cld; geom[3] = 8; break;
         case 5: *dev = const_cast<double*>(m.og.Op); geom[0] = 4 * m.ksteps; geom[1] = 16; geom[2] = m.og.ntile; geom[3] = 8; break;

@@ -56,6 +56,8 @@ struct JxMix {
     const int* seg;                // [NU * usplit][segld] samples per segment
     const double* w4;              // [NU][wld][4] weights (A, B, C, D) of sample u of column x'
     const double* Cm;              // [wld][cld]   C[u][j], zero padded
+    const float* w4f;              // fp32 arithmetic (dtype 2): the same two tables rounded to fp32
+    const float* Cmf;
 };
 
 typedef unsigned jx_mx_u4 __attribute__((ext_vector_type(4)));
@@ -178,6 +180,106 @@ jx_rowmix_kernel(JxMix m, const TC* __restrict__ cft, double* __restrict__ Dt) {
 #pragma unroll
         for (int r = 0; r < RT; ++r)
             if (r < m.R) dp[(size_t)r * tW] = acc[r];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Stage 1 in fp32 arithmetic (jx_config.dtype = 2; BASELINE configs[4]'s fp32 variant): the walk of jx_rowmix_kernel with fp32
+// knots, weights, operator and sums.  The R multiply-adds of a sample are R / 2 packed ones (v_pk_fma_f32: two rows of the
+// operator as one 64-bit scalar operand, the sample in both halves), the hand-over of the column pieces and the rows written
+// to Dt are fp32.  What this costs in accuracy is measured, not assumed: test_fp32_variant_tolerance_sweep, bench.py.
+// ------------------------------------------------------------------------------------------------------------------
+typedef float jx_mx_v2f __attribute__((ext_vector_type(2)));
+
+template <int RT, int NS>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8)))
+jx_rowmix_f32_kernel(JxMix m, const float2* __restrict__ cft, float* __restrict__ Dt) {
+    static_assert(NS == 8 && RT % 2 == 0, "segment counts come in groups of 8; operator rows in pairs");
+    extern __shared__ __attribute__((aligned(16))) float sm_mixf[];            // [gpb][usplit - 1][RT][64] sums of the later pieces
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
+    const int usp = m.usplit, gpb = wpb / usp;
+    const int xh = wv % usp, gi = wv / usp;
+    const int ngrp = (m.n + 63) >> 6, nq = (ngrp + gpb - 1) / gpb;
+    const int id = blockIdx.x;
+    int gq, xq;
+    if (m.cper > 0) { const int xcd = id & 7, jj = id >> 3; gq = xcd % nq; xq = xcd / nq + m.cper * jj; }
+    else { gq = id % nq; xq = id / nq; }
+    const int grp = gq * gpb + gi;
+    const bool active = grp < ngrp && xq < m.NU;
+    const int xv = min(xq, m.NU - 1) * usp + xh;
+    const int ur = __builtin_amdgcn_readfirstlane(m.urange[xv]), ubeg = ur & 0xffff, ucnt = ur >> 16;
+    const size_t w = (size_t)grp * 64 + lane;
+    const size_t tW = (size_t)m.tW;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(cft), 0, m.cft_bytes, 0x00020000);
+    const unsigned loff = (unsigned)((unsigned)grp * 64u + (unsigned)lane) * (unsigned)sizeof(float2);
+    const unsigned kstride = (unsigned)(tW * sizeof(float2));
+    const int k0 = __builtin_amdgcn_readfirstlane(m.seg0[xv]), nseg = active ? __builtin_amdgcn_readfirstlane(m.nseg[xv]) : 0;
+    const int* __restrict__ sc = m.seg + (size_t)xv * m.segld;
+    const float* __restrict__ wp = m.w4f + ((size_t)(xv / usp) * m.wld + ubeg) * 4;
+    const float* __restrict__ cp = m.Cmf + (size_t)ubeg * RT;
+    int pf[3] = {0, 0, 0};                                                     // (L2 pre-touch of the column's scalar streams, see jx_rowmix_kernel)
+    if (active) {
+        const char* wb = reinterpret_cast<const char*>(wp);
+        const int wbytes = ucnt * 16, sbytes = m.segld * 4;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int o = lane * 64 + k * 4096;
+            if (o < wbytes) pf[k] = *reinterpret_cast<const int*>(wb + o);
+        }
+        if (lane * 64 < sbytes) pf[2] = *reinterpret_cast<const int*>(reinterpret_cast<const char*>(sc) + lane * 64);
+    }
+    jx_mx_v2f acc[RT / 2];
+#pragma unroll
+    for (int j = 0; j < RT / 2; ++j) acc[j] = jx_mx_v2f{0.f, 0.f};
+    float2 q[NS];
+    unsigned kb = (unsigned)k0 * kstride;
+#pragma unroll
+    for (int i = 0; i < NS - 1; ++i) { q[i] = jx_mx_ldknot<float2>(rs, loff, kb); kb += kstride; }
+    for (int s0 = 0; s0 < nseg; s0 += NS) {
+        int cnt[NS];
+#pragma unroll
+        for (int j = 0; j < NS; ++j) cnt[j] = sc[s0 + j];
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            q[(j + NS - 1) % NS] = jx_mx_ldknot<float2>(rs, loff, kb);
+            kb += kstride;
+            for (int i = 0; i < cnt[j]; ++i) {
+                const float wa = wp[0], wb = wp[1], wc = wp[2], wd = wp[3];
+                float f = wa * q[j].x;
+                f = fmaf(wb, q[(j + 1) % NS].x, f);
+                f = fmaf(wc, q[j].y, f);
+                f = fmaf(wd, q[(j + 1) % NS].y, f);
+                const jx_mx_v2f ff = jx_mx_v2f{f, f};
+#pragma unroll
+                for (int r = 0; r < RT / 2; ++r) acc[r] = __builtin_elementwise_fma(jx_mx_v2f{cp[2 * r], cp[2 * r + 1]}, ff, acc[r]);
+                wp += 4; cp += RT;
+            }
+        }
+    }
+    if (m.n < 0 && (pf[0] | pf[1] | pf[2]) == 0x5a5a1234) Dt[0] = 0.f;   // (never: keeps the prefetch loads alive)
+    if (usp > 1) {
+        if (xh > 0) {
+            float* __restrict__ sp = sm_mixf + ((size_t)(gi * (usp - 1) + xh - 1) * RT) * 64 + lane;
+#pragma unroll
+            for (int r = 0; r < RT / 2; ++r) { sp[(2 * r) * 64] = acc[r].x; sp[(2 * r + 1) * 64] = acc[r].y; }
+        }
+        __syncthreads();
+        if (xh == 0) {
+            for (int hh = 1; hh < usp; ++hh) {                  // fixed order: piece 0 + piece 1 (+ piece 2 ...)
+                const float* __restrict__ sp = sm_mixf + ((size_t)(gi * (usp - 1) + hh - 1) * RT) * 64 + lane;
+#pragma unroll
+                for (int r = 0; r < RT / 2; ++r) { acc[r].x += sp[(2 * r) * 64]; acc[r].y += sp[(2 * r + 1) * 64]; }
+            }
+        }
+    }
+    if (xh == 0 && active) {
+        float* __restrict__ dp = Dt + (size_t)xq * m.R * tW + w;
+#pragma unroll
+        for (int r = 0; r < RT / 2; ++r) {
+            if (2 * r < m.R) dp[(size_t)(2 * r) * tW] = acc[r].x;
+            if (2 * r + 1 < m.R) dp[(size_t)(2 * r + 1) * tW] = acc[r].y;
+        }
     }
 }
 
@@ -372,6 +474,8 @@ struct JxOpg {
     const double* Op;              // [ksplit * kper + slack][4][16][ntile]
     const double* Dt;              // LOAD: [4 (ksplit kper + slack)][tW]
     const JxSamp* ent;             // EVAL: [4 (ksplit kper + slack)]
+    const float* Opf;              // fp32 arithmetic (dtype 2): the operator and the stage-1 rows in fp32
+    const float* Dtf;
 };
 
 #ifndef JX_OPG_RD
@@ -476,12 +580,83 @@ jx_opgemm_kernel(JxOpg g, const TC* __restrict__ cft, double* __restrict__ Pt) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Stage 2 in fp32 arithmetic (dtype 2, low-rank form): the product of jx_opgemm_kernel<LOAD> on v_mfma_f32_16x16x4_f32, stage-1
+// rows, operator and partial rows in fp32 (the tail adds the K slices in fp64).  Same blocks, K slices and XCD ownership.
+//   D of the fp32 instruction: register g of lane l = out[walker 4 (l >> 4) + g][x = l & 15]
+// ------------------------------------------------------------------------------------------------------------------
+typedef float jx_mx_v4f __attribute__((ext_vector_type(4)));
+
+template <int NXT>
+__global__ void __launch_bounds__(256)
+jx_opgemm_f32_kernel(JxOpg g, float* __restrict__ Pt) {
+    constexpr int RD = JX_OPG_RD;
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwb = (g.n + 127) >> 7, nunit = g.ksplit * g.nog;
+    const int id = blockIdx.x, xcd = id & 7, jj = id >> 3;
+    const int wb = jj % nwb;
+    int ks, og;
+    if (g.kmajor) {
+        const int lu = jj / nwb;
+        og = lu % g.nog; ks = (lu / g.nog) * 8 + xcd;
+        if (ks >= g.ksplit) return;
+    } else {
+        const int unit = (jj / nwb) * 8 + xcd;
+        if (unit >= nunit) return;
+        ks = unit / g.nog; og = unit - ks * g.nog;
+    }
+    const size_t tW = (size_t)g.tW;
+    const size_t wbase = (size_t)wb * 128 + wv * 32 + li;
+    const int s0 = ks * g.kper, s1 = s0 + g.kper;
+    jx_mx_v4f acc[2][NXT];
+#pragma unroll
+    for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+        for (int t = 0; t < NXT; ++t) acc[mm][t] = jx_mx_v4f{0.f, 0.f, 0.f, 0.f};
+    const float* __restrict__ opb = g.Opf + ((size_t)lk * 16 + li) * g.ntile + (size_t)og * NXT;
+    const size_t opstep = (size_t)64 * g.ntile;
+    float b[RD][NXT], a[RD][2];
+    auto fetch = [&](int slot, int s) {
+#pragma unroll
+        for (int t = 0; t < NXT; ++t) b[slot][t] = opb[(size_t)s * opstep + t];
+        const float* dp = g.Dtf + (size_t)(4 * s + lk) * tW + wbase;
+        a[slot][0] = dp[0]; a[slot][1] = dp[16];
+    };
+#pragma unroll
+    for (int u = 0; u < RD - 1; ++u) fetch(u, min(s0 + u, s1 - 1));
+    for (int s = s0; s < s1; s += RD) {
+#pragma unroll
+        for (int u = 0; u < RD; ++u) {
+            fetch((u + RD - 1) % RD, min(s + u + RD - 1, s1 - 1));
+#pragma unroll
+            for (int t = 0; t < NXT; ++t) {
+                acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][0], b[u][t], acc[0][t], 0, 0, 0);
+                acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][1], b[u][t], acc[1][t], 0, 0, 0);
+            }
+        }
+    }
+    const size_t wrow = (size_t)wb * 128 + wv * 32 + 4 * lk;
+#pragma unroll
+    for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const size_t w = wrow + mm * 16 + gq;
+            if (w < (size_t)g.n) {
+                float* row = Pt + (size_t)ks * g.pstride + w * g.ldx + (size_t)(og * NXT) * 16 + li;
+#pragma unroll
+                for (int t = 0; t < NXT; ++t) row[t * 16] = acc[mm][t][gq];
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Tail: the extracted row arrives as nks partial rows P[ks][w][ldx] (one per K slice); they are added in a fixed order
 // (a result does not depend on the launch it was part of), then conversion, data radii, chi^2 and total as in
 // jx_tail_kernel (joxsz_funcs.py:472-479, 538).  One block per walker.
 // ------------------------------------------------------------------------------------------------------------------
+template <typename TP /* partial rows: double, or float behind the fp32 product */>
 __global__ void __launch_bounds__(JX_TAIL_THREADS)
-jx_tail_row_kernel(JxDev c, const double* __restrict__ Pt, int nks, long long pstride /*doubles between partials*/, int ldx,
+jx_tail_row_kernel(JxDev c, const TP* __restrict__ Pt, int nks, long long pstride /*doubles between partials*/, int ldx,
                    const double* __restrict__ cfac, const double* __restrict__ sz0,
                    const double* __restrict__ base, double* __restrict__ logp, int w0,
                    double* __restrict__ tap_row, double* __restrict__ tap_bright, double* __restrict__ tap_chisq,
@@ -491,7 +666,7 @@ jx_tail_row_kernel(JxDev c, const double* __restrict__ Pt, int nks, long long ps
     const int nrow = c.nrow;
     double* s_prof = sm + JX_LDS_HDR;  // [nrow]
     const int w = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
-    const double* Pw = Pt + (size_t)w * ldx;
+    const TP* Pw = Pt + (size_t)w * ldx;
     for (int k = tid; k < nrow; k += nth) {
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
         int ks = 0;
@@ -499,15 +674,15 @@ jx_tail_row_kernel(JxDev c, const double* __restrict__ Pt, int nks, long long ps
         for (; ks + 15 < nks; ks += 16) {
             double v[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = Pw[(size_t)(ks + u) * pstride + k];
+            for (int u = 0; u < 16; ++u) v[u] = (double)Pw[(size_t)(ks + u) * pstride + k];
 #pragma unroll
             for (int u = 0; u < 16; u += 4) { a0 += v[u]; a1 += v[u + 1]; a2 += v[u + 2]; a3 += v[u + 3]; }
         }
         for (; ks + 3 < nks; ks += 4) {
-            a0 += Pw[(size_t)ks * pstride + k]; a1 += Pw[(size_t)(ks + 1) * pstride + k];
-            a2 += Pw[(size_t)(ks + 2) * pstride + k]; a3 += Pw[(size_t)(ks + 3) * pstride + k];
+            a0 += (double)Pw[(size_t)ks * pstride + k]; a1 += (double)Pw[(size_t)(ks + 1) * pstride + k];
+            a2 += (double)Pw[(size_t)(ks + 2) * pstride + k]; a3 += (double)Pw[(size_t)(ks + 3) * pstride + k];
         }
-        for (; ks < nks; ++ks) a0 += Pw[(size_t)ks * pstride + k];
+        for (; ks < nks; ++ks) a0 += (double)Pw[(size_t)ks * pstride + k];
         const double acc = (a0 + a1) + (a2 + a3);
         if (tap_row) tap_row[(size_t)w * nrow + k] = acc;
         const double b = acc * cfac[(size_t)w * nrow + k];

@@ -128,7 +128,7 @@ CONV_MODES = {'auto': 0, 'rocfft': 1, 'custom': 2, 'mix': 2}        # 'custom' =
 ROUTES = {'map': 0, 'operator': 1}
 
 
-DTYPES = {'f64': 0, 'f32': 1}
+DTYPES = {'f64': 0, 'f32': 1, 'f32c': 2}        # 'f32': fp32 spline arrays, fp64 sums; 'f32c': fp32 arithmetic in stages 1 and 2 as well
 
 
 def config_from_problem(pb, device=0, max_batch=0, fft_pad=0, map_split=0, conv='auto', dtype='f64'):
