@@ -109,6 +109,7 @@ struct jx_ctx {
     double* d_Tm = nullptr; int tm_ld = 0, tm_ntile = 0, tm_npair = 0;
     double* d_ppc = nullptr;           // [chunk][N] prep kernel -> jx_abel_gemm_kernel
     bool abel_gemm = true;
+    int ag_narrow = -1;                // JOXSZ_AG_NARROW: 16-walker blocks of the spline-array product for every launch (1) / never (0)
     bool f32 = false;                  // jx_config.dtype >= 1: fp32 spline arrays, fp32 evaluation of the map samples
     bool f32c = false;                 // jx_config.dtype == 2: fp32 arithmetic in stage 1 and stage 2 as well (packed fp32 FMAs, fp32 matrix cores)
 
@@ -1020,6 +1021,7 @@ static int finalize_impl(jx_ctx* ctx) {
     if (const char* e = env_str("JOXSZ_MIX_WPB")) { const int v = atoi(e); if (v >= 1 && v <= 16) { ctx->mix.wpb_force = v; ctx->mix.wpb = std::min(v, 4); } }
     if (const char* e = env_str("JOXSZ_MIX_KSPLIT")) { const int v = atoi(e); if (v >= 1) ctx->mix.ksplit_force = v; }
     if (const char* e = env_str("JOXSZ_ABEL_GEMM")) ctx->abel_gemm = atoi(e) != 0;
+    if (const char* e = env_str("JOXSZ_AG_NARROW")) ctx->ag_narrow = atoi(e) != 0;
     ctx->op_narrow = env_str("JOXSZ_OP_NARROW") != nullptr;
     if (const char* e = env_str("JOXSZ_SIDE_STREAM")) ctx->side_on = atoi(e) != 0;
     if (const char* e = env_str("JOXSZ_SIDE_FORK")) ctx->side_fork = atoi(e) != 0;
@@ -1411,7 +1413,7 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
         if (ag) {
             // 32 walkers per block, or 16 when that would leave SIMDs without a wave (a walker's sums do not depend on it)
             const int gy = (ctx->tm_npair + 3) / 4;
-            const bool narrow = (size_t)((n + 31) / 32) * gy * 4 < 1024;
+            const bool narrow = ctx->ag_narrow >= 0 ? ctx->ag_narrow != 0 : (size_t)((n + 31) / 32) * gy * 4 < 1024;
             const dim3 grid(narrow ? (n + 15) / 16 : (n + 31) / 32, gy);
             const double* pp_src = ctx->d.inject_pp ? ctx->d.inject_pp : ctx->d_ppc;
             const size_t shg = sizeof(double) * JX_OPM_JC * 33;
