@@ -260,6 +260,12 @@ int  jx_get_conv_mode(jx_ctx* ctx);
  * `ntile`, tW walker stride of the work buffers, ldx doubles per partial row, ksplit K slices of the last launch.
  * JX_ERR_UNSUPPORTED with the rocFFT back end. */
 int  jx_get_conv_layout(jx_ctx* ctx, int32_t out[12]);
+/* Which outputs of the extracted row the matrix-core product computes when no tap asks for the row: out = {nrow; outputs the
+ * data-radii spline of the tail (joxsz_funcs.py:476) reads with a weight above 1e-22 of its largest -- the cardinal functions
+ * of a cubic spline decay by 2 - sqrt(3) per knot, so the row beyond the last data radius + ~35 pixels does not reach an fp64
+ * sum; outputs computed (whole tiles of 16); output tiles per block; K slices; 1 when the restriction is in use (contracted
+ * route, fewer tiles than the whole row; JOXSZ_PRUNE_OUTPUTS=0: never)}.  The row and brightness taps always get every output. */
+int  jx_get_output_pruning(jx_ctx* ctx, int32_t out[6]);
 /* What the truncation of the low-rank form costs on this problem, measured in jx_finalize against the rocFFT sequence
  * (exact, independent kernels) at the probe points: the current parameter values and the corners of the prior box in the
  * thawed shape parameters of the pressure profile (a, b, r_p).  out = {singular-value cut in use; largest difference of the

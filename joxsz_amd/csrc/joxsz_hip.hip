@@ -62,6 +62,9 @@ struct MixBack {
     int form = 0;                      // 0 low-rank (stage 1 + stage 2), 1 full operator on the samples
     JxMix mx{};
     JxOpg og{};
+    JxOpg og_u{};                      // the product restricted to the outputs the tail reads (nxt_u tiles per block, ksplit_u slices); og: every output (taps)
+    int nxt_u = 0, ksplit_u = 0, ksplit_u_force = 0;
+    bool has_u = false, last_was_u = false;
     int RT = 0, nxt = 0, r = 0, ns = 0, ksteps = 0, wpb = 4, wpb_force = 0, ksplit_force = 0, last_ksplit = 1, dbg = 0;
     bool mfma = false;                 // stage 1 on the fp64 matrix cores (R <= 16: jx_rowmix_mfma_kernel)
     int r_tol = 0;                     // terms above the singular-value cut (r < r_tol: capped to one 16-row tile)
@@ -89,6 +92,8 @@ struct jx_ctx {
 
     // derived sizes
     int nrow = 0, nt = 0, Sh = 0, K = 0, chunk = 0, num_cu = 256;
+    int nrow_use = 0;                  // outputs of the extracted row the data-radii spline reads with a weight above JX_PRUNE_TOL of its largest (<= nrow)
+    bool prune = true;                 // JOXSZ_PRUNE_OUTPUTS=0: the matrix-core product computes every output of the row, read or not
     int64_t device_bytes = 0;
     int conv_mode = 1;                 // 1 rocFFT sequence, 2 contracted route
 
@@ -447,6 +452,7 @@ static int fft_plans(jx_ctx* ctx, FftBack& fb, int batch, Plan3** out) {
 #define JX_MIX_NXTS(X) X(1) X(2) X(3) X(4) X(5) X(6)
 #define JX_MIX_KSPLIT_MAX 64
 #define JX_LR_TOL_DEFAULT 1e-8
+#define JX_PRUNE_TOL 1e-22            // weights of the data-radii spline below this fraction of the largest are not read (an fp64 sum cannot see them)
 #define JX_MIX_CAP_REACH 4             // ranks up to rank_cap + this many terms are cut to rank_cap (then measured by the guard)
 struct MixBuild {
     bool ok = false;
@@ -454,6 +460,8 @@ struct MixBuild {
     int form = 0, NU = 0, r = 0, ns = 0, R = 0, RT = 0, nxt = 0, ntile = 0, nog = 0, ksteps = 0;
     int r_tol = 0;                     // terms above the cut before the cap
     bool mfma = false;
+    int nxt_u = 0, ntile_u = 0, nog_u = 0;     // tiling of the outputs in use (0: all of them)
+    std::vector<double> Op_u;
     size_t krows = 0;
     jxt::MixColumns cols;
     std::vector<double> Cm, Op;
@@ -463,13 +471,13 @@ struct MixBuild {
     double cost_lowrank = 0.0, cost_full = 0.0;
 };
 
-static void mix_output_tiling(int nrow, MixBuild& mb) {
+static void mix_output_tiling(int nrow, int* nxt, int* nog, int* ntile) {
     const int tiles = (nrow + 15) / 16;
     double best = 1e300;
-#define JX_PICK(Xv) { const int og = (tiles + Xv - 1) / Xv; const double cost = (double)og * Xv * (1.0 + 0.5 / Xv); if (cost < best) { best = cost; mb.nxt = Xv; mb.nog = og; } }
+#define JX_PICK(Xv) { const int og = (tiles + Xv - 1) / Xv; const double cost = (double)og * Xv * (1.0 + 0.5 / Xv); if (cost < best) { best = cost; *nxt = Xv; *nog = og; } }
     JX_MIX_NXTS(JX_PICK)
 #undef JX_PICK
-    mb.ntile = mb.nog * mb.nxt;
+    *ntile = *nog * *nxt;
 }
 
 // form_force: -1 the cheaper form, 0 low-rank, 1 full.  tW: walker stride of the spline arrays (the full form's sample entries
@@ -484,7 +492,8 @@ static void plan_mix(jx_ctx* ctx, const std::vector<double>& beam, const std::ve
     if (ctx->qn != NU) { mb.why = "quadrant table size"; return; }
     if (NU > 9 * 64) { mb.why = "map side beyond the symmetric map kernel's range"; return; }
     mb.NU = NU; mb.tol = tol; mb.beam_tol = 1e-14;
-    mix_output_tiling(nrow, mb);
+    mix_output_tiling(nrow, &mb.nxt, &mb.nog, &mb.ntile);
+    if (ctx->prune && ctx->nrow_use > 0 && (ctx->nrow_use + 15) / 16 < (nrow + 15) / 16) mix_output_tiling(ctx->nrow_use, &mb.nxt_u, &mb.nog_u, &mb.ntile_u);
     // transfer-function weights of the extracted row, real for a real filter that is symmetric in each wavenumber
     std::vector<double> hy;
     jxt::tf_hy_table(filt, S, hy);
@@ -524,8 +533,10 @@ static void plan_mix(jx_ctx* ctx, const std::vector<double>& beam, const std::ve
     // matrix cores reach in the product kernels (measured: 256^2 with 32 terms 0.141 ms low-rank against 0.126 ms full; 257^2 0.155 against 0.132)
     const double nsamp = (double)NU * NU;
     // (stage 1 on the matrix cores: 16 multiply-adds per sample there, the 4 of the evaluation beside them on the vector units)
-    mb.cost_lowrank = (lowrank_ok && mb.RT) ? (mb.mfma ? nsamp * 18.0 : 1.6 * nsamp * (4.0 + mb.RT)) + (double)nrow * NU * mb.R : 1e300;
-    mb.cost_full = (double)nrow * nsamp * 0.5 + nsamp * 6.0 * mb.nog;
+    const double nout = mb.ntile_u > 0 ? 16.0 * mb.ntile_u : (double)nrow;      // outputs the timed product computes
+    const int nog_t = mb.ntile_u > 0 ? mb.nog_u : mb.nog;
+    mb.cost_lowrank = (lowrank_ok && mb.RT) ? (mb.mfma ? nsamp * 18.0 : 1.6 * nsamp * (4.0 + mb.RT)) + nout * NU * mb.R : 1e300;
+    mb.cost_full = nout * nsamp * 0.5 + nsamp * 6.0 * nog_t;
     int form = (mb.cost_lowrank <= mb.cost_full) ? 0 : 1;
     if (form_force == 0) { if (!lowrank_ok || !mb.RT) { mb.why = "low-rank form: " + why_lr; return; } form = 0; }
     if (form_force == 1) form = 1;
@@ -567,6 +578,13 @@ static void plan_mix(jx_ctx* ctx, const std::vector<double>& beam, const std::ve
             }
         }
     }
+    if (mb.ntile_u > 0 && mb.ntile_u < mb.ntile) {
+        // the same operator for the outputs in use alone: tiles [0, ntile_u) of every row, compact
+        const size_t rows = mb.Op.size() / ((size_t)16 * mb.ntile);
+        mb.Op_u.assign(rows * 16 * (size_t)mb.ntile_u, 0.0);
+        for (size_t kx = 0; kx < rows * 16; ++kx)
+            for (int t = 0; t < mb.ntile_u; ++t) mb.Op_u[kx * mb.ntile_u + t] = mb.Op[kx * mb.ntile + t];
+    } else { mb.ntile_u = 0; mb.nxt_u = 0; mb.nog_u = 0; }
     mb.ok = true;
 }
 
@@ -578,7 +596,7 @@ static void mix_teardown(jx_ctx* ctx, MixBack& m) {
     m.ready = false;
 }
 
-static void mix_kslices(const MixBack& m, int* ksplit_out, int* kper_out);
+static void mix_kslices(const MixBack& m, bool used, int* ksplit_out, int* kper_out);
 
 static int mix_setup(jx_ctx* ctx, const MixBuild& mb, long long tW) {
     MixBack& m = ctx->mix;
@@ -620,18 +638,33 @@ static int mix_setup(jx_ctx* ctx, const MixBuild& mb, long long tW) {
         float* qf;
         if ((rc = dev_put_l(ctx, m.allocs, of.data(), of.size(), &qf))) return rc; og.Opf = qf;
     }
+    m.has_u = mb.ntile_u > 0;
+    m.og_u = og;
+    if (m.has_u) {
+        JxOpg& ou = m.og_u;
+        m.nxt_u = mb.nxt_u;
+        ou.ntile = mb.ntile_u; ou.nog = mb.nog_u; ou.ldx = 16 * mb.ntile_u;
+        if ((rc = dev_put_l(ctx, m.allocs, mb.Op_u.data(), mb.Op_u.size(), &qd))) return rc; ou.Op = qd;
+        if (ctx->f32c && mb.form == 0) {
+            std::vector<float> of(mb.Op_u.begin(), mb.Op_u.end());
+            float* qf;
+            if ((rc = dev_put_l(ctx, m.allocs, of.data(), of.size(), &qf))) return rc; ou.Opf = qf;
+        }
+    }
     m.ncol = 2 * N;
     if ((rc = dev_new_l(ctx, m.allocs, 2 * esz * cft_rows * tW / sizeof(double) + 1, &m.cft, true))) return rc;
     if (mb.form == 0) {
         if ((rc = dev_new_l(ctx, m.allocs, mb.krows * (size_t)tW, &m.Dt, true))) return rc;    // (fp32 arithmetic: the same buffer holds floats)
         og.Dt = m.Dt; og.Dtf = reinterpret_cast<const float*>(m.Dt);
+        m.og_u.Dt = og.Dt; m.og_u.Dtf = og.Dtf;
     } else {
         JxSamp* qe;
-        if ((rc = dev_put_l(ctx, m.allocs, mb.ent.data(), mb.ent.size(), &qe))) return rc; og.ent = qe;
+        if ((rc = dev_put_l(ctx, m.allocs, mb.ent.data(), mb.ent.size(), &qe))) return rc; og.ent = qe; m.og_u.ent = qe;
     }
     og.pstride = (long long)tW * og.ldx + 272;                // (not a power of two: the tail reads all slices of a walker at once)
+    m.og_u.pstride = (long long)tW * m.og_u.ldx + 272;
     if ((rc = dev_new_l(ctx, m.allocs, (size_t)JX_MIX_KSPLIT_MAX * og.pstride, &m.Pt))) return rc;
-    { int kp; mix_kslices(m, &m.last_ksplit, &kp); }              // (reported by jx_get_conv_layout before the first launch too)
+    { int kp; mix_kslices(m, false, &m.last_ksplit, &kp); if (m.has_u) mix_kslices(m, true, &m.ksplit_u, &kp); }   // (reported before the first launch too)
     m.bytes = ctx->device_bytes - before;
     m.ready = true;
     return JX_OK;
@@ -640,9 +673,14 @@ static int mix_setup(jx_ctx* ctx, const MixBuild& mb, long long tW) {
 // K slices of the matrix-core product: a function of the problem alone (about 64 k-steps each, whole multiples of 8 slices so
 // that a full chunk fills whole rounds of blocks), never of the launch -- a walker's sums are grouped the same way wherever it
 // sits in whatever batch, so its result is bitwise independent of both
-static void mix_kslices(const MixBack& m, int* ksplit_out, int* kper_out) {
+static void mix_kslices(const MixBack& m, bool used, int* ksplit_out, int* kper_out) {
     int ksplit = m.ksplit_force > 0 ? m.ksplit_force : (m.ksteps + 32) / 64;
     if (ksplit >= 8 && m.ksplit_force <= 0) ksplit = (ksplit + 4) / 8 * 8;
+    if (used) {
+        // fewer output groups per walker block: as many more K slices, so that the launch still fills the chip
+        if (m.ksplit_u_force > 0) ksplit = m.ksplit_u_force;
+        else ksplit = std::max(ksplit, (ksplit * m.og.nog + m.og_u.nog - 1) / m.og_u.nog / 2);
+    }
     ksplit = std::max(1, std::min(ksplit, JX_MIX_KSPLIT_MAX));
     int kper = (m.ksteps + ksplit - 1) / ksplit;
     kper = (kper + JX_OPG_RD - 1) / JX_OPG_RD * JX_OPG_RD;
@@ -652,7 +690,7 @@ static void mix_kslices(const MixBack& m, int* ksplit_out, int* kper_out) {
 
 // stage 1 + stage 2 (low-rank form) or the one product of the full form; es: the launch's event set or null
 template <typename F>
-static int launch_mix(jx_ctx* ctx, int n, EvSet* es, F&& between /* called between stage 1 and the matrix-core product */) {
+static int launch_mix(jx_ctx* ctx, int n, EvSet* es, bool used /* the product for the outputs the tail reads alone */, F&& between /* called between stage 1 and the matrix-core product */) {
     MixBack& m = ctx->mix;
     hipStream_t st = ctx->stream;
     if (m.form == 0) {
@@ -707,23 +745,26 @@ static int launch_mix(jx_ctx* ctx, int n, EvSet* es, F&& between /* called betwe
     if (es) HIPCHK(ctx, hipEventRecord(es->e[3], st));
     { const int rcb = between(); if (rcb) return rcb; }
     {
-        JxOpg og = m.og;
+        used = used && m.has_u;
+        JxOpg og = used ? m.og_u : m.og;
+        const int nxt = used ? m.nxt_u : m.nxt;
         og.n = n;
         const int nwb = (n + 127) / 128;
         int ksplit, kper;
-        mix_kslices(m, &ksplit, &kper);
+        mix_kslices(m, used, &ksplit, &kper);
         og.ksplit = ksplit; og.kper = kper;
-        m.last_ksplit = ksplit;                                   // (the tail sums this many partials)
+        if (used) m.ksplit_u = ksplit; else m.last_ksplit = ksplit;   // (the tail sums this many partials)
+        m.last_was_u = used;
         const int nunit = ksplit * og.nog;
         og.kmajor = ksplit >= 8 ? 1 : 0;
         const dim3 g2((unsigned)(og.kmajor ? 8 * nwb * og.nog * ((ksplit + 7) / 8) : 8 * nwb * ((nunit + 7) / 8)));
         const size_t lds = m.form == 1 ? (size_t)JX_OPG_ECH * 4 * sizeof(JxSamp) : 0;
         bool done = false;
-#define JX_OPGF_GO(Xv) if (!done && ctx->f32c && m.nxt == Xv) { \
+#define JX_OPGF_GO(Xv) if (!done && ctx->f32c && nxt == Xv) { \
             hipLaunchKernelGGL((jx_opgemm_f32_kernel<Xv>), g2, dim3(256), 0, st, og, reinterpret_cast<float*>(m.Pt)); done = true; }
         JX_MIX_NXTS(JX_OPGF_GO)
 #undef JX_OPGF_GO
-#define JX_OPG_GO(Xv) if (!done && m.nxt == Xv) { \
+#define JX_OPG_GO(Xv) if (!done && nxt == Xv) { \
             if (m.form == 1 && ctx->f32) hipLaunchKernelGGL((jx_opgemm_kernel<1, Xv, float2>), g2, dim3(256), lds, st, og, reinterpret_cast<const float2*>(m.cft), m.Pt); \
             else if (m.form == 1) hipLaunchKernelGGL((jx_opgemm_kernel<1, Xv, double2>), g2, dim3(256), lds, st, og, reinterpret_cast<const double2*>(m.cft), m.Pt); \
             else hipLaunchKernelGGL((jx_opgemm_kernel<0, Xv, double2>), g2, dim3(256), lds, st, og, reinterpret_cast<const double2*>(m.cft), m.Pt); \
@@ -1020,6 +1061,7 @@ static int finalize_impl(jx_ctx* ctx) {
     if (const char* e = env_str("JOXSZ_MIX_MFMA")) ctx->mix_mfma = atoi(e) != 0;
     if (const char* e = env_str("JOXSZ_MIX_WPB")) { const int v = atoi(e); if (v >= 1 && v <= 16) { ctx->mix.wpb_force = v; ctx->mix.wpb = std::min(v, 4); } }
     if (const char* e = env_str("JOXSZ_MIX_KSPLIT")) { const int v = atoi(e); if (v >= 1) ctx->mix.ksplit_force = v; }
+    if (const char* e = env_str("JOXSZ_MIX_KSPLIT_USE")) { const int v = atoi(e); if (v >= 1) ctx->mix.ksplit_u_force = v; }
     if (const char* e = env_str("JOXSZ_ABEL_GEMM")) ctx->abel_gemm = atoi(e) != 0;
     if (const char* e = env_str("JOXSZ_AG_NARROW")) ctx->ag_narrow = atoi(e) != 0;
     ctx->op_narrow = env_str("JOXSZ_OP_NARROW") != nullptr;
@@ -1047,6 +1089,32 @@ static int finalize_impl(jx_ctx* ctx) {
     d.prep_pow = env_str("JOXSZ_PREP_POW") && atoi(env_str("JOXSZ_PREP_POW")) ? 1 : 0;
 
     int rc;
+    // ---- evaluation matrix of g at the data radii (joxsz_funcs.py:476), and which outputs of the extracted row it reads at all:
+    //      the cardinal functions of a cubic spline decay by 2 - sqrt(3) per knot, so data radii inside r_max give the row beyond
+    //      r_max + ~35 pixels weights below 1e-22 of the largest -- nothing an fp64 sum can see.  The matrix-core product computes the
+    //      outputs in use (whole tiles of 16); the row and brightness taps still get every output.
+    std::vector<double> h_E, h_flux;
+    {
+        std::vector<double> radius = host_vec<double>(ctx, JX_T_RADIUS);
+        std::vector<double> xk(radius.begin() + S / 2, radius.end());
+        for (size_t i = 1; i < xk.size(); ++i)
+            if (!(xk[i] > xk[i - 1])) { ctx->err = "radius[S//2:] must be increasing"; return JX_ERR_INVALID; }
+        h_flux = host_vec<double>(ctx, JX_T_FLUX_DATA);
+        std::vector<double> q(h_flux.begin(), h_flux.begin() + c.nflux);
+        if (!jxt::nak_eval_matrix(xk, q, h_E)) { ctx->err = "profile spline: singular system"; return JX_ERR_INVALID; }
+        if (const char* e = env_str("JOXSZ_PRUNE_OUTPUTS")) ctx->prune = atoi(e) != 0;
+        double emax = 0.0;
+        for (double v : h_E) if (std::isfinite(v)) emax = std::max(emax, std::fabs(v));
+        int kuse = 0;
+        bool finite = true;
+        for (int k = 0; k < ctx->nrow; ++k)
+            for (int dd = 0; dd < c.nflux; ++dd) {
+                const double v = h_E[(size_t)dd * ctx->nrow + k];
+                if (!std::isfinite(v)) finite = false;
+                else if (std::fabs(v) > JX_PRUNE_TOL * emax) kuse = k + 1;
+            }
+        ctx->nrow_use = (finite && emax > 0.0) ? std::max(1, kuse) : ctx->nrow;
+    }
     // ---- which back end: contracted route or the rocFFT sequence
     std::vector<double> beam_h = host_vec<double>(ctx, JX_T_BEAM_2D);
     MixBuild mixb;
@@ -1122,17 +1190,9 @@ static int finalize_impl(jx_ctx* ctx) {
         hw[0] += 1.0;
         double* p; if ((rc = dev_put(ctx, hw.data(), hw.size(), &p))) return rc; d.hw = p;
     }
-    // ---- evaluation matrix of g at the data radii (joxsz_funcs.py:476)
     {
-        std::vector<double> radius = host_vec<double>(ctx, JX_T_RADIUS);
-        std::vector<double> xk(radius.begin() + S / 2, radius.end());
-        for (size_t i = 1; i < xk.size(); ++i)
-            if (!(xk[i] > xk[i - 1])) { ctx->err = "radius[S//2:] must be increasing"; return JX_ERR_INVALID; }
-        std::vector<double> flux = host_vec<double>(ctx, JX_T_FLUX_DATA);
-        std::vector<double> q(flux.begin(), flux.begin() + c.nflux), E;
-        if (!jxt::nak_eval_matrix(xk, q, E)) { ctx->err = "profile spline: singular system"; return JX_ERR_INVALID; }
-        double* p; if ((rc = dev_put(ctx, E.data(), E.size(), &p))) return rc; d.emat = p;
-        if ((rc = dev_put(ctx, flux.data(), flux.size(), &p))) return rc; d.flux = p;
+        double* p; if ((rc = dev_put(ctx, h_E.data(), h_E.size(), &p))) return rc; d.emat = p;
+        if ((rc = dev_put(ctx, h_flux.data(), h_flux.size(), &p))) return rc; d.flux = p;
     }
     // ---- twiddles of the final inverse transform of the extracted row (rocFFT sequence's tail)
     {
@@ -1441,12 +1501,17 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
             HIPCHK(ctx, hipEventRecord(ctx->ev_side, ctx->side_stream));
             return JX_OK;
         };
-        if ((rc = launch_mix(ctx, n, (tm || tm2) ? &es : nullptr, between))) return rc;
+        // the matrix-core product computes the outputs the data-radii spline of the tail reads (nrow_use of nrow); the whole row when
+        // the row or the brightness profile is tapped
+        const bool used = m.has_u && !t.row && !t.bright;
+        if ((rc = launch_mix(ctx, n, (tm || tm2) ? &es : nullptr, used, between))) return rc;
+        const int nks = used ? m.ksplit_u : m.last_ksplit, nuse = used ? std::min(ctx->nrow_use, d.nrow) : d.nrow;
+        const JxOpg& ogt = used ? m.og_u : m.og;
         const size_t sh = sizeof(double) * (JX_LDS_HDR + (size_t)d.nrow + 8);
         if (side) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_side, 0));
-        if (ctx->f32c) hipLaunchKernelGGL(jx_tail_row_kernel<float>, dim3(n), dim3(JX_TAIL_THREADS), sh, st, d, reinterpret_cast<const float*>(m.Pt), m.last_ksplit,
-                                          m.og.pstride, m.og.ldx, ctx->d_cfac, ctx->d_sz0, ctx->d_base, logp_dev, w0, t.row, t.bright, t.chisq, t.parts);
-        else hipLaunchKernelGGL(jx_tail_row_kernel<double>, dim3(n), dim3(JX_TAIL_THREADS), sh, st, d, m.Pt, m.last_ksplit, m.og.pstride, m.og.ldx,
+        if (ctx->f32c) hipLaunchKernelGGL(jx_tail_row_kernel<float>, dim3(n), dim3(JX_TAIL_THREADS), sh, st, d, reinterpret_cast<const float*>(m.Pt), nks,
+                                          ogt.pstride, ogt.ldx, nuse, ctx->d_cfac, ctx->d_sz0, ctx->d_base, logp_dev, w0, t.row, t.bright, t.chisq, t.parts);
+        else hipLaunchKernelGGL(jx_tail_row_kernel<double>, dim3(n), dim3(JX_TAIL_THREADS), sh, st, d, m.Pt, nks, ogt.pstride, ogt.ldx, nuse,
                                 ctx->d_cfac, ctx->d_sz0, ctx->d_base, logp_dev, w0, t.row, t.bright, t.chisq, t.parts);
 
         if (tm) HIPCHK(ctx, hipEventRecord(es.e[5], st));
@@ -1992,12 +2057,21 @@ int jx_debug_workspace(jx_ctx* ctx, int which, void** dev, int32_t geom[4]) {
         case 1: *dev = m.cft; geom[0] = ctx->cfg.N; geom[1] = (int)m.tW; geom[2] = 2; geom[3] = ctx->f32 ? 4 : 8; break;
         case 2: if (m.form != 0) { ctx->err = "no stage-1 rows in the full form"; return JX_ERR_UNSUPPORTED; }
                 *dev = m.Dt; geom[0] = m.mx.NU; geom[1] = m.mx.R; geom[2] = (int)m.tW; geom[3] = ctx->f32c ? 4 : 8; break;
-        case 3: *dev = m.Pt; geom[0] = m.last_ksplit; geom[1] = (int)m.tW; geom[2] = m.og.ldx; geom[3] = ctx->f32c ? 4 : 8; break;
+        case 3: *dev = m.Pt; geom[0] = m.last_was_u ? m.ksplit_u : m.last_ksplit; geom[1] = (int)m.tW; geom[2] = m.last_was_u ? m.og_u.ldx : m.og.ldx; geom[3] = ctx->f32c ? 4 : 8; break;
         case 4: if (m.form != 0) { ctx->err = "no stage-1 operator in the full form"; return JX_ERR_UNSUPPORTED; }
                 *dev = const_cast<double*>(m.mx.Cm); geom[0] = 1; geom[1] = m.mx.wld; geom[2] = m.mx.cld; geom[3] = 8; break;
         case 5: *dev = const_cast<double*>(m.og.Op); geom[0] = 4 * m.ksteps; geom[1] = 16; geom[2] = m.og.ntile; geom[3] = 8; break;
         default: ctx->err = "unknown work buffer"; return JX_ERR_INVALID;
     }
+    return JX_OK;
+}
+
+int jx_get_output_pruning(jx_ctx* ctx, int32_t out[6]) {
+    if (!ctx || !ctx->finalized || !out) return JX_ERR_STATE;
+    const MixBack& m = ctx->mix;
+    const bool u = ctx->conv_mode == 2 && m.has_u;
+    out[0] = ctx->nrow; out[1] = ctx->nrow_use; out[2] = u ? 16 * m.og_u.ntile : ctx->nrow; out[3] = u ? m.nxt_u : 0; out[4] = u ? m.ksplit_u : 0;
+    out[5] = u ? 1 : 0;
     return JX_OK;
 }
 

@@ -33,7 +33,11 @@
 // (cdna_hip_programming.md Guideline 17).  The first JX_LDS_HDR doubles hold the small per-block scalars.
 #define JX_LDS_DECL extern __shared__ __attribute__((aligned(16))) double sm[]
 #define JX_LDS_HDR 32          // [0..18] parameter vector, [20..27] reduction scratch, [28] int flag
+#ifdef JX_PREP_THREADS_OVERRIDE
+#define JX_PREP_THREADS JX_PREP_THREADS_OVERRIDE
+#else
 #define JX_PREP_THREADS 256
+#endif
 #define JX_TAIL_THREADS 256
 
 // semantic slots of the parameter vector (joxsz_amd/problem.py PAR_SLOTS)

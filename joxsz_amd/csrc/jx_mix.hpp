@@ -656,7 +656,8 @@ jx_opgemm_f32_kernel(JxOpg g, float* __restrict__ Pt) {
 // ------------------------------------------------------------------------------------------------------------------
 template <typename TP /* partial rows: double, or float behind the fp32 product */>
 __global__ void __launch_bounds__(JX_TAIL_THREADS)
-jx_tail_row_kernel(JxDev c, const TP* __restrict__ Pt, int nks, long long pstride /*doubles between partials*/, int ldx,
+jx_tail_row_kernel(JxDev c, const TP* __restrict__ Pt, int nks, long long pstride /*elements between partials*/, int ldx,
+                   int nuse /* outputs present in the partial rows: the ones the data-radii matrix reads (<= nrow; the taps get nrow) */,
                    const double* __restrict__ cfac, const double* __restrict__ sz0,
                    const double* __restrict__ base, double* __restrict__ logp, int w0,
                    double* __restrict__ tap_row, double* __restrict__ tap_bright, double* __restrict__ tap_chisq,
@@ -667,7 +668,7 @@ jx_tail_row_kernel(JxDev c, const TP* __restrict__ Pt, int nks, long long pstrid
     double* s_prof = sm + JX_LDS_HDR;  // [nrow]
     const int w = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
     const TP* Pw = Pt + (size_t)w * ldx;
-    for (int k = tid; k < nrow; k += nth) {
+    for (int k = tid; k < nuse; k += nth) {
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
         int ks = 0;
         // (sixteen slices requested together -- one trip to memory instead of four -- and added in the order of the loop below)
@@ -696,12 +697,12 @@ jx_tail_row_kernel(JxDev c, const TP* __restrict__ Pt, int nks, long long pstrid
         double m = 0.0;
         // (eight coefficients requested together, then their eight multiply-adds in the order of a plain loop: the loop is a
         //  chain of dependent memory round trips otherwise -- 7 of the kernel's 13 us)
-        for (int k0 = tid & 7; k0 < nrow; k0 += 64) {
+        for (int k0 = tid & 7; k0 < nuse; k0 += 64) {
             double ev[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) ev[u] = e[min(k0 + 8 * u, nrow - 1)];
+            for (int u = 0; u < 8; ++u) ev[u] = e[min(k0 + 8 * u, nuse - 1)];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) if (k0 + 8 * u < nrow) m = fma(ev[u], s_prof[k0 + 8 * u], m);
+            for (int u = 0; u < 8; ++u) if (k0 + 8 * u < nuse) m = fma(ev[u], s_prof[k0 + 8 * u], m);
         }
         m += __shfl_xor(m, 1, 64); m += __shfl_xor(m, 2, 64); m += __shfl_xor(m, 4, 64);
         const double z = (c.flux[c.nflux + dd] - m) / c.flux[2 * c.nflux + dd];

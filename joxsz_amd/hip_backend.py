@@ -19,7 +19,7 @@ EXPORTS = (
     'jx_set_par_vals', 'jx_dev_alloc', 'jx_dev_free', 'jx_memcpy_h2d', 'jx_memcpy_d2h',
     'jx_timing_reset', 'jx_timing_enable', 'jx_timing_get', 'jx_get_info', 'jx_get_conv_mode', 'jx_get_conv_layout', 'jx_debug_workspace', 'jx_device_count',
     'jx_device_name', 'jx_strerror', 'jx_last_error', 'jx_destroy',
-    'jx_get_truncation', 'jx_comm_unique_id', 'jx_comm_init_rank', 'jx_allgather_logp', 'jx_comm_allreduce_max', 'jx_comm_destroy',
+    'jx_get_truncation', 'jx_get_output_pruning', 'jx_comm_unique_id', 'jx_comm_init_rank', 'jx_allgather_logp', 'jx_comm_allreduce_max', 'jx_comm_destroy',
     'jx_comm_count', 'jx_comm_set_overlap', 'jx_comm_gather_time', 'jx_map_kernel_time', 'jx_copy_bandwidth', 'jx_stream_bandwidth',
 )
 
@@ -95,6 +95,7 @@ def load_library(path=None):
     lib.jx_get_conv_mode.argtypes = [vp]
     lib.jx_get_conv_layout.argtypes = [vp, ctypes.POINTER(ctypes.c_int32)]
     lib.jx_get_truncation.argtypes = [vp, dp]
+    lib.jx_get_output_pruning.argtypes = [vp, ctypes.POINTER(ctypes.c_int32)]
     lib.jx_debug_workspace.argtypes = [vp, ci, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int32)]
     lib.jx_comm_unique_id.argtypes = [vp]
     lib.jx_comm_init_rank.argtypes = [vp, vp, ci, ci]
@@ -195,6 +196,10 @@ class HipContext:
         self.conv_layout = None
         if self.conv == 'custom':
             self.conv_layout = self._layout()
+        pr = (ctypes.c_int32 * 6)()
+        self._chk(self.lib.jx_get_output_pruning(self._h, pr), 'jx_get_output_pruning')
+        self.output_pruning = dict(nrow=int(pr[0]), outputs_read_by_the_tail=int(pr[1]), outputs_computed=int(pr[2]), tiles_per_block=int(pr[3]),
+                                   k_slices=int(pr[4]), active=bool(pr[5]))
         self.truncation = self._truncation()
         if self.truncation['warning'] and not os.environ.get('JOXSZ_QUIET'):
             import warnings
@@ -228,7 +233,12 @@ class HipContext:
         """One line when the guard changed the tables or has little room left (jx_finalize, joxsz_hip.hip): what happened and
         what it costs.  Stages 1 and 2 of the low-rank form cost about (4 + rank) and rank multiply-adds per map sample, so
         the step scales roughly with (4 + 2 rank) / (4 + 2 * 16) of the 16-term tables a smooth transfer function gets."""
-        if self.conv != 'custom' or d['rank'] <= 0 or d['est_rel_row_err'] < 0:
+        if self.conv != 'custom':
+            return None
+        if d['retried'] > 0 and d['rank'] <= 0:
+            return ('the truncation guard found the low-rank tables of this beam / transfer function outside its bounds and rebuilt them until the '
+                    'exact full form was the cheaper one: nothing is truncated now; the SZ stages cost about 1.6x those of the 16-term tables')
+        if d['rank'] <= 0 or d['est_rel_row_err'] < 0:
             return None
         rel = (4.0 + 2.0 * d['rank']) / (4.0 + 2.0 * 16)
         msgs = []

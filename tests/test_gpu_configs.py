@@ -406,9 +406,12 @@ def test_truncation_guard_and_automatic_tightening(monkeypatch):
     monkeypatch.setenv('JOXSZ_TRUNC_BOUND', '1e-11')                  # row bound 1e-11, log-likelihood bound 1e-10 over the box
     post = _post(pb)
     tr1 = post.ctx.truncation
-    assert tr1['retried'] >= 1 and tr1['tol'] < 1e-8 and tr1['rank'] > tr['rank']
-    assert 0 <= tr1['est_rel_row_err'] <= 1e-11 and 0 <= tr1['est_rel_sz_like_err_box'] <= 1e-10
-    assert tr1['rank'] == post.ctx.conv_layout['rank']
+    assert tr1['retried'] >= 1
+    if post.ctx.conv_layout['form'] == 'full':                       # (more terms made the exact form the cheaper one: nothing left to truncate)
+        assert tr1['rank'] == 0 and tr1['est_rel_row_err'] == -1.0
+    else:
+        assert tr1['tol'] < 1e-8 and tr1['rank'] > tr['rank'] and tr1['rank'] == post.ctx.conv_layout['rank']
+        assert 0 <= tr1['est_rel_row_err'] <= 1e-11 and 0 <= tr1['est_rel_sz_like_err_box'] <= 1e-10
     post.close()
     monkeypatch.setenv('JOXSZ_TRUNC_BOUND', '1e-18')                  # never met: ends with every term above rounding
     post = _post(pb)
@@ -436,6 +439,40 @@ def test_truncation_guard_and_automatic_tightening(monkeypatch):
     assert tr3['tol'] == 1e-7 and tr3['retried'] == 0 and tr3['est_rel_sz_like_err_box'] > tr['est_rel_sz_like_err_box']
 
 
+@pytest.mark.parametrize('S,N,form', [(512, 500, 'lowrank'), (512, 500, 'full'), (513, 500, 'lowrank'), (1024, 1000, 'lowrank'), (256, 300, 'full')])
+def test_the_product_computes_the_outputs_the_data_radii_spline_reads(S, N, form, monkeypatch):
+    """The tail interpolates the extracted row at the data radii with a cubic spline (joxsz_funcs.py:476); the weights of that
+    spline decay by 2 - sqrt(3) per knot, so the row beyond the last data radius + ~35 pixels never reaches an fp64 sum.  The
+    timed matrix-core product computes the outputs read (whole tiles of 16; jx_get_output_pruning) -- 96 of 256 at 512^2, 96 of
+    512 at 1024^2 -- and the result is the one of the product over every output (JOXSZ_PRUNE_OUTPUTS=0) to the last bits; the
+    row tap still delivers the whole row."""
+    from joxsz_amd import datasets
+    pb = _problem(S, N, seed=S + 1)
+    th = datasets.walker_ball(pb, 150, spread=0.03, seed=S + 1)
+    monkeypatch.setenv('JOXSZ_MIX_FORM', form)
+    post = _post(pb)
+    pr = post.ctx.output_pruning
+    nrow = S - S // 2
+    assert pr['nrow'] == nrow and pr['active'] and 80 <= pr['outputs_read_by_the_tail'] <= 96 and pr['outputs_computed'] == 96
+    a = post.log_prob(th)
+    row = post.stage(th[:3], 'map_row')
+    chi_a = post.stage(th, 'chisq')                                  # (a tap: the whole row is computed)
+    post.close()
+    assert row.shape == (3, nrow)
+    monkeypatch.setenv('JOXSZ_PRUNE_OUTPUTS', '0')
+    ref = _post(pb)
+    assert not ref.ctx.output_pruning['active']
+    b = ref.log_prob(th)
+    chi_b = ref.stage(th, 'chisq')
+    ref.close()
+    fin = np.isfinite(b)
+    assert fin.sum() >= 100 and np.array_equal(np.isfinite(a), fin)
+    np.testing.assert_allclose(a[fin], b[fin], rtol=1e-13)
+    np.testing.assert_allclose(chi_a[fin], chi_b[fin], rtol=1e-11)
+    st = orc.sz_stages(pb, orc.pars_dict(pb, th[0]))
+    assert np.abs(row[0] - st['map_row']).max() / np.abs(st['map_row']).max() < 1e-9
+
+
 def test_truncation_guard_speaks_up_when_it_changes_the_tables():
     """Transfer functions that sit just over the guard's bounds at the default tables (a sharper and a softer normal-cdf
     roll-off than CL J1226.9+3332's, found with scripts/guard_scan.py): jx_finalize first takes the 16-term cap away, then --
@@ -457,9 +494,12 @@ def test_truncation_guard_speaks_up_when_it_changes_the_tables():
             post = JoxszPosterior(pb, device=0)
         tr = post.ctx.truncation
         assert len(rec) == 1 and tr['warning'] == str(rec[0].message)
-        assert tr['cap_removed'] == cap_removed and (tr['retried'] > tr['cap_removed']) == tightened and tr['rank'] > 16
-        assert ('%d terms' % tr['rank']) in tr['warning']
-        assert 0 <= tr['est_rel_row_err'] <= tr['bound'] and 0 <= tr['est_rel_sz_like_err_box'] <= tr['bound_sz_like']
+        assert tr['cap_removed'] == cap_removed and (tr['retried'] > tr['cap_removed']) == tightened
+        if post.ctx.conv_layout['form'] == 'full':                   # the tightening ended in the exact form (cheaper than 30 terms)
+            assert tightened and tr['rank'] == 0 and 'full form' in tr['warning']
+        else:
+            assert tr['rank'] > 16 and ('%d terms' % tr['rank']) in tr['warning']
+            assert 0 <= tr['est_rel_row_err'] <= tr['bound'] and 0 <= tr['est_rel_sz_like_err_box'] <= tr['bound_sz_like']
         th = datasets.walker_ball(pb, 12, spread=0.03, seed=3)
         a = post.log_prob(th)
         post.close()
