@@ -65,14 +65,25 @@ def pmc_file(S):
     return None
 
 
-def pmc_traffic(j, kernel, walkers_per_launch):
-    """HBM bytes per launch of `kernel` from that file, rescaled to this launch size."""
+def pmc_kernel_entry(j, kernel):
+    """The PMC entry of the full-size launches of `kernel` (base name, template arguments dropped): instances of the same kernel
+    template that only ran on a handful of walkers (set-up, guard, taps) are in the file too; the full-size one has the largest
+    grid (the most bytes where an older file carries no grid)."""
     if not j:
         return None
+    best = None
     for name, d in j['kernels'].items():
-        if kernel in name:
-            return d['total_bytes'] / j.get('walkers_per_launch', 1024) * walkers_per_launch
-    return None
+        if name.split('<')[0].replace('void ', '').strip() == kernel:
+            key = (d.get('grid_size', 0), d['total_bytes'])
+            if best is None or key > best[0]:
+                best = (key, d)
+    return best[1] if best else None
+
+
+def pmc_traffic(j, kernel, walkers_per_launch):
+    """HBM bytes per launch of `kernel` from that file, rescaled to this launch size."""
+    d = pmc_kernel_entry(j, kernel)
+    return d['total_bytes'] / j.get('walkers_per_launch', 1024) * walkers_per_launch if d else None
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -253,6 +264,7 @@ def main():
     ap.add_argument('--dtype', choices=('f64', 'f32', 'f32c'), default='f64',
                     help="'f64': the reference's arithmetic (the metric); 'f32': fp32 spline arrays; 'f32c': fp32 arithmetic in stages 1 and 2")
     ap.add_argument('--no-f32', action='store_true', help='skip the side measurement of the fp32 variant')
+    ap.add_argument('--no-host-pointer', action='store_true', help='skip the side measurement of jx_eval with host pointers (profiling runs: keeps the trace to the timed steps)')
     ap.add_argument('--no-other-configs', action='store_true', help='skip the strong-scaling rows of BASELINE configs[3] and configs[4]')
     args = ap.parse_args()
 
@@ -394,7 +406,7 @@ def main():
 
     # the path emcee calls (joxsz_main.py:206, vectorize=True): host theta in, host log-probabilities out, one sync per call
     host_ptr = None
-    if rank == 0:
+    if rank == 0 and not args.no_host_pointer:
         try:
             for _ in range(3):
                 ctx.eval(theta)
@@ -583,12 +595,16 @@ def main():
                                 % (NU, lay['R'])}
             p_ms = stage_ms['tf_fft_ms']
             K4 = lay['ksteps'] * 4
-            fl2 = 2.0 * nrow * K4 * walkers_per_launch
+            prn = ctx.output_pruning
+            nout = prn['outputs_computed'] if prn['active'] else nrow      # the timed product computes the outputs the tail's data-radii spline reads
+            fl2 = 2.0 * nout * K4 * walkers_per_launch
             ach2 = fl2 / (p_ms * 1e-3) / 1e12 if p_ms > 0 else 0.0
             roof2 = {'kernel': 'jx_opgemm_kernel', 'bound': 'mfma', 'achieved': ach2, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': ach2 / FP64_PEAK_TFLOPS, 'traffic': pmc_traffic(pj, 'jx_opgemm_kernel', walkers_per_launch),
                      'launch_ms': p_ms, 'launch_ms_source': 'HIP events of the stage pass', 'flops_per_launch': fl2,
-                     'note': 'nrow x K x walkers product on v_mfma_f64_16x16x4 (nrow = %d outputs, K = %d rows of the operator)' % (nrow, K4)}
+                     'outputs_computed': nout, 'outputs_of_the_row': nrow,
+                     'note': 'outputs x K x walkers product on v_mfma_f64_16x16x4 (%d of the row\'s %d outputs: the ones the data-radii spline of the tail reads '
+                             'with a weight above 1e-22 of its largest, in whole tiles of 16; K = %d rows of the operator)' % (nout, nrow, K4)}
             if not lowrank:
                 roof, roof2 = roof2, None
         # HBM bytes of the step: exactly the kernels of the step (stage_kernels), nothing else the PMC file holds
@@ -596,8 +612,7 @@ def main():
         step_pmc = None
         step_pmc_kernels = None
         if pj and mixed:
-            step_pmc_kernels = {n.split('<')[0].replace('void ', '').strip(): d['total_bytes'] / pj.get('walkers_per_launch', 1024) * W
-                                for n, d in pj['kernels'].items() if n.split('<')[0].replace('void ', '').strip() in step_names}
+            step_pmc_kernels = {n: pmc_traffic(pj, n, W) for n in step_names if pmc_kernel_entry(pj, n)}
             step_pmc = sum(step_pmc_kernels.values()) if step_pmc_kernels else None
         if ns_route and 'ms_per_step' in ns_route:
             ns_route['speedup_of_default_route'] = ns_route['ms_per_step'] / ms_step
@@ -612,7 +627,7 @@ def main():
                                    % (W, S, S, args.N, 'SZ-only' if pb.sz_only else 'joint X-ray+SZ',
                                       ' (BASELINE configs[2])' if (W, S, args.N, pb.sz_only) == (1024, 512, 500, False) else ''),
                        'walkers_per_gpu': W, 'S': S, 'N': args.N, 'B': pb.B, 'chunk': ctx.chunk, 'route': ctx.route, 'conv': ctx.conv,
-                       'conv_layout': ctx.conv_layout, 'parallelism': 'walkers sharded x%d' % world, 'device': ctx.device_name,
+                       'conv_layout': ctx.conv_layout, 'output_pruning': ctx.output_pruning, 'parallelism': 'walkers sharded x%d' % world, 'device': ctx.device_name,
                        'gather': (('overlapped: second stream, two output buffers' if overlap else 'strict: on the compute stream') if comm is not None else None)},
             'n_ranks_seen': (comm.n_ranks_seen if comm is not None else 1),
             'gather_ms_per_step': gather_ms,

@@ -1381,7 +1381,11 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
     hipStream_t st = ctx->stream;
     if (ctx->comm_overlap)                                         // a gather still reading this output buffer: the evaluation waits for it, and only for it
         for (auto& g : ctx->gslot)
-            if (g.busy && g.send == (const void*)logp_dev) { HIPCHK(ctx, hipStreamWaitEvent(st, g.done, 0)); g.busy = false; }
+            if (g.busy && g.send == (const void*)logp_dev) {
+                // (a gather that has already finished costs a query on the host, not a barrier in the queue)
+                if (hipEventQuery(g.done) != hipSuccess) HIPCHK(ctx, hipStreamWaitEvent(st, g.done, 0));
+                g.busy = false;
+            }
     EvSet es;
     // timing mode 2 records the two events around the time-dominant kernel only (stage 1 of the contracted route)
     const bool tm = ctx->timing_on && ctx->timing_mode != 2 && !use_ref;

@@ -23,7 +23,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def collect(counter, outdir):
     cmd = ['rocprofv3', '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', outdir, '--',
-           sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '1', '--no-cpu', '--no-f32', '--no-other-configs']
+           sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '1', '--no-cpu', '--no-f32', '--no-other-configs', '--no-host-pointer']
     env = dict(os.environ, TMPDIR='/tmp')
     res = subprocess.run(cmd, check=True, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
     collect.bench = json.loads(res.stdout.strip().splitlines()[-1])
@@ -36,6 +36,7 @@ def collect(counter, outdir):
     for r in rows:
         if r['Counter_Name'] == counter and int(r['Grid_Size']) == big[r['Kernel_Name']]:
             acc[r['Kernel_Name']].append(float(r['Counter_Value']))
+    collect.grid = dict(big)
     return {k: sum(v) / len(v) for k, v in acc.items() if not k.startswith('__amd')}
 
 
@@ -51,7 +52,7 @@ def main():
     for k in sorted(set(fetch) | set(write)):
         rd = fetch.get(k, 0.0) * 1024 * 2
         wr = write.get(k, 0.0) * 1024
-        out['kernels'][k.split('(')[0].strip()] = {'read_bytes': rd, 'write_bytes': wr, 'total_bytes': rd + wr,
+        out['kernels'][k.split('(')[0].strip()] = {'read_bytes': rd, 'write_bytes': wr, 'total_bytes': rd + wr, 'grid_size': collect.grid.get(k, 0),
                                                      'fetch_size_kib_raw': fetch.get(k, 0.0), 'write_size_kib_raw': write.get(k, 0.0)}
     path = os.path.join(ROOT, 'gpurun_out', '%s_pmc_traffic.json' % tag)
     json.dump(out, open(path, 'w'), indent=1)

