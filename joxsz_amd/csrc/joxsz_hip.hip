@@ -104,6 +104,8 @@ struct jx_ctx {
     int map_threads = 512;
     size_t map_lds = 0;
     bool dmat_mirror = false;
+    bool map_ok = true;                // the Abel + map kernel fits its spline in LDS (radial grids up to ~1690 points); without it: no map taps, no rocFFT
+                                       // reference facility (guard), profile taps from the matrix product's own arrays
     std::vector<double> h_Qtab;        // [qn][qn] pixel radii of the quadrant (host; table builds)
     int qn = 0;
 
@@ -1115,6 +1117,16 @@ static int finalize_impl(jx_ctx* ctx) {
             }
         ctx->nrow_use = (finite && emax > 0.0) ? std::max(1, kuse) : ctx->nrow;
     }
+    // ---- does the Abel + map kernel (taps, rocFFT route, the guard's reference facility) fit this radial grid in LDS?  Without it
+    //      the contracted route still runs -- its timed kernels never needed it -- but nothing can measure a truncation, so there
+    //      is none: every singular term above rounding is kept and no cap applies.
+    {
+        JxDev dt = d;
+        dt.quad = 1; dt.fast_map = (dmat_mirror && qn <= 9 * 64) ? 1 : 0; dt.q_na = dt.q_nb = qn;
+        int th; size_t ld;
+        ctx->map_ok = map_geometry(dt, 512, &th, &ld);
+        if (!ctx->map_ok) { lr_tol0 = std::min(lr_tol0, 1e-13); ctx->rank_cap = 0; ctx->tol_pinned = true; }
+    }
     // ---- which back end: contracted route or the rocFFT sequence
     std::vector<double> beam_h = host_vec<double>(ctx, JX_T_BEAM_2D);
     MixBuild mixb;
@@ -1273,7 +1285,10 @@ static int finalize_impl(jx_ctx* ctx) {
         while (chunk > 1 && per_walker * chunk > budget) chunk /= 2;
     }
     ctx->chunk = chunk;
-    if (!map_geometry(d, 512, &ctx->map_threads, &ctx->map_lds)) { ctx->err = "radial grid too long for the LDS-resident spline"; return JX_ERR_UNSUPPORTED; }
+    if (!map_geometry(d, 512, &ctx->map_threads, &ctx->map_lds)) {
+        if (ctx->conv_mode != 2) { ctx->err = "radial grid too long for the LDS-resident spline of the Abel + map kernel (the rocFFT sequence needs it)"; return JX_ERR_UNSUPPORTED; }
+        ctx->map_ok = false;
+    }
     {
         const int lds = 160 * 1024 - 1024;
 #define JX_ATTR(V, NA) HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_abel_map_sym_kernel<V, NA>, hipFuncAttributeMaxDynamicSharedMemorySize, lds))
@@ -1368,6 +1383,7 @@ struct Taps {
 // the reference facility of a contracted-route context: the rocFFT sequence for up to 16 walkers at a time
 static int ensure_ref(jx_ctx* ctx) {
     if (ctx->fft.ready) return JX_OK;
+    if (!ctx->map_ok) { ctx->err = "radial grid too long for the Abel + map kernel: the rocFFT reference facility (beam-convolved map tap, truncation probe) does not exist on this problem"; return JX_ERR_UNSUPPORTED; }
     return fft_setup(ctx, ctx->fft, std::min(16, ctx->chunk), ctx->d.P);
 }
 
@@ -1398,7 +1414,8 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
     // contracted route: the spline arrays come from one matrix product, unless the profile taps are asked for (they live in
     // the Abel kernel, which then writes the arrays itself) or the matrix product is switched off
     const bool want_abel_taps = t.pp || t.ab || t.y;
-    const bool ag = mix && ctx->abel_gemm && (ctx->f32 || (!want_abel_taps && !ctx->d.inject_pp));
+    // (a grid too long for the Abel kernel: always the matrix product; the profile taps are then read off its own arrays)
+    const bool ag = mix && ctx->abel_gemm && (ctx->f32 || !ctx->map_ok || (!want_abel_taps && !ctx->d.inject_pp));
     if (tm || tm2) {
         if (ctx->ev_inflight.size() > 2048 && (rc = drain_events(ctx))) return rc;
         if ((rc = get_evset(ctx, &es))) return rc;
@@ -1474,6 +1491,7 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
         MixBack& m = ctx->mix;
         if (ctx->f32 && (want_abel_taps || t.need_img)) { ctx->err = "dtype f32: the profile and map taps exist in the f64 build of the context only"; return JX_ERR_UNSUPPORTED; }
         if (ctx->f32 && !ag) { ctx->err = "dtype f32 takes its spline arrays from the matrix product only (JOXSZ_ABEL_GEMM=0 is an f64 setting)"; return JX_ERR_UNSUPPORTED; }
+        if (!ctx->map_ok && (!ag || t.need_img)) { ctx->err = "radial grid too long for the Abel + map kernel: no Compton-y map tap on this problem (and JOXSZ_ABEL_GEMM=0 is not available)"; return JX_ERR_UNSUPPORTED; }
         if (ag) {
             // 32 walkers per block, or 16 when that would leave SIMDs without a wave (a walker's sums do not depend on it)
             const int gy = (ctx->tm_npair + 3) / 4;
@@ -1486,6 +1504,13 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
             if (ctx->f32) { if (narrow) JX_AG_GO(float, 1); else JX_AG_GO(float, 2); }
             else { if (narrow) JX_AG_GO(double, 1); else JX_AG_GO(double, 2); }
 #undef JX_AG_GO
+            if (!ctx->map_ok && want_abel_taps && !ctx->f32) {
+                // the profile taps without the Abel kernel: the pressure profile as the per-walker kernel wrote it, the spline
+                // ordinates y_k of the matrix product, the Abel integral as y / y_scale
+                if (t.pp) HIPCHK(ctx, hipMemcpyAsync(t.pp, pp_src, sizeof(double) * (size_t)n * d.N, hipMemcpyDeviceToDevice, st));
+                if (t.y || t.ab) hipLaunchKernelGGL(jx_unpack_splines_kernel, dim3((unsigned)((d.N + 255) / 256), (unsigned)n), dim3(256), 0, st,
+                                                    reinterpret_cast<const double2*>(m.cft), m.tW, d.N, d.y_scale, t.y, t.ab);
+            }
         } else {
             // phases 1-3 of the Abel kernel (profile, Abel integral, Compton y, spline moments): taps out, arrays walker-minor
             JxDev dm = ctx->d;
@@ -1627,6 +1652,7 @@ static void probe_vectors(jx_ctx* ctx, std::vector<double>& th, int* npts) {
 static int measure_truncation(jx_ctx* ctx, double est[3], int* used) {
     est[0] = est[1] = est[2] = -1.0; *used = 0;
     if (ctx->conv_mode != 2 || ctx->mix.form != 0) return JX_OK;            // nothing truncated
+    if (!ctx->map_ok) return JX_OK;                                         // nothing to measure against (and every term above rounding is kept)
     const jx_config& c = ctx->cfg;
     int rc, npts = 0;
     std::vector<double> th;
@@ -1807,7 +1833,7 @@ static int build_operator(jx_ctx* ctx) {
     auto fail = [&](int code) { (void)hipStreamSynchronize(st); ctx->d.inject_pp = nullptr; ctx->timing_on = tm; (void)hipFree(inj); return code; };
     if (hipMemcpyAsync(ctx->d_theta, th.data(), sizeof(double) * th.size(), hipMemcpyHostToDevice, st) != hipSuccess) return fail(JX_ERR_HIP);
     // (fp32 contexts take their spline arrays from the matrix product of the injected profiles: no profile taps there)
-    Taps t = all_taps(ctx, !ctx->f32);
+    Taps t = all_taps(ctx, !ctx->f32 && ctx->map_ok);
     std::vector<double> eye;
     ctx->timing_on = false;
     for (int j0 = 0; j0 < N; j0 += ctx->chunk) {

@@ -60,6 +60,16 @@ struct JxMix {
     const float* Cmf;
 };
 
+// Profile taps off the matrix product's arrays (radial grids too long for the Abel kernel): y[w][k] = cft[k][w].x, ab = y / y_scale
+__global__ void __launch_bounds__(256)
+jx_unpack_splines_kernel(const double2* __restrict__ cft, long long tW, int N, double y_scale, double* __restrict__ tap_y, double* __restrict__ tap_ab) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y;
+    if (k >= N) return;
+    const double y = cft[(size_t)k * tW + w].x;
+    if (tap_y) tap_y[(size_t)w * N + k] = y;
+    if (tap_ab) tap_ab[(size_t)w * N + k] = y / y_scale;
+}
+
 typedef unsigned jx_mx_u4 __attribute__((ext_vector_type(4)));
 typedef unsigned jx_mx_u2 __attribute__((ext_vector_type(2)));
 template <typename TC> __device__ __forceinline__ TC jx_mx_ldknot(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff);

@@ -547,3 +547,36 @@ def test_truncation_guard_odd_side_and_measured_transfer_function(monkeypatch):
     fin = np.isfinite(b)
     assert fin.sum() >= 6 and np.array_equal(np.isfinite(a), fin)
     np.testing.assert_allclose(a[fin], b[fin], rtol=1e-10)
+
+
+def test_radial_grid_beyond_the_abel_kernels_lds():
+    """N = 1818 at 1025^2 (joxsz_main.py:24,104: R_b and the step set N; round 3 refused it): the Abel + map kernel cannot hold
+    that spline in LDS, but the timed kernels of the contracted route never needed it.  The context comes up without the
+    kernel: every singular term above rounding is kept (nothing could measure a truncation), the log-posterior and the profile
+    taps -- read off the matrix product's own arrays -- agree with the oracle, and the taps that only the kernel could serve
+    (Compton-y map, beam-convolved map) and the rocFFT route say so."""
+    from joxsz_amd import datasets
+    from joxsz_amd.hip_backend import JoxszHipError
+    pb = datasets.synthetic_problem(S=1025, N=1818, seed=8)
+    th = datasets.walker_ball(pb, 6, spread=0.03, seed=8)
+    with pytest.raises(JoxszHipError, match='unsupported'):
+        _post(pb, conv='rocfft')
+    post = _post(pb)
+    assert post.ctx.conv == 'custom'
+    tr = post.ctx.truncation
+    assert tr['retried'] == 0 and (tr['rank'] == 0 or tr['tol'] <= 1.01e-13)
+    got = post.log_prob(th)
+    pp, y, row = post.stage(th[:2], 'pp'), post.stage(th[:2], 'y'), post.stage(th[:2], 'map_row')
+    for tap in ('y_2d', 'conv_2d'):
+        with pytest.raises(JoxszHipError, match='unsupported'):
+            post.stage(th[:1], tap)
+    post.close()
+    want = orc.log_posterior_batch(pb, th[:3])
+    fin = np.isfinite(want)
+    assert fin.sum() >= 2 and np.array_equal(np.isfinite(got[:3]), fin)
+    np.testing.assert_allclose(got[:3][fin], want[fin], rtol=1e-9)
+    for w in range(2):
+        st = orc.sz_stages(pb, orc.pars_dict(pb, th[w]))
+        np.testing.assert_allclose(pp[w], st['pp'], rtol=1e-12)
+        np.testing.assert_allclose(y[w], st['y'], rtol=1e-10, atol=1e-13 * np.abs(st['y']).max())
+        assert np.abs(row[w] - st['map_row']).max() <= 1e-9 * np.abs(st['map_row']).max()
