@@ -164,7 +164,7 @@ struct jx_ctx {
     // behind the evaluation by an event; a send buffer still being gathered holds back the next evaluation that writes it
     bool comm_overlap = false;
     hipStream_t comm_stream = nullptr;
-    struct GatherSlot { const void* send = nullptr; hipEvent_t done = nullptr; bool busy = false; };
+    struct GatherSlot { const char* send = nullptr; size_t bytes = 0; hipEvent_t done = nullptr; bool busy = false; };
     GatherSlot gslot[4];
     hipEvent_t ev_fork = nullptr;      // compute stream -> collective stream
     std::vector<std::pair<hipEvent_t, hipEvent_t>> gt_inflight, gt_free;   // events around every all-gather (its own duration)
@@ -876,13 +876,13 @@ int jx_allgather_logp(jx_ctx* ctx, const double* send_dev, double* recv_dev, int
     if (ctx->comm_overlap) {
         // remember the send buffer: the next evaluation that writes it waits for this gather (run_chunk), nothing else does
         jx_ctx::GatherSlot* slot = nullptr;
-        for (auto& g : ctx->gslot) if (g.busy && g.send == (const void*)send_dev) slot = &g;
+        for (auto& g : ctx->gslot) if (g.busy && g.send == (const char*)send_dev) slot = &g;
         if (!slot) for (auto& g : ctx->gslot) if (!g.busy) { slot = &g; break; }
         if (!slot) {                                                 // every slot taken: retire the oldest by waiting for it on the compute stream
             slot = &ctx->gslot[0];
             HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, slot->done, 0));
         }
-        slot->send = send_dev; slot->busy = true;
+        slot->send = (const char*)send_dev; slot->bytes = sizeof(double) * (size_t)count; slot->busy = true;
         HIPCHK(ctx, hipEventRecord(slot->done, cs));
     }
     return JX_OK;
@@ -1397,7 +1397,7 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
     hipStream_t st = ctx->stream;
     if (ctx->comm_overlap)                                         // a gather still reading this output buffer: the evaluation waits for it, and only for it
         for (auto& g : ctx->gslot)
-            if (g.busy && g.send == (const void*)logp_dev) {
+            if (g.busy && g.send < (const char*)(logp_dev + w0 + n) && (const char*)(logp_dev + w0) < g.send + g.bytes) {     // (byte ranges overlap)
                 // (a gather that has already finished costs a query on the host, not a barrier in the queue)
                 if (hipEventQuery(g.done) != hipSuccess) HIPCHK(ctx, hipStreamWaitEvent(st, g.done, 0));
                 g.busy = false;

@@ -47,6 +47,50 @@ def test_rccl_gather_through_the_c_abi_world_1():
     post.close()
 
 
+def test_overlapped_gather_world_1():
+    """jx_comm_set_overlap: the collectives on a second stream of the context, each behind an event.  Two alternating output
+    buffers (what bench.py does) and ONE buffer written by every step (the evaluation must then wait for the gather that is
+    still reading it) both deliver the evaluation's values; jx_sync covers both streams; the gather's own time is reported."""
+    from joxsz_amd import datasets
+    from joxsz_amd.dist import RcclGather
+    from joxsz_amd.posterior import JoxszPosterior
+    pb = datasets.synthetic_problem(S=64, N=80, seed=3)
+    W = 48
+    ths = [np.ascontiguousarray(datasets.walker_ball(pb, W, spread=0.03, seed=10 + i)) for i in range(3)]
+    post = JoxszPosterior(pb, device=0)
+    ctx = post.ctx
+    wants = [post.log_prob(t) for t in ths]
+    comm = RcclGather(ctx, rank=0, world=1, overlap=True)
+    tp = [ctx.dev_alloc(t.nbytes) for t in ths]
+    for p_, t in zip(tp, ths):
+        ctx.h2d(p_, t)
+    lp, al = [ctx.dev_alloc(8 * W) for _ in range(2)], [ctx.dev_alloc(8 * W) for _ in range(3)]
+    ctx.timing_enable(True)
+    for i in range(3):                                    # alternating send buffers, one receive buffer per step
+        ctx.eval_device(tp[i], W, lp[i % 2])
+        comm.all_gather(lp[i % 2], al[i], W)
+    comm.barrier()
+    ctx.sync()
+    for i in range(3):
+        got = np.empty(W)
+        ctx.d2h(got, al[i])
+        np.testing.assert_array_equal(got, wants[i])
+    ms, n = ctx.comm_gather_time()
+    assert n == 3 and 0 < ms < 50
+    for i in range(3):                                    # the same send buffer every step: each evaluation waits for the previous gather
+        ctx.eval_device(tp[i], W, lp[0])
+        comm.all_gather(lp[0], al[i], W)
+    ctx.sync()
+    ctx.timing_enable(False)
+    for i in range(3):
+        got = np.empty(W)
+        ctx.d2h(got, al[i])
+        np.testing.assert_array_equal(got, wants[i])
+    assert comm.max_over_ranks([1.5, -2.0, 7.0]).tolist() == [1.5, -2.0, 7.0]
+    comm.close()
+    post.close()
+
+
 _RANK_SCRIPT = r"""
 import os, sys
 import numpy as np
