@@ -137,6 +137,7 @@ struct jx_ctx {
 
     // batch staging for the host-pointer API
     double *d_theta = nullptr, *d_logp = nullptr;
+    double *h_theta = nullptr, *h_logp = nullptr;   // pinned host staging of jx_eval (a pageable hipMemcpyAsync stages and synchronises by itself)
     int batch_cap = 0;
     // taps (chunk capacity, allocated on first use)
     double *t_pp = nullptr, *t_ab = nullptr, *t_y = nullptr, *t_row = nullptr, *t_bright = nullptr,
@@ -1089,6 +1090,12 @@ static int finalize_impl(jx_ctx* ctx) {
     d.y_scale = c.kpc_cm * c.sigma_T / c.m_e;
     d.inv_h_mean = (double)(N - 1) / (r[N - 1] - r[0]);
     d.prep_pow = env_str("JOXSZ_PREP_POW") && atoi(env_str("JOXSZ_PREP_POW")) ? 1 : 0;
+    if (!c.sz_only) {
+        const std::vector<double> lt = host_vec<double>(ctx, JX_T_LNT);
+        for (int i = 1; i < c.ntab; ++i)
+            if (!(lt[i] > lt[i - 1])) { ctx->err = "lnT must be increasing"; return JX_ERR_INVALID; }
+        d.inv_dlnT = (double)(c.ntab - 1) / (lt[c.ntab - 1] - lt[0]);
+    }
 
     int rc;
     // ---- evaluation matrix of g at the data radii (joxsz_funcs.py:476), and which outputs of the extracted row it reads at all:
@@ -1334,8 +1341,11 @@ static int ensure_batch(jx_ctx* ctx, int n) {
     if (n <= ctx->batch_cap) return JX_OK;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->d_theta) { (void)hipFree(ctx->d_theta); (void)hipFree(ctx->d_logp); ctx->d_theta = ctx->d_logp = nullptr; ctx->batch_cap = 0; }
+    if (ctx->h_theta) { (void)hipHostFree(ctx->h_theta); (void)hipHostFree(ctx->h_logp); ctx->h_theta = ctx->h_logp = nullptr; }
     HIPCHK(ctx, hipMalloc((void**)&ctx->d_theta, sizeof(double) * (size_t)n * ctx->cfg.ndim));
     HIPCHK(ctx, hipMalloc((void**)&ctx->d_logp, sizeof(double) * (size_t)n));
+    HIPCHK(ctx, hipHostMalloc((void**)&ctx->h_theta, sizeof(double) * (size_t)n * ctx->cfg.ndim, hipHostMallocDefault));
+    HIPCHK(ctx, hipHostMalloc((void**)&ctx->h_logp, sizeof(double) * (size_t)n, hipHostMallocDefault));
     ctx->batch_cap = n;
     return JX_OK;
 }
@@ -1435,7 +1445,7 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
     auto launch_prep = [&](hipStream_t ps, double* pp_buf) {
         JxDev dp = d;
         dp.inject_pp = ctx->d.inject_pp;
-        const size_t sh = sizeof(double) * (JX_LDS_HDR + (size_t)2 * d.N + 2 * d.nann + (size_t)d.nband * d.nann + 8);
+        const size_t sh = sizeof(double) * (JX_LDS_HDR + (size_t)2 * d.N + 2 * d.nann + (size_t)d.nband * d.nann + 2 * (size_t)d.nconv + 8);
         if (d.prep_pow) hipLaunchKernelGGL(jx_prep_kernel<true>, dim3(n), dim3(JX_PREP_THREADS), sh, ps, dp, theta_dev, w0,
                                            base_buf, cfac_buf, pp_buf, sz0_buf, t.tprof, t.xprofs, t.parts, t.integ);
         else hipLaunchKernelGGL(jx_prep_kernel<false>, dim3(n), dim3(JX_PREP_THREADS), sh, ps, dp, theta_dev, w0,
@@ -1913,10 +1923,13 @@ int jx_eval(jx_ctx* ctx, const double* theta, int nwalkers, double* logp) {
     HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
     int rc = ensure_batch(ctx, nwalkers);
     if (rc) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d_theta, theta, sizeof(double) * (size_t)nwalkers * ctx->cfg.ndim, hipMemcpyHostToDevice, ctx->stream));
+    // through pinned staging: the copies are then plain DMA enqueued on the stream, and the call waits once, at its end
+    memcpy(ctx->h_theta, theta, sizeof(double) * (size_t)nwalkers * ctx->cfg.ndim);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_theta, ctx->h_theta, sizeof(double) * (size_t)nwalkers * ctx->cfg.ndim, hipMemcpyHostToDevice, ctx->stream));
     if ((rc = jx_eval_device(ctx, ctx->d_theta, nwalkers, ctx->d_logp))) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(logp, ctx->d_logp, sizeof(double) * (size_t)nwalkers, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_logp, ctx->d_logp, sizeof(double) * (size_t)nwalkers, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(logp, ctx->h_logp, sizeof(double) * (size_t)nwalkers);
     return JX_OK;
 }
 
@@ -2256,6 +2269,8 @@ void jx_destroy(jx_ctx* ctx) {
     for (void* p : ctx->samp_buf) if (p) (void)hipFree(p);
     if (ctx->d_theta) (void)hipFree(ctx->d_theta);
     if (ctx->d_logp) (void)hipFree(ctx->d_logp);
+    if (ctx->h_theta) (void)hipHostFree(ctx->h_theta);
+    if (ctx->h_logp) (void)hipHostFree(ctx->h_logp);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     if (--g_rocfft_refs == 0) rocfft_cleanup();
     delete ctx;

@@ -56,6 +56,7 @@ struct JxDev {
     int map_split;               // row slabs per walker in the Abel+map kernel
     double y_scale;              // kpc_cm * sigma_T / m_e            (joxsz_funcs.py:459)
     double inv_h_mean;           // (N-1)/(r_N - r_1): first guess of the interval index in the generic map kernel
+    double inv_dlnT;             // (ntab-1)/(lnT[ntab-1] - lnT[0]): first guess of the interval of the count-rate tables
     // constant tensors (device)
     const double* r_pp;          // [N]
     const double* d_mat;         // [S*S]
@@ -172,18 +173,30 @@ __device__ __forceinline__ double jx_convert(const JxDev& c, double T) {
     return slope * (T - c.conv_T[lo]) + c.conv_v[lo];
 }
 
+// the same from copies of the two small tables (LDS): the search is a chain of dependent reads, a memory round trip each otherwise
+__device__ __forceinline__ double jx_convert_tab(const double* ct, const double* cv, int nconv, double T) {
+    int hi = 1;
+    while (hi < nconv - 1 && T > ct[hi]) ++hi;
+    const int lo = hi - 1;
+    const double slope = (cv[hi] - cv[lo]) / (ct[hi] - ct[lo]);
+    return slope * (T - ct[lo]) + cv[lo];
+}
+
 // np.interp(x, xp, fp) -- clamped linear interpolation -- for two tables on one grid: identical arithmetic per table, one
 // interval search
-__device__ __forceinline__ void jx_interp_clamped2(const double* xp, const double* f0, const double* f1, int n, double x,
+__device__ __forceinline__ void jx_interp_clamped2(const double* xp, const double* f0, const double* f1, int n, double x, double inv_dx_mean,
                                                    double* o0, double* o1) {
     if (x != x) { *o0 = x; *o1 = x; return; }
     if (x <= xp[0]) { *o0 = f0[0]; *o1 = f1[0]; return; }
     if (x >= xp[n - 1]) { *o0 = f0[n - 1]; *o1 = f1[n - 1]; return; }
-    int lo = 0, hi = n - 1;
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (xp[mid] <= x) lo = mid; else hi = mid;
-    }
+    // the interval [xp[lo], xp[lo + 1]) that holds x: a guess from the grid's mean spacing (exact for the uniform ln T grid of
+    // mbproj2's count-rate tables, joxsz_funcs.py:669), corrected by comparisons -- the bisection's answer for any increasing
+    // grid, in two dependent loads instead of seven
+    int lo = (int)((x - xp[0]) * inv_dx_mean);
+    lo = max(0, min(n - 2, lo));
+    while (lo > 0 && xp[lo] > x) --lo;
+    while (lo < n - 2 && xp[lo + 1] <= x) ++lo;
+    const int hi = lo + 1;
     const double dx = xp[hi] - xp[lo], t = x - xp[lo];
     *o0 = (f0[hi] - f0[lo]) / dx * t + f0[lo];
     *o1 = (f1[hi] - f1[lo]) / dx * t + f1[lo];
@@ -252,6 +265,7 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
     double* s_ne = s_t + c.N;                 // [nann]
     double* s_T = s_ne + c.nann;              // [nann]
     double* s_rate = s_T + c.nann;            // [nband*nann]
+    double* s_conv = s_rate + c.nband * c.nann;   // [2 nconv] the Compton -> mJy/beam table (temperatures, factors)
 
     // the constants of this thread's prior are requested before the parameters are assembled (they do not depend on them)
     const bool has_par = tid < c.npar;
@@ -259,6 +273,7 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
     const double pk_a = has_par ? (pk_kind == 1 ? c.par_mu[tid] : c.par_min[tid]) : 0.0;
     const double pk_b = has_par ? (pk_kind == 1 ? c.par_sigma[tid] : c.par_max[tid]) : 0.0;
     const double pk_ln = has_par ? c.par_lnorm[tid] : 0.0;
+    for (int i = tid; i < 2 * c.nconv; i += nth) s_conv[i] = (i < c.nconv) ? c.conv_T[i] : c.conv_v[i - c.nconv];   // (visible behind the barriers of jx_load_params)
     jx_load_params(c, theta, gw, p);
     double pc[5] = {0, 1, 1, 0, 1};           // radius-independent factors of the density (every thread its own copy)
     if (POW) jx_ne_consts(p, c.ne_mode, pc);
@@ -357,7 +372,7 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
     const double t0 = jx_block_sum(part, red);
     for (int k = tid; k < c.nrow; k += nth) {
         const double T = (k == 0) ? t0 : s_t[k - 1];
-        cfac[(size_t)w * c.nrow + k] = jx_convert(c, T) * p[P_CALIB];
+        cfac[(size_t)w * c.nrow + k] = jx_convert_tab(s_conv, s_conv + c.nconv, c.nconv, T) * p[P_CALIB];
         if (tap_tprof) tap_tprof[(size_t)w * c.nrow + k] = T;
     }
     __syncthreads();
@@ -397,7 +412,7 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
             const double lt = log(s_T[j]);
             const double* tab = c.lnrate + (size_t)b * 2 * c.ntab;
             double i0, i1;                     // one search of the temperature grid serves both metallicity tables
-            jx_interp_clamped2(c.lnT, tab, tab + c.ntab, c.ntab, lt, &i0, &i1);
+            jx_interp_clamped2(c.lnT, tab, tab + c.ntab, c.ntab, lt, c.inv_dlnT, &i0, &i1);
             const double z0 = exp(i0), z1 = exp(i1);
             s_rate[q] = (z0 + (z1 - z0) * p[P_Z]) * s_ne[j] * s_ne[j];
         }

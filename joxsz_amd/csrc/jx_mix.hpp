@@ -139,6 +139,7 @@ jx_rowmix_kernel(JxMix m, const TC* __restrict__ cft, double* __restrict__ Dt) {
     double acc[RT];
 #pragma unroll
     for (int j = 0; j < RT; ++j) acc[j] = 0.0;
+    unsigned wo = 0u, co = 0u;                                // byte offsets into the piece's weight and operator streams
     TC q[NS];
     unsigned kb = (unsigned)k0 * kstride;                    // (uniform) byte offset of the next knot to request
 #pragma unroll
@@ -155,17 +156,20 @@ jx_rowmix_kernel(JxMix m, const TC* __restrict__ cft, double* __restrict__ Dt) {
             q[(j + NS - 1) % NS] = jx_mx_ldknot<TC>(rs, loff, kb);
             kb += kstride;
             for (int i = 0; i < cnt[j]; ++i) {
-                const double wa = wp[0], wb = wp[1], wc = wp[2], wd = wp[3];
+                // (both scalar streams through one 32-bit byte offset each: s_load base, offset -- no 64-bit pointer arithmetic per sample)
+                const double* __restrict__ wq = reinterpret_cast<const double*>(reinterpret_cast<const char*>(wp) + wo);
+                const double* __restrict__ cq = reinterpret_cast<const double*>(reinterpret_cast<const char*>(cp) + co);
+                const double wa = wq[0], wb = wq[1], wc = wq[2], wd = wq[3];
                 double f = wa * (double)q[j].x;
                 f = fma(wb, (double)q[(j + 1) % NS].x, f);
                 f = fma(wc, (double)q[j].y, f);
                 f = fma(wd, (double)q[(j + 1) % NS].y, f);
 #pragma unroll
-                for (int r = 0; r < RT; ++r) acc[r] = fma(cp[r], f, acc[r]);
+                for (int r = 0; r < RT; ++r) acc[r] = fma(cq[r], f, acc[r]);
 #ifdef JOXSZ_ABLATIONS
                 if (!(m.dbg & 2))                             // timing experiment (wrong results): the scalar streams stand still
 #endif
-                { wp += 4; cp += RT; }
+                { wo += 32u; co += 8u * RT; }
             }
         }
     }
