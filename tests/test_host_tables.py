@@ -371,3 +371,32 @@ def test_mix_full_operator_with_a_measured_like_beam_and_a_rough_transfer_functi
     assert np.abs(out - ref['map_row']).max() <= 1e-13 * np.abs(ref['map_row']).max()
     # weights that are not real (a filter without the symmetry in each wavenumber) are refused
     assert lib.jxt_mix_full_operator(_p(np.ascontiguousarray(pb.beam_2d)), B, pb.step ** 2, _p(np.ascontiguousarray(rng.random((S, S)))), S, _p(Om)) == -1
+
+
+@pytest.mark.parametrize('S', [171, 256, 512, 513, 1024])
+def test_the_data_radii_spline_reads_a_bounded_part_of_the_row(lib, S):
+    """DESIGN 4.1 on the CPU: the evaluation matrix E of the not-a-knot spline through the extracted row (joxsz_funcs.py:476), as the
+    library builds it (jxt::nak_eval_matrix), against scipy's interp1d on unit vectors; its columns decay by about 2 - sqrt(3)
+    per knot beyond the last data radius, so that with CL J1226.9+3332's 19 radii (<= 116 arcsec = pixel 58 at 2 arcsec) no
+    column beyond 96 carries a weight above 1e-22 of the largest: what the matrix-core product need not compute.  A row element
+    dropped at that level changes g(r) by less than 1e-20 of the row's largest entry -- four orders under fp64's rounding."""
+    from scipy.interpolate import interp1d
+    c = S // 2
+    xk = 2.0 * (np.arange(S) - c)[c:].astype(np.float64)
+    q = 3.136 + 6.273 * np.arange(19)
+    nrow = xk.size
+    E = np.zeros((q.size, nrow))
+    assert lib.jxt_nak_eval_matrix(_p(xk), nrow, _p(q), q.size, _p(E)) == 0
+    ref = np.zeros_like(E)
+    for k in range(0, nrow, max(1, nrow // 40)):
+        e = np.zeros(nrow); e[k] = 1.0
+        ref[:, k] = interp1d(xk, e, 'cubic', fill_value='extrapolate')(q)
+        assert np.abs(E[:, k] - ref[:, k]).max() < 1e-12
+    m = np.abs(E).max(axis=0)
+    kuse = int(np.max(np.nonzero(m > 1e-22 * m.max())[0])) + 1
+    assert kuse <= min(nrow, 96)
+    if nrow > 120:
+        k0 = 70
+        ratio = m[k0 + 20] / m[k0]
+        assert abs(ratio ** (1 / 20.0) - (2 - np.sqrt(3))) < 0.01          # the cardinal functions' decay per knot
+        assert np.abs(E[:, 96:]).sum(axis=1).max() < 1e-20 * m.max()
