@@ -577,7 +577,8 @@ def main():
             if lowrank:
                 # stage 1: per sample and walker 4 FMAs of the spline evaluation + R of the mixing
                 k_ms = tm_timed['beam_fft_ms'] / max(1, tm_timed['launches'])
-                fl = 2.0 * NU * NU * (4 + lay['R']) * walkers_per_launch
+                NUe = ctx.sampling['rows_evaluated']                      # rows (= columns) of the quadrant stage 1 evaluates (the sub-grid)
+                fl = 2.0 * NUe * NUe * (4 + lay['R']) * walkers_per_launch
                 ach = fl / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
                 roof = {'kernel': 'jx_rowmix_kernel', 'bound': 'valu (fp64 vector FMA; the same 78.6 TFLOP/s as the dense fp64 matrix-core peak)',
                         'achieved': ach, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / FP64_PEAK_TFLOPS,
@@ -586,13 +587,15 @@ def main():
                         'peak_measured': FP64_FMA_MEASURED_TFLOPS, 'frac_of_peak_measured': ach / FP64_FMA_MEASURED_TFLOPS,
                         'launch_ms': k_ms, 'launch_ms_source': 'HIP events around this kernel inside the timed region (jx_timing_enable(2))',
                         'flops_per_launch': fl, 'share_of_step': k_ms / max(1e-12, ms_step * walkers_per_launch / W),
-                        'algorithmic_bytes_per_launch': walkers_per_launch * (16.0 * pb.N + 8.0 * NU * lay['R']),
+                        'algorithmic_bytes_per_launch': walkers_per_launch * (16.0 * pb.N + 8.0 * NUe * lay['R']),
+                        'samples_evaluated_per_walker': NUe * NUe, 'distinct_samples_per_walker': NU * NU,
                         'survey_8d_bytes_per_launch': walkers_per_launch * S * S * 8.0,
-                        'note': 'algorithmic flops = 2 * NU^2 * (4 + R) per walker (4 FMAs evaluate a map sample from the spline, R mix it into '
-                                'the rows kept per column; NU = %d distinct rows = distinct columns, R = %d) / HIP-event duration.  The S x S map of '
+                        'note': 'algorithmic flops = 2 * NUe^2 * (4 + R) per walker (4 FMAs evaluate a map sample from the spline, R mix it into '
+                                'the rows kept per column; NUe = %d of the quadrant\'s %d distinct rows = columns are evaluated -- the sub-grid of '
+                                'jx_get_sampling, the interpolation to the others sits in the operators -- R = %d) / HIP-event duration.  The S x S map of '
                                 'SURVEY 8(d) (S^2 * 8 B per walker) is never written: every sample lives in a register.  The kernel is bound by '
                                 'the fp64 vector units, not by HBM; peak_measured = sustained v_fmac_f64 rate of this chip (scripts/ubench/fma_sgpr.hip)'
-                                % (NU, lay['R'])}
+                                % (NUe, NU, lay['R'])}
             p_ms = stage_ms['tf_fft_ms']
             K4 = lay['ksteps'] * 4
             prn = ctx.output_pruning
@@ -627,7 +630,8 @@ def main():
                                    % (W, S, S, args.N, 'SZ-only' if pb.sz_only else 'joint X-ray+SZ',
                                       ' (BASELINE configs[2])' if (W, S, args.N, pb.sz_only) == (1024, 512, 500, False) else ''),
                        'walkers_per_gpu': W, 'S': S, 'N': args.N, 'B': pb.B, 'chunk': ctx.chunk, 'route': ctx.route, 'conv': ctx.conv,
-                       'conv_layout': ctx.conv_layout, 'output_pruning': ctx.output_pruning, 'parallelism': 'walkers sharded x%d' % world, 'device': ctx.device_name,
+                       'conv_layout': ctx.conv_layout, 'output_pruning': ctx.output_pruning,
+                       'sampling': {k: v for k, v in ctx.sampling.items() if k != 'rows'}, 'parallelism': 'walkers sharded x%d' % world, 'device': ctx.device_name,
                        'gather': (('overlapped: second stream, two output buffers' if overlap else 'strict: on the compute stream') if comm is not None else None)},
             'n_ranks_seen': (comm.n_ranks_seen if comm is not None else 1),
             'gather_ms_per_step': gather_ms,

@@ -260,6 +260,16 @@ int  jx_get_conv_mode(jx_ctx* ctx);
  * `ntile`, tW walker stride of the work buffers, ldx doubles per partial row, ksplit K slices of the last launch.
  * JX_ERR_UNSUPPORTED with the rocFFT back end. */
 int  jx_get_conv_layout(jx_ctx* ctx, int32_t out[12]);
+/* Which map samples stage 1 of the low-rank form evaluates: out = {distinct rows (= columns) of the map quadrant NU; rows stage 1
+ * evaluates; full resolution below this many pixels from the axis; every second row up to here (u1), every fourth up to 2 u1, every eighth beyond; interpolation
+ * points; 1 when a sub-grid is in use; rebuilds in which the guard took it away; 0}; rows (optional, nrows_cap entries): the kept
+ * indices.  Away from the cluster core the Compton-y map varies on the scale of the radius, far above the pixel, so the quadrant
+ * is recoverable from a tensor sub-grid of its rows and columns by local polynomial interpolation, Q ~ L Q_sub L^T, and the
+ * contraction needs only the transformed operators L^T C and G (L x I): measured error 1e-12 of the row's maximum over the prior
+ * box (profiles/r04_subsample_proto.log), measured again on the caller's data by the guard of jx_get_truncation, which takes the
+ * sub-grid away first.  JOXSZ_MIX_SUBSAMPLE=0: every distinct sample; "u0,u1,npts": another sub-grid.  Not used when the quadrant
+ * reaches beyond the radial grid (fill values: the map is not smooth there), nor by the full form. */
+int  jx_get_sampling(jx_ctx* ctx, int32_t out[8], int32_t* rows, int nrows_cap);
 /* Which outputs of the extracted row the matrix-core product computes when no tap asks for the row: out = {nrow; outputs the
  * data-radii spline of the tail (joxsz_funcs.py:476) reads with a weight above 1e-22 of its largest -- the cardinal functions
  * of a cubic spline decay by 2 - sqrt(3) per knot, so the row beyond the last data radius + ~35 pixels does not reach an fp64

@@ -65,6 +65,8 @@ struct MixBack {
     JxOpg og_u{};                      // the product restricted to the outputs the tail reads (nxt_u tiles per block, ksplit_u slices); og: every output (taps)
     int nxt_u = 0, ksplit_u = 0, ksplit_u_force = 0;
     bool has_u = false, last_was_u = false;
+    int NU_full = 0;                   // distinct rows of the quadrant (mx.NU: the ones stage 1 evaluates)
+    std::vector<int> sub;              // indices of the rows (= columns) stage 1 evaluates; empty: all
     int RT = 0, nxt = 0, r = 0, ns = 0, ksteps = 0, wpb = 4, wpb_force = 0, ksplit_force = 0, last_ksplit = 1, dbg = 0;
     bool mfma = false;                 // stage 1 on the fp64 matrix cores (R <= 16: jx_rowmix_mfma_kernel)
     int r_tol = 0;                     // terms above the singular-value cut (r < r_tol: capped to one 16-row tile)
@@ -93,6 +95,8 @@ struct jx_ctx {
     // derived sizes
     int nrow = 0, nt = 0, Sh = 0, K = 0, chunk = 0, num_cu = 256;
     int nrow_use = 0;                  // outputs of the extracted row the data-radii spline reads with a weight above JX_PRUNE_TOL of its largest (<= nrow)
+    bool subsample = true;             // JOXSZ_MIX_SUBSAMPLE=0: stage 1 evaluates every distinct map sample (default: a tensor sub-grid, the rest by interpolation folded into the operators)
+    int sub_u0 = 40, sub_u1 = 160, sub_npts = 12;   // full resolution below u0 pixels from the axis, every second row up to u1, every fourth up to 2 u1, every eighth beyond; interpolation points
     bool prune = true;                 // JOXSZ_PRUNE_OUTPUTS=0: the matrix-core product computes every output of the row, read or not
     int64_t device_bytes = 0;
     int conv_mode = 1;                 // 1 rocFFT sequence, 2 contracted route
@@ -126,11 +130,12 @@ struct jx_ctx {
     // truncation guard
     double trunc_est[3] = {-1.0, -1.0, -1.0};   // measure_truncation: row at the current values, row over the probe points, SZ log-likelihood
     double trunc_bound = 1e-9, trunc_bound_ll = 1e-8;
-    int trunc_retried = 0, trunc_points = 0, trunc_uncapped = 0;   // rebuilds in all; of which: the cap on the rank taken away
+    int trunc_retried = 0, trunc_points = 0, trunc_uncapped = 0, trunc_unsub = 0;   // rebuilds in all; of which: the cap on the rank taken away
     bool tol_pinned = false;           // JOXSZ_LOWRANK_TOL given: the guard measures but never overrides
     int form_force = -1;               // JOXSZ_MIX_FORM: 0 low-rank, 1 full
     int map_pair = 1;                  // full-map kernel: two walkers per block (JOXSZ_MAP_PAIR=0: one)
     int usplit = 2;                    // pieces a map column is walked in by stage 1 (JOXSZ_MIX_USPLIT: 1..4; a setting, never a function of the launch)
+    bool usplit_forced = false;        // (otherwise plan_mix picks it from the columns stage 1 walks and the chunk)
     int rank_cap = 16;                 // low-rank form: a rank within JX_MIX_CAP_REACH terms above this is cut to it, so that stage 1 fits one 16-row matrix-core
                                        // tile (the guard measures the result and takes the cap away when it costs accuracy; JOXSZ_MIX_RANKCAP=0: never)
     bool mix_mfma = false;             // JOXSZ_MIX_MFMA=1: stage 1 on the fp64 matrix cores when R <= 16 (measured slower than the vector-unit kernel: DESIGN 6.1)
@@ -465,6 +470,8 @@ struct MixBuild {
     bool mfma = false;
     int nxt_u = 0, ntile_u = 0, nog_u = 0;     // tiling of the outputs in use (0: all of them)
     std::vector<double> Op_u;
+    int NU_full = 0;                   // distinct rows of the quadrant; NU below = the rows stage 1 evaluates (sub)
+    std::vector<int> sub;              // their indices (empty: all)
     size_t krows = 0;
     jxt::MixColumns cols;
     std::vector<double> Cm, Op;
@@ -494,7 +501,7 @@ static void plan_mix(jx_ctx* ctx, const std::vector<double>& beam, const std::ve
     const int NU = std::max(S / 2, S - 1 - S / 2) + 1;
     if (ctx->qn != NU) { mb.why = "quadrant table size"; return; }
     if (NU > 9 * 64) { mb.why = "map side beyond the symmetric map kernel's range"; return; }
-    mb.NU = NU; mb.tol = tol; mb.beam_tol = 1e-14;
+    mb.NU = NU; mb.tol = tol; mb.beam_tol = 1e-14;          // (NU: replaced by the size of the sub-grid below when stage 1 evaluates one)
     mix_output_tiling(nrow, &mb.nxt, &mb.nog, &mb.ntile);
     if (ctx->prune && ctx->nrow_use > 0 && (ctx->nrow_use + 15) / 16 < (nrow + 15) / 16) mix_output_tiling(ctx->nrow_use, &mb.nxt_u, &mb.nog_u, &mb.ntile_u);
     // transfer-function weights of the extracted row, real for a real filter that is symmetric in each wavenumber
@@ -506,7 +513,40 @@ static void plan_mix(jx_ctx* ctx, const std::vector<double>& beam, const std::ve
     if (!(maxim <= 1e-15 * maxre)) { mb.why = "transfer-function weights are not real"; return; }
     // ---- low-rank form: separable terms of the beam x singular terms of the weights
     std::vector<double> U, V, by, bx;
-    bool lowrank_ok = jxt::mix_column_tables(ctx->h_Qtab, ctx->qn, NU, r, mb.cols, ctx->usplit);
+    // Which rows (= columns) of the quadrant stage 1 evaluates: all of them, or -- when the quadrant lies inside the radial grid
+    // (no fill values, no NaN radius: the map is then smooth away from the core) -- the sub-grid of jxt::mix_row_subset, the
+    // others entering through the interpolation folded into both operators below.  jx_finalize measures the result with the
+    // truncation (the guard) and takes the sub-grid away first when a bound is exceeded.
+    mb.NU_full = NU;
+    std::vector<double> Lint;                                    // [NU][ns]
+    std::vector<double> Qsub;
+    int NUs = NU;
+    if (ctx->subsample && form_force != 1) {
+        bool inside = true;
+        for (double v : ctx->h_Qtab) if (!(v <= r.back())) { inside = false; break; }
+        jxt::mix_row_subset(NU, ctx->sub_u0, ctx->sub_u1, mb.sub);
+        if (!inside || (int)mb.sub.size() > (3 * NU) / 4 || (int)mb.sub.size() < 2 * ctx->sub_npts) mb.sub.clear();
+        else {
+            NUs = (int)mb.sub.size();
+            jxt::mix_interp_matrix(NU, mb.sub, ctx->sub_npts, Lint);
+            Qsub.resize((size_t)NUs * NUs);
+            for (int a = 0; a < NUs; ++a)
+                for (int b2 = 0; b2 < NUs; ++b2) Qsub[(size_t)a * NUs + b2] = ctx->h_Qtab[(size_t)mb.sub[a] * ctx->qn + mb.sub[b2]];
+        }
+    }
+    if (!ctx->usplit_forced) {
+        // pieces per column: a chunk of 1024 walkers should fill the chip in as few rounds of waves as possible (24 resident waves per CU:
+        // scripts/ubench/occ_rowmix.hip), each piece paying its ring fill once more -- rounds x (1 / pieces + 0.08), measured
+        // against JOXSZ_MIX_USPLIT = 1..4 at 512^2 with and without the sub-grid (profiles/r04_subsample_scan.log)
+        const double cap = 24.0 * std::max(1, ctx->num_cu), ngrp = 16.0;      // (a nominal chunk of 1024 walkers, not this context's: the grouping of a walker's sums must not depend on max_batch)
+        double best = 1e300;
+        for (int usp = 1; usp <= 4; ++usp) {
+            const double c = std::ceil(NUs * usp * ngrp / cap) * (1.0 / usp + 0.08);
+            if (c < best * (1.0 - 1e-9)) { best = c; ctx->usplit = usp; }
+        }
+    }
+    bool lowrank_ok = mb.sub.empty() ? jxt::mix_column_tables(ctx->h_Qtab, ctx->qn, NU, r, mb.cols, ctx->usplit)
+                                     : jxt::mix_column_tables(Qsub, NUs, NUs, r, mb.cols, ctx->usplit);
     std::string why_lr = lowrank_ok ? "" : "pixel radii do not grow along the columns of d_mat";
     if (lowrank_ok && form_force != 1) {
         mb.r = jxt::lowrank_factor_qr(A.data(), S, Sh, tol, U, V);
@@ -534,11 +574,11 @@ static void plan_mix(jx_ctx* ctx, const std::vector<double>& beam, const std::ve
     }
     // cost of each form in fused multiply-adds per walker; stage 1 runs on the vector units at about 0.6 of the rate the
     // matrix cores reach in the product kernels (measured: 256^2 with 32 terms 0.141 ms low-rank against 0.126 ms full; 257^2 0.155 against 0.132)
-    const double nsamp = (double)NU * NU;
+    const double nsamp = (double)NU * NU, nsamp_lr = (double)NUs * NUs;         // (the low-rank form evaluates the sub-grid)
     // (stage 1 on the matrix cores: 16 multiply-adds per sample there, the 4 of the evaluation beside them on the vector units)
     const double nout = mb.ntile_u > 0 ? 16.0 * mb.ntile_u : (double)nrow;      // outputs the timed product computes
     const int nog_t = mb.ntile_u > 0 ? mb.nog_u : mb.nog;
-    mb.cost_lowrank = (lowrank_ok && mb.RT) ? (mb.mfma ? nsamp * 18.0 : 1.6 * nsamp * (4.0 + mb.RT)) + nout * NU * mb.R : 1e300;
+    mb.cost_lowrank = (lowrank_ok && mb.RT) ? (mb.mfma ? nsamp_lr * 18.0 : 1.6 * nsamp_lr * (4.0 + mb.RT)) + nout * NUs * mb.R : 1e300;
     mb.cost_full = nout * nsamp * 0.5 + nsamp * 6.0 * nog_t;
     int form = (mb.cost_lowrank <= mb.cost_full) ? 0 : 1;
     if (form_force == 0) { if (!lowrank_ok || !mb.RT) { mb.why = "low-rank form: " + why_lr; return; } form = 0; }
@@ -547,11 +587,45 @@ static void plan_mix(jx_ctx* ctx, const std::vector<double>& beam, const std::ve
     if (form != 0) mb.mfma = false;
     if (form == 0) {
         mb.cld = mb.RT;
-        jxt::mix_stage1_operator(U, mb.r, by, mb.ns, S, B, NU, (mb.cols.wld + 4 + 1) & ~1, mb.cld, mb.Cm);   // (zero rows behind the last: the matrix-core kernel reads whole groups of four)
-        const size_t K = (size_t)NU * mb.R;
-        mb.ksteps = (int)((K + 3) / 4);
-        mb.krows = 4 * ((size_t)mb.ksteps + (size_t)JX_MIX_KSPLIT_MAX * JX_OPG_RD + JX_OPG_RD);
-        jxt::mix_stage2_operator(V, mb.r, bx, mb.ns, S, B, NU, mb.krows, mb.ntile, mb.Op);
+        if (mb.sub.empty()) {
+            jxt::mix_stage1_operator(U, mb.r, by, mb.ns, S, B, NU, (mb.cols.wld + 4 + 1) & ~1, mb.cld, mb.Cm);   // (zero rows behind the last: the matrix-core kernel reads whole groups of four)
+            const size_t K = (size_t)NU * mb.R;
+            mb.ksteps = (int)((K + 3) / 4);
+            mb.krows = 4 * ((size_t)mb.ksteps + (size_t)JX_MIX_KSPLIT_MAX * JX_OPG_RD + JX_OPG_RD);
+            jxt::mix_stage2_operator(V, mb.r, bx, mb.ns, S, B, NU, mb.krows, mb.ntile, mb.Op);
+        } else {
+            // both operators on every row / column of the quadrant first, then through the interpolation: C_sub = L^T C,
+            // Op_sub[(x'_s R + j)] = sum_x' L[x'][x'_s] Op[(x' R + j)]
+            std::vector<double> Cf, Of;
+            const int rows_f = (NU + 3) & ~3;
+            jxt::mix_stage1_operator(U, mb.r, by, mb.ns, S, B, NU, rows_f, mb.cld, Cf);
+            const int rows_s = (mb.cols.wld + 4 + 1) & ~1;
+            mb.Cm.assign((size_t)rows_s * mb.cld, 0.0);
+            for (int u = 0; u < NU; ++u)
+                for (int a = 0; a < NUs; ++a) {
+                    const double l = Lint[(size_t)u * NUs + a];
+                    if (l == 0.0) continue;
+                    for (int j = 0; j < mb.cld; ++j) mb.Cm[(size_t)a * mb.cld + j] += l * Cf[(size_t)u * mb.cld + j];
+                }
+            const size_t Kf = (size_t)NU * mb.R;
+            const size_t krows_f = 4 * ((Kf + 3) / 4);
+            jxt::mix_stage2_operator(V, mb.r, bx, mb.ns, S, B, NU, krows_f, mb.ntile, Of);
+            const size_t K = (size_t)NUs * mb.R;
+            mb.ksteps = (int)((K + 3) / 4);
+            mb.krows = 4 * ((size_t)mb.ksteps + (size_t)JX_MIX_KSPLIT_MAX * JX_OPG_RD + JX_OPG_RD);
+            const size_t rowlen = (size_t)16 * mb.ntile;
+            mb.Op.assign(mb.krows * rowlen, 0.0);
+            for (int x = 0; x < NU; ++x)
+                for (int a = 0; a < NUs; ++a) {
+                    const double l = Lint[(size_t)x * NUs + a];
+                    if (l == 0.0) continue;
+                    for (int j = 0; j < mb.R; ++j) {
+                        const double* src = &Of[((size_t)x * mb.R + j) * rowlen];
+                        double* dst = &mb.Op[((size_t)a * mb.R + j) * rowlen];
+                        for (size_t e = 0; e < rowlen; ++e) dst[e] += l * src[e];
+                    }
+                }
+        }
     } else {
         // ---- full form: every distinct sample (u <= x' when the quadrant is symmetric) is a row of the operator
         mb.r = 0; mb.ns = 0; mb.R = 0; mb.RT = 0;
@@ -581,6 +655,7 @@ static void plan_mix(jx_ctx* ctx, const std::vector<double>& beam, const std::ve
             }
         }
     }
+    if (form == 0 && !mb.sub.empty()) mb.NU = NUs; else mb.sub.clear();
     if (mb.ntile_u > 0 && mb.ntile_u < mb.ntile) {
         // the same operator for the outputs in use alone: tiles [0, ntile_u) of every row, compact
         const size_t rows = mb.Op.size() / ((size_t)16 * mb.ntile);
@@ -608,6 +683,7 @@ static int mix_setup(jx_ctx* ctx, const MixBuild& mb, long long tW) {
     int rc;
     m.form = mb.form; m.RT = mb.RT; m.nxt = mb.nxt; m.r = mb.r; m.ns = mb.ns; m.ksteps = mb.ksteps; m.tW = tW; m.tol = mb.tol;
     m.mfma = mb.mfma; m.r_tol = mb.r_tol;
+    m.NU_full = mb.NU_full; m.sub = mb.sub;
     int* qi; double* qd;
     const size_t esz = ctx->f32 ? sizeof(float) : sizeof(double);
     const size_t cft_rows = (size_t)N + 2 * JX_MIX_NS + 2;
@@ -679,11 +755,10 @@ static int mix_setup(jx_ctx* ctx, const MixBuild& mb, long long tW) {
 static void mix_kslices(const MixBack& m, bool used, int* ksplit_out, int* kper_out) {
     int ksplit = m.ksplit_force > 0 ? m.ksplit_force : (m.ksteps + 32) / 64;
     if (ksplit >= 8 && m.ksplit_force <= 0) ksplit = (ksplit + 4) / 8 * 8;
-    if (used) {
-        // fewer output groups per walker block: as many more K slices, so that the launch still fills the chip
-        if (m.ksplit_u_force > 0) ksplit = m.ksplit_u_force;
-        else ksplit = std::max(ksplit, (ksplit * m.og.nog + m.og_u.nog - 1) / m.og_u.nog / 2);
-    }
+    // few output groups per walker block (the outputs in use alone; small sides): more K slices, of about 16 k-steps each, so
+    // that the launch still fills the chip (measured: profiles/r04_subsample_scan.log)
+    if (used && m.ksplit_u_force > 0) ksplit = m.ksplit_u_force;
+    else if (used || m.ksplit_force <= 0) ksplit = std::max(ksplit, std::min((m.ksteps + 15) / 16, std::max(1, 32 / std::max(1, used ? m.og_u.nog : m.og.nog))));
     ksplit = std::max(1, std::min(ksplit, JX_MIX_KSPLIT_MAX));
     int kper = (m.ksteps + ksplit - 1) / ksplit;
     kper = (kper + JX_OPG_RD - 1) / JX_OPG_RD * JX_OPG_RD;
@@ -1059,7 +1134,14 @@ static int finalize_impl(jx_ctx* ctx) {
     if (const char* e = env_str("JOXSZ_TRUNC_BOUND")) { const double v = atof(e); if (v > 0.0) { ctx->trunc_bound = v; ctx->trunc_bound_ll = std::min(ctx->trunc_bound_ll, 10.0 * v); } }
     if (const char* e = env_str("JOXSZ_MIX_FORM")) { if (!strcmp(e, "lowrank")) ctx->form_force = 0; else if (!strcmp(e, "full")) ctx->form_force = 1; }
     if (const char* e = env_str("JOXSZ_MAP_PAIR")) ctx->map_pair = atoi(e) != 0;
-    if (const char* e = env_str("JOXSZ_MIX_USPLIT")) { const int v = atoi(e); if (v >= 1 && v <= 4) ctx->usplit = v; }
+    if (const char* e = env_str("JOXSZ_MIX_USPLIT")) { const int v = atoi(e); if (v >= 1 && v <= 4) { ctx->usplit = v; ctx->usplit_forced = true; } }
+    if (const char* e = env_str("JOXSZ_MIX_SUBSAMPLE")) {
+        // 0: every distinct sample; "u0,u1,npts": full resolution below u0 pixels from the axis, every second row up to u1, every fourth up to 2 u1, every eighth beyond
+        int a0 = 0, a1 = 0, a2 = 0;
+        const int got = sscanf(e, "%d,%d,%d", &a0, &a1, &a2);
+        if (got == 1 && a0 == 0) ctx->subsample = false;
+        else if (got == 3 && a0 >= 8 && a1 >= a0 && a2 >= 4 && a2 <= 16) { ctx->sub_u0 = a0; ctx->sub_u1 = a1; ctx->sub_npts = a2; }
+    }
     if (const char* e = env_str("JOXSZ_MIX_RANKCAP")) { const int v = atoi(e); if (v >= 0 && v <= 16) ctx->rank_cap = v; }
     if (const char* e = env_str("JOXSZ_MIX_MFMA")) ctx->mix_mfma = atoi(e) != 0;
     if (const char* e = env_str("JOXSZ_MIX_WPB")) { const int v = atoi(e); if (v >= 1 && v <= 16) { ctx->mix.wpb_force = v; ctx->mix.wpb = std::min(v, 4); } }
@@ -1724,22 +1806,38 @@ int jx_finalize(jx_ctx* ctx) {
         // inside the 1e-6 the log-posterior is held to.  (An estimate that could not be taken counts as too large.)
         return !(ctx->trunc_est[0] >= 0.0 && ctx->trunc_est[0] <= ctx->trunc_bound && ctx->trunc_est[2] >= 0.0 && ctx->trunc_est[2] <= ctx->trunc_bound_ll);
     };
-    // (an f32 context is measured and reported but never rebuilt: the rounding of its spline arrays is of the bounds' size)
-    while (!ctx->tol_pinned && !ctx->f32 && ctx->mix.form == 0 && (ctx->mix.tol > 2e-13 || ctx->mix.r < ctx->mix.r_tol) && too_large()) {
-        // first the cap on the rank goes (the same cut, every term above it kept), then the cut tightens
-        const bool capped = ctx->mix.r < ctx->mix.r_tol;
-        if (capped) { ctx->rank_cap = 0; ctx->trunc_uncapped += 1; }
-        const double tol = capped ? ctx->mix.tol : std::max(1e-13, ctx->mix.tol * 1e-1);
+    auto rebuild = [&](double tol) -> int {
         MixBuild mb;
         plan_mix(ctx, host_vec<double>(ctx, JX_T_BEAM_2D), host_vec<double>(ctx, JX_T_FILTERING), host_vec<double>(ctx, JX_T_R_PP), tol, ctx->form_force, ctx->mix.tW, mb);
-        if (!mb.ok) { ctx->err = "contracted route, tighter singular-value cut: " + mb.why; return JX_ERR_UNSUPPORTED; }
+        if (!mb.ok) { ctx->err = "contracted route, tables rebuilt by the guard: " + mb.why; return JX_ERR_UNSUPPORTED; }
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         const long long tW = ctx->mix.tW;
         mix_teardown(ctx, ctx->mix);
-        if ((rc = mix_setup(ctx, mb, tW))) return rc;
+        int rc2 = mix_setup(ctx, mb, tW);
+        if (rc2) return rc2;
         HIPCHK(ctx, hipDeviceSynchronize());
-        ctx->trunc_retried += 1;
-        if ((rc = measure_truncation(ctx, ctx->trunc_est, &ctx->trunc_points))) return rc;
+        return measure_truncation(ctx, ctx->trunc_est, &ctx->trunc_points);
+    };
+    // (an f32 context is measured and reported but never rebuilt: the rounding of its spline arrays is of the bounds' size)
+    const bool sub_at_start = !ctx->mix.sub.empty();
+    double tol_now = ctx->mix.tol;
+    while (!ctx->tol_pinned && !ctx->f32 && ctx->mix.form == 0 && (ctx->mix.tol > 2e-13 || ctx->mix.r < ctx->mix.r_tol || !ctx->mix.sub.empty()) && too_large()) {
+        // first the sub-grid of stage 1 goes (every distinct sample evaluated), then the cap on the rank (the same cut, every
+        // term above it kept), then the cut tightens
+        const bool subbed = !ctx->mix.sub.empty();
+        const bool capped = !subbed && ctx->mix.r < ctx->mix.r_tol;
+        if (subbed) { ctx->subsample = false; ctx->trunc_unsub += 1; }
+        else ctx->trunc_retried += 1;
+        if (capped) { ctx->rank_cap = 0; ctx->trunc_uncapped += 1; }
+        tol_now = (subbed || capped) ? ctx->mix.tol : std::max(1e-13, ctx->mix.tol * 1e-1);
+        if ((rc = rebuild(tol_now))) return rc;
+    }
+    if (sub_at_start && ctx->trunc_unsub > 0 && ctx->trunc_retried > 0) {
+        // the truncation was (also) at fault: the sub-grid once more on the tables the loop ended at, kept when the bounds hold
+        ctx->subsample = true;
+        if ((rc = rebuild(tol_now))) return rc;
+        if (ctx->mix.form == 0 && !ctx->mix.sub.empty() && !too_large()) ctx->trunc_unsub = 0;
+        else { ctx->subsample = false; if ((rc = rebuild(tol_now))) return rc; }
     }
     return JX_OK;
 }
@@ -2106,6 +2204,16 @@ int jx_debug_workspace(jx_ctx* ctx, int which, void** dev, int32_t geom[4]) {
         case 5: *dev = const_cast<double*>(m.og.Op); geom[0] = 4 * m.ksteps; geom[1] = 16; geom[2] = m.og.ntile; geom[3] = 8; break;
         default: ctx->err = "unknown work buffer"; return JX_ERR_INVALID;
     }
+    return JX_OK;
+}
+
+int jx_get_sampling(jx_ctx* ctx, int32_t out[8], int32_t* rows, int nrows_cap) {
+    if (!ctx || !ctx->finalized || !out) return JX_ERR_STATE;
+    const MixBack& m = ctx->mix;
+    const bool on = ctx->conv_mode == 2 && m.form == 0 && !m.sub.empty();
+    out[0] = on ? m.NU_full : (ctx->conv_mode == 2 ? ctx->qn : 0); out[1] = on ? (int)m.sub.size() : out[0];
+    out[2] = ctx->sub_u0; out[3] = ctx->sub_u1; out[4] = ctx->sub_npts; out[5] = on ? 1 : 0; out[6] = ctx->trunc_unsub; out[7] = 0;
+    if (rows) for (int i = 0; i < nrows_cap && i < out[1]; ++i) rows[i] = on ? m.sub[i] : i;
     return JX_OK;
 }
 

@@ -663,6 +663,48 @@ inline bool mix_column_tables(const std::vector<double>& Qtab /*[qn][qn]: (|iy-c
     return true;
 }
 
+// ---------------------------------------------------------------------------------------
+// Rows (= columns) of the quadrant that stage 1 evaluates.  Away from the cluster core the Compton-y map varies on the scale
+// of the radius, far above the pixel: the quadrant is recoverable from a subset of its rows and columns by local polynomial
+// interpolation, Q ~ L Q_sub L^T, and the contraction needs only the transformed operators C_sub = L^T C (stage 1) and
+// G_sub = G (L x I) (stage 2).  Kept: every index below u0, every second up to u1, every fourth up to 2 u1, every eighth beyond, and the last.
+// ---------------------------------------------------------------------------------------
+inline void mix_row_subset(int NU, int u0, int u1, std::vector<int>& sub) {
+    sub.clear();
+    u0 = std::min(u0, NU); u1 = std::max(u0, std::min(u1, NU));
+    const int u2 = 2 * u1;                                                          // every eighth beyond twice u1
+    for (int u = 0; u < u0; ++u) sub.push_back(u);
+    for (int u = u0; u < u1; u += 2) sub.push_back(u);
+    for (int u = std::max(u1, sub.empty() ? 0 : sub.back() + 1); u < std::min(u2, NU); u += 4) sub.push_back(u);
+    for (int u = std::max(u2, sub.empty() ? 0 : sub.back() + 1); u < NU; u += 8) sub.push_back(u);
+    if (sub.empty() || sub.back() != NU - 1) sub.push_back(NU - 1);
+}
+
+// L [NU][ns], row-major: the value at index u from the npts kept indices nearest to it (Lagrange form; the kept set is mirrored
+// about 0 -- the quadrant is even in u -- so that stencils near the axis stay centred).  Kept indices get a unit row.
+inline void mix_interp_matrix(int NU, const std::vector<int>& sub, int npts, std::vector<double>& L) {
+    const int ns = (int)sub.size();
+    npts = std::max(2, std::min(npts, ns));
+    std::vector<long double> ext;
+    std::vector<int> emap;
+    for (int i = std::min(npts, ns - 1); i >= 1; --i) { ext.push_back(-(long double)sub[i]); emap.push_back(i); }
+    for (int i = 0; i < ns; ++i) { ext.push_back((long double)sub[i]); emap.push_back(i); }
+    const int ne = (int)ext.size();
+    L.assign((size_t)NU * ns, 0.0);
+    for (int u = 0; u < NU; ++u) {
+        int j = 0;
+        while (j < ne && ext[j] < (long double)u) ++j;                              // first node >= u
+        if (j < ne && ext[j] == (long double)u) { L[(size_t)u * ns + emap[j]] = 1.0; continue; }
+        int lo = std::max(0, std::min(ne - npts, j - npts / 2));
+        for (int a = 0; a < npts; ++a) {
+            long double w = 1.0L;
+            for (int b = 0; b < npts; ++b)
+                if (b != a) w *= ((long double)u - ext[lo + b]) / (ext[lo + a] - ext[lo + b]);
+            L[(size_t)u * ns + emap[lo + a]] += (double)w;
+        }
+    }
+}
+
 // Separable terms of the beam image, step^2 beam[a][b] ~ sum_s by[s][a] bx[s][b] (terms above tol of the largest).
 inline int beam_separable_terms(const std::vector<double>& beam, int B, double scale, double tol, std::vector<double>& by,
                                 std::vector<double>& bx, std::vector<double>* sigma = nullptr) {

@@ -19,7 +19,7 @@ EXPORTS = (
     'jx_set_par_vals', 'jx_dev_alloc', 'jx_dev_free', 'jx_memcpy_h2d', 'jx_memcpy_d2h',
     'jx_timing_reset', 'jx_timing_enable', 'jx_timing_get', 'jx_get_info', 'jx_get_conv_mode', 'jx_get_conv_layout', 'jx_debug_workspace', 'jx_device_count',
     'jx_device_name', 'jx_strerror', 'jx_last_error', 'jx_destroy',
-    'jx_get_truncation', 'jx_get_output_pruning', 'jx_comm_unique_id', 'jx_comm_init_rank', 'jx_allgather_logp', 'jx_comm_allreduce_max', 'jx_comm_destroy',
+    'jx_get_truncation', 'jx_get_output_pruning', 'jx_get_sampling', 'jx_comm_unique_id', 'jx_comm_init_rank', 'jx_allgather_logp', 'jx_comm_allreduce_max', 'jx_comm_destroy',
     'jx_comm_count', 'jx_comm_set_overlap', 'jx_comm_gather_time', 'jx_map_kernel_time', 'jx_copy_bandwidth', 'jx_stream_bandwidth',
 )
 
@@ -96,6 +96,7 @@ def load_library(path=None):
     lib.jx_get_conv_layout.argtypes = [vp, ctypes.POINTER(ctypes.c_int32)]
     lib.jx_get_truncation.argtypes = [vp, dp]
     lib.jx_get_output_pruning.argtypes = [vp, ctypes.POINTER(ctypes.c_int32)]
+    lib.jx_get_sampling.argtypes = [vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), ci]
     lib.jx_debug_workspace.argtypes = [vp, ci, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int32)]
     lib.jx_comm_unique_id.argtypes = [vp]
     lib.jx_comm_init_rank.argtypes = [vp, vp, ci, ci]
@@ -200,6 +201,12 @@ class HipContext:
         self._chk(self.lib.jx_get_output_pruning(self._h, pr), 'jx_get_output_pruning')
         self.output_pruning = dict(nrow=int(pr[0]), outputs_read_by_the_tail=int(pr[1]), outputs_computed=int(pr[2]), tiles_per_block=int(pr[3]),
                                    k_slices=int(pr[4]), active=bool(pr[5]))
+        sm = (ctypes.c_int32 * 8)()
+        rows = (ctypes.c_int32 * 4096)()
+        self._chk(self.lib.jx_get_sampling(self._h, sm, rows, 4096), 'jx_get_sampling')
+        self.sampling = dict(rows_of_the_quadrant=int(sm[0]), rows_evaluated=int(sm[1]), full_below=int(sm[2]), every_second_up_to=int(sm[3]),
+                             interpolation_points=int(sm[4]), active=bool(sm[5]), removed_by_the_guard=int(sm[6]),
+                             rows=np.array(rows[:min(int(sm[1]), 4096)], dtype=np.int64))
         self.truncation = self._truncation()
         if self.truncation['warning'] and not os.environ.get('JOXSZ_QUIET'):
             import warnings
@@ -248,6 +255,9 @@ class HipContext:
         elif d['cap_removed']:
             msgs.append('the truncation guard took the 16-term cap away on this beam / transfer function: %d terms kept '
                         '(SZ stages about %.2fx)' % (d['rank'], rel))
+        if self.sampling['removed_by_the_guard']:
+            msgs.append('the truncation guard took the sub-grid of stage 1 away on these inputs: every distinct map sample is evaluated '
+                        '(%d rows instead of ~%d: SZ stages about 2x)' % (self.sampling['rows_of_the_quadrant'], self.sampling['rows_of_the_quadrant'] // 2))
         near = max(d['est_rel_row_err'] / d['bound'], d['est_rel_sz_like_err_box'] / d['bound_sz_like'])
         if not msgs and near > 0.5 and self.dtype == 'f64':
             msgs.append('the truncation of the low-rank form sits at %.0f %% of its bound (SZ log-likelihood over the prior box %.1e of %.0e): '

@@ -360,7 +360,7 @@ def test_fp32_variant_tolerance_sweep(S, N, W):
     assert seen['f32c'][1] > seen['f32'][1]                                 # fp32 sums cost more than fp32 inputs
 
 
-def test_fp32_variant_exists_on_the_contracted_route_only():
+def test_fp32_variant_exists_on_the_contracted_route_only(monkeypatch):
     """dtype f32 on the rocFFT sequence must be an error, never a silent fp64 evaluation; on the contracted route it exists at
     every side (odd and small ones included, both forms) and differs from fp64 by fp32 rounding only."""
     from joxsz_amd.hip_backend import JoxszHipError
@@ -368,8 +368,10 @@ def test_fp32_variant_exists_on_the_contracted_route_only():
     pb = datasets.synthetic_problem(S=512, N=500, seed=1)
     with pytest.raises(JoxszHipError, match='unsupported'):
         _post(pb, dtype='f32', conv='rocfft')
-    with pytest.raises(JoxszHipError, match='low-rank form'):               # fp32 arithmetic: low-rank form only (171^2 takes the full form)
+    monkeypatch.setenv('JOXSZ_MIX_FORM', 'full')
+    with pytest.raises(JoxszHipError, match='low-rank form'):               # fp32 arithmetic: low-rank form only
         _post(datasets.synthetic_problem(S=171, N=313, seed=1), dtype='f32c')
+    monkeypatch.delenv('JOXSZ_MIX_FORM')
     for S, N in ((513, 500), (96, 120), (171, 313)):
         pb = datasets.synthetic_problem(S=S, N=N, seed=1)
         th = datasets.walker_ball(pb, 12, spread=0.02, seed=1)
@@ -471,6 +473,86 @@ def test_the_product_computes_the_outputs_the_data_radii_spline_reads(S, N, form
     np.testing.assert_allclose(chi_a[fin], chi_b[fin], rtol=1e-11)
     st = orc.sz_stages(pb, orc.pars_dict(pb, th[0]))
     assert np.abs(row[0] - st['map_row']).max() / np.abs(st['map_row']).max() < 1e-9
+
+
+@pytest.mark.parametrize('S,N', [(512, 500), (513, 500), (1024, 1000), (300, 260)])
+def test_stage_one_evaluates_a_sub_grid_of_the_quadrant(S, N, monkeypatch):
+    """Away from the core the Compton-y map varies on the scale of the radius, not of the pixel: stage 1 of the low-rank form
+    evaluates a tensor sub-grid of the quadrant's rows and columns (jx_get_sampling: every row below 40 pixels from the axis,
+    every second up to 160, every fourth up to 320, every eighth beyond) and the interpolation to the others sits in both operators.  Against the
+    same context with every distinct sample evaluated (JOXSZ_MIX_SUBSAMPLE=0): the extracted row to 1e-10 of its maximum,
+    the log-posterior to 1e-10 -- two orders inside what the truncation of the transfer-function weights costs already -- and
+    both against the oracle."""
+    from joxsz_amd import datasets
+    pb = _problem(S, N, seed=S + 7)
+    th = datasets.walker_ball(pb, 80, spread=0.04, seed=S + 7)
+    monkeypatch.setenv('JOXSZ_MIX_FORM', 'lowrank')
+    post = _post(pb)
+    smp = post.ctx.sampling
+    NU = S // 2 + 1
+    assert smp['active'] and smp['rows_of_the_quadrant'] == NU and smp['removed_by_the_guard'] == 0
+    rows_kept = smp['rows']
+    assert len(rows_kept) == smp['rows_evaluated'] < 0.75 * NU and rows_kept[0] == 0 and rows_kept[-1] == NU - 1
+    assert np.array_equal(rows_kept[:smp['full_below']], np.arange(smp['full_below'])) and np.all(np.diff(rows_kept) >= 1) and np.diff(rows_kept).max() <= 8
+    a, row_a, chi_a = post.log_prob(th), post.stage(th[:4], 'map_row'), post.stage(th, 'chisq')
+    tr_a = post.ctx.truncation
+    post.close()
+    monkeypatch.setenv('JOXSZ_MIX_SUBSAMPLE', '0')
+    ref = _post(pb)
+    assert not ref.ctx.sampling['active'] and ref.ctx.sampling['rows_evaluated'] == NU
+    b, row_b, chi_b = ref.log_prob(th), ref.stage(th[:4], 'map_row'), ref.stage(th, 'chisq')
+    tr_b = ref.ctx.truncation
+    ref.close()
+    fin = np.isfinite(b)
+    assert fin.sum() >= 50 and np.array_equal(np.isfinite(a), fin)
+    np.testing.assert_allclose(a[fin], b[fin], rtol=1e-10)
+    np.testing.assert_allclose(chi_a[fin], chi_b[fin], rtol=1e-8, atol=1e-8)
+    assert np.abs(row_a - row_b).max() / np.abs(row_b).max() < 1e-10
+    # the guard's own measurement (against the rocFFT facility) moves by less than a fifth of its bounds
+    assert abs(tr_a['est_rel_row_err'] - tr_b['est_rel_row_err']) < 0.2 * tr_a['bound']
+    assert abs(tr_a['est_rel_sz_like_err_box'] - tr_b['est_rel_sz_like_err_box']) < 0.2 * tr_a['bound_sz_like']
+    want = orc.log_posterior_batch(pb, th[:6])
+    np.testing.assert_allclose(a[:6][np.isfinite(want)], want[np.isfinite(want)], rtol=1e-6)
+    st = orc.sz_stages(pb, orc.pars_dict(pb, th[0]))
+    assert np.abs(row_a[0] - st['map_row']).max() / np.abs(st['map_row']).max() < 1e-7
+
+
+def test_sub_grid_is_not_taken_beyond_the_radial_grid_and_the_guard_removes_a_coarse_one(monkeypatch):
+    """(a) A quadrant that reaches beyond the last radius of the grid holds fill values (joxsz_funcs.py:455): no smoothness to
+    interpolate on, every distinct sample is evaluated.  (b) A sub-grid far too coarse for the profile (JOXSZ_MIX_SUBSAMPLE=
+    8,8,4: every fourth row from 8 pixels on, 4-point) is measured by the guard of jx_finalize like the truncation, taken away,
+    and HipContext says so once; results then equal those of the context that never had one."""
+    import warnings
+    from joxsz_amd import datasets
+    from joxsz_amd.hip_backend import JoxszTruncationWarning
+    monkeypatch.setenv('JOXSZ_MIX_FORM', 'lowrank')
+    pb = _problem(512, 300, seed=9)                                   # corner of the quadrant at 362 pixels, grid ends at 300
+    post = _post(pb)
+    assert not post.ctx.sampling['active'] and post.ctx.sampling['rows_evaluated'] == 257
+    th = datasets.walker_ball(pb, 6, spread=0.03, seed=9)
+    got = post.log_prob(th)
+    post.close()
+    want = orc.log_posterior_batch(pb, th)
+    fin = np.isfinite(want)
+    assert fin.sum() >= 3
+    np.testing.assert_allclose(got[fin], want[fin], rtol=1e-6)
+    pb = _problem(512, 500, seed=9)
+    th = datasets.walker_ball(pb, 40, spread=0.03, seed=9)
+    monkeypatch.setenv('JOXSZ_MIX_SUBSAMPLE', '8,8,4')
+    with pytest.warns(JoxszTruncationWarning, match='sub-grid') as rec:
+        post = _post(pb)
+    smp, tr = post.ctx.sampling, post.ctx.truncation
+    assert len(rec) == 1 and not smp['active'] and smp['removed_by_the_guard'] == 1 and smp['rows_evaluated'] == 257
+    assert tr['retried'] == 0 and tr['cap_removed'] == 0 and tr['rank'] == 16 and 0 <= tr['est_rel_row_err'] <= tr['bound']
+    a = post.log_prob(th)
+    post.close()
+    monkeypatch.setenv('JOXSZ_MIX_SUBSAMPLE', '0')
+    with warnings.catch_warnings():
+        warnings.simplefilter('error', JoxszTruncationWarning)
+        ref = _post(pb)
+    b = ref.log_prob(th)
+    ref.close()
+    np.testing.assert_array_equal(a, b)
 
 
 def test_truncation_guard_speaks_up_when_it_changes_the_tables():

@@ -310,6 +310,7 @@ def test_timed_kernels_against_numpy_on_the_oracle_map(S, N, W, monkeypatch):
     ctx = post.ctx
     lay = ctx.conv_layout
     prune = ctx.output_pruning
+    ctx_sampling = ctx.sampling
     assert lay['form'] == 'lowrank'
     rows = post.stage(th, 'map_row')                           # (runs the profile taps' Abel kernel for the spline arrays)
     D_tap = ctx.workspace('stage1')[:, :, :W].copy()
@@ -321,13 +322,18 @@ def test_timed_kernels_against_numpy_on_the_oracle_map(S, N, W, monkeypatch):
     Op = ctx.workspace('product_op')
     y_tap = post.stage(th[:2], 'y')
     post.close()
-    NU, R, nrow = lay['NU'], lay['R'], S - S // 2
+    # (stage 1 evaluates a sub-grid of the quadrant's rows and columns -- jx_get_sampling -- the interpolation to the others is
+    # folded into both operators: the numpy statement below is the same with Q restricted to that sub-grid)
+    smp = ctx_sampling
+    sub = smp['rows']
+    NU, R, nrow = len(sub), lay['R'], S - S // 2
+    assert smp['rows_of_the_quadrant'] == lay['NU'] and D.shape[0] == NU and (NU < lay['NU']) == smp['active']
     Cm = Cm[:NU, :R]
     G = np.zeros((nrow, NU * R))
     for x in range(nrow):
         G[x] = Op[:NU * R, x & 15, x >> 4]
     c = S // 2
-    iy = np.array([c + b if c + b < S else c - b for b in range(NU)])
+    iy = np.array([c + b if c + b < S else c - b for b in sub])
     for w in (0, W - 1):
         st = orc.sz_stages(pb, orc.pars_dict(pb, th[w]))
         Q = st['y_2d'][np.ix_(iy, iy)]
