@@ -521,7 +521,7 @@ static void plan_mix(jx_ctx* ctx, const std::vector<double>& beam, const std::ve
     std::vector<double> Lint;                                    // [NU][ns]
     std::vector<double> Qsub;
     int NUs = NU;
-    if (ctx->subsample && form_force != 1) {
+    if (ctx->subsample) {
         bool inside = true;
         for (double v : ctx->h_Qtab) if (!(v <= r.back())) { inside = false; break; }
         jxt::mix_row_subset(NU, ctx->sub_u0, ctx->sub_u1, mb.sub);
@@ -574,12 +574,12 @@ static void plan_mix(jx_ctx* ctx, const std::vector<double>& beam, const std::ve
     }
     // cost of each form in fused multiply-adds per walker; stage 1 runs on the vector units at about 0.6 of the rate the
     // matrix cores reach in the product kernels (measured: 256^2 with 32 terms 0.141 ms low-rank against 0.126 ms full; 257^2 0.155 against 0.132)
-    const double nsamp = (double)NU * NU, nsamp_lr = (double)NUs * NUs;         // (the low-rank form evaluates the sub-grid)
+    const double nsamp_lr = (double)NUs * NUs;                                   // (samples evaluated: the sub-grid when there is one)
     // (stage 1 on the matrix cores: 16 multiply-adds per sample there, the 4 of the evaluation beside them on the vector units)
     const double nout = mb.ntile_u > 0 ? 16.0 * mb.ntile_u : (double)nrow;      // outputs the timed product computes
     const int nog_t = mb.ntile_u > 0 ? mb.nog_u : mb.nog;
     mb.cost_lowrank = (lowrank_ok && mb.RT) ? (mb.mfma ? nsamp_lr * 18.0 : 1.6 * nsamp_lr * (4.0 + mb.RT)) + nout * NUs * mb.R : 1e300;
-    mb.cost_full = nout * nsamp * 0.5 + nsamp * 6.0 * nog_t;
+    mb.cost_full = nout * nsamp_lr * 0.5 + nsamp_lr * 6.0 * nog_t;                // (the full form evaluates the same sub-grid)
     int form = (mb.cost_lowrank <= mb.cost_full) ? 0 : 1;
     if (form_force == 0) { if (!lowrank_ok || !mb.RT) { mb.why = "low-rank form: " + why_lr; return; } form = 0; }
     if (form_force == 1) form = 1;
@@ -631,10 +631,39 @@ static void plan_mix(jx_ctx* ctx, const std::vector<double>& beam, const std::ve
         mb.r = 0; mb.ns = 0; mb.R = 0; mb.RT = 0;
         std::vector<double> Om;                                  // [nrow][NU][NU]
         jxt::mix_full_operator(beam, B, c.step * c.step, A, S, NU, Om);
-        const bool tri = jxt::quadrant_is_symmetric(ctx->h_Qtab, ctx->qn, NU);
+        int NQ = NU;                                             // rows = columns of the samples evaluated
+        if (!mb.sub.empty()) {
+            // the sub-grid: Om_sub[x][a][b] = sum_{u, x'} L[u][a] L[x'][b] Om[x][u][x'] (L: at most sub_npts entries per row)
+            std::vector<std::vector<std::pair<int, double>>> Ls(NU);
+            for (int u = 0; u < NU; ++u)
+                for (int a = 0; a < NUs; ++a) { const double l = Lint[(size_t)u * NUs + a]; if (l != 0.0) Ls[u].emplace_back(a, l); }
+            std::vector<double> Os((size_t)nrow * NUs * NUs, 0.0), T((size_t)NU * NUs);
+            for (int x = 0; x < nrow; ++x) {
+                std::fill(T.begin(), T.end(), 0.0);
+                const double* ox = &Om[(size_t)x * NU * NU];
+                for (int u = 0; u < NU; ++u)
+                    for (int xq = 0; xq < NU; ++xq) {
+                        const double v = ox[(size_t)u * NU + xq];
+                        if (v == 0.0) continue;
+                        for (const auto& e : Ls[xq]) T[(size_t)u * NUs + e.first] += e.second * v;
+                    }
+                double* os = &Os[(size_t)x * NUs * NUs];
+                for (int u = 0; u < NU; ++u)
+                    for (const auto& e : Ls[u]) {
+                        const double* tu = &T[(size_t)u * NUs];
+                        double* oa = &os[(size_t)e.first * NUs];
+                        for (int b2 = 0; b2 < NUs; ++b2) oa[b2] += e.second * tu[b2];
+                    }
+            }
+            Om.swap(Os);
+            NQ = NUs;
+        }
+        const std::vector<double>& Qt = mb.sub.empty() ? ctx->h_Qtab : Qsub;
+        const int qld = mb.sub.empty() ? ctx->qn : NUs;
+        const bool tri = jxt::quadrant_is_symmetric(Qt, qld, NQ);
         std::vector<int> ku, kx;
-        for (int u = 0; u < NU; ++u)
-            for (int x = tri ? u : 0; x < NU; ++x) { ku.push_back(u); kx.push_back(x); }
+        for (int u = 0; u < NQ; ++u)
+            for (int x = tri ? u : 0; x < NQ; ++x) { ku.push_back(u); kx.push_back(x); }
         const size_t K = ku.size();
         mb.ksteps = (int)((K + 3) / 4);
         mb.krows = 4 * ((size_t)mb.ksteps + (size_t)JX_MIX_KSPLIT_MAX * JX_OPG_RD + JX_OPG_RD + JX_OPG_ECH);
@@ -644,18 +673,18 @@ static void plan_mix(jx_ctx* ctx, const std::vector<double>& beam, const std::ve
         for (size_t k = 0; k < K; ++k) {
             const int u = ku[k], xq = kx[k];
             int k16; double w[4];
-            jxt::spline_sample_weights(r, ctx->h_Qtab[(size_t)u * ctx->qn + xq], &k16, w);
+            jxt::spline_sample_weights(r, Qt[(size_t)u * qld + xq], &k16, w);
             JxSamp& e = mb.ent[k];
             e.off = (long long)(k16 / 16) * tW;
             e.a = w[0]; e.b = w[1]; e.c = w[2]; e.d = w[3];
             for (int x = 0; x < nrow; ++x) {
-                double v = Om[((size_t)x * NU + u) * NU + xq];
-                if (tri && xq != u) v += Om[((size_t)x * NU + xq) * NU + u];
+                double v = Om[((size_t)x * NQ + u) * NQ + xq];
+                if (tri && xq != u) v += Om[((size_t)x * NQ + xq) * NQ + u];
                 mb.Op[(k * 16 + (x & 15)) * mb.ntile + (x >> 4)] = v;
             }
         }
     }
-    if (form == 0 && !mb.sub.empty()) mb.NU = NUs; else mb.sub.clear();
+    if (form == 0 && !mb.sub.empty()) mb.NU = NUs;               // (stage 1 walks the sub-grid's columns; the full form keeps NU and lists its samples)
     if (mb.ntile_u > 0 && mb.ntile_u < mb.ntile) {
         // the same operator for the outputs in use alone: tiles [0, ntile_u) of every row, compact
         const size_t rows = mb.Op.size() / ((size_t)16 * mb.ntile);
@@ -1743,7 +1772,7 @@ static void probe_vectors(jx_ctx* ctx, std::vector<double>& th, int* npts) {
 // all probe points (-1 each where nothing finite came back)
 static int measure_truncation(jx_ctx* ctx, double est[3], int* used) {
     est[0] = est[1] = est[2] = -1.0; *used = 0;
-    if (ctx->conv_mode != 2 || ctx->mix.form != 0) return JX_OK;            // nothing truncated
+    if (ctx->conv_mode != 2 || (ctx->mix.form != 0 && ctx->mix.sub.empty())) return JX_OK;   // nothing truncated, every distinct sample evaluated
     if (!ctx->map_ok) return JX_OK;                                         // nothing to measure against (and every term above rounding is kept)
     const jx_config& c = ctx->cfg;
     int rc, npts = 0;
@@ -1794,7 +1823,7 @@ int jx_finalize(jx_ctx* ctx) {
     int rc = finalize_impl(ctx);
     if (rc) return rc;
     if (const char* e = env_str("JOXSZ_TRUNC_PROBE")) { if (atoi(e) == 0) return JX_OK; }
-    if (ctx->conv_mode != 2 || ctx->mix.form != 0) return JX_OK;
+    if (ctx->conv_mode != 2 || (ctx->mix.form != 0 && ctx->mix.sub.empty())) return JX_OK;
     // The low-rank form drops the small singular values of the transfer-function weights.  What that costs is measured on the
     // caller's own beam / transfer function / prior box (measure_truncation); beyond the bounds the tables are rebuilt with
     // a cut ten times tighter -- in place: stream, communicator and every other piece of the context stay -- until the
@@ -1821,7 +1850,7 @@ int jx_finalize(jx_ctx* ctx) {
     // (an f32 context is measured and reported but never rebuilt: the rounding of its spline arrays is of the bounds' size)
     const bool sub_at_start = !ctx->mix.sub.empty();
     double tol_now = ctx->mix.tol;
-    while (!ctx->tol_pinned && !ctx->f32 && ctx->mix.form == 0 && (ctx->mix.tol > 2e-13 || ctx->mix.r < ctx->mix.r_tol || !ctx->mix.sub.empty()) && too_large()) {
+    while (!ctx->f32 && (!ctx->mix.sub.empty() || (!ctx->tol_pinned && ctx->mix.form == 0 && (ctx->mix.tol > 2e-13 || ctx->mix.r < ctx->mix.r_tol))) && too_large()) {
         // first the sub-grid of stage 1 goes (every distinct sample evaluated), then the cap on the rank (the same cut, every
         // term above it kept), then the cut tightens
         const bool subbed = !ctx->mix.sub.empty();
@@ -1832,7 +1861,13 @@ int jx_finalize(jx_ctx* ctx) {
         tol_now = (subbed || capped) ? ctx->mix.tol : std::max(1e-13, ctx->mix.tol * 1e-1);
         if ((rc = rebuild(tol_now))) return rc;
     }
-    if (sub_at_start && ctx->trunc_unsub > 0 && ctx->trunc_retried > 0) {
+    if (sub_at_start && ctx->trunc_unsub > 0 && ctx->trunc_retried == 0 && too_large()) {
+        // every distinct sample evaluated and still outside (a cut set by hand, which is measured but never tightened): the
+        // sub-grid was not what the bounds object to
+        ctx->subsample = true;
+        if ((rc = rebuild(tol_now))) return rc;
+        ctx->trunc_unsub = 0;
+    } else if (sub_at_start && ctx->trunc_unsub > 0 && ctx->trunc_retried > 0) {
         // the truncation was (also) at fault: the sub-grid once more on the tables the loop ended at, kept when the bounds hold
         ctx->subsample = true;
         if ((rc = rebuild(tol_now))) return rc;
@@ -2210,7 +2245,7 @@ int jx_debug_workspace(jx_ctx* ctx, int which, void** dev, int32_t geom[4]) {
 int jx_get_sampling(jx_ctx* ctx, int32_t out[8], int32_t* rows, int nrows_cap) {
     if (!ctx || !ctx->finalized || !out) return JX_ERR_STATE;
     const MixBack& m = ctx->mix;
-    const bool on = ctx->conv_mode == 2 && m.form == 0 && !m.sub.empty();
+    const bool on = ctx->conv_mode == 2 && !m.sub.empty();
     out[0] = on ? m.NU_full : (ctx->conv_mode == 2 ? ctx->qn : 0); out[1] = on ? (int)m.sub.size() : out[0];
     out[2] = ctx->sub_u0; out[3] = ctx->sub_u1; out[4] = ctx->sub_npts; out[5] = on ? 1 : 0; out[6] = ctx->trunc_unsub; out[7] = 0;
     if (rows) for (int i = 0; i < nrows_cap && i < out[1]; ++i) rows[i] = on ? m.sub[i] : i;

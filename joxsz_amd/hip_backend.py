@@ -242,27 +242,26 @@ class HipContext:
         the step scales roughly with (4 + 2 rank) / (4 + 2 * 16) of the 16-term tables a smooth transfer function gets."""
         if self.conv != 'custom':
             return None
-        if d['retried'] > 0 and d['rank'] <= 0:
-            return ('the truncation guard found the low-rank tables of this beam / transfer function outside its bounds and rebuilt them until the '
-                    'exact full form was the cheaper one: nothing is truncated now; the SZ stages cost about 1.6x those of the 16-term tables')
-        if d['rank'] <= 0 or d['est_rel_row_err'] < 0:
-            return None
-        rel = (4.0 + 2.0 * d['rank']) / (4.0 + 2.0 * 16)
         msgs = []
-        if d['retried'] > d['cap_removed']:
-            msgs.append('the truncation guard tightened the singular-value cut to %.0e on this beam / transfer function: %d terms kept, '
-                        'the SZ stages cost about %.1fx those of the 16-term tables' % (d['tol'], d['rank'], rel))
-        elif d['cap_removed']:
-            msgs.append('the truncation guard took the 16-term cap away on this beam / transfer function: %d terms kept '
-                        '(SZ stages about %.2fx)' % (d['rank'], rel))
         if self.sampling['removed_by_the_guard']:
-            msgs.append('the truncation guard took the sub-grid of stage 1 away on these inputs: every distinct map sample is evaluated '
-                        '(%d rows instead of ~%d: SZ stages about 2x)' % (self.sampling['rows_of_the_quadrant'], self.sampling['rows_of_the_quadrant'] // 2))
-        near = max(d['est_rel_row_err'] / d['bound'], d['est_rel_sz_like_err_box'] / d['bound_sz_like'])
-        if not msgs and near > 0.5 and self.dtype == 'f64':
-            msgs.append('the truncation of the low-rank form sits at %.0f %% of its bound (SZ log-likelihood over the prior box %.1e of %.0e): '
-                        'slightly different inputs rebuild the tables with more terms (about -35 %% throughput at 31 terms)'
-                        % (100 * near, d['est_rel_sz_like_err_box'], d['bound_sz_like']))
+            msgs.append('the truncation guard took the sub-grid of map samples away on these inputs: every distinct sample is evaluated '
+                        '(%d rows and columns instead of about %d: the SZ stages cost 2-4x)' % (self.sampling['rows_of_the_quadrant'], self.sampling['rows_of_the_quadrant'] // 2))
+        if d['retried'] > 0 and d['rank'] <= 0:
+            msgs.append('the truncation guard found the low-rank tables of this beam / transfer function outside its bounds and rebuilt them until the '
+                        'exact full form was the cheaper one: nothing is truncated now; the SZ stages cost about 1.6x those of the 16-term tables')
+        elif d['rank'] > 0 and d['est_rel_row_err'] >= 0:
+            rel = (4.0 + 2.0 * d['rank']) / (4.0 + 2.0 * 16)
+            if d['retried'] > d['cap_removed']:
+                msgs.append('the truncation guard tightened the singular-value cut to %.0e on this beam / transfer function: %d terms kept, '
+                            'the SZ stages cost about %.1fx those of the 16-term tables' % (d['tol'], d['rank'], rel))
+            elif d['cap_removed']:
+                msgs.append('the truncation guard took the 16-term cap away on this beam / transfer function: %d terms kept '
+                            '(SZ stages about %.2fx)' % (d['rank'], rel))
+            near = max(d['est_rel_row_err'] / d['bound'], d['est_rel_sz_like_err_box'] / d['bound_sz_like'])
+            if not msgs and near > 0.5 and self.dtype == 'f64':
+                msgs.append('the truncation of the low-rank form sits at %.0f %% of its bound (SZ log-likelihood over the prior box %.1e of %.0e): '
+                            'slightly different inputs rebuild the tables with more terms (about -35 %% throughput at 31 terms)'
+                            % (100 * near, d['est_rel_sz_like_err_box'], d['bound_sz_like']))
         return '; '.join(msgs) if msgs else None
 
     # -- plumbing --
