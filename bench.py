@@ -334,7 +334,7 @@ def main():
     ctx.h2d(th_ptr, theta)
     comm = None
     lp_ptrs, all_ptrs = [lp_ptr], [None]
-    overlap = multi and not os.environ.get('JOXSZ_BENCH_STRICT_GATHER')
+    overlap = multi and not os.environ.get('JOXSZ_BENCH_STRICT_GATHER')      # (JOXSZ_BENCH_OVERLAP_GATHER=1 pins the other mode; neither: the warm-up picks)
     if multi:
         # RCCL through the library's own C-ABI (jx_comm_*), no torch in this process.  The gather of step n runs on a second
         # stream of the context behind an event; step n+1 writes the OTHER of two output buffers, so its kernels overlap the
@@ -361,6 +361,27 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    gather_probe = None
+    if comm is not None and not os.environ.get('JOXSZ_BENCH_STRICT_GATHER') and not os.environ.get('JOXSZ_BENCH_OVERLAP_GATHER'):
+        # Which of the two gather modes this machine wants is not known in advance: the second stream hides the collective's
+        # latency (tens of microseconds over 8 ranks) but costs every kernel of the step a little (two active queues); in line it
+        # costs its own duration.  Still inside the warm-up: the same short run in both modes, the ranks agree on the faster one
+        # (one max-reduction each -- every rank takes the same branch), and the timed region below runs in that mode.
+        gather_probe = {}
+        nprobe = max(10, min(50, args.steps))
+        for mode in (True, False):
+            ctx.comm_set_overlap(mode)
+            for _ in range(3):
+                step()
+            fence()
+            t_probe = time.perf_counter()
+            for _ in range(nprobe):
+                step()
+            fence()
+            gather_probe['overlapped' if mode else 'strict'] = 1e3 * comm.max_over_ranks(time.perf_counter() - t_probe) / nprobe
+        overlap = gather_probe['overlapped'] < gather_probe['strict']
+        ctx.comm_set_overlap(overlap)
+        fence()
     # Timed region: HIP events around the time-dominant kernel only (stage 1 of the contracted route; jx_timing_enable(2)) --
     # its duration is what `roofline` prices.  Events behind every stage cost a few per cent of a step (markers between
     # dependent kernels), so the full stage breakdown comes from a second, identical pass of the same K steps right after.
@@ -567,6 +588,10 @@ def main():
                              'tf_fft_ms': 'jx_opgemm_kernel (stage 2: beam along x + circular transfer-function kernels + row extraction as one fp64 matrix-core product)' if lowrank
                                           else 'jx_opgemm_kernel (full form: map samples evaluated by the lanes that feed the fp64 matrix cores)',
                              'tail_ms': 'jx_tail_row_kernel (partial rows summed in fixed order, conversion, chi^2, total)'}
+        try:
+            ev_null_ms = ctx.event_bracket_time(64)
+        except Exception:
+            ev_null_ms = None
         value = W * world * args.steps / elapsed
         ms_step = 1e3 * elapsed / args.steps
         pj = pmc_file(S)
@@ -586,6 +611,11 @@ def main():
                         'traffic_source': (pj or {}).get('file'), 'traffic_measured_in_this_run': False,
                         'peak_measured': FP64_FMA_MEASURED_TFLOPS, 'frac_of_peak_measured': ach / FP64_FMA_MEASURED_TFLOPS,
                         'launch_ms': k_ms, 'launch_ms_source': 'HIP events around this kernel inside the timed region (jx_timing_enable(2))',
+                        'launch_ms_of_an_empty_kernel': ev_null_ms,
+                        'launch_ms_note': 'a pair of HIP events around one kernel of a dependent chain also spans the command processor\'s hand-over '
+                                          'in front of and behind it -- launch_ms_of_an_empty_kernel is what the same pair reads around a kernel that does nothing '
+                                          '(jx_event_bracket_time); rocprofv3\'s kernel trace (profiles/*_kernel_stats.csv) counts the kernel alone, so its average sits '
+                                          'between launch_ms - launch_ms_of_an_empty_kernel and launch_ms.  achieved and frac use launch_ms as measured (the lower figure)',
                         'flops_per_launch': fl, 'share_of_step': k_ms / max(1e-12, ms_step * walkers_per_launch / W),
                         'algorithmic_bytes_per_launch': walkers_per_launch * (16.0 * pb.N + 8.0 * NUe * lay['R']),
                         'samples_evaluated_per_walker': NUe * NUe, 'distinct_samples_per_walker': NU * NU,
@@ -617,6 +647,17 @@ def main():
         if pj and mixed:
             step_pmc_kernels = {n: pmc_traffic(pj, n, W) for n in step_names if pmc_kernel_entry(pj, n)}
             step_pmc = sum(step_pmc_kernels.values()) if step_pmc_kernels else None
+        # every kernel of the step with the duration the stage pass read for it: since the sub-grid of stage 1 no kernel
+        # dominates -- the per-walker kernel, stage 1 and the spline-array product are within 15 % of one another
+        step_kernels = None
+        if mixed and stage_kernels:
+            bounds = {'prep_ms': 'latency + fp64 exp/log chains of the grid pass on the vector units (73 % busy; DESIGN 6.3)',
+                      'abel_map_ms': 'fp64 matrix cores at one wave per SIMD: operand fetch of the k loop (DESIGN 6.3)',
+                      'beam_fft_ms': 'fp64 vector FMA issue (`roofline`)' if lowrank else None,
+                      'tf_fft_ms': 'fp64 matrix cores + operand fetch (`roofline_product`)' if lowrank else 'fp64 matrix cores fed by the lanes that evaluate the samples (`roofline`)',
+                      'tail_ms': 'L2 reads of the partial rows + latency'}
+            step_kernels = [{'kernel': stage_kernels[k].split(' ')[0], 'ms_hip_events_stage_pass': stage_ms[k], 'share_of_stage_sum': stage_ms[k] / max(1e-12, sum(stage_ms[q] for q in bounds)),
+                             'bound': bounds[k]} for k in ('prep_ms', 'abel_map_ms', 'beam_fft_ms', 'tf_fft_ms', 'tail_ms') if bounds[k]]
         if ns_route and 'ms_per_step' in ns_route:
             ns_route['speedup_of_default_route'] = ns_route['ms_per_step'] / ms_step
         out = {
@@ -632,7 +673,8 @@ def main():
                        'walkers_per_gpu': W, 'S': S, 'N': args.N, 'B': pb.B, 'chunk': ctx.chunk, 'route': ctx.route, 'conv': ctx.conv,
                        'conv_layout': ctx.conv_layout, 'output_pruning': ctx.output_pruning,
                        'sampling': {k: v for k, v in ctx.sampling.items() if k != 'rows'}, 'parallelism': 'walkers sharded x%d' % world, 'device': ctx.device_name,
-                       'gather': (('overlapped: second stream, two output buffers' if overlap else 'strict: on the compute stream') if comm is not None else None)},
+                       'gather': (('overlapped: second stream, two output buffers' if overlap else 'strict: on the compute stream') if comm is not None else None),
+                       'gather_probe_ms_per_step': gather_probe},
             'n_ranks_seen': (comm.n_ranks_seen if comm is not None else 1),
             'gather_ms_per_step': gather_ms,
             'roofline': roof,
@@ -646,6 +688,7 @@ def main():
                               'survey_8d_bytes_per_step': 2.0 * W * S * S * 8.0,
                               'note': 'the step is compute-bound (fp64 vector units, then fp64 matrix cores): its HBM traffic is the small '
                                       'per-walker arrays between the kernels'},
+            'step_kernels': step_kernels,
             'north_star_abel_map_kernel': full_map,
             'north_star_route': ns_route,
             'host_pointer': host_ptr,

@@ -303,6 +303,10 @@ int  jx_debug_workspace(jx_ctx* ctx, int which, void** dev, int32_t geom[4]);
  * around (profile -> Abel integral -> spline -> map; S^2 * 8 bytes per walker).  The evaluation path never stores the map;
  * this call exists for that measurement and allocates its own scratch image. */
 int  jx_map_kernel_time(jx_ctx* ctx, const double* theta_dev, int nwalkers, int repeats, double* ms_out);
+/* What a pair of HIP events around one kernel of a dependent chain reads when the kernel does nothing (a one-wave kernel that
+ * returns at once, another in front and behind): the part of a stage's HIP-event duration that is not the kernel -- rocprofv3's
+ * kernel trace does not count it.  Mean over `repeats` (<= 256) brackets, in ms. */
+int  jx_event_bracket_time(jx_ctx* ctx, int repeats, double* ms_out);
 /* Device-to-device copy bandwidth of this GPU in GB/s (bytes read + bytes written per second): `nbytes` copied `repeats` times
  * between two scratch buffers, HIP events on the context's stream.  The practical HBM roofline beside the nominal 8 TB/s. */
 int  jx_copy_bandwidth(jx_ctx* ctx, size_t nbytes, int repeats, double* gbps_out);

@@ -1871,7 +1871,7 @@ int jx_finalize(jx_ctx* ctx) {
         // the truncation was (also) at fault: the sub-grid once more on the tables the loop ended at, kept when the bounds hold
         ctx->subsample = true;
         if ((rc = rebuild(tol_now))) return rc;
-        if (ctx->mix.form == 0 && !ctx->mix.sub.empty() && !too_large()) ctx->trunc_unsub = 0;
+        if (!ctx->mix.sub.empty() && !too_large()) ctx->trunc_unsub = 0;             // (either form: the full form's figures are those of the sub-grid alone)
         else { ctx->subsample = false; if ((rc = rebuild(tol_now))) return rc; }
     }
     return JX_OK;
@@ -2310,6 +2310,35 @@ int jx_map_kernel_time(jx_ctx* ctx, const double* theta_dev, int nwalkers, int r
     HIPCHK(ctx, hipEventElapsedTime(&ms, e0, e1));
     HIPCHK(ctx, hipGetLastError());
     *ms_out = (double)ms / repeats;
+    return JX_OK;
+}
+
+// What a pair of HIP events around ONE kernel of a dependent chain reads when that kernel does nothing: a one-wave kernel that
+// returns at once, between two events, with another such kernel in front and behind (the situation of the stage events of
+// jx_timing_enable).  The figure (a few microseconds: the command processor's hand-over between dependent dispatches, which
+// rocprofv3's kernel trace does not count into a kernel's duration) is what the HIP-event duration of a short kernel carries on
+// top of the kernel itself; bench.py reports it beside `roofline.launch_ms`.
+__global__ void jx_null_kernel(int* p) { if (p && threadIdx.x == 1024) *p = 0; }
+
+int jx_event_bracket_time(jx_ctx* ctx, int repeats, double* ms_out) {
+    if (!ctx || repeats < 1 || repeats > 256 || !ms_out) return JX_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    Scratch sc;
+    std::vector<hipEvent_t> ev(2 * (size_t)repeats);
+    for (auto& e : ev) HIPCHK(ctx, sc.event(&e));
+    hipStream_t st = ctx->stream;
+    for (int i = 0; i < repeats; ++i) {
+        hipLaunchKernelGGL(jx_null_kernel, dim3(1), dim3(64), 0, st, (int*)nullptr);
+        HIPCHK(ctx, hipEventRecord(ev[2 * i], st));
+        hipLaunchKernelGGL(jx_null_kernel, dim3(1), dim3(64), 0, st, (int*)nullptr);
+        HIPCHK(ctx, hipEventRecord(ev[2 * i + 1], st));
+        hipLaunchKernelGGL(jx_null_kernel, dim3(1), dim3(64), 0, st, (int*)nullptr);
+    }
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    HIPCHK(ctx, hipGetLastError());
+    double sum = 0.0;
+    for (int i = 0; i < repeats; ++i) { float ms = 0.f; HIPCHK(ctx, hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1])); sum += ms; }
+    *ms_out = sum / repeats;
     return JX_OK;
 }
 

@@ -26,8 +26,9 @@ python scripts/step_gaps.py > gpurun_out/${TAG}_step_gaps.log 2>&1
 rm -rf gpurun_out/gaps
 # 5. fp64 FMA rate of the chip with uniform multipliers (the measured peak bench.py quotes)
 timeout -k 10 120 scripts/ubench/fma_sgpr > gpurun_out/${TAG}_fma_sgpr.log 2>&1
-# 6. the N > 1 plumbing rehearsed at N = 1 (RCCL communicator of one rank, gather, barrier, max over ranks): overlapped and strict
+# 6. the N > 1 plumbing rehearsed at N = 1 (RCCL communicator of one rank, gather, barrier, max over ranks): the mode the warm-up picks, then each mode pinned
 JOXSZ_BENCH_FORCE_DIST=1 python bench.py --no-cpu --no-full-map --no-f32 --no-other-configs > gpurun_out/${TAG}_bench_force_dist.json 2> gpurun_out/${TAG}_bench_force_dist.err
+JOXSZ_BENCH_FORCE_DIST=1 JOXSZ_BENCH_OVERLAP_GATHER=1 python bench.py --no-cpu --no-full-map --no-f32 --no-other-configs > gpurun_out/${TAG}_bench_force_dist_overlap.json 2> gpurun_out/${TAG}_bench_force_dist_overlap.err
 JOXSZ_BENCH_FORCE_DIST=1 JOXSZ_BENCH_STRICT_GATHER=1 python bench.py --no-cpu --no-full-map --no-f32 --no-other-configs > gpurun_out/${TAG}_bench_force_dist_strict.json 2> gpurun_out/${TAG}_bench_force_dist_strict.err
 # 7. the arithmetic variants, the other shapes, the sampler, the guard over a family of inputs
 python scripts/dtype_sweep.py 512 500 1024 > gpurun_out/${TAG}_dtype_sweep.log 2>&1

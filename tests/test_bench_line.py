@@ -86,10 +86,15 @@ def test_every_roofline_figure_of_the_line_follows_from_the_profiles():
 
 
 def test_the_rehearsed_n_gt_1_lines_carry_the_gather_time():
-    for name, mode in (('r04_bench_force_dist.json', 'overlapped'), ('r04_bench_force_dist_strict.json', 'strict')):
+    for name, mode in (('r04_bench_force_dist_overlap.json', 'overlapped'), ('r04_bench_force_dist_strict.json', 'strict'), ('r04_bench_force_dist.json', None)):
         f = _line(name)
-        assert f['n_ranks_seen'] == 1 and f['config']['gather'].startswith(mode)
-        assert 0 < f['gather_ms_per_step'] < 0.05 and f['gather_ms_per_step'] < 0.2 * f['ms_per_step']
+        assert f['n_ranks_seen'] == 1 and 0 < f['gather_ms_per_step'] < 0.05 and f['gather_ms_per_step'] < 0.2 * f['ms_per_step']
+        pr = f['config']['gather_probe_ms_per_step']
+        if mode is not None:
+            assert f['config']['gather'].startswith(mode) and pr is None
+        else:
+            # no mode pinned: the warm-up ran both and the timed region took the faster (the ranks agree through one max-reduction each)
+            assert set(pr) == {'overlapped', 'strict'} and f['config']['gather'].startswith(min(pr, key=pr.get))
 
 
 def test_rocprof_kernel_statistics_agree_with_the_bench_line():
@@ -98,9 +103,21 @@ def test_rocprof_kernel_statistics_agree_with_the_bench_line():
     import csv
     d = _line('r04_bench.json')
     rows = list(csv.DictReader(open(os.path.join(ROOT, 'profiles', 'r04_kernel_stats.csv'))))
-    top = rows[0]
-    assert d['roofline']['kernel'] in top['Name']
-    assert abs(float(top['AverageUs']) * 1e-3 - d['roofline']['launch_ms']) <= 0.10 * d['roofline']['launch_ms']
+    # (since the sub-grid of stage 1 no kernel dominates: the per-walker kernel, stage 1 and the spline-array product lie within 15 %
+    # of one another; `roofline` stays with stage 1, the one with the arithmetic, and `step_kernels` lists all five)
+    top = [r for r in rows[:3] if d['roofline']['kernel'] in r['Name']][0]
+    assert float(top['AverageUs']) >= 0.95 * float(rows[0]['AverageUs'])
+    sk = {k['kernel']: k for k in d['step_kernels']}
+    assert len(sk) == 5
+    for r in rows[:5]:
+        name = [k for k in sk if k in r['Name']][0]
+        ev = sk[name]['ms_hip_events_stage_pass']
+        assert float(r['AverageUs']) * 1e-3 <= ev * 1.02 and ev <= float(r['AverageUs']) * 1e-3 + d['roofline']['launch_ms_of_an_empty_kernel'] + 0.0015, (name, ev, r['AverageUs'])
+    # (a pair of HIP events around a kernel of a dependent chain also spans the hand-over in front of and behind it: what the pair
+    # reads around an empty kernel is reported beside launch_ms; rocprofv3 counts the kernel alone)
+    roof = d['roofline']
+    assert 0 < roof['launch_ms_of_an_empty_kernel'] < 0.010
+    assert roof['launch_ms'] - roof['launch_ms_of_an_empty_kernel'] - 0.05 * roof['launch_ms'] <= float(top['AverageUs']) * 1e-3 <= roof['launch_ms'] * 1.02
     # the kernels of the step add up to the step (launch gaps excluded)
     step_us = sum(float(r['AverageUs']) for r in rows if int(r['FullSizeCalls']) >= 100)
     assert 0.85 * d['ms_per_step'] * 1e3 <= step_us <= 1.02 * d['ms_per_step'] * 1e3
