@@ -143,6 +143,8 @@ struct jx_ctx {
     // batch staging for the host-pointer API
     double *d_theta = nullptr, *d_logp = nullptr;
     double *h_theta = nullptr, *h_logp = nullptr;   // pinned host staging of jx_eval (a pageable hipMemcpyAsync stages and synchronises by itself)
+    double *hd_theta = nullptr, *hd_logp = nullptr; // the same two buffers as the device sees them (mapped, coherent)
+    int eval_direct = 3;                            // JOXSZ_EVAL_DIRECT bit 0: the tail writes the log-probabilities into the host buffer itself; bit 1: the per-walker kernel reads theta from it
     int batch_cap = 0;
     // taps (chunk capacity, allocated on first use)
     double *t_pp = nullptr, *t_ab = nullptr, *t_y = nullptr, *t_row = nullptr, *t_bright = nullptr,
@@ -1171,6 +1173,7 @@ static int finalize_impl(jx_ctx* ctx) {
         if (got == 1 && a0 == 0) ctx->subsample = false;
         else if (got == 3 && a0 >= 8 && a1 >= a0 && a2 >= 4 && a2 <= 16) { ctx->sub_u0 = a0; ctx->sub_u1 = a1; ctx->sub_npts = a2; }
     }
+    if (const char* e = env_str("JOXSZ_EVAL_DIRECT")) { const int v = atoi(e); if (v >= 0 && v <= 3) ctx->eval_direct = v; }
     if (const char* e = env_str("JOXSZ_MIX_RANKCAP")) { const int v = atoi(e); if (v >= 0 && v <= 16) ctx->rank_cap = v; }
     if (const char* e = env_str("JOXSZ_MIX_MFMA")) ctx->mix_mfma = atoi(e) != 0;
     if (const char* e = env_str("JOXSZ_MIX_WPB")) { const int v = atoi(e); if (v >= 1 && v <= 16) { ctx->mix.wpb_force = v; ctx->mix.wpb = std::min(v, 4); } }
@@ -1455,8 +1458,10 @@ static int ensure_batch(jx_ctx* ctx, int n) {
     if (ctx->h_theta) { (void)hipHostFree(ctx->h_theta); (void)hipHostFree(ctx->h_logp); ctx->h_theta = ctx->h_logp = nullptr; }
     HIPCHK(ctx, hipMalloc((void**)&ctx->d_theta, sizeof(double) * (size_t)n * ctx->cfg.ndim));
     HIPCHK(ctx, hipMalloc((void**)&ctx->d_logp, sizeof(double) * (size_t)n));
-    HIPCHK(ctx, hipHostMalloc((void**)&ctx->h_theta, sizeof(double) * (size_t)n * ctx->cfg.ndim, hipHostMallocDefault));
-    HIPCHK(ctx, hipHostMalloc((void**)&ctx->h_logp, sizeof(double) * (size_t)n, hipHostMallocDefault));
+    HIPCHK(ctx, hipHostMalloc((void**)&ctx->h_theta, sizeof(double) * (size_t)n * ctx->cfg.ndim, hipHostMallocMapped | hipHostMallocCoherent));
+    HIPCHK(ctx, hipHostMalloc((void**)&ctx->h_logp, sizeof(double) * (size_t)n, hipHostMallocMapped | hipHostMallocCoherent));
+    HIPCHK(ctx, hipHostGetDevicePointer((void**)&ctx->hd_theta, ctx->h_theta, 0));
+    HIPCHK(ctx, hipHostGetDevicePointer((void**)&ctx->hd_logp, ctx->h_logp, 0));
     ctx->batch_cap = n;
     return JX_OK;
 }
@@ -2057,10 +2062,14 @@ int jx_eval(jx_ctx* ctx, const double* theta, int nwalkers, double* logp) {
     int rc = ensure_batch(ctx, nwalkers);
     if (rc) return rc;
     // through pinned staging: the copies are then plain DMA enqueued on the stream, and the call waits once, at its end
+    // The staging buffers are mapped into the device's address space: the per-walker kernel reads its 13 parameters straight
+    // from the host buffer and the tail stores the log-probability there (posted writes over PCIe, visible at the
+    // synchronisation) -- no copy command on either side of the five kernels.  JOXSZ_EVAL_DIRECT=0: both as DMA copies.
     memcpy(ctx->h_theta, theta, sizeof(double) * (size_t)nwalkers * ctx->cfg.ndim);
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d_theta, ctx->h_theta, sizeof(double) * (size_t)nwalkers * ctx->cfg.ndim, hipMemcpyHostToDevice, ctx->stream));
-    if ((rc = jx_eval_device(ctx, ctx->d_theta, nwalkers, ctx->d_logp))) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(ctx->h_logp, ctx->d_logp, sizeof(double) * (size_t)nwalkers, hipMemcpyDeviceToHost, ctx->stream));
+    const bool th_direct = (ctx->eval_direct & 2) != 0, lp_direct = (ctx->eval_direct & 1) != 0;
+    if (!th_direct) HIPCHK(ctx, hipMemcpyAsync(ctx->d_theta, ctx->h_theta, sizeof(double) * (size_t)nwalkers * ctx->cfg.ndim, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = jx_eval_device(ctx, th_direct ? ctx->hd_theta : ctx->d_theta, nwalkers, lp_direct ? ctx->hd_logp : ctx->d_logp))) return rc;
+    if (!lp_direct) HIPCHK(ctx, hipMemcpyAsync(ctx->h_logp, ctx->d_logp, sizeof(double) * (size_t)nwalkers, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     memcpy(logp, ctx->h_logp, sizeof(double) * (size_t)nwalkers);
     return JX_OK;

@@ -153,4 +153,21 @@ int jxt_mix_full_operator(const double* beam, int B, double scale, const double*
     return 0;
 }
 
+// the rows (= columns) of the quadrant kept by the sub-grid (returns their number; sub may be null) and the
+// interpolation matrix L [NU][ns] from them to every row
+int jxt_mix_row_subset(int NU, int u0, int u1, int* sub) {
+    std::vector<int> v;
+    jxt::mix_row_subset(NU, u0, u1, v);
+    if (sub) memcpy(sub, v.data(), sizeof(int) * v.size());
+    return (int)v.size();
+}
+
+int jxt_mix_interp_matrix(int NU, const int* sub, int ns, int npts, double* L /*[NU*ns]*/) {
+    std::vector<int> v(sub, sub + ns);
+    std::vector<double> Lm;
+    jxt::mix_interp_matrix(NU, v, npts, Lm);
+    memcpy(L, Lm.data(), sizeof(double) * Lm.size());
+    return 0;
+}
+
 }  // extern "C"

@@ -373,6 +373,80 @@ def test_mix_full_operator_with_a_measured_like_beam_and_a_rough_transfer_functi
     assert lib.jxt_mix_full_operator(_p(np.ascontiguousarray(pb.beam_2d)), B, pb.step ** 2, _p(np.ascontiguousarray(rng.random((S, S)))), S, _p(Om)) == -1
 
 
+@pytest.mark.parametrize('NU,u0,u1,npts', [(257, 40, 160, 12), (513, 40, 160, 12), (129, 40, 160, 12), (257, 32, 128, 8), (86, 40, 160, 12), (171, 40, 160, 12), (190, 40, 160, 12)])
+def test_sub_grid_rows_and_interpolation_matrix(lib, NU, u0, u1, npts):
+    """DESIGN 4.2 on the CPU: the rows the sub-grid keeps (every one below u0, every second to u1, every fourth to 2 u1, every eighth
+    beyond, the last) and the matrix L that carries values on them to every row -- unit rows at kept indices, rows that sum to
+    one, exact on even polynomials up to degree 2 (npts - 1) thanks to the mirrored stencil near the axis (the quadrant is even in
+    each index) and on any polynomial of degree < npts away from it."""
+    IP = ctypes.POINTER(ctypes.c_int)
+    lib.jxt_mix_row_subset.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, IP]
+    lib.jxt_mix_interp_matrix.argtypes = [ctypes.c_int, IP, ctypes.c_int, ctypes.c_int, DP]
+    ns = lib.jxt_mix_row_subset(NU, u0, u1, None)
+    sub = np.zeros(ns, np.int32)
+    assert lib.jxt_mix_row_subset(NU, u0, u1, sub.ctypes.data_as(IP)) == ns
+    assert sub[0] == 0 and sub[-1] == NU - 1 and np.all(np.diff(sub) >= 1) and np.array_equal(sub[:min(u0, NU)], np.arange(min(u0, NU)))
+    # the rule, restated: a coarser stride is entered at its start row only where sixteen of its steps still fit before the last row
+    want, u, stride = [], 0, 1
+    while u < NU:
+        want.append(u)
+        for t, st in enumerate((u0, u1, 2 * u1)):
+            if u >= st and stride < (2 << t) and NU - 1 - u >= 16 * (2 << t):
+                stride = 2 << t
+        u += stride
+    if want[-1] != NU - 1:
+        want.append(NU - 1)
+    assert np.array_equal(sub, want)
+    L = np.zeros((NU, ns))
+    assert lib.jxt_mix_interp_matrix(NU, sub.ctypes.data_as(IP), ns, npts, _p(L)) == 0
+    assert np.array_equal(L[sub], np.eye(ns))                            # kept rows: themselves
+    np.testing.assert_allclose(L.sum(axis=1), 1.0, atol=1e-12)
+    assert (L != 0).sum(axis=1).max() <= npts
+    u = np.arange(NU, dtype=np.float64) / NU
+    for deg in (2, 4, 2 * (min(npts, ns) - 1) if NU > 200 else 6):       # even powers: reproduced everywhere, the axis included
+        f = u ** deg
+        np.testing.assert_allclose(L @ f[sub], f, atol=2e-11 * max(1.0, np.abs(L).sum(axis=1).max()))
+    far = np.arange(NU) > sub[min(npts, ns - 1)]                         # away from the axis no mirror enters: any polynomial below degree npts
+    f = (u - 0.3) ** (min(npts, ns) - 1)
+    np.testing.assert_allclose((L @ f[sub])[far], f[far], atol=1e-10)
+    # a smooth even function of the radius, the shape of the map along a row: what the interpolation actually meets
+    rho = np.hypot(np.arange(NU)[:, None], np.arange(NU)[None, :])
+    Q = (1.0 + (rho / 30.0) ** 2) ** -1.2
+    Qs = Q[np.ix_(sub, sub)]
+    err = np.abs(L @ Qs @ L.T - Q).max() / np.abs(Q).max()
+    assert err < (1e-8 if npts < 12 else 1e-10), err
+
+
+@pytest.mark.parametrize('S,N', [(128, 140), (200, 160)])
+def test_full_operator_through_the_sub_grid_against_the_oracle(lib, S, N):
+    """The contraction of 4.2 stated in numpy on the ORACLE's own Compton-y map: Omega (every distinct sample) folded through L on
+    both indices, applied to the map's samples on the sub-grid alone, gives the oracle's row -- to 1e-11 of its maximum with a
+    sub-grid that is coarse for a map this small (every row within 24 pixels, every second to 48, then every fourth where sixteen
+    such steps fit before the edge)."""
+    IP = ctypes.POINTER(ctypes.c_int)
+    lib.jxt_mix_row_subset.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, IP]
+    lib.jxt_mix_interp_matrix.argtypes = [ctypes.c_int, IP, ctypes.c_int, ctypes.c_int, DP]
+    pb = _problem(S, N)
+    ref = _reference_row(pb, seed=S)
+    Q, NU = _quadrant(ref['y_2d'])
+    nrow = S - S // 2
+    Om = np.zeros((nrow, NU, NU))
+    lib.jxt_mix_full_operator.argtypes = [DP, ctypes.c_int, ctypes.c_double, DP, ctypes.c_int, DP]
+    assert lib.jxt_mix_full_operator(_p(np.ascontiguousarray(pb.beam_2d)), pb.B, pb.step ** 2, _p(np.ascontiguousarray(pb.filtering)), S, _p(Om)) == 0
+    ns = lib.jxt_mix_row_subset(NU, 24, 48, None)
+    sub = np.zeros(ns, np.int32)
+    lib.jxt_mix_row_subset(NU, 24, 48, sub.ctypes.data_as(IP))
+    assert ns < 0.75 * NU
+    L = np.zeros((NU, ns))
+    lib.jxt_mix_interp_matrix(NU, sub.ctypes.data_as(IP), ns, 12, _p(L))
+    Oms = np.einsum('xuv,ua,vb->xab', Om, L, L)
+    full = np.einsum('xuv,uv->x', Om, Q)
+    out = np.einsum('xab,ab->x', Oms, Q[np.ix_(sub, sub)])
+    scale = np.abs(ref['map_row']).max()
+    assert np.abs(full - ref['map_row']).max() <= 1e-13 * scale
+    assert np.abs(out - ref['map_row']).max() <= 1e-11 * scale
+
+
 @pytest.mark.parametrize('S', [171, 256, 512, 513, 1024])
 def test_the_data_radii_spline_reads_a_bounded_part_of_the_row(lib, S):
     """DESIGN 4.1 on the CPU: the evaluation matrix E of the not-a-knot spline through the extracted row (joxsz_funcs.py:476), as the
