@@ -120,6 +120,7 @@ struct jx_ctx {
     double* d_Tm = nullptr; int tm_ld = 0, tm_ntile = 0, tm_npair = 0;
     double* d_ppc = nullptr;           // [chunk][N] prep kernel -> jx_abel_gemm_kernel
     bool abel_gemm = true;
+    bool ag_single = false;            // JOXSZ_AG_SINGLE=1: one column tile per wave (twice the blocks) in the spline-array product
     int ag_narrow = -1;                // JOXSZ_AG_NARROW: 16-walker blocks of the spline-array product for every launch (1) / never (0)
     bool f32 = false;                  // jx_config.dtype >= 1: fp32 spline arrays, fp32 evaluation of the map samples
     bool f32c = false;                 // jx_config.dtype == 2: fp32 arithmetic in stage 1 and stage 2 as well (packed fp32 FMAs, fp32 matrix cores)
@@ -1181,6 +1182,7 @@ static int finalize_impl(jx_ctx* ctx) {
     if (const char* e = env_str("JOXSZ_MIX_KSPLIT_USE")) { const int v = atoi(e); if (v >= 1) ctx->mix.ksplit_u_force = v; }
     if (const char* e = env_str("JOXSZ_ABEL_GEMM")) ctx->abel_gemm = atoi(e) != 0;
     if (const char* e = env_str("JOXSZ_AG_NARROW")) ctx->ag_narrow = atoi(e) != 0;
+    if (const char* e = env_str("JOXSZ_AG_SINGLE")) ctx->ag_single = atoi(e) != 0;
     ctx->op_narrow = env_str("JOXSZ_OP_NARROW") != nullptr;
     if (const char* e = env_str("JOXSZ_SIDE_STREAM")) ctx->side_on = atoi(e) != 0;
     if (const char* e = env_str("JOXSZ_SIDE_FORK")) ctx->side_fork = atoi(e) != 0;
@@ -1627,9 +1629,13 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
             const size_t shg = sizeof(double) * JX_OPM_JC * 33;
 #define JX_AG_GO(TOv, NWTv) hipLaunchKernelGGL((jx_abel_gemm_kernel<1, TOv, 1, NWTv>), grid, dim3(256), shg, st, pp_src, n, d.N, ctx->d_Tm, ctx->tm_ld, \
                                                d.K, ctx->tm_ntile, ctx->tm_npair, reinterpret_cast<TOv*>(m.cft), m.tW, (long long)m.ncol)
-            if (ctx->f32) { if (narrow) JX_AG_GO(float, 1); else JX_AG_GO(float, 2); }
+#define JX_AG_GO1(TOv) hipLaunchKernelGGL((jx_abel_gemm_kernel<1, TOv, 1, 2, 1>), dim3(grid.x, (unsigned)((ctx->tm_ntile + 3) / 4)), dim3(256), shg, st, pp_src, n, d.N, ctx->d_Tm, ctx->tm_ld, \
+                                               d.K, ctx->tm_ntile, ctx->tm_npair, reinterpret_cast<TOv*>(m.cft), m.tW, (long long)m.ncol)
+            if (ctx->ag_single && !narrow) { if (ctx->f32) JX_AG_GO1(float); else JX_AG_GO1(double); }
+            else if (ctx->f32) { if (narrow) JX_AG_GO(float, 1); else JX_AG_GO(float, 2); }
             else { if (narrow) JX_AG_GO(double, 1); else JX_AG_GO(double, 2); }
 #undef JX_AG_GO
+#undef JX_AG_GO1
             if (!ctx->map_ok && want_abel_taps && !ctx->f32) {
                 // the profile taps without the Abel kernel: the pressure profile as the per-walker kernel wrote it, the spline
                 // ordinates y_k of the matrix product, the Abel integral as y / y_scale

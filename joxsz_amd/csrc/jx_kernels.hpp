@@ -1446,27 +1446,39 @@ jx_operator_mfma_kernel(const double* __restrict__ pp /*[launch][N]*/, int n, in
 // cf_ws = walker stride; columns >= ncol are not stored.
 // NWT = 16-walker tiles per block (2, or 1 for launches too small to give every SIMD a wave otherwise: a walker's sums are
 // the same either way).
-template <int NPW, typename TO = double, int TR = 0, int NWT = 2>
+// SINGLE = 1: a wave owns ONE column tile (tile 4 * blockIdx.y + wave; the four of a block adjacent, so their k-ranges differ
+// by six steps at most) -- twice the blocks of the paired form, two per CU: one block's barriers and first-touch waits then
+// overlap the other's matrix instructions, and the fp64 matrix instruction issues every 114 cycles from two waves per SIMD
+// instead of every 156 from one.  Blocks with the longest k-ranges have the lowest blockIdx.y: dispatched first.
+template <int NPW, typename TO = double, int TR = 0, int NWT = 2, int SINGLE = 0>
 __global__ void __launch_bounds__(256)
 jx_abel_gemm_kernel(const double* __restrict__ pp /*[launch][N]*/, int n, int N, const double* __restrict__ Tm /*[JX_AG_ROWS(N)][ldt], zero rows behind N-1*/,
                     int ldt, int K, int ntile, int npair, TO* __restrict__ cf /*[launch][cf_ws]; float for the fp32 variant (rounded once, on store)*/, long long cf_ws,
                     long long ncol = 0) {
     JX_LDS_DECL;
-    constexpr int NTL = 2 * NPW;
+    static_assert(!SINGLE || NPW == 1, "one tile per wave");
+    constexpr int NTL = SINGLE ? 1 : 2 * NPW;
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wb = blockIdx.x * 16 * NWT, grp = blockIdx.y;
     const int ktot4 = (N + 4 * JX_AG_R - 1) / (4 * JX_AG_R) * JX_AG_R;          // k-steps, in whole groups of JX_AG_R
     int tile[NTL], ks[NTL], toff[NTL];
+    if (SINGLE) {
+        const int t = grp * 4 + wv;
+        tile[0] = t;
+        ks[0] = (t < ntile) ? (max(0, 8 * t - K) >> 2) : ktot4;
+        toff[0] = min(t, ntile - 1) * 16;
+    } else {
 #pragma unroll
-    for (int i = 0; i < NPW; ++i) {
-        const int p = (grp * 4 + wv) * NPW + i;
-        tile[2 * i] = p; tile[2 * i + 1] = 2 * npair - 1 - p;
+        for (int i = 0; i < NPW; ++i) {
+            const int p = (grp * 4 + wv) * NPW + i;
+            tile[2 * i] = p; tile[(2 * i + 1) % NTL] = 2 * npair - 1 - p;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int t = tile[2 * i + h];
-            ks[2 * i + h] = (p < npair && t < ntile) ? (max(0, 8 * t - K) >> 2) : ktot4;   // first k-step with entries (ktot4: none)
-            toff[2 * i + h] = min(t, ntile - 1) * 16;
+            for (int h = 0; h < 2; ++h) {
+                const int t = tile[(2 * i + h) % NTL];
+                ks[(2 * i + h) % NTL] = (p < npair && t < ntile) ? (max(0, 8 * t - K) >> 2) : ktot4;   // first k-step with entries (ktot4: none)
+                toff[(2 * i + h) % NTL] = min(t, ntile - 1) * 16;
+            }
         }
     }
     jx_op_v4d acc[NTL][NWT];
