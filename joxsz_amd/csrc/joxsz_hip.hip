@@ -537,17 +537,6 @@ static void plan_mix(jx_ctx* ctx, const std::vector<double>& beam, const std::ve
                 for (int b2 = 0; b2 < NUs; ++b2) Qsub[(size_t)a * NUs + b2] = ctx->h_Qtab[(size_t)mb.sub[a] * ctx->qn + mb.sub[b2]];
         }
     }
-    if (!ctx->usplit_forced) {
-        // pieces per column: a chunk of 1024 walkers should fill the chip in as few rounds of waves as possible (24 resident waves per CU:
-        // scripts/ubench/occ_rowmix.hip), each piece paying its ring fill once more -- rounds x (1 / pieces + 0.08), measured
-        // against JOXSZ_MIX_USPLIT = 1..4 at 512^2 with and without the sub-grid (profiles/r04_subsample_scan.log)
-        const double cap = 24.0 * std::max(1, ctx->num_cu), ngrp = 16.0;      // (a nominal chunk of 1024 walkers, not this context's: the grouping of a walker's sums must not depend on max_batch)
-        double best = 1e300;
-        for (int usp = 1; usp <= 4; ++usp) {
-            const double c = std::ceil(NUs * usp * ngrp / cap) * (1.0 / usp + 0.08);
-            if (c < best * (1.0 - 1e-9)) { best = c; ctx->usplit = usp; }
-        }
-    }
     bool lowrank_ok = mb.sub.empty() ? jxt::mix_column_tables(ctx->h_Qtab, ctx->qn, NU, r, mb.cols, ctx->usplit)
                                      : jxt::mix_column_tables(Qsub, NUs, NUs, r, mb.cols, ctx->usplit);
     std::string why_lr = lowrank_ok ? "" : "pixel radii do not grow along the columns of d_mat";
@@ -573,6 +562,25 @@ static void plan_mix(jx_ctx* ctx, const std::vector<double>& beam, const std::ve
             JX_MIX_RTS(JX_PICK)
 #undef JX_PICK
             if (!mb.RT) { lowrank_ok = false; why_lr = "rank of the separable form beyond the stage-1 kernel (" + std::to_string(mb.r) + " x " + std::to_string(mb.ns) + " terms)"; }
+        }
+    }
+    if (!ctx->usplit_forced && lowrank_ok && mb.RT) {
+        // pieces per column: a chunk of 1024 walkers should fill the chip in as few rounds of waves as possible (24 resident waves per CU:
+        // scripts/ubench/occ_rowmix.hip), each piece paying its ring fill once more -- rounds x (1 / pieces + 0.08), measured
+        // against JOXSZ_MIX_USPLIT = 1..4 at 512^2 with and without the sub-grid (profiles/r04_subsample_scan.log); the hand-over of
+        // the later pieces (RT sums per lane each) has to fit the 64 KB of dynamic LDS of one walker group
+        const double cap = 24.0 * std::max(1, ctx->num_cu), ngrp = 16.0;      // (a nominal chunk of 1024 walkers, not this context's: the grouping of a walker's sums must not depend on max_batch)
+        double best = 1e300;
+        int pick = 1;
+        for (int usp = 1; usp <= 4; ++usp) {
+            if ((size_t)(usp - 1) * mb.RT * 64 * sizeof(double) > (size_t)64 * 1024) break;
+            const double c = std::ceil(NUs * usp * ngrp / cap) * (1.0 / usp + 0.08);
+            if (c < best * (1.0 - 1e-9)) { best = c; pick = usp; }
+        }
+        if (pick != ctx->usplit) {
+            ctx->usplit = pick;
+            lowrank_ok = mb.sub.empty() ? jxt::mix_column_tables(ctx->h_Qtab, ctx->qn, NU, r, mb.cols, ctx->usplit)
+                                        : jxt::mix_column_tables(Qsub, NUs, NUs, r, mb.cols, ctx->usplit);
         }
     }
     // cost of each form in fused multiply-adds per walker; stage 1 runs on the vector units at about 0.6 of the rate the

@@ -360,6 +360,8 @@ def test_lowrank_form_against_full_form(monkeypatch):
     other, the rocFFT sequence and the oracle; ragged walker counts included."""
     from joxsz_amd import datasets
     modes = {'default': {'JOXSZ_MIX_FORM': 'lowrank'}, 'tight': {'JOXSZ_MIX_FORM': 'lowrank', 'JOXSZ_LOWRANK_TOL': '1e-13'},
+             # (every distinct sample with ~48 rows per column: the pieces per column are limited by the LDS hand-over, not by the chip)
+             'tight_all': {'JOXSZ_MIX_FORM': 'lowrank', 'JOXSZ_LOWRANK_TOL': '1e-13', 'JOXSZ_MIX_SUBSAMPLE': '0'},
              'full': {'JOXSZ_MIX_FORM': 'full'}}
     for S, N, nw in ((256, 300, 6), (512, 500, 37)):
         pb = datasets.synthetic_problem(S=S, N=N, seed=11)
@@ -378,7 +380,7 @@ def test_lowrank_form_against_full_form(monkeypatch):
         ref = _post(pb, conv='rocfft')
         res['rocfft'] = (ref.stage(th, 'map_row'), ref.stage(th, 'bright'), ref.log_prob(th), 0)
         ref.close()
-        for mode in ('tight', 'full'):
+        for mode in ('tight', 'tight_all', 'full'):
             for a, b in zip(res[mode][:2], res['rocfft'][:2]):
                 np.testing.assert_allclose(a, b, rtol=1e-10, atol=1e-11 * np.abs(b).max(), err_msg=mode)
             np.testing.assert_allclose(res[mode][2], res['rocfft'][2], rtol=1e-9, err_msg=mode)
