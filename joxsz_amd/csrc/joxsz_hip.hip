@@ -1256,7 +1256,7 @@ static int finalize_impl(jx_ctx* ctx) {
         dt.quad = 1; dt.fast_map = (dmat_mirror && qn <= 9 * 64) ? 1 : 0; dt.q_na = dt.q_nb = qn;
         int th; size_t ld;
         ctx->map_ok = map_geometry(dt, 512, &th, &ld);
-        if (!ctx->map_ok) { lr_tol0 = std::min(lr_tol0, 1e-13); ctx->rank_cap = 0; ctx->tol_pinned = true; }
+        if (!ctx->map_ok) { lr_tol0 = std::min(lr_tol0, 1e-13); ctx->rank_cap = 0; ctx->tol_pinned = true; ctx->subsample = false; }   // (nothing could measure a truncation or a sub-grid: neither is taken)
     }
     // ---- which back end: contracted route or the rocFFT sequence
     std::vector<double> beam_h = host_vec<double>(ctx, JX_T_BEAM_2D);

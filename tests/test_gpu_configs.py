@@ -656,6 +656,7 @@ def test_radial_grid_beyond_the_abel_kernels_lds():
     assert post.ctx.conv == 'custom'
     tr = post.ctx.truncation
     assert tr['retried'] == 0 and (tr['rank'] == 0 or tr['tol'] <= 1.01e-13)
+    assert not post.ctx.sampling['active'] and post.ctx.sampling['removed_by_the_guard'] == 0     # (nor a sub-grid of map samples: nothing could measure it)
     got = post.log_prob(th)
     pp, y, row = post.stage(th[:2], 'pp'), post.stage(th[:2], 'y'), post.stage(th[:2], 'map_row')
     for tap in ('y_2d', 'conv_2d'):
