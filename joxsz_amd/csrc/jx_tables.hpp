@@ -620,6 +620,9 @@ struct MixColumns {
 
 // Column x' of the quadrant, rows u = 0..NU-1: radius Q[u][x'].  Returns false when the interval index decreases along a
 // column (a d_mat that is not a centred distance matrix): the route is then not taken.
+#ifndef MIX_SEG_COST
+#define MIX_SEG_COST 0.35
+#endif
 inline bool mix_column_tables(const std::vector<double>& Qtab /*[qn][qn]: (|iy-c|, |ix-c|)*/, int qn, int NU,
                               const std::vector<double>& r, MixColumns& t, int usplit = 1) {
     const int N = (int)r.size();
@@ -644,8 +647,21 @@ inline bool mix_column_tables(const std::vector<double>& Qtab /*[qn][qn]: (|iy-c
             kof[(size_t)a * NU + u] = k;
             for (int j = 0; j < 4; ++j) t.w4[((size_t)a * t.wld + u) * 4 + j] = w[j];
         }
+        // the pieces of a column are cut at equal COST, not at equal length: a sample costs its 4 + R multiply-adds, a knot interval
+        // entered (with or without a sample in it) a knot request and a turn of the ring -- about a third of a sample (measured:
+        // profiles/r04_subsample_scan.log); far from the axis a column crosses several intervals per sample, near it several samples share one
+        std::vector<double> cum(NU + 1, 0.0);
+        for (int u = 0; u < NU; ++u) cum[u + 1] = cum[u] + 1.0 + MIX_SEG_COST * (u == 0 ? 1 : kof[(size_t)a * NU + u] - kof[(size_t)a * NU + u - 1]);
+        std::vector<int> cut(usplit + 1, 0);
+        cut[usplit] = NU;
+        for (int h = 1; h < usplit; ++h) {
+            const double want = cum[NU] * h / usplit;
+            int u = cut[h - 1] + 1;
+            while (u < NU - (usplit - h) && cum[u] < want) ++u;
+            cut[h] = u;
+        }
         for (int h = 0; h < usplit; ++h) {
-            const int ub = (int)((long long)h * NU / usplit), ue = (int)((long long)(h + 1) * NU / usplit), v = a * usplit + h;
+            const int ub = cut[h], ue = cut[h + 1], v = a * usplit + h;
             t.urange[v] = ub | ((ue - ub) << 16);
             t.seg0[v] = kof[(size_t)a * NU + ub];
             t.nseg[v] = kof[(size_t)a * NU + ue - 1] - t.seg0[v] + 1;
