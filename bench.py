@@ -65,6 +65,24 @@ def pmc_file(S):
     return None
 
 
+def sq_counters_file():
+    """The committed SQ counter pass of the newest round (profiles/rNN_sq_counters.csv): {'file', 'rows'} or {}."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_sq_counters.csv')))
+    if not files:
+        return {}
+    try:
+        lines = open(files[-1]).read().splitlines()
+        cols = lines[0].split(',')
+        rows = []
+        for ln in lines[1:]:                                  # (kernel names carry commas of their own: the counters are the last fields)
+            parts = ln.rsplit(',', len(cols) - 1)
+            rows.append(dict(zip(cols, parts)))
+        return {'file': os.path.relpath(files[-1], ROOT), 'rows': rows}
+    except Exception:
+        return {}
+
+
 def pmc_kernel_entry(j, kernel):
     """The PMC entry of the full-size launches of `kernel` (base name, template arguments dropped): instances of the same kernel
     template that only ran on a handful of walkers (set-up, guard, taps) are in the file too; the full-size one has the largest
@@ -658,6 +676,21 @@ def main():
                       'tail_ms': 'L2 reads of the partial rows + latency'}
             step_kernels = [{'kernel': stage_kernels[k].split(' ')[0], 'ms_hip_events_stage_pass': stage_ms[k], 'share_of_stage_sum': stage_ms[k] / max(1e-12, sum(stage_ms[q] for q in bounds)),
                              'bound': bounds[k]} for k in ('prep_ms', 'abel_map_ms', 'beam_fft_ms', 'tf_fft_ms', 'tail_ms') if bounds[k]]
+            # where each kernel's wave cycles go, from the committed counter pass of the same command (profiles/*_sq_counters.csv; not measured in this run)
+            sq = sq_counters_file()
+            for e in step_kernels:
+                row = next((r for r in sq.get('rows', []) if e['kernel'] in r['kernel'] and float(r['SQ_WAVE_CYCLES']) > 1e6), None)
+                if row:
+                    wc = float(row['SQ_WAVE_CYCLES'])
+                    e['wave_cycles_source'] = sq['file']
+                    e['share_of_wave_cycles'] = {'waiting': float(row['SQ_WAIT_ANY']) / wc, 'issue_stalled': float(row['SQ_WAIT_INST_ANY']) / wc,
+                                                 'issuing': float(row['SQ_ACTIVE_INST_ANY']) / wc, 'issuing_valu': float(row['SQ_ACTIVE_INST_VALU']) / wc}
+            if roof is not None:
+                longest = max(step_kernels, key=lambda e: e['ms_hip_events_stage_pass'])
+                roof['longest_kernel_of_the_step'] = {'kernel': longest['kernel'], 'ms_hip_events_stage_pass': longest['ms_hip_events_stage_pass']}
+                roof['longest_kernel_note'] = ('no kernel dominates the step: the per-walker kernel (latency + fp64 exp/log chains; no flop or byte count prices it, its '
+                                               'vector-issue share is in step_kernels), stage 1 and the spline-array product lie within 15 % of one another; `roofline` prices '
+                                               'stage 1, the kernel that holds the arithmetic of the path')
         if ns_route and 'ms_per_step' in ns_route:
             ns_route['speedup_of_default_route'] = ns_route['ms_per_step'] / ms_step
         out = {

@@ -106,9 +106,11 @@ def test_rocprof_kernel_statistics_agree_with_the_bench_line():
     # (since the sub-grid of stage 1 no kernel dominates: the per-walker kernel, stage 1 and the spline-array product lie within 15 %
     # of one another; `roofline` stays with stage 1, the one with the arithmetic, and `step_kernels` lists all five)
     top = [r for r in rows[:3] if d['roofline']['kernel'] in r['Name']][0]
-    assert float(top['AverageUs']) >= 0.95 * float(rows[0]['AverageUs'])
+    assert float(top['AverageUs']) >= 0.90 * float(rows[0]['AverageUs'])
+    lk = d['roofline']['longest_kernel_of_the_step']
+    assert lk['kernel'] in rows[0]['Name'] or abs(lk['ms_hip_events_stage_pass'] - max(k['ms_hip_events_stage_pass'] for k in d['step_kernels'])) < 1e-12
     sk = {k['kernel']: k for k in d['step_kernels']}
-    assert len(sk) == 5
+    assert len(sk) == 5 and all(0 < k['share_of_wave_cycles']['issuing_valu'] < 1 for k in d['step_kernels'])
     for r in rows[:5]:
         name = [k for k in sk if k in r['Name']][0]
         ev = sk[name]['ms_hip_events_stage_pass']
