@@ -303,6 +303,10 @@ int  jx_debug_workspace(jx_ctx* ctx, int which, void** dev, int32_t geom[4]);
  * around (profile -> Abel integral -> spline -> map; S^2 * 8 bytes per walker).  The evaluation path never stores the map;
  * this call exists for that measurement and allocates its own scratch image. */
 int  jx_map_kernel_time(jx_ctx* ctx, const double* theta_dev, int nwalkers, int repeats, double* ms_out);
+/* Test hook: the table-driven exp and log the per-walker kernel evaluates its profile chains with (csrc/jx_fastmath.hpp; 16 and 22
+ * vector instructions against the device library's 38 and 95; JOXSZ_PREP_FASTMATH=0 selects the library's), on n host values
+ * through the tables of this context.  Held to 2 ulp against long double by tests/test_gpu_fastmath.py. */
+int  jx_fastmath_eval(jx_ctx* ctx, const double* x, int n, double* exp_out, double* log_out);
 /* What a pair of HIP events around one kernel of a dependent chain reads when the kernel does nothing (a one-wave kernel that
  * returns at once, another in front and behind): the part of a stage's HIP-event duration that is not the kernel -- rocprofv3's
  * kernel trace does not count it.  Mean over `repeats` (<= 256) brackets, in ms. */

@@ -120,6 +120,7 @@ struct jx_ctx {
     double* d_Tm = nullptr; int tm_ld = 0, tm_ntile = 0, tm_npair = 0;
     double* d_ppc = nullptr;           // [chunk][N] prep kernel -> jx_abel_gemm_kernel
     bool abel_gemm = true;
+    bool prep_fastmath = true;         // JOXSZ_PREP_FASTMATH=0: the per-walker kernel's exp / log from the device library instead of jx_fastmath.hpp's tables
     bool ag_single = false;            // JOXSZ_AG_SINGLE=1: one column tile per wave (twice the blocks) in the spline-array product
     int ag_narrow = -1;                // JOXSZ_AG_NARROW: 16-walker blocks of the spline-array product for every launch (1) / never (0)
     bool f32 = false;                  // jx_config.dtype >= 1: fp32 spline arrays, fp32 evaluation of the map samples
@@ -1191,6 +1192,7 @@ static int finalize_impl(jx_ctx* ctx) {
     if (const char* e = env_str("JOXSZ_ABEL_GEMM")) ctx->abel_gemm = atoi(e) != 0;
     if (const char* e = env_str("JOXSZ_AG_NARROW")) ctx->ag_narrow = atoi(e) != 0;
     if (const char* e = env_str("JOXSZ_AG_SINGLE")) ctx->ag_single = atoi(e) != 0;
+    if (const char* e = env_str("JOXSZ_PREP_FASTMATH")) ctx->prep_fastmath = atoi(e) != 0;
     ctx->op_narrow = env_str("JOXSZ_OP_NARROW") != nullptr;
     if (const char* e = env_str("JOXSZ_SIDE_STREAM")) ctx->side_on = atoi(e) != 0;
     if (const char* e = env_str("JOXSZ_SIDE_FORK")) ctx->side_fork = atoi(e) != 0;
@@ -1354,6 +1356,12 @@ static int finalize_impl(jx_ctx* ctx) {
             for (double& v : lr) v = std::log(v);
             if ((rc = dev_put(ctx, lr.data(), lr.size(), &p))) return rc;
             d.lr_pp = p;
+        }
+        {
+            std::vector<double> fm;
+            jxt::fastmath_tables(fm);                             // exp / log tables of the per-walker kernel (jx_fastmath.hpp)
+            if ((rc = dev_put(ctx, fm.data(), fm.size(), &p))) return rc;
+            d.fm_tab = p;
         }
         PUTD(r_pp, JX_T_R_PP) PUTD(d_mat, JX_T_D_MAT) PUTD(conv_T, JX_T_CONV_T) PUTD(conv_v, JX_T_CONV_V)
         PUTD(par_vals, JX_T_PAR_VALS) PUTD(par_min, JX_T_PAR_MIN) PUTD(par_max, JX_T_PAR_MAX)
@@ -1571,10 +1579,12 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
     auto launch_prep = [&](hipStream_t ps, double* pp_buf) {
         JxDev dp = d;
         dp.inject_pp = ctx->d.inject_pp;
-        const size_t sh = sizeof(double) * (JX_LDS_HDR + (size_t)2 * d.N + 2 * d.nann + (size_t)d.nband * d.nann + 2 * (size_t)d.nconv + 8);
-        if (d.prep_pow) hipLaunchKernelGGL(jx_prep_kernel<true>, dim3(n), dim3(JX_PREP_THREADS), sh, ps, dp, theta_dev, w0,
+        const size_t sh = sizeof(double) * (JX_LDS_HDR + (size_t)2 * d.N + 2 * d.nann + (size_t)d.nband * d.nann + 2 * (size_t)d.nconv + 8 + JX_FM_TABLE_DOUBLES);
+        if (d.prep_pow) hipLaunchKernelGGL((jx_prep_kernel<true, false>), dim3(n), dim3(JX_PREP_THREADS), sh, ps, dp, theta_dev, w0,
                                            base_buf, cfac_buf, pp_buf, sz0_buf, t.tprof, t.xprofs, t.parts, t.integ);
-        else hipLaunchKernelGGL(jx_prep_kernel<false>, dim3(n), dim3(JX_PREP_THREADS), sh, ps, dp, theta_dev, w0,
+        else if (ctx->prep_fastmath) hipLaunchKernelGGL((jx_prep_kernel<false, true>), dim3(n), dim3(JX_PREP_THREADS), sh, ps, dp, theta_dev, w0,
+                                                        base_buf, cfac_buf, pp_buf, sz0_buf, t.tprof, t.xprofs, t.parts, t.integ);
+        else hipLaunchKernelGGL((jx_prep_kernel<false, false>), dim3(n), dim3(JX_PREP_THREADS), sh, ps, dp, theta_dev, w0,
                                 base_buf, cfac_buf, pp_buf, sz0_buf, t.tprof, t.xprofs, t.parts, t.integ);
     };
     {
@@ -2333,6 +2343,33 @@ int jx_map_kernel_time(jx_ctx* ctx, const double* theta_dev, int nwalkers, int r
     HIPCHK(ctx, hipEventElapsedTime(&ms, e0, e1));
     HIPCHK(ctx, hipGetLastError());
     *ms_out = (double)ms / repeats;
+    return JX_OK;
+}
+
+// Test hook: the table-driven exp and log of the per-walker kernel (jx_fastmath.hpp) on n host values, through the same tables the
+// context uploaded -- what tests/test_gpu_fastmath.py holds to 2 ulp against long double.
+__global__ void __launch_bounds__(256) jx_fastmath_kernel(const double* __restrict__ tab, const double* __restrict__ x, double* __restrict__ oe, double* __restrict__ ol, int n) {
+    __shared__ double st[JX_FM_TABLE_DOUBLES];
+    for (int i = threadIdx.x; i < JX_FM_TABLE_DOUBLES; i += blockDim.x) st[i] = tab[i];
+    __syncthreads();
+    const JxFm t{st, st + JX_FM_EXP_N};
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { oe[i] = jx_fm_exp(t, x[i]); ol[i] = jx_fm_log(t, x[i]); }
+}
+
+int jx_fastmath_eval(jx_ctx* ctx, const double* x, int n, double* exp_out, double* log_out) {
+    if (!ctx || !x || n < 1 || !exp_out || !log_out) return JX_ERR_INVALID;
+    if (!ctx->finalized) { ctx->err = "jx_fastmath_eval before jx_finalize"; return JX_ERR_STATE; }
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    Scratch sc;
+    double *dx = nullptr, *de = nullptr, *dl = nullptr;
+    HIPCHK(ctx, sc.alloc((void**)&dx, sizeof(double) * (size_t)n)); HIPCHK(ctx, sc.alloc((void**)&de, sizeof(double) * (size_t)n)); HIPCHK(ctx, sc.alloc((void**)&dl, sizeof(double) * (size_t)n));
+    HIPCHK(ctx, hipMemcpyAsync(dx, x, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(jx_fastmath_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d.fm_tab, dx, de, dl, n);
+    HIPCHK(ctx, hipMemcpyAsync(exp_out, de, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(log_out, dl, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipGetLastError());
     return JX_OK;
 }
 

@@ -18,6 +18,8 @@
 // 64 non-temporal stores (with 4), 128 Abel loop without the reciprocal square root.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
+#include "jx_fastmath.hpp"
 #include <stdint.h>
 
 // Timing-only ablations of the map kernel (JxDev::dbg, environment JOXSZ_DBG) exist in a diagnostic build only
@@ -62,6 +64,7 @@ struct JxDev {
     const double* d_mat;         // [S*S]
     long long img_ld, img_ws;    // row and walker strides (doubles) of the y-map image
     int dbg;                     // timing-only ablations (JOXSZ_DBG): 1 skip phases 1-4, 2 skip phase 5, 4 phase 5 stores only
+    const double* fm_tab;        // [JX_FM_TABLE_DOUBLES] tables of jx_fastmath.hpp (jxt::fastmath_tables)
     int prep_pow;                // 1 (JOXSZ_PREP_POW=1): the prep kernel evaluates the profiles with pow() as written in the reference
     const double* lr_pp;         // [N] log(r_pp)
     const double* inject_pp;     // operator build only: [nlaunch][N] pressure profiles that replace press_fun(theta) (else null)
@@ -133,33 +136,46 @@ __device__ __forceinline__ double jx_ne_pc(const double* p, const double* pc, do
 // time goes into.  The exponents are O(10) and carry an absolute error of a few 1e-16 each, so the values agree with
 // the pow() forms to ~1e-14 relative (the pow() forms stay available: JOXSZ_PREP_POW=1).
 // pl = {log r_p, (b-c)/a, log r_c, r_c, log r_s, 3 beta - alpha/2, eps/gamma, n0^2, n02^2, r_c2}
-__device__ __forceinline__ void jx_prof_consts(const double* p, int mode, double* pl) {
+// exp / log of the profile chains: the device library's, or the table-driven pair of jx_fastmath.hpp (tables in LDS)
+struct JxMathLib {
+    __device__ __forceinline__ double e(double x) const { return exp(x); }
+    __device__ __forceinline__ double l(double x) const { return log(x); }
+};
+struct JxMathTab {
+    JxFm t;
+    __device__ __forceinline__ double e(double x) const { return jx_fm_exp(t, x); }
+    __device__ __forceinline__ double l(double x) const { return jx_fm_log(t, x); }
+};
+template <class M>
+__device__ __forceinline__ void jx_prof_consts(const M& m, const double* p, int mode, double* pl) {
     const double ln10 = 2.30258509299404568402;
-    pl[0] = log(p[P_RP]);
+    pl[0] = m.l(p[P_RP]);
     pl[1] = (p[P_B] - p[P_C]) / p[P_A];
     pl[2] = p[P_LOGRC] * ln10;
-    pl[3] = exp(pl[2]);
+    pl[3] = m.e(pl[2]);
     pl[4] = p[P_LOGRS] * ln10;
     pl[5] = 3.0 * p[P_BETA] - p[P_ALPHA] / 2.0;
     pl[6] = p[P_EPS] / p[P_GAMMA];
-    pl[7] = exp(2.0 * ln10 * p[P_LOGN0]);
-    pl[8] = (mode == 1) ? exp(2.0 * ln10 * p[P_LOGN02]) : 0.0;
-    pl[9] = (mode == 1) ? exp(ln10 * p[P_LOGRC2]) : 1.0;
+    pl[7] = m.e(2.0 * ln10 * p[P_LOGN0]);
+    pl[8] = (mode == 1) ? m.e(2.0 * ln10 * p[P_LOGN02]) : 0.0;
+    pl[9] = (mode == 1) ? m.e(ln10 * p[P_LOGRC2]) : 1.0;
 }
 // pressure and x^a at radius r (lr = log r)
-__device__ __forceinline__ double jx_press_log(const double* p, const double* pl, double lr, double* xa_out) {
+template <class M>
+__device__ __forceinline__ double jx_press_log(const M& m, const double* p, const double* pl, double lr, double* xa_out) {
     const double lx = lr - pl[0];
-    const double xa = exp(p[P_A] * lx);
+    const double xa = m.e(p[P_A] * lx);
     *xa_out = xa;
-    return p[P_P0] * exp(-(p[P_C] * lx + pl[1] * log(1.0 + xa)));
+    return p[P_P0] * m.e(-(p[P_C] * lx + pl[1] * m.l(1.0 + xa)));
 }
-__device__ __forceinline__ double jx_ne_log(const double* p, const double* pl, double r, double lr, int mode) {
+template <class M>
+__device__ __forceinline__ double jx_ne_log(const M& m, const double* p, const double* pl, double r, double lr, int mode) {
     const double x = r / pl[3];
-    const double u = exp(p[P_GAMMA] * (lr - pl[4]));
-    double res = pl[7] * exp(-(p[P_ALPHA] * (lr - pl[2]) + pl[5] * log(1.0 + x * x) + pl[6] * log(1.0 + u)));
+    const double u = m.e(p[P_GAMMA] * (lr - pl[4]));
+    double res = pl[7] * m.e(-(p[P_ALPHA] * (lr - pl[2]) + pl[5] * m.l(1.0 + x * x) + pl[6] * m.l(1.0 + u)));
     if (mode == 1) {
         const double x2 = r / pl[9];
-        res += pl[8] * exp(-3.0 * p[P_BETA2] * log(1.0 + x2 * x2));
+        res += pl[8] * m.e(-3.0 * p[P_BETA2] * m.l(1.0 + x2 * x2));
     }
     return sqrt(res);
 }
@@ -246,7 +262,9 @@ __device__ __forceinline__ void jx_load_params(const JxDev& c, const double* __r
 // ------------------------------------------------------------------------------------
 // POW: the profiles with pow() as written in the reference (JOXSZ_PREP_POW=1) instead of through their exponents -- a
 // compile-time choice: the code of the form not taken would be a quarter of the kernel and its registers the kernel's.
-template <bool POW>
+// FM: exp and log of the log form through the tables of jx_fastmath.hpp (staged in LDS behind the conversion table): 16 and 22
+// vector instructions instead of the device library's 38 and 95; held to 2 ulp (JOXSZ_PREP_FASTMATH=0: the library's).
+template <bool POW, bool FM = false>
 __global__ void __launch_bounds__(JX_PREP_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
                double* __restrict__ base, double* __restrict__ cfac, double* __restrict__ pp_out /*[chunk][N] or null*/,
@@ -266,6 +284,10 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
     double* s_T = s_ne + c.nann;              // [nann]
     double* s_rate = s_T + c.nann;            // [nband*nann]
     double* s_conv = s_rate + c.nband * c.nann;   // [2 nconv] the Compton -> mJy/beam table (temperatures, factors)
+    double* s_fm = s_conv + 2 * c.nconv;          // [JX_FM_TABLE_DOUBLES] exp / log tables (FM)
+    static_assert(!(POW && FM), "the tables serve the log form");
+    typename std::conditional<FM, JxMathTab, JxMathLib>::type mt;
+    if constexpr (FM) { mt.t.et = s_fm; mt.t.lt = s_fm + JX_FM_EXP_N; }
 
     // the constants of this thread's prior are requested before the parameters are assembled (they do not depend on them)
     const bool has_par = tid < c.npar;
@@ -274,6 +296,7 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
     const double pk_b = has_par ? (pk_kind == 1 ? c.par_sigma[tid] : c.par_max[tid]) : 0.0;
     const double pk_ln = has_par ? c.par_lnorm[tid] : 0.0;
     for (int i = tid; i < 2 * c.nconv; i += nth) s_conv[i] = (i < c.nconv) ? c.conv_T[i] : c.conv_v[i - c.nconv];   // (visible behind the barriers of jx_load_params)
+    if (FM) for (int i = tid; i < JX_FM_TABLE_DOUBLES; i += nth) s_fm[i] = c.fm_tab[i];
     jx_load_params(c, theta, gw, p);
     double pc[5] = {0, 1, 1, 0, 1};           // radius-independent factors of the density (every thread its own copy)
     if (POW) jx_ne_consts(p, c.ne_mode, pc);
@@ -307,7 +330,7 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
     double ci = 0.0;                          // this thread's share of integ_wp . pp
     constexpr bool logform = !POW;
     double pl[10];
-    jx_prof_consts(p, c.ne_mode, pl);
+    jx_prof_consts(mt, p, c.ne_mode, pl);
     const int N_ = c.N, nt_ = c.nt, mode_ = c.ne_mode;
     if (logform) {
         // Two radii per trip, straight-line: the evaluations are chains of dependent fp64 operations, and two independent
@@ -318,8 +341,8 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
             const bool two = i + nth < nprof;
             const double ra = c.r_pp[i], rb = c.r_pp[i2], lra = c.lr_pp[i], lrb = c.lr_pp[i2];
             double xaa, xab;
-            const double pa = jx_press_log(p, pl, lra, &xaa), pb = jx_press_log(p, pl, lrb, &xab);
-            const double na = jx_ne_log(p, pl, ra, lra, mode_), nb = jx_ne_log(p, pl, rb, lrb, mode_);
+            const double pa = jx_press_log(mt, p, pl, lra, &xaa), pb = jx_press_log(mt, p, pl, lrb, &xab);
+            const double na = jx_ne_log(mt, p, pl, ra, lra, mode_), nb = jx_ne_log(mt, p, pl, rb, lrb, mode_);
             // positive constant factors of mass_fun cannot change the sign test
             const double ma = pa * (p[P_C] + p[P_B] * xaa) / (ra * (1.0 + xaa)) * ra * ra / na;
             const double mb = pb * (p[P_C] + p[P_B] * xab) / (rb * (1.0 + xab)) * rb * rb / nb;
@@ -387,9 +410,9 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
             const int grp = tid >> 6, k = tid & 63;
             if (k < c.nann && grp < 3) {
                 const double rn = c.x_r_ne[k], r = c.x_r_T[k];
-                if (grp == 0) s_ne[k] = jx_ne_log(p, pl, rn, log(rn), c.ne_mode);
-                else if (grp == 1) { double xa; s_T[k] = jx_press_log(p, pl, log(r), &xa) * exp(2.30258509299404568402 * p[P_LOGTR]); }
-                else s_x[k] = (rn == r) ? 0.0 : jx_ne_log(p, pl, r, log(r), c.ne_mode);
+                if (grp == 0) s_ne[k] = jx_ne_log(mt, p, pl, rn, mt.l(rn), c.ne_mode);
+                else if (grp == 1) { double xa; s_T[k] = jx_press_log(mt, p, pl, mt.l(r), &xa) * mt.e(2.30258509299404568402 * p[P_LOGTR]); }
+                else s_x[k] = (rn == r) ? 0.0 : jx_ne_log(mt, p, pl, r, mt.l(r), c.ne_mode);
             }
             __syncthreads();
             if (tid < c.nann) s_T[tid] = s_T[tid] / ((c.x_r_ne[tid] == c.x_r_T[tid]) ? s_ne[tid] : s_x[tid]);   // T_X
@@ -397,9 +420,9 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
             const double rn = c.x_r_ne[tid], r = c.x_r_T[tid];
             if (logform) {
                 double xa;
-                const double lr = log(r);
-                s_ne[tid] = jx_ne_log(p, pl, rn, (rn == r) ? lr : log(rn), c.ne_mode);
-                s_T[tid] = jx_press_log(p, pl, lr, &xa) / jx_ne_log(p, pl, r, lr, c.ne_mode) * exp(2.30258509299404568402 * p[P_LOGTR]);   // T_X
+                const double lr = mt.l(r);
+                s_ne[tid] = jx_ne_log(mt, p, pl, rn, (rn == r) ? lr : mt.l(rn), c.ne_mode);
+                s_T[tid] = jx_press_log(mt, p, pl, lr, &xa) / jx_ne_log(mt, p, pl, r, lr, c.ne_mode) * mt.e(2.30258509299404568402 * p[P_LOGTR]);   // T_X
             } else {
                 s_ne[tid] = jx_ne_pc(p, pc, rn, c.ne_mode);
                 s_T[tid] = jx_press(p, r) / jx_ne_pc(p, pc, r, c.ne_mode) * pow(10.0, p[P_LOGTR]);   // T_X
@@ -409,11 +432,11 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
         const int nba = c.nband * c.nann;
         for (int q = tid; q < nba; q += nth) {
             const int b = q / c.nann, j = q - b * c.nann;
-            const double lt = log(s_T[j]);
+            const double lt = mt.l(s_T[j]);
             const double* tab = c.lnrate + (size_t)b * 2 * c.ntab;
             double i0, i1;                     // one search of the temperature grid serves both metallicity tables
             jx_interp_clamped2(c.lnT, tab, tab + c.ntab, c.ntab, lt, c.inv_dlnT, &i0, &i1);
-            const double z0 = exp(i0), z1 = exp(i1);
+            const double z0 = mt.e(i0), z1 = mt.e(i1);
             s_rate[q] = (z0 + (z1 - z0) * p[P_Z]) * s_ne[j] * s_ne[j];
         }
         __syncthreads();
@@ -428,7 +451,7 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
             if (tap_xprofs) tap_xprofs[(size_t)w * nba + q] = model;
             if (!(model > 0.0)) bad = 1;       // np.array(profs).min() > 0 fails (NaN included)
             const double ct = c.cts[q];
-            if (ct == ct) lk += ct * log(model) - model;
+            if (ct == ct) lk += ct * mt.l(model) - model;
         }
         xlike = jx_block_sum(lk, red);
         if (bad) rej |= REJ_XRAY;              // (the block-wide OR of rej below carries it to everybody)
@@ -468,12 +491,13 @@ jx_pp_kernel(JxDev c, const double* __restrict__ theta, int w0, double* __restri
         for (int i = tid; i < N_; i += nth) out[i] = jx_press(p, c.r_pp[i]);
     } else {
         double pl[10];
-        jx_prof_consts(p, c.ne_mode, pl);
+        const JxMathLib mt;
+        jx_prof_consts(mt, p, c.ne_mode, pl);
         // (two radii per trip, like the grid pass of jx_prep_kernel: two independent chains per lane)
         for (int i = tid; i < N_; i += 2 * nth) {
             const int i2 = min(i + nth, N_ - 1);
             double xa, xb;
-            const double pa = jx_press_log(p, pl, c.lr_pp[i], &xa), pb = jx_press_log(p, pl, c.lr_pp[i2], &xb);
+            const double pa = jx_press_log(mt, p, pl, c.lr_pp[i], &xa), pb = jx_press_log(mt, p, pl, c.lr_pp[i2], &xb);
             out[i] = pa;
             if (i + nth < N_) out[i2] = pb;
         }

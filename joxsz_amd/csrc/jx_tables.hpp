@@ -680,6 +680,24 @@ inline bool mix_column_tables(const std::vector<double>& Qtab /*[qn][qn]: (|iy-c
 }
 
 // ---------------------------------------------------------------------------------------
+// Tables of jx_fastmath.hpp: [64] 2^(j/64), then [128][2] (1/c_i, log c_i) for the 128 intervals of z in [OFF, 2 OFF) that the
+// high mantissa bits select (OFF = the double with high word 0x3FE5F000: 1.0 is the centre of interval 80, which gets c = 1
+// exactly); c_i = 1 / (the double nearest to the reciprocal of the interval's centre), so that z / c_i - 1 is one fused
+// multiply-add.  Built in long double.
+// ---------------------------------------------------------------------------------------
+inline void fastmath_tables(std::vector<double>& t) {
+    t.assign(64 + 2 * 128, 0.0);
+    for (int j = 0; j < 64; ++j) t[j] = (double)exp2l((long double)j / 64.0L);
+    auto from_hi = [](uint32_t hi) { const uint64_t b = (uint64_t)hi << 32; double d; memcpy(&d, &b, 8); return d; };
+    for (int i = 0; i < 128; ++i) {
+        const double z0 = from_hi(0x3FE5F000u + ((uint32_t)i << 13)), z1 = from_hi(0x3FE5F000u + ((uint32_t)(i + 1) << 13));
+        double invc = (double)(1.0L / (((long double)z0 + (long double)z1) / 2.0L)), logc = (double)(-logl((long double)invc));
+        if (i == 80) { invc = 1.0; logc = 0.0; }
+        t[64 + 2 * i] = invc; t[64 + 2 * i + 1] = logc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // Rows (= columns) of the quadrant that stage 1 evaluates.  Away from the cluster core the Compton-y map varies on the scale
 // of the radius, far above the pixel: the quadrant is recoverable from a subset of its rows and columns by local polynomial
 // interpolation, Q ~ L Q_sub L^T, and the contraction needs only the transformed operators C_sub = L^T C (stage 1) and

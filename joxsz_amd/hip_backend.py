@@ -20,7 +20,7 @@ EXPORTS = (
     'jx_timing_reset', 'jx_timing_enable', 'jx_timing_get', 'jx_get_info', 'jx_get_conv_mode', 'jx_get_conv_layout', 'jx_debug_workspace', 'jx_device_count',
     'jx_device_name', 'jx_strerror', 'jx_last_error', 'jx_destroy',
     'jx_get_truncation', 'jx_get_output_pruning', 'jx_get_sampling', 'jx_comm_unique_id', 'jx_comm_init_rank', 'jx_allgather_logp', 'jx_comm_allreduce_max', 'jx_comm_destroy',
-    'jx_comm_count', 'jx_comm_set_overlap', 'jx_comm_gather_time', 'jx_map_kernel_time', 'jx_event_bracket_time', 'jx_copy_bandwidth', 'jx_stream_bandwidth',
+    'jx_comm_count', 'jx_comm_set_overlap', 'jx_comm_gather_time', 'jx_map_kernel_time', 'jx_event_bracket_time', 'jx_fastmath_eval', 'jx_copy_bandwidth', 'jx_stream_bandwidth',
 )
 
 TENSORS = ('r_pp', 'd_mat', 'beam_2d', 'filtering', 'radius', 'flux_data', 'conv_T', 'conv_v',
@@ -108,6 +108,7 @@ def load_library(path=None):
     lib.jx_comm_gather_time.argtypes = [vp, dp, i64p]
     lib.jx_map_kernel_time.argtypes = [vp, vp, ci, ci, dp]
     lib.jx_event_bracket_time.argtypes = [vp, ci, dp]
+    lib.jx_fastmath_eval.argtypes = [vp, dp, ci, dp, dp]
     lib.jx_copy_bandwidth.argtypes = [vp, cs, ci, dp]
     lib.jx_stream_bandwidth.argtypes = [vp, ci, cs, ci, dp]
     lib.jx_device_count.argtypes = []
@@ -434,6 +435,14 @@ class HipContext:
         if n < 0:
             self._chk(n, 'jx_comm_count')
         return n
+
+    def fastmath_eval(self, x):
+        """Test hook: (exp(x), log(x)) as the per-walker kernel's table-driven functions compute them (``jx_fastmath_eval``)."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        e, l = np.empty_like(x), np.empty_like(x)
+        dp = ctypes.POINTER(ctypes.c_double)
+        self._chk(self.lib.jx_fastmath_eval(self._h, x.ctypes.data_as(dp), int(x.size), e.ctypes.data_as(dp), l.ctypes.data_as(dp)), 'jx_fastmath_eval')
+        return e, l
 
     def event_bracket_time(self, repeats=64):
         """What a pair of HIP events around one kernel of a dependent chain reads when the kernel does nothing (``jx_event_bracket_time``), ms."""
