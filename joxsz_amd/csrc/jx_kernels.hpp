@@ -128,6 +128,16 @@ __device__ __forceinline__ double jx_ne_pc(const double* p, const double* pc, do
     }
     return sqrt(res);
 }
+// 1 / n_e: all the grid pass needs of the density (T_SZ = P / n_e, the mass profile ~ 1 / n_e).  Single-beta model: the square
+// root and the division go into the exponent, n_e^-1 = n_0^-1 exp(+E / 2); double-beta: through jx_ne_log.
+template <class M>
+__device__ __forceinline__ double jx_inv_ne_log(const M& m, const double* p, const double* pl, double r, double lr, int mode) {
+    if (mode == 1) return 1.0 / jx_ne_log(m, p, pl, r, lr, mode);
+    const double x = r / pl[3];
+    const double u = m.e(p[P_GAMMA] * (lr - pl[4]));
+    return pl[10] * m.e(0.5 * (p[P_ALPHA] * (lr - pl[2]) + pl[5] * m.l(1.0 + x * x) + pl[6] * m.l(1.0 + u)));
+}
+
 
 // The two profiles in log form.  Every power in joxsz_funcs.py:275-287 and :375-395 has a positive base, so
 //     press = P0 exp(-(c lx + ((b-c)/a) log(1 + x^a))),   x^a = exp(a lx),   lx = log r - log r_p
@@ -159,6 +169,7 @@ __device__ __forceinline__ void jx_prof_consts(const M& m, const double* p, int 
     pl[7] = m.e(2.0 * ln10 * p[P_LOGN0]);
     pl[8] = (mode == 1) ? m.e(2.0 * ln10 * p[P_LOGN02]) : 0.0;
     pl[9] = (mode == 1) ? m.e(ln10 * p[P_LOGRC2]) : 1.0;
+    pl[10] = m.e(-ln10 * p[P_LOGN0]);              // 1 / sqrt(pl[7])
 }
 // pressure and x^a at radius r (lr = log r)
 template <class M>
@@ -329,7 +340,7 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
     const int nprof = (veto || pp_out || c.calc_integ) ? c.N : c.nt;
     double ci = 0.0;                          // this thread's share of integ_wp . pp
     constexpr bool logform = !POW;
-    double pl[10];
+    double pl[11];
     jx_prof_consts(mt, p, c.ne_mode, pl);
     const int N_ = c.N, nt_ = c.nt, mode_ = c.ne_mode;
     if (logform) {
@@ -342,15 +353,15 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
             const double ra = c.r_pp[i], rb = c.r_pp[i2], lra = c.lr_pp[i], lrb = c.lr_pp[i2];
             double xaa, xab;
             const double pa = jx_press_log(mt, p, pl, lra, &xaa), pb = jx_press_log(mt, p, pl, lrb, &xab);
-            const double na = jx_ne_log(mt, p, pl, ra, lra, mode_), nb = jx_ne_log(mt, p, pl, rb, lrb, mode_);
-            // positive constant factors of mass_fun cannot change the sign test
-            const double ma = pa * (p[P_C] + p[P_B] * xaa) / (ra * (1.0 + xaa)) * ra * ra / na;
-            const double mb = pb * (p[P_C] + p[P_B] * xab) / (rb * (1.0 + xab)) * rb * rb / nb;
+            const double ia = jx_inv_ne_log(mt, p, pl, ra, lra, mode_), ib = jx_inv_ne_log(mt, p, pl, rb, lrb, mode_);      // 1 / n_e
+            // positive constant factors of mass_fun cannot change the sign test:  -r^2 / n_e dP/dr ~ P (c + b x^a) r / ((1 + x^a) n_e)
+            const double ma = pa * (p[P_C] + p[P_B] * xaa) * ra * ia / (1.0 + xaa);
+            const double mb = pb * (p[P_C] + p[P_B] * xab) * rb * ib / (1.0 + xab);
             if (pp_out) { pp_out[(size_t)w * N_ + i] = pa; if (two) pp_out[(size_t)w * N_ + i2] = pb; }
             if (c.calc_integ) { ci = fma(c.integ_wp[i], pa, ci); if (two) ci = fma(c.integ_wp[i2], pb, ci); }
             if (veto) { s_m[i] = ma; if (two) s_m[i2] = mb; }
-            if (i < nt_) s_t[i] = pa / na;
-            if (two && i2 < nt_) s_t[i2] = pb / nb;
+            if (i < nt_) s_t[i] = pa * ia;
+            if (two && i2 < nt_) s_t[i2] = pb * ib;
         }
     } else {
         for (int i = tid; i < nprof; i += nth) {
@@ -490,7 +501,7 @@ jx_pp_kernel(JxDev c, const double* __restrict__ theta, int w0, double* __restri
     if (POW) {
         for (int i = tid; i < N_; i += nth) out[i] = jx_press(p, c.r_pp[i]);
     } else {
-        double pl[10];
+        double pl[11];
         const JxMathLib mt;
         jx_prof_consts(mt, p, c.ne_mode, pl);
         // (two radii per trip, like the grid pass of jx_prep_kernel: two independent chains per lane)
