@@ -265,8 +265,8 @@ int  jx_get_conv_layout(jx_ctx* ctx, int32_t out[12]);
  * points; 1 when a sub-grid is in use; rebuilds in which the guard took it away; 0}; rows (optional, nrows_cap entries): the kept
  * indices.  Away from the cluster core the Compton-y map varies on the scale of the radius, far above the pixel, so the quadrant
  * is recoverable from a tensor sub-grid of its rows and columns by local polynomial interpolation, Q ~ L Q_sub L^T, and the
- * contraction needs only the transformed operators L^T C and G (L x I): measured error 1e-12 of the row's maximum over the prior
- * box (profiles/r04_subsample_proto.log), measured again on the caller's data by the guard of jx_get_truncation, which takes the
+ * contraction needs only the transformed operators L^T C and G (L x I): measured error 1e-13 of the row's maximum over the outputs in use
+ * at the corners of the prior box in (a, b, r_p), 1e-8 on the log-posterior over the whole box (profiles/r04_subsample_check.log, r04_box_parity.log), measured again on the caller's data by the guard of jx_get_truncation, which takes the
  * sub-grid away first.  JOXSZ_MIX_SUBSAMPLE=0: every distinct sample; "u0,u1,npts": another sub-grid.  Not used when the quadrant
  * reaches beyond the radial grid (fill values: the map is not smooth there), nor by the full form. */
 int  jx_get_sampling(jx_ctx* ctx, int32_t out[8], int32_t* rows, int nrows_cap);

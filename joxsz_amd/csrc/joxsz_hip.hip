@@ -96,7 +96,7 @@ struct jx_ctx {
     int nrow = 0, nt = 0, Sh = 0, K = 0, chunk = 0, num_cu = 256;
     int nrow_use = 0;                  // outputs of the extracted row the data-radii spline reads with a weight above JX_PRUNE_TOL of its largest (<= nrow)
     bool subsample = true;             // JOXSZ_MIX_SUBSAMPLE=0: stage 1 evaluates every distinct map sample (default: a tensor sub-grid, the rest by interpolation folded into the operators)
-    int sub_u0 = 40, sub_u1 = 160, sub_npts = 12;   // full resolution below u0 pixels from the axis, every second row up to u1, every fourth up to 2 u1, every eighth beyond; interpolation points
+    int sub_u0 = 40, sub_u1 = 160, sub_npts = 14;   // full resolution below u0 pixels from the axis, every second row up to u1, every fourth up to 2 u1, every eighth beyond; interpolation points
     bool prune = true;                 // JOXSZ_PRUNE_OUTPUTS=0: the matrix-core product computes every output of the row, read or not
     int64_t device_bytes = 0;
     int conv_mode = 1;                 // 1 rocFFT sequence, 2 contracted route

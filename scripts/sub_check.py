@@ -26,7 +26,7 @@ pts = np.array(pts)
 os.environ['JOXSZ_MIX_FORM'] = 'full'
 os.environ['JOXSZ_TRUNC_PROBE'] = '0'
 rows = {}
-for sub in ('0', '40,160,12', '48,160,12', '64,192,12', '40,160,8', '40,160,16', '24,96,12'):
+for sub in ('0', '40,160,14', '40,160,12', '48,160,14', '64,192,14', '40,160,8', '40,160,16', '24,96,12'):
     os.environ['JOXSZ_MIX_SUBSAMPLE'] = sub
     post = JoxszPosterior(pb, device=0)
     rows[sub] = (post.stage(pts, 'map_row'), post.stage(pts, 'pp'), post.ctx.sampling['rows_evaluated'])

@@ -562,6 +562,47 @@ def test_sub_grid_is_not_taken_beyond_the_radial_grid_and_the_guard_removes_a_co
     np.testing.assert_array_equal(a, b)
 
 
+@pytest.mark.parametrize('S,N,measured', [(512, 500, False), (512, 500, True), (256, 300, False)])
+def test_default_route_over_the_whole_prior_box_against_the_oracle(S, N, measured):
+    """The approximations of the default route (the truncated transfer-function expansion, the sub-grid of map samples, the
+    table-driven exp / log) are measured by the guard at nine points; here walkers drawn UNIFORMLY OVER THE WHOLE PRIOR BOX -- steep
+    and flat profiles, knees, everything the box allows, not a ball around the fiducial vector -- go through the default route and
+    through the CPU oracle: the same walkers rejected, the others within north_star's 1e-6 (observed: < 1e-8).  Synthetic and
+    measured (bundled) beam and transfer function."""
+    from joxsz_amd import datasets
+    if measured:
+        from test_gpu_parity import _measured_problem
+        pb = _measured_problem(S, N)
+        p0 = orc.pars_dict(pb, datasets.fiducial_theta(pb))
+        datasets.fill_data(pb, orc.sz_stages(pb, p0)['bright'], orc.calc_profiles(pb, p0), seed=S)
+    else:
+        pb = _problem(S, N, seed=S + 11)
+    rng = np.random.default_rng(S + int(measured))
+    names = list(pb.par_names)
+    th0 = datasets.fiducial_theta(pb)
+    nw = 400                                                           # (most of the box is rejected: r_c > r_s, the mass veto, non-positive count rates)
+    th = np.repeat(th0[None, :], nw, axis=0)
+    for k, ip in enumerate(pb.thawed_idx):
+        lo, hi = pb.par_min[ip], pb.par_max[ip]
+        if np.isfinite(lo) and np.isfinite(hi) and hi > lo:
+            th[:, k] = rng.uniform(lo, hi, nw)
+        elif pb.par_kind[ip] == 1 and pb.par_sigma[ip] > 0:
+            th[:, k] = pb.par_mu[ip] + pb.par_sigma[ip] * rng.uniform(-3.0, 3.0, nw)
+    post = _post(pb)
+    got = post.log_prob(th)
+    smp, form = post.ctx.sampling, post.ctx.conv_layout['form']
+    post.close()
+    want = orc.log_posterior_batch(pb, th)
+    fin = np.isfinite(want)
+    assert fin.sum() >= 20, (fin.sum(), names)
+    assert np.array_equal(np.isfinite(got), fin)
+    rel = np.abs(got[fin] - want[fin]) / np.abs(want[fin])
+    print('whole prior box, S=%d N=%d %s: %d of %d walkers finite, form %s, sub-grid %s: log-posterior max rel err %.2e, median %.2e'
+          % (S, N, 'measured inputs' if measured else 'synthetic inputs', fin.sum(), nw, form, smp['active'], rel.max(), np.median(rel)))
+    assert rel.max() < 1e-6, (rel.max(), form, smp['active'])
+    assert np.median(rel) < 1e-9
+
+
 def test_truncation_guard_speaks_up_when_it_changes_the_tables():
     """Transfer functions that sit just over the guard's bounds at the default tables (a sharper and a softer normal-cdf
     roll-off than CL J1226.9+3332's, found with scripts/guard_scan.py): jx_finalize first takes the 16-term cap away, then --
