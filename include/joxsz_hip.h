@@ -266,9 +266,10 @@ int  jx_get_conv_layout(jx_ctx* ctx, int32_t out[12]);
  * indices.  Away from the cluster core the Compton-y map varies on the scale of the radius, far above the pixel, so the quadrant
  * is recoverable from a tensor sub-grid of its rows and columns by local polynomial interpolation, Q ~ L Q_sub L^T, and the
  * contraction needs only the transformed operators L^T C and G (L x I): measured error 1e-13 of the row's maximum over the outputs in use
- * at the corners of the prior box in (a, b, r_p), 1e-8 on the log-posterior over the whole box (profiles/r04_subsample_check.log, r04_box_parity.log), measured again on the caller's data by the guard of jx_get_truncation, which takes the
- * sub-grid away first.  JOXSZ_MIX_SUBSAMPLE=0: every distinct sample; "u0,u1,npts": another sub-grid.  Not used when the quadrant
- * reaches beyond the radial grid (fill values: the map is not smooth there), nor by the full form. */
+ * at the corners of the prior box in (a, b, r_p), 1e-8 on the log-posterior over the whole box (profiles/r04_subsample_check.log,
+ * r04_box_parity.log), measured again on the caller's data by the guard of jx_get_truncation, which takes the sub-grid away first.  JOXSZ_MIX_SUBSAMPLE=0: every distinct sample; "u0,u1,npts": another sub-grid.  Not used when the quadrant
+ * reaches beyond the radial grid (fill values: the map is not smooth there), nor where nothing could measure it (radial grids beyond
+ * the Abel kernel's LDS).  Both forms of the contracted route use it. */
 int  jx_get_sampling(jx_ctx* ctx, int32_t out[8], int32_t* rows, int nrows_cap);
 /* Which outputs of the extracted row the matrix-core product computes when no tap asks for the row: out = {nrow; outputs the
  * data-radii spline of the tail (joxsz_funcs.py:476) reads with a weight above 1e-22 of its largest -- the cardinal functions
