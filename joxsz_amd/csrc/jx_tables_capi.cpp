@@ -170,4 +170,12 @@ int jxt_mix_interp_matrix(int NU, const int* sub, int ns, int npts, double* L /*
     return 0;
 }
 
+// tables of csrc/jx_fastmath.hpp: out[0..64) = 2^(j/64), out[64..320) = (1/c_i, log c_i) of the 128 mantissa intervals
+int jxt_fastmath_tables(double* out /*[320]*/) {
+    std::vector<double> t;
+    jxt::fastmath_tables(t);
+    memcpy(out, t.data(), sizeof(double) * t.size());
+    return (int)t.size();
+}
+
 }  // extern "C"

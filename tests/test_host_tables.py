@@ -447,6 +447,57 @@ def test_full_operator_through_the_sub_grid_against_the_oracle(lib, S, N):
     assert np.abs(out - ref['map_row']).max() <= 1e-11 * scale
 
 
+def test_fastmath_tables_and_the_scheme_they_serve(lib):
+    """csrc/jx_fastmath.hpp on the CPU: the tables the per-walker kernel stages in LDS (jxt::fastmath_tables) are what the scheme
+    assumes -- 2^(j/64) and, for each of the 128 mantissa intervals, 1/c and log c with c = 1 exactly where 1.0 sits -- and the scheme
+    itself, restated in numpy with long double standing in for the fused multiply-adds, stays within 2 ulp of exp and log in long
+    double (the device functions are held to the same bar on the GPU: tests/test_gpu_fastmath.py)."""
+    tab = np.zeros(320)
+    lib.jxt_fastmath_tables.argtypes = [DP]
+    assert lib.jxt_fastmath_tables(_p(tab)) == 320
+    LD = np.longdouble
+    et, lt = tab[:64], tab[64:].reshape(128, 2)
+    np.testing.assert_allclose(et.astype(LD), np.exp2(np.arange(64, dtype=LD) / 64), rtol=1.2e-16)
+    hi0 = 0x3FE5F000
+    z0 = (np.array([(hi0 + (i << 13)) << 32 for i in range(129)], dtype=np.uint64)).view(np.float64)
+    assert z0[80] == 1.0 - 2.0 ** -9 and z0[81] == 1.0 + 2.0 ** -8 and lt[80, 0] == 1.0 and lt[80, 1] == 0.0
+    for i in range(128):                                                  # |z / c - 1| < 2^-7.9 over the interval; log c to half an ulp
+        for z in (z0[i], np.nextafter(z0[i + 1], 0.0)):
+            assert abs(LD(z) * LD(lt[i, 0]) - 1) < 2.0 ** -7.9, i
+        assert abs(LD(lt[i, 1]) + np.log(LD(lt[i, 0]))) <= 0.51 * np.spacing(abs(lt[i, 1])) + 1e-300
+    rng = np.random.default_rng(0)
+
+    def ulps(got, want):
+        return np.abs((got.astype(LD) - want) / np.spacing(np.abs(want.astype(np.float64))).astype(LD)).astype(np.float64)
+
+    # exp: x = (64 m + j) ln 2 / 64 + r
+    x = np.concatenate((rng.uniform(-700, 700, 200000), rng.uniform(-1e-3, 1e-3, 50000)))
+    kd = np.rint(x * 92.332482616893657)
+    r = ((x.astype(LD) - kd.astype(LD) * LD(1.08304246932675596e-02)) - kd.astype(LD) * LD(2.98158582698529328e-12)).astype(np.float64)
+    k = kd.astype(np.int64)
+    p = r * (1 + r * (0.5 + r * (1 / 6 + r * (1 / 24 + r * (1 / 120 + r / 720)))))
+    sv = et[k & 63]
+    got = np.ldexp((sv.astype(LD) * p.astype(LD) + sv.astype(LD)).astype(np.float64), (k >> 6).astype(np.int32))
+    assert ulps(got, np.exp(x.astype(LD))).max() < 2.0
+    # log: x = 2^k z, z in [OFF, 2 OFF)
+    x = np.concatenate((np.exp(rng.uniform(np.log(1e-300), np.log(1e300), 200000)), rng.uniform(0.5, 2.0, 100000), 1.0 + rng.uniform(-1e-6, 1e-6, 20000)))
+    bits = x.view(np.uint64)
+    hi = (bits >> np.uint64(32)).astype(np.int64)
+    tmp = hi - hi0
+    i = (tmp >> 13) & 127
+    kk = tmp >> 20
+    z = (((hi - (kk << 20)).astype(np.uint64) << np.uint64(32)) | (bits & np.uint64(0xFFFFFFFF))).view(np.float64)
+    invc, logc = lt[i, 0], lt[i, 1]
+    rr = (z.astype(LD) * invc.astype(LD) - 1).astype(np.float64)
+    kd = kk.astype(np.float64)
+    w = (kd.astype(LD) * LD(0.69314718055989033) + logc.astype(LD)).astype(np.float64)
+    q = ((((rr / 7 - 1 / 6) * rr + 1 / 5) * rr - 1 / 4) * rr + 1 / 3) * rr - 0.5
+    hi2 = w + rr
+    lo = (w - hi2) + rr + kd * 5.49792301870837116e-14
+    got = (q.astype(LD) * (rr * rr).astype(LD) + lo.astype(LD)).astype(np.float64) + hi2
+    assert ulps(got, np.log(x.astype(LD))).max() < 2.0
+
+
 @pytest.mark.parametrize('S', [171, 256, 512, 513, 1024])
 def test_the_data_radii_spline_reads_a_bounded_part_of_the_row(lib, S):
     """DESIGN 4.1 on the CPU: the evaluation matrix E of the not-a-knot spline through the extracted row (joxsz_funcs.py:476), as the
