@@ -1533,7 +1533,10 @@ static int ensure_ref(jx_ctx* ctx) {
 
 // One chunk: walkers [w0, w0+n) of the batch whose thetas live at theta_dev.  use_ref: through the reference facility
 // (rocFFT sequence) of a contracted-route context instead of its own back end.
-static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int w0, int n, const Taps& t, bool use_ref = false) {
+static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int w0, int n, const Taps& t, bool use_ref = false, const JxSm* smp = nullptr /* contracted route: the stretch move inside the per-walker kernel and the tail */) {
+    JxSm smv;
+    memset(&smv, 0, sizeof(smv));
+    if (smp) smv = *smp;
     const bool fftb = ctx->conv_mode == 1 || use_ref;
     const JxDev& d = fftb ? ctx->fft.d : ctx->d;
     const bool op_route = ctx->route == JX_ROUTE_OPERATOR && !t.pp && !ctx->d.inject_pp && !use_ref;   // stage taps and the operator build: map route
@@ -1581,11 +1584,11 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
         dp.inject_pp = ctx->d.inject_pp;
         const size_t sh = sizeof(double) * (JX_LDS_HDR + (size_t)2 * d.N + 2 * d.nann + (size_t)d.nband * d.nann + 2 * (size_t)d.nconv + 8 + JX_FM_TABLE_DOUBLES);
         if (d.prep_pow) hipLaunchKernelGGL((jx_prep_kernel<true, false>), dim3(n), dim3(JX_PREP_THREADS), sh, ps, dp, theta_dev, w0,
-                                           base_buf, cfac_buf, pp_buf, sz0_buf, t.tprof, t.xprofs, t.parts, t.integ);
+                                           base_buf, cfac_buf, pp_buf, sz0_buf, t.tprof, t.xprofs, t.parts, t.integ, smv);
         else if (ctx->prep_fastmath) hipLaunchKernelGGL((jx_prep_kernel<false, true>), dim3(n), dim3(JX_PREP_THREADS), sh, ps, dp, theta_dev, w0,
-                                                        base_buf, cfac_buf, pp_buf, sz0_buf, t.tprof, t.xprofs, t.parts, t.integ);
+                                                        base_buf, cfac_buf, pp_buf, sz0_buf, t.tprof, t.xprofs, t.parts, t.integ, smv);
         else hipLaunchKernelGGL((jx_prep_kernel<false, false>), dim3(n), dim3(JX_PREP_THREADS), sh, ps, dp, theta_dev, w0,
-                                base_buf, cfac_buf, pp_buf, sz0_buf, t.tprof, t.xprofs, t.parts, t.integ);
+                                base_buf, cfac_buf, pp_buf, sz0_buf, t.tprof, t.xprofs, t.parts, t.integ, smv);
     };
     {
         double* pp_buf = op_route ? ctx->d_pp : ((ag && !ctx->d.inject_pp) ? ctx->d_ppc : (double*)nullptr);
@@ -1689,9 +1692,9 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
         const size_t sh = sizeof(double) * (JX_LDS_HDR + (size_t)d.nrow + 8);
         if (side) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_side, 0));
         if (ctx->f32c) hipLaunchKernelGGL(jx_tail_row_kernel<float>, dim3(n), dim3(JX_TAIL_THREADS), sh, st, d, reinterpret_cast<const float*>(m.Pt), nks,
-                                          ogt.pstride, ogt.ldx, nuse, ctx->d_cfac, ctx->d_sz0, ctx->d_base, logp_dev, w0, t.row, t.bright, t.chisq, t.parts);
+                                          ogt.pstride, ogt.ldx, nuse, ctx->d_cfac, ctx->d_sz0, ctx->d_base, logp_dev, w0, t.row, t.bright, t.chisq, t.parts, smv);
         else hipLaunchKernelGGL(jx_tail_row_kernel<double>, dim3(n), dim3(JX_TAIL_THREADS), sh, st, d, m.Pt, nks, ogt.pstride, ogt.ldx, nuse,
-                                ctx->d_cfac, ctx->d_sz0, ctx->d_base, logp_dev, w0, t.row, t.bright, t.chisq, t.parts);
+                                ctx->d_cfac, ctx->d_sz0, ctx->d_base, logp_dev, w0, t.row, t.bright, t.chisq, t.parts, smv);
 
         if (tm) HIPCHK(ctx, hipEventRecord(es.e[5], st));
         if (tm || tm2) ctx->ev_inflight.push_back(es);
@@ -1961,9 +1964,21 @@ int jx_sample(jx_ctx* ctx, const double* theta0, int nwalkers, int nsteps, doubl
         for (double v : l0) if (!std::isfinite(v)) { ctx->err = "initial positions must have finite log-posterior"; return JX_ERR_INVALID; }
     }
     const dim3 grid((half + 255) / 256), block(256);
+    const bool fused = ctx->conv_mode == 2 && ctx->route != JX_ROUTE_OPERATOR && !ctx->side_stream && !(env_str("JOXSZ_SAMPLE_FUSED") && atoi(env_str("JOXSZ_SAMPLE_FUSED")) == 0);
     for (int it = 0; it < nsteps; ++it) {
         for (int hs = 0; hs < 2; ++hs) {
             const int s1 = hs * half, s2 = (1 - hs) * half;
+            if (fused) {
+                // contracted route: the proposal is drawn by the per-walker kernel, the tail accepts or rejects -- five launches per half step, not seven
+                JxSm sm;
+                memset(&sm, 0, sizeof(sm));
+                sm.on = 1; sm.ndim = ndim; sm.half = half; sm.s1 = s1; sm.s2 = s2; sm.iter2 = 2 * it + hs; sm.a = a; sm.seed = seed;
+                sm.x = x; sm.q = q; sm.zz = zz; sm.lp = lp; sm.nacc = reinterpret_cast<long long*>(nacc);
+                Taps none;
+                for (int w0 = 0; w0 < half; w0 += ctx->chunk)
+                    if ((rc = run_chunk(ctx, q, lq, w0, std::min(ctx->chunk, half - w0), none, false, &sm))) return rc;
+                continue;
+            }
             hipLaunchKernelGGL(jx_sm_propose_kernel, grid, block, 0, st, x, q, zz, ndim, half, s1, s2, 2 * it + hs, a, seed);
             if ((rc = jx_eval_device(ctx, q, half, lq))) return rc;
             hipLaunchKernelGGL(jx_sm_accept_kernel, grid, block, 0, st, x, lp, q, lq, zz, nacc, ndim, half, s1, 2 * it + hs, seed);

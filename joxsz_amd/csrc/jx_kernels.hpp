@@ -251,14 +251,46 @@ __device__ __forceinline__ int jx_block_or(int v, int* redi) {
     return *redi;
 }
 
+// The stretch move folded into the likelihood's own kernels (jx_sample on the contracted route): the per-walker kernel draws the
+// proposal of its walker itself (what jx_sm_propose_kernel does, same arithmetic, same random numbers) and the tail accepts or
+// rejects it (jx_sm_accept_kernel) -- two launches fewer per half step.  on = 0: a plain evaluation.
+struct JxSm {
+    int on, ndim, half, s1, s2, iter2;
+    double a;
+    unsigned long long seed;
+    double* x;                   // [W][ndim] positions of the whole ensemble
+    double* q;                   // [half][ndim] proposals of this half step
+    double* zz;                  // [half] stretch factors
+    double* lp;                  // [W] log-posteriors of the ensemble
+    long long* nacc;             // [W] acceptance counters
+};
+__device__ __forceinline__ void jx_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* out);
+__device__ __forceinline__ double jx_u01(uint32_t hi, uint32_t lo);
+
 // full parameter vector of batch walker gw into p[0..JX_MAX_PAR) (LDS): the current values with the thawed ones
 // replaced by theta (updateThawed, joxsz_funcs.py:516).  Ends with a barrier.
-__device__ __forceinline__ void jx_load_params(const JxDev& c, const double* __restrict__ theta, int gw, double* p) {
+__device__ __forceinline__ void jx_load_params(const JxDev& c, const double* __restrict__ theta, int gw, double* p, const JxSm* sm = nullptr) {
     const int tid = threadIdx.x;
     // (all three requests first: one round trip to memory instead of two on the critical path of every per-walker kernel)
     const double pv = (tid < c.npar) ? c.par_vals[tid] : 0.0;
     const int ti = (tid < c.ndim) ? c.thawed_idx[tid] : -1;
-    const double tv = (tid < c.ndim) ? theta[(size_t)gw * c.ndim + tid] : 0.0;
+    double tv = 0.0;
+    if (sm && sm->on) {
+        // the proposal of walker gw of this half (jx_sm_propose_kernel's arithmetic: separately rounded operations, replayable on the host)
+        if (tid < c.ndim) {
+            uint32_t r[4];
+            jx_philox((uint32_t)gw, (uint32_t)sm->iter2, 0u, 0u, (uint32_t)sm->seed, (uint32_t)(sm->seed >> 32), r);
+            const double u1 = jx_u01(r[0], r[1]), u2 = jx_u01(r[2], r[3]);
+            const double t = __dadd_rn(__dmul_rn(sm->a - 1.0, u1), 1.0);
+            const double z = __ddiv_rn(__dmul_rn(t, t), sm->a);
+            int j = (int)__dmul_rn(u2, (double)sm->half);
+            j = min(j, sm->half - 1);
+            const double xp = sm->x[(size_t)(sm->s2 + j) * c.ndim + tid], xi = sm->x[(size_t)(sm->s1 + gw) * c.ndim + tid];
+            tv = __dsub_rn(xp, __dmul_rn(__dsub_rn(xp, xi), z));
+            sm->q[(size_t)gw * c.ndim + tid] = tv;
+            if (tid == 0) sm->zz[gw] = z;
+        }
+    } else if (tid < c.ndim) tv = theta[(size_t)gw * c.ndim + tid];
     if (tid < JX_MAX_PAR) p[tid] = pv;
     __syncthreads();
     if (ti >= 0) p[ti] = tv;
@@ -280,7 +312,8 @@ __global__ void __launch_bounds__(JX_PREP_THREADS) __attribute__((amdgpu_waves_p
 jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
                double* __restrict__ base, double* __restrict__ cfac, double* __restrict__ pp_out /*[chunk][N] or null*/,
                double* __restrict__ sz0 /*[chunk] integrated-Compton term of the SZ log-likelihood, or null*/,
-               double* __restrict__ tap_tprof, double* __restrict__ tap_xprofs, double* __restrict__ tap_parts, double* __restrict__ tap_integ) {
+               double* __restrict__ tap_tprof, double* __restrict__ tap_xprofs, double* __restrict__ tap_parts, double* __restrict__ tap_integ,
+               JxSm smv) {
     JX_LDS_DECL;
     double* p = sm;
     double* red = sm + 20;
@@ -308,7 +341,7 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
     const double pk_ln = has_par ? c.par_lnorm[tid] : 0.0;
     for (int i = tid; i < 2 * c.nconv; i += nth) s_conv[i] = (i < c.nconv) ? c.conv_T[i] : c.conv_v[i - c.nconv];   // (visible behind the barriers of jx_load_params)
     if (FM) for (int i = tid; i < JX_FM_TABLE_DOUBLES; i += nth) s_fm[i] = c.fm_tab[i];
-    jx_load_params(c, theta, gw, p);
+    jx_load_params(c, theta, gw, p, &smv);
     double pc[5] = {0, 1, 1, 0, 1};           // radius-independent factors of the density (every thread its own copy)
     if (POW) jx_ne_consts(p, c.ne_mode, pc);
 

@@ -675,7 +675,7 @@ jx_tail_row_kernel(JxDev c, const TP* __restrict__ Pt, int nks, long long pstrid
                    const double* __restrict__ cfac, const double* __restrict__ sz0,
                    const double* __restrict__ base, double* __restrict__ logp, int w0,
                    double* __restrict__ tap_row, double* __restrict__ tap_bright, double* __restrict__ tap_chisq,
-                   double* __restrict__ tap_parts) {
+                   double* __restrict__ tap_parts, JxSm smv) {
     JX_LDS_DECL;
     double* red = sm + 20;
     const int nrow = c.nrow;
@@ -730,6 +730,19 @@ jx_tail_row_kernel(JxDev c, const TP* __restrict__ Pt, int nks, long long pstrid
         double tot = (b == -INFINITY) ? -INFINITY : b + ll;
         if (tot != tot) tot = -INFINITY;             // never hand NaN to the sampler
         logp[w0 + w] = tot;
+        if (smv.on) {
+            // accept or reject the proposal of walker w0 + w of this half (jx_sm_accept_kernel's arithmetic and random number)
+            const int i = w0 + w;
+            uint32_t r[4];
+            jx_philox((uint32_t)i, (uint32_t)smv.iter2, 1u, 0u, (uint32_t)smv.seed, (uint32_t)(smv.seed >> 32), r);
+            const double u3 = jx_u01(r[0], r[1]);
+            const double lnpdiff = __dadd_rn(__dmul_rn((double)(smv.ndim - 1), log(smv.zz[i])), __dsub_rn(tot, smv.lp[smv.s1 + i]));
+            if (isfinite(tot) && log(u3) < lnpdiff) {
+                for (int dd = 0; dd < smv.ndim; ++dd) smv.x[(size_t)(smv.s1 + i) * smv.ndim + dd] = smv.q[(size_t)i * smv.ndim + dd];
+                smv.lp[smv.s1 + i] = tot;
+                smv.nacc[smv.s1 + i] += 1;
+            }
+        }
         if (tap_chisq) tap_chisq[w] = chisq;
         if (tap_parts) tap_parts[(size_t)w * 4 + 1] = ll;
     }

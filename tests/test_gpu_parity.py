@@ -547,6 +547,32 @@ def test_device_sampler_against_host_replay():
     assert not np.array_equal(chain, DeviceStretchMove(_post(pb), seed=99).run(p0, 12)[0])
 
 
+def test_stretch_move_inside_the_likelihood_kernels_against_the_separate_kernels(monkeypatch):
+    """On the contracted route jx_sample draws a walker's proposal in the per-walker kernel and accepts or rejects it in the tail (five
+    launches per half step); JOXSZ_SAMPLE_FUSED=0 keeps the proposal and the acceptance as kernels of their own (seven): the same random
+    numbers, the same arithmetic -- identical chains, log-posteriors and acceptance counts, bit for bit; ragged ensembles and several
+    chunks per half included."""
+    from joxsz_amd import datasets
+    from joxsz_amd.sampler import DeviceStretchMove, initial_ball
+    pb = datasets.synthetic_problem(S=128, N=150, seed=5)
+    p0f = orc.pars_dict(pb, datasets.fiducial_theta(pb))
+    datasets.fill_data(pb, orc.sz_stages(pb, p0f)['bright'], orc.calc_profiles(pb, p0f), seed=5)
+    res = {}
+    for fused in ('1', '0'):
+        monkeypatch.setenv('JOXSZ_SAMPLE_FUSED', fused)
+        for nw, mb in ((90, 0), (90, 32)):                        # (max_batch 32: two chunks per half step, the second ragged)
+            post = _post(pb, **({'max_batch': mb} if mb else {}))
+            p0 = initial_ball(post.log_prob, datasets.fiducial_theta(pb), nw, spread=0.01, rng=np.random.default_rng(5))
+            res[(fused, mb)] = DeviceStretchMove(post, a=2.0, seed=77).run(p0, 10)
+            post.close()
+    for mb in (0, 32):
+        for a, b in zip(res[('1', mb)], res[('0', mb)]):
+            np.testing.assert_array_equal(a, b)
+    for a, b in zip(res[('1', 0)], res[('1', 32)]):              # and the chunking does not matter either
+        np.testing.assert_array_equal(a, b)
+    assert 0 < res[('1', 0)][2].sum() < 10 * 90
+
+
 def test_largest_config_shape():
     """BASELINE configs[4] shape (S=1024, N=1000): two walkers against the oracle, both back ends."""
     from joxsz_amd import datasets
