@@ -1965,6 +1965,12 @@ int jx_sample(jx_ctx* ctx, const double* theta0, int nwalkers, int nsteps, doubl
     }
     const dim3 grid((half + 255) / 256), block(256);
     const bool fused = ctx->conv_mode == 2 && ctx->route != JX_ROUTE_OPERATOR && !ctx->side_stream && !(env_str("JOXSZ_SAMPLE_FUSED") && atoi(env_str("JOXSZ_SAMPLE_FUSED")) == 0);
+    // shares of a half step: one per rank of the communicator, or JOXSZ_SAMPLE_VIRTUAL_RANKS of them run in turn by this process
+    const bool dist = ctx->comm != nullptr;                                  // (a communicator of one rank runs the same collectives: in place, on its own share = everything)
+    int nshare = dist ? ctx->comm_size : 1;
+    if (!dist) if (const char* e = env_str("JOXSZ_SAMPLE_VIRTUAL_RANKS")) nshare = std::max(1, atoi(e));
+    if (nshare > 1 && (!fused || half % nshare)) { ctx->err = "jx_sample over " + std::to_string(nshare) + " ranks: the contracted route and a half ensemble divisible by the ranks"; return JX_ERR_INVALID; }
+    const int r_first = dist ? ctx->comm_rank : 0, r_last = dist ? ctx->comm_rank + 1 : nshare;
     for (int it = 0; it < nsteps; ++it) {
         for (int hs = 0; hs < 2; ++hs) {
             const int s1 = hs * half, s2 = (1 - hs) * half;
@@ -1975,8 +1981,21 @@ int jx_sample(jx_ctx* ctx, const double* theta0, int nwalkers, int nsteps, doubl
                 sm.on = 1; sm.ndim = ndim; sm.half = half; sm.s1 = s1; sm.s2 = s2; sm.iter2 = 2 * it + hs; sm.a = a; sm.seed = seed;
                 sm.x = x; sm.q = q; sm.zz = zz; sm.lp = lp; sm.nacc = reinterpret_cast<long long*>(nacc);
                 Taps none;
-                for (int w0 = 0; w0 < half; w0 += ctx->chunk)
-                    if ((rc = run_chunk(ctx, q, lq, w0, std::min(ctx->chunk, half - w0), none, false, &sm))) return rc;
+                // Walkers shard over the ranks of the context's communicator (jx_comm_init_rank): the proposals of a half step read the OTHER half
+                // and the walker's own position only, so a rank moves its contiguous share of the half alone, and one in-place all-gather of the
+                // share's positions and log-posteriors brings every rank's copy of the ensemble up to date before the next half step -- the RCCL
+                // exchange of a real sampling run.  (JOXSZ_SAMPLE_VIRTUAL_RANKS=R, no communicator: the R shares one after the other in this
+                // process -- the same chain by construction; the test of the share arithmetic where there is one GPU.)
+                for (int r = r_first; r < r_last; ++r) {
+                    const int lo = (int)((long long)r * half / nshare), hi = (int)((long long)(r + 1) * half / nshare);
+                    for (int w0 = lo; w0 < hi; w0 += ctx->chunk)
+                        if ((rc = run_chunk(ctx, q, lq, w0, std::min(ctx->chunk, hi - w0), none, false, &sm))) return rc;
+                }
+                if (dist) {
+                    const size_t share = (size_t)half / nshare;
+                    NCCLCHK(ctx, g_rccl.AllGather(x + ((size_t)s1 + ctx->comm_rank * share) * ndim, x + (size_t)s1 * ndim, share * ndim, ncclDouble, ctx->comm, st));
+                    NCCLCHK(ctx, g_rccl.AllGather(lp + (size_t)s1 + ctx->comm_rank * share, lp + (size_t)s1, share, ncclDouble, ctx->comm, st));
+                }
                 continue;
             }
             hipLaunchKernelGGL(jx_sm_propose_kernel, grid, block, 0, st, x, q, zz, ndim, half, s1, s2, 2 * it + hs, a, seed);
@@ -1988,6 +2007,7 @@ int jx_sample(jx_ctx* ctx, const double* theta0, int nwalkers, int nsteps, doubl
     }
     if (chain) SCHK(hipMemcpyAsync(chain_out, chain, sizeof(double) * (size_t)nsteps * W * ndim, hipMemcpyDeviceToHost, st));
     if (lps) SCHK(hipMemcpyAsync(logp_out, lps, sizeof(double) * (size_t)nsteps * W, hipMemcpyDeviceToHost, st));
+    if (dist) NCCLCHK(ctx, g_rccl.AllReduce(nacc, nacc, (size_t)W, ncclInt64, ncclSum, ctx->comm, st));      // (a rank counted its own shares only)
     if (naccept_out) SCHK(hipMemcpyAsync(naccept_out, nacc, sizeof(long long) * (size_t)W, hipMemcpyDeviceToHost, st));
     SCHK(hipStreamSynchronize(st));
     SCHK(hipGetLastError());

@@ -47,6 +47,43 @@ def test_rccl_gather_through_the_c_abi_world_1():
     post.close()
 
 
+def test_device_sampler_over_ranks(monkeypatch):
+    """jx_sample shards every half step over the ranks of the context's communicator: a rank moves its contiguous share of the half
+    (proposal in the per-walker kernel, acceptance in the tail) and one in-place RCCL all-gather of the share's positions and
+    log-posteriors updates every rank's copy of the ensemble.  On the one GPU of a test box: (a) a communicator of one rank runs
+    those collectives for real (in place, share = the half) -- same chain as without a communicator; (b) JOXSZ_SAMPLE_VIRTUAL_RANKS=R
+    runs the R shares of a half step one after the other in one process -- the share arithmetic of R = 3 and 5 ranks, ragged
+    chunks included, gives the chain of one rank bit for bit (the shares of a half step do not read one another)."""
+    from joxsz_amd import datasets
+    from joxsz_amd.dist import RcclGather
+    from joxsz_amd.posterior import JoxszPosterior
+    from joxsz_amd.sampler import DeviceStretchMove, initial_ball
+    from joxsz_amd.hip_backend import JoxszHipError
+    from oracle import joxsz_oracle as orc
+    pb = datasets.synthetic_problem(S=96, N=120, seed=8)
+    p0f = orc.pars_dict(pb, datasets.fiducial_theta(pb))
+    datasets.fill_data(pb, orc.sz_stages(pb, p0f)['bright'], orc.calc_profiles(pb, p0f), seed=8)
+    post = JoxszPosterior(pb, device=0, max_batch=16)
+    p0 = initial_ball(post.log_prob, datasets.fiducial_theta(pb), 90, spread=0.01, rng=np.random.default_rng(8))    # half = 45 = 3 x 15 = 5 x 9
+    ref = DeviceStretchMove(post, a=2.0, seed=5).run(p0, 8)
+    assert 0 < ref[2].sum() < 8 * 90
+    for r in (3, 5):
+        monkeypatch.setenv('JOXSZ_SAMPLE_VIRTUAL_RANKS', str(r))
+        got = DeviceStretchMove(post, a=2.0, seed=5).run(p0, 8)
+        for a, b in zip(got, ref):
+            np.testing.assert_array_equal(a, b)
+    monkeypatch.setenv('JOXSZ_SAMPLE_VIRTUAL_RANKS', '4')          # 45 walkers do not split four ways: refused, loudly
+    with pytest.raises(JoxszHipError, match='divisible'):
+        DeviceStretchMove(post, a=2.0, seed=5).run(p0, 2)
+    monkeypatch.delenv('JOXSZ_SAMPLE_VIRTUAL_RANKS')
+    comm = RcclGather(post.ctx, rank=0, world=1)
+    got = DeviceStretchMove(post, a=2.0, seed=5).run(p0, 8)
+    comm.close()
+    post.close()
+    for a, b in zip(got, ref):
+        np.testing.assert_array_equal(a, b)
+
+
 def test_overlapped_gather_world_1():
     """jx_comm_set_overlap: the collectives on a second stream of the context, each behind an event.  Two alternating output
     buffers (what bench.py does) and ONE buffer written by every step (the evaluation must then wait for the gather that is
