@@ -175,7 +175,8 @@ int  jx_set_stream(jx_ctx* ctx, void* hip_stream);
  * theta0 [nwalkers][ndim] (finite log-posterior required, nwalkers even); chain_out [nsteps][nwalkers][ndim],
  * logp_out [nsteps][nwalkers], naccept_out [nwalkers] are host arrays and may be NULL.  Random numbers are
  * Philox4x32-10 keyed by seed with counter (walker slot, 2 iteration + half, draw, 0): a run is reproducible and can
- * be replayed on the host (joxsz_amd/sampler.py).  *
+ * be replayed on the host (joxsz_amd/sampler.py).
+ *
  * Over several GPUs: with a communicator on the context (jx_comm_init_rank) every rank calls jx_sample with the same arguments; a rank
  * moves its contiguous share of each half step (the half ensemble must divide by the ranks), then one in-place RCCL all-gather of
  * the share's positions and log-posteriors brings every rank's copy of the ensemble up to date; chains, log-posteriors and summed
