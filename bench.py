@@ -461,6 +461,26 @@ def main():
         except Exception as exc:
             host_ptr = {'error': str(exc)}
 
+    # the caller of the path: the device-resident stretch-move loop on an ensemble of 2 W walkers -- each half step one
+    # evaluation of W proposals, drawn in the per-walker kernel and accepted or rejected in the tail
+    samp = None
+    if rank == 0 and comm is None and args.route == 'map' and not args.no_host_pointer:
+        try:
+            x0 = np.ascontiguousarray(np.concatenate((theta, good[W:2 * W] if len(good) >= 2 * W else theta[::-1] * (1 + 1e-9))))
+            ns1, ns = 10, 60
+            ctx.sample(x0, ns)                                     # (warm-up at the longer length: the call's device buffers are sized once)                                       # (two run lengths: the slope is the step, the intercept the call's set-up, initial evaluation and copy back)
+            t = time.perf_counter()
+            ctx.sample(x0, ns1, seed=3)
+            t1 = time.perf_counter() - t
+            t = time.perf_counter()
+            _, lps_s, nacc_s = ctx.sample(x0, ns, seed=3)
+            dt = ((time.perf_counter() - t) - t1) / (ns - ns1)
+            samp = {'value': 2 * W / dt, 'unit': 'walker-updates/s', 'ms_per_step': 1e3 * dt, 'walkers': 2 * W, 'steps': ns, 'ms_per_call_besides_the_steps': 1e3 * (t1 - ns1 * dt),
+                    'acceptance': float(nacc_s.sum()) / (2 * W * ns), 'finite': bool(np.isfinite(lps_s).all()),
+                    'note': 'jx_sample: proposals, evaluation, accept/reject and chain on the device, one copy back at the end; a step = two half steps of %d walkers' % W}
+        except Exception as exc:
+            samp = {'error': str(exc)}
+
     # the fp32 variant on the same walkers (BASELINE configs[4]'s tolerance sweep): beside the f64 metric, never instead of it
     f32 = None
     if rank == 0 and comm is None and args.route == 'map' and args.dtype == 'f64' and not args.no_f32:
@@ -725,6 +745,7 @@ def main():
             'north_star_abel_map_kernel': full_map,
             'north_star_route': ns_route,
             'host_pointer': host_ptr,
+            'device_sampler': samp,
             'hbm_copy_bandwidth_measured_GBps': copy_gbs,
             'hbm_stream_bandwidth_measured_GBps': streams,
             'truncation': ctx.truncation,

@@ -79,6 +79,8 @@ def test_every_roofline_figure_of_the_line_follows_from_the_profiles():
     assert abs(ns['speedup_of_default_route'] - ns['ms_per_step'] / d['ms_per_step']) < 1e-9 * ns['speedup_of_default_route']
     hp = d['host_pointer']                                               # the path emcee calls
     assert hp['max_abs_diff_vs_device_resident'] == 0.0 and 0.5 * d['value'] < hp['value'] <= 1.02 * d['value']
+    ds = d['device_sampler']                                            # the caller of the path: the device-resident stretch-move loop
+    assert ds['finite'] and 0.2 < ds['acceptance'] < 0.6 and 0.7 * d['value'] < ds['value'] < 1.1 * d['value']
     fv = d['fp32_variant']
     assert fv['f32']['rel_dlogp_vs_f64']['max'] < 1e-8 and fv['f32c']['rel_dlogp_vs_f64']['max'] < 1e-6 and fv['f32c']['speedup_vs_f64'] > 1.05
     oc = d['other_configs']
