@@ -280,6 +280,14 @@ int  jx_get_conv_layout(jx_ctx* ctx, int32_t out[12]);
  * reaches beyond the radial grid (fill values: the map is not smooth there), nor where nothing could measure it (radial grids beyond
  * the Abel kernel's LDS).  Both forms of the contracted route use it. */
 int  jx_get_sampling(jx_ctx* ctx, int32_t out[8], int32_t* rows, int nrows_cap);
+/* Which radii of the pressure profile the spline-array product (jx_abel_gemm_kernel) multiplies: out = {radii of the grid N; radii in
+ * use; every radius below this index; every second up to here (u1), every fourth up to 2 u1, every eighth beyond; interpolation points;
+ * 1 when the sub-grid is in use}; rows (optional): the kept indices; returns how often the guard took the sub-grid away (>= 0).  The
+ * profile is smooth away from the core, so its values on a sub-grid of the radial grid carry the others by high-order interpolation,
+ * pp ~ L pp_sub, and the product needs only L^T Tm: K shrinks from N to the kept radii (222 of 500), and the k loop that bounds that
+ * kernel with it.  Measured on the caller's data by the guard of jx_get_truncation, which takes it away first.
+ * JOXSZ_AG_SUBSAMPLE=0: every radius; "u0,u1,npts": another sub-grid.  Not used where nothing could measure it. */
+int  jx_get_radial_sampling(jx_ctx* ctx, int32_t out[6], int32_t* rows, int nrows_cap);
 /* Which outputs of the extracted row the matrix-core product computes when no tap asks for the row: out = {nrow; outputs the
  * data-radii spline of the tail (joxsz_funcs.py:476) reads with a weight above 1e-22 of its largest -- the cardinal functions
  * of a cubic spline decay by 2 - sqrt(3) per knot, so the row beyond the last data radius + ~35 pixels does not reach an fp64

@@ -119,6 +119,13 @@ struct jx_ctx {
     // spline arrays as one matrix product (jx_abel_gemm_kernel)
     double* d_Tm = nullptr; int tm_ld = 0, tm_ntile = 0, tm_npair = 0;
     double* d_ppc = nullptr;           // [chunk][N] prep kernel -> jx_abel_gemm_kernel
+    // radial sub-grid of the spline-array product: Tm through the interpolation from the kept radii, their indices, the first k-step of every column tile
+    bool ag_sub = true;                // JOXSZ_AG_SUBSAMPLE=0: every radius of the profile; "u0,u1,npts": another sub-grid
+    int ag_u0 = 64, ag_u1 = 256, ag_npts = 18;
+    bool ag_sub_on = false;            // in use (set at the end of finalize_impl; the guard of jx_finalize may take it away)
+    int ag_ns = 0, ag_removed = 0;
+    double* d_Tm_s = nullptr; int* d_rsub = nullptr; int* d_tks = nullptr;
+    std::vector<int> h_rsub;
     bool abel_gemm = true;
     bool prep_fastmath = true;         // JOXSZ_PREP_FASTMATH=0: the per-walker kernel's exp / log from the device library instead of jx_fastmath.hpp's tables
     bool ag_single = false;            // JOXSZ_AG_SINGLE=1: one column tile per wave (twice the blocks) in the spline-array product
@@ -1192,6 +1199,12 @@ static int finalize_impl(jx_ctx* ctx) {
     if (const char* e = env_str("JOXSZ_ABEL_GEMM")) ctx->abel_gemm = atoi(e) != 0;
     if (const char* e = env_str("JOXSZ_AG_NARROW")) ctx->ag_narrow = atoi(e) != 0;
     if (const char* e = env_str("JOXSZ_AG_SINGLE")) ctx->ag_single = atoi(e) != 0;
+    if (const char* e = env_str("JOXSZ_AG_SUBSAMPLE")) {
+        int a0 = 0, a1 = 0, a2 = 0;
+        const int got = sscanf(e, "%d,%d,%d", &a0, &a1, &a2);
+        if (got == 1 && a0 == 0) ctx->ag_sub = false;
+        else if (got == 3 && a0 >= 8 && a1 >= a0 && a2 >= 4 && a2 <= 24) { ctx->ag_u0 = a0; ctx->ag_u1 = a1; ctx->ag_npts = a2; }
+    }
     if (const char* e = env_str("JOXSZ_PREP_FASTMATH")) ctx->prep_fastmath = atoi(e) != 0;
     ctx->op_narrow = env_str("JOXSZ_OP_NARROW") != nullptr;
     if (const char* e = env_str("JOXSZ_SIDE_STREAM")) ctx->side_on = atoi(e) != 0;
@@ -1455,6 +1468,41 @@ static int finalize_impl(jx_ctx* ctx) {
         }
         if ((rc = dev_put(ctx, h_Tm.data(), h_Tm.size(), &ctx->d_Tm))) return rc;
         if ((rc = dev_new(ctx, (size_t)chunk * N, &ctx->d_ppc, true))) return rc;
+        // The pressure profile is smooth away from the core: its values on a sub-grid of the radial grid carry the others by high-order
+        // interpolation, pp ~ L pp_sub, and the product needs only L^T Tm -- K shrinks from N to the kept radii (222 of 500, 285 of 1000)
+        // and with it the k loop that bounds the kernel.  Measured by the guard of jx_finalize like the sub-grid of map samples.
+        if (ctx->ag_sub && ctx->map_ok) {
+            std::vector<int> rs;
+            jxt::mix_row_subset(N, ctx->ag_u0, ctx->ag_u1, rs);
+            const int ns = (int)rs.size();
+            if (ns <= (3 * N) / 4 && ns >= 2 * ctx->ag_npts && ctx->ag_u0 >= ctx->ag_npts) {
+                std::vector<double> L;
+                jxt::mix_interp_matrix(N, rs, ctx->ag_npts, L);
+                const int ld = ctx->tm_ld, rows = JX_AG_ROWS(ns);
+                std::vector<double> Ts((size_t)rows * ld, 0.0);
+                for (int j = 0; j < N; ++j)
+                    for (int a = 0; a < ns; ++a) {
+                        const double l = L[(size_t)j * ns + a];
+                        if (l == 0.0) continue;
+                        const double* src = &h_Tm[(size_t)j * ld];
+                        double* dst = &Ts[(size_t)a * ld];
+                        for (int e = 0; e < ld; ++e) dst[e] += l * src[e];
+                    }
+                // first k-step (four rows) of every column tile with an entry; made non-decreasing in the tile (the kernel's blocks start at their lowest tile's)
+                std::vector<int> tks(ctx->tm_ntile, 0);
+                for (int t = 0; t < ctx->tm_ntile; ++t) {
+                    int first = ns;
+                    for (int a = 0; a < ns && first == ns; ++a)
+                        for (int e = 16 * t; e < std::min(16 * t + 16, ld); ++e) if (Ts[(size_t)a * ld + e] != 0.0) { first = a; break; }
+                    tks[t] = std::min(first, ns - 1) / 4;
+                }
+                for (int t = ctx->tm_ntile - 2; t >= 0; --t) tks[t] = std::min(tks[t], tks[t + 1]);
+                if ((rc = dev_put(ctx, Ts.data(), Ts.size(), &ctx->d_Tm_s))) return rc;
+                if ((rc = dev_put(ctx, rs.data(), rs.size(), &ctx->d_rsub))) return rc;
+                if ((rc = dev_put(ctx, tks.data(), tks.size(), &ctx->d_tks))) return rc;
+                ctx->h_rsub = rs; ctx->ag_ns = ns; ctx->ag_sub_on = true;
+            }
+        }
         HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_rowmix_mfma_kernel<JX_MIX_NS, double2>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
         HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_rowmix_mfma_kernel<JX_MIX_NS, float2>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
 #define JX_OPG_ATTR(Xv) HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_opgemm_kernel<1, Xv, double2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); \
@@ -1648,11 +1696,18 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
             const dim3 grid(narrow ? (n + 15) / 16 : (n + 31) / 32, gy);
             const double* pp_src = ctx->d.inject_pp ? ctx->d.inject_pp : ctx->d_ppc;
             const size_t shg = sizeof(double) * JX_OPM_JC * 33;
-#define JX_AG_GO(TOv, NWTv) hipLaunchKernelGGL((jx_abel_gemm_kernel<1, TOv, 1, NWTv>), grid, dim3(256), shg, st, pp_src, n, d.N, ctx->d_Tm, ctx->tm_ld, \
-                                               d.K, ctx->tm_ntile, ctx->tm_npair, reinterpret_cast<TOv*>(m.cft), m.tW, (long long)m.ncol)
-#define JX_AG_GO1(TOv) hipLaunchKernelGGL((jx_abel_gemm_kernel<1, TOv, 1, 2, 1>), dim3(grid.x, (unsigned)((ctx->tm_ntile + 3) / 4)), dim3(256), shg, st, pp_src, n, d.N, ctx->d_Tm, ctx->tm_ld, \
-                                               d.K, ctx->tm_ntile, ctx->tm_npair, reinterpret_cast<TOv*>(m.cft), m.tW, (long long)m.ncol)
-            if (ctx->ag_single && !narrow) { if (ctx->f32) JX_AG_GO1(float); else JX_AG_GO1(double); }
+            const bool rsg = ctx->ag_sub_on;                        // the radial sub-grid: K = the kept radii, gathered from the profiles
+            const int agN = rsg ? ctx->ag_ns : d.N;
+            const double* agT = rsg ? ctx->d_Tm_s : ctx->d_Tm;
+            const int* agR = rsg ? ctx->d_rsub : nullptr;
+            const int* agK = rsg ? ctx->d_tks : nullptr;
+#define JX_AG_GO(TOv, NWTv) do { if (rsg) hipLaunchKernelGGL((jx_abel_gemm_kernel<1, TOv, 1, NWTv, 0, true>), grid, dim3(256), shg, st, pp_src, n, agN, agT, ctx->tm_ld, \
+                                               d.K, ctx->tm_ntile, ctx->tm_npair, reinterpret_cast<TOv*>(m.cft), m.tW, (long long)m.ncol, agR, d.N, agK); \
+                                  else hipLaunchKernelGGL((jx_abel_gemm_kernel<1, TOv, 1, NWTv, 0, false>), grid, dim3(256), shg, st, pp_src, n, agN, agT, ctx->tm_ld, \
+                                               d.K, ctx->tm_ntile, ctx->tm_npair, reinterpret_cast<TOv*>(m.cft), m.tW, (long long)m.ncol, agR, d.N, agK); } while (0)
+#define JX_AG_GO1(TOv) hipLaunchKernelGGL((jx_abel_gemm_kernel<1, TOv, 1, 2, 1>), dim3(grid.x, (unsigned)((ctx->tm_ntile + 3) / 4)), dim3(256), shg, st, pp_src, n, agN, agT, ctx->tm_ld, \
+                                               d.K, ctx->tm_ntile, ctx->tm_npair, reinterpret_cast<TOv*>(m.cft), m.tW, (long long)m.ncol, agR, d.N, agK)
+            if (ctx->ag_single && !narrow && !rsg) { if (ctx->f32) JX_AG_GO1(float); else JX_AG_GO1(double); }
             else if (ctx->f32) { if (narrow) JX_AG_GO(float, 1); else JX_AG_GO(float, 2); }
             else { if (narrow) JX_AG_GO(double, 1); else JX_AG_GO(double, 2); }
 #undef JX_AG_GO
@@ -1804,7 +1859,7 @@ static void probe_vectors(jx_ctx* ctx, std::vector<double>& th, int* npts) {
 // all probe points (-1 each where nothing finite came back)
 static int measure_truncation(jx_ctx* ctx, double est[3], int* used) {
     est[0] = est[1] = est[2] = -1.0; *used = 0;
-    if (ctx->conv_mode != 2 || (ctx->mix.form != 0 && ctx->mix.sub.empty())) return JX_OK;   // nothing truncated, every distinct sample evaluated
+    if (ctx->conv_mode != 2 || (ctx->mix.form != 0 && ctx->mix.sub.empty() && !ctx->ag_sub_on)) return JX_OK;   // nothing truncated, every distinct sample and radius evaluated
     if (!ctx->map_ok) return JX_OK;                                         // nothing to measure against (and every term above rounding is kept)
     const jx_config& c = ctx->cfg;
     int rc, npts = 0;
@@ -1855,7 +1910,7 @@ int jx_finalize(jx_ctx* ctx) {
     int rc = finalize_impl(ctx);
     if (rc) return rc;
     if (const char* e = env_str("JOXSZ_TRUNC_PROBE")) { if (atoi(e) == 0) return JX_OK; }
-    if (ctx->conv_mode != 2 || (ctx->mix.form != 0 && ctx->mix.sub.empty())) return JX_OK;
+    if (ctx->conv_mode != 2 || (ctx->mix.form != 0 && ctx->mix.sub.empty() && !ctx->ag_sub_on)) return JX_OK;
     // The low-rank form drops the small singular values of the transfer-function weights.  What that costs is measured on the
     // caller's own beam / transfer function / prior box (measure_truncation); beyond the bounds the tables are rebuilt with
     // a cut ten times tighter -- in place: stream, communicator and every other piece of the context stay -- until the
@@ -1880,8 +1935,13 @@ int jx_finalize(jx_ctx* ctx) {
         return measure_truncation(ctx, ctx->trunc_est, &ctx->trunc_points);
     };
     // (an f32 context is measured and reported but never rebuilt: the rounding of its spline arrays is of the bounds' size)
-    const bool sub_at_start = !ctx->mix.sub.empty();
+    const bool sub_at_start = !ctx->mix.sub.empty(), rad_at_start = ctx->ag_sub_on;
     double tol_now = ctx->mix.tol;
+    if (!ctx->f32 && ctx->ag_sub_on && too_large()) {
+        // the radial sub-grid of the spline-array product goes first: nothing to rebuild, the full operator is resident
+        ctx->ag_sub_on = false; ctx->ag_removed += 1;
+        if ((rc = measure_truncation(ctx, ctx->trunc_est, &ctx->trunc_points))) return rc;
+    }
     while (!ctx->f32 && (!ctx->mix.sub.empty() || (!ctx->tol_pinned && ctx->mix.form == 0 && (ctx->mix.tol > 2e-13 || ctx->mix.r < ctx->mix.r_tol))) && too_large()) {
         // first the sub-grid of stage 1 goes (every distinct sample evaluated), then the cap on the rank (the same cut, every
         // term above it kept), then the cut tightens
@@ -1905,6 +1965,16 @@ int jx_finalize(jx_ctx* ctx) {
         if ((rc = rebuild(tol_now))) return rc;
         if (!ctx->mix.sub.empty() && !too_large()) ctx->trunc_unsub = 0;             // (either form: the full form's figures are those of the sub-grid alone)
         else { ctx->subsample = false; if ((rc = rebuild(tol_now))) return rc; }
+    }
+    if (rad_at_start && !ctx->ag_sub_on && (ctx->trunc_unsub > 0 || ctx->trunc_retried > 0 || too_large())) {
+        // something else was (also) at fault: the radial sub-grid once more on what the guard ended at, kept when it changes nothing for the worse
+        const double e0 = ctx->trunc_est[0], e2 = ctx->trunc_est[2];
+        const bool was_ok = !too_large();
+        ctx->ag_sub_on = true;
+        if ((rc = measure_truncation(ctx, ctx->trunc_est, &ctx->trunc_points))) return rc;
+        const bool keep = was_ok ? !too_large() : (ctx->trunc_est[0] <= 1.5 * e0 + 1e-13 && ctx->trunc_est[2] <= 1.5 * e2 + 1e-13);
+        if (keep) ctx->ag_removed = 0;
+        else { ctx->ag_sub_on = false; if ((rc = measure_truncation(ctx, ctx->trunc_est, &ctx->trunc_points))) return rc; }
     }
     return JX_OK;
 }
@@ -2318,6 +2388,15 @@ int jx_get_sampling(jx_ctx* ctx, int32_t out[8], int32_t* rows, int nrows_cap) {
     out[2] = ctx->sub_u0; out[3] = ctx->sub_u1; out[4] = ctx->sub_npts; out[5] = on ? 1 : 0; out[6] = ctx->trunc_unsub; out[7] = 0;
     if (rows) for (int i = 0; i < nrows_cap && i < out[1]; ++i) rows[i] = on ? m.sub[i] : i;
     return JX_OK;
+}
+
+int jx_get_radial_sampling(jx_ctx* ctx, int32_t out[6], int32_t* rows, int nrows_cap) {
+    if (!ctx || !ctx->finalized || !out) return JX_ERR_STATE;
+    const bool on = ctx->ag_sub_on;
+    out[0] = ctx->cfg.N; out[1] = on ? ctx->ag_ns : ctx->cfg.N; out[2] = ctx->ag_u0; out[3] = ctx->ag_u1; out[4] = ctx->ag_npts;
+    out[5] = on ? 1 : 0;
+    if (rows) for (int i = 0; i < nrows_cap && i < out[1]; ++i) rows[i] = on ? ctx->h_rsub[i] : i;
+    return ctx->ag_removed;
 }
 
 int jx_get_output_pruning(jx_ctx* ctx, int32_t out[6]) {

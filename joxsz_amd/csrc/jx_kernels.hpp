@@ -1518,11 +1518,15 @@ jx_operator_mfma_kernel(const double* __restrict__ pp /*[launch][N]*/, int n, in
 // by six steps at most) -- twice the blocks of the paired form, two per CU: one block's barriers and first-touch waits then
 // overlap the other's matrix instructions, and the fp64 matrix instruction issues every 114 cycles from two waves per SIMD
 // instead of every 156 from one.  Blocks with the longest k-ranges have the lowest blockIdx.y: dispatched first.
-template <int NPW, typename TO = double, int TR = 0, int NWT = 2, int SINGLE = 0>
+// RS: the radial sub-grid (a compile-time choice: the plain form keeps its straight-line staging loads)
+template <int NPW, typename TO = double, int TR = 0, int NWT = 2, int SINGLE = 0, bool RS = false>
 __global__ void __launch_bounds__(256)
 jx_abel_gemm_kernel(const double* __restrict__ pp /*[launch][N]*/, int n, int N, const double* __restrict__ Tm /*[JX_AG_ROWS(N)][ldt], zero rows behind N-1*/,
                     int ldt, int K, int ntile, int npair, TO* __restrict__ cf /*[launch][cf_ws]; float for the fp32 variant (rounded once, on store)*/, long long cf_ws,
-                    long long ncol = 0) {
+                    long long ncol = 0,
+                    // radial sub-grid: the rows of Tm are then N of the Npp radii of a profile (rsub[k] = the radius of row k), the
+                    // interpolation to the others folded into Tm, and tks[t] = the first k-step of column tile t with entries (null: all radii)
+                    const int* __restrict__ rsub = nullptr, int Npp = 0, const int* __restrict__ tks = nullptr) {
     JX_LDS_DECL;
     static_assert(!SINGLE || NPW == 1, "one tile per wave");
     constexpr int NTL = SINGLE ? 1 : 2 * NPW;
@@ -1534,7 +1538,7 @@ jx_abel_gemm_kernel(const double* __restrict__ pp /*[launch][N]*/, int n, int N,
     if (SINGLE) {
         const int t = grp * 4 + wv;
         tile[0] = t;
-        ks[0] = (t < ntile) ? (max(0, 8 * t - K) >> 2) : ktot4;
+        ks[0] = (t < ntile) ? (RS ? tks[t] : (max(0, 8 * t - K) >> 2)) : ktot4;
         toff[0] = min(t, ntile - 1) * 16;
     } else {
 #pragma unroll
@@ -1544,7 +1548,7 @@ jx_abel_gemm_kernel(const double* __restrict__ pp /*[launch][N]*/, int n, int N,
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int t = tile[(2 * i + h) % NTL];
-                ks[(2 * i + h) % NTL] = (p < npair && t < ntile) ? (max(0, 8 * t - K) >> 2) : ktot4;   // first k-step with entries (ktot4: none)
+                ks[(2 * i + h) % NTL] = (p < npair && t < ntile) ? (RS ? tks[t] : (max(0, 8 * t - K) >> 2)) : ktot4;   // first k-step with entries (ktot4: none)
                 toff[(2 * i + h) % NTL] = min(t, ntile - 1) * 16;
             }
         }
@@ -1555,7 +1559,7 @@ jx_abel_gemm_kernel(const double* __restrict__ pp /*[launch][N]*/, int n, int N,
 #pragma unroll
         for (int nt = 0; nt < NWT; ++nt) acc[t][nt] = jx_op_v4d{0.0, 0.0, 0.0, 0.0};
     // the block's first chunk of radii: the first row of its lowest tile
-    const int kminb = max(0, 8 * (grp * 4 * NPW) - K) >> 2;
+    const int kminb = RS ? tks[min(grp * 4 * NPW, ntile - 1)] : (max(0, 8 * (grp * 4 * NPW) - K) >> 2);      // (tks does not decrease with the tile)
     const int j00 = (4 * kminb / JX_OPM_JC) * JX_OPM_JC;
     int kg = j00 >> 2;
     const double* gb = Tm + (size_t)lk * ldt + li;
@@ -1573,10 +1577,12 @@ jx_abel_gemm_kernel(const double* __restrict__ pp /*[launch][N]*/, int n, int N,
     const int sl = tid / JX_OPM_JC, sj = tid % JX_OPM_JC;                       // consecutive threads: consecutive radii of one walker
     double stg[NST];
     auto fetch = [&](int j0) {
+        const int rcol = RS ? rsub[min(j0 + sj, N - 1)] : 0;          // (this thread's radius of the chunk)
 #pragma unroll
         for (int i = 0; i < NST; ++i) {
             const int l = sl + i * (256 / JX_OPM_JC);
-            stg[i] = (wb + l < n && j0 + sj < N) ? pp[(size_t)(wb + l) * N + j0 + sj] : 0.0;
+            if (RS) stg[i] = (wb + l < n && j0 + sj < N) ? pp[(size_t)(wb + l) * Npp + rcol] : 0.0;
+            else stg[i] = (wb + l < n && j0 + sj < N) ? pp[(size_t)(wb + l) * N + j0 + sj] : 0.0;
         }
     };
     fetch(j00);

@@ -19,7 +19,7 @@ EXPORTS = (
     'jx_set_par_vals', 'jx_dev_alloc', 'jx_dev_free', 'jx_memcpy_h2d', 'jx_memcpy_d2h',
     'jx_timing_reset', 'jx_timing_enable', 'jx_timing_get', 'jx_get_info', 'jx_get_conv_mode', 'jx_get_conv_layout', 'jx_debug_workspace', 'jx_device_count',
     'jx_device_name', 'jx_strerror', 'jx_last_error', 'jx_destroy',
-    'jx_get_truncation', 'jx_get_output_pruning', 'jx_get_sampling', 'jx_comm_unique_id', 'jx_comm_init_rank', 'jx_allgather_logp', 'jx_comm_allreduce_max', 'jx_comm_destroy',
+    'jx_get_truncation', 'jx_get_output_pruning', 'jx_get_sampling', 'jx_get_radial_sampling', 'jx_comm_unique_id', 'jx_comm_init_rank', 'jx_allgather_logp', 'jx_comm_allreduce_max', 'jx_comm_destroy',
     'jx_comm_count', 'jx_comm_set_overlap', 'jx_comm_gather_time', 'jx_map_kernel_time', 'jx_event_bracket_time', 'jx_fastmath_eval', 'jx_copy_bandwidth', 'jx_stream_bandwidth',
 )
 
@@ -97,6 +97,7 @@ def load_library(path=None):
     lib.jx_get_truncation.argtypes = [vp, dp]
     lib.jx_get_output_pruning.argtypes = [vp, ctypes.POINTER(ctypes.c_int32)]
     lib.jx_get_sampling.argtypes = [vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), ci]
+    lib.jx_get_radial_sampling.argtypes = [vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), ci]
     lib.jx_debug_workspace.argtypes = [vp, ci, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int32)]
     lib.jx_comm_unique_id.argtypes = [vp]
     lib.jx_comm_init_rank.argtypes = [vp, vp, ci, ci]
@@ -209,6 +210,14 @@ class HipContext:
         self.sampling = dict(rows_of_the_quadrant=int(sm[0]), rows_evaluated=int(sm[1]), full_below=int(sm[2]), every_second_up_to=int(sm[3]),
                              interpolation_points=int(sm[4]), active=bool(sm[5]), removed_by_the_guard=int(sm[6]),
                              rows=np.array(rows[:min(int(sm[1]), 4096)], dtype=np.int64))
+        rm = (ctypes.c_int32 * 6)()
+        rrows = (ctypes.c_int32 * 8192)()
+        removed = self.lib.jx_get_radial_sampling(self._h, rm, rrows, 8192)
+        if removed < 0:
+            self._chk(removed, 'jx_get_radial_sampling')
+        self.radial_sampling = dict(radii_of_the_grid=int(rm[0]), radii_in_use=int(rm[1]), full_below=int(rm[2]), every_second_up_to=int(rm[3]),
+                                    interpolation_points=int(rm[4]), active=bool(rm[5]), removed_by_the_guard=int(removed),
+                                    rows=np.array(rrows[:min(int(rm[1]), 8192)], dtype=np.int64))
         self.truncation = self._truncation()
         if self.truncation['warning'] and not os.environ.get('JOXSZ_QUIET'):
             import warnings
@@ -245,6 +254,9 @@ class HipContext:
         if self.conv != 'custom':
             return None
         msgs = []
+        if self.radial_sampling['removed_by_the_guard']:
+            msgs.append('the truncation guard took the radial sub-grid of the spline-array product away on these inputs: every radius of the profile '
+                        'is multiplied (%d instead of %d: that kernel costs about 2x)' % (self.radial_sampling['radii_of_the_grid'], self.radial_sampling['radii_of_the_grid'] * 4 // 9))
         if self.sampling['removed_by_the_guard']:
             msgs.append('the truncation guard took the sub-grid of map samples away on these inputs: every distinct sample is evaluated '
                         '(%d rows and columns instead of about %d: the SZ stages cost 2-4x)' % (self.sampling['rows_of_the_quadrant'], self.sampling['rows_of_the_quadrant'] // 2))

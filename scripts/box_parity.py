@@ -27,7 +27,7 @@ want = orc.log_posterior_batch(pb, th)
 fin = np.isfinite(want)
 print('S=%d N=%d: %d of %d box-uniform walkers finite' % (S, N, fin.sum(), nw))
 extra = [('sub-grid ' + v, {'JOXSZ_MIX_SUBSAMPLE': v}) for v in os.environ.get('BOX_SUBGRIDS', '').split(';') if v]
-for name, env in extra + [('default', {}), ('every distinct map sample', {'JOXSZ_MIX_SUBSAMPLE': '0'}), ("device library's exp / log", {'JOXSZ_PREP_FASTMATH': '0'}),
+for name, env in extra + [('default', {}), ('every radius of the profile', {'JOXSZ_AG_SUBSAMPLE': '0'}), ('every distinct map sample', {'JOXSZ_MIX_SUBSAMPLE': '0'}), ("device library's exp / log", {'JOXSZ_PREP_FASTMATH': '0'}),
                   ('full form', {'JOXSZ_MIX_FORM': 'full'}), ('full form, every sample', {'JOXSZ_MIX_FORM': 'full', 'JOXSZ_MIX_SUBSAMPLE': '0'}),
                   ('rocFFT sequence', {'JOXSZ_CONV': 'rocfft'})]:
     for k, v in env.items(): os.environ[k] = v

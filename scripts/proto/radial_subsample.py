@@ -41,7 +41,7 @@ pps = [orc.press_fun(orc.pars_dict(pb, tv), pb.r_pp) for tv in pts]
 kmax = 366 if N <= 600 else 727           # knots the quadrant of the map reaches
 print('N = %d, band half-width %d, thawed shape parameters %s, %d probe profiles, core steepness pp[0]/pp[40]: %s'
       % (N, K, keys, len(pps), ' '.join('%.1e' % (q[0] / q[40]) for q in pps[:9])))
-for (u0, u1, npts) in ((40, 160, 12), (32, 128, 12), (64, 160, 12), (40, 160, 8), (40, 160, 16), (24, 96, 12), (48, 192, 14)):
+for (u0, u1, npts) in ((40, 160, 12), (32, 128, 12), (64, 160, 12), (40, 160, 8), (40, 160, 16), (24, 96, 12), (48, 192, 14), (64, 256, 14), (64, 256, 16), (48, 256, 14), (64, 320, 14), (96, 320, 14), (64, 256, 18)):
     ns = lib.jxt_mix_row_subset(N, u0, u1, None)
     sub = np.zeros(ns, np.int32)
     lib.jxt_mix_row_subset(N, u0, u1, sub.ctypes.data_as(IP))

@@ -512,8 +512,9 @@ def test_stage_one_evaluates_a_sub_grid_of_the_quadrant(S, N, form, monkeypatch)
     np.testing.assert_allclose(chi_a[fin], chi_b[fin], rtol=1e-8, atol=1e-8)
     assert np.abs(row_a - row_b).max() / np.abs(row_b).max() < 1e-10
     if form == 'full':
-        # nothing truncated: without the sub-grid nothing to measure, with it the guard measures the sub-grid alone
-        assert tr_b['est_rel_row_err'] == -1.0 and 0 <= tr_a['est_rel_row_err'] < 1e-10 and 0 <= tr_a['est_rel_sz_like_err_box'] < 1e-9
+        # nothing truncated: what the guard measures is the sub-grids alone (without the one of the map samples: the radial one of
+        # the spline-array product, at rounding level)
+        assert 0 <= tr_b['est_rel_row_err'] < 1e-12 and 0 <= tr_a['est_rel_row_err'] < 1e-10 and 0 <= tr_a['est_rel_sz_like_err_box'] < 1e-9
     else:
         # the guard's own measurement (against the rocFFT facility) moves by less than a fifth of its bounds
         assert abs(tr_a['est_rel_row_err'] - tr_b['est_rel_row_err']) < 0.2 * tr_a['bound']
@@ -601,6 +602,67 @@ def test_default_route_over_the_whole_prior_box_against_the_oracle(S, N, measure
           % (S, N, 'measured inputs' if measured else 'synthetic inputs', fin.sum(), nw, form, smp['active'], rel.max(), np.median(rel)))
     assert rel.max() < 1e-6, (rel.max(), form, smp['active'])
     assert np.median(rel) < 1e-9
+
+
+@pytest.mark.parametrize('S,N,kw', [(512, 500, {}), (1024, 1000, {}), (256, 300, dict(sz_only=True)), (512, 500, dict(ne_mode='double'))])
+def test_spline_array_product_on_a_radial_sub_grid(S, N, kw, monkeypatch):
+    """The pressure profile is smooth away from the core: the spline-array product multiplies its values on a sub-grid of the radial grid
+    (jx_get_radial_sampling: every radius below 64, every second to 256, every fourth beyond -- 222 of 500) by an operator that carries
+    the 18-point interpolation to the others.  Against the same context with every radius (JOXSZ_AG_SUBSAMPLE=0): spline ordinates to
+    1e-12 of their maximum, the extracted row to 1e-11, the log-posterior to 1e-10; and against the oracle."""
+    from joxsz_amd import datasets
+    pb = _problem(S, N, seed=S + 3, **kw)
+    th = datasets.walker_ball(pb, 64, spread=0.05, seed=S + 3)
+    post = _post(pb)
+    rs = post.ctx.radial_sampling
+    assert rs['active'] and rs['radii_of_the_grid'] == N and rs['radii_in_use'] == len(rs['rows']) < 0.75 * N and rs['removed_by_the_guard'] == 0
+    assert np.array_equal(rs['rows'][:rs['full_below']], np.arange(rs['full_below'])) and rs['rows'][-1] == N - 1 and np.diff(rs['rows']).max() <= 8
+    a, row_a = post.log_prob(th), post.stage(th[:4], 'map_row')
+    post.log_prob(th[:8])
+    cf_a = post.ctx.workspace('splines')[:, :8, :].copy()
+    post.close()
+    monkeypatch.setenv('JOXSZ_AG_SUBSAMPLE', '0')
+    ref = _post(pb)
+    assert not ref.ctx.radial_sampling['active'] and ref.ctx.radial_sampling['radii_in_use'] == N
+    b, row_b = ref.log_prob(th), ref.stage(th[:4], 'map_row')
+    ref.log_prob(th[:8])
+    cf_b = ref.ctx.workspace('splines')[:, :8, :].copy()
+    ref.close()
+    fin = np.isfinite(b)
+    assert fin.sum() >= 30 and np.array_equal(np.isfinite(a), fin)
+    np.testing.assert_allclose(a[fin], b[fin], rtol=1e-10)
+    assert np.abs(row_a - row_b).max() / np.abs(row_b).max() < 1e-11
+    for comp, bar in ((0, 1e-12), (1, 1e-9)):                             # y_k; M_k (second differences amplify)
+        assert np.abs(cf_a[:, :, comp] - cf_b[:, :, comp]).max() <= bar * np.abs(cf_b[:, :, comp]).max()
+    want = orc.log_posterior_batch(pb, th[:4])
+    ok = np.isfinite(want)
+    np.testing.assert_allclose(a[:4][ok], want[ok], rtol=1e-6)
+
+
+def test_guard_takes_a_coarse_radial_sub_grid_away(monkeypatch):
+    """A radial sub-grid far too coarse for the profile (JOXSZ_AG_SUBSAMPLE=8,8,4) is measured by the guard of jx_finalize like the
+    other approximations and taken away (no tables to rebuild: the full operator is resident); HipContext says so once; results equal
+    those of the context that never had one."""
+    import warnings
+    from joxsz_amd import datasets
+    from joxsz_amd.hip_backend import JoxszTruncationWarning
+    pb = _problem(512, 500, seed=19)
+    th = datasets.walker_ball(pb, 40, spread=0.03, seed=19)
+    monkeypatch.setenv('JOXSZ_AG_SUBSAMPLE', '8,8,4')
+    with pytest.warns(JoxszTruncationWarning, match='radial sub-grid'):
+        post = _post(pb)
+    rs, tr = post.ctx.radial_sampling, post.ctx.truncation
+    assert not rs['active'] and rs['removed_by_the_guard'] == 1 and rs['radii_in_use'] == 500
+    assert post.ctx.sampling['active'] and tr['retried'] == 0 and 0 <= tr['est_rel_row_err'] <= tr['bound']
+    a = post.log_prob(th)
+    post.close()
+    monkeypatch.setenv('JOXSZ_AG_SUBSAMPLE', '0')
+    with warnings.catch_warnings():
+        warnings.simplefilter('error', JoxszTruncationWarning)
+        ref = _post(pb)
+    b = ref.log_prob(th)
+    ref.close()
+    np.testing.assert_array_equal(a, b)
 
 
 def test_truncation_guard_speaks_up_when_it_changes_the_tables():
