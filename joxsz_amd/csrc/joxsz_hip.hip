@@ -115,6 +115,8 @@ struct jx_ctx {
 
     // per-walker scalars (chunk capacity)
     double *d_base = nullptr, *d_cfac = nullptr, *d_sz0 = nullptr;
+    double* d_xr = nullptr;            // [chunk][2] Cash log-likelihood and reject flag of the two-block form of the per-walker kernel
+    bool prep_split = true;            // JOXSZ_PREP_SPLIT=0: one block per walker in the per-walker kernel (as in every call with taps)
     double* d_img = nullptr;           // contracted route: quadrant of the Compton-y map (y_2d tap only; allocated on first use)
     // spline arrays as one matrix product (jx_abel_gemm_kernel)
     double* d_Tm = nullptr; int tm_ld = 0, tm_ntile = 0, tm_npair = 0;
@@ -1199,6 +1201,7 @@ static int finalize_impl(jx_ctx* ctx) {
     if (const char* e = env_str("JOXSZ_ABEL_GEMM")) ctx->abel_gemm = atoi(e) != 0;
     if (const char* e = env_str("JOXSZ_AG_NARROW")) ctx->ag_narrow = atoi(e) != 0;
     if (const char* e = env_str("JOXSZ_AG_SINGLE")) ctx->ag_single = atoi(e) != 0;
+    if (const char* e = env_str("JOXSZ_PREP_SPLIT")) ctx->prep_split = atoi(e) != 0;
     if (const char* e = env_str("JOXSZ_AG_SUBSAMPLE")) {
         int a0 = 0, a1 = 0, a2 = 0;
         const int got = sscanf(e, "%d,%d,%d", &a0, &a1, &a2);
@@ -1450,6 +1453,7 @@ static int finalize_impl(jx_ctx* ctx) {
         HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_abel_map_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     }
     if ((rc = dev_new(ctx, (size_t)chunk, &ctx->d_base))) return rc;
+    if ((rc = dev_new(ctx, (size_t)chunk * 2, &ctx->d_xr))) return rc;
     if ((rc = dev_new(ctx, (size_t)chunk * ctx->nrow, &ctx->d_cfac))) return rc;
     if (c.calc_integ && (rc = dev_new(ctx, (size_t)chunk, &ctx->d_sz0, true))) return rc;
     if (ctx->conv_mode == 2) {
@@ -1627,15 +1631,22 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
     // kernel writes, and whatever produced theta -- is therefore complete when it starts.  Calls with taps stay in line.
     const bool any_tap = t.pp || t.ab || t.y || t.row || t.bright || t.chisq || t.tprof || t.xprofs || t.parts || t.integ || t.need_img;
     const bool side = mix && ag && ctx->side_stream && !ctx->d.inject_pp && !any_tap;
+    // two blocks per walker in the per-walker kernel (the X-ray side beside the rest): the timed sequence of the contracted route only
+    // (up to ~640 radii: beyond, the grid pass on half the threads is the longer of the two chains by more than the split saves --
+    //  measured at N = 1000: 32.5 -> 34.7 us; at N = 500: 27.6 -> 23.4, at N = 313: 26.8 -> 22.3)
+    const bool xr_split = mix && ctx->prep_split && !any_tap && !side && !d.sz_only && !d.prep_pow && 3 * d.nann <= 128 && d.nband * d.nann <= 4096 && d.N <= 640;
     auto launch_prep = [&](hipStream_t ps, double* pp_buf) {
         JxDev dp = d;
         dp.inject_pp = ctx->d.inject_pp;
-        const size_t sh = sizeof(double) * (JX_LDS_HDR + (size_t)2 * d.N + 2 * d.nann + (size_t)d.nband * d.nann + 2 * (size_t)d.nconv + 8 + JX_FM_TABLE_DOUBLES);
-        if (d.prep_pow) hipLaunchKernelGGL((jx_prep_kernel<true, false>), dim3(n), dim3(JX_PREP_THREADS), sh, ps, dp, theta_dev, w0,
+        dp.xr_split = xr_split ? 1 : 0;
+        dp.xr_out = ctx->d_xr;
+        const unsigned pgrid = xr_split ? 2u * (unsigned)n : (unsigned)n, pthr = xr_split ? 128u : (unsigned)JX_PREP_THREADS;
+        const size_t sh = sizeof(double) * (JX_LDS_HDR + (size_t)2 * d.N + 2 * d.nann + 2 * (size_t)d.nband * d.nann + 2 * (size_t)d.nconv + 8 + JX_FM_TABLE_DOUBLES);
+        if (d.prep_pow) hipLaunchKernelGGL((jx_prep_kernel<true, false>), dim3(pgrid), dim3(pthr), sh, ps, dp, theta_dev, w0,
                                            base_buf, cfac_buf, pp_buf, sz0_buf, t.tprof, t.xprofs, t.parts, t.integ, smv);
-        else if (ctx->prep_fastmath) hipLaunchKernelGGL((jx_prep_kernel<false, true>), dim3(n), dim3(JX_PREP_THREADS), sh, ps, dp, theta_dev, w0,
+        else if (ctx->prep_fastmath) hipLaunchKernelGGL((jx_prep_kernel<false, true>), dim3(pgrid), dim3(pthr), sh, ps, dp, theta_dev, w0,
                                                         base_buf, cfac_buf, pp_buf, sz0_buf, t.tprof, t.xprofs, t.parts, t.integ, smv);
-        else hipLaunchKernelGGL((jx_prep_kernel<false, false>), dim3(n), dim3(JX_PREP_THREADS), sh, ps, dp, theta_dev, w0,
+        else hipLaunchKernelGGL((jx_prep_kernel<false, false>), dim3(pgrid), dim3(pthr), sh, ps, dp, theta_dev, w0,
                                 base_buf, cfac_buf, pp_buf, sz0_buf, t.tprof, t.xprofs, t.parts, t.integ, smv);
     };
     {
@@ -1746,9 +1757,12 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
         const JxOpg& ogt = used ? m.og_u : m.og;
         const size_t sh = sizeof(double) * (JX_LDS_HDR + (size_t)d.nrow + 8);
         if (side) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_side, 0));
-        if (ctx->f32c) hipLaunchKernelGGL(jx_tail_row_kernel<float>, dim3(n), dim3(JX_TAIL_THREADS), sh, st, d, reinterpret_cast<const float*>(m.Pt), nks,
+        JxDev dtl = d;
+        dtl.xr_split = xr_split ? 1 : 0;
+        dtl.xr_out = ctx->d_xr;
+        if (ctx->f32c) hipLaunchKernelGGL(jx_tail_row_kernel<float>, dim3(n), dim3(JX_TAIL_THREADS), sh, st, dtl, reinterpret_cast<const float*>(m.Pt), nks,
                                           ogt.pstride, ogt.ldx, nuse, ctx->d_cfac, ctx->d_sz0, ctx->d_base, logp_dev, w0, t.row, t.bright, t.chisq, t.parts, smv);
-        else hipLaunchKernelGGL(jx_tail_row_kernel<double>, dim3(n), dim3(JX_TAIL_THREADS), sh, st, d, m.Pt, nks, ogt.pstride, ogt.ldx, nuse,
+        else hipLaunchKernelGGL(jx_tail_row_kernel<double>, dim3(n), dim3(JX_TAIL_THREADS), sh, st, dtl, m.Pt, nks, ogt.pstride, ogt.ldx, nuse,
                                 ctx->d_cfac, ctx->d_sz0, ctx->d_base, logp_dev, w0, t.row, t.bright, t.chisq, t.parts, smv);
 
         if (tm) HIPCHK(ctx, hipEventRecord(es.e[5], st));

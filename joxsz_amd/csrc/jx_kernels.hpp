@@ -65,6 +65,8 @@ struct JxDev {
     long long img_ld, img_ws;    // row and walker strides (doubles) of the y-map image
     int dbg;                     // timing-only ablations (JOXSZ_DBG): 1 skip phases 1-4, 2 skip phase 5, 4 phase 5 stores only
     const double* fm_tab;        // [JX_FM_TABLE_DOUBLES] tables of jx_fastmath.hpp (jxt::fastmath_tables)
+    int xr_split;                // 1: jx_prep_kernel runs as 2 n blocks -- n for everything but the X-ray side, n for the X-ray side alone -- and the tail adds the two
+    double* xr_out;              // [chunk][2] Cash log-likelihood and its reject flag (xr_split)
     int prep_pow;                // 1 (JOXSZ_PREP_POW=1): the prep kernel evaluates the profiles with pow() as written in the reference
     const double* lr_pp;         // [N] log(r_pp)
     const double* inject_pp;     // operator build only: [nlaunch][N] pressure profiles that replace press_fun(theta) (else null)
@@ -318,7 +320,14 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
     double* p = sm;
     double* red = sm + 20;
     int& redi = *reinterpret_cast<int*>(sm + 28);
-    const int w = blockIdx.x;                 // walker within the chunk
+    // xr_split: the dependent phases of a walker are two chains that share nothing but its parameters -- priors, grid pass, mass veto and
+    // conversion factors on one side, the X-ray model and its Cash sum on the other.  Run as two blocks (of half the threads) they take
+    // max(the two) instead of the sum, and the arithmetic of the one hides the waits of the other.  Blocks [0, n): all but the X-ray
+    // side; blocks [n, 2n): the X-ray side alone (-> xr_out); the tail adds them.
+    const int nblk = c.xr_split ? (int)(gridDim.x >> 1) : (int)gridDim.x;
+    const bool xonly = c.xr_split && (int)blockIdx.x >= nblk;      // this block: the X-ray side alone
+    const bool noxr = c.xr_split && !xonly;                        // this block: everything else
+    const int w = xonly ? (int)blockIdx.x - nblk : (int)blockIdx.x;   // walker within the chunk
     const int gw = w0 + w;                    // walker within the batch
     const int tid = threadIdx.x, nth = blockDim.x;
 
@@ -329,6 +338,7 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
     double* s_rate = s_T + c.nann;            // [nband*nann]
     double* s_conv = s_rate + c.nband * c.nann;   // [2 nconv] the Compton -> mJy/beam table (temperatures, factors)
     double* s_fm = s_conv + 2 * c.nconv;          // [JX_FM_TABLE_DOUBLES] exp / log tables (FM)
+    double* s_term = s_fm + JX_FM_TABLE_DOUBLES;  // [nband*nann] terms of the Cash sum
     static_assert(!(POW && FM), "the tables serve the log form");
     typename std::conditional<FM, JxMathTab, JxMathLib>::type mt;
     if constexpr (FM) { mt.t.et = s_fm; mt.t.lt = s_fm + JX_FM_EXP_N; }
@@ -345,9 +355,13 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
     double pc[5] = {0, 1, 1, 0, 1};           // radius-independent factors of the density (every thread its own copy)
     if (POW) jx_ne_consts(p, c.ne_mode, pc);
 
-    // ---- priors on every parameter (joxsz_funcs.py:518) ----
-    double pr = 0.0;
+    constexpr bool logform = !POW;
+    double pl[11];
+    jx_prof_consts(mt, p, c.ne_mode, pl);
+    double pr = 0.0, parprior = 0.0;
     int rej = 0;
+    if (!xonly) {                              // (a block of the X-ray side alone goes straight to that side)
+    // ---- priors on every parameter (joxsz_funcs.py:518) ----
     if (has_par) {
         const double v = p[tid];
         if (pk_kind == 1) {
@@ -360,7 +374,7 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
         } else if (v < pk_a || v > pk_b) rej |= REJ_BOX;
         if (v != v) rej |= REJ_BOX;           // NaN parameter: reject (emcee cannot use NaN)
     }
-    const double parprior = jx_block_sum(pr, red);
+    parprior = jx_block_sum(pr, red);
     if (!(fabs(parprior) <= 1.79769313486231570e308)) rej |= REJ_BOX;     // joxsz_funcs.py:519-520: a non-finite prior returns -inf at once
 
     // ---- model prior: r_c <= r_s (joxsz_funcs.py:397-407) ----
@@ -372,9 +386,6 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
     const bool veto = c.exclude_unphy_mass != 0;
     const int nprof = (veto || pp_out || c.calc_integ) ? c.N : c.nt;
     double ci = 0.0;                          // this thread's share of integ_wp . pp
-    constexpr bool logform = !POW;
-    double pl[11];
-    jx_prof_consts(mt, p, c.ne_mode, pl);
     const int N_ = c.N, nt_ = c.nt, mode_ = c.ne_mode;
     if (logform) {
         // Two radii per trip, straight-line: the evaluations are chains of dependent fp64 operations, and two independent
@@ -443,16 +454,18 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
         if (tap_tprof) tap_tprof[(size_t)w * c.nrow + k] = T;
     }
     __syncthreads();
+    }                                          // (!xonly)
 
     // ---- X-ray: calcProfiles + Cash (joxsz_funcs.py:527-532, 495-505) ----
     double xlike = 0.0;
-    if (!c.sz_only) {
-        if (logform && c.nann <= 64 && nth >= 192) {
-            // three waves side by side: density at the n_e radii, pressure at the T radii, density at the T radii (only
+    int xbad = 0;
+    if (!c.sz_only && !noxr) {
+        if (logform && 3 * c.nann <= nth) {
+            // three jobs per shell side by side: density at the n_e radii, pressure at the T radii, density at the T radii (only
             // where the two radii differ), then T_X = P / n_e * 10^log(T_X/T_SZ)
             double* s_x = s_m;                 // (the mass profile is dead: two block reductions since its last read)
-            const int grp = tid >> 6, k = tid & 63;
-            if (k < c.nann && grp < 3) {
+            const int grp = tid / c.nann, k = tid - grp * c.nann;
+            if (grp < 3) {
                 const double rn = c.x_r_ne[k], r = c.x_r_T[k];
                 if (grp == 0) s_ne[k] = jx_ne_log(mt, p, pl, rn, mt.l(rn), c.ne_mode);
                 else if (grp == 1) { double xa; s_T[k] = jx_press_log(mt, p, pl, mt.l(r), &xa) * mt.e(2.30258509299404568402 * p[P_LOGTR]); }
@@ -484,7 +497,6 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
             s_rate[q] = (z0 + (z1 - z0) * p[P_Z]) * s_ne[j] * s_ne[j];
         }
         __syncthreads();
-        double lk = 0.0;
         int bad = 0;
         for (int q = tid; q < nba; q += nth) {
             const int b = q / c.nann, i = q - b * c.nann;
@@ -495,13 +507,31 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
             if (tap_xprofs) tap_xprofs[(size_t)w * nba + q] = model;
             if (!(model > 0.0)) bad = 1;       // np.array(profs).min() > 0 fails (NaN included)
             const double ct = c.cts[q];
-            if (ct == ct) lk += ct * mt.l(model) - model;
+            s_term[q] = (ct == ct) ? ct * mt.l(model) - model : 0.0;
         }
-        xlike = jx_block_sum(lk, red);
-        if (bad) rej |= REJ_XRAY;              // (the block-wide OR of rej below carries it to everybody)
+        // The terms are added in ONE order whatever the block's size (256 threads, or 128 in the two-block form): 64 consecutive pairs
+        // per shuffle tree, the trees' sums in sequence -- what jx_block_sum does with one pair per thread of a 256-thread block.
+        xbad = jx_block_or(bad, &redi);        // (its barriers order s_term as well)
+        if (tid < 64) {
+            double tot = 0.0;
+            for (int q0 = 0; q0 < nba; q0 += 64) {
+                double v = (q0 + tid < nba) ? s_term[q0 + tid] : 0.0;
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+                tot += v;
+            }
+            if (tid == 0) red[0] = tot;
+        }
+        __syncthreads();
+        xlike = red[0];
+        __syncthreads();
+        if (xbad) rej |= REJ_XRAY;
         // cashLogLikelihood returns -inf for a non-finite sum; per band in the reference,
         // a non-finite band makes the total non-finite as well
-        if (!(fabs(xlike) <= 1.79769313486231570e308)) rej |= REJ_XRAY;
+        if (!(fabs(xlike) <= 1.79769313486231570e308)) { rej |= REJ_XRAY; xbad = 1; }
+    }
+    if (xonly) {                               // the X-ray side alone: its sum and its verdict for the tail
+        if (tid == 0) { c.xr_out[2 * (size_t)w] = xlike; c.xr_out[2 * (size_t)w + 1] = xbad ? 1.0 : 0.0; }
+        return;
     }
     const int rejall = jx_block_or(rej, &redi);
     if (tid == 0) {

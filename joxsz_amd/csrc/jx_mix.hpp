@@ -726,7 +726,9 @@ jx_tail_row_kernel(JxDev c, const TP* __restrict__ Pt, int nks, long long pstrid
     const double chisq = jx_block_sum(part, red);
     if (tid == 0) {
         const double ll = -chisq / 2.0 + (sz0 ? sz0[w] : 0.0);
-        const double b = base[w];
+        double b = base[w];
+        // (two-block form of the per-walker kernel: the priors arrive here, the Cash log-likelihood and its verdict beside them)
+        if (c.xr_split && b != -INFINITY) b = (c.xr_out[2 * (size_t)w + 1] != 0.0) ? -INFINITY : b + c.xr_out[2 * (size_t)w];
         double tot = (b == -INFINITY) ? -INFINITY : b + ll;
         if (tot != tot) tot = -INFINITY;             // never hand NaN to the sampler
         logp[w0 + w] = tot;

@@ -574,6 +574,36 @@ def test_stretch_move_inside_the_likelihood_kernels_against_the_separate_kernels
     assert 0 < res[('1', 0)][2].sum() < 10 * 90
 
 
+def test_per_walker_kernel_as_two_blocks_per_walker(monkeypatch):
+    """The timed sequence runs the per-walker kernel as two blocks per walker -- priors, grid pass, mass veto and conversion factors in
+    one, the X-ray model and its Cash sum in the other, the tail adding the two (radial grids up to 640 points).  Against one block per
+    walker (JOXSZ_PREP_SPLIT=0, what every call with taps runs): the same bits for every walker, the rejected ones (box, NaN, r_c > r_s,
+    mass veto, non-positive count rates) included, both density models; and the taps' parts add up to the timed value."""
+    from joxsz_amd import datasets
+    for kw in ({}, dict(ne_mode='double')):
+        pb = datasets.synthetic_problem(S=128, N=150, seed=13, **kw)
+        p0 = orc.pars_dict(pb, datasets.fiducial_theta(pb))
+        datasets.fill_data(pb, orc.sz_stages(pb, p0)['bright'], orc.calc_profiles(pb, p0), seed=13)
+        th = datasets.walker_ball(pb, 300, spread=0.08, seed=13)
+        th[7, 2] = np.nan
+        res = {}
+        for sp in ('1', '0'):
+            monkeypatch.setenv('JOXSZ_PREP_SPLIT', sp)
+            post = _post(pb, max_batch=128)                           # (three chunks, the last ragged)
+            res[sp] = (post.log_prob(th), post.stage(th, 'parts'))
+            post.close()
+        a, b = res['1'][0], res['0'][0]
+        np.testing.assert_array_equal(a, b)
+        fin = np.isfinite(a)
+        assert 30 < fin.sum() < 300
+        parts = res['1'][1]
+        np.testing.assert_allclose(a[fin], parts[fin, 0] + parts[fin, 1] + parts[fin, 2], rtol=1e-13)
+        want = orc.log_posterior_batch(pb, th[:12])
+        ok = np.isfinite(want)
+        assert np.array_equal(np.isfinite(a[:12]), ok)
+        np.testing.assert_allclose(a[:12][ok], want[ok], rtol=1e-9)
+
+
 def test_largest_config_shape():
     """BASELINE configs[4] shape (S=1024, N=1000): two walkers against the oracle, both back ends."""
     from joxsz_amd import datasets
