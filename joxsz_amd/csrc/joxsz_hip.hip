@@ -25,6 +25,7 @@
 #include "../../include/joxsz_hip.h"
 #include "jx_kernels.hpp"
 #include "jx_mix.hpp"
+#include "jx_exact.hpp"
 #include "jx_tables.hpp"
 
 namespace {
@@ -37,7 +38,9 @@ struct EvSet {
     hipEvent_t e[6];
     int walkers;
     bool op;                           // operator route: only e[0], e[1], e[5] were recorded
-    bool p1only = false;               // timing mode 2: only e[2], e[3] (around the time-dominant kernel) were recorded
+    bool p1only = false;               // timing modes 2..4: only e[2], e[3] (around one kernel of the step) were recorded
+    int p1stage = 2;                   //   which one: 2 stage 1 (contracted forms) / the ordinate product (exact form), 3 the per-walker kernel, 4 the row product + tail (exact form)
+    bool exact = false;                // exact form: e[0], e[1], e[2], e[5] were recorded (per-walker kernel, ordinate product, row product + tail)
 };
 
 // rocFFT sequence: constants in the padded full-image layout, work buffers for `cap` walkers, plans per batch size
@@ -59,7 +62,11 @@ struct FftBack {
 // contracted route: tables and work buffers (freed and rebuilt when the truncation probe asks for a tighter cut)
 struct MixBack {
     bool ready = false;
-    int form = 0;                      // 0 low-rank (stage 1 + stage 2), 1 full operator on the samples
+    int form = 0;                      // 0 low-rank (stage 1 + stage 2), 1 full operator on the samples (round 3-4, JOXSZ_MIX_FORM=legacy|lowrank|full); 2 exact (default)
+    // exact form (jx_exact.hpp): the ordinate product's operator Ty and first k-steps, the row operator Opk, the ordinates y
+    int Nk = 0, Nkp = 0, x_nxt = 0, x_ng = 0, x_ng_use = 0, x_npair = 0, x_nSj = 0, x_ldpp = 0;
+    double *x_Typ = nullptr, *x_Opk = nullptr, *x_y = nullptr, *x_cf = nullptr, *x_P = nullptr, *x_ppi = nullptr;
+    bool x_pairwise = true;            // JOXSZ_X_PAIRWISE=0: the ordinates read back by one block per 16 walkers (jx_rowop_tail_kernel)
     JxMix mx{};
     JxOpg og{};
     JxOpg og_u{};                      // the product restricted to the outputs the tail reads (nxt_u tiles per block, ksplit_u slices); og: every output (taps)
@@ -112,6 +119,7 @@ struct jx_ctx {
                                        // reference facility (guard), profile taps from the matrix product's own arrays
     std::vector<double> h_Qtab;        // [qn][qn] pixel radii of the quadrant (host; table builds)
     int qn = 0;
+    std::vector<double> h_G;           // [N][N] moment operator of the mirrored spline (host; table builds)
 
     // per-walker scalars (chunk capacity)
     double *d_base = nullptr, *d_cfac = nullptr, *d_sz0 = nullptr;
@@ -143,7 +151,7 @@ struct jx_ctx {
     double trunc_bound = 1e-9, trunc_bound_ll = 1e-8;
     int trunc_retried = 0, trunc_points = 0, trunc_uncapped = 0, trunc_unsub = 0;   // rebuilds in all; of which: the cap on the rank taken away
     bool tol_pinned = false;           // JOXSZ_LOWRANK_TOL given: the guard measures but never overrides
-    int form_force = -1;               // JOXSZ_MIX_FORM: 0 low-rank, 1 full
+    int form_force = 2;                // JOXSZ_MIX_FORM: 2 exact (default); the contracted forms of rounds 3-4: -1 legacy (the cheaper of the two), 0 lowrank, 1 full
     int map_pair = 1;                  // full-map kernel: two walkers per block (JOXSZ_MAP_PAIR=0: one)
     int usplit = 2;                    // pieces a map column is walked in by stage 1 (JOXSZ_MIX_USPLIT: 1..4; a setting, never a function of the launch)
     bool usplit_forced = false;        // (otherwise plan_mix picks it from the columns stage 1 walks and the chunk)
@@ -492,6 +500,9 @@ struct MixBuild {
     int cld = 0;
     double tol = 0.0, beam_tol = 0.0;
     double cost_lowrank = 0.0, cost_full = 0.0;
+    // exact form
+    int Nk = 0, Nkp = 0, x_nxt = 0, x_ng = 0, x_ng_use = 0, x_npair = 0, x_nSj = 0;
+    std::vector<double> xTyp, xOpk;
 };
 
 static void mix_output_tiling(int nrow, int* nxt, int* nog, int* ntile) {
@@ -507,6 +518,7 @@ static void mix_output_tiling(int nrow, int* nxt, int* nog, int* ntile) {
 // carry element offsets into them).
 static void plan_mix(jx_ctx* ctx, const std::vector<double>& beam, const std::vector<double>& filt, const std::vector<double>& r,
                      double tol, int form_force, long long tW, MixBuild& mb) {
+    if (form_force == 2 && ctx->f32) form_force = -1;          // (the fp32 variants exist on the forms of rounds 3-4)
     const jx_config& c = ctx->cfg;
     const int S = c.S, B = c.B, Sh = S / 2 + 1, nrow = S - S / 2;
     if (!ctx->dmat_mirror) { mb.why = "d_mat lacks the mirror structure of centdistmat"; return; }
@@ -524,6 +536,31 @@ static void plan_mix(jx_ctx* ctx, const std::vector<double>& beam, const std::ve
     double maxre = 0.0, maxim = 0.0;
     for (size_t e = 0; e < A.size(); ++e) { A[e] = hy[2 * e]; maxre = std::max(maxre, std::fabs(hy[2 * e])); maxim = std::max(maxim, std::fabs(hy[2 * e + 1])); }
     if (!(maxim <= 1e-15 * maxre)) { mb.why = "transfer-function weights are not real"; return; }
+    if (form_force == 2) {
+        // (the row of 16 walkers and the eight waves' partial tiles have to fit the LDS of the row product: data radii reaching
+        //  across a very large map go to the contracted forms)
+        const int nuse0 = std::min(ctx->prune ? std::max(1, ctx->nrow_use) : nrow, nrow);
+        if (sizeof(double) * JX_RST_LDS_DOUBLES((nuse0 + 1) | 1, c.nflux, 0) > (size_t)158 * 1024) form_force = -1;
+    }
+    if (form_force == 2) {
+        // ---- exact form: the row as one constant operator on the spline ordinates (every pixel, every radius, nothing truncated)
+        std::vector<double> Wy;
+        mb.form = 2;
+        mb.Nk = jxt::exact_row_operator(beam, B, c.step * c.step, A, S, NU, ctx->h_Qtab, ctx->qn, r, ctx->h_G, ctx->K, Wy);
+        if (!ctx->map_ok) mb.Nk = c.N;                          // (the profile taps are then read off the product's own array: every ordinate)
+        mb.Nkp = (mb.Nk + 15) & ~15;
+        const int tiles_use = (std::max(1, ctx->prune ? ctx->nrow_use : nrow) + 15) / 16, tiles = (nrow + 15) / 16;
+        mb.x_nxt = std::min(6, tiles_use);
+        mb.x_ng_use = (tiles_use + mb.x_nxt - 1) / mb.x_nxt;
+        mb.x_ng = (tiles + mb.x_nxt - 1) / mb.x_nxt;
+        jxt::exact_row_layout(Wy, nrow, c.N, mb.Nkp / 16, mb.x_nxt, mb.x_ng, mb.xOpk);
+        mb.x_npair = (mb.Nkp / 16 + 1) / 2;
+        mb.x_nSj = (c.N + 15) / 16;
+        jxt::abel_ordinate_layout(r, c.kpc_cm * c.sigma_T / c.m_e, mb.Nkp / 16, mb.x_nSj, mb.xTyp);
+        mb.r = 0; mb.ns = 0; mb.R = 0; mb.RT = 0; mb.NU_full = NU; mb.krows = 0;
+        mb.ok = true;
+        return;
+    }
     // ---- low-rank form: separable terms of the beam x singular terms of the weights
     std::vector<double> U, V, by, bx;
     // Which rows (= columns) of the quadrant stage 1 evaluates: all of them, or -- when the quadrant lies inside the radial grid
@@ -735,6 +772,19 @@ static int mix_setup(jx_ctx* ctx, const MixBuild& mb, long long tW) {
     m.mfma = mb.mfma; m.r_tol = mb.r_tol;
     m.NU_full = mb.NU_full; m.sub = mb.sub;
     int* qi; double* qd;
+    if (mb.form == 2) {
+        // exact form: two constant operators and the ordinates of a chunk; none of the work buffers of the contracted forms
+        m.Nk = mb.Nk; m.Nkp = mb.Nkp; m.x_nxt = mb.x_nxt; m.x_ng = mb.x_ng; m.x_ng_use = mb.x_ng_use;
+        m.x_npair = mb.x_npair; m.x_nSj = mb.x_nSj; m.x_ldpp = 16 * mb.x_nSj;
+        m.cft = nullptr; m.Dt = nullptr; m.Pt = nullptr; m.x_cf = nullptr; m.x_ppi = nullptr; m.has_u = false; m.ncol = 2 * N;
+        if ((rc = dev_put_l(ctx, m.allocs, mb.xTyp.data(), mb.xTyp.size(), &m.x_Typ))) return rc;
+        if ((rc = dev_put_l(ctx, m.allocs, mb.xOpk.data(), mb.xOpk.size(), &m.x_Opk))) return rc;
+        if ((rc = dev_new_l(ctx, m.allocs, (size_t)tW * m.Nkp, &m.x_y, true))) return rc;
+        if ((rc = dev_new_l(ctx, m.allocs, (size_t)(tW / 16) * m.x_npair * m.x_ng * 256 * m.x_nxt, &m.x_P, true))) return rc;
+        m.bytes = ctx->device_bytes - before;
+        m.ready = true;
+        return JX_OK;
+    }
     const size_t esz = ctx->f32 ? sizeof(float) : sizeof(double);
     const size_t cft_rows = (size_t)N + 2 * JX_MIX_NS + 2;
     if (2 * esz * cft_rows * tW >= ((size_t)1 << 32)) { ctx->err = "contracted route: launch too large for 32-bit knot offsets (lower max_batch)"; return JX_ERR_UNSUPPORTED; }
@@ -1182,7 +1232,10 @@ static int finalize_impl(jx_ctx* ctx) {
     //  log-posterior a small difference of large terms -- keep every term above rounding, where it costs next to nothing)
     if (const char* e = env_str("JOXSZ_LOWRANK_TOL")) { const double v2 = atof(e); if (v2 > 0.0 && v2 < 1e-6) { lr_tol0 = v2; ctx->tol_pinned = true; } }
     if (const char* e = env_str("JOXSZ_TRUNC_BOUND")) { const double v = atof(e); if (v > 0.0) { ctx->trunc_bound = v; ctx->trunc_bound_ll = std::min(ctx->trunc_bound_ll, 10.0 * v); } }
-    if (const char* e = env_str("JOXSZ_MIX_FORM")) { if (!strcmp(e, "lowrank")) ctx->form_force = 0; else if (!strcmp(e, "full")) ctx->form_force = 1; }
+    if (const char* e = env_str("JOXSZ_MIX_FORM")) {
+        if (!strcmp(e, "lowrank")) ctx->form_force = 0; else if (!strcmp(e, "full")) ctx->form_force = 1;
+        else if (!strcmp(e, "legacy")) ctx->form_force = -1; else if (!strcmp(e, "exact")) ctx->form_force = 2;
+    }
     if (const char* e = env_str("JOXSZ_MAP_PAIR")) ctx->map_pair = atoi(e) != 0;
     if (const char* e = env_str("JOXSZ_MIX_USPLIT")) { const int v = atoi(e); if (v >= 1 && v <= 4) { ctx->usplit = v; ctx->usplit_forced = true; } }
     if (const char* e = env_str("JOXSZ_MIX_SUBSAMPLE")) {
@@ -1201,6 +1254,7 @@ static int finalize_impl(jx_ctx* ctx) {
     if (const char* e = env_str("JOXSZ_ABEL_GEMM")) ctx->abel_gemm = atoi(e) != 0;
     if (const char* e = env_str("JOXSZ_AG_NARROW")) ctx->ag_narrow = atoi(e) != 0;
     if (const char* e = env_str("JOXSZ_AG_SINGLE")) ctx->ag_single = atoi(e) != 0;
+    if (const char* e = env_str("JOXSZ_X_PAIRWISE")) ctx->mix.x_pairwise = atoi(e) != 0;
     if (const char* e = env_str("JOXSZ_PREP_SPLIT")) ctx->prep_split = atoi(e) != 0;
     if (const char* e = env_str("JOXSZ_AG_SUBSAMPLE")) {
         int a0 = 0, a1 = 0, a2 = 0;
@@ -1276,6 +1330,9 @@ static int finalize_impl(jx_ctx* ctx) {
         ctx->map_ok = map_geometry(dt, 512, &th, &ld);
         if (!ctx->map_ok) { lr_tol0 = std::min(lr_tol0, 1e-13); ctx->rank_cap = 0; ctx->tol_pinned = true; ctx->subsample = false; }   // (nothing could measure a truncation or a sub-grid: neither is taken)
     }
+    // ---- spline moment operator of the mirrored grid (joxsz_funcs.py:460) and the half-width of its band
+    if (!jxt::mirrored_spline_op(r, ctx->h_G)) { ctx->err = "spline operator: singular system"; return JX_ERR_INVALID; }
+    ctx->K = d.K = jxt::band_halfwidth(ctx->h_G, N, 1e-20);
     // ---- which back end: contracted route or the rocFFT sequence
     std::vector<double> beam_h = host_vec<double>(ctx, JX_T_BEAM_2D);
     MixBuild mixb;
@@ -1310,10 +1367,8 @@ static int finalize_impl(jx_ctx* ctx) {
     // ---- spline moment operator of the mirrored grid, stored as a band; operator of the spline-array matrix product
     std::vector<double> h_Tm;
     {
-        std::vector<double> G;
-        if (!jxt::mirrored_spline_op(r, G)) { ctx->err = "spline operator: singular system"; return JX_ERR_INVALID; }
-        int K = jxt::band_halfwidth(G, N, 1e-20);
-        ctx->K = d.K = K;
+        const std::vector<double>& G = ctx->h_G;
+        const int K = ctx->K;
         std::vector<double> band((size_t)(2 * K + 1) * N, 0.0);
         for (int i = 0; i < N; ++i)
             for (int k = -K; k <= K; ++k) {
@@ -1321,7 +1376,7 @@ static int finalize_impl(jx_ctx* ctx) {
                 if (j >= 0 && j < N) band[(size_t)(k + K) * N + i] = G[(size_t)i * N + j];
             }
         double* p; if ((rc = dev_put(ctx, band.data(), band.size(), &p))) return rc; d.gband = p;
-        if (ctx->conv_mode == 2) {
+        if (ctx->conv_mode == 2 && mixb.form != 2) {
             ctx->tm_ntile = (2 * N + 15) / 16;
             ctx->tm_npair = (ctx->tm_ntile + 1) / 2;
             ctx->tm_ld = 32 * ctx->tm_npair;
@@ -1471,11 +1526,11 @@ static int finalize_impl(jx_ctx* ctx) {
             HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_tail, hipEventDisableTiming));
         }
         if ((rc = dev_put(ctx, h_Tm.data(), h_Tm.size(), &ctx->d_Tm))) return rc;
-        if ((rc = dev_new(ctx, (size_t)chunk * N, &ctx->d_ppc, true))) return rc;
+        if ((rc = dev_new(ctx, (size_t)chunk * (mixb.form == 2 ? 16 * (size_t)mixb.x_nSj : (size_t)N), &ctx->d_ppc, true))) return rc;   // (exact form: rows padded with zeros to whole 16-radius steps)
         // The pressure profile is smooth away from the core: its values on a sub-grid of the radial grid carry the others by high-order
         // interpolation, pp ~ L pp_sub, and the product needs only L^T Tm -- K shrinks from N to the kept radii (222 of 500, 285 of 1000)
         // and with it the k loop that bounds the kernel.  Measured by the guard of jx_finalize like the sub-grid of map samples.
-        if (ctx->ag_sub && ctx->map_ok) {
+        if (ctx->ag_sub && ctx->map_ok && mixb.form != 2) {
             std::vector<int> rs;
             jxt::mix_row_subset(N, ctx->ag_u0, ctx->ag_u1, rs);
             const int ns = (int)rs.size();
@@ -1513,6 +1568,10 @@ static int finalize_impl(jx_ctx* ctx) {
         HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_opgemm_kernel<1, Xv, float2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
         JX_MIX_NXTS(JX_OPG_ATTR)
 #undef JX_OPG_ATTR
+#define JX_ROP_ATTR(Xv) HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_rowop_tail_kernel<Xv>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024)); \
+        HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_rowsum_tail_kernel<Xv>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+        JX_MIX_NXTS(JX_ROP_ATTR)
+#undef JX_ROP_ATTR
     } else {
         if ((rc = fft_setup(ctx, ctx->fft, chunk, P))) return rc;
     }
@@ -1547,9 +1606,12 @@ static int drain_events(jx_ctx* ctx) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     for (auto& es : ctx->ev_inflight) {
         float ms[5] = {0, 0, 0, 0, 0}, tot;
-        if (es.p1only) {                               // two events per launch sequence: the time-dominant kernel alone
+        if (es.p1only) {                               // two events per launch sequence: one kernel of the step alone
             HIPCHK(ctx, hipEventElapsedTime(&ms[2], es.e[2], es.e[3]));
-            ctx->acc.beam_fft_ms += ms[2];
+            if (es.p1stage == 3) ctx->acc.prep_ms += ms[2];
+            else if (es.p1stage == 4) ctx->acc.tail_ms += ms[2];
+            else if (es.exact) ctx->acc.abel_map_ms += ms[2];
+            else ctx->acc.beam_fft_ms += ms[2];
             ctx->acc.launches += 1; ctx->acc.walkers += es.walkers;
             ctx->ev_free.push_back(es);
             continue;
@@ -1557,6 +1619,10 @@ static int drain_events(jx_ctx* ctx) {
         if (es.op) {                                   // collapsed route: prep, then one kernel
             HIPCHK(ctx, hipEventElapsedTime(&ms[0], es.e[0], es.e[1]));
             HIPCHK(ctx, hipEventElapsedTime(&ms[4], es.e[1], es.e[5]));
+        } else if (es.exact) {                         // exact form: per-walker kernel, ordinate product, row product + tail
+            HIPCHK(ctx, hipEventElapsedTime(&ms[0], es.e[0], es.e[1]));
+            HIPCHK(ctx, hipEventElapsedTime(&ms[1], es.e[1], es.e[2]));
+            HIPCHK(ctx, hipEventElapsedTime(&ms[4], es.e[2], es.e[5]));
         } else {
             for (int k = 0; k < 5; ++k) HIPCHK(ctx, hipEventElapsedTime(&ms[k], es.e[k], es.e[k + 1]));
         }
@@ -1603,8 +1669,8 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
             }
     EvSet es;
     // timing mode 2 records the two events around the time-dominant kernel only (stage 1 of the contracted route)
-    const bool tm = ctx->timing_on && ctx->timing_mode != 2 && !use_ref;
-    const bool tm2 = ctx->timing_on && ctx->timing_mode == 2 && !fftb && !op_route;
+    const bool tm = ctx->timing_on && ctx->timing_mode == 1 && !use_ref;
+    const bool tm2 = ctx->timing_on && ctx->timing_mode >= 2 && !fftb && !op_route;
     // the operator route has no per-walker work buffers beyond these three, so its launches can be much larger than a chunk
     double* base_buf = op_route ? ctx->d_base_op : ctx->d_base;
     double* cfac_buf = op_route ? ctx->d_cfac_op : ctx->d_cfac;
@@ -1614,13 +1680,16 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
     // the Abel kernel, which then writes the arrays itself) or the matrix product is switched off
     const bool want_abel_taps = t.pp || t.ab || t.y;
     // (a grid too long for the Abel kernel: always the matrix product; the profile taps are then read off its own arrays)
-    const bool ag = mix && ctx->abel_gemm && (ctx->f32 || !ctx->map_ok || (!want_abel_taps && !ctx->d.inject_pp));
+    const bool exact = mix && ctx->mix.form == 2;                   // the exact form: ordinate product + row product with the tail as its epilogue
+    const bool ag = exact || (mix && ctx->abel_gemm && (ctx->f32 || !ctx->map_ok || (!want_abel_taps && !ctx->d.inject_pp)));
     if (tm || tm2) {
         if (ctx->ev_inflight.size() > 2048 && (rc = drain_events(ctx))) return rc;
         if ((rc = get_evset(ctx, &es))) return rc;
         es.walkers = n;
         es.op = false;
         es.p1only = tm2;
+        es.exact = exact;
+        es.p1stage = (exact && ctx->timing_mode >= 3) ? ctx->timing_mode : 2;
         if (tm) HIPCHK(ctx, hipEventRecord(es.e[0], st));
     }
     // Contracted route: only the pressure profile is in the way of the SZ chain (spline arrays -> stage 1 -> stage 2); priors,
@@ -1630,7 +1699,7 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
     // the tail.  Everything the fork event follows on the compute stream -- the previous tail, which reads the buffers this
     // kernel writes, and whatever produced theta -- is therefore complete when it starts.  Calls with taps stay in line.
     const bool any_tap = t.pp || t.ab || t.y || t.row || t.bright || t.chisq || t.tprof || t.xprofs || t.parts || t.integ || t.need_img;
-    const bool side = mix && ag && ctx->side_stream && !ctx->d.inject_pp && !any_tap;
+    const bool side = mix && ag && !exact && ctx->side_stream && !ctx->d.inject_pp && !any_tap;
     // two blocks per walker in the per-walker kernel (the X-ray side beside the rest): the timed sequence of the contracted route only
     // (up to ~640 radii: beyond, the grid pass on half the threads is the longer of the two chains by more than the split saves --
     //  measured at N = 1000: 32.5 -> 34.7 us; at N = 500: 27.6 -> 23.4, at N = 313: 26.8 -> 22.3)
@@ -1640,6 +1709,7 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
         dp.inject_pp = ctx->d.inject_pp;
         dp.xr_split = xr_split ? 1 : 0;
         dp.xr_out = ctx->d_xr;
+        dp.pp_ld = (exact && pp_buf == ctx->d_ppc) ? ctx->mix.x_ldpp : 0;
         const unsigned pgrid = xr_split ? 2u * (unsigned)n : (unsigned)n, pthr = xr_split ? 128u : (unsigned)JX_PREP_THREADS;
         const size_t sh = sizeof(double) * (JX_LDS_HDR + (size_t)2 * d.N + 2 * d.nann + 2 * (size_t)d.nband * d.nann + 2 * (size_t)d.nconv + 8 + JX_FM_TABLE_DOUBLES);
         if (d.prep_pow) hipLaunchKernelGGL((jx_prep_kernel<true, false>), dim3(pgrid), dim3(pthr), sh, ps, dp, theta_dev, w0,
@@ -1662,7 +1732,11 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
                 launch_prep(ctx->side_stream, nullptr);
                 HIPCHK(ctx, hipEventRecord(ctx->ev_side, ctx->side_stream));
             }
-        } else launch_prep(st, pp_buf);
+        } else {
+            if (tm2 && es.p1stage == 3) HIPCHK(ctx, hipEventRecord(es.e[2], st));
+            launch_prep(st, pp_buf);
+            if (tm2 && es.p1stage == 3) HIPCHK(ctx, hipEventRecord(es.e[3], st));
+        }
     }
     if (tm) HIPCHK(ctx, hipEventRecord(es.e[1], st));
     if (op_route) {
@@ -1700,6 +1774,87 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
         if (ctx->f32 && (want_abel_taps || t.need_img)) { ctx->err = "dtype f32: the profile and map taps exist in the f64 build of the context only"; return JX_ERR_UNSUPPORTED; }
         if (ctx->f32 && !ag) { ctx->err = "dtype f32 takes its spline arrays from the matrix product only (JOXSZ_ABEL_GEMM=0 is an f64 setting)"; return JX_ERR_UNSUPPORTED; }
         if (!ctx->map_ok && (!ag || t.need_img)) { ctx->err = "radial grid too long for the Abel + map kernel: no Compton-y map tap on this problem (and JOXSZ_ABEL_GEMM=0 is not available)"; return JX_ERR_UNSUPPORTED; }
+        if (exact) {
+            // ---- exact form: y = y_scale A pp on the matrix cores and each column-tile pair's share of out = Wy y (jx_ordrow_kernel), then the
+            //      partial rows added in pair order with the tail behind them (jx_rowsum_tail_kernel)
+            const int N = d.N;
+            const double* pp_src = ctx->d_ppc;
+            if (ctx->d.inject_pp) {                              // (operator build: the unit profiles into the padded rows of the product)
+                if (!m.x_ppi && (rc = dev_new_l(ctx, m.allocs, (size_t)ctx->chunk * m.x_ldpp, &m.x_ppi, true))) return rc;
+                HIPCHK(ctx, hipMemcpy2DAsync(m.x_ppi, sizeof(double) * m.x_ldpp, ctx->d.inject_pp, sizeof(double) * N, sizeof(double) * N, n, hipMemcpyDeviceToDevice, st));
+                pp_src = m.x_ppi;
+            }
+            JxRowOp ro;
+            memset(&ro, 0, sizeof(ro));
+            const bool all = t.row || t.bright;                  // the row and brightness taps get every output; the data-radii matrix reads the same ones either way
+            ro.n = n; ro.nS = m.Nkp / 16; ro.ldy = m.Nkp; ro.ng = all ? m.x_ng : m.x_ng_use;
+            ro.nuse = std::min(ctx->prune ? ctx->nrow_use : d.nrow, d.nrow);
+            ro.ldr = (ro.nuse + 1) | 1;
+            ro.lde = ro.nuse;
+            ro.ldpp = m.x_ldpp; ro.nSj = m.x_nSj; ro.npair = m.x_npair;
+#ifdef JOXSZ_ABLATIONS
+            ro.dbg = m.dbg;
+#endif
+            ro.Opk = m.x_Opk; ro.Typ = m.x_Typ; ro.pp = pp_src; ro.y = m.x_y; ro.P = m.x_P;
+            const size_t lds_max = (size_t)158 * 1024;
+            const bool pairwise = m.x_pairwise;
+            {
+                JxRowOp r1 = ro;
+                if (!pairwise) r1.ng = 0;                        // (the ordinates alone: the row product reads them back)
+                const int ntw = (n + 15) / 16;
+                const dim3 grid((unsigned)(8 * ((ntw + 7) / 8) * m.x_npair));
+                const size_t sh1 = sizeof(double) * JX_ORD_LDS_DOUBLES;
+                if (tm2 && es.p1stage == 2) HIPCHK(ctx, hipEventRecord(es.e[2], st));
+                bool done = false;
+#define JX_ORD_GO(Xv) if (!done && m.x_nxt == Xv) { hipLaunchKernelGGL((jx_ordrow_kernel<Xv>), grid, dim3(256), sh1, st, r1); done = true; }
+                JX_MIX_NXTS(JX_ORD_GO)
+#undef JX_ORD_GO
+                if (!done) { ctx->err = "no ordinate-product kernel for this output tiling"; return JX_ERR_UNSUPPORTED; }
+                if (tm2 && es.p1stage == 2) HIPCHK(ctx, hipEventRecord(es.e[3], st));
+            }
+            if (want_abel_taps) {
+                if (ctx->map_ok) {
+                    // the profile taps come from the Abel kernel's own phases 1-3 (an independent evaluation of the same three lines)
+                    if (!m.x_cf && (rc = dev_new_l(ctx, m.allocs, (size_t)ctx->chunk * 2 * N, &m.x_cf, true))) return rc;
+                    JxDev dm = ctx->d;
+                    dm.cf_out = m.x_cf; dm.cf_ws = 2LL * N; dm.cf_tr = 0;
+                    launch_map(st, dm, ctx->map_threads, ctx->map_lds, theta_dev, w0, n, nullptr, t.pp, t.ab, t.y, true);
+                } else {
+                    if (t.pp) HIPCHK(ctx, hipMemcpy2DAsync(t.pp, sizeof(double) * N, pp_src, sizeof(double) * m.x_ldpp, sizeof(double) * N, n, hipMemcpyDeviceToDevice, st));
+                    if (t.y || t.ab) hipLaunchKernelGGL(jx_unpack_ordinates_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)n), dim3(256), 0, st,
+                                                        m.x_y, m.Nkp, N, d.y_scale, t.y, t.ab);
+                }
+            }
+            if (t.need_img) {
+                if (!ctx->d_img && (rc = dev_new(ctx, (size_t)ctx->chunk * d.img_ws, &ctx->d_img, true))) return rc;
+                launch_map(st, ctx->d, ctx->map_threads, ctx->map_lds, theta_dev, w0, n, ctx->d_img, nullptr, nullptr, nullptr, false);
+            }
+            if (tm) HIPCHK(ctx, hipEventRecord(es.e[2], st));
+            {
+                JxDev dtl = d;
+                dtl.xr_split = xr_split ? 1 : 0;
+                dtl.xr_out = ctx->d_xr;
+                const size_t extra = pairwise ? 0 : sizeof(double) * (size_t)JX_ROP_NW * 16 * JX_ROP_LDP(m.x_nxt);
+                if (extra + sizeof(double) * JX_RST_LDS_DOUBLES(ro.ldr, d.nflux, ro.lde) > lds_max) ro.lde = 0;   // (the data-radii matrix from memory then)
+                const size_t shr = extra + sizeof(double) * JX_RST_LDS_DOUBLES(ro.ldr, d.nflux, ro.lde);
+                if (shr > lds_max) { ctx->err = "exact form: the outputs the data-radii spline reads do not fit the tail's LDS (JOXSZ_MIX_FORM=legacy runs them)"; return JX_ERR_UNSUPPORTED; }
+                if (tm2 && es.p1stage == 4) HIPCHK(ctx, hipEventRecord(es.e[2], st));
+                bool done = false;
+                const dim3 gridt((unsigned)((n + 15) / 16));
+#define JX_ROP_GO(Xv) if (!done && m.x_nxt == Xv) { \
+                    if (pairwise) hipLaunchKernelGGL((jx_rowsum_tail_kernel<Xv>), gridt, dim3(JX_RST_THREADS), shr, st, dtl, ro, ctx->d_cfac, ctx->d_sz0, ctx->d_base, logp_dev, w0, t.row, t.bright, t.chisq, t.parts, smv); \
+                    else hipLaunchKernelGGL((jx_rowop_tail_kernel<Xv>), gridt, dim3(64 * JX_ROP_NW), shr, st, dtl, ro, ctx->d_cfac, ctx->d_sz0, ctx->d_base, logp_dev, w0, t.row, t.bright, t.chisq, t.parts, smv); \
+                    done = true; }
+                JX_MIX_NXTS(JX_ROP_GO)
+#undef JX_ROP_GO
+                if (!done) { ctx->err = "no row-product kernel for this output tiling"; return JX_ERR_UNSUPPORTED; }
+                if (tm2 && es.p1stage == 4) HIPCHK(ctx, hipEventRecord(es.e[3], st));
+            }
+            if (tm) HIPCHK(ctx, hipEventRecord(es.e[5], st));
+            if (tm || tm2) ctx->ev_inflight.push_back(es);
+            HIPCHK(ctx, hipGetLastError());
+            return JX_OK;
+        }
         if (ag) {
             // 32 walkers per block, or 16 when that would leave SIMDs without a wave (a walker's sums do not depend on it)
             const int gy = (ctx->tm_npair + 3) / 4;
@@ -1873,7 +2028,7 @@ static void probe_vectors(jx_ctx* ctx, std::vector<double>& th, int* npts) {
 // all probe points (-1 each where nothing finite came back)
 static int measure_truncation(jx_ctx* ctx, double est[3], int* used) {
     est[0] = est[1] = est[2] = -1.0; *used = 0;
-    if (ctx->conv_mode != 2 || (ctx->mix.form != 0 && ctx->mix.sub.empty() && !ctx->ag_sub_on)) return JX_OK;   // nothing truncated, every distinct sample and radius evaluated
+    if (ctx->conv_mode != 2 || ctx->mix.form == 2 || (ctx->mix.form != 0 && ctx->mix.sub.empty() && !ctx->ag_sub_on)) return JX_OK;   // nothing truncated, every distinct sample and radius evaluated
     if (!ctx->map_ok) return JX_OK;                                         // nothing to measure against (and every term above rounding is kept)
     const jx_config& c = ctx->cfg;
     int rc, npts = 0;
@@ -1924,7 +2079,7 @@ int jx_finalize(jx_ctx* ctx) {
     int rc = finalize_impl(ctx);
     if (rc) return rc;
     if (const char* e = env_str("JOXSZ_TRUNC_PROBE")) { if (atoi(e) == 0) return JX_OK; }
-    if (ctx->conv_mode != 2 || (ctx->mix.form != 0 && ctx->mix.sub.empty() && !ctx->ag_sub_on)) return JX_OK;
+    if (ctx->conv_mode != 2 || ctx->mix.form == 2 || (ctx->mix.form != 0 && ctx->mix.sub.empty() && !ctx->ag_sub_on)) return JX_OK;
     // The low-rank form drops the small singular values of the transfer-function weights.  What that costs is measured on the
     // caller's own beam / transfer function / prior box (measure_truncation); beyond the bounds the tables are rebuilt with
     // a cut ten times tighter -- in place: stream, communicator and every other piece of the context stay -- until the
@@ -2330,7 +2485,7 @@ int jx_memcpy_d2h(jx_ctx* ctx, void* host, const void* dev, size_t n) {
 int jx_timing_enable(jx_ctx* ctx, int on) {
     if (!ctx) return JX_ERR_INVALID;
     ctx->timing_on = on != 0;
-    ctx->timing_mode = (on == 2) ? 2 : (on ? 1 : 0);
+    ctx->timing_mode = (on >= 2 && on <= 4) ? on : (on ? 1 : 0);
     return JX_OK;
 }
 
@@ -2369,6 +2524,11 @@ int jx_get_conv_layout(jx_ctx* ctx, int32_t out[12]) {
     if (!ctx || !ctx->finalized || !out) return JX_ERR_STATE;
     if (ctx->conv_mode != 2) { ctx->err = "layout of the contracted route only"; return JX_ERR_UNSUPPORTED; }
     const MixBack& m = ctx->mix;
+    if (m.form == 2) {
+        out[0] = 2; out[1] = ctx->qn; out[2] = m.Nk; out[3] = m.Nkp; out[4] = 0; out[5] = 0; out[6] = m.x_nxt; out[7] = m.x_nxt * m.x_ng;
+        out[8] = m.Nkp / 4; out[9] = (int32_t)m.tW; out[10] = 16 * m.x_nxt * m.x_ng_use; out[11] = JX_ROP_NW;
+        return JX_OK;
+    }
     out[0] = m.form; out[1] = ctx->qn; out[2] = m.r; out[3] = m.ns; out[4] = m.form == 0 ? m.mx.R : 0; out[5] = m.RT;
     out[6] = m.nxt; out[7] = m.og.ntile; out[8] = m.ksteps; out[9] = (int32_t)m.tW; out[10] = m.og.ldx; out[11] = m.last_ksplit;
     return JX_OK;
@@ -2379,6 +2539,14 @@ int jx_debug_workspace(jx_ctx* ctx, int which, void** dev, int32_t geom[4]) {
     if (ctx->conv_mode != 2) { ctx->err = "work buffers of the contracted route only"; return JX_ERR_UNSUPPORTED; }
     const MixBack& m = ctx->mix;
     geom[0] = geom[1] = geom[2] = geom[3] = 0;
+    if (m.form == 2) {
+        if (which == 6) { *dev = m.x_y; geom[0] = 1; geom[1] = (int)m.tW; geom[2] = m.Nkp; geom[3] = 8; return JX_OK; }
+        if (which == 7) { *dev = m.x_Opk; geom[0] = m.x_ng * (m.Nkp / 16) * 4; geom[1] = 64; geom[2] = m.x_nxt; geom[3] = 8; return JX_OK; }
+        if (which == 0 && ctx->d_img) { *dev = ctx->d_img; geom[0] = ctx->chunk; geom[1] = ctx->d.q_nb; geom[2] = (int)ctx->d.img_ld; geom[3] = 8; return JX_OK; }
+        ctx->err = "exact form: work buffers 6 (ordinates [1][tW][Nkp]) and 7 (row operator) -- and 0 after a y_2d tap -- exist; the others belong to the contracted forms";
+        return JX_ERR_UNSUPPORTED;
+    }
+    if (which >= 6) { ctx->err = "work buffers 6 and 7 belong to the exact form"; return JX_ERR_UNSUPPORTED; }
     switch (which) {
         case 0: if (!ctx->d_img) { ctx->err = "the map quadrant exists after the first y_2d tap"; return JX_ERR_STATE; }
                 *dev = ctx->d_img; geom[0] = ctx->chunk; geom[1] = ctx->d.q_nb; geom[2] = (int)ctx->d.img_ld; geom[3] = 8; break;
@@ -2416,6 +2584,11 @@ int jx_get_radial_sampling(jx_ctx* ctx, int32_t out[6], int32_t* rows, int nrows
 int jx_get_output_pruning(jx_ctx* ctx, int32_t out[6]) {
     if (!ctx || !ctx->finalized || !out) return JX_ERR_STATE;
     const MixBack& m = ctx->mix;
+    if (ctx->conv_mode == 2 && m.form == 2) {
+        out[0] = ctx->nrow; out[1] = ctx->prune ? ctx->nrow_use : ctx->nrow; out[2] = std::min(16 * m.x_nxt * m.x_ng_use, 16 * m.x_nxt * m.x_ng);
+        out[3] = m.x_nxt; out[4] = JX_ROP_NW; out[5] = m.x_ng_use < m.x_ng ? 1 : 0;
+        return JX_OK;
+    }
     const bool u = ctx->conv_mode == 2 && m.has_u;
     out[0] = ctx->nrow; out[1] = ctx->nrow_use; out[2] = u ? 16 * m.og_u.ntile : ctx->nrow; out[3] = u ? m.nxt_u : 0; out[4] = u ? m.ksplit_u : 0;
     out[5] = u ? 1 : 0;

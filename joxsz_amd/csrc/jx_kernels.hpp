@@ -70,6 +70,7 @@ struct JxDev {
     int prep_pow;                // 1 (JOXSZ_PREP_POW=1): the prep kernel evaluates the profiles with pow() as written in the reference
     const double* lr_pp;         // [N] log(r_pp)
     const double* inject_pp;     // operator build only: [nlaunch][N] pressure profiles that replace press_fun(theta) (else null)
+    int pp_ld;                   // doubles per walker of jx_prep_kernel's profile output (0: N; the exact form pads its rows to whole 16-radius steps)
     int fast_map, q_na, q_nb;    // symmetric-map form: table sizes (|ix-c|, |iy-c|)
     double* xcol;                // quad mode: copy of the quadrant's last column (map column 0): [chunk][q_nb], or walker-minor
     long long xcol_ld;           //   [q_nb padded][xcol_ld] when xcol_ld > 0 (fused FIR path)
@@ -386,7 +387,8 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
     const bool veto = c.exclude_unphy_mass != 0;
     const int nprof = (veto || pp_out || c.calc_integ) ? c.N : c.nt;
     double ci = 0.0;                          // this thread's share of integ_wp . pp
-    const int N_ = c.N, nt_ = c.nt, mode_ = c.ne_mode;
+    const int nt_ = c.nt, mode_ = c.ne_mode;
+    const size_t ppo = (size_t)w * (c.pp_ld ? c.pp_ld : c.N);
     if (logform) {
         // Two radii per trip, straight-line: the evaluations are chains of dependent fp64 operations, and two independent
         // chains in flight per lane are what keeps the SIMD issuing when few waves are resident.  (The second index is
@@ -401,7 +403,7 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
             // positive constant factors of mass_fun cannot change the sign test:  -r^2 / n_e dP/dr ~ P (c + b x^a) r / ((1 + x^a) n_e)
             const double ma = pa * (p[P_C] + p[P_B] * xaa) * ra * ia / (1.0 + xaa);
             const double mb = pb * (p[P_C] + p[P_B] * xab) * rb * ib / (1.0 + xab);
-            if (pp_out) { pp_out[(size_t)w * N_ + i] = pa; if (two) pp_out[(size_t)w * N_ + i2] = pb; }
+            if (pp_out) { pp_out[ppo + i] = pa; if (two) pp_out[ppo + i2] = pb; }
             if (c.calc_integ) { ci = fma(c.integ_wp[i], pa, ci); if (two) ci = fma(c.integ_wp[i2], pb, ci); }
             if (veto) { s_m[i] = ma; if (two) s_m[i2] = mb; }
             if (i < nt_) s_t[i] = pa * ia;
@@ -413,7 +415,7 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
             const double x = r / p[P_RP];
             const double xa = pow(x, p[P_A]);
             const double press = p[P_P0] / (pow(x, p[P_C]) * pow(1.0 + xa, (p[P_B] - p[P_C]) / p[P_A]));   // == jx_press(p, r)
-            if (pp_out) pp_out[(size_t)w * N_ + i] = press;
+            if (pp_out) pp_out[ppo + i] = press;
             if (c.calc_integ) ci = fma(c.integ_wp[i], press, ci);
             if (veto || i < nt_) {
                 const double ne = jx_ne_pc(p, pc, r, mode_);
@@ -1565,10 +1567,11 @@ jx_abel_gemm_kernel(const double* __restrict__ pp /*[launch][N]*/, int n, int N,
     const int wb = blockIdx.x * 16 * NWT, grp = blockIdx.y;
     const int ktot4 = (N + 4 * JX_AG_R - 1) / (4 * JX_AG_R) * JX_AG_R;          // k-steps, in whole groups of JX_AG_R
     int tile[NTL], ks[NTL], toff[NTL];
+    const bool tk = RS || tks != nullptr;                      // the first k-step of a column tile from a table (radial sub-grid; ordinates-only operator of the exact form)
     if (SINGLE) {
         const int t = grp * 4 + wv;
         tile[0] = t;
-        ks[0] = (t < ntile) ? (RS ? tks[t] : (max(0, 8 * t - K) >> 2)) : ktot4;
+        ks[0] = (t < ntile) ? (tk ? tks[t] : (max(0, 8 * t - K) >> 2)) : ktot4;
         toff[0] = min(t, ntile - 1) * 16;
     } else {
 #pragma unroll
@@ -1578,7 +1581,7 @@ jx_abel_gemm_kernel(const double* __restrict__ pp /*[launch][N]*/, int n, int N,
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int t = tile[(2 * i + h) % NTL];
-                ks[(2 * i + h) % NTL] = (p < npair && t < ntile) ? (RS ? tks[t] : (max(0, 8 * t - K) >> 2)) : ktot4;   // first k-step with entries (ktot4: none)
+                ks[(2 * i + h) % NTL] = (p < npair && t < ntile) ? (tk ? tks[t] : (max(0, 8 * t - K) >> 2)) : ktot4;   // first k-step with entries (ktot4: none)
                 toff[(2 * i + h) % NTL] = min(t, ntile - 1) * 16;
             }
         }
@@ -1589,7 +1592,7 @@ jx_abel_gemm_kernel(const double* __restrict__ pp /*[launch][N]*/, int n, int N,
 #pragma unroll
         for (int nt = 0; nt < NWT; ++nt) acc[t][nt] = jx_op_v4d{0.0, 0.0, 0.0, 0.0};
     // the block's first chunk of radii: the first row of its lowest tile
-    const int kminb = RS ? tks[min(grp * 4 * NPW, ntile - 1)] : (max(0, 8 * (grp * 4 * NPW) - K) >> 2);      // (tks does not decrease with the tile)
+    const int kminb = tk ? tks[min(grp * 4 * NPW, ntile - 1)] : (max(0, 8 * (grp * 4 * NPW) - K) >> 2);      // (tks does not decrease with the tile)
     const int j00 = (4 * kminb / JX_OPM_JC) * JX_OPM_JC;
     int kg = j00 >> 2;
     const double* gb = Tm + (size_t)lk * ldt + li;

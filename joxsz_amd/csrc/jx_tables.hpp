@@ -836,10 +836,12 @@ inline bool quadrant_is_symmetric(const std::vector<double>& Qtab, int qn, int N
 // Per distinct row u (independent: one thread each):  KqU[dx][j] = sum_{m in u} sum_q K2[q][j] beam[q - m + o][dx + o],
 // T[n][d] = sum_{dx: n + dx in [0,S)} KqU[dx][(d - dx) mod S]  (one table for all interior n, 2 o boundary ones), and
 // Om[x][u][x'] = sum_{n in x'} T[n][(c + x - n) mod S].
-inline void mix_full_operator(const std::vector<double>& beam, int B, double scale, const std::vector<double>& Hy /*[S][Sh] real*/,
-                              int S, int NU, std::vector<double>& Om /*[nrow][NU][NU]*/) {
+// (rows: the operator one row at a time -- sink(piece, u, x, om[NU]) receives Om[x][u][0..NU) from the thread that owns the
+//  rows [u0, u1) of piece `piece`; begin(piece count) is called once before the threads start)
+template <typename Begin, typename Sink>
+inline void mix_full_operator_rows(const std::vector<double>& beam, int B, double scale, const std::vector<double>& Hy /*[S][Sh] real*/,
+                                   int S, int NU, Begin&& begin, Sink&& sink) {
     const int c = S / 2, Sh = S / 2 + 1, o = (B - 1) / 2, nrow = S - c;
-    Om.assign((size_t)nrow * NU * NU, 0.0);
     std::vector<double> K2((size_t)S * S);
     {
         std::vector<double> cs(S);
@@ -858,8 +860,8 @@ inline void mix_full_operator(const std::vector<double>& beam, int B, double sca
     std::vector<int> bidx(S, -1);
     int nbnd = 0;
     for (int n = 0; n < S; ++n) if (!(n >= o && n + o < S)) bidx[n] = nbnd++;
-    auto per_u = [&](int u0, int u1) {
-        std::vector<double> Kq((size_t)B * S), Tint(S), Tb((size_t)std::max(nbnd, 1) * S);
+    auto per_u = [&](int piece, int u0, int u1) {
+        std::vector<double> Kq((size_t)B * S), Tint(S), Tb((size_t)std::max(nbnd, 1) * S), omr(NU);
         for (int u = u0; u < u1; ++u) {
             std::fill(Kq.begin(), Kq.end(), 0.0);
             for (int m = 0; m < S; ++m) {
@@ -889,15 +891,124 @@ inline void mix_full_operator(const std::vector<double>& beam, int B, double sca
                 }
             }
             for (int x = 0; x < nrow; ++x) {
-                double* om = &Om[((size_t)x * NU + u) * NU];
+                std::fill(omr.begin(), omr.end(), 0.0);
                 for (int n = 0; n < S; ++n) {
                     const int d = ((c + x - n) % S + S) % S;
-                    om[std::abs(n - c)] += (bidx[n] < 0) ? Tint[d] : Tb[(size_t)bidx[n] * S + d];
+                    omr[std::abs(n - c)] += (bidx[n] < 0) ? Tint[d] : Tb[(size_t)bidx[n] * S + d];
                 }
+                sink(piece, u, x, omr.data());
             }
         }
     };
-    jx_parallel_for(NU, per_u);
+    // (the pieces of jx_parallel_for: the same split, so that a piece knows its index)
+    int nt = (int)std::thread::hardware_concurrency();
+    nt = std::max(1, std::min(std::min(nt, 16), NU));
+    const int per = (NU + nt - 1) / nt, npiece = (NU + per - 1) / per;
+    begin(npiece);
+    std::vector<std::thread> th;
+    for (int t = 0; t < npiece; ++t) {
+        const int a = t * per, b2 = std::min(NU, a + per);
+        th.emplace_back([&per_u, t, a, b2]() { per_u(t, a, b2); });
+    }
+    for (auto& t : th) t.join();
+}
+
+inline void mix_full_operator(const std::vector<double>& beam, int B, double scale, const std::vector<double>& Hy /*[S][Sh] real*/,
+                              int S, int NU, std::vector<double>& Om /*[nrow][NU][NU]*/) {
+    const int nrow = S - S / 2;
+    Om.assign((size_t)nrow * NU * NU, 0.0);
+    mix_full_operator_rows(beam, B, scale, Hy, S, NU, [](int) {},
+                           [&](int, int u, int x, const double* om) { memcpy(&Om[((size_t)x * NU + u) * NU], om, sizeof(double) * NU); });
+}
+
+// ---------------------------------------------------------------------------------------
+// Exact form (round 5): the extracted row as ONE constant operator on the spline ordinates.  Every map sample is linear in the
+// spline arrays (spline_sample_weights: f = A y_k + B y_k+1 + C M_k + D M_k+1, joxsz_funcs.py:460-462), the moments are linear
+// in the ordinates (M = G y: mirrored_spline_op, the band of half-width K the other kernels use), and the map from the
+// quadrant of distinct samples to the row is Om (mix_full_operator: any beam image, any real transfer-function weights,
+// nothing truncated; joxsz_funcs.py:464-467, row of :472).  So
+//     out[x] = sum_i Wy[x][i] y_i,      Wy = Om W_y + Om W_M G      (sums in long double)
+// with no sample sub-grid, no singular-value cut and no low-rank / full split.  Returns the number of leading ordinates
+// with a non-zero column: the radial grid beyond the map's corner plus the band of G does not reach the row.
+// ---------------------------------------------------------------------------------------
+inline int exact_row_operator(const std::vector<double>& beam, int B, double scale, const std::vector<double>& Hy /*[S][Sh] real*/, int S, int NU,
+                              const std::vector<double>& Qtab /*[qn][qn] pixel radii of the quadrant*/, int qn, const std::vector<double>& r,
+                              const std::vector<double>& G /*[N][N]*/, int K, std::vector<double>& Wy /*[nrow][N]*/) {
+    const int N = (int)r.size(), nrow = S - S / 2;
+    std::vector<int> sk((size_t)NU * NU);
+    std::vector<double> sw((size_t)NU * NU * 4);
+    for (int u = 0; u < NU; ++u)
+        for (int xq = 0; xq < NU; ++xq) {
+            int k16;
+            spline_sample_weights(r, Qtab[(size_t)u * qn + xq], &k16, &sw[((size_t)u * NU + xq) * 4]);
+            sk[(size_t)u * NU + xq] = k16 / 16;
+        }
+    std::vector<std::vector<long double>> acc;                  // per piece: [nrow][2][N] (ordinate weights, moment weights)
+    mix_full_operator_rows(beam, B, scale, Hy, S, NU,
+        [&](int npiece) { acc.assign(npiece, std::vector<long double>((size_t)nrow * 2 * N, 0.0L)); },
+        [&](int piece, int u, int x, const double* om) {
+            long double* ay = &acc[piece][(size_t)x * 2 * N];
+            long double* am = ay + N;
+            for (int xq = 0; xq < NU; ++xq) {
+                const double v = om[xq];
+                if (v == 0.0) continue;
+                const int k = sk[(size_t)u * NU + xq];
+                const double* w = &sw[((size_t)u * NU + xq) * 4];
+                ay[k] += (long double)v * w[0]; am[k] += (long double)v * w[2];
+                if (k + 1 < N) { ay[k + 1] += (long double)v * w[1]; am[k + 1] += (long double)v * w[3]; }
+            }
+        });
+    Wy.assign((size_t)nrow * N, 0.0);
+    auto rows = [&](int x0, int x1) {
+        std::vector<long double> ay(N), am(N);
+        for (int x = x0; x < x1; ++x) {
+            std::fill(ay.begin(), ay.end(), 0.0L); std::fill(am.begin(), am.end(), 0.0L);
+            for (const auto& a : acc)                                // (pieces in order: the sums do not depend on thread timing)
+                for (int i = 0; i < N; ++i) { ay[i] += a[(size_t)x * 2 * N + i]; am[i] += a[(size_t)x * 2 * N + N + i]; }
+            for (int i = 0; i < N; ++i) {
+                long double s = ay[i];
+                for (int k = std::max(0, i - K); k <= std::min(N - 1, i + K); ++k) s += am[k] * (long double)G[(size_t)k * N + i];
+                Wy[(size_t)x * N + i] = (double)s;
+            }
+        }
+    };
+    jx_parallel_for(nrow, rows);
+    int nk = 1;
+    for (int x = 0; x < nrow; ++x)
+        for (int i = nk; i < N; ++i) if (Wy[(size_t)x * N + i] != 0.0) nk = i + 1;
+    return nk;
+}
+
+// B operand of the row product (jx_rowop_tail_kernel): macro step s (16 ordinates) x sub-step e x lane (lk, li) x the NXT output
+// tiles of group g,   Opk[(((g nS + s) 4 + e) 64 + 16 lk + li) NXT + t] = Wy[16 (g NXT + t) + li][16 s + 4 lk + e]
+// (zero beyond nrow and beyond the grid): a lane's NXT values are contiguous, a wave's step is one contiguous run.
+inline void exact_row_layout(const std::vector<double>& Wy, int nrow, int N, int nS, int NXT, int ng, std::vector<double>& Opk) {
+    Opk.assign((size_t)ng * nS * 4 * 64 * NXT, 0.0);
+    for (int g = 0; g < ng; ++g)
+        for (int s = 0; s < nS; ++s)
+            for (int e = 0; e < 4; ++e)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int t = 0; t < NXT; ++t) {
+                        const int x = 16 * (g * NXT + t) + (lane & 15), i = 16 * s + 4 * (lane >> 4) + e;
+                        if (x < nrow && i < N) Opk[((((size_t)g * nS + s) * 4 + e) * 64 + lane) * NXT + t] = Wy[(size_t)x * N + i];
+                    }
+}
+
+// B operand of the ordinate product (jx_ordrow_kernel): y_k = sum_j y_scale A[k][j] pp_j (joxsz_funcs.py:457-459), macro step s (16
+// radii) x column tile t (16 ordinates) x lane (lk, li) x sub-step e,   Typ[((s nS + t) 64 + 16 lk + li) 4 + e] = y_scale A[16 t + li][16 s + 4 lk + e]
+// (zero beyond the grid; A is upper triangular, so tile t has entries from step s = t on).
+inline void abel_ordinate_layout(const std::vector<double>& r, double y_scale, int nS, int nSj, std::vector<double>& Typ) {
+    const int N = (int)r.size();
+    std::vector<double> A;
+    abel_matrix(r, A);
+    Typ.assign((size_t)nSj * nS * 256, 0.0);
+    for (int s = 0; s < nSj; ++s)
+        for (int t = 0; t <= s && t < nS; ++t)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 4; ++e) {
+                    const int k = 16 * t + (lane & 15), j = 16 * s + 4 * (lane >> 4) + e;
+                    if (k < N && j < N && k <= j) Typ[(((size_t)s * nS + t) * 64 + lane) * 4 + e] = y_scale * A[(size_t)k * N + j];
+                }
 }
 
 // smallest even 2^a 3^b 5^c >= n

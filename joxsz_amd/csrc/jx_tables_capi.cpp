@@ -178,4 +178,46 @@ int jxt_fastmath_tables(double* out /*[320]*/) {
     return (int)t.size();
 }
 
+// Exact form (round 5): Wy [nrow][N] with  map_out[S//2, S//2 + x] = sum_i Wy[x][i] y_i  for the ordinates y of the mirrored cubic spline
+// (joxsz_funcs.py:460-467, row of :472), built from d_mat's quadrant, the beam image, the filter and the radial grid alone.
+// Returns the number of leading ordinates with a non-zero column, -1 when the transfer-function weights are not real, -2 when
+// d_mat lacks the mirror structure of centdistmat.
+int jxt_exact_row_operator(const double* d_mat, const double* beam, int B, double scale, const double* filt, int S, const double* r, int N, double* Wy) {
+    const int Sh = S / 2 + 1, c = S / 2, NU = std::max(c, S - 1 - c) + 1;
+    std::vector<double> Q((size_t)NU * NU);
+    for (int b = 0; b < NU; ++b)
+        for (int a = 0; a < NU; ++a) {
+            const int iy = (c + b < S) ? c + b : c - b, ix = (c + a < S) ? c + a : c - a;
+            Q[(size_t)b * NU + a] = d_mat[(size_t)iy * S + ix];
+        }
+    for (int iy = 0; iy < S; ++iy)
+        for (int ix = 0; ix < S; ++ix)
+            if (memcmp(&Q[(size_t)std::abs(iy - c) * NU + std::abs(ix - c)], &d_mat[(size_t)iy * S + ix], sizeof(double)) != 0) return -2;
+    std::vector<double> hy, wy, rv(r, r + N), G;
+    jxt::tf_hy_table(std::vector<double>(filt, filt + (size_t)S * S), S, hy);
+    std::vector<double> A((size_t)S * Sh);
+    double mre = 0, mim = 0;
+    for (size_t e = 0; e < A.size(); ++e) { A[e] = hy[2 * e]; mre = std::max(mre, std::fabs(hy[2 * e])); mim = std::max(mim, std::fabs(hy[2 * e + 1])); }
+    if (!(mim <= 1e-15 * mre)) return -1;
+    if (!jxt::mirrored_spline_op(rv, G)) return -3;
+    const int K = jxt::band_halfwidth(G, N, 1e-20);
+    const int nk = jxt::exact_row_operator(std::vector<double>(beam, beam + (size_t)B * B), B, scale, A, S, NU, Q, NU, rv, G, K, wy);
+    std::copy(wy.begin(), wy.end(), Wy);
+    return nk;
+}
+
+// the layouts the kernels of the exact form read: Opk (row operator) and Typ (ordinate operator)
+int jxt_exact_row_layout(const double* Wy, int nrow, int N, int nS, int NXT, int ng, double* Opk) {
+    std::vector<double> o;
+    jxt::exact_row_layout(std::vector<double>(Wy, Wy + (size_t)nrow * N), nrow, N, nS, NXT, ng, o);
+    std::copy(o.begin(), o.end(), Opk);
+    return 0;
+}
+int jxt_abel_ordinate_layout(const double* r, int n, double y_scale, int nS, int nSj, double* out) {
+    std::vector<double> o;
+    jxt::abel_ordinate_layout(std::vector<double>(r, r + n), y_scale, nS, nSj, o);
+    std::copy(o.begin(), o.end(), out);
+    return 0;
+}
+
 }  // extern "C"

@@ -235,7 +235,7 @@ class HipContext:
         lay = (ctypes.c_int32 * 12)()
         self._chk(self.lib.jx_get_conv_layout(self._h, lay), 'jx_get_conv_layout')
         d = dict(zip(('form', 'NU', 'rank', 'beam_terms', 'R', 'RT', 'nxt', 'ntile', 'ksteps', 'tW', 'ldx', 'ksplit'), [int(v) for v in lay]))
-        d['form'] = ('lowrank', 'full')[d['form']]
+        d['form'] = ('lowrank', 'full', 'exact')[d['form']]
         return d
 
     def _truncation(self):
@@ -355,7 +355,7 @@ class HipContext:
         chunk: 'y_map' [chunk, NU, ld] quadrant of the Compton-y map (after a y_2d tap), 'splines' [N, tW, 2] walker-minor
         (y_k, M_k), 'stage1' [NU, R, tW] rows kept per map column, 'partials' [ksplit, tW, ldx] partial rows; the constant
         operators 'stage1_op' [1, wld, cld] (C[u][j]) and 'product_op' [K, 16, ntile] (Op[kappa][x & 15][x >> 4])."""
-        ids = {'y_map': 0, 'splines': 1, 'stage1': 2, 'partials': 3, 'stage1_op': 4, 'product_op': 5}
+        ids = {'y_map': 0, 'splines': 1, 'stage1': 2, 'partials': 3, 'stage1_op': 4, 'product_op': 5, 'ordinates': 6, 'row_op': 7}
         ptr = ctypes.c_void_p()
         geom = (ctypes.c_int32 * 4)()
         self._chk(self.lib.jx_debug_workspace(self._h, ids[which], ctypes.byref(ptr), geom), 'jx_debug_workspace')
