@@ -1710,6 +1710,30 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
         dp.xr_split = xr_split ? 1 : 0;
         dp.xr_out = ctx->d_xr;
         dp.pp_ld = (exact && pp_buf == ctx->d_ppc) ? ctx->mix.x_ldpp : 0;
+#ifdef JOXSZ_ABLATIONS
+        if (env_str("JOXSZ_P_STAMPS")) {                        // (diagnostic build only)
+            static long long* stamps = nullptr;
+            if (!stamps) { (void)hipMalloc((void**)&stamps, sizeof(long long) * 8 * 65536); (void)hipMemset(stamps, 0, sizeof(long long) * 8 * 65536); }
+            dp.stamps = stamps;
+            static int calls = 0;
+            if (++calls == 40) {
+                (void)hipStreamSynchronize(ps);
+                const int nb = xr_split ? 2 * n : n;
+                std::vector<long long> h((size_t)nb * 8);
+                (void)hipMemcpy(h.data(), stamps, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
+                long long t0 = h[0];
+                for (int b = 0; b < nb; ++b) t0 = std::min(t0, h[(size_t)b * 8]);
+                for (int half = 0; half < (xr_split ? 2 : 1); ++half) {
+                    const int b0 = half * n, b1 = b0 + n;
+                    double mx[7] = {0}, sm[7] = {0};
+                    for (int b = b0; b < b1; ++b)
+                        for (int k = 0; k < 7; ++k) { const double v = h[(size_t)b * 8 + k] ? (h[(size_t)b * 8 + k] - t0) * 0.01 : 0.0; mx[k] = std::max(mx[k], v); sm[k] += v / n; }
+                    fprintf(stderr, "prep stamps, %s blocks (us after the first start; mean/max): start %.2f/%.2f params %.2f/%.2f priors %.2f/%.2f grid pass %.2f/%.2f veto+integ %.2f/%.2f factors %.2f/%.2f end %.2f/%.2f\n",
+                            half ? "X-ray" : (xr_split ? "SZ-side" : "all"), sm[0], mx[0], sm[1], mx[1], sm[2], mx[2], sm[3], mx[3], sm[4], mx[4], sm[5], mx[5], sm[6], mx[6]);
+                }
+            }
+        }
+#endif
         const unsigned pgrid = xr_split ? 2u * (unsigned)n : (unsigned)n, pthr = xr_split ? 128u : (unsigned)JX_PREP_THREADS;
         const size_t sh = sizeof(double) * (JX_LDS_HDR + (size_t)2 * d.N + 2 * d.nann + 2 * (size_t)d.nband * d.nann + 2 * (size_t)d.nconv + 8 + JX_FM_TABLE_DOUBLES);
         if (d.prep_pow) hipLaunchKernelGGL((jx_prep_kernel<true, false>), dim3(pgrid), dim3(pthr), sh, ps, dp, theta_dev, w0,
@@ -1794,6 +1818,25 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
             ro.ldpp = m.x_ldpp; ro.nSj = m.x_nSj; ro.npair = m.x_npair;
 #ifdef JOXSZ_ABLATIONS
             ro.dbg = m.dbg;
+            if (env_str("JOXSZ_X_STAMPS")) {                    // (diagnostic build only: the environment is read on the launch path here)
+                static long long* stamps = nullptr;
+                if (!stamps) { HIPCHK(ctx, hipMalloc((void**)&stamps, sizeof(long long) * 8 * 65536)); }
+                ro.stamps = stamps;
+                static int calls = 0;
+                if (++calls == 40) {
+                    HIPCHK(ctx, hipStreamSynchronize(st));
+                    const int nb = 8 * ((((n + 15) / 16) + 7) / 8) * m.x_npair;
+                    std::vector<long long> h((size_t)nb * 8);
+                    HIPCHK(ctx, hipMemcpy(h.data(), stamps, sizeof(long long) * h.size(), hipMemcpyDeviceToHost));
+                    long long t0 = h[0];
+                    for (int b = 0; b < nb; ++b) t0 = std::min(t0, h[(size_t)b * 8]);
+                    double mx[5] = {0, 0, 0, 0, 0}, sm[5] = {0, 0, 0, 0, 0};
+                    for (int b = 0; b < nb; ++b)
+                        for (int k = 0; k < 5; ++k) { const double v = (h[(size_t)b * 8 + k] - t0) * 0.01; mx[k] = std::max(mx[k], v); sm[k] += v / nb; }
+                    fprintf(stderr, "ordrow stamps (us after the first block's start; mean / max over %d blocks): start %.2f/%.2f  first loads %.2f/%.2f  k loop %.2f/%.2f  ordinates %.2f/%.2f  end %.2f/%.2f\n",
+                            nb, sm[0], mx[0], sm[1], mx[1], sm[2], mx[2], sm[3], mx[3], sm[4], mx[4]);
+                }
+            }
 #endif
             ro.Opk = m.x_Opk; ro.Typ = m.x_Typ; ro.pp = pp_src; ro.y = m.x_y; ro.P = m.x_P;
             const size_t lds_max = (size_t)158 * 1024;

@@ -50,7 +50,13 @@ struct JxRowOp {
     const double* pp;              // [n][ldpp] pressure profiles (jx_prep_kernel)
     double* y;                     // [tW][ldy] ordinates, walker-major
     double* P;                     // [walker tiles][npair][ng_all][16][16 NXT] partial rows
+    long long* stamps;             // diagnostic build only: [blocks][8] wall-clock stamps (100 MHz) of jx_ordrow_kernel's phases
 };
+#ifdef JOXSZ_ABLATIONS
+#define JX_STAMP(g, k) do { if ((g).stamps && threadIdx.x == 0) (g).stamps[(size_t)blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define JX_STAMP(g, k) do { } while (0)
+#endif
 
 // ------------------------------------------------------------------------------------------------------------------
 // The tail on a walker tile's row in LDS (s_row[w][x], x < nuse, conversion not yet applied): joxsz_funcs.py:473, 476, 478, 538.
@@ -158,7 +164,7 @@ __device__ __forceinline__ void jx_row_epilogue(const JxDev& c, const JxRowOp& g
 #define JX_ORD_LDS_DOUBLES (4 * 2 * 256 + 16 * 36)
 
 template <int NXT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
 jx_ordrow_kernel(JxRowOp g) {
     extern __shared__ __attribute__((aligned(16))) double sm_or[];
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
@@ -167,6 +173,7 @@ jx_ordrow_kernel(JxRowOp g) {
     const int id = blockIdx.x, xcd = id & 7, jj = id >> 3;
     const int p = jj % g.npair, wt = (jj / g.npair) * 8 + xcd;
     if (wt >= ntw) return;
+    JX_STAMP(g, 0);
     const int wb = wt * 16;
     const int q = 2 * g.npair - 1 - p;                          // the pair's upper tile (may lie beyond the last: then p alone)
     const bool hasq = q < g.nS;
@@ -177,10 +184,9 @@ jx_ordrow_kernel(JxRowOp g) {
     const int wq = min(wb + li, g.n - 1);                       // (a walker beyond the launch repeats the last: finite work, never stored)
     const double* __restrict__ ppl = g.pp + (size_t)wq * g.ldpp + 4 * lk;
     const double* __restrict__ tb = g.Typ + (size_t)lane * 4;
-    jx_ro_v4d ap[4], aq[4];
+    jx_ro_v4d ap[2], aq[2];                                     // two chains per tile (sub-steps e and e + 2 share one)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { ap[e] = jx_ro_v4d{0.0, 0.0, 0.0, 0.0}; aq[e] = jx_ro_v4d{0.0, 0.0, 0.0, 0.0}; }
-    // the row-operator fragments of this wave's output tiles (group 0) are requested now: they arrive behind the ordinate product
+    for (int e = 0; e < 2; ++e) { ap[e] = jx_ro_v4d{0.0, 0.0, 0.0, 0.0}; aq[e] = jx_ro_v4d{0.0, 0.0, 0.0, 0.0}; }
     constexpr int NTT = (NXT + 3) / 4;
     double bpv[NTT][4], bqv[NTT][4];
     auto load_op = [&](int gi) {
@@ -195,7 +201,7 @@ jx_ordrow_kernel(JxRowOp g) {
             }
         }
     };
-    if (g.ng > 0) load_op(0);
+
     auto load_a = [&](int s) -> jx_ro_v4d { return *reinterpret_cast<const jx_ro_v4d*>(ppl + 16 * s); };   // (rows padded with zeros to 16 nSj)
     auto load_b = [&](int s, int t) -> jx_ro_v4d { return *reinterpret_cast<const jx_ro_v4d*>(tb + ((size_t)s * g.nS + t) * 256); };
     {
@@ -203,32 +209,36 @@ jx_ordrow_kernel(JxRowOp g) {
         jx_ro_v4d a0, bp0, bq0, a1, bp1, bq1;
         const int tq = hasq ? q : p;                            // (no upper tile: its loads repeat the lower one's, its products are skipped)
         if (s < g.nSj) { a0 = load_a(s); bp0 = load_b(s, p); bq0 = load_b(s, tq); }
+#ifdef JOXSZ_ABLATIONS
+        if (g.stamps) { if (a0[0] + bp0[0] + bq0[0] == 1.234e300) ap[0][0] = 1.0; JX_STAMP(g, 1); }
+#endif
         for (; s < g.nSj; s += 8) {
             const int s1n = s + 4, s2n = s + 8;
             if (s1n < g.nSj) { a1 = load_a(s1n); bp1 = load_b(s1n, p); bq1 = load_b(s1n, tq); }
             if (!JX_DBG(g, 1)) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) ap[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[e], bp0[e], ap[e], 0, 0, 0);
+            for (int e = 0; e < 4; ++e) ap[e & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[e], bp0[e], ap[e & 1], 0, 0, 0);
             } else ap[0] += a0 + bp0 + bq0;
             if (hasq && s >= q && !JX_DBG(g, 1)) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) aq[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[e], bq0[e], aq[e], 0, 0, 0);
+                for (int e = 0; e < 4; ++e) aq[e & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[e], bq0[e], aq[e & 1], 0, 0, 0);
             }
             if (s1n < g.nSj) {
                 if (s2n < g.nSj) { a0 = load_a(s2n); bp0 = load_b(s2n, p); bq0 = load_b(s2n, tq); }
                 if (!JX_DBG(g, 1)) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) ap[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[e], bp1[e], ap[e], 0, 0, 0);
+                for (int e = 0; e < 4; ++e) ap[e & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[e], bp1[e], ap[e & 1], 0, 0, 0);
                 } else ap[0] += a1 + bp1 + bq1;
                 if (hasq && s1n >= q && !JX_DBG(g, 1)) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) aq[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[e], bq1[e], aq[e], 0, 0, 0);
+                    for (int e = 0; e < 4; ++e) aq[e & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[e], bq1[e], aq[e & 1], 0, 0, 0);
                 }
             }
         }
     }
+    JX_STAMP(g, 2);
     {
-        const jx_ro_v4d yp = (ap[0] + ap[1]) + (ap[2] + ap[3]), yq = (aq[0] + aq[1]) + (aq[2] + aq[3]);
+        const jx_ro_v4d yp = ap[0] + ap[1], yq = aq[0] + aq[1];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             s1[((wv * 2 + 0) * 16 + lk + 4 * r) * 16 + li] = yp[r];
@@ -244,12 +254,13 @@ jx_ordrow_kernel(JxRowOp g) {
         if (tile < g.nS && wb + w < g.n) g.y[(size_t)(wb + w) * g.ldy + 16 * tile + cc] = v;
     }
     __syncthreads();
+    JX_STAMP(g, 3);
 
     // ---- this pair's share of the row product: P[x] = sum over the pair's 32 ordinates of Wy[x][k] y[k]; wave v owns the output tiles v, v + 4
     const jx_ro_v4d yp = *reinterpret_cast<const jx_ro_v4d*>(s_yt + li * 36 + 4 * lk);
     const jx_ro_v4d yq = *reinterpret_cast<const jx_ro_v4d*>(s_yt + li * 36 + 16 + 4 * lk);
     for (int gi = 0; gi < (JX_DBG(g, 2) ? 0 : g.ng); ++gi) {
-        if (gi > 0) load_op(gi);
+        load_op(gi);
         double* __restrict__ Pb = g.P + (((size_t)wt * g.npair + p) * g.ng + gi) * (size_t)(256 * NXT);
 #pragma unroll
         for (int tt = 0; tt < NTT; ++tt) {
@@ -268,6 +279,7 @@ jx_ordrow_kernel(JxRowOp g) {
             }
         }
     }
+    JX_STAMP(g, 4);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

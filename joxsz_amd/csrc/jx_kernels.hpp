@@ -29,6 +29,11 @@
 #else
 #define JX_DBG(c, bits) false
 #endif
+#ifdef JOXSZ_ABLATIONS
+#define JX_PSTAMP(c, k) do { if ((c).stamps && threadIdx.x == 0) (c).stamps[(size_t)blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define JX_PSTAMP(c, k) do { } while (0)
+#endif
 #define JX_MAX_PAR 19
 // All LDS lives in the dynamic region, 16-byte aligned, with 16-byte-multiple carve offsets: a static
 // __shared__ in front of it shifts the base and every ds_read/write_b128 is then replayed at ~64 cycles
@@ -70,6 +75,7 @@ struct JxDev {
     int prep_pow;                // 1 (JOXSZ_PREP_POW=1): the prep kernel evaluates the profiles with pow() as written in the reference
     const double* lr_pp;         // [N] log(r_pp)
     const double* inject_pp;     // operator build only: [nlaunch][N] pressure profiles that replace press_fun(theta) (else null)
+    long long* stamps;           // diagnostic build only (make ABLATIONS=1, JOXSZ_X_STAMPS): [blocks][8] wall-clock stamps of jx_prep_kernel's phases
     int pp_ld;                   // doubles per walker of jx_prep_kernel's profile output (0: N; the exact form pads its rows to whole 16-radius steps)
     int fast_map, q_na, q_nb;    // symmetric-map form: table sizes (|ix-c|, |iy-c|)
     double* xcol;                // quad mode: copy of the quadrant's last column (map column 0): [chunk][q_nb], or walker-minor
@@ -331,6 +337,7 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
     const int w = xonly ? (int)blockIdx.x - nblk : (int)blockIdx.x;   // walker within the chunk
     const int gw = w0 + w;                    // walker within the batch
     const int tid = threadIdx.x, nth = blockDim.x;
+    JX_PSTAMP(c, 0);
 
     double* s_m = sm + JX_LDS_HDR;            // [N] mass profile
     double* s_t = s_m + c.N;                  // [N] T_SZ on r_pp[:nt]
@@ -353,6 +360,7 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
     for (int i = tid; i < 2 * c.nconv; i += nth) s_conv[i] = (i < c.nconv) ? c.conv_T[i] : c.conv_v[i - c.nconv];   // (visible behind the barriers of jx_load_params)
     if (FM) for (int i = tid; i < JX_FM_TABLE_DOUBLES; i += nth) s_fm[i] = c.fm_tab[i];
     jx_load_params(c, theta, gw, p, &smv);
+    JX_PSTAMP(c, 1);
     double pc[5] = {0, 1, 1, 0, 1};           // radius-independent factors of the density (every thread its own copy)
     if (POW) jx_ne_consts(p, c.ne_mode, pc);
 
@@ -376,6 +384,7 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
         if (v != v) rej |= REJ_BOX;           // NaN parameter: reject (emcee cannot use NaN)
     }
     parprior = jx_block_sum(pr, red);
+    JX_PSTAMP(c, 2);
     if (!(fabs(parprior) <= 1.79769313486231570e308)) rej |= REJ_BOX;     // joxsz_funcs.py:519-520: a non-finite prior returns -inf at once
 
     // ---- model prior: r_c <= r_s (joxsz_funcs.py:397-407) ----
@@ -425,6 +434,7 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
         }
     }
     __syncthreads();
+    JX_PSTAMP(c, 3);
     if (veto) {
         for (int i = tid; i < c.N; i += nth) {
             double g;                          // np.gradient(m, 1)
@@ -446,6 +456,7 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
         }
     }
 
+    JX_PSTAMP(c, 4);
     // ---- h(0), conversion factors (joxsz_funcs.py:470-473) ----
     double part = 0.0;
     for (int k = tid; k < c.nt; k += nth) part += c.hw[k] * s_t[k];
@@ -456,6 +467,7 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
         if (tap_tprof) tap_tprof[(size_t)w * c.nrow + k] = T;
     }
     __syncthreads();
+    JX_PSTAMP(c, 5);
     }                                          // (!xonly)
 
     // ---- X-ray: calcProfiles + Cash (joxsz_funcs.py:527-532, 495-505) ----
@@ -533,6 +545,7 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
     }
     if (xonly) {                               // the X-ray side alone: its sum and its verdict for the tail
         if (tid == 0) { c.xr_out[2 * (size_t)w] = xlike; c.xr_out[2 * (size_t)w + 1] = xbad ? 1.0 : 0.0; }
+        JX_PSTAMP(c, 6);
         return;
     }
     const int rejall = jx_block_or(rej, &redi);
@@ -547,6 +560,7 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
             tap_parts[(size_t)w * 4 + 3] = (double)rejall;
         }
     }
+    JX_PSTAMP(c, 6);
 }
 
 // ------------------------------------------------------------------------------------

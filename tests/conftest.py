@@ -43,3 +43,11 @@ def golden_bundled():
 def golden_integ(request):
     """The reference run with calc_integ = True (joxsz_funcs.py:480-487): odd and even numbers of Simpson samples."""
     return load_golden(request.param)
+
+
+@pytest.fixture
+def legacy_forms(monkeypatch):
+    """The contracted forms of rounds 3-4 (low-rank / full, with their sub-grids and the truncation guard): kept for one round behind
+    JOXSZ_MIX_FORM=legacy beside the exact form that replaced them as the default."""
+    monkeypatch.setenv('JOXSZ_MIX_FORM', 'legacy')
+    return monkeypatch

@@ -240,7 +240,7 @@ def test_odd_side_custom_route(S, N):
     th[3, 1] = 9.0
     post = _post(pb, conv='custom')
     lay = post.ctx.conv_layout
-    assert post.ctx.conv == 'custom' and lay['NU'] == S // 2 + 1 and (lay['rank'] > 0) == (lay['form'] == 'lowrank')
+    assert post.ctx.conv == 'custom' and lay['NU'] == S // 2 + 1 and lay['form'] == 'exact'
     got = post.log_prob(th)
     rows, bright, chisq, y2d, conv = (post.stage(th[:6], s) for s in ('map_row', 'bright', 'chisq', 'y_2d', 'conv_2d'))
     assert np.array_equal(post.log_prob(th), got)
@@ -261,9 +261,7 @@ def test_odd_side_custom_route(S, N):
         assert _relerr(y2d[k], st['y_2d']) < RTOL_STAGE
         assert _relerr(conv[k], st['conv_2d']) < RTOL_STAGE
         assert _relerr(rows[k], st['map_row']) < RTOL_STAGE
-        # (the rejected walker's conversion factors grow by 36 orders of magnitude towards the edge, where the row has decayed by
-        #  four: what the singular-value cut of the low-rank form leaves there, 1e-11 of the row's maximum, is then all that 'bright' shows)
-        assert _relerr(bright[k], st['bright']) < (RTOL_STAGE if fin[k] else 1e-6)
+        assert _relerr(bright[k], st['bright']) < RTOL_STAGE       # (the rejected walker too: nothing is truncated)
         assert abs(chisq[k] - st['chisq']) / 2 < 1e-6 * max(1.0, 1e-3 * st['chisq'])      # absolute near the mode, relative far from it
 
 
@@ -277,7 +275,7 @@ def test_odd_side_1025():
     th = datasets.walker_ball(pb, 6, spread=0.03, seed=7)
     th[2, 1] = 9.0
     post = _post(pb, conv='custom')
-    assert post.ctx.conv == 'custom' and post.ctx.conv_layout['form'] == 'lowrank'
+    assert post.ctx.conv == 'custom' and post.ctx.conv_layout['form'] == 'exact'
     got = post.log_prob(th)
     rows = post.stage(th[:2], 'map_row')
     conv = post.stage(th[:1], 'conv_2d')[0]                    # (round 2 refused this tap at 1025^2; it comes from the rocFFT facility now)
@@ -396,7 +394,7 @@ def test_lowrank_form_against_full_form(monkeypatch):
             assert _relerr(res[mode][0][0], st['map_row']) < RTOL_STAGE, mode
 
 
-def test_rough_transfer_function_takes_the_full_form():
+def test_rough_transfer_function_takes_the_full_form(legacy_forms):
     """A transfer function whose weights are not low-rank (here: multiplied by uncorrelated noise, symmetrised) makes the
     low-rank form the dearer one: the library takes the full form by itself and still matches the oracle."""
     from joxsz_amd import datasets
@@ -438,8 +436,9 @@ def _measured_problem(S, N):
 
 @pytest.mark.parametrize('S,N', [(512, 512), (513, 513)])
 def test_measured_beam_and_transfer_function_at_the_headline_sides(S, N):
-    """The reference's default inputs at the headline sides: the measured beam image is not separable (28 terms) and the
-    measured transfer function is rough, so the full form runs -- exact, against the oracle and the rocFFT sequence."""
+    """The reference's default inputs at the headline sides (measured beam image: not separable; measured transfer function: rough
+    from one wavenumber to the next): the exact form is the same one operator product as for any other input -- against the oracle
+    and the rocFFT sequence."""
     from joxsz_amd import datasets
     pb = _measured_problem(S, N)
     p0 = orc.pars_dict(pb, datasets.fiducial_theta(pb))
@@ -447,7 +446,7 @@ def test_measured_beam_and_transfer_function_at_the_headline_sides(S, N):
     th = datasets.walker_ball(pb, 20, spread=0.04, seed=S)
     th[2, 1] = 9.0
     post = _post(pb)
-    assert post.ctx.conv == 'custom' and post.ctx.conv_layout['form'] == 'full'
+    assert post.ctx.conv == 'custom' and post.ctx.conv_layout['form'] == 'exact'
     got = post.log_prob(th)
     rows, chisq = post.stage(th[:4], 'map_row'), post.stage(th, 'chisq')
     post.close()
@@ -513,7 +512,7 @@ def test_contracted_route_chunking():
     pb = datasets.synthetic_problem(S=128, N=150, seed=13)
     th = datasets.walker_ball(pb, 77, spread=0.04, seed=13)
     post = _post(pb, conv='custom')
-    assert post.ctx.conv_layout['form'] in ('lowrank', 'full')
+    assert post.ctx.conv_layout['form'] == 'exact'
     one = post.log_prob(th)
     post.close()
     for mb in (16, 20, 50):
@@ -696,7 +695,7 @@ def test_prep_log_form_against_pow_form(monkeypatch):
 
 
 @pytest.mark.parametrize('S,N,W', [(64, 80, 5), (256, 300, 70), (171, 313, 33), (512, 500, 130)])
-def test_spline_arrays_matrix_product_against_abel_kernel(S, N, W, monkeypatch):
+def test_spline_arrays_matrix_product_against_abel_kernel(S, N, W, monkeypatch, legacy_forms):
     """Contracted route: the spline ordinates and moments (y_k, M_k) of a launch come from one matrix product on the matrix
     cores (``jx_abel_gemm_kernel``: Abel weights, Compton-y scale and spline moments folded into one constant operator;
     joxsz_funcs.py:457-460), walker-minor.  Against the Abel kernel's own phases 1-3 (JOXSZ_ABEL_GEMM=0, which also serves
@@ -725,7 +724,7 @@ def test_spline_arrays_matrix_product_against_abel_kernel(S, N, W, monkeypatch):
 
 
 @pytest.mark.parametrize('S,N,usplit', [(512, 500, '2'), (512, 500, '1'), (513, 500, '3')])
-def test_stage_1_on_the_matrix_cores_against_the_vector_unit_kernel(S, N, usplit, monkeypatch):
+def test_stage_1_on_the_matrix_cores_against_the_vector_unit_kernel(S, N, usplit, monkeypatch, legacy_forms):
     """The opt-in form of stage 1 (JOXSZ_MIX_MFMA=1: jx_rowmix_mfma_kernel, the samples of four rows through LDS into
     v_mfma_f64_16x16x4, operator in LDS) against the default jx_rowmix_kernel on the same tables: the rows kept per map column
     (work buffer 'stage1') to rounding, the log-posterior far inside the 1e-6 bar, one, two and three pieces per column (the
