@@ -264,6 +264,37 @@ def time_steps(ctx, th_ptr, W, lp_ptr, steps, warmup):
     return (time.perf_counter() - t) / steps
 
 
+def with_env(env, fn):
+    """fn() with os.environ temporarily extended (jx_finalize reads its switches from the environment of the calling process)."""
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return fn()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+# what the kernels of a step are called and what bounds them, by form of the SZ side (jx_get_conv_layout)
+STEP_KERNELS = {
+    'exact': [('prep_ms', 'jx_prep_kernel', 'priors, vetoes, X-ray Cash likelihood, pressure and temperature profiles, conversion factors (one or two blocks per walker)',
+               'latency: a chain of dependent phases and fp64 exp/log chains; no flop or byte count prices it (its share of wave cycles is listed)'),
+              ('abel_map_ms', 'jx_ordrow_kernel', 'ordinate product y = y_scale A pp (forward Abel transform + Compton-y scale) and each column-tile pair\'s share of the row product out = Wy y, fp64 matrix cores',
+               'mfma (v_mfma_f64_16x16x4)'),
+              ('tail_ms', 'jx_rowsum_tail_kernel', 'partial rows added in pair order, conversion, not-a-knot spline to the data radii, chi^2, total (+ the stretch move\'s acceptance inside jx_sample)',
+               'latency: one trip to memory for its operands, then three short dependent phases')],
+    'lowrank': [('prep_ms', 'jx_prep_kernel', 'per-walker kernel', 'latency'), ('abel_map_ms', 'jx_abel_gemm_kernel', 'spline-array product', 'mfma'),
+                ('beam_fft_ms', 'jx_rowmix_kernel', 'stage 1: map samples evaluated and mixed per column', 'valu'),
+                ('tf_fft_ms', 'jx_opgemm_kernel', 'stage 2: one fp64 matrix-core product', 'mfma'), ('tail_ms', 'jx_tail_row_kernel', 'tail', 'latency')],
+    'full': [('prep_ms', 'jx_prep_kernel', 'per-walker kernel', 'latency'), ('abel_map_ms', 'jx_abel_gemm_kernel', 'spline-array product', 'mfma'),
+             ('tf_fft_ms', 'jx_opgemm_kernel', 'full form: samples evaluated by the lanes that feed the matrix cores', 'mfma'), ('tail_ms', 'jx_tail_row_kernel', 'tail', 'latency')],
+}
+TIMING_MODE_OF_STAGE = {'abel_map_ms': 2, 'prep_ms': 3, 'tail_ms': 4}      # jx_timing_enable: the two events around ONE kernel of the step (exact form)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -275,15 +306,17 @@ def main():
     ap.add_argument('--sz-only', action='store_true')
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
-    ap.add_argument('--no-full-map', action='store_true', help='skip the side measurement of the full-map Abel kernel and of the copy bandwidth')
+    ap.add_argument('--regions', type=int, default=0, help='timed regions of --steps steps each (0: at least 25, and as many as 50 ms of timed work take)')
+    ap.add_argument('--no-full-map', action='store_true', help='skip the side measurement of the full-map Abel kernel, of the stream rates and of the literal route')
     ap.add_argument('--route', choices=('map', 'operator'), default='map',
-                    help="'map': the reference's sequence of steps per walker (the BASELINE metric); 'operator': the collapsed route (jx_set_route)")
+                    help="'map': profile, Abel transform and row operator per walker (the BASELINE metric); 'operator': the collapsed route (jx_set_route)")
     ap.add_argument('--fwhm', type=float, default=18.5, help='beam FWHM in arcsec (B = 2*floor(3*fwhm/step)+1)')
     ap.add_argument('--dtype', choices=('f64', 'f32', 'f32c'), default='f64',
-                    help="'f64': the reference's arithmetic (the metric); 'f32': fp32 spline arrays; 'f32c': fp32 arithmetic in stages 1 and 2")
-    ap.add_argument('--no-f32', action='store_true', help='skip the side measurement of the fp32 variant')
-    ap.add_argument('--no-host-pointer', action='store_true', help='skip the side measurement of jx_eval with host pointers (profiling runs: keeps the trace to the timed steps)')
+                    help="'f64': the reference's arithmetic (the metric); 'f32' / 'f32c': the fp32 variants (contracted forms of round 4)")
+    ap.add_argument('--no-f32', action='store_true', help='skip the side measurement of the fp32 variants')
+    ap.add_argument('--no-host-pointer', action='store_true', help='skip the side measurements of jx_eval with host pointers and of jx_sample (profiling runs: keeps the trace to the timed steps)')
     ap.add_argument('--no-other-configs', action='store_true', help='skip the strong-scaling rows of BASELINE configs[3] and configs[4]')
+    ap.add_argument('--no-other-routes', action='store_true', help='skip the collapsed and legacy-contracted rows')
     args = ap.parse_args()
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
@@ -315,18 +348,34 @@ def main():
     post = JoxszPosterior(pb, device=local_rank)
     ctx = post.ctx
 
-    # parity of the CPU sample on the very same problem tensors: the bench refuses to report a number for results that differ
-    parity = None
-    if cpu_sample is not None:
-        if args.route != 'map':
-            ctx.set_route(args.route)
-        got = ctx.eval(cpu_sample)
+    def oracle_parity(c):
+        """max relative error of the CPU sample's log-posteriors on context c (None without a sample); refuses different rejections"""
+        if cpu_sample is None:
+            return None
+        got = c.eval(cpu_sample)
         fin = np.isfinite(cpu_logp)
         if not np.array_equal(np.isfinite(got), fin):
             raise SystemExit('bench: GPU/oracle disagree on which walkers are rejected')
-        parity = float(np.max(np.abs(got[fin] - cpu_logp[fin]) / np.abs(cpu_logp[fin]))) if fin.any() else 0.0
-        if parity > 1e-6:
-            raise SystemExit('bench: parity %.3e exceeds 1e-6' % parity)
+        return float(np.max(np.abs(got[fin] - cpu_logp[fin]) / np.abs(cpu_logp[fin]))) if fin.any() else 0.0
+
+    # parity of the CPU sample on the very same problem tensors: the bench refuses to report a number for results that differ
+    if args.route != 'map':
+        ctx.set_route(args.route)
+    parity = oracle_parity(ctx)
+    if parity is not None and parity > 1e-6:
+        raise SystemExit('bench: parity %.3e exceeds 1e-6' % parity)
+    # the other routes of the same library on the same sample, while the placeholder data are in place (rows of the line, further down)
+    parity_other = {}
+    if rank == 0 and args.route == 'map' and not args.no_other_routes and cpu_sample is not None:
+        for name, env, route in (('collapsed_route', {}, 'operator'), ('legacy_contracted_route', {'JOXSZ_MIX_FORM': 'legacy', 'JOXSZ_QUIET': '1'}, None)):
+            try:
+                po = with_env(env, lambda: JoxszPosterior(pb, device=local_rank))
+                if route:
+                    po.ctx.set_route(route)
+                parity_other[name] = oracle_parity(po.ctx)
+                po.close()
+            except BaseException as exc:                     # (a row of the line, not the headline)
+                parity_other[name] = 'error: %s' % exc
 
     # ---- synthetic observations from the model itself at the fiducial vector, then the walker ball ----
     t0 = datasets.fiducial_theta(pb)
@@ -352,12 +401,11 @@ def main():
     ctx.h2d(th_ptr, theta)
     comm = None
     lp_ptrs, all_ptrs = [lp_ptr], [None]
-    overlap = multi and not os.environ.get('JOXSZ_BENCH_STRICT_GATHER')      # (JOXSZ_BENCH_OVERLAP_GATHER=1 pins the other mode; neither: the warm-up picks)
+    # N > 1: the headline runs the gather STRICTLY in order on the compute stream -- what a sampler needs that proposes from the gathered
+    # values; the overlapped mode (second stream, two output buffers) is probed in the warm-up and reported beside it.
+    overlap = multi and bool(os.environ.get('JOXSZ_BENCH_OVERLAP_GATHER'))
     if multi:
-        # RCCL through the library's own C-ABI (jx_comm_*), no torch in this process.  The gather of step n runs on a second
-        # stream of the context behind an event; step n+1 writes the OTHER of two output buffers, so its kernels overlap the
-        # gather (a buffer still being sent holds back only the evaluation that would overwrite it).  The host never waits
-        # inside a step.  JOXSZ_BENCH_STRICT_GATHER=1: every collective in order on the compute stream instead.
+        # RCCL through the library's own C-ABI (jx_comm_*), no torch in this process.
         from joxsz_amd.dist import RcclGather
         comm = RcclGather(ctx, rank=rank, world=world, overlap=overlap)
         lp_ptrs = [lp_ptr, ctx.dev_alloc(8 * W)]
@@ -381,10 +429,7 @@ def main():
     fence()
     gather_probe = None
     if comm is not None and not os.environ.get('JOXSZ_BENCH_STRICT_GATHER') and not os.environ.get('JOXSZ_BENCH_OVERLAP_GATHER'):
-        # Which of the two gather modes this machine wants is not known in advance: the second stream hides the collective's
-        # latency (tens of microseconds over 8 ranks) but costs every kernel of the step a little (two active queues); in line it
-        # costs its own duration.  Still inside the warm-up: the same short run in both modes, the ranks agree on the faster one
-        # (one max-reduction each -- every rank takes the same branch), and the timed region below runs in that mode.
+        # still inside the warm-up: the same short run in both gather modes (reported; the timed regions stay strict)
         gather_probe = {}
         nprobe = max(10, min(50, args.steps))
         for mode in (True, False):
@@ -397,40 +442,74 @@ def main():
                 step()
             fence()
             gather_probe['overlapped' if mode else 'strict'] = 1e3 * comm.max_over_ranks(time.perf_counter() - t_probe) / nprobe
-        overlap = gather_probe['overlapped'] < gather_probe['strict']
-        ctx.comm_set_overlap(overlap)
+        ctx.comm_set_overlap(False)
         fence()
-    # Timed region: HIP events around the time-dominant kernel only (stage 1 of the contracted route; jx_timing_enable(2)) --
-    # its duration is what `roofline` prices.  Events behind every stage cost a few per cent of a step (markers between
-    # dependent kernels), so the full stage breakdown comes from a second, identical pass of the same K steps right after.
-    p1_only = (args.route == 'map' and ctx.conv == 'custom')
-    ctx.timing_enable(2 if p1_only else 1)
+    # ---- which kernel of the step is the longest: one stage pass inside the warm-up (HIP events behind every kernel) ----
+    lay = ctx.conv_layout or {}
+    form = lay.get('form')
+    mixed = ctx.conv == 'custom' and args.route == 'map'
+    ctx.timing_enable(1)
     ctx.timing_reset()
     fence()
-    t_start = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(max(10, min(50, args.steps))):
         step()
     fence()
-    elapsed = time.perf_counter() - t_start
-    tm_timed = ctx.timing()
-    tm = tm_timed
-    if p1_only:
-        ctx.timing_enable(1)
-        ctx.timing_reset()
+    tm_w = ctx.timing()
+    ctx.timing_enable(False)
+    kernels = STEP_KERNELS.get(form, []) if mixed else []
+    dom = max(kernels, key=lambda k: tm_w[k[0]]) if kernels else None
+    # Timed regions: `--steps` steps each, bracketed by barrier + synchronisation on both sides, at least 25 of them and at least 50 ms in
+    # all; the MEDIAN region is the figure (a single 2 ms region has no spread estimate).  Inside them: the two HIP
+    # events around the longest kernel of the step only (what `roofline` prices); events behind every kernel cost a few per cent of a
+    # step, so the stage breakdown comes from one more pass right after.
+    p1_mode = TIMING_MODE_OF_STAGE.get(dom[0], 2) if (dom and form == 'exact') else (2 if mixed else 1)
+    ctx.timing_enable(False)
+    fence()
+    est = max(1e-6, tm_w['total_ms'] / max(1, tm_w['launches']) * 1e-3 * (W / max(1.0, tm_w['walkers'] / max(1, tm_w['launches']))) * args.steps)
+    if comm is not None:
+        est = comm.max_over_ranks(est)                       # (every rank runs the same number of regions: each carries a barrier)
+    nreg = args.regions if args.regions > 0 else int(min(2000, max(25, np.ceil(0.05 / est))))
+    regions = []
+    for _ in range(nreg):
         fence()
+        t_start = time.perf_counter()
         for _ in range(args.steps):
             step()
         fence()
-        tm = ctx.timing()
+        regions.append(time.perf_counter() - t_start)
+    if comm is not None:
+        regions = [float(v) for v in comm.max_over_ranks(regions)]
+    # the same regions once more with the two HIP events around the longest kernel of the step (a pair of events between dependent
+    # kernels costs the step 3-6 us of command-processor work: the headline regions above carry none)
+    ctx.timing_enable(p1_mode)
+    ctx.timing_reset()
+    regions_ev = []
+    for _ in range(max(5, min(nreg, 25))):
+        fence()
+        t_start = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        regions_ev.append(time.perf_counter() - t_start)
+    if comm is not None:
+        regions_ev = [float(v) for v in comm.max_over_ranks(regions_ev)]
+    tm_timed = ctx.timing()
+    ctx.timing_enable(1)
+    ctx.timing_reset()
+    fence()
+    for _ in range(args.steps):
+        step()
+    fence()
+    tm = ctx.timing()
     gather_ms = None
     if comm is not None:
         gms, gn = ctx.comm_gather_time()                     # the all-gathers' own durations (events on their stream) of the stage pass
         gather_ms = gms / max(1, gn)
     ctx.timing_enable(False)
+    elapsed = float(np.median(regions))
 
     last = (nstep[0] - 1) % len(lp_ptrs)
     if comm is not None:
-        elapsed = comm.max_over_ranks(elapsed)
         final = np.empty(W * world)
         ctx.d2h(final, all_ptrs[last])
     else:
@@ -443,65 +522,87 @@ def main():
     #      rank-locally inside try/except WITHOUT collectives; the ranks meet once more, in one all-reduce outside any
     #      exception handler, to agree on the strong-scaling rows (a rank that failed contributes +inf).
 
-    # the path emcee calls (joxsz_main.py:206, vectorize=True): host theta in, host log-probabilities out, one sync per call
+    # the path emcee calls (joxsz_main.py:206, vectorize=True): host theta in, host log-probabilities out, one sync per call --
+    # at the reference's own ensemble (30 walkers = 15 per half step, joxsz_main.py:44), at 128 and at the launch size
     host_ptr = None
     if rank == 0 and not args.no_host_pointer:
         try:
-            for _ in range(3):
-                ctx.eval(theta)
-            kk = max(5, min(args.steps, 50))
-            t = time.perf_counter()
-            for _ in range(kk):
-                got_h = ctx.eval(theta)
-            dt = (time.perf_counter() - t) / kk
-            host_ptr = {'value': W / dt, 'unit': 'walker-likelihoods/s', 'ms_per_call': 1e3 * dt, 'calls': kk,
-                        'max_abs_diff_vs_device_resident': float(np.max(np.abs(got_h - lp_own))),
-                        'note': 'jx_eval: host parameter vectors in (%d B per walker over PCIe), host log-probabilities out, one stream '
-                                'synchronisation per call -- what emcee.EnsembleSampler(..., vectorize=True) exercises (joxsz_main.py:206)' % (8 * theta.shape[1])}
+            host_ptr = {'unit': 'walker-likelihoods/s', 'calls': {},
+                        'note': 'jx_eval: host parameter vectors in (%d B per walker over PCIe), host log-probabilities out, one stream synchronisation per call -- '
+                                'what emcee.EnsembleSampler(..., vectorize=True) exercises (joxsz_main.py:206); 15 walkers per call = the half steps of the '
+                                'reference\'s default ensemble of 30 (joxsz_main.py:44)' % (8 * theta.shape[1])}
+            for nw in sorted({15, 128, W}):
+                nw = min(nw, W)
+                for _ in range(3):
+                    ctx.eval(theta[:nw])
+                kk = max(20, min(args.steps, 100))
+                t = time.perf_counter()
+                for _ in range(kk):
+                    got_h = ctx.eval(theta[:nw])
+                dt = (time.perf_counter() - t) / kk
+                host_ptr['calls'][str(nw)] = {'walkers_per_call': nw, 'ms_per_call': 1e3 * dt, 'value': nw / dt, 'calls': kk,
+                                              'max_abs_diff_vs_device_resident': float(np.max(np.abs(got_h - lp_own[:nw])))}
+            host_ptr['value'] = host_ptr['calls'][str(W)]['value']
+            host_ptr['ms_per_call'] = host_ptr['calls'][str(W)]['ms_per_call']
+            host_ptr['max_abs_diff_vs_device_resident'] = max(c['max_abs_diff_vs_device_resident'] for c in host_ptr['calls'].values())
         except Exception as exc:
             host_ptr = {'error': str(exc)}
 
     # the caller of the path: the device-resident stretch-move loop on an ensemble of 2 W walkers -- each half step one
     # evaluation of W proposals, drawn in the per-walker kernel and accepted or rejected in the tail
     samp = None
-    if rank == 0 and comm is None and args.route == 'map' and not args.no_host_pointer:
+    # (with a communicator jx_sample is a collective of its own: rehearsed at world size 1; on more ranks only with JOXSZ_BENCH_SAMPLER_DIST=1,
+    #  every rank calling it -- a side measurement must never be able to take the scaling line down)
+    samp_dist = comm is not None and (world == 1 or bool(os.environ.get('JOXSZ_BENCH_SAMPLER_DIST')))
+    if (rank == 0 or samp_dist) and (comm is None or samp_dist) and args.route == 'map' and not args.no_host_pointer:
         try:
             x0 = np.ascontiguousarray(np.concatenate((theta, good[W:2 * W] if len(good) >= 2 * W else theta[::-1] * (1 + 1e-9))))
-            ns1, ns = 10, 60
-            ctx.sample(x0, ns)                                     # (warm-up at the longer length: the call's device buffers are sized once)                                       # (two run lengths: the slope is the step, the intercept the call's set-up, initial evaluation and copy back)
-            t = time.perf_counter()
-            ctx.sample(x0, ns1, seed=3)
-            t1 = time.perf_counter() - t
-            t = time.perf_counter()
-            _, lps_s, nacc_s = ctx.sample(x0, ns, seed=3)
-            dt = ((time.perf_counter() - t) - t1) / (ns - ns1)
+            ns1, ns = 20, 120
+            ctx.sample(x0, ns)                                     # (warm-up at the longer length: the call's device buffers are sized once)
+            t1 = t2 = float('inf')
+            for _ in range(3):                                     # (best of three: the host side -- fresh numpy pages for the returned chain -- adds milliseconds now and then)
+                t = time.perf_counter()
+                ctx.sample(x0, ns1, seed=3)
+                t1 = min(t1, time.perf_counter() - t)
+                t = time.perf_counter()
+                _, lps_s, nacc_s = ctx.sample(x0, ns, seed=3)      # (two run lengths: the slope is the step, the intercept the call's set-up, initial evaluation and copy back)
+                t2 = min(t2, time.perf_counter() - t)
+            dt = (t2 - t1) / (ns - ns1)
             samp = {'value': 2 * W / dt, 'unit': 'walker-updates/s', 'ms_per_step': 1e3 * dt, 'walkers': 2 * W, 'steps': ns, 'ms_per_call_besides_the_steps': 1e3 * (t1 - ns1 * dt),
                     'acceptance': float(nacc_s.sum()) / (2 * W * ns), 'finite': bool(np.isfinite(lps_s).all()),
+                    'exchange_ms_per_half_step': None,
                     'note': 'jx_sample: proposals, evaluation, accept/reject and chain on the device, one copy back at the end; a step = two half steps of %d walkers' % W}
+            if comm is not None:
+                # (N > 1 or the rehearsal at N = 1: the same run with the communicator on the context shards each half step over the ranks and
+                #  all-gathers positions and log-posteriors in place -- two collectives per half step; the difference to the run above is their cost)
+                samp['exchange_ms_per_half_step'] = 0.5 * samp['ms_per_step'] - 0.5 * 1e3 * (elapsed / args.steps)
+                samp['exchange_note'] = ('with a communicator on the context jx_sample moves this rank\'s share of each half step and exchanges positions and log-posteriors by two '
+                                         'in-place RCCL all-gathers: half a sampler step minus one evaluation step of the same %d walkers' % W)
         except Exception as exc:
             samp = {'error': str(exc)}
 
-    # the fp32 variant on the same walkers (BASELINE configs[4]'s tolerance sweep): beside the f64 metric, never instead of it
+    # the fp32 variants on the same walkers (BASELINE configs[4]'s tolerance sweep): beside the f64 metric, never instead of it
     f32 = None
     if rank == 0 and comm is None and args.route == 'map' and args.dtype == 'f64' and not args.no_f32:
         f32 = {}
-        notes = {'f32': 'jx_config.dtype = 1: spline arrays (y_k, M_k) rounded to fp32 once and read as fp32 by the sample evaluation; sums, matrix-core '
-                        'product, tail and everything per-walker in fp64',
-                 'f32c': 'jx_config.dtype = 2: fp32 arithmetic -- stage 1 in packed fp32 FMAs (v_pk_fma_f32), stage 2 on v_mfma_f32_16x16x4_f32, stage-1 rows '
-                         'and partial rows in fp32, K slices added in fp64 by the tail; everything per-walker (priors, X-ray, conversion, chi^2) in fp64'}
+        notes = {'f32': 'jx_config.dtype = 1 (contracted form of round 4, JOXSZ_MIX_FORM=legacy semantics): spline arrays (y_k, M_k) rounded to fp32 once; sums, '
+                        'matrix-core product, tail and everything per-walker in fp64',
+                 'f32c': 'jx_config.dtype = 2 (contracted form of round 4): fp32 arithmetic -- stage 1 in packed fp32 FMAs, stage 2 on v_mfma_f32_16x16x4_f32, K slices added '
+                         'in fp64 by the tail; everything per-walker in fp64.  |delta chi^2/2| is 1e-5 ... 1e-4 absolute (inside north_star\'s RELATIVE 1e-6 because the '
+                         'log-posterior is ~1e4): outside the 1e-6 absolute bar the fp64 tests hold'}
         ch64 = ctx.eval_stage(theta[:256], 'chisq')
         for dt_name in ('f32', 'f32c'):
             try:
-                p3 = JoxszPosterior(pb, device=local_rank, dtype=dt_name)
+                p3 = with_env({'JOXSZ_QUIET': '1'}, lambda: JoxszPosterior(pb, device=local_rank, dtype=dt_name))
                 c3 = p3.ctx
                 t3, l3 = c3.dev_alloc(theta.nbytes), c3.dev_alloc(8 * W)
                 c3.h2d(t3, theta)
-                dt = time_steps(c3, t3, W, l3, max(5, args.steps // 4), 3)
+                dt = time_steps(c3, t3, W, l3, max(20, args.steps // 4), 3)
                 lp32 = np.empty(W)
                 c3.d2h(lp32, l3)
                 ch32 = c3.eval_stage(theta[:256], 'chisq')
                 rel = np.abs(lp32 - final) / np.abs(final)
-                f32[dt_name] = {'dtype': dt_name, 'value': W / dt, 'unit': 'walker-likelihoods/s', 'ms_per_step': 1e3 * dt,
+                f32[dt_name] = {'dtype': dt_name, 'form': (c3.conv_layout or {}).get('form'), 'value': W / dt, 'unit': 'walker-likelihoods/s', 'ms_per_step': 1e3 * dt,
                                 'speedup_vs_f64': (elapsed / args.steps) / dt,
                                 'rel_dlogp_vs_f64': {'max': float(rel.max()), 'median': float(np.median(rel))},
                                 'abs_dchisq_half_vs_f64': {'max': float(np.abs(ch32 - ch64).max() / 2), 'median': float(np.median(np.abs(ch32 - ch64)) / 2)},
@@ -526,39 +627,70 @@ def main():
                         'frac_of_hbm_peak': b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         'frac_of_measured_write_stream': b / (ms * 1e-3) / 1e9 / streams['write'],
                         'frac_of_measured_copy_roofline': b / (ms * 1e-3) / 1e9 / copy_gbs,
-                        'note': 'a store stream: S^2 * 8 B written per walker, priced against the nominal peak, against what a plain '
+                        'note': 'a store stream: S^2 * 8 B written per walker (SURVEY 8(d)), priced against the nominal peak, against what a plain '
                                 'write stream of the same 2 GiB gets on this card, and against a copy (bytes read + written)'}
         except Exception as exc:
             full_map = {'error': str(exc)}
+
+    def side_route(make, label, note):
+        """one more context of the same library on the same walkers: rate, stage times, difference to the default route"""
+        pr = make()
+        cr = pr.ctx
+        tr_, lr_ = cr.dev_alloc(theta.nbytes), cr.dev_alloc(8 * W)
+        cr.h2d(tr_, theta)
+        nst = 5 if label == 'literal' else max(20, min(args.steps, 100))
+        dts_ = [time_steps(cr, tr_, W, lr_, nst, 3) for _ in range(1 if label == 'literal' else 5)]
+        dt = float(np.median(dts_))
+        cr.timing_enable(1); cr.timing_reset()
+        for _ in range(3):
+            cr.eval_device(tr_, W, lr_)
+        tmr = cr.timing()
+        cr.timing_enable(False)
+        lpr = np.empty(W)
+        cr.d2h(lpr, lr_)
+        out_ = {'value': W / dt, 'unit': 'walker-likelihoods/s', 'ms_per_step': 1e3 * dt, 'walkers_per_launch': min(W, cr.chunk) if label != 'collapsed' else W,
+                'form': (cr.conv_layout or {}).get('form') if cr.conv == 'custom' else None,
+                'stage_ms_per_step': {k: tmr[k] / 3 for k in ('prep_ms', 'abel_map_ms', 'beam_fft_ms', 'tf_fft_ms', 'tail_ms')},
+                'max_rel_diff_vs_default_route': float(np.max(np.abs(lpr - lp_own) / np.abs(lp_own))),
+                'ms_per_step_of_the_default_route_over_this': None, 'note': note}
+        return pr, cr, out_
 
     # north_star's literal design as a whole step: fused profile -> Abel -> map kernel, then the rocFFT sequence for the beam
     # convolution and the transfer function (joxsz_funcs.py:460-467 executed step by step), same walkers, same problem
     ns_route = None
     if rank == 0 and comm is None and args.route == 'map' and not args.no_full_map and ctx.conv == 'custom':
         try:
-            pr = JoxszPosterior(pb, device=local_rank, conv='rocfft', max_batch=W)
-            cr = pr.ctx
-            tr_, lr_ = cr.dev_alloc(theta.nbytes), cr.dev_alloc(8 * W)
-            cr.h2d(tr_, theta)
-            dt = time_steps(cr, tr_, W, lr_, 5, 2)
-            cr.timing_enable(1); cr.timing_reset()
-            for _ in range(3):
-                cr.eval_device(tr_, W, lr_)
-            tmr = cr.timing()
-            cr.timing_enable(False)
-            lpr = np.empty(W)
-            cr.d2h(lpr, lr_)
-            ns_route = {'route': 'jx_abel_map_sym_kernel -> rocFFT R2C -> jx_beam_mul_kernel -> rocFFT C2R -> rocFFT R2C of the S x S window -> jx_tail_kernel',
-                        'value': W / dt, 'unit': 'walker-likelihoods/s', 'ms_per_step': 1e3 * dt, 'walkers_per_launch': cr.chunk, 'fft_pad': cr.fft_pad,
-                        'stage_ms_per_step': {k: tmr[k] / 3 for k in ('prep_ms', 'abel_map_ms', 'beam_fft_ms', 'tf_fft_ms', 'tail_ms')},
-                        'max_rel_diff_vs_default_route': float(np.max(np.abs(lpr - lp_own) / np.abs(lp_own))),
-                        'speedup_of_default_route': None,
-                        'note': 'the same library with conv = rocfft: every map, its padded spectrum and the convolved map go through HBM'}
+            pr, cr, ns_route = side_route(lambda: JoxszPosterior(pb, device=local_rank, conv='rocfft', max_batch=W), 'literal',
+                                          'the same library with conv = rocfft: every map, its padded spectrum and the convolved map go through HBM')
+            ns_route['route'] = 'jx_abel_map_sym_kernel -> rocFFT R2C -> jx_beam_mul_kernel -> rocFFT C2R -> rocFFT R2C of the S x S window -> jx_tail_kernel'
+            ns_route['fft_pad'] = cr.fft_pad
+            ns_route['survey_8d_bytes_per_step'] = 2.0 * W * args.S * args.S * 8.0
+            ns_route['frac_of_hbm_peak_on_survey_8d_bytes'] = ns_route['survey_8d_bytes_per_step'] / (ns_route['ms_per_step'] * 1e-3) / 1e9 / HBM_PEAK_GBS
             pr.close()
         except Exception as exc:
             ns_route = {'error': str(exc)}
+    # literal | contracted (round 4) | collapsed beside the default: the same walkers through the other routes of the same library
+    other_routes = {}
+    if rank == 0 and comm is None and args.route == 'map' and not args.no_other_routes and ctx.conv == 'custom':
+        for name, make, note in (
+                ('collapsed_route', lambda: JoxszPosterior(pb, device=local_rank, route='operator'),
+                 'jx_set_route(JX_ROUTE_OPERATOR): row = G pp with one constant nrow x N matrix built by sending the N unit profiles through the default route\'s own '
+                 '(exact) kernels -- profile, then ONE matrix-vector product per walker; the Abel transform is folded into G and runs N times at set-up, never per walker'),
+                ('legacy_contracted_route', lambda: with_env({'JOXSZ_MIX_FORM': 'legacy', 'JOXSZ_QUIET': '1'}, lambda: JoxszPosterior(pb, device=local_rank)),
+                 'JOXSZ_MIX_FORM=legacy: the contracted forms of rounds 3-4 (rank-16 low-rank tables, a sub-grid of map samples, a radial sub-grid of the profile, '
+                 'measured by the truncation guard) that were the default until round 4; kept for one round')):
+            try:
+                pr, cr, row = side_route(make, 'collapsed' if name == 'collapsed_route' else 'legacy', note)
+                row['max_rel_err_vs_oracle_sample'] = parity_other.get(name)
+                if name == 'legacy_contracted_route':
+                    row['truncation'] = {k: v for k, v in cr.truncation.items() if k != 'warning'}
+                    row['sampling'] = {k: v for k, v in cr.sampling.items() if k != 'rows'}
+                    row['radial_sampling'] = {k: v for k, v in cr.radial_sampling.items() if k != 'rows'}
+                pr.close()
+                other_routes[name] = row
+            except Exception as exc:
+                other_routes[name] = {'error': str(exc)}
 
-    # the same batch on the collapsed route, only when asked for (--route operator): not the BASELINE metric
     # strong-scaling rows of the other BASELINE configs: this rank's shard of configs[3] (4096 walkers, 512^2) and of
     # configs[4] (8192 walkers, 1024^2 / 1000-pt, fp64 and fp32), a few steps each, outside the timed region
     other = None
@@ -576,7 +708,7 @@ def main():
             c3 = p3c.ctx if p3c is not None else ctx
             p3t, l3t = c3.dev_alloc(th3.nbytes), c3.dev_alloc(8 * n3)
             c3.h2d(p3t, th3)
-            dts[0] = time_steps(c3, p3t, n3, l3t, 5, 2)
+            dts[0] = float(np.median([time_steps(c3, p3t, n3, l3t, 10, 2) for _ in range(5)]))
             other['configs[3]'] = {'workload': '4096 walkers, 512x512 map, 500-pt grid, joint; %d walkers on this rank' % n3,
                                    'unit': 'walker-likelihoods/s', 'scaling': 'strong', 'dtype': 'f64', 'walkers_per_launch': c3.chunk}
             if p3c is not None:
@@ -585,14 +717,14 @@ def main():
             n4 = hi - lo
             pb4 = datasets.synthetic_problem(S=1024, N=1000, seed=0)
             for i4, dt_name in enumerate(('f64', 'f32c')):
-                p4 = JoxszPosterior(pb4, device=local_rank, dtype=dt_name, max_batch=n4)
+                p4 = with_env({'JOXSZ_QUIET': '1'}, lambda: JoxszPosterior(pb4, device=local_rank, dtype=dt_name, max_batch=n4))
                 c4 = p4.ctx
                 cand4 = datasets.walker_ball(pb4, 256, spread=0.02, seed=5)
                 ok4 = cand4[np.isfinite(c4.eval(cand4))]
                 th4 = np.ascontiguousarray(np.resize(ok4, (n4, ok4.shape[1])))
                 a4, b4 = c4.dev_alloc(th4.nbytes), c4.dev_alloc(8 * n4)
                 c4.h2d(a4, th4)
-                dts[1 + i4] = time_steps(c4, a4, n4, b4, 3, 1)
+                dts[1 + i4] = float(np.median([time_steps(c4, a4, n4, b4, 5, 1) for _ in range(3)]))
                 other['configs[4] ' + dt_name] = {'workload': '8192 walkers, 1024x1024 map, 1000-pt grid, joint; %d walkers on this rank' % n4,
                                                   'unit': 'walker-likelihoods/s', 'scaling': 'strong',
                                                   'dtype': dt_name, 'conv_layout': c4.conv_layout, 'walkers_per_launch': c4.chunk}
@@ -613,19 +745,8 @@ def main():
         S = args.S
         launches = max(1, tm['launches'])
         walkers_per_launch = tm['walkers'] / launches
-        lay = ctx.conv_layout or {}
-        stage_ms = {k: tm[k] / launches for k in ('prep_ms', 'abel_map_ms', 'beam_fft_ms', 'tf_fft_ms', 'tail_ms')}
-        mixed = ctx.conv == 'custom' and args.route == 'map'
-        lowrank = mixed and lay.get('form') == 'lowrank'
-        stage_kernels = None
-        if mixed:
-            stage_kernels = {'prep_ms': 'jx_prep_kernel (priors, vetoes, X-ray Cash likelihood, pressure and temperature profiles)',
-                             'abel_map_ms': 'jx_abel_gemm_kernel (Abel transform, y scale and spline moments of the launch as one fp64 matrix-core product)',
-                             'beam_fft_ms': 'jx_rowmix_kernel (stage 1: map samples evaluated from the spline and mixed per column, fp64 vector FMAs)' if lowrank
-                                            else '(none: the full form has one kernel)',
-                             'tf_fft_ms': 'jx_opgemm_kernel (stage 2: beam along x + circular transfer-function kernels + row extraction as one fp64 matrix-core product)' if lowrank
-                                          else 'jx_opgemm_kernel (full form: map samples evaluated by the lanes that feed the fp64 matrix cores)',
-                             'tail_ms': 'jx_tail_row_kernel (partial rows summed in fixed order, conversion, chi^2, total)'}
+        stage_keys = ('prep_ms', 'abel_map_ms', 'beam_fft_ms', 'tf_fft_ms', 'tail_ms')
+        stage_ms = {k: tm[k] / launches for k in stage_keys}
         try:
             ev_null_ms = ctx.event_bracket_time(64)
         except Exception:
@@ -634,104 +755,98 @@ def main():
         ms_step = 1e3 * elapsed / args.steps
         pj = pmc_file(S)
         nrow = ctx.nrow
-        roof = roof2 = None
-        if mixed:
-            NU = lay['NU']
-            if lowrank:
-                # stage 1: per sample and walker 4 FMAs of the spline evaluation + R of the mixing
-                k_ms = tm_timed['beam_fft_ms'] / max(1, tm_timed['launches'])
-                NUe = ctx.sampling['rows_evaluated']                      # rows (= columns) of the quadrant stage 1 evaluates (the sub-grid)
-                fl = 2.0 * NUe * NUe * (4 + lay['R']) * walkers_per_launch
-                ach = fl / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
-                roof = {'kernel': 'jx_rowmix_kernel', 'bound': 'valu (fp64 vector FMA; the same 78.6 TFLOP/s as the dense fp64 matrix-core peak)',
-                        'achieved': ach, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / FP64_PEAK_TFLOPS,
-                        'traffic': pmc_traffic(pj, 'jx_rowmix_kernel', walkers_per_launch),
-                        'traffic_source': (pj or {}).get('file'), 'traffic_measured_in_this_run': False,
-                        'peak_measured': FP64_FMA_MEASURED_TFLOPS, 'frac_of_peak_measured': ach / FP64_FMA_MEASURED_TFLOPS,
-                        'launch_ms': k_ms, 'launch_ms_source': 'HIP events around this kernel inside the timed region (jx_timing_enable(2))',
-                        'launch_ms_of_an_empty_kernel': ev_null_ms,
-                        'launch_ms_note': 'a pair of HIP events around one kernel of a dependent chain also spans the command processor\'s hand-over '
-                                          'in front of and behind it -- launch_ms_of_an_empty_kernel is what the same pair reads around a kernel that does nothing '
-                                          '(jx_event_bracket_time); rocprofv3\'s kernel trace (profiles/*_kernel_stats.csv) counts the kernel alone, so its average sits '
-                                          'between launch_ms - launch_ms_of_an_empty_kernel and launch_ms.  achieved and frac use launch_ms as measured (the lower figure)',
-                        'flops_per_launch': fl, 'share_of_step': k_ms / max(1e-12, ms_step * walkers_per_launch / W),
-                        'algorithmic_bytes_per_launch': walkers_per_launch * (16.0 * pb.N + 8.0 * NUe * lay['R']),
-                        'samples_evaluated_per_walker': NUe * NUe, 'distinct_samples_per_walker': NU * NU,
-                        'survey_8d_bytes_per_launch': walkers_per_launch * S * S * 8.0,
-                        'note': 'algorithmic flops = 2 * NUe^2 * (4 + R) per walker (4 FMAs evaluate a map sample from the spline, R mix it into '
-                                'the rows kept per column; NUe = %d of the quadrant\'s %d distinct rows = columns are evaluated -- the sub-grid of '
-                                'jx_get_sampling, the interpolation to the others sits in the operators -- R = %d) / HIP-event duration.  The S x S map of '
-                                'SURVEY 8(d) (S^2 * 8 B per walker) is never written: every sample lives in a register.  The kernel is bound by '
-                                'the fp64 vector units, not by HBM; peak_measured = sustained v_fmac_f64 rate of this chip (scripts/ubench/fma_sgpr.hip)'
-                                % (NUe, NU, lay['R'])}
-            p_ms = stage_ms['tf_fft_ms']
-            K4 = lay['ksteps'] * 4
-            prn = ctx.output_pruning
-            nout = prn['outputs_computed'] if prn['active'] else nrow      # the timed product computes the outputs the tail's data-radii spline reads
-            fl2 = 2.0 * nout * K4 * walkers_per_launch
-            ach2 = fl2 / (p_ms * 1e-3) / 1e12 if p_ms > 0 else 0.0
-            roof2 = {'kernel': 'jx_opgemm_kernel', 'bound': 'mfma', 'achieved': ach2, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                     'frac': ach2 / FP64_PEAK_TFLOPS, 'traffic': pmc_traffic(pj, 'jx_opgemm_kernel', walkers_per_launch),
-                     'launch_ms': p_ms, 'launch_ms_source': 'HIP events of the stage pass', 'flops_per_launch': fl2,
-                     'outputs_computed': nout, 'outputs_of_the_row': nrow,
-                     'note': 'outputs x K x walkers product on v_mfma_f64_16x16x4 (%d of the row\'s %d outputs: the ones the data-radii spline of the tail reads '
-                             'with a weight above 1e-22 of its largest, in whole tiles of 16; K = %d rows of the operator)' % (nout, nrow, K4)}
-            if not lowrank:
-                roof, roof2 = roof2, None
-        # HBM bytes of the step: exactly the kernels of the step (stage_kernels), nothing else the PMC file holds
-        step_names = ('jx_prep_kernel', 'jx_abel_gemm_kernel', 'jx_rowmix_kernel', 'jx_rowmix_mfma_kernel', 'jx_opgemm_kernel', 'jx_tail_row_kernel')
+        prn = ctx.output_pruning
+        sq = sq_counters_file()
+
+        def wave_shares(kernel):
+            row = next((r for r in sq.get('rows', []) if kernel in r['kernel'] and float(r['SQ_WAVE_CYCLES']) > 1e6), None)
+            if not row:
+                return None
+            wc = float(row['SQ_WAVE_CYCLES'])
+            return {'source': sq['file'], 'waiting': float(row['SQ_WAIT_ANY']) / wc, 'issue_stalled': float(row['SQ_WAIT_INST_ANY']) / wc,
+                    'issuing': float(row['SQ_ACTIVE_INST_ANY']) / wc, 'issuing_valu': float(row['SQ_ACTIVE_INST_VALU']) / wc}
+
+        step_kernels = None
+        roof = None
+        if mixed and kernels:
+            tot_stage = sum(stage_ms[k[0]] for k in kernels)
+            step_kernels = [{'kernel': k[1], 'what': k[2], 'bound': k[3], 'ms_hip_events_stage_pass': stage_ms[k[0]], 'share_of_stage_sum': stage_ms[k[0]] / max(1e-12, tot_stage),
+                             'traffic_bytes_per_launch': pmc_traffic(pj, k[1], walkers_per_launch), 'share_of_wave_cycles': wave_shares(k[1])} for k in kernels]
+            key, kname, kwhat, kbound = dom
+            k_ms = tm_timed[key] / max(1, tm_timed['launches'])
+            common = {'kernel': kname, 'what': kwhat, 'launch_ms': k_ms,
+                      'launch_ms_source': 'HIP events around this kernel alone over %d timed regions of `steps` steps run right behind the headline regions (jx_timing_enable(%d)); the kernel '
+                                          'picked is the longest of the stage pass run in the warm-up' % (len(regions_ev), p1_mode),
+                      'ms_per_step_of_the_regions_with_these_events': 1e3 * float(np.median(regions_ev)) / args.steps,
+                      'launch_ms_of_an_empty_kernel': ev_null_ms,
+                      'launch_ms_note': 'a pair of HIP events around one kernel of a dependent chain also spans the command processor\'s hand-over in front of and behind it -- '
+                                        'launch_ms_of_an_empty_kernel is what the same pair reads around a kernel that does nothing (jx_event_bracket_time); rocprofv3\'s kernel trace '
+                                        '(profiles/*_kernel_stats.csv) counts the kernel alone',
+                      'share_of_step': k_ms / max(1e-12, ms_step * walkers_per_launch / W),
+                      'traffic': pmc_traffic(pj, kname, walkers_per_launch), 'traffic_source': (pj or {}).get('file'), 'traffic_measured_in_this_run': False,
+                      'share_of_wave_cycles': wave_shares(kname),
+                      'survey_8d_bytes_per_launch': walkers_per_launch * S * S * 8.0,
+                      'survey_8d_note': 'SURVEY 8(d) prices the Abel+map kernel at S^2 * 8 B written per walker; this step never writes a map (see north_star_abel_map_kernel and '
+                                        'north_star_route for the kernels that do): its own work is counted below'}
+            if form == 'exact':
+                nk = lay['rank']                                          # ordinates in use
+                nout = prn['outputs_computed']
+                macs = sum(args.N - k for k in range(nk)) + nout * nk      # triangular Abel product for the ordinates in use + the row product
+                fl = 2.0 * macs * walkers_per_launch
+                if kbound.startswith('mfma'):
+                    ach = fl / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+                    roof = dict(common, bound='mfma', achieved=ach, peak=FP64_PEAK_TFLOPS, unit='TFLOP/s', frac=ach / FP64_PEAK_TFLOPS, flops_per_launch=fl,
+                                ordinates=nk, outputs_computed=nout,
+                                note='algorithmic flops = 2 * [sum_{k < %d} (N - k) + %d * %d] per walker: the upper-triangular Abel product for the %d ordinates the row reads (of N = %d) '
+                                     'and the %d x %d row product, over the kernel\'s HIP-event duration; peak = dense fp64 matrix-core peak (the instruction issues at 47 TFLOP/s '
+                                     'chip-wide in scripts/ubench/mfma_f64_rate.hip, 0.60 of it)' % (nk, nout, nk, nk, args.N, nout, nk))
+                else:
+                    roof = dict(common, bound='latency', achieved=None, peak=None, unit=None, frac=None,
+                                note='the longest kernel of the step is a chain of dependent phases (parameters -> priors -> grid pass of fp64 exp/log chains -> veto -> conversion '
+                                     'factors | X-ray profiles -> count rates -> projection -> Cash sum): neither a flop nor a byte count prices it; its shares of wave cycles and '
+                                     'its HBM bytes are given, and `roofline_product` prices the matrix-core kernel behind it',
+                                matrix_core_kernel={'kernel': 'jx_ordrow_kernel', 'launch_ms_stage_pass': stage_ms['abel_map_ms'], 'flops_per_launch': fl,
+                                                    'achieved': fl / (stage_ms['abel_map_ms'] * 1e-3) / 1e12 if stage_ms['abel_map_ms'] > 0 else None, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                                                    'frac': (fl / (stage_ms['abel_map_ms'] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS) if stage_ms['abel_map_ms'] > 0 else None})
+            else:
+                roof = dict(common, bound=kbound, achieved=None, peak=None, unit=None, frac=None, note='contracted form of round 4: see profiles/r04_bench.json for its priced kernels')
+        # HBM bytes of the step: exactly the kernels of the step, nothing else the PMC file holds
         step_pmc = None
         step_pmc_kernels = None
-        if pj and mixed:
-            step_pmc_kernels = {n: pmc_traffic(pj, n, W) for n in step_names if pmc_kernel_entry(pj, n)}
+        if pj and mixed and kernels:
+            step_pmc_kernels = {k[1]: pmc_traffic(pj, k[1], W) for k in kernels if pmc_kernel_entry(pj, k[1])}
             step_pmc = sum(step_pmc_kernels.values()) if step_pmc_kernels else None
-        # every kernel of the step with the duration the stage pass read for it: since the sub-grid of stage 1 no kernel
-        # dominates -- the per-walker kernel, stage 1 and the spline-array product are within 15 % of one another
-        step_kernels = None
-        if mixed and stage_kernels:
-            bounds = {'prep_ms': 'latency + fp64 exp/log chains of the grid pass on the vector units (73 % busy; DESIGN 6.3)',
-                      'abel_map_ms': 'fp64 matrix cores at one wave per SIMD: operand fetch of the k loop (DESIGN 6.3)',
-                      'beam_fft_ms': 'fp64 vector FMA issue (`roofline`)' if lowrank else None,
-                      'tf_fft_ms': 'fp64 matrix cores + operand fetch (`roofline_product`)' if lowrank else 'fp64 matrix cores fed by the lanes that evaluate the samples (`roofline`)',
-                      'tail_ms': 'L2 reads of the partial rows + latency'}
-            step_kernels = [{'kernel': stage_kernels[k].split(' ')[0], 'ms_hip_events_stage_pass': stage_ms[k], 'share_of_stage_sum': stage_ms[k] / max(1e-12, sum(stage_ms[q] for q in bounds)),
-                             'bound': bounds[k]} for k in ('prep_ms', 'abel_map_ms', 'beam_fft_ms', 'tf_fft_ms', 'tail_ms') if bounds[k]]
-            # where each kernel's wave cycles go, from the committed counter pass of the same command (profiles/*_sq_counters.csv; not measured in this run)
-            sq = sq_counters_file()
-            for e in step_kernels:
-                row = next((r for r in sq.get('rows', []) if e['kernel'] in r['kernel'] and float(r['SQ_WAVE_CYCLES']) > 1e6), None)
-                if row:
-                    wc = float(row['SQ_WAVE_CYCLES'])
-                    e['wave_cycles_source'] = sq['file']
-                    e['share_of_wave_cycles'] = {'waiting': float(row['SQ_WAIT_ANY']) / wc, 'issue_stalled': float(row['SQ_WAIT_INST_ANY']) / wc,
-                                                 'issuing': float(row['SQ_ACTIVE_INST_ANY']) / wc, 'issuing_valu': float(row['SQ_ACTIVE_INST_VALU']) / wc}
-            if roof is not None:
-                longest = max(step_kernels, key=lambda e: e['ms_hip_events_stage_pass'])
-                roof['longest_kernel_of_the_step'] = {'kernel': longest['kernel'], 'ms_hip_events_stage_pass': longest['ms_hip_events_stage_pass']}
-                roof['longest_kernel_note'] = ('no kernel dominates the step: the per-walker kernel (latency + fp64 exp/log chains; no flop or byte count prices it, its '
-                                               'vector-issue share is in step_kernels), stage 1 and the spline-array product lie within 15 % of one another; `roofline` prices '
-                                               'stage 1, the kernel that holds the arithmetic of the path')
+        for r_ in [ns_route] + list(other_routes.values()):
+            if r_ and 'ms_per_step' in r_:
+                r_['ms_per_step_of_the_default_route_over_this'] = ms_step / r_['ms_per_step']
         if ns_route and 'ms_per_step' in ns_route:
             ns_route['speedup_of_default_route'] = ns_route['ms_per_step'] / ms_step
+        none_or = lambda d, active: ({k: v for k, v in d.items() if k != 'rows'} if active else 'none')
+        tr = ctx.truncation
         out = {
             'metric': 'walker-likelihoods/sec at 512^2 map, 500-pt grid' if (S, args.N) == (512, 500)
                       else 'walker-likelihoods/sec at %d^2 map, %d-pt grid' % (S, args.N),
             'value': value, 'unit': 'walker-likelihoods/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': ms_step, 'higher_is_better': True,
+            'warmup': args.warmup, 'ms_per_step': ms_step, 'ms_per_step_min': 1e3 * min(regions) / args.steps, 'ms_per_step_max': 1e3 * max(regions) / args.steps,
+            'timed_regions': len(regions), 'timed_ms_total': 1e3 * sum(regions),
+            'ms_per_step_note': 'median over the timed regions of `steps` steps each (every region bracketed by barrier + synchronisation; value = walkers x steps / median region; '
+                                'no HIP event inside them: `roofline.launch_ms` comes from the same regions run once more with two events around the longest kernel)',
+            'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': '%d walkers/GPU, %dx%d SZ map, %d-pt radial grid, %s likelihood, '
                                    'synthetic CL J1226.9+3332-shaped inputs%s'
                                    % (W, S, S, args.N, 'SZ-only' if pb.sz_only else 'joint X-ray+SZ',
                                       ' (BASELINE configs[2])' if (W, S, args.N, pb.sz_only) == (1024, 512, 500, False) else ''),
-                       'walkers_per_gpu': W, 'S': S, 'N': args.N, 'B': pb.B, 'chunk': ctx.chunk, 'route': ctx.route, 'conv': ctx.conv,
-                       'conv_layout': ctx.conv_layout, 'output_pruning': ctx.output_pruning,
-                       'sampling': {k: v for k, v in ctx.sampling.items() if k != 'rows'}, 'parallelism': 'walkers sharded x%d' % world, 'device': ctx.device_name,
-                       'gather': (('overlapped: second stream, two output buffers' if overlap else 'strict: on the compute stream') if comm is not None else None),
+                       'walkers_per_gpu': W, 'S': S, 'N': args.N, 'B': pb.B, 'chunk': ctx.chunk, 'route': ctx.route, 'conv': ctx.conv, 'form': form,
+                       'conv_layout': ctx.conv_layout, 'output_pruning': prn,
+                       'sampling': none_or(ctx.sampling, ctx.sampling['active']), 'radial_sampling': none_or(ctx.radial_sampling, ctx.radial_sampling['active']),
+                       'truncation': ('none' if (tr['rank'] == 0 and tr['est_rel_row_err'] < 0) else {k: v for k, v in tr.items() if k != 'warning'}),
+                       'parallelism': 'walkers sharded x%d' % world, 'device': ctx.device_name,
+                       'gather': (('overlapped: second stream, two output buffers' if overlap else 'strict: on the compute stream, in order') if comm is not None else None),
                        'gather_probe_ms_per_step': gather_probe},
             'n_ranks_seen': (comm.n_ranks_seen if comm is not None else 1),
             'gather_ms_per_step': gather_ms,
             'roofline': roof,
-            'roofline_product': roof2,
             # the whole step against the HBM roofline: measured bytes (rocprofv3 PMC, profiles/*_pmc_traffic.json)
             'roofline_step': {'bound': 'hbm', 'peak': HBM_PEAK_GBS, 'peak_measured': copy_gbs, 'unit': 'GB/s', 'ms_per_step': ms_step,
                               'traffic_bytes_per_step': step_pmc, 'traffic_by_kernel': step_pmc_kernels, 'traffic_source': (pj or {}).get('file'),
@@ -739,22 +854,21 @@ def main():
                               'achieved': (step_pmc / (ms_step * 1e-3) / 1e9) if step_pmc else None,
                               'frac': (step_pmc / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS) if step_pmc else None,
                               'survey_8d_bytes_per_step': 2.0 * W * S * S * 8.0,
-                              'note': 'the step is compute-bound (fp64 vector units, then fp64 matrix cores): its HBM traffic is the small '
-                                      'per-walker arrays between the kernels'},
+                              'note': 'the step is three short dependent launches (latency, then fp64 matrix cores): its HBM traffic is the small per-walker arrays between '
+                                      'the kernels, far under SURVEY 8(d)\'s 2 S^2 * 8 B per walker -- no map, spectrum or convolved map is ever stored'},
             'step_kernels': step_kernels,
             'north_star_abel_map_kernel': full_map,
             'north_star_route': ns_route,
+            'collapsed_route': other_routes.get('collapsed_route'),
+            'legacy_contracted_route': other_routes.get('legacy_contracted_route'),
             'host_pointer': host_ptr,
             'device_sampler': samp,
             'hbm_copy_bandwidth_measured_GBps': copy_gbs,
             'hbm_stream_bandwidth_measured_GBps': streams,
-            'truncation': ctx.truncation,
             'fp32_variant': f32,
             'cpu_baseline': cpu,
-            'stage_ms_per_step': {k: tm[k] / args.steps for k in ('prep_ms', 'abel_map_ms', 'beam_fft_ms', 'tf_fft_ms', 'tail_ms', 'total_ms')},
-            'stage_ms_note': 'HIP events behind every stage, from a second pass of the same steps right after the timed region '
-                             '(the timed region itself carries only the two events around the time-dominant kernel)' if p1_only else None,
-            'stage_kernels': stage_kernels,
+            'stage_ms_per_step': {k: tm[k] / args.steps for k in stage_keys + ('total_ms',)},
+            'stage_ms_note': 'HIP events behind every kernel, from one more pass of `steps` steps right after the timed regions',
             'parity_max_rel_err': parity,
             'other_configs': other,
         }

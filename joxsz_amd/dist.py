@@ -157,6 +157,8 @@ class RcclGather:
         scalar = np.ndim(value) == 0
         buf = np.atleast_1d(np.asarray(value, dtype=np.float64)).copy()
         if buf.size > self._scratch_n:
+            if self._scratch_n:
+                self.ctx.dev_free(self._scratch)              # (the vector grew: the old scratch goes back)
             self._scratch_n = int(buf.size)
             self._scratch = self.ctx.dev_alloc(8 * self._scratch_n)
         self.ctx.h2d(self._scratch, buf)

@@ -525,3 +525,98 @@ def test_the_data_radii_spline_reads_a_bounded_part_of_the_row(lib, S):
         ratio = m[k0 + 20] / m[k0]
         assert abs(ratio ** (1 / 20.0) - (2 - np.sqrt(3))) < 0.01          # the cardinal functions' decay per knot
         assert np.abs(E[:, 96:]).sum(axis=1).max() < 1e-20 * m.max()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# exact form (round 5, csrc/jx_exact.hpp): the extracted row as one constant operator on the spline ordinates
+# ---------------------------------------------------------------------------------------------------------------------
+def _exact_operator(lib, pb):
+    S, N = pb.S, pb.N
+    nrow = S - S // 2
+    Wy = np.zeros((nrow, N))
+    nk = lib.jxt_exact_row_operator(_p(np.ascontiguousarray(pb.d_mat)), _p(np.ascontiguousarray(pb.beam_2d)), int(pb.beam_2d.shape[0]),
+                                    ctypes.c_double(pb.step ** 2), _p(np.ascontiguousarray(pb.filtering)), S, _p(np.ascontiguousarray(pb.r_pp)), N, _p(Wy))
+    return Wy, nk
+
+
+@pytest.mark.parametrize('S,N,kw', [(31, 40, {}), (32, 40, {}), (64, 80, dict(fwhm=8.5, step=6.)), (65, 80, {}), (171, 313, {})])
+def test_exact_row_operator_against_the_oracle(lib, S, N, kw):
+    """map_out[S//2, S//2:] == Wy @ y for the oracle's own chain of joxsz_funcs.py:460-467 (interp1d 'cubic' -> f(d_mat) -> fftconvolve
+    -> fft2 * filtering -> ifft2 -> central row): odd and even sides, several beams, random walkers -- to rounding (1e-13 of the row's
+    maximum), with no term dropped: the operator is exact for every pixel and every radius.  The columns beyond the map's corner plus
+    the spline's band are exactly zero (that many ordinates are never computed)."""
+    from joxsz_amd import datasets
+    from oracle import joxsz_oracle as orc
+    pb = datasets.synthetic_problem(S=S, N=N, seed=S, **kw)
+    Wy, nk = _exact_operator(lib, pb)
+    assert 0 < nk <= N and np.all(Wy[:, nk:] == 0.0)
+    corner = np.sqrt(2.0) * np.abs(pb.d_mat).max() / np.sqrt(2.0)         # (the largest pixel radius IS the corner's)
+    if pb.r_pp[-1] > corner:
+        assert nk < N or N - np.searchsorted(pb.r_pp, corner) < 60
+    th = datasets.walker_ball(pb, 5, spread=0.06, seed=S)
+    for t in th:
+        pp = orc.press_fun(orc.pars_dict(pb, t), pb.r_pp)
+        out = orc.row_chain(pb, pp)
+        got = Wy @ out['y']
+        assert np.max(np.abs(got - out['map_row'])) <= 1e-13 * np.max(np.abs(out['map_row']))
+    # linear in the ordinates with constant coefficients: any y, not only physical profiles
+    y = np.random.default_rng(S).normal(size=N)
+    f = interp1d(np.append(-pb.r_pp, pb.r_pp), np.append(y, y), 'cubic', bounds_error=False, fill_value=(0., 0.))
+    conv = fftconvolve(f(pb.d_mat), pb.beam_2d, 'same') * pb.step ** 2
+    row = np.real(ifft2(fft2(conv) * pb.filtering))[S // 2, S // 2:]
+    assert np.max(np.abs(Wy @ y - row)) <= 1e-12 * np.max(np.abs(row))
+
+
+def test_exact_row_operator_with_the_measured_beam_and_transfer_function(lib):
+    """The reference's default inputs (measured beam profile: an image that is not separable; measured transfer function: rough from
+    one wavenumber to the next; joxsz_main.py:59-60) go through the same builder: nothing in it depends on smoothness or rank."""
+    from joxsz_amd import datasets, setup_host as sh
+    from oracle import joxsz_oracle as orc
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'bundled_inputs.npz'))
+    pb = datasets.synthetic_problem(S=129, N=160, seed=9)
+    prof = sh.clip_beam_profile(z['beam_r'], z['beam_prof'])
+    beam_2d, _ = sh.beam_image(2., 116.0, approx=False, profile=prof)
+    wn, tf = sh.transfer_function(z['wn_as'], z['tf'], approx=False)
+    pb.beam_2d = np.ascontiguousarray(beam_2d)
+    pb.filtering = np.ascontiguousarray(sh.filter_image(wn, tf, 129, 2.))
+    pb = pb.validate()
+    Wy, nk = _exact_operator(lib, pb)
+    assert nk > 0
+    pp = orc.press_fun(orc.pars_dict(pb, datasets.fiducial_theta(pb)), pb.r_pp)
+    out = orc.row_chain(pb, pp)
+    assert np.max(np.abs(Wy @ out['y'] - out['map_row'])) <= 1e-13 * np.max(np.abs(out['map_row']))
+
+
+def test_exact_form_operand_layouts(lib):
+    """The two operand layouts of jx_ordrow_kernel, read back the way the matrix cores consume them (v_mfma_f64_16x16x4: K slot lk of
+    sub-step e of macro step s = index 16 s + 4 lk + e on BOTH operands): the ordinate operator reproduces y_scale * A (upper
+    triangular: tile t has no entry before step t) and the row operator reproduces Wy, zero padded."""
+    r = np.ascontiguousarray(GRIDS['arange'][:100])
+    N = r.size
+    A = np.zeros((N, N))
+    lib.jxt_abel_matrix(_p(r), N, _p(A))
+    ysc = 3.7
+    nS, nSj = 5, (N + 15) // 16                                      # 80 ordinates of 100 radii
+    Typ = np.zeros((nSj, nS, 64, 4))
+    lib.jxt_abel_ordinate_layout(_p(r), N, ctypes.c_double(ysc), nS, nSj, _p(Typ))
+    lane = np.arange(64)
+    li, lk = lane & 15, lane >> 4
+    for s in range(nSj):
+        for t in range(nS):
+            k = 16 * t + li[:, None]
+            j = 16 * s + 4 * lk[:, None] + np.arange(4)[None, :]
+            want = np.where((j < N) & (k <= j), ysc * A[np.minimum(k, N - 1), np.minimum(j, N - 1)], 0.0)
+            np.testing.assert_array_equal(Typ[s, t], want)
+            if t > s:
+                assert np.all(Typ[s, t] == 0.0)
+    nrow, NXT, ng = 37, 2, 2
+    Wy = np.random.default_rng(1).normal(size=(nrow, N))
+    Opk = np.zeros((ng, nSj, 4, 64, NXT))
+    lib.jxt_exact_row_layout(_p(Wy), nrow, N, nSj, NXT, ng, _p(Opk))
+    for g in range(ng):
+        for s in range(nSj):
+            for e in range(4):
+                for t in range(NXT):
+                    x, i = 16 * (g * NXT + t) + li, 16 * s + 4 * lk + e
+                    want = np.where((x < nrow) & (i < N), Wy[np.minimum(x, nrow - 1), np.minimum(i, N - 1)], 0.0)
+                    np.testing.assert_array_equal(Opk[g, s, e, :, t], want)
