@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define JX_ABI_VERSION 4
+#define JX_ABI_VERSION 5
 
 typedef struct jx_ctx jx_ctx;
 
@@ -68,9 +68,14 @@ typedef struct jx_config {
     int32_t max_batch;        /* walkers processed per internal chunk (0 = library default)    */
     int32_t fft_pad;          /* padded side of the beam convolution (0 = library default)     */
     int32_t map_split;        /* row slabs per walker in the Abel+map kernel (0 = default)     */
-    int32_t conv_mode;        /* beam + transfer-function step: 0 auto, 1 rocFFT sequence, 2 contracted route (hand-written kernels) */
-    int32_t dtype;            /* arithmetic of the SZ stages: 0 = f64 (the reference's); 1 = fp32 spline arrays, every sum in fp64; 2 = fp32
-                               * arithmetic in stage 1 (packed fp32 FMAs) and stage 2 (fp32 matrix cores), K slices added in fp64 (low-rank form only) */
+    int32_t conv_mode;        /* beam + transfer-function step: 0 auto, 1 rocFFT sequence (joxsz_funcs.py:460-467 executed literally), 2 hand-written kernels:
+                               * the exact form (default: the row as one constant operator on the spline ordinates, see jx_get_conv_layout) or, behind the option
+                               * JOXSZ_MIX_FORM, the contracted forms of rounds 3-4 */
+    int32_t dtype;            /* arithmetic of the SZ stages: 0 = f64 (the reference's; the exact form).  The fp32 variants run on the contracted low-rank form of
+                               * round 4 (16 singular terms, a sub-grid of map samples; measured by its guard, jx_get_truncation): 1 = fp32 spline arrays, every sum in
+                               * fp64 (|delta chi^2/2| ~1e-6); 2 = fp32 arithmetic in stage 1 (packed fp32 FMAs) and stage 2 (fp32 matrix cores), K slices added in fp64:
+                               * |delta chi^2/2| 2e-5 at 512^2, 1e-4 at 1024^2 ABSOLUTE -- inside north_star's relative 1e-6 only because the log-posterior is ~1e4;
+                               * jx_audit measures it on the caller's walkers */
     int32_t calc_integ;       /* SZ_data.calc_integ: integrated-Compton term (joxsz_funcs.py:480-484, joxsz_main.py:65) */
     int32_t reserved1;        /* keeps the doubles 8-byte aligned; must be 0                   */
     double step;              /* arcsec                                   (joxsz_main.py:21)   */
@@ -136,10 +141,11 @@ typedef enum jx_stage {
  * with HIP events on the context's stream. */
 typedef struct jx_timing {
     double prep_ms;       /* priors, mass veto, T profile, X-ray Cash      */
-    double abel_map_ms;   /* Abel integral + spline arrays (contracted route: one matrix product) / profile -> Abel -> spline -> y map (rocFFT sequence) */
-    double beam_fft_ms;   /* contracted route: stage 1, the map samples evaluated and mixed per column (jx_rowmix_kernel); rocFFT: R2C + multiply + C2R */
-    double tf_fft_ms;     /* contracted route: stage 2 / the full form's product on the matrix cores (jx_opgemm_kernel); rocFFT: R2C of the S x S window */
-    double tail_ms;       /* filter + central row + conversion + chi^2     */
+    double abel_map_ms;   /* exact form: ordinate product (Abel transform + Compton-y scale) and row product on the matrix cores (jx_ordrow_kernel); contracted forms:
+                           * Abel integral + spline arrays as one matrix product; rocFFT sequence: profile -> Abel -> spline -> y map */
+    double beam_fft_ms;   /* exact form: 0; contracted forms: stage 1 (jx_rowmix_kernel); rocFFT: R2C + multiply + C2R */
+    double tf_fft_ms;     /* exact form: 0; contracted forms: stage 2 / the full form's product (jx_opgemm_kernel); rocFFT: R2C of the S x S window */
+    double tail_ms;       /* exact form: partial rows added, conversion, data radii, chi^2, total (jx_rowsum_tail_kernel); otherwise filter + central row + conversion + chi^2 */
     double total_ms;      /* first event to last event of each launch      */
     int64_t launches;     /* internal chunks timed                         */
     int64_t walkers;      /* walkers those chunks processed                */
@@ -148,13 +154,42 @@ typedef struct jx_timing {
 
 int  jx_create(const jx_config* cfg, jx_ctx** out);
 int  jx_upload(jx_ctx* ctx, int tensor_id, const void* host, size_t nbytes);
-/* Build the walker-independent tables (Abel weights, spline operators, the operators of the contracted route or the beam
- * spectrum and transfer-function table of the rocFFT sequence) and the work buffers; measure the truncation of the
- * low-rank form (jx_get_truncation).  Must be called once after all uploads and before jx_eval.  Environment variables are
- * read here and nowhere else: JOXSZ_CONV (auto|rocfft|custom), JOXSZ_MIX_FORM (lowrank|full), JOXSZ_LOWRANK_TOL,
- * JOXSZ_TRUNC_PROBE, JOXSZ_TRUNC_BOUND, JOXSZ_CHUNK, JOXSZ_ABEL_GEMM, JOXSZ_PREP_POW, JOXSZ_MAP_SPLIT, JOXSZ_FFT_PAD,
- * JOXSZ_OP_NARROW, JOXSZ_MIX_WPB, JOXSZ_MIX_KSPLIT (tuning). */
+/* Build the walker-independent tables (Abel weights, spline operators, the row operator of the exact form -- or the operators of a
+ * contracted form, or the beam spectrum and transfer-function table of the rocFFT sequence) and the work buffers.  Must be called once
+ * after all uploads and before jx_eval.  The options below are read here and nowhere else (the two SAMPLE_ ones: by jx_sample). */
 int  jx_finalize(jx_ctx* ctx);
+
+/* One switch of the library, per context.  `name` with or without its JOXSZ_ prefix, any case; `value` as text (NULL or "": unset, whatever
+ * the environment says).  The process environment variable of the same name is the DEFAULT of every option, so nothing has to depend on
+ * it.  JX_ERR_INVALID for a name that is not in this table, JX_ERR_STATE after jx_finalize for an option that is read there.
+ *
+ *   name                         values (default)          effect
+ *   JOXSZ_CONV                   auto|rocfft|custom (auto) overrides jx_config.conv_mode
+ *   JOXSZ_MIX_FORM               exact|legacy|lowrank|full (exact)  form of the hand-written route: the exact form, or the contracted forms of rounds 3-4
+ *                                                          (legacy: the cheaper of low-rank and full, as round 4 picked; they carry their own options below)
+ *   JOXSZ_X_PAIRWISE             1|0 (1)                   exact form: 0 = its reference kernels (one block per 16 walkers reads the ordinates back; jx_rowop_tail_kernel)
+ *   JOXSZ_PRUNE_OUTPUTS          1|0 (1)                   0: the row product computes every output of the row, read by the data-radii spline or not
+ *   JOXSZ_CHUNK                  walkers                   overrides jx_config.max_batch
+ *   JOXSZ_FFT_PAD, JOXSZ_MAP_SPLIT, JOXSZ_MAP_PAIR         rocFFT sequence / Abel + map kernel: padded side, row slabs per walker, two walkers per block (1)
+ *   JOXSZ_EVAL_DIRECT            0..3 (3)                  jx_eval: bit 0 the tail stores into the caller-visible host buffer, bit 1 the per-walker kernel reads theta from it
+ *   JOXSZ_PREP_SPLIT             1|0 (1)                   per-walker kernel as two blocks per walker (X-ray side beside the rest); same bits
+ *   JOXSZ_PREP_POW               0|1 (0)                   per-walker kernel: profiles with pow() as written in the reference instead of through their exponents
+ *   JOXSZ_PREP_FASTMATH          1|0 (1)                   per-walker kernel: table-driven exp / log (2 ulp) instead of the device library's
+ *   JOXSZ_OP_NARROW              0|1 (0)                   collapsed route: the small-launch kernel at every launch size
+ *   JOXSZ_SAMPLE_FUSED           1|0 (1)                   jx_sample: proposal and acceptance inside the likelihood's kernels (0: kernels of their own)
+ *   JOXSZ_SAMPLE_VIRTUAL_RANKS   R                         jx_sample without a communicator: R shares of each half step in turn (a test of the share arithmetic)
+ *   -- contracted forms only (JOXSZ_MIX_FORM=legacy|lowrank|full) --
+ *   JOXSZ_LOWRANK_TOL            cut (1e-8 / 1e-13)        singular-value cut of the transfer-function weights, pinned (measured, never tightened)
+ *   JOXSZ_TRUNC_PROBE, JOXSZ_TRUNC_BOUND                   truncation guard: 0 = off; bound on the row estimate (1e-9)
+ *   JOXSZ_MIX_SUBSAMPLE          0 | u0,u1,npts            sub-grid of map samples: 0 = every distinct sample
+ *   JOXSZ_MIX_RANKCAP            0..16 (16)                cap on the rank of the low-rank form
+ *   JOXSZ_AG_SUBSAMPLE           0 | u0,u1,npts            radial sub-grid of the spline-array product: 0 = every radius
+ *   JOXSZ_MIX_MFMA, JOXSZ_MIX_USPLIT, JOXSZ_MIX_WPB, JOXSZ_MIX_KSPLIT, JOXSZ_MIX_KSPLIT_USE, JOXSZ_ABEL_GEMM, JOXSZ_AG_NARROW, JOXSZ_AG_SINGLE,
+ *   JOXSZ_SIDE_STREAM, JOXSZ_SIDE_FORK                     tuning experiments of round 4
+ *   -- diagnostic build only (make ABLATIONS=1; results are wrong or the launch path reads the clock) --
+ *   JOXSZ_DBG, JOXSZ_MIX_DBG, JOXSZ_X_STAMPS, JOXSZ_P_STAMPS
+ */
+int  jx_set_option(jx_ctx* ctx, const char* name, const char* value);
 
 /* theta: [nwalkers, ndim] row-major float64; logp: [nwalkers] float64.
  * The call returns after logp is complete (synchronous on the context's stream). */
@@ -188,8 +223,11 @@ int  jx_set_stream(jx_ctx* ctx, void* hip_stream);
 int  jx_sample(jx_ctx* ctx, const double* theta0_host, int nwalkers, int nsteps, double a, uint64_t seed,
                double* chain_out, double* logp_out, int64_t* naccept_out);
 /* Route of jx_eval / jx_eval_device / jx_sample for the SZ side of the log-posterior.
- *   JX_ROUTE_MAP (default): the reference's own sequence, joxsz_funcs.py:453-472 -- profile, Abel integral, Compton-y
- *       map, beam convolution, transfer function, central row -- every walker, every call.
+ *   JX_ROUTE_MAP (default): per walker, every call: pressure profile (joxsz_funcs.py:453), forward Abel transform and Compton-y scale
+ *       (:457-459), then everything that is linear with constant coefficients behind them -- the mirrored cubic spline, the S x S map, the
+ *       beam convolution, the transfer function, the central row (:460-472) -- as ONE constant operator on the spline ordinates, built
+ *       at jx_finalize from the caller's d_mat, beam image and filter with nothing truncated (the exact form; conv_mode 1 executes the
+ *       same lines literally through rocFFT).
  *   JX_ROUTE_OPERATOR: those steps are linear in the pressure profile with constant coefficients, so the row is
  *       G pp with one constant nrow x N matrix.  Switching to this route builds G once by sending the N unit profiles
  *       through the MAP route's kernels (a few launches); afterwards a walker costs press_fun + one nrow x N
@@ -213,6 +251,15 @@ int  jx_eval_stage(jx_ctx* ctx, const double* theta_host, int nwalkers, int stag
  * the host-side fit object; joxsz_funcs.py:515-516). */
 int  jx_set_par_vals(jx_ctx* ctx, const double* par_vals, int npar);
 
+/* Run-time assurance: the given walkers (host parameter vectors [n][ndim]) through this context's own route AND through the rocFFT sequence
+ * held inside the same context (joxsz_funcs.py:460-467 executed literally, 16 walkers at a time: an independent implementation on the same
+ * inputs), compared where a chain lives.  out = {largest |difference of the SZ log-likelihood| (absolute), largest difference of the extracted
+ * row relative to the row's largest entry, index of the walker with the largest log-likelihood difference (-1: none), walkers compared: those
+ * that gave finite numbers on both sides and are not rejected (prior box, mass veto, r_c > r_s, X-ray model)}.  The exact form reads ~1e-11 / 1e-14; a contracted form or an fp32 variant reads what its approximations cost on
+ * exactly these walkers (joxsz_amd/chain.py::mcmc_run calls it every few hundred steps and warns once).  Costs ~1 ms per 16 walkers.
+ * All zeros with conv_mode 1 (the rocFFT sequence is then the route itself). */
+int  jx_audit(jx_ctx* ctx, const double* theta_host, int n, double out[4]);
+
 /* Device memory helpers so that the host side needs no other GPU runtime. */
 int  jx_dev_alloc(jx_ctx* ctx, size_t nbytes, void** dev_out);
 int  jx_dev_free(jx_ctx* ctx, void* dev);
@@ -226,7 +273,9 @@ int  jx_memcpy_d2h(jx_ctx* ctx, void* host, const void* dev, size_t nbytes);
  *                       (joxsz_amd/dist.py: a file under the launcher's run directory; the C-ABI does not care);
  *   jx_comm_init_rank   every rank, collectively (ncclCommInitRank on the context's device);
  *   jx_allgather_logp   recv_dev[rank * count .. ] <- send_dev[0 .. count) of every rank (float64), asynchronous on the
- *                       context's stream like jx_eval_device; send and receive buffers are device memory;
+ *                       context's stream like jx_eval_device; send and receive buffers are device memory.  In overlap mode the gather
+ *                       runs on the second stream: read recv_dev only behind jx_sync (jx_memcpy_d2h and the caller's own kernels on
+ *                       the compute stream are NOT ordered behind it);
  *   jx_comm_allreduce_max  in-place maximum over the ranks of `count` float64 on the device (timing, barriers);
  *   jx_comm_set_overlap on != 0: the communicator's collectives run on a second stream of the context, each ordered behind
  *                       what the compute stream holds at the moment of the call; the next evaluation does NOT wait for the
@@ -250,8 +299,9 @@ int  jx_comm_destroy(jx_ctx* ctx);
 int  jx_comm_count(jx_ctx* ctx);
 
 int  jx_timing_reset(jx_ctx* ctx);
-int  jx_timing_enable(jx_ctx* ctx, int on);        /* 0 off; 1 an event behind every stage; 2 only the two events around stage 1 of the
-                                                     * contracted route (the time-dominant kernel): beam_fft_ms, launches and walkers are filled */
+int  jx_timing_enable(jx_ctx* ctx, int on);        /* 0 off; 1 an event behind every kernel of the step; 2..4 only the two events around ONE kernel -- exact form:
+                                                     * 2 the ordinate + row product (abel_map_ms), 3 the per-walker kernel (prep_ms), 4 the tail (tail_ms);
+                                                     * contracted forms: 2 = stage 1 (beam_fft_ms); launches and walkers are filled */
 int  jx_timing_get(jx_ctx* ctx, jx_timing* out);   /* synchronises the stream */
 
 /* Introspection: derived sizes chosen by the library. */
@@ -259,8 +309,11 @@ int  jx_get_info(jx_ctx* ctx, int32_t* fft_pad, int32_t* chunk, int32_t* spline_
                  int32_t* nrow, int64_t* device_bytes);
 /* 1 = rocFFT sequence, 2 = contracted route (what `conv_mode` resolved to); <0 on error */
 int  jx_get_conv_mode(jx_ctx* ctx);
-/* What the contracted route looks like on this problem: out = {form, NU, rank, beam_terms, R, RT, nxt, ntile, ksteps, tW,
- * ldx, ksplit}.  form 0 = low-rank: the beam image in `beam_terms` separable terms, the transfer-function weights of the
+/* What the hand-written route looks like on this problem: out = {form, NU, rank, beam_terms, R, RT, nxt, ntile, ksteps, tW,
+ * ldx, ksplit}.  form 2 = exact (default): out[2] = ordinates the row operator reads (the radial grid beyond the map's corner plus the
+ * band of the spline's moment operator does not reach the row: 400 of 500 at 512^2), out[3] = the same in whole tiles of 16, out[6] = output
+ * tiles per group, out[7] = output tiles of the whole row, out[8] = k-steps of the row product, out[10] = outputs the timed launch computes,
+ * out[11] = 8; nothing is truncated or sub-sampled.  form 0 = low-rank: the beam image in `beam_terms` separable terms, the transfer-function weights of the
  * extracted row in `rank` singular terms (cut JOXSZ_LOWRANK_TOL relative to the largest, default 1e-8 at sides >= 400 and
  * 1e-13 below, see jx_get_truncation), R = rank * beam_terms rows kept per map column by stage 1 (kernel instance RT >= R),
  * stage 2 one matrix-core product with K = NU * R in `ksteps` steps of 4; form 1 = full: one operator row per distinct map
@@ -314,7 +367,10 @@ int  jx_get_truncation(jx_ctx* ctx, double out[12]);
  *   2 stage-1 rows [NU][R][tW] (low-rank form): geom = {NU, R, tW, 8}
  *   3 partial rows of the last launch, slice ks of walker w at ks (tW ldx + 272) + w ldx: geom = {ksplit, tW, ldx, 8}
  *   4 stage-1 operator C[u][j] (low-rank form), rows of `cld` doubles: geom = {1, wld, cld, 8}
- *   5 operator of the matrix-core product, Op[(kappa * 16 + (x & 15)) * ntile + (x >> 4)]: geom = {4 ksteps, 16, ntile, 8} */
+ *   5 operator of the matrix-core product, Op[(kappa * 16 + (x & 15)) * ntile + (x >> 4)]: geom = {4 ksteps, 16, ntile, 8}
+ * exact form (the others belong to the contracted forms):
+ *   6 Compton-y ordinates of the last chunk, walker-major y[w][k]: geom = {1, tW, Nkp, 8}
+ *   7 row operator as the matrix cores read it, Opk[(((g nS + s) 4 + e) 64 + lane) nxt + t] = Wy[16 (g nxt + t) + (lane & 15)][16 s + 4 (lane >> 4) + e]: geom = {ng nS 4, 64, nxt, 8} */
 int  jx_debug_workspace(jx_ctx* ctx, int which, void** dev, int32_t geom[4]);
 /* Duration (ms, HIP events on the context's stream, mean of `repeats` launches) of the Abel + map kernel writing the full
  * S x S Compton-y map of `nwalkers` walkers whose parameter vectors are at theta_dev: the kernel BASELINE's metric is worded

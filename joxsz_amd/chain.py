@@ -66,8 +66,33 @@ class _Runner:
         return chain, lp, self.host.naccepted - before
 
 
+class JoxszAuditWarning(UserWarning):
+    """The live walkers of a chain, sent through the rocFFT sequence as well (``jx_audit``), differ from the route in use by more than the bound."""
+
+
+def audit_walkers(post, walkers, bound=1e-6, nmax=64, log=None):
+    """Run-time assurance where the chain lives: up to ``nmax`` of the given walkers through the context's own route
+    and through the rocFFT sequence held inside it (``HipContext.audit``).  Warns (once per call) when the SZ log-likelihood differs by
+    more than ``bound`` ABSOLUTE on any of them; returns the audit's figures, or None for a posterior without a device context."""
+    ctx = getattr(post, 'ctx', None)
+    if ctx is None or not hasattr(ctx, 'audit'):
+        return None
+    w = np.asarray(walkers, dtype=np.float64)
+    if len(w) > nmax:
+        w = w[np.linspace(0, len(w) - 1, nmax).astype(int)]
+    res = ctx.audit(w)
+    if log is not None:
+        log('audit of %d live walkers: |delta SZ log-likelihood| <= %.2e, row <= %.2e of its maximum' % (res['walkers_compared'], res['max_abs_sz_loglike_diff'], res['max_rel_row_diff']))
+    if res['max_abs_sz_loglike_diff'] > bound:
+        import warnings
+        warnings.warn('the SZ log-likelihood of walker %d differs by %.2e from the rocFFT sequence (bound %.0e): the route in use approximates more than '
+                      'this chain can take (a contracted form or an fp32 variant? the default exact f64 context reads ~1e-11)'
+                      % (res['worst_walker'], res['max_abs_sz_loglike_diff'], bound), JoxszAuditWarning, stacklevel=2)
+    return res
+
+
 def mcmc_run(post, nwalkers, nburn, nsteps, nthin=1, initspread=0.1, a=2.0, seed=0, prelim_iters=1000, max_prelim=20,
-             device=None, theta0=None, log=None):
+             device=None, theta0=None, log=None, audit_every=500, audit_bound=1e-6):
     """joxsz_funcs.py:572-635 with the whole ensemble advanced on the device.
 
     1. start ball around the current parameters (``_generateInitPars``, joxsz_funcs.py:548-570);
@@ -77,8 +102,10 @@ def mcmc_run(post, nwalkers, nburn, nsteps, nthin=1, initspread=0.1, a=2.0, seed
        (joxsz_funcs.py:618-624).
 
     ``post`` is a ``JoxszPosterior`` (device sampler) or any batched callable theta[W, ndim] -> logp[W] (host
-    sampler; ``theta0`` is then required).  Returns dict(chain [nsteps//nthin, W, ndim], log_prob, accepted [W],
-    acceptance_fraction, burn_best, prelim_blocks)."""
+    sampler; ``theta0`` is then required).  With a device context the live walkers are AUDITED -- sent through the rocFFT sequence as well,
+    ``audit_walkers`` -- behind the burn-in and then every ``audit_every`` kept steps (0: never; the sampling then runs in blocks of that
+    many steps, the chain is the same walker-for-walker only for one block: each block draws from its own counter stream).  Returns
+    dict(chain [nsteps//nthin, W, ndim], log_prob, accepted [W], acceptance_fraction, burn_best, prelim_blocks, audits)."""
     log = (lambda *_: None) if log is None else log
     device = hasattr(post, 'sample') if device is None else device
     log_prob = getattr(post, 'log_prob', post)
@@ -101,11 +128,29 @@ def mcmc_run(post, nwalkers, nburn, nsteps, nthin=1, initspread=0.1, a=2.0, seed
         log('Burn-in period')
         chain, lp, _ = run.sample(p0, nburn)
         p0 = chain[-1]
+    audits = []
+    do_audit = bool(audit_every) and device and hasattr(getattr(post, 'ctx', None), 'audit')
+    if do_audit:
+        audits.append(audit_walkers(post, p0, audit_bound, log=log))
     log('Starting sampling')
-    chain, lp, acc = run.sample(p0, nsteps)
+    if do_audit and nsteps > audit_every:
+        parts, lps, acc = [], [], 0
+        done = 0
+        while done < nsteps:
+            n = min(audit_every, nsteps - done)
+            c_, l_, a_ = run.sample(p0, n)
+            parts.append(c_); lps.append(l_); acc = acc + np.asarray(a_, np.float64)
+            p0 = c_[-1]
+            done += n
+            audits.append(audit_walkers(post, p0, audit_bound, log=log))
+        chain, lp = np.concatenate(parts), np.concatenate(lps)
+    else:
+        chain, lp, acc = run.sample(p0, nsteps)
+        if do_audit:
+            audits.append(audit_walkers(post, chain[-1], audit_bound, log=log))
     keep = slice(nthin - 1, None, nthin)
     out = dict(chain=chain[keep], log_prob=lp[keep], accepted=np.asarray(acc, np.float64),
-               acceptance_fraction=float(np.mean(acc) / max(nsteps, 1)), burn_best=max(bestprob, newlike), prelim_blocks=blocks)
+               acceptance_fraction=float(np.mean(acc) / max(nsteps, 1)), burn_best=max(bestprob, newlike), prelim_blocks=blocks, audits=audits)
     log('Finished sampling')
     log('Acceptance fraction: %s' % out['acceptance_fraction'])
     return out

@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cctype>
 #include <map>
 #include <string>
 #include <vector>
@@ -94,6 +95,8 @@ struct jx_ctx {
     std::string devname;
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr;  // created by jx_create; `stream` may point at a caller's stream instead (jx_set_stream)
+
+    std::map<std::string, std::string> opts;   // jx_set_option (the process environment is the default of every name)
 
     // host copies of the uploaded tensors
     std::vector<std::vector<unsigned char>> host;
@@ -206,6 +209,12 @@ struct jx_ctx {
 
 static int g_rocfft_refs = 0;
 
+static const char* opt_str(const jx_ctx* ctx, const char* name) {
+    if (ctx) { const auto it = ctx->opts.find(name); if (it != ctx->opts.end()) return it->second.empty() ? nullptr : it->second.c_str(); }
+    const char* e = getenv(name);
+    return (e && e[0]) ? e : nullptr;
+}
+
 #define HIPCHK(ctx, call)                                                                          \
     do {                                                                                           \
         hipError_t e_ = (call);                                                                    \
@@ -283,7 +292,19 @@ static std::vector<T> host_vec(jx_ctx* ctx, int id) {
     return v;
 }
 
-static const char* env_str(const char* name) { const char* e = getenv(name); return (e && e[0]) ? e : nullptr; }
+// Every switch of the library: set per context with jx_set_option (before jx_finalize for those it reads, which is all but the two
+// SAMPLE_ ones), with the process environment as the default of each.  The list is the one include/joxsz_hip.h documents
+// (tests/test_abi.py holds the two and the uses in this file together).
+static const char* const kOptions[] = {
+    "JOXSZ_CONV", "JOXSZ_MIX_FORM", "JOXSZ_X_PAIRWISE", "JOXSZ_PRUNE_OUTPUTS", "JOXSZ_CHUNK", "JOXSZ_FFT_PAD", "JOXSZ_MAP_SPLIT", "JOXSZ_MAP_PAIR",
+    "JOXSZ_EVAL_DIRECT", "JOXSZ_PREP_SPLIT", "JOXSZ_PREP_POW", "JOXSZ_PREP_FASTMATH", "JOXSZ_OP_NARROW", "JOXSZ_SAMPLE_FUSED", "JOXSZ_SAMPLE_VIRTUAL_RANKS",
+    // the contracted forms of rounds 3-4 (JOXSZ_MIX_FORM=legacy|lowrank|full)
+    "JOXSZ_LOWRANK_TOL", "JOXSZ_TRUNC_PROBE", "JOXSZ_TRUNC_BOUND", "JOXSZ_MIX_SUBSAMPLE", "JOXSZ_MIX_RANKCAP", "JOXSZ_MIX_MFMA", "JOXSZ_MIX_USPLIT", "JOXSZ_MIX_WPB",
+    "JOXSZ_MIX_KSPLIT", "JOXSZ_MIX_KSPLIT_USE", "JOXSZ_ABEL_GEMM", "JOXSZ_AG_NARROW", "JOXSZ_AG_SINGLE", "JOXSZ_AG_SUBSAMPLE", "JOXSZ_SIDE_STREAM", "JOXSZ_SIDE_FORK",
+    // diagnostic build only (make ABLATIONS=1): timing experiments, results are wrong
+    "JOXSZ_DBG", "JOXSZ_MIX_DBG", "JOXSZ_X_STAMPS", "JOXSZ_P_STAMPS",
+};
+static const char* opt_str(const jx_ctx* ctx, const char* name);
 
 // librccl, loaded on first use (dlopen): the functions of the all-gather path only
 namespace {
@@ -1223,55 +1244,55 @@ static int finalize_impl(jx_ctx* ctx) {
 
     // ---- environment, read here and nowhere else
     int want = c.conv_mode;
-    if (const char* e = env_str("JOXSZ_CONV")) {
+    if (const char* e = opt_str(ctx, "JOXSZ_CONV")) {
         if (!strcmp(e, "rocfft")) want = 1; else if (!strcmp(e, "custom") || !strcmp(e, "mix")) want = 2; else if (!strcmp(e, "auto")) want = 0;
     }
     if (want < 0 || want > 2) { ctx->err = "conv_mode must be 0, 1 or 2"; return JX_ERR_INVALID; }
     double lr_tol0 = (S < 400) ? 1e-13 : JX_LR_TOL_DEFAULT;
     // (singular-value cut of the transfer-function weights: small maps -- a beam image comparable with the map, the
     //  log-posterior a small difference of large terms -- keep every term above rounding, where it costs next to nothing)
-    if (const char* e = env_str("JOXSZ_LOWRANK_TOL")) { const double v2 = atof(e); if (v2 > 0.0 && v2 < 1e-6) { lr_tol0 = v2; ctx->tol_pinned = true; } }
-    if (const char* e = env_str("JOXSZ_TRUNC_BOUND")) { const double v = atof(e); if (v > 0.0) { ctx->trunc_bound = v; ctx->trunc_bound_ll = std::min(ctx->trunc_bound_ll, 10.0 * v); } }
-    if (const char* e = env_str("JOXSZ_MIX_FORM")) {
+    if (const char* e = opt_str(ctx, "JOXSZ_LOWRANK_TOL")) { const double v2 = atof(e); if (v2 > 0.0 && v2 < 1e-6) { lr_tol0 = v2; ctx->tol_pinned = true; } }
+    if (const char* e = opt_str(ctx, "JOXSZ_TRUNC_BOUND")) { const double v = atof(e); if (v > 0.0) { ctx->trunc_bound = v; ctx->trunc_bound_ll = std::min(ctx->trunc_bound_ll, 10.0 * v); } }
+    if (const char* e = opt_str(ctx, "JOXSZ_MIX_FORM")) {
         if (!strcmp(e, "lowrank")) ctx->form_force = 0; else if (!strcmp(e, "full")) ctx->form_force = 1;
         else if (!strcmp(e, "legacy")) ctx->form_force = -1; else if (!strcmp(e, "exact")) ctx->form_force = 2;
     }
-    if (const char* e = env_str("JOXSZ_MAP_PAIR")) ctx->map_pair = atoi(e) != 0;
-    if (const char* e = env_str("JOXSZ_MIX_USPLIT")) { const int v = atoi(e); if (v >= 1 && v <= 4) { ctx->usplit = v; ctx->usplit_forced = true; } }
-    if (const char* e = env_str("JOXSZ_MIX_SUBSAMPLE")) {
+    if (const char* e = opt_str(ctx, "JOXSZ_MAP_PAIR")) ctx->map_pair = atoi(e) != 0;
+    if (const char* e = opt_str(ctx, "JOXSZ_MIX_USPLIT")) { const int v = atoi(e); if (v >= 1 && v <= 4) { ctx->usplit = v; ctx->usplit_forced = true; } }
+    if (const char* e = opt_str(ctx, "JOXSZ_MIX_SUBSAMPLE")) {
         // 0: every distinct sample; "u0,u1,npts": full resolution below u0 pixels from the axis, every second row up to u1, every fourth up to 2 u1, every eighth beyond
         int a0 = 0, a1 = 0, a2 = 0;
         const int got = sscanf(e, "%d,%d,%d", &a0, &a1, &a2);
         if (got == 1 && a0 == 0) ctx->subsample = false;
         else if (got == 3 && a0 >= 8 && a1 >= a0 && a2 >= 4 && a2 <= 16) { ctx->sub_u0 = a0; ctx->sub_u1 = a1; ctx->sub_npts = a2; }
     }
-    if (const char* e = env_str("JOXSZ_EVAL_DIRECT")) { const int v = atoi(e); if (v >= 0 && v <= 3) ctx->eval_direct = v; }
-    if (const char* e = env_str("JOXSZ_MIX_RANKCAP")) { const int v = atoi(e); if (v >= 0 && v <= 16) ctx->rank_cap = v; }
-    if (const char* e = env_str("JOXSZ_MIX_MFMA")) ctx->mix_mfma = atoi(e) != 0;
-    if (const char* e = env_str("JOXSZ_MIX_WPB")) { const int v = atoi(e); if (v >= 1 && v <= 16) { ctx->mix.wpb_force = v; ctx->mix.wpb = std::min(v, 4); } }
-    if (const char* e = env_str("JOXSZ_MIX_KSPLIT")) { const int v = atoi(e); if (v >= 1) ctx->mix.ksplit_force = v; }
-    if (const char* e = env_str("JOXSZ_MIX_KSPLIT_USE")) { const int v = atoi(e); if (v >= 1) ctx->mix.ksplit_u_force = v; }
-    if (const char* e = env_str("JOXSZ_ABEL_GEMM")) ctx->abel_gemm = atoi(e) != 0;
-    if (const char* e = env_str("JOXSZ_AG_NARROW")) ctx->ag_narrow = atoi(e) != 0;
-    if (const char* e = env_str("JOXSZ_AG_SINGLE")) ctx->ag_single = atoi(e) != 0;
-    if (const char* e = env_str("JOXSZ_X_PAIRWISE")) ctx->mix.x_pairwise = atoi(e) != 0;
-    if (const char* e = env_str("JOXSZ_PREP_SPLIT")) ctx->prep_split = atoi(e) != 0;
-    if (const char* e = env_str("JOXSZ_AG_SUBSAMPLE")) {
+    if (const char* e = opt_str(ctx, "JOXSZ_EVAL_DIRECT")) { const int v = atoi(e); if (v >= 0 && v <= 3) ctx->eval_direct = v; }
+    if (const char* e = opt_str(ctx, "JOXSZ_MIX_RANKCAP")) { const int v = atoi(e); if (v >= 0 && v <= 16) ctx->rank_cap = v; }
+    if (const char* e = opt_str(ctx, "JOXSZ_MIX_MFMA")) ctx->mix_mfma = atoi(e) != 0;
+    if (const char* e = opt_str(ctx, "JOXSZ_MIX_WPB")) { const int v = atoi(e); if (v >= 1 && v <= 16) { ctx->mix.wpb_force = v; ctx->mix.wpb = std::min(v, 4); } }
+    if (const char* e = opt_str(ctx, "JOXSZ_MIX_KSPLIT")) { const int v = atoi(e); if (v >= 1) ctx->mix.ksplit_force = v; }
+    if (const char* e = opt_str(ctx, "JOXSZ_MIX_KSPLIT_USE")) { const int v = atoi(e); if (v >= 1) ctx->mix.ksplit_u_force = v; }
+    if (const char* e = opt_str(ctx, "JOXSZ_ABEL_GEMM")) ctx->abel_gemm = atoi(e) != 0;
+    if (const char* e = opt_str(ctx, "JOXSZ_AG_NARROW")) ctx->ag_narrow = atoi(e) != 0;
+    if (const char* e = opt_str(ctx, "JOXSZ_AG_SINGLE")) ctx->ag_single = atoi(e) != 0;
+    if (const char* e = opt_str(ctx, "JOXSZ_X_PAIRWISE")) ctx->mix.x_pairwise = atoi(e) != 0;
+    if (const char* e = opt_str(ctx, "JOXSZ_PREP_SPLIT")) ctx->prep_split = atoi(e) != 0;
+    if (const char* e = opt_str(ctx, "JOXSZ_AG_SUBSAMPLE")) {
         int a0 = 0, a1 = 0, a2 = 0;
         const int got = sscanf(e, "%d,%d,%d", &a0, &a1, &a2);
         if (got == 1 && a0 == 0) ctx->ag_sub = false;
         else if (got == 3 && a0 >= 8 && a1 >= a0 && a2 >= 4 && a2 <= 24) { ctx->ag_u0 = a0; ctx->ag_u1 = a1; ctx->ag_npts = a2; }
     }
-    if (const char* e = env_str("JOXSZ_PREP_FASTMATH")) ctx->prep_fastmath = atoi(e) != 0;
-    ctx->op_narrow = env_str("JOXSZ_OP_NARROW") != nullptr;
-    if (const char* e = env_str("JOXSZ_SIDE_STREAM")) ctx->side_on = atoi(e) != 0;
-    if (const char* e = env_str("JOXSZ_SIDE_FORK")) ctx->side_fork = atoi(e) != 0;
+    if (const char* e = opt_str(ctx, "JOXSZ_PREP_FASTMATH")) ctx->prep_fastmath = atoi(e) != 0;
+    ctx->op_narrow = opt_str(ctx, "JOXSZ_OP_NARROW") != nullptr;
+    if (const char* e = opt_str(ctx, "JOXSZ_SIDE_STREAM")) ctx->side_on = atoi(e) != 0;
+    if (const char* e = opt_str(ctx, "JOXSZ_SIDE_FORK")) ctx->side_fork = atoi(e) != 0;
     ctx->f32 = c.dtype >= 1;
     ctx->f32c = c.dtype == 2;
     if (ctx->f32 && !ctx->abel_gemm) { ctx->err = "dtype f32 takes its spline arrays from the matrix product only (JOXSZ_ABEL_GEMM=0 is an f64 setting)"; return JX_ERR_UNSUPPORTED; }
 
     int chunk = c.max_batch > 0 ? c.max_batch : 1024;
-    if (const char* e = env_str("JOXSZ_CHUNK")) { int v = atoi(e); if (v > 0) chunk = v; }
+    if (const char* e = opt_str(ctx, "JOXSZ_CHUNK")) { int v = atoi(e); if (v > 0) chunk = v; }
 
     JxDev& d = ctx->d;
     memset(&d, 0, sizeof(d));
@@ -1280,12 +1301,12 @@ static int finalize_impl(jx_ctx* ctx) {
     d.npar = c.npar; d.ndim = c.ndim; d.ne_mode = c.ne_mode; d.exclude_unphy_mass = c.exclude_unphy_mass;
     d.sz_only = c.sz_only;
 #ifdef JOXSZ_ABLATIONS
-    if (const char* e = env_str("JOXSZ_DBG")) d.dbg = atoi(e);      // diagnostic build only: timing experiments, results are wrong
-    if (const char* e = env_str("JOXSZ_MIX_DBG")) ctx->mix.dbg = atoi(e);
+    if (const char* e = opt_str(ctx, "JOXSZ_DBG")) d.dbg = atoi(e);      // diagnostic build only: timing experiments, results are wrong
+    if (const char* e = opt_str(ctx, "JOXSZ_MIX_DBG")) ctx->mix.dbg = atoi(e);
 #endif
     d.y_scale = c.kpc_cm * c.sigma_T / c.m_e;
     d.inv_h_mean = (double)(N - 1) / (r[N - 1] - r[0]);
-    d.prep_pow = env_str("JOXSZ_PREP_POW") && atoi(env_str("JOXSZ_PREP_POW")) ? 1 : 0;
+    d.prep_pow = opt_str(ctx, "JOXSZ_PREP_POW") && atoi(opt_str(ctx, "JOXSZ_PREP_POW")) ? 1 : 0;
     if (!c.sz_only) {
         const std::vector<double> lt = host_vec<double>(ctx, JX_T_LNT);
         for (int i = 1; i < c.ntab; ++i)
@@ -1307,7 +1328,7 @@ static int finalize_impl(jx_ctx* ctx) {
         h_flux = host_vec<double>(ctx, JX_T_FLUX_DATA);
         std::vector<double> q(h_flux.begin(), h_flux.begin() + c.nflux);
         if (!jxt::nak_eval_matrix(xk, q, h_E)) { ctx->err = "profile spline: singular system"; return JX_ERR_INVALID; }
-        if (const char* e = env_str("JOXSZ_PRUNE_OUTPUTS")) ctx->prune = atoi(e) != 0;
+        if (const char* e = opt_str(ctx, "JOXSZ_PRUNE_OUTPUTS")) ctx->prune = atoi(e) != 0;
         double emax = 0.0;
         for (double v : h_E) if (std::isfinite(v)) emax = std::max(emax, std::fabs(v));
         int kuse = 0;
@@ -1351,7 +1372,7 @@ static int finalize_impl(jx_ctx* ctx) {
         return JX_ERR_UNSUPPORTED;
     }
     int P = c.fft_pad > 0 ? c.fft_pad : jxt::next_smooth_even(S + o);
-    if (const char* e = env_str("JOXSZ_FFT_PAD")) { int v = atoi(e); if (v > 0 && ctx->conv_mode == 1) P = v; }
+    if (const char* e = opt_str(ctx, "JOXSZ_FFT_PAD")) { int v = atoi(e); if (v > 0 && ctx->conv_mode == 1) P = v; }
     if (P < S + o) { ctx->err = "fft_pad smaller than S + (B-1)/2"; return JX_ERR_INVALID; }
     d.P = P; d.Ph = P / 2 + 1;
 
@@ -1478,7 +1499,7 @@ static int finalize_impl(jx_ctx* ctx) {
         }
     }
     int split = c.map_split > 0 ? c.map_split : 1;
-    if (const char* e = env_str("JOXSZ_MAP_SPLIT")) { int v = atoi(e); if (v > 0) split = v; }
+    if (const char* e = opt_str(ctx, "JOXSZ_MAP_SPLIT")) { int v = atoi(e); if (v > 0) split = v; }
     d.map_split = std::min(split, S);
 
     // ---- chunk capacity: the work buffers of a launch stay under 24 GB
@@ -1488,7 +1509,7 @@ static int finalize_impl(jx_ctx* ctx) {
         d.quad = 1;
         d.img_ld = (d.q_na + 16) & ~15; d.img_ws = (long long)d.q_nb * d.img_ld;          // rows start on cache lines, >= 1 spare column
         const size_t per_walker = sizeof(double) * ((size_t)mixb.krows + (size_t)(JX_MIX_KSPLIT_MAX + 1) * 16 * mixb.ntile + 8 * (size_t)N + 64);
-        if (c.max_batch <= 0 && !env_str("JOXSZ_CHUNK")) while (chunk > 128 && per_walker * chunk > budget) chunk /= 2;
+        if (c.max_batch <= 0 && !opt_str(ctx, "JOXSZ_CHUNK")) while (chunk > 128 && per_walker * chunk > budget) chunk /= 2;
     } else {
         d.quad = 0; d.img_ld = P; d.img_ws = (long long)P * P;
         const size_t per_walker = sizeof(double) * ((size_t)P * P * 2 + (size_t)P * d.Ph * 2 + (size_t)S * ctx->Sh * 2);
@@ -1703,7 +1724,7 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
     // two blocks per walker in the per-walker kernel (the X-ray side beside the rest): the timed sequence of the contracted route only
     // (up to ~640 radii: beyond, the grid pass on half the threads is the longer of the two chains by more than the split saves --
     //  measured at N = 1000: 32.5 -> 34.7 us; at N = 500: 27.6 -> 23.4, at N = 313: 26.8 -> 22.3)
-    const bool xr_split = mix && ctx->prep_split && !any_tap && !side && !d.sz_only && !d.prep_pow && 3 * d.nann <= 128 && d.nband * d.nann <= 4096 && d.N <= 640;
+    const bool xr_split = mix && ctx->prep_split && !any_tap && !side && !d.sz_only && !d.prep_pow && !d.calc_integ /* (its sums are grouped by the block's size) */ && 3 * d.nann <= 128 && d.nband * d.nann <= 4096 && d.N <= 640;
     auto launch_prep = [&](hipStream_t ps, double* pp_buf) {
         JxDev dp = d;
         dp.inject_pp = ctx->d.inject_pp;
@@ -1711,7 +1732,7 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
         dp.xr_out = ctx->d_xr;
         dp.pp_ld = (exact && pp_buf == ctx->d_ppc) ? ctx->mix.x_ldpp : 0;
 #ifdef JOXSZ_ABLATIONS
-        if (env_str("JOXSZ_P_STAMPS")) {                        // (diagnostic build only)
+        if (opt_str(ctx, "JOXSZ_P_STAMPS")) {                        // (diagnostic build only)
             static long long* stamps = nullptr;
             if (!stamps) { (void)hipMalloc((void**)&stamps, sizeof(long long) * 8 * 65536); (void)hipMemset(stamps, 0, sizeof(long long) * 8 * 65536); }
             dp.stamps = stamps;
@@ -1818,7 +1839,7 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
             ro.ldpp = m.x_ldpp; ro.nSj = m.x_nSj; ro.npair = m.x_npair;
 #ifdef JOXSZ_ABLATIONS
             ro.dbg = m.dbg;
-            if (env_str("JOXSZ_X_STAMPS")) {                    // (diagnostic build only: the environment is read on the launch path here)
+            if (opt_str(ctx, "JOXSZ_X_STAMPS")) {                    // (diagnostic build only: the environment is read on the launch path here)
                 static long long* stamps = nullptr;
                 if (!stamps) { HIPCHK(ctx, hipMalloc((void**)&stamps, sizeof(long long) * 8 * 65536)); }
                 ro.stamps = stamps;
@@ -2121,7 +2142,7 @@ extern "C" {
 int jx_finalize(jx_ctx* ctx) {
     int rc = finalize_impl(ctx);
     if (rc) return rc;
-    if (const char* e = env_str("JOXSZ_TRUNC_PROBE")) { if (atoi(e) == 0) return JX_OK; }
+    if (const char* e = opt_str(ctx, "JOXSZ_TRUNC_PROBE")) { if (atoi(e) == 0) return JX_OK; }
     if (ctx->conv_mode != 2 || ctx->mix.form == 2 || (ctx->mix.form != 0 && ctx->mix.sub.empty() && !ctx->ag_sub_on)) return JX_OK;
     // The low-rank form drops the small singular values of the transfer-function weights.  What that costs is measured on the
     // caller's own beam / transfer function / prior box (measure_truncation); beyond the bounds the tables are rebuilt with
@@ -2246,11 +2267,11 @@ int jx_sample(jx_ctx* ctx, const double* theta0, int nwalkers, int nsteps, doubl
         for (double v : l0) if (!std::isfinite(v)) { ctx->err = "initial positions must have finite log-posterior"; return JX_ERR_INVALID; }
     }
     const dim3 grid((half + 255) / 256), block(256);
-    const bool fused = ctx->conv_mode == 2 && ctx->route != JX_ROUTE_OPERATOR && !ctx->side_stream && !(env_str("JOXSZ_SAMPLE_FUSED") && atoi(env_str("JOXSZ_SAMPLE_FUSED")) == 0);
+    const bool fused = ctx->conv_mode == 2 && ctx->route != JX_ROUTE_OPERATOR && !ctx->side_stream && !(opt_str(ctx, "JOXSZ_SAMPLE_FUSED") && atoi(opt_str(ctx, "JOXSZ_SAMPLE_FUSED")) == 0);
     // shares of a half step: one per rank of the communicator, or JOXSZ_SAMPLE_VIRTUAL_RANKS of them run in turn by this process
     const bool dist = ctx->comm != nullptr;                                  // (a communicator of one rank runs the same collectives: in place, on its own share = everything)
     int nshare = dist ? ctx->comm_size : 1;
-    if (!dist) if (const char* e = env_str("JOXSZ_SAMPLE_VIRTUAL_RANKS")) nshare = std::max(1, atoi(e));
+    if (!dist) if (const char* e = opt_str(ctx, "JOXSZ_SAMPLE_VIRTUAL_RANKS")) nshare = std::max(1, atoi(e));
     if (nshare > 1 && (!fused || half % nshare)) { ctx->err = "jx_sample over " + std::to_string(nshare) + " ranks: the contracted route and a half ensemble divisible by the ranks"; return JX_ERR_INVALID; }
     const int r_first = dist ? ctx->comm_rank : 0, r_last = dist ? ctx->comm_rank + 1 : nshare;
     for (int it = 0; it < nsteps; ++it) {
@@ -2485,6 +2506,74 @@ int jx_eval_stage(jx_ctx* ctx, const double* theta, int nwalkers, int stage, dou
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
     return JX_OK;
+}
+
+int jx_set_option(jx_ctx* ctx, const char* name, const char* value) {
+    if (!ctx || !name) return JX_ERR_INVALID;
+    std::string key = name;
+    for (char& ch : key) ch = (char)toupper((unsigned char)ch);
+    if (key.rfind("JOXSZ_", 0) != 0) key = "JOXSZ_" + key;
+    bool known = false;
+    for (const char* k : kOptions) if (key == k) known = true;
+    if (!known) { ctx->err = "jx_set_option: unknown option " + key; return JX_ERR_INVALID; }
+    const bool at_call = key == "JOXSZ_SAMPLE_FUSED" || key == "JOXSZ_SAMPLE_VIRTUAL_RANKS";
+    if (ctx->finalized && !at_call) { ctx->err = "jx_set_option(" + key + ") after jx_finalize: read there and nowhere else"; return JX_ERR_STATE; }
+    ctx->opts[key] = value ? value : "";                         // (an empty value: the option unset, whatever the environment says)
+    return JX_OK;
+}
+
+// Run-time assurance: the given walkers through the context's own route (as jx_eval runs it) AND through the rocFFT sequence held inside
+// the same context (joxsz_funcs.py:460-467 executed literally, 16 walkers at a time: an independent implementation, not the same tables).
+int jx_audit(jx_ctx* ctx, const double* theta, int n, double out[4]) {
+    if (!ctx || !theta || n < 1 || !out) return JX_ERR_INVALID;
+    if (!ctx->finalized) { ctx->err = "jx_audit before jx_finalize"; return JX_ERR_STATE; }
+    out[0] = out[1] = 0.0; out[2] = -1.0; out[3] = 0.0;
+    if (ctx->conv_mode != 2) return JX_OK;                       // (the rocFFT sequence IS this context's route: nothing to compare)
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    int rc;
+    if ((rc = ensure_taps(ctx))) return rc;
+    if ((rc = ensure_ref(ctx))) return rc;
+    const int cap = ctx->fft.cap, nrow = ctx->nrow, ndim = ctx->cfg.ndim;
+    if ((rc = ensure_batch(ctx, cap))) return rc;
+    std::vector<double> ra((size_t)cap * nrow), rb((size_t)cap * nrow), la((size_t)cap * 4), lb((size_t)cap * 4);
+    const bool tm = ctx->timing_on;
+    const int route = ctx->route;
+    ctx->timing_on = false;
+    ctx->route = JX_ROUTE_MAP;                                   // (the taps exist on this route; the collapsed route is built from it)
+    Taps t = all_taps(ctx, false);
+    auto fetch = [&](std::vector<double>& rows, std::vector<double>& parts, int m) {
+        if (hipMemcpyAsync(rows.data(), ctx->t_row, sizeof(double) * (size_t)m * nrow, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return (int)JX_ERR_HIP;
+        if (hipMemcpyAsync(parts.data(), ctx->t_parts, sizeof(double) * (size_t)m * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return (int)JX_ERR_HIP;
+        return (hipStreamSynchronize(ctx->stream) == hipSuccess) ? (int)JX_OK : (int)JX_ERR_HIP;
+    };
+    rc = JX_OK;
+    for (int w0 = 0; w0 < n && !rc; w0 += cap) {
+        const int m = std::min(cap, n - w0);
+        if (hipMemcpyAsync(ctx->d_theta, theta + (size_t)w0 * ndim, sizeof(double) * (size_t)m * ndim, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { rc = JX_ERR_HIP; break; }
+        rc = run_chunk(ctx, ctx->d_theta, ctx->d_logp, 0, m, t);
+        if (!rc) rc = fetch(ra, la, m);
+        if (!rc) rc = run_chunk(ctx, ctx->d_theta, ctx->d_logp, 0, m, t, true);
+        if (!rc) rc = fetch(rb, lb, m);
+        if (rc) break;
+        for (int p = 0; p < m; ++p) {
+            double mx = 0.0, df = 0.0;
+            bool fin = true;
+            for (int k = 0; k < nrow; ++k) {
+                const double a = ra[(size_t)p * nrow + k], b = rb[(size_t)p * nrow + k];
+                if (!std::isfinite(a) || !std::isfinite(b)) { fin = false; break; }
+                mx = std::max(mx, std::fabs(b)); df = std::max(df, std::fabs(a - b));
+            }
+            const double sa = la[(size_t)p * 4 + 1], sb = lb[(size_t)p * 4 + 1];     // SZ log-likelihood (-chi^2/2 [+ integrated-Compton term])
+            if (!fin || !(mx > 0.0) || !std::isfinite(sa) || !std::isfinite(sb)) continue;
+            if (la[(size_t)p * 4 + 3] != 0.0) continue;               // (a rejected walker -- outside the prior box, vetoed -- is no place a chain lives)
+            out[3] += 1.0;
+            out[1] = std::max(out[1], df / mx);
+            if (std::fabs(sa - sb) >= out[0]) { out[0] = std::fabs(sa - sb); out[2] = (double)(w0 + p); }
+        }
+    }
+    ctx->timing_on = tm;
+    ctx->route = route;
+    return rc;
 }
 
 int jx_set_par_vals(jx_ctx* ctx, const double* v, int npar) {

@@ -10,12 +10,12 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('JOXSZ_LIB') or os.path.join(_HERE, 'csrc', 'libjoxsz_hip.so')    # JOXSZ_LIB: A/B builds
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # must list every function include/joxsz_hip.h declares (tests/test_abi.py checks this)
 EXPORTS = (
     'jx_create', 'jx_upload', 'jx_finalize', 'jx_eval', 'jx_eval_device', 'jx_sync', 'jx_set_stream', 'jx_sample', 'jx_eval_stage',
-    'jx_set_route', 'jx_get_route', 'jx_get_operator',
+    'jx_set_route', 'jx_get_route', 'jx_get_operator', 'jx_set_option', 'jx_audit',
     'jx_set_par_vals', 'jx_dev_alloc', 'jx_dev_free', 'jx_memcpy_h2d', 'jx_memcpy_d2h',
     'jx_timing_reset', 'jx_timing_enable', 'jx_timing_get', 'jx_get_info', 'jx_get_conv_mode', 'jx_get_conv_layout', 'jx_debug_workspace', 'jx_device_count',
     'jx_device_name', 'jx_strerror', 'jx_last_error', 'jx_destroy',
@@ -83,6 +83,8 @@ def load_library(path=None):
     lib.jx_sample.argtypes = [vp, dp, ci, ci, ctypes.c_double, ctypes.c_uint64, dp, dp, ctypes.POINTER(ctypes.c_int64)]
     lib.jx_eval_stage.argtypes = [vp, dp, ci, ci, dp, cs]
     lib.jx_set_par_vals.argtypes = [vp, dp, ci]
+    lib.jx_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_char_p]
+    lib.jx_audit.argtypes = [vp, dp, ci, dp]
     lib.jx_dev_alloc.argtypes = [vp, cs, ctypes.POINTER(vp)]
     lib.jx_dev_free.argtypes = [vp, vp]
     lib.jx_memcpy_h2d.argtypes = [vp, vp, vp, cs]
@@ -162,7 +164,7 @@ def config_from_problem(pb, device=0, max_batch=0, fft_pad=0, map_split=0, conv=
 class HipContext:
     """Thin owner of one ``jx_ctx``: uploads a ``Problem`` and evaluates batches."""
 
-    def __init__(self, pb, device=0, max_batch=0, fft_pad=0, map_split=0, conv='auto', lib_path=None, route=None, dtype='f64'):
+    def __init__(self, pb, device=0, max_batch=0, fft_pad=0, map_split=0, conv='auto', lib_path=None, route=None, dtype='f64', options=None):
         self._h = ctypes.c_void_p()
         self.lib = load_library(lib_path)
         pb.validate()
@@ -175,6 +177,10 @@ class HipContext:
             self._h = ctypes.c_void_p()
             raise JoxszHipError('jx_create: %s' % self.lib.jx_strerror(rc).decode())
         try:
+            # switches of the library for THIS context (jx_set_option; names with or without their JOXSZ_ prefix): the process environment
+            # is only the default of each
+            for k, v in (options or {}).items():
+                self._chk(self.lib.jx_set_option(self._h, str(k).encode(), None if v is None else str(v).encode()), 'jx_set_option(%s)' % k)
             for tid, name in enumerate(TENSORS):
                 if name == 'integ_w':
                     if not getattr(pb, 'calc_integ', False):
@@ -272,6 +278,12 @@ class HipContext:
                 msgs.append('the truncation guard took the 16-term cap away on this beam / transfer function: %d terms kept '
                             '(SZ stages about %.2fx)' % (d['rank'], rel))
             near = max(d['est_rel_row_err'] / d['bound'], d['est_rel_sz_like_err_box'] / d['bound_sz_like'])
+            if self.dtype != 'f64' and near > 1.0:
+                # (an fp32 context is measured but never rebuilt -- its rounding is of the bounds' size -- so nothing takes its 16-term cap or
+                #  its sub-grids away: say what was measured)
+                msgs.append('fp32 context: the contracted tables read %.1e on the row and %.1e on the SZ log-likelihood over the prior box (bounds %.0e / %.0e) and are '
+                            'NOT rebuilt for fp32 contexts; build the f64 context (the exact form) or check the walkers with audit()'
+                            % (d['est_rel_row_err'], d['est_rel_sz_like_err_box'], d['bound'], d['bound_sz_like']))
             if not msgs and near > 0.5 and self.dtype == 'f64':
                 msgs.append('the truncation of the low-rank form sits at %.0f %% of its bound (SZ log-likelihood over the prior box %.1e of %.0e): '
                             'slightly different inputs rebuild the tables with more terms (about -35 %% throughput at 31 terms)'
@@ -331,6 +343,17 @@ class HipContext:
         self._chk(self.lib.jx_eval_stage(self._h, t.ctypes.data_as(dp), W, STAGES.index(stage),
                                          out.ctypes.data_as(dp), out.nbytes), 'jx_eval_stage(%s)' % stage)
         return out
+
+    def set_option(self, name, value):
+        """One switch of the library (``jx_set_option``): after construction only the two JOXSZ_SAMPLE_ options can still change."""
+        self._chk(self.lib.jx_set_option(self._h, str(name).encode(), None if value is None else str(value).encode()), 'jx_set_option(%s)' % name)
+
+    def audit(self, theta):
+        """Run-time assurance (``jx_audit``): the walkers through this context's route and through the rocFFT sequence held inside it."""
+        t = self._theta(theta)
+        out = (ctypes.c_double * 4)()
+        self._chk(self.lib.jx_audit(self._h, t.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), t.shape[0], out), 'jx_audit')
+        return dict(max_abs_sz_loglike_diff=out[0], max_rel_row_diff=out[1], worst_walker=int(out[2]), walkers_compared=int(out[3]))
 
     def set_par_vals(self, vals):
         v = np.ascontiguousarray(vals, dtype=np.float64)

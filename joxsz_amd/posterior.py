@@ -19,10 +19,10 @@ from .hip_backend import HipContext
 
 
 class JoxszPosterior:
-    def __init__(self, problem, device=0, max_batch=0, fft_pad=0, map_split=0, conv='auto', route=None, dtype='f64'):
+    def __init__(self, problem, device=0, max_batch=0, fft_pad=0, map_split=0, conv='auto', route=None, dtype='f64', options=None):
         self.problem = problem
         self.ctx = HipContext(problem, device=device, max_batch=max_batch, fft_pad=fft_pad, map_split=map_split,
-                              conv=conv, route=route, dtype=dtype)
+                              conv=conv, route=route, dtype=dtype, options=options)
         self.thawed = list(problem.thawed)                 # joxsz_main.py:179
         self.ndim = problem.ndim
         self.exclude_unphy_mass = bool(problem.exclude_unphy_mass)

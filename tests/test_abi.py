@@ -76,3 +76,37 @@ def test_product_does_not_import_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', text, flags=re.M), f
                 assert 'oracle/' not in text or f.endswith(('.hpp', '.cpp')), f
+
+
+def test_every_switch_of_the_library_is_an_option_and_documented():
+    """no switch of the library depends on the process environment alone, and none is undocumented.  Every name the
+    native sources look up (opt_str(ctx, "JOXSZ_...")) is in the library's option table (kOptions: what jx_set_option accepts), every
+    name of that table is looked up somewhere, and every one of them appears in the option table of include/joxsz_hip.h; nothing in
+    csrc/ calls getenv except the one fall-back inside opt_str."""
+    csrc = os.path.join(ROOT, 'joxsz_amd', 'csrc')
+    used, text_all = set(), ''
+    for f in os.listdir(csrc):
+        if f.endswith(('.hip', '.hpp', '.cpp')):
+            text = open(os.path.join(csrc, f)).read()
+            text_all += text
+            used |= set(re.findall(r'opt_str\(ctx, "(JOXSZ_[A-Z0-9_]+)"\)', text))
+    assert len(re.findall(r'\bgetenv\(', text_all)) == 1 and 'env_str(' not in text_all
+    table = re.search(r'kOptions\[\] = \{(.*?)\};', text_all, flags=re.S).group(1)
+    table = set(re.findall(r'"(JOXSZ_[A-Z0-9_]+)"', table))
+    assert used == table, (sorted(used - table), sorted(table - used))
+    header = open(os.path.join(ROOT, 'include', 'joxsz_hip.h')).read()
+    doc = header[header.index('One switch of the library'):header.index('int  jx_set_option')]
+    missing = [n for n in sorted(table) if n not in doc]
+    assert not missing, missing
+    # the Python side: its own three variables are documented in the README
+    readme = open(os.path.join(ROOT, 'README.md')).read()
+    for n in ('JOXSZ_LIB', 'JOXSZ_QUIET', 'JOXSZ_ROUTE'):
+        assert n in readme, n
+
+
+def test_set_option_refuses_unknown_names(lib):
+    """jx_set_option needs no device to refuse a name it does not know... but it needs a context: checked on the GPU (test_gpu_configs.py);
+    here: the symbol is there and the binding passes options through."""
+    import inspect
+    assert 'options' in inspect.signature(hip_backend.HipContext.__init__).parameters
+    assert hasattr(lib, 'jx_set_option') and hasattr(lib, 'jx_audit')

@@ -69,9 +69,9 @@ def test_exact_form_against_the_rocfft_sequence(S, N, measured, kw):
         assert rel <= 1e-12
     else:
         # (maps smaller than the data's reach -- 116 arcsec against a half side of 30-65: the data-radii spline EXTRAPOLATES, its matrix
-        #  has entries of 1e3-1e5 and chi^2 is 1e6-1e10 -- carry the row's 1e-15 into the log-posterior amplified by that much, in
+        #  has entries of 1e3-1e5 and chi^2 is 1e3-1e6 -- carry the row's 1e-15 into the log-posterior amplified by that much, in
         #  either route; against the oracle the exact form is the closer of the two)
-        assert dchi <= 1e-12 * max(1.0, np.max(chi_b[fin]))
+        assert dchi <= 1e-10 * max(1.0, np.max(chi_b[fin]))
         assert rel <= 1e-9
     want = orc.log_posterior_batch(pb, th[:3])
     np.testing.assert_allclose(a[:3], want, rtol=1e-11)
@@ -122,3 +122,60 @@ def test_pairwise_kernel_against_the_reference_form(monkeypatch):
     assert fin.sum() >= 300 and not fin[7] and np.array_equal(np.isfinite(b), fin)
     np.testing.assert_allclose(a[fin], b[fin], rtol=1e-13)
     assert np.max(np.abs(ra - rb)) <= 1e-13 * np.abs(rb).max() and np.max(np.abs(ba - bb)) <= 1e-13 * np.abs(bb).max()
+
+
+def test_options_belong_to_the_context_not_to_the_process():
+    """jx_set_option: two contexts of one process with different forms, no environment involved; unknown names and late changes refused."""
+    from joxsz_amd import datasets
+    from joxsz_amd.hip_backend import JoxszHipError
+    pb = _filled(datasets.synthetic_problem(S=512, N=500, seed=8), 8)
+    th = datasets.walker_ball(pb, 20, spread=0.03, seed=8)
+    assert 'JOXSZ_MIX_FORM' not in os.environ
+    a = _post(pb)
+    b = _post(pb, options={'MIX_FORM': 'legacy', 'joxsz_trunc_probe': '0'})
+    assert a.ctx.conv_layout['form'] == 'exact' and b.ctx.conv_layout['form'] == 'lowrank' and b.ctx.truncation['points'] == 0
+    la, lb = a.log_prob(th), b.log_prob(th)
+    fin = np.isfinite(la)
+    assert fin.sum() >= 15 and np.array_equal(np.isfinite(lb), fin)
+    np.testing.assert_allclose(lb[fin], la[fin], rtol=1e-6)
+    assert np.any(lb[fin] != la[fin])
+    with pytest.raises(JoxszHipError, match='unknown option'):
+        _post(pb, options={'NO_SUCH_SWITCH': '1'})
+    with pytest.raises(JoxszHipError, match='after jx_finalize'):
+        a.ctx.set_option('MIX_FORM', 'legacy')
+    a.ctx.set_option('SAMPLE_FUSED', '0')                            # (read by jx_sample: may change any time)
+    a.close(); b.close()
+
+
+def test_audit_certifies_the_exact_form_and_catches_a_coarse_sub_grid():
+    """jx_audit (run-time assurance): live walkers through the context's route and through the rocFFT sequence held inside
+    it.  The exact f64 context reads rounding (SZ log-likelihood to 1e-8 absolute, row to 1e-12); a contracted context whose sub-grid of
+    map samples is far too coarse for the profile -- with its set-up guard switched off, as if the nine probe vectors had passed -- is
+    caught on the very walkers handed in; mcmc_run audits a running chain and warns."""
+    import warnings
+    from joxsz_amd import datasets
+    from joxsz_amd.chain import audit_walkers, JoxszAuditWarning, mcmc_run
+    pb = _filled(datasets.synthetic_problem(S=512, N=500, seed=9), 9)
+    th = datasets.walker_ball(pb, 40, spread=0.03, seed=9)
+    th[3, 1] = 9.0                                                    # (a rejected walker: not compared -- no chain lives there)
+    post = _post(pb)
+    res = post.ctx.audit(th)
+    assert 30 <= res['walkers_compared'] <= 39 and res['max_abs_sz_loglike_diff'] <= 1e-8 and res['max_rel_row_diff'] <= 1e-12, res
+    with warnings.catch_warnings():
+        warnings.simplefilter('error', JoxszAuditWarning)
+        assert audit_walkers(post, th)['max_abs_sz_loglike_diff'] <= 1e-8
+        out = mcmc_run(post, 32, 0, 30, prelim_iters=0, initspread=0.01, audit_every=10, seed=3)
+    assert len(out['audits']) == 4 and all(a_['max_abs_sz_loglike_diff'] <= 1e-8 for a_ in out['audits']) and out['chain'].shape == (30, 32, pb.ndim)
+    post.close()
+    coarse = _post(pb, options={'MIX_FORM': 'lowrank', 'MIX_SUBSAMPLE': '8,8,4', 'TRUNC_PROBE': '0', 'AG_SUBSAMPLE': '0'})
+    assert coarse.ctx.sampling['active'] and coarse.ctx.truncation['points'] == 0
+    bad = coarse.ctx.audit(th)
+    assert bad['max_abs_sz_loglike_diff'] > 1e-6 and bad['max_rel_row_diff'] > 1e-9 and 0 <= bad['worst_walker'] < 40, bad
+    with pytest.warns(JoxszAuditWarning):
+        audit_walkers(coarse, th)
+    coarse.close()
+    f32 = _post(pb, dtype='f32c')
+    r32 = f32.ctx.audit(th[:16])
+    print('audit: exact %s | coarse sub-grid %s | f32c %s' % (res, bad, r32))
+    assert 1e-9 < r32['max_abs_sz_loglike_diff'] < 1e-3
+    f32.close()
