@@ -173,6 +173,7 @@ int  jx_finalize(jx_ctx* ctx);
  *   JOXSZ_FFT_PAD, JOXSZ_MAP_SPLIT, JOXSZ_MAP_PAIR         rocFFT sequence / Abel + map kernel: padded side, row slabs per walker, two walkers per block (1)
  *   JOXSZ_EVAL_DIRECT            0..3 (3)                  jx_eval: bit 0 the tail stores into the caller-visible host buffer, bit 1 the per-walker kernel reads theta from it
  *   JOXSZ_PREP_SPLIT             1|0 (1)                   per-walker kernel as two blocks per walker (X-ray side beside the rest); same bits
+ *   JOXSZ_PREP_LEAN              1|0 (1)                   the two-block form as jx_walker2_kernel (every table of a block in one batched copy into LDS); 0: inside jx_prep_kernel; same bits
  *   JOXSZ_PREP_POW               0|1 (0)                   per-walker kernel: profiles with pow() as written in the reference instead of through their exponents
  *   JOXSZ_PREP_FASTMATH          1|0 (1)                   per-walker kernel: table-driven exp / log (2 ulp) instead of the device library's
  *   JOXSZ_OP_NARROW              0|1 (0)                   collapsed route: the small-launch kernel at every launch size

@@ -128,6 +128,7 @@ struct jx_ctx {
     double *d_base = nullptr, *d_cfac = nullptr, *d_sz0 = nullptr;
     double* d_xr = nullptr;            // [chunk][2] Cash log-likelihood and reject flag of the two-block form of the per-walker kernel
     bool prep_split = true;            // JOXSZ_PREP_SPLIT=0: one block per walker in the per-walker kernel (as in every call with taps)
+    bool prep_lean = true;             // JOXSZ_PREP_LEAN=0: the two-block form runs in jx_prep_kernel itself instead of jx_walker2_kernel (same bits)
     double* d_img = nullptr;           // contracted route: quadrant of the Compton-y map (y_2d tap only; allocated on first use)
     // spline arrays as one matrix product (jx_abel_gemm_kernel)
     double* d_Tm = nullptr; int tm_ld = 0, tm_ntile = 0, tm_npair = 0;
@@ -297,7 +298,7 @@ static std::vector<T> host_vec(jx_ctx* ctx, int id) {
 // (tests/test_abi.py holds the two and the uses in this file together).
 static const char* const kOptions[] = {
     "JOXSZ_CONV", "JOXSZ_MIX_FORM", "JOXSZ_X_PAIRWISE", "JOXSZ_PRUNE_OUTPUTS", "JOXSZ_CHUNK", "JOXSZ_FFT_PAD", "JOXSZ_MAP_SPLIT", "JOXSZ_MAP_PAIR",
-    "JOXSZ_EVAL_DIRECT", "JOXSZ_PREP_SPLIT", "JOXSZ_PREP_POW", "JOXSZ_PREP_FASTMATH", "JOXSZ_OP_NARROW", "JOXSZ_SAMPLE_FUSED", "JOXSZ_SAMPLE_VIRTUAL_RANKS",
+    "JOXSZ_EVAL_DIRECT", "JOXSZ_PREP_SPLIT", "JOXSZ_PREP_LEAN", "JOXSZ_PREP_POW", "JOXSZ_PREP_FASTMATH", "JOXSZ_OP_NARROW", "JOXSZ_SAMPLE_FUSED", "JOXSZ_SAMPLE_VIRTUAL_RANKS",
     // the contracted forms of rounds 3-4 (JOXSZ_MIX_FORM=legacy|lowrank|full)
     "JOXSZ_LOWRANK_TOL", "JOXSZ_TRUNC_PROBE", "JOXSZ_TRUNC_BOUND", "JOXSZ_MIX_SUBSAMPLE", "JOXSZ_MIX_RANKCAP", "JOXSZ_MIX_MFMA", "JOXSZ_MIX_USPLIT", "JOXSZ_MIX_WPB",
     "JOXSZ_MIX_KSPLIT", "JOXSZ_MIX_KSPLIT_USE", "JOXSZ_ABEL_GEMM", "JOXSZ_AG_NARROW", "JOXSZ_AG_SINGLE", "JOXSZ_AG_SUBSAMPLE", "JOXSZ_SIDE_STREAM", "JOXSZ_SIDE_FORK",
@@ -1277,6 +1278,7 @@ static int finalize_impl(jx_ctx* ctx) {
     if (const char* e = opt_str(ctx, "JOXSZ_AG_SINGLE")) ctx->ag_single = atoi(e) != 0;
     if (const char* e = opt_str(ctx, "JOXSZ_X_PAIRWISE")) ctx->mix.x_pairwise = atoi(e) != 0;
     if (const char* e = opt_str(ctx, "JOXSZ_PREP_SPLIT")) ctx->prep_split = atoi(e) != 0;
+    if (const char* e = opt_str(ctx, "JOXSZ_PREP_LEAN")) ctx->prep_lean = atoi(e) != 0;
     if (const char* e = opt_str(ctx, "JOXSZ_AG_SUBSAMPLE")) {
         int a0 = 0, a1 = 0, a2 = 0;
         const int got = sscanf(e, "%d,%d,%d", &a0, &a1, &a2);
@@ -1419,10 +1421,12 @@ static int finalize_impl(jx_ctx* ctx) {
         }
     }
     // ---- h(0) weights: spline through (+-r_pp[:nt], t) evaluated at 0 (joxsz_funcs.py:470-473)
+    std::vector<double> h_hw;
     {
         std::vector<double> rt(r.begin(), r.begin() + ctx->nt), G;
         if (!jxt::mirrored_spline_op(rt, G)) { ctx->err = "h(0) operator: singular system"; return JX_ERR_INVALID; }
-        std::vector<double> hw(ctx->nt);
+        std::vector<double>& hw = h_hw;
+        hw.assign(ctx->nt, 0.0);
         for (int j = 0; j < ctx->nt; ++j) hw[j] = -0.5 * rt[0] * rt[0] * G[j];
         hw[0] += 1.0;
         double* p; if ((rc = dev_put(ctx, hw.data(), hw.size(), &p))) return rc; d.hw = p;
@@ -1466,10 +1470,31 @@ static int finalize_impl(jx_ctx* ctx) {
         }
         PUTI(par_kind, JX_T_PAR_KIND) PUTI(thawed_idx, JX_T_THAWED_IDX)
         ctx->d_par_vals = const_cast<double*>(d.par_vals);
+        {   // exp / log tables, radii and their logarithms, h(0) weights, conversion table in one run: what an SZ-side block of jx_walker2_kernel copies into LDS
+            std::vector<double> pack;
+            jxt::fastmath_tables(pack);
+            pack.insert(pack.end(), r.begin(), r.end());
+            for (double v : r) pack.push_back(std::log(v));
+            pack.insert(pack.end(), h_hw.begin(), h_hw.end());
+            for (int id : {JX_T_CONV_T, JX_T_CONV_V}) { const std::vector<double> v = host_vec<double>(ctx, id); pack.insert(pack.end(), v.begin(), v.end()); }
+            if (pack.size() != JX_SZ_PACK_DOUBLES(d)) { ctx->err = "per-walker table pack: size"; return JX_ERR_INVALID; }
+            if ((rc = dev_put(ctx, pack.data(), pack.size(), &p))) return rc;
+            d.sz_pack = p;
+        }
         if (!c.sz_only) {
             PUTD(x_r_ne, JX_T_X_R_NE) PUTD(x_r_T, JX_T_X_R_T) PUTD(projvols, JX_T_PROJVOLS) PUTD(cts, JX_T_CTS)
             PUTD(areascales, JX_T_AREASCALES) PUTD(exposures, JX_T_EXPOSURES) PUTD(backrates, JX_T_BACKRATES)
             PUTD(geomarea, JX_T_GEOMAREA) PUTD(lnT, JX_T_LNT) PUTD(lnrate, JX_T_LNRATE)
+            // exp / log tables and the small tables of the X-ray side in one run: what an X-ray block of jx_walker2_kernel copies into LDS
+            std::vector<double> pack;
+            jxt::fastmath_tables(pack);
+            for (int id : {JX_T_X_R_NE, JX_T_X_R_T, JX_T_GEOMAREA, JX_T_LNT, JX_T_PROJVOLS, JX_T_AREASCALES, JX_T_EXPOSURES, JX_T_BACKRATES, JX_T_CTS}) {
+                const std::vector<double> v = host_vec<double>(ctx, id);
+                pack.insert(pack.end(), v.begin(), v.end());
+            }
+            if (pack.size() != JX_XR_PACK_DOUBLES(d)) { ctx->err = "X-ray table pack: size"; return JX_ERR_INVALID; }
+            if ((rc = dev_put(ctx, pack.data(), pack.size(), &p))) return rc;
+            d.xr_pack = p;
         }
 #undef PUTD
 #undef PUTI
@@ -1756,6 +1781,11 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
         }
 #endif
         const unsigned pgrid = xr_split ? 2u * (unsigned)n : (unsigned)n, pthr = xr_split ? 128u : (unsigned)JX_PREP_THREADS;
+        if (xr_split && ctx->prep_lean && ctx->prep_fastmath && pp_buf && sizeof(double) * JX_W2_LDS_DOUBLES(d) <= (size_t)19 * 1024 + 512) {
+            // the two-block form as two lean roles (same arithmetic, same bits; every table of a role in one batched copy into LDS)
+            hipLaunchKernelGGL(jx_walker2_kernel, dim3(pgrid), dim3(JX_W2_THREADS), sizeof(double) * JX_W2_LDS_DOUBLES(d), ps, dp, theta_dev, w0, base_buf, cfac_buf, pp_buf, smv);
+            return;
+        }
         const size_t sh = sizeof(double) * (JX_LDS_HDR + (size_t)2 * d.N + 2 * d.nann + 2 * (size_t)d.nband * d.nann + 2 * (size_t)d.nconv + 8 + JX_FM_TABLE_DOUBLES);
         if (d.prep_pow) hipLaunchKernelGGL((jx_prep_kernel<true, false>), dim3(pgrid), dim3(pthr), sh, ps, dp, theta_dev, w0,
                                            base_buf, cfac_buf, pp_buf, sz0_buf, t.tprof, t.xprofs, t.parts, t.integ, smv);

@@ -74,6 +74,8 @@ struct JxDev {
     double* xr_out;              // [chunk][2] Cash log-likelihood and its reject flag (xr_split)
     int prep_pow;                // 1 (JOXSZ_PREP_POW=1): the prep kernel evaluates the profiles with pow() as written in the reference
     const double* lr_pp;         // [N] log(r_pp)
+    const double* sz_pack;       // jx_walker2_kernel: the tables of its two roles, each role's in one run (layouts at the kernel)
+    const double* xr_pack;
     const double* inject_pp;     // operator build only: [nlaunch][N] pressure profiles that replace press_fun(theta) (else null)
     long long* stamps;           // diagnostic build only (make ABLATIONS=1, JOXSZ_X_STAMPS): [blocks][8] wall-clock stamps of jx_prep_kernel's phases
     int pp_ld;                   // doubles per walker of jx_prep_kernel's profile output (0: N; the exact form pads its rows to whole 16-radius steps)
@@ -307,6 +309,98 @@ __device__ __forceinline__ void jx_load_params(const JxDev& c, const double* __r
 }
 
 // ------------------------------------------------------------------------------------
+// The X-ray side of a walker: calcProfiles + Cash (joxsz_funcs.py:527-532, 495-505; mbproj2 Fit.calcProfiles).  Called by every thread of a
+// block (block barriers inside); its tables arrive through a struct of pointers -- global memory (jx_prep_kernel), or the copies an X-ray
+// block of jx_walker2_kernel staged in LDS at its start (every table but the count-rate tables).  The terms of the Cash sum are added in
+// ONE order whatever the block's size: 64 consecutive pairs per shuffle tree, the trees' sums in sequence.
+// ------------------------------------------------------------------------------------
+struct JxXrTab {
+    const double *x_r_ne, *x_r_T, *lnT, *lnrate, *projvols, *areascales, *exposures, *backrates, *geomarea, *cts;
+};
+// dst[0, n) <- src[0, n) by the block's threads, U loads per thread requested before the first is stored (one trip to memory per U x threads)
+template <int U>
+__device__ __forceinline__ void jx_copy_batched(double* __restrict__ dst, const double* __restrict__ src, int n, int tid, int nth) {
+    for (int i0 = 0; i0 < n; i0 += U * nth) {
+        double v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = src[min(i0 + u * nth + tid, n - 1)];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const int i = i0 + u * nth + tid; if (i < n) dst[i] = v[u]; }
+    }
+}
+
+template <bool POW, class M>
+__device__ __forceinline__ void jx_xray_side(const JxDev& c, const JxXrTab& xt, const double* p, const double* pl, const double* pc, const M& mt, int tid, int nth,
+                                             double* s_x, double* s_ne, double* s_T, double* s_rate, double* s_term, double* red, int* redi,
+                                             size_t w, double* __restrict__ tap_xprofs, double* xlike_out, int* xbad_out) {
+    constexpr bool logform = !POW;
+    if (logform && 3 * c.nann <= nth) {
+        // three jobs per shell side by side: density at the n_e radii, pressure at the T radii, density at the T radii (only
+        // where the two radii differ), then T_X = P / n_e * 10^log(T_X/T_SZ)
+        const int grp = tid / c.nann, k = tid - grp * c.nann;
+        if (grp < 3) {
+            const double rn = xt.x_r_ne[k], r = xt.x_r_T[k];
+            if (grp == 0) s_ne[k] = jx_ne_log(mt, p, pl, rn, mt.l(rn), c.ne_mode);
+            else if (grp == 1) { double xa; s_T[k] = jx_press_log(mt, p, pl, mt.l(r), &xa) * mt.e(2.30258509299404568402 * p[P_LOGTR]); }
+            else s_x[k] = (rn == r) ? 0.0 : jx_ne_log(mt, p, pl, r, mt.l(r), c.ne_mode);
+        }
+        __syncthreads();
+        if (tid < c.nann) s_T[tid] = s_T[tid] / ((xt.x_r_ne[tid] == xt.x_r_T[tid]) ? s_ne[tid] : s_x[tid]);   // T_X
+    } else if (tid < c.nann) {
+        const double rn = xt.x_r_ne[tid], r = xt.x_r_T[tid];
+        if (logform) {
+            double xa;
+            const double lr = mt.l(r);
+            s_ne[tid] = jx_ne_log(mt, p, pl, rn, (rn == r) ? lr : mt.l(rn), c.ne_mode);
+            s_T[tid] = jx_press_log(mt, p, pl, lr, &xa) / jx_ne_log(mt, p, pl, r, lr, c.ne_mode) * mt.e(2.30258509299404568402 * p[P_LOGTR]);   // T_X
+        } else {
+            s_ne[tid] = jx_ne_pc(p, pc, rn, c.ne_mode);
+            s_T[tid] = jx_press(p, r) / jx_ne_pc(p, pc, r, c.ne_mode) * pow(10.0, p[P_LOGTR]);   // T_X
+        }
+    }
+    __syncthreads();
+    const int nba = c.nband * c.nann;
+    for (int q = tid; q < nba; q += nth) {
+        const int b = q / c.nann, j = q - b * c.nann;
+        const double lt = mt.l(s_T[j]);
+        const double* tab = xt.lnrate + (size_t)b * 2 * c.ntab;
+        double i0, i1;                     // one search of the temperature grid serves both metallicity tables
+        jx_interp_clamped2(xt.lnT, tab, tab + c.ntab, c.ntab, lt, c.inv_dlnT, &i0, &i1);
+        const double z0 = mt.e(i0), z1 = mt.e(i1);
+        s_rate[q] = (z0 + (z1 - z0) * p[P_Z]) * s_ne[j] * s_ne[j];
+    }
+    __syncthreads();
+    int bad = 0;
+    for (int q = tid; q < nba; q += nth) {
+        const int b = q / c.nann, i = q - b * c.nann;
+        double proj = 0.0;
+        for (int j = 0; j < c.nann; ++j) proj += xt.projvols[i * c.nann + j] * s_rate[b * c.nann + j];
+        const double ae = xt.areascales[q] * xt.exposures[q];
+        const double model = proj * ae + xt.backrates[q] * xt.geomarea[i] * ae * p[P_BACKSCALE];
+        if (tap_xprofs) tap_xprofs[w * nba + q] = model;
+        if (!(model > 0.0)) bad = 1;       // np.array(profs).min() > 0 fails (NaN included)
+        const double ct = xt.cts[q];
+        s_term[q] = (ct == ct) ? ct * mt.l(model) - model : 0.0;
+    }
+    int xbad = jx_block_or(bad, redi);     // (its barriers order s_term as well)
+    if (tid < 64) {
+        double tot = 0.0;
+        for (int q0 = 0; q0 < nba; q0 += 64) {
+            double v = (q0 + tid < nba) ? s_term[q0 + tid] : 0.0;
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            tot += v;
+        }
+        if (tid == 0) red[0] = tot;
+    }
+    __syncthreads();
+    const double xlike = red[0];
+    __syncthreads();
+    // cashLogLikelihood returns -inf for a non-finite sum; per band in the reference, a non-finite band makes the total non-finite as well
+    if (!(fabs(xlike) <= 1.79769313486231570e308)) xbad = 1;
+    *xlike_out = xlike; *xbad_out = xbad;
+}
+
+// ------------------------------------------------------------------------------------
 // K0: per-walker scalar work.  One 256-thread block per walker.
 //   base  [W]  parprior + model prior + X-ray log-likelihood, or -inf when rejected
 //   cfac  [W, nrow]  convert([h(0), t_prof]) * calibration   (joxsz_funcs.py:473)
@@ -474,74 +568,10 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
     double xlike = 0.0;
     int xbad = 0;
     if (!c.sz_only && !noxr) {
-        if (logform && 3 * c.nann <= nth) {
-            // three jobs per shell side by side: density at the n_e radii, pressure at the T radii, density at the T radii (only
-            // where the two radii differ), then T_X = P / n_e * 10^log(T_X/T_SZ)
-            double* s_x = s_m;                 // (the mass profile is dead: two block reductions since its last read)
-            const int grp = tid / c.nann, k = tid - grp * c.nann;
-            if (grp < 3) {
-                const double rn = c.x_r_ne[k], r = c.x_r_T[k];
-                if (grp == 0) s_ne[k] = jx_ne_log(mt, p, pl, rn, mt.l(rn), c.ne_mode);
-                else if (grp == 1) { double xa; s_T[k] = jx_press_log(mt, p, pl, mt.l(r), &xa) * mt.e(2.30258509299404568402 * p[P_LOGTR]); }
-                else s_x[k] = (rn == r) ? 0.0 : jx_ne_log(mt, p, pl, r, mt.l(r), c.ne_mode);
-            }
-            __syncthreads();
-            if (tid < c.nann) s_T[tid] = s_T[tid] / ((c.x_r_ne[tid] == c.x_r_T[tid]) ? s_ne[tid] : s_x[tid]);   // T_X
-        } else if (tid < c.nann) {
-            const double rn = c.x_r_ne[tid], r = c.x_r_T[tid];
-            if (logform) {
-                double xa;
-                const double lr = mt.l(r);
-                s_ne[tid] = jx_ne_log(mt, p, pl, rn, (rn == r) ? lr : mt.l(rn), c.ne_mode);
-                s_T[tid] = jx_press_log(mt, p, pl, lr, &xa) / jx_ne_log(mt, p, pl, r, lr, c.ne_mode) * mt.e(2.30258509299404568402 * p[P_LOGTR]);   // T_X
-            } else {
-                s_ne[tid] = jx_ne_pc(p, pc, rn, c.ne_mode);
-                s_T[tid] = jx_press(p, r) / jx_ne_pc(p, pc, r, c.ne_mode) * pow(10.0, p[P_LOGTR]);   // T_X
-            }
-        }
-        __syncthreads();
-        const int nba = c.nband * c.nann;
-        for (int q = tid; q < nba; q += nth) {
-            const int b = q / c.nann, j = q - b * c.nann;
-            const double lt = mt.l(s_T[j]);
-            const double* tab = c.lnrate + (size_t)b * 2 * c.ntab;
-            double i0, i1;                     // one search of the temperature grid serves both metallicity tables
-            jx_interp_clamped2(c.lnT, tab, tab + c.ntab, c.ntab, lt, c.inv_dlnT, &i0, &i1);
-            const double z0 = mt.e(i0), z1 = mt.e(i1);
-            s_rate[q] = (z0 + (z1 - z0) * p[P_Z]) * s_ne[j] * s_ne[j];
-        }
-        __syncthreads();
-        int bad = 0;
-        for (int q = tid; q < nba; q += nth) {
-            const int b = q / c.nann, i = q - b * c.nann;
-            double proj = 0.0;
-            for (int j = 0; j < c.nann; ++j) proj += c.projvols[i * c.nann + j] * s_rate[b * c.nann + j];
-            const double ae = c.areascales[q] * c.exposures[q];
-            const double model = proj * ae + c.backrates[q] * c.geomarea[i] * ae * p[P_BACKSCALE];
-            if (tap_xprofs) tap_xprofs[(size_t)w * nba + q] = model;
-            if (!(model > 0.0)) bad = 1;       // np.array(profs).min() > 0 fails (NaN included)
-            const double ct = c.cts[q];
-            s_term[q] = (ct == ct) ? ct * mt.l(model) - model : 0.0;
-        }
-        // The terms are added in ONE order whatever the block's size (256 threads, or 128 in the two-block form): 64 consecutive pairs
-        // per shuffle tree, the trees' sums in sequence -- what jx_block_sum does with one pair per thread of a 256-thread block.
-        xbad = jx_block_or(bad, &redi);        // (its barriers order s_term as well)
-        if (tid < 64) {
-            double tot = 0.0;
-            for (int q0 = 0; q0 < nba; q0 += 64) {
-                double v = (q0 + tid < nba) ? s_term[q0 + tid] : 0.0;
-                for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-                tot += v;
-            }
-            if (tid == 0) red[0] = tot;
-        }
-        __syncthreads();
-        xlike = red[0];
-        __syncthreads();
+        const JxXrTab xt{c.x_r_ne, c.x_r_T, c.lnT, c.lnrate, c.projvols, c.areascales, c.exposures, c.backrates, c.geomarea, c.cts};
+        // (s_m, the mass profile, is dead by now: two block reductions since its last read)
+        jx_xray_side<POW>(c, xt, p, pl, pc, mt, tid, nth, s_m, s_ne, s_T, s_rate, s_term, red, &redi, (size_t)w, tap_xprofs, &xlike, &xbad);
         if (xbad) rej |= REJ_XRAY;
-        // cashLogLikelihood returns -inf for a non-finite sum; per band in the reference,
-        // a non-finite band makes the total non-finite as well
-        if (!(fabs(xlike) <= 1.79769313486231570e308)) { rej |= REJ_XRAY; xbad = 1; }
     }
     if (xonly) {                               // the X-ray side alone: its sum and its verdict for the tail
         if (tid == 0) { c.xr_out[2 * (size_t)w] = xlike; c.xr_out[2 * (size_t)w + 1] = xbad ? 1.0 : 0.0; }
@@ -560,6 +590,143 @@ jx_prep_kernel(JxDev c, const double* __restrict__ theta, int w0,
             tap_parts[(size_t)w * 4 + 3] = (double)rejall;
         }
     }
+    JX_PSTAMP(c, 6);
+}
+
+// ------------------------------------------------------------------------------------
+// The per-walker work of the TIMED path as two lean roles in one launch (what jx_prep_kernel's two-block form does, same arithmetic, same
+// bits): blocks [0, n) -- parameters, priors, grid pass (pressure, mass veto, T_SZ), h(0), conversion factors; blocks [n, 2n) -- the X-ray
+// side alone.  jx_prep_kernel serves every call with taps, the pow() form, the integrated-Compton term, long grids; it is held to 128
+// registers for its occupancy and spills when anything is added to it (profiles/r05_xray_in_tail.log).  Here every table a role reads
+// -- exp / log tables, the radii and their logarithms, the h(0) weights, the conversion table; or exp / log tables and the small tables of the
+// X-ray side -- comes from ONE packed array (jx_finalize) in ONE batched copy into LDS at the block's start, beside the parameter loads: a
+// block pays one trip to memory in front of its first barrier instead of one per phase (the count-rate tables stay in memory: two gathers
+// behind the temperature search, which runs on the LDS copy of the grid).
+//   sz_pack  [JX_FM_TABLE_DOUBLES + 2 N + nt + 2 nconv]    fm | r_pp | log r_pp | hw | conv_T | conv_v
+//   xr_pack  [JX_FM_TABLE_DOUBLES + 3 nann + ntab + nann^2 + 4 nband nann]    fm | x_r_ne | x_r_T | geomarea | lnT | projvols | areascales | exposures | backrates | cts
+// ------------------------------------------------------------------------------------
+#define JX_W2_THREADS 128
+#define JX_SZ_PACK_DOUBLES(c) ((size_t)JX_FM_TABLE_DOUBLES + 2 * (size_t)(c).N + (c).nt + 2 * (size_t)(c).nconv)
+#define JX_XR_PACK_DOUBLES(c) ((size_t)JX_FM_TABLE_DOUBLES + 3 * (size_t)(c).nann + (c).ntab + (size_t)(c).nann * (c).nann + 4 * (size_t)(c).nband * (c).nann)
+#define JX_W2_LDS_DOUBLES(c) (JX_LDS_HDR + ((JX_SZ_PACK_DOUBLES(c) + (size_t)(c).N + (c).nt) > (JX_XR_PACK_DOUBLES(c) + 3 * (size_t)(c).nann + 2 * (size_t)(c).nband * (c).nann) \
+                                             ? (JX_SZ_PACK_DOUBLES(c) + (size_t)(c).N + (c).nt) : (JX_XR_PACK_DOUBLES(c) + 3 * (size_t)(c).nann + 2 * (size_t)(c).nband * (c).nann)) + 8)
+
+__global__ void __launch_bounds__(JX_W2_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
+jx_walker2_kernel(JxDev c, const double* __restrict__ theta, int w0, double* __restrict__ base, double* __restrict__ cfac, double* __restrict__ pp_out, JxSm smv) {
+    JX_LDS_DECL;
+    double* p = sm;
+    double* red = sm + 20;
+    int& redi = *reinterpret_cast<int*>(sm + 28);
+    const int nblk = (int)(gridDim.x >> 1);
+    const bool xonly = (int)blockIdx.x >= nblk;
+    const int w = xonly ? (int)blockIdx.x - nblk : (int)blockIdx.x, gw = w0 + w;
+    const int tid = threadIdx.x, nth = JX_W2_THREADS;
+    JX_PSTAMP(c, 0);
+    double* s_pack = sm + JX_LDS_HDR;                      // the role's packed tables, the exp / log tables first
+    JxMathTab mt;
+    mt.t.et = s_pack; mt.t.lt = s_pack + JX_FM_EXP_N;
+    if (xonly) {
+        // ---- the X-ray side alone ----
+        jx_copy_batched<12>(s_pack, c.xr_pack, (int)JX_XR_PACK_DOUBLES(c), tid, nth);
+        jx_load_params(c, theta, gw, p, &smv);
+        JX_PSTAMP(c, 1);
+        const int nann = c.nann, nba = c.nband * c.nann;
+        const double* t = s_pack + JX_FM_TABLE_DOUBLES;
+        const JxXrTab xt{t, t + nann, t + 3 * nann, c.lnrate, t + 3 * nann + c.ntab, t + 3 * nann + c.ntab + nann * nann, t + 3 * nann + c.ntab + nann * nann + nba,
+                         t + 3 * nann + c.ntab + nann * nann + 2 * nba, t + 2 * nann, t + 3 * nann + c.ntab + nann * nann + 3 * nba};
+        double* s_ne = s_pack + JX_XR_PACK_DOUBLES(c);
+        double* s_T = s_ne + nann;
+        double* s_x = s_T + nann;
+        double* s_rate = s_x + nann;
+        double* s_term = s_rate + nba;
+        double pl[11];
+        jx_prof_consts(mt, p, c.ne_mode, pl);
+        const double pc[5] = {0, 1, 1, 0, 1};
+        double xlike = 0.0;
+        int xbad = 0;
+        jx_xray_side<false>(c, xt, p, pl, pc, mt, tid, nth, s_x, s_ne, s_T, s_rate, s_term, red, &redi, (size_t)w, nullptr, &xlike, &xbad);
+        if (tid == 0) { c.xr_out[2 * (size_t)w] = xlike; c.xr_out[2 * (size_t)w + 1] = xbad ? 1.0 : 0.0; }
+        JX_PSTAMP(c, 6);
+        return;
+    }
+    // ---- everything but the X-ray side ----
+    const int N = c.N, nt = c.nt;
+    const double* s_r = s_pack + JX_FM_TABLE_DOUBLES;      // [N]
+    const double* s_lr = s_r + N;                           // [N]
+    const double* s_hw = s_lr + N;                          // [nt]
+    const double* s_conv = s_hw + nt;                       // [2 nconv]
+    double* s_m = s_pack + JX_SZ_PACK_DOUBLES(c);          // [N] mass profile
+    double* s_t = s_m + N;                                  // [nt] T_SZ on r_pp[:nt]
+    const bool has_par = tid < c.npar;
+    const int pk_kind = has_par ? c.par_kind[tid] : 0;
+    const double pk_a = has_par ? (pk_kind == 1 ? c.par_mu[tid] : c.par_min[tid]) : 0.0;
+    const double pk_b = has_par ? (pk_kind == 1 ? c.par_sigma[tid] : c.par_max[tid]) : 0.0;
+    const double pk_ln = has_par ? c.par_lnorm[tid] : 0.0;
+    jx_copy_batched<20>(s_pack, c.sz_pack, (int)JX_SZ_PACK_DOUBLES(c), tid, nth);
+    jx_load_params(c, theta, gw, p, &smv);
+    JX_PSTAMP(c, 1);
+    double pl[11];
+    jx_prof_consts(mt, p, c.ne_mode, pl);
+    double pr = 0.0;
+    int rej = 0;
+    // priors on every parameter (joxsz_funcs.py:518)
+    if (has_par) {
+        const double v = p[tid];
+        if (pk_kind == 1) {
+            const double sg = pk_b;
+            if (sg <= 0.0) { rej |= REJ_BOX; }
+            else {
+                const double z = (v - pk_a) / sg;
+                pr = pk_ln - 0.5 * z * z;
+            }
+        } else if (v < pk_a || v > pk_b) rej |= REJ_BOX;
+        if (v != v) rej |= REJ_BOX;           // NaN parameter: reject (emcee cannot use NaN)
+    }
+    const double parprior = jx_block_sum(pr, red);
+    JX_PSTAMP(c, 2);
+    if (!(fabs(parprior) <= 1.79769313486231570e308)) rej |= REJ_BOX;     // joxsz_funcs.py:519-520
+    if (tid == 0 && p[P_LOGRC] > p[P_LOGRS]) rej |= REJ_RCRS;             // model prior: r_c <= r_s (joxsz_funcs.py:397-407; 10^x is monotonic)
+    // one pass over the radial grid, two radii per trip (jx_prep_kernel's arithmetic)
+    const bool veto = c.exclude_unphy_mass != 0;
+    const int mode_ = c.ne_mode;
+    const size_t ppo = (size_t)w * (c.pp_ld ? c.pp_ld : N);
+    for (int i = tid; i < N; i += 2 * nth) {
+        const int i2 = min(i + nth, N - 1);
+        const bool two = i + nth < N;
+        const double ra = s_r[i], rb = s_r[i2], lra = s_lr[i], lrb = s_lr[i2];
+        double xaa, xab;
+        const double pa = jx_press_log(mt, p, pl, lra, &xaa), pb = jx_press_log(mt, p, pl, lrb, &xab);
+        const double ia = jx_inv_ne_log(mt, p, pl, ra, lra, mode_), ib = jx_inv_ne_log(mt, p, pl, rb, lrb, mode_);      // 1 / n_e
+        const double ma = pa * (p[P_C] + p[P_B] * xaa) * ra * ia / (1.0 + xaa);
+        const double mb = pb * (p[P_C] + p[P_B] * xab) * rb * ib / (1.0 + xab);
+        pp_out[ppo + i] = pa; if (two) pp_out[ppo + i2] = pb;
+        if (veto) { s_m[i] = ma; if (two) s_m[i2] = mb; }
+        if (i < nt) s_t[i] = pa * ia;
+        if (two && i2 < nt) s_t[i2] = pb * ib;
+    }
+    __syncthreads();
+    JX_PSTAMP(c, 3);
+    if (veto) {
+        for (int i = tid; i < N; i += nth) {
+            double g;                          // np.gradient(m, 1)
+            if (i == 0) g = s_m[1] - s_m[0];
+            else if (i == N - 1) g = s_m[N - 1] - s_m[N - 2];
+            else g = (s_m[i + 1] - s_m[i - 1]) / 2.0;
+            if (!(g > 0.0)) rej |= REJ_MASS;
+        }
+    }
+    JX_PSTAMP(c, 4);
+    // h(0), conversion factors (joxsz_funcs.py:470-473)
+    double part = 0.0;
+    for (int k = tid; k < nt; k += nth) part += s_hw[k] * s_t[k];
+    const double t0 = jx_block_sum(part, red);
+    for (int k = tid; k < c.nrow; k += nth) {
+        const double T = (k == 0) ? t0 : s_t[k - 1];
+        cfac[(size_t)w * c.nrow + k] = jx_convert_tab(s_conv, s_conv + c.nconv, c.nconv, T) * p[P_CALIB];
+    }
+    JX_PSTAMP(c, 5);
+    const int rejall = jx_block_or(rej, &redi);
+    if (tid == 0) base[w] = (rejall != 0) ? -INFINITY : (parprior + 0.0);   // (the X-ray term arrives from the other block: the tail adds the two)
     JX_PSTAMP(c, 6);
 }
 
