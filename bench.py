@@ -20,16 +20,21 @@ with N > 1 makes THIS process the launcher: it starts N fresh child processes
 (one per GPU) before anything touches a GPU, never initialises HIP itself,
 relays rank 0's single JSON line and exits non-zero if any rank fails.
 
-Prints ONE JSON line (rank 0) with
-  `roofline`            the time-dominant kernel of the step (stage 1 of the contracted route: fp64 vector FMAs) on its
-                        algorithmic flops over its HIP-event duration, measured inside the timed region;
-  `roofline_product`    the matrix-core product behind it, same way;
+Prints ONE JSON line (rank 0).  `ms_per_step` is the MEDIAN over at least 25 timed regions of `--steps` steps each (each
+bracketed by barrier + synchronisation; `ms_per_step_min` / `_max`, `timed_regions`, `timed_ms_total`); beside the contract's fields:
+  `roofline`            the longest kernel of the step (picked from a stage pass in the warm-up): the matrix-core kernel on its
+                        algorithmic flops over its HIP-event duration against the fp64 peak, or -- when the per-walker kernel is the
+                        longest -- `bound: "latency"`, `frac: null`, its shares of wave cycles, and the matrix-core kernel beside it;
   `roofline_step`       the whole step against the HBM roofline (rocprofv3 PMC bytes of the committed profile / ms_per_step);
+  `step_kernels`        the three kernels of the step: duration, bound, PMC bytes, shares of wave cycles;
   `north_star_abel_map_kernel`  the fused profile -> Abel -> spline -> full S x S map kernel the north_star's ">= 60 % of
                         the HBM roofline" is about (jx_map_kernel_time), against the nominal and the measured copy roofline;
   `north_star_route`    the whole step of north_star's literal design (that kernel, then the rocFFT sequence) on the same walkers;
-  `host_pointer`        jx_eval with host pointers, one synchronisation per call: the path emcee exercises;
-  `gather_ms_per_step`  (N > 1, or JOXSZ_BENCH_FORCE_DIST=1) the all-gather's own duration on its stream;
+  `legacy_contracted_route`, `collapsed_route`   the contracted forms of round 4 and the collapsed (operator) route of the same library
+                        on the same walkers: rate, stage times, difference to the default, error against the oracle sample;
+  `host_pointer`        jx_eval with host pointers, one synchronisation per call, at 15 / 128 / 1024 walkers per call: the path emcee exercises;
+  `device_sampler`      jx_sample (with the communicator on the context in the N > 1 rehearsal: `exchange_ms_per_half_step`);
+  `gather_ms_per_step`  (N > 1, or JOXSZ_BENCH_FORCE_DIST=1) the all-gather's own duration on its stream (strict mode: the headline);
   `cpu_baseline`        the numpy/scipy oracle on this box's host cores (process pool, single process, per-stage ms);
   `other_configs`       strong-scaling rows of BASELINE configs[3] and configs[4] (this rank's shard).
 """
@@ -280,7 +285,7 @@ def with_env(env, fn):
 
 # what the kernels of a step are called and what bounds them, by form of the SZ side (jx_get_conv_layout)
 STEP_KERNELS = {
-    'exact': [('prep_ms', 'jx_prep_kernel', 'priors, vetoes, X-ray Cash likelihood, pressure and temperature profiles, conversion factors (one or two blocks per walker)',
+    'exact': [('prep_ms', 'jx_walker2_kernel', 'per-walker work as two lean roles in one launch: parameters, priors, grid pass (pressure, mass veto, T_SZ), h(0), conversion factors | X-ray profiles, count rates, projection, Cash sum',
                'latency: a chain of dependent phases and fp64 exp/log chains; no flop or byte count prices it (its share of wave cycles is listed)'),
               ('abel_map_ms', 'jx_ordrow_kernel', 'ordinate product y = y_scale A pp (forward Abel transform + Compton-y scale) and each column-tile pair\'s share of the row product out = Wy y, fp64 matrix cores',
                'mfma (v_mfma_f64_16x16x4)'),
@@ -575,9 +580,9 @@ def main():
             if comm is not None:
                 # (N > 1 or the rehearsal at N = 1: the same run with the communicator on the context shards each half step over the ranks and
                 #  all-gathers positions and log-posteriors in place -- two collectives per half step; the difference to the run above is their cost)
-                samp['exchange_ms_per_half_step'] = 0.5 * samp['ms_per_step'] - 0.5 * 1e3 * (elapsed / args.steps)
+                samp['exchange_ms_per_half_step'] = 0.5 * samp['ms_per_step'] - 1e3 * (elapsed / args.steps)
                 samp['exchange_note'] = ('with a communicator on the context jx_sample moves this rank\'s share of each half step and exchanges positions and log-posteriors by two '
-                                         'in-place RCCL all-gathers: half a sampler step minus one evaluation step of the same %d walkers' % W)
+                                         'in-place RCCL all-gathers: half a sampler step (one half step) minus one evaluation step of the same %d walkers (which carries the log-probability gather)' % W)
         except Exception as exc:
             samp = {'error': str(exc)}
 

@@ -1,12 +1,16 @@
 // C-ABI implementation (include/joxsz_hip.h) for gfx950: context, uploads, table building and the per-chunk launch
-// sequence.  Two back ends for the SZ side of the log-posterior (joxsz_funcs.py:457-472):
-//   * the contracted route (jx_mix.hpp; default): the sum over map rows is taken before any transform -- low-rank form
-//     (stage 1 on the vector units + stage 2 on the matrix cores) or full form (one matrix-core product fed by the sample
-//     evaluation), chosen at jx_finalize by the cost of each;
-//   * the rocFFT sequence (2-D R2C -> beam multiply -> C2R -> R2C of the S x S window): the independent cross-check, the
-//     fallback for inputs without the mirror structure, and -- as a small reference facility inside every contracted-route
-//     context -- the source of the beam-convolved-map tap and of the truncation probe.
-// The environment is read once, in jx_finalize; nothing on the launch path calls getenv.
+// sequence.  The SZ side of the log-posterior (joxsz_funcs.py:457-472) behind the Compton-y profile:
+//   * the exact form (jx_exact.hpp; default since round 5): the spline, the map, the beam convolution, the transfer function and the row
+//     extraction as ONE constant operator on the spline ordinates, built on the host at jx_finalize (jx_tables.hpp: every pixel, every
+//     radius, nothing truncated) -- per step: jx_walker2_kernel -> jx_ordrow_kernel -> jx_rowsum_tail_kernel;
+//   * the contracted forms of rounds 3-4 (jx_mix.hpp; option JOXSZ_MIX_FORM=legacy|lowrank|full, kept for one round): low-rank (stage 1 on
+//     the vector units + stage 2 on the matrix cores) or full (one matrix-core product fed by the sample evaluation), with their
+//     truncation guard;
+//   * the rocFFT sequence (2-D R2C -> beam multiply -> C2R -> R2C of the S x S window): the reference's lines executed literally -- the
+//     independent cross-check, the fallback for inputs without the mirror structure, and, as a small reference facility inside every other
+//     context, the source of the beam-convolved-map tap and of jx_audit.
+// Every switch is an option of the context (jx_set_option; the process environment is the default of each name), read once, in
+// jx_finalize; nothing on the launch path calls getenv.
 #include <hip/hip_runtime.h>
 #include <rocfft/rocfft.h>
 #include <rccl/rccl.h>

@@ -1,5 +1,6 @@
-// Contracted route of the SZ side (round 3; default): the sum over map rows is taken BEFORE any transform, so no row is
-// ever transformed and no row spectrum ever reaches HBM.
+// Contracted forms of the SZ side (rounds 3-4; the default until round 4, since round 5 behind the option JOXSZ_MIX_FORM=legacy|lowrank|full
+// and kept for one round beside the exact form of jx_exact.hpp, which replaced them: DESIGN 10): the sum over map rows is taken BEFORE any
+// transform, so no row is ever transformed and no row spectrum ever reaches HBM.
 //
 // Reference lines computed (joxsz_funcs.py:462-467, row of :472):
 //     y_2d    = f(d_mat)                                     S x S samples of the mirrored cubic spline

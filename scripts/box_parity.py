@@ -1,5 +1,5 @@
-"""Walkers drawn uniformly over the whole prior box through the default route against the CPU oracle, with the route's approximations
-switched off one at a time: which of them the worst walker's error belongs to.   python scripts/box_parity.py [S N nwalkers]   (GPU box)"""
+"""Walkers drawn uniformly over the whole prior box through the default route (the exact form) against the CPU oracle, beside the other
+routes of the same library on the same walkers.   python scripts/box_parity.py [S N nwalkers]   (GPU box)"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -26,9 +26,9 @@ for k, ip in enumerate(pb.thawed_idx):
 want = orc.log_posterior_batch(pb, th)
 fin = np.isfinite(want)
 print('S=%d N=%d: %d of %d box-uniform walkers finite' % (S, N, fin.sum(), nw))
-extra = [('sub-grid ' + v, {'JOXSZ_MIX_SUBSAMPLE': v}) for v in os.environ.get('BOX_SUBGRIDS', '').split(';') if v]
-for name, env in extra + [('default', {}), ('every radius of the profile', {'JOXSZ_AG_SUBSAMPLE': '0'}), ('every distinct map sample', {'JOXSZ_MIX_SUBSAMPLE': '0'}), ("device library's exp / log", {'JOXSZ_PREP_FASTMATH': '0'}),
-                  ('full form', {'JOXSZ_MIX_FORM': 'full'}), ('full form, every sample', {'JOXSZ_MIX_FORM': 'full', 'JOXSZ_MIX_SUBSAMPLE': '0'}),
+for name, env in [('default (exact form)', {}), ("device library's exp / log", {'JOXSZ_PREP_FASTMATH': '0'}), ('reference kernels of the exact form', {'JOXSZ_X_PAIRWISE': '0'}),
+                  ('contracted forms of round 4', {'JOXSZ_MIX_FORM': 'legacy', 'JOXSZ_QUIET': '1'}),
+                  ('round 4 full form, every sample', {'JOXSZ_MIX_FORM': 'full', 'JOXSZ_MIX_SUBSAMPLE': '0', 'JOXSZ_AG_SUBSAMPLE': '0', 'JOXSZ_QUIET': '1'}),
                   ('rocFFT sequence', {'JOXSZ_CONV': 'rocfft'})]:
     for k, v in env.items(): os.environ[k] = v
     post = JoxszPosterior(pb, device=0)
@@ -39,5 +39,5 @@ for name, env in extra + [('default', {}), ('every radius of the profile', {'JOX
     for k in env: del os.environ[k]
     rel = np.abs(got[fin] - want[fin]) / np.abs(want[fin])
     i = int(np.argmax(rel))
-    print('%-28s form %-8s same rejections %s | log-posterior rel err max %.2e (walker %d: logp %.6g, chi^2 %.4g) median %.2e'
+    print('%-36s form %-8s same rejections %s | log-posterior rel err max %.2e (walker %d: logp %.6g, chi^2 %.4g) median %.2e'
           % (name, lay.get('form', '-'), np.array_equal(np.isfinite(got), fin), rel.max(), np.flatnonzero(fin)[i], want[fin][i], chi[fin][i], np.median(rel)), flush=True)

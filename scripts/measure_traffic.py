@@ -23,7 +23,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def collect(counter, outdir):
     cmd = ['rocprofv3', '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', outdir, '--',
-           sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '1', '--no-cpu', '--no-f32', '--no-other-configs', '--no-host-pointer']
+           sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '1', '--no-cpu', '--no-f32', '--no-other-configs', '--no-other-routes', '--no-host-pointer', '--regions', '2']
     env = dict(os.environ, TMPDIR='/tmp')
     res = subprocess.run(cmd, check=True, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
     collect.bench = json.loads(res.stdout.strip().splitlines()[-1])

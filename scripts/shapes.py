@@ -82,4 +82,4 @@ for label, S, N, W, measured, kw, dtype in cases:
              ('centre row %.1e, box SZ-like %.1e, cut %.0e%s' % (tr['est_rel_row_err'], tr['est_rel_sz_like_err_box'], tr['tol'], ', tightened x%d' % tr['retried'] if tr['retried'] else '')) if tr.get('points') else 'n/a (exact form)',
              dt, np.max(np.abs(a[fin] - b[fin]) / np.abs(b[fin])),
              (', |d chi2/2| %.1e' % (np.max(np.abs(chi_a[fin] - chi_b[fin])) / 2)) if chi_a is not None else '',
-             np.max(np.abs(a[:2] - want) / np.abs(want))), flush=True)
+             max([abs(x - y) / abs(y) for x, y in zip(a[:2], want) if np.isfinite(y)] or [0.0])), flush=True)

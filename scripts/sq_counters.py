@@ -16,7 +16,7 @@ CNT = ['SQ_WAVE_CYCLES', 'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY'
 def main():
     out = os.path.join(ROOT, 'gpurun_out', 'sq_pmc')
     cmd = ['rocprofv3', '--kernel-trace', '--pmc'] + CNT + ['--output-format', 'csv', '-d', out, '--',
-           sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '1', '--no-cpu', '--no-full-map', '--no-f32', '--no-other-configs', '--no-host-pointer']
+           sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '1', '--no-cpu', '--no-full-map', '--no-f32', '--no-other-configs', '--no-other-routes', '--no-host-pointer', '--regions', '2']
     subprocess.run(cmd, check=True, env=dict(os.environ, TMPDIR='/tmp'), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     f = glob.glob(out + '/*/*counter_collection.csv')[0]
     rows = list(csv.DictReader(open(f)))

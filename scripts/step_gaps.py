@@ -5,13 +5,13 @@ import csv, glob, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(ROOT, 'gpurun_out', 'gaps')
 subprocess.run(['rocprofv3', '--kernel-trace', '--output-format', 'csv', '-d', out, '--', sys.executable, os.path.join(ROOT, 'bench.py'),
-                '--steps', '20', '--warmup', '5', '--no-cpu', '--no-full-map', '--no-f32', '--no-other-configs', '--no-host-pointer'], check=True, env=dict(os.environ, TMPDIR='/tmp'),
+                '--steps', '20', '--warmup', '5', '--no-cpu', '--no-full-map', '--no-f32', '--no-other-configs', '--no-other-routes', '--no-host-pointer', '--regions', '2'], check=True, env=dict(os.environ, TMPDIR='/tmp'),
                stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 f = sorted(glob.glob(out + '/*/*kernel_trace.csv'))[-1]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
 names = [r['Kernel_Name'].split('(')[0][:40] for r in rows]
 # steady state: the last 10 occurrences of the tail kernel delimit 10 steps
-tails = [i for i, n in enumerate(names) if 'jx_tail_row_kernel' in n]
+tails = [i for i, n in enumerate(names) if 'jx_rowsum_tail_kernel' in n or 'jx_tail_row_kernel' in n]
 lo, hi = tails[-11], tails[-1]
 busy = gap = 0
 per = {}

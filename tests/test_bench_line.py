@@ -1,10 +1,13 @@
-"""The bench line committed with the round (profiles/r04_bench.json, written by bench.py on an MI355X) carries every field of
+"""The bench line committed with the round (profiles/r05_bench.json, written by bench.py on an MI355X) carries every field of
 the driver's contract and of SURVEY 8(d): metric / config of BASELINE.json, roofline and cpu_baseline objects, figures that
-hang together."""
+hang together -- and what VERDICT r04 asked of it: a median over repeated regions, the literal / contracted / collapsed routes
+beside the default with their error against the oracle, the host-pointer path at the reference's own ensemble size."""
+import csv
 import json
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TAG = 'r05'
 
 
 def _line(name):
@@ -13,7 +16,7 @@ def _line(name):
 
 
 def test_committed_bench_line_follows_the_contract():
-    d = _line('r04_bench.json')
+    d = _line(TAG + '_bench.json')
     base = json.load(open(os.path.join(ROOT, 'BASELINE.json')))
     assert d['metric'].split(';')[0] == base['metric'].split(';')[0].replace('²', '^2')
     for k in ('value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config'):
@@ -21,26 +24,23 @@ def test_committed_bench_line_follows_the_contract():
     assert d['n_gpus'] == 1 and d['higher_is_better'] is True and d['scaling'] == 'weak' and d['vs_baseline'] is None
     assert d['dtype'] == 'f64' and d['data'] == 'synthetic' and 'workload' in d['config'] and 'model' not in d['config']
     assert '1024 walkers' in d['config']['workload'] and '512x512' in d['config']['workload']
-    # value = walkers per step / time per step
+    # value = walkers per step / time per step, the time a MEDIAN over at least 25 regions and 50 ms of timed work
     assert abs(d['value'] - d['config']['walkers_per_gpu'] / (d['ms_per_step'] * 1e-3)) <= 1e-6 * d['value']
+    assert d['timed_regions'] >= 25 and d['timed_ms_total'] >= 50.0
+    assert d['ms_per_step_min'] <= d['ms_per_step'] <= d['ms_per_step_max'] <= 1.5 * d['ms_per_step_min']
     assert d['value'] >= 10000                                            # north_star's target on one MI355X
-    r = d['roofline']
-    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'kernel', 'launch_ms'):
-        assert k in r, k
-    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9 and 0 < r['frac'] < 1 and r['traffic'] is not None
-    # achieved = algorithmic flops of the launch / the kernel's measured duration
-    assert abs(r['achieved'] - r['flops_per_launch'] / (r['launch_ms'] * 1e-3) / 1e12) < 1e-6 * r['achieved']
+    assert d['ms_per_step'] <= 0.060
     c = d['cpu_baseline']
     for k in ('value', 'unit', 'cores', 'kind', 'sample'):
         assert k in c, k
     assert c['kind'] == 'port' and c['cores'] >= 1 and c['unit'] == d['unit'] and c['value'] > 0
     assert 'single_process' in c and 'stage_ms_per_call' in c
-    assert d['parity_max_rel_err'] <= 1e-6                                # north_star's tolerance, checked inside the run
+    assert d['parity_max_rel_err'] <= 1e-12                               # checked inside the run, on ~7 500 walkers (north_star's bar: 1e-6)
     ns = d['north_star_abel_map_kernel']
     assert ns['frac_of_hbm_peak'] >= 0.60                                 # north_star: >= 60 % of the HBM roofline in the Abel+map kernel
     assert abs(ns['achieved_GBps'] - ns['bytes_per_launch'] / (ns['launch_ms'] * 1e-3) / 1e9) < 1e-6 * ns['achieved_GBps']
-    t = d['truncation']
-    assert t['points'] >= 9 and 0 <= t['est_rel_row_err'] <= t['bound'] and 0 <= t['est_rel_sz_like_err_box'] <= 1e-8
+    cfg = d['config']
+    assert cfg['form'] == 'exact' and cfg['truncation'] == 'none' and cfg['sampling'] == 'none' and cfg['radial_sampling'] == 'none'
     assert d['n_ranks_seen'] == 1
 
 
@@ -54,76 +54,96 @@ def _fracs(o, path=''):
 
 
 def test_every_roofline_figure_of_the_line_follows_from_the_profiles():
-    """roofline_step summed the stream micro-benchmarks of the PMC file (frac 2.71).  Every fraction of the line is
-    now in (0, 1]; the step's HBM bytes are exactly the five kernels of the step in the committed PMC file of this round; the
-    product's flops count the outputs it computes; the two objects the judge asked for are there."""
-    d = _line('r04_bench.json')
+    """Every fraction of the line is in (0, 1] (or null where nothing prices the kernel); the step's HBM bytes are exactly the three
+    kernels of the step in the committed PMC file of this round; the matrix-core kernel is priced on its algorithmic flops."""
+    d = _line(TAG + '_bench.json')
     fr = dict(_fracs(d))
-    assert len(fr) >= 6
+    assert len(fr) >= 5
     for k, v in fr.items():
         assert v is None or 0 < v <= 1.0, (k, v)
+    r = d['roofline']
+    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'kernel', 'launch_ms', 'share_of_wave_cycles'):
+        assert k in r, k
+    assert r['traffic'] is not None and r['launch_ms'] > 0
+    names = {'jx_walker2_kernel', 'jx_ordrow_kernel', 'jx_rowsum_tail_kernel'}
+    assert r['kernel'] in names
+    if r['bound'] == 'mfma':
+        assert r['kernel'] == 'jx_ordrow_kernel' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
+        assert abs(r['achieved'] - r['flops_per_launch'] / (r['launch_ms'] * 1e-3) / 1e12) < 1e-6 * r['achieved']
+        nk, nout, N = r['ordinates'], r['outputs_computed'], d['config']['N']
+        assert abs(r['flops_per_launch'] - 2.0 * (sum(N - k for k in range(nk)) + nout * nk) * 1024) < 1e-6 * r['flops_per_launch']
+        assert nout == d['config']['output_pruning']['outputs_computed'] and nk == d['config']['conv_layout']['rank']
+    else:                                                                 # the per-walker kernel is the longest: nothing prices a chain of dependent phases
+        assert r['bound'] == 'latency' and r['frac'] is None and r['matrix_core_kernel']['frac'] > 0
     rs = d['roofline_step']
-    assert rs['traffic_source'] == 'profiles/r04_pmc_traffic.json' and rs['traffic_measured_in_this_run'] is False
+    assert rs['traffic_source'] == 'profiles/%s_pmc_traffic.json' % TAG and rs['traffic_measured_in_this_run'] is False
     pj = json.load(open(os.path.join(ROOT, rs['traffic_source'])))
-    names = {'jx_prep_kernel', 'jx_abel_gemm_kernel', 'jx_rowmix_kernel', 'jx_opgemm_kernel', 'jx_tail_row_kernel'}
     assert set(rs['traffic_by_kernel']) == names
     import bench
-    want = sum(bench.pmc_kernel_entry(pj, n)['total_bytes'] for n in names)      # (the full-size instance of each kernel template)
+    want = sum(bench.pmc_kernel_entry(pj, n)['total_bytes'] for n in names)      # (the full-size instance of each kernel)
     assert abs(rs['traffic_bytes_per_step'] - want) <= 1e-9 * want and abs(sum(rs['traffic_by_kernel'].values()) - want) <= 1e-9 * want
-    assert 0.05 < rs['frac'] < 0.5 and abs(rs['frac'] - rs['traffic_bytes_per_step'] / (rs['ms_per_step'] * 1e-3) / 1e9 / rs['peak']) < 1e-9
-    rp = d['roofline_product']
-    assert rp['outputs_computed'] == d['config']['output_pruning']['outputs_computed'] <= rp['outputs_of_the_row']
-    assert abs(rp['achieved'] - rp['flops_per_launch'] / (rp['launch_ms'] * 1e-3) / 1e12) < 1e-6 * rp['achieved']
+    assert 0.02 < rs['frac'] < 0.5 and abs(rs['frac'] - rs['traffic_bytes_per_step'] / (rs['ms_per_step'] * 1e-3) / 1e9 / rs['peak']) < 1e-9
+    assert rs['traffic_bytes_per_step'] < 0.05 * rs['survey_8d_bytes_per_step']   # no map, spectrum or convolved map is ever stored
+    sk = {k['kernel']: k for k in d['step_kernels']}
+    assert set(sk) == names and all(0 < k['share_of_wave_cycles']['issuing_valu'] < 1 for k in d['step_kernels'])
+
+
+def test_the_other_routes_of_the_library_are_in_the_line():
+    """literal | contracted | collapsed beside the default, each with its rate and its error against the oracle sample; the
+    host-pointer path at 15, 128 and 1024 walkers per call; the device sampler."""
+    d = _line(TAG + '_bench.json')
     ns = d['north_star_route']                                           # north_star's literal design as a whole step
-    assert 'rocFFT' in ns['route'] and ns['walkers_per_launch'] == 1024 and ns['ms_per_step'] > d['ms_per_step'] and ns['max_rel_diff_vs_default_route'] < 1e-9
+    assert 'rocFFT' in ns['route'] and ns['walkers_per_launch'] == 1024 and ns['ms_per_step'] > d['ms_per_step'] and ns['max_rel_diff_vs_default_route'] < 1e-12
     assert abs(ns['speedup_of_default_route'] - ns['ms_per_step'] / d['ms_per_step']) < 1e-9 * ns['speedup_of_default_route']
+    assert 0 < ns['frac_of_hbm_peak_on_survey_8d_bytes'] < 0.2
+    co, lg = d['collapsed_route'], d['legacy_contracted_route']
+    assert co['max_rel_err_vs_oracle_sample'] <= 1e-12 and co['max_rel_diff_vs_default_route'] <= 1e-13 and co['value'] > 0.5 * d['value']
+    assert lg['form'] in ('lowrank', 'full') and 1e-13 < lg['max_rel_err_vs_oracle_sample'] <= 1e-6 and lg['ms_per_step'] > d['ms_per_step']
+    assert lg['truncation']['rank'] > 0 and lg['sampling']['active'] and lg['radial_sampling']['active']      # what the default no longer has
     hp = d['host_pointer']                                               # the path emcee calls
-    assert hp['max_abs_diff_vs_device_resident'] == 0.0 and 0.5 * d['value'] < hp['value'] <= 1.02 * d['value']
+    assert set(hp['calls']) == {'15', '128', '1024'} and hp['max_abs_diff_vs_device_resident'] == 0.0
+    assert hp['calls']['15']['ms_per_call'] <= hp['calls']['1024']['ms_per_call'] and 0.5 * d['value'] < hp['value'] <= 1.02 * d['value']
     ds = d['device_sampler']                                            # the caller of the path: the device-resident stretch-move loop
-    assert ds['finite'] and 0.2 < ds['acceptance'] < 0.6 and 0.7 * d['value'] < ds['value'] < 1.1 * d['value']
+    assert ds['finite'] and 0.2 < ds['acceptance'] < 0.6 and 0.6 * d['value'] < ds['value'] < 1.1 * d['value']
     fv = d['fp32_variant']
-    assert fv['f32']['rel_dlogp_vs_f64']['max'] < 1e-8 and fv['f32c']['rel_dlogp_vs_f64']['max'] < 1e-6 and fv['f32c']['speedup_vs_f64'] > 1.05
+    assert fv['f32']['rel_dlogp_vs_f64']['max'] < 1e-8 and fv['f32c']['rel_dlogp_vs_f64']['max'] < 1e-6 and fv['f32c']['form'] == 'lowrank'
+    assert fv['f32c']['abs_dchisq_half_vs_f64']['max'] > 1e-6                       # (documented: outside the absolute bar the fp64 tests hold)
     oc = d['other_configs']
     assert 'error' not in oc and all(oc[k]['value'] > 0 for k in ('configs[3]', 'configs[4] f64', 'configs[4] f32c'))
+    assert oc['configs[4] f64']['conv_layout']['form'] == 'exact'
 
 
-def test_the_rehearsed_n_gt_1_lines_carry_the_gather_time():
-    for name, mode in (('r04_bench_force_dist_overlap.json', 'overlapped'), ('r04_bench_force_dist_strict.json', 'strict'), ('r04_bench_force_dist.json', None)):
-        f = _line(name)
-        assert f['n_ranks_seen'] == 1 and 0 < f['gather_ms_per_step'] < 0.05 and f['gather_ms_per_step'] < 0.2 * f['ms_per_step']
-        pr = f['config']['gather_probe_ms_per_step']
-        if mode is not None:
-            assert f['config']['gather'].startswith(mode) and pr is None
-        else:
-            # no mode pinned: the warm-up ran both and the timed region took the faster (the ranks agree through one max-reduction each)
-            assert set(pr) == {'overlapped', 'strict'} and f['config']['gather'].startswith(min(pr, key=pr.get))
+def test_the_rehearsed_n_gt_1_lines_carry_the_gather_and_the_sampler_exchange():
+    """The N > 1 plumbing at N = 1 (RCCL communicator of one rank): strict gather is the headline mode, the overlapped one is probed in the
+    warm-up and reported; the sharded sampler's exchange has its own figure."""
+    f = _line(TAG + '_bench_force_dist.json')
+    assert f['n_ranks_seen'] == 1 and 0 < f['gather_ms_per_step'] < 0.05 and f['gather_ms_per_step'] < 0.3 * f['ms_per_step']
+    assert f['config']['gather'].startswith('strict') and set(f['config']['gather_probe_ms_per_step']) == {'overlapped', 'strict'}
+    assert f['device_sampler']['finite'] and f['device_sampler']['exchange_ms_per_half_step'] is not None
+    o = _line(TAG + '_bench_force_dist_overlap.json')
+    assert o['config']['gather'].startswith('overlapped') and o['config']['gather_probe_ms_per_step'] is None
+    d = _line(TAG + '_bench.json')
+    assert abs(f['value'] - d['value']) <= 0.15 * d['value']              # the gather and its events cost a few microseconds at N = 1
 
 
 def test_rocprof_kernel_statistics_agree_with_the_bench_line():
-    """profiles/r04_kernel_stats.csv (rocprofv3 --kernel-trace of the same command, full-size launches only): the dominant
-    kernel's average duration within 10 % of the HIP-event duration the roofline is computed from."""
-    import csv
-    d = _line('r04_bench.json')
-    rows = list(csv.DictReader(open(os.path.join(ROOT, 'profiles', 'r04_kernel_stats.csv'))))
-    # (since the sub-grid of stage 1 no kernel dominates: the per-walker kernel, stage 1 and the spline-array product lie within 15 %
-    # of one another; `roofline` stays with stage 1, the one with the arithmetic, and `step_kernels` lists all five)
-    top = [r for r in rows[:3] if d['roofline']['kernel'] in r['Name']][0]
-    assert float(top['AverageUs']) >= 0.90 * float(rows[0]['AverageUs'])
-    lk = d['roofline']['longest_kernel_of_the_step']
-    assert lk['kernel'] in rows[0]['Name'] or abs(lk['ms_hip_events_stage_pass'] - max(k['ms_hip_events_stage_pass'] for k in d['step_kernels'])) < 1e-12
+    """profiles/r05_kernel_stats.csv (rocprofv3 --kernel-trace of the same command, full-size launches only): three kernels per step; each
+    kernel's average within its HIP-event duration of the stage pass; the roofline kernel's launch_ms likewise; the kernels add up to the step."""
+    d = _line(TAG + '_bench.json')
+    rows = list(csv.DictReader(open(os.path.join(ROOT, 'profiles', TAG + '_kernel_stats.csv'))))
     sk = {k['kernel']: k for k in d['step_kernels']}
-    assert len(sk) == 5 and all(0 < k['share_of_wave_cycles']['issuing_valu'] < 1 for k in d['step_kernels'])
-    for r in rows[:5]:
-        name = [k for k in sk if k in r['Name']][0]
-        ev = sk[name]['ms_hip_events_stage_pass']
-        assert float(r['AverageUs']) * 1e-3 <= ev * 1.02 and ev <= float(r['AverageUs']) * 1e-3 + d['roofline']['launch_ms_of_an_empty_kernel'] + 0.0015, (name, ev, r['AverageUs'])
-    # (a pair of HIP events around a kernel of a dependent chain also spans the hand-over in front of and behind it: what the pair
-    # reads around an empty kernel is reported beside launch_ms; rocprofv3 counts the kernel alone)
+    # (VERDICT r04 item 2: three launches per step -- every other kernel of the trace is set-up, a tap or the empty-kernel measurement)
+    most = max(int(r['FullSizeCalls']) for r in rows)
+    step = [r for r in rows if int(r['FullSizeCalls']) == most]
+    assert len(step) == 3 and all(any(k in r['Name'] for k in sk) for r in step)
     roof = d['roofline']
     assert 0 < roof['launch_ms_of_an_empty_kernel'] < 0.010
-    assert roof['launch_ms'] - roof['launch_ms_of_an_empty_kernel'] - 0.05 * roof['launch_ms'] <= float(top['AverageUs']) * 1e-3 <= roof['launch_ms'] * 1.02
-    # the kernels of the step add up to the step (launch gaps excluded)
-    step_us = sum(float(r['AverageUs']) for r in rows if int(r['FullSizeCalls']) >= 100)
-    assert 0.85 * d['ms_per_step'] * 1e3 <= step_us <= 1.02 * d['ms_per_step'] * 1e3
-    f = _line('r04_bench_force_dist.json')
-    assert f['n_ranks_seen'] == 1 and abs(f['value'] - d['value']) <= 0.12 * d['value']      # the N > 1 plumbing at N = 1: the gather and its events
+    for r in step:
+        name = [k for k in sk if k in r['Name']][0]
+        ev = sk[name]['ms_hip_events_stage_pass']
+        # (a pair of HIP events around a kernel of a dependent chain also spans the hand-over in front of and behind it)
+        assert float(r['AverageUs']) * 1e-3 <= ev * 1.02 and ev <= float(r['AverageUs']) * 1e-3 + roof['launch_ms_of_an_empty_kernel'] + 0.002, (name, ev, r['AverageUs'])
+        if name == roof['kernel']:
+            assert float(r['AverageUs']) * 1e-3 <= roof['launch_ms'] * 1.02 and roof['launch_ms'] <= float(r['AverageUs']) * 1e-3 + roof['launch_ms_of_an_empty_kernel'] + 0.002
+    step_us = sum(float(r['AverageUs']) for r in step)
+    assert 0.85 * d['ms_per_step'] * 1e3 <= step_us <= 1.05 * d['ms_per_step'] * 1e3

@@ -574,33 +574,51 @@ def test_stretch_move_inside_the_likelihood_kernels_against_the_separate_kernels
 
 
 def test_per_walker_kernel_as_two_blocks_per_walker(monkeypatch):
-    """The timed sequence runs the per-walker kernel as two blocks per walker -- priors, grid pass, mass veto and conversion factors in
-    one, the X-ray model and its Cash sum in the other, the tail adding the two (radial grids up to 640 points).  Against one block per
-    walker (JOXSZ_PREP_SPLIT=0, what every call with taps runs): the same bits for every walker, the rejected ones (box, NaN, r_c > r_s,
-    mass veto, non-positive count rates) included, both density models; and the taps' parts add up to the timed value."""
+    """The timed sequence launches the per-walker work as 2 n blocks of 128 threads -- n for everything but the X-ray side, n for the X-ray side
+    alone; the tail adds the two (radial grids up to 640 points) -- since round 5 as two lean roles of a kernel of their own (jx_walker2_kernel:
+    every table of a block copied into LDS in one batch), or inside jx_prep_kernel (JOXSZ_PREP_LEAN=0).  Against the one-block form of
+    jx_prep_kernel (JOXSZ_PREP_SPLIT=0, what every call with taps runs): the same bits for every walker in all three, the rejected ones (box,
+    NaN, r_c > r_s, mass veto, non-positive count rates) included, both density models, ragged chunks; the taps' parts add up to the timed
+    value; and the headline shape (two trips of the grid pass per lane)."""
     from joxsz_amd import datasets
+    modes = (('one block', {'JOXSZ_PREP_SPLIT': '0'}), ('two blocks in jx_prep_kernel', {'JOXSZ_PREP_LEAN': '0'}), ('two lean roles', {}))
+
+    def run(pb, th, **kw):
+        res = {}
+        for name, env in modes:
+            for k in ('JOXSZ_PREP_SPLIT', 'JOXSZ_PREP_LEAN'):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            post = _post(pb, **kw)
+            res[name] = (post.log_prob(th), post.stage(th, 'parts'))
+            post.close()
+        return res
+
     for kw in ({}, dict(ne_mode='double')):
         pb = datasets.synthetic_problem(S=128, N=150, seed=13, **kw)
         p0 = orc.pars_dict(pb, datasets.fiducial_theta(pb))
         datasets.fill_data(pb, orc.sz_stages(pb, p0)['bright'], orc.calc_profiles(pb, p0), seed=13)
         th = datasets.walker_ball(pb, 300, spread=0.08, seed=13)
         th[7, 2] = np.nan
-        res = {}
-        for sp in ('1', '0'):
-            monkeypatch.setenv('JOXSZ_PREP_SPLIT', sp)
-            post = _post(pb, max_batch=128)                           # (three chunks, the last ragged)
-            res[sp] = (post.log_prob(th), post.stage(th, 'parts'))
-            post.close()
-        a, b = res['1'][0], res['0'][0]
-        np.testing.assert_array_equal(a, b)
+        res = run(pb, th, max_batch=128)                              # (three chunks, the last ragged)
+        a = res['one block'][0]
+        for name, (got, _) in res.items():
+            np.testing.assert_array_equal(got, a, err_msg=name)
         fin = np.isfinite(a)
         assert 30 < fin.sum() < 300
-        parts = res['1'][1]
+        parts = res['two lean roles'][1]
         np.testing.assert_allclose(a[fin], parts[fin, 0] + parts[fin, 1] + parts[fin, 2], rtol=1e-13)
         want = orc.log_posterior_batch(pb, th[:12])
         ok = np.isfinite(want)
         assert np.array_equal(np.isfinite(a[:12]), ok)
         np.testing.assert_allclose(a[:12][ok], want[ok], rtol=1e-9)
+    pb = datasets.synthetic_problem(S=512, N=500, seed=12)
+    th = datasets.walker_ball(pb, 200, spread=0.05, seed=12)
+    res = run(pb, th)
+    for name, (got, _) in res.items():
+        np.testing.assert_array_equal(got, res['one block'][0], err_msg=name)
+    assert np.isfinite(res['one block'][0]).sum() >= 100
 
 
 def test_largest_config_shape():
