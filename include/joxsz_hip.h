@@ -171,6 +171,8 @@ int  jx_finalize(jx_ctx* ctx);
  *   JOXSZ_PRUNE_OUTPUTS          1|0 (1)                   0: the row product computes every output of the row, read by the data-radii spline or not
  *   JOXSZ_CHUNK                  walkers                   overrides jx_config.max_batch
  *   JOXSZ_FFT_PAD, JOXSZ_MAP_SPLIT, JOXSZ_MAP_PAIR         rocFFT sequence / Abel + map kernel: padded side, row slabs per walker, two walkers per block (1)
+ *   JOXSZ_FFT_COLUMNS            custom|rocfft (custom)    rocFFT sequence: its column passes hand-written (jx_fft.hpp: rocFFT transforms the rows, one kernel per column group does
+ *                                                          forward, times the beam spectrum, inverse) wherever both sides are 2^a 3^b 5^c and <= 1280; rocfft: rocFFT's own 2-D plans
  *   JOXSZ_EVAL_DIRECT            0..3 (3)                  jx_eval: bit 0 the tail stores into the caller-visible host buffer, bit 1 the per-walker kernel reads theta from it
  *   JOXSZ_PREP_SPLIT             1|0 (1)                   per-walker kernel as two blocks per walker (X-ray side beside the rest); same bits
  *   JOXSZ_PREP_LEAN              1|0 (1)                   the two-block form as jx_walker2_kernel (every table of a block in one batched copy into LDS); 0: inside jx_prep_kernel; same bits

@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <cctype>
+#include <functional>
 #include <map>
 #include <string>
 #include <vector>
@@ -31,12 +32,14 @@
 #include "jx_kernels.hpp"
 #include "jx_mix.hpp"
 #include "jx_exact.hpp"
+#include "jx_fft.hpp"
 #include "jx_tables.hpp"
 
 namespace {
 
 struct Plan3 {
-    rocfft_plan beam_fwd = nullptr, beam_inv = nullptr, tf_fwd = nullptr;
+    rocfft_plan beam_fwd = nullptr, beam_inv = nullptr, tf_fwd = nullptr;         // 2-D plans (JOXSZ_FFT_COLUMNS=rocfft, or a side that is not 2^a 3^b 5^c)
+    rocfft_plan row_fwd = nullptr, row_inv = nullptr, row_tf = nullptr;           // batched 1-D row plans beside the column kernels of jx_fft.hpp
 };
 
 struct EvSet {
@@ -57,6 +60,13 @@ struct FftBack {
     size_t map_lds = 0;
     double *img = nullptr, *conv = nullptr;
     double2 *spec = nullptr, *tfspec = nullptr;
+    // hand-written column passes (jx_fft.hpp): rows of the padded image kept (S: the zero rows are never stored), leading dimensions of the
+    // row spectra (multiples of 8 complex), columns per block, the two transforms, the tables in those leading dimensions, Z of the tail
+    bool cols = false;
+    int rows = 0, ldc = 0, ldt = 0;
+    JxFft fP{}, fS{};
+    double2 *bhat_p = nullptr, *htab_p = nullptr;
+    double* zbuf = nullptr;
     std::map<int, Plan3> plans;
     rocfft_execution_info info = nullptr;
     void* work = nullptr;
@@ -301,7 +311,7 @@ static std::vector<T> host_vec(jx_ctx* ctx, int id) {
 // SAMPLE_ ones), with the process environment as the default of each.  The list is the one include/joxsz_hip.h documents
 // (tests/test_abi.py holds the two and the uses in this file together).
 static const char* const kOptions[] = {
-    "JOXSZ_CONV", "JOXSZ_MIX_FORM", "JOXSZ_X_PAIRWISE", "JOXSZ_PRUNE_OUTPUTS", "JOXSZ_CHUNK", "JOXSZ_FFT_PAD", "JOXSZ_MAP_SPLIT", "JOXSZ_MAP_PAIR",
+    "JOXSZ_CONV", "JOXSZ_MIX_FORM", "JOXSZ_X_PAIRWISE", "JOXSZ_PRUNE_OUTPUTS", "JOXSZ_CHUNK", "JOXSZ_FFT_PAD", "JOXSZ_FFT_COLUMNS", "JOXSZ_MAP_SPLIT", "JOXSZ_MAP_PAIR",
     "JOXSZ_EVAL_DIRECT", "JOXSZ_PREP_SPLIT", "JOXSZ_PREP_LEAN", "JOXSZ_PREP_POW", "JOXSZ_PREP_FASTMATH", "JOXSZ_OP_NARROW", "JOXSZ_SAMPLE_FUSED", "JOXSZ_SAMPLE_VIRTUAL_RANKS",
     // the contracted forms of rounds 3-4 (JOXSZ_MIX_FORM=legacy|lowrank|full)
     "JOXSZ_LOWRANK_TOL", "JOXSZ_TRUNC_PROBE", "JOXSZ_TRUNC_BOUND", "JOXSZ_MIX_SUBSAMPLE", "JOXSZ_MIX_RANKCAP", "JOXSZ_MIX_MFMA", "JOXSZ_MIX_USPLIT", "JOXSZ_MIX_WPB",
@@ -420,6 +430,9 @@ static void fft_teardown(FftBack& fb) {
         if (kv.second.beam_fwd) rocfft_plan_destroy(kv.second.beam_fwd);
         if (kv.second.beam_inv) rocfft_plan_destroy(kv.second.beam_inv);
         if (kv.second.tf_fwd) rocfft_plan_destroy(kv.second.tf_fwd);
+        if (kv.second.row_fwd) rocfft_plan_destroy(kv.second.row_fwd);
+        if (kv.second.row_inv) rocfft_plan_destroy(kv.second.row_inv);
+        if (kv.second.row_tf) rocfft_plan_destroy(kv.second.row_tf);
     }
     fb.plans.clear();
     if (fb.info) { rocfft_execution_info_destroy(fb.info); fb.info = nullptr; }
@@ -427,6 +440,90 @@ static void fft_teardown(FftBack& fb) {
     fb.allocs.clear();
     if (fb.work) { (void)hipFree(fb.work); fb.work = nullptr; fb.work_cap = 0; }
     fb.ready = false;
+}
+
+// radices of a transform length for jx_fft.hpp: the split into the fewest passes, among those the one with the least work per thread
+// (butterflies of a column per thread x size of the butterfly); largest radix first (the first pass has no twiddles).  0 passes: the
+// length has a prime factor beyond 5.
+static int fft_factor(int n, int* radix, int tpc = 64) {
+    static const int kR[] = {16, 12, 10, 9, 8, 6, 5, 4, 3, 2};
+    const int first = n > 640 ? 0 : 2;                            // (radices 16 and 12: the 4-columns-per-block kernels only, jx_fft.hpp)
+    std::vector<int> best, cur;
+    double best_cost = 0.0;
+    std::function<void(int, int, double)> go = [&](int rem, int at, double cost) {
+        if (rem == 1) {
+            if (best.empty() || cur.size() < best.size() || (cur.size() == best.size() && cost < best_cost)) { best = cur; best_cost = cost; }
+            return;
+        }
+        if ((int)cur.size() >= JX_FFT_MAXPASS || (!best.empty() && cur.size() >= best.size())) return;
+        for (int i = std::max(at, first); i < (int)(sizeof(kR) / sizeof(kR[0])); ++i) {
+            const int r = kR[i];
+            if (rem % r) continue;
+            cur.push_back(r);
+            go(rem / r, i, cost + (double)((n / r + tpc - 1) / tpc) * r * (std::log2((double)r) + 1.0));
+            cur.pop_back();
+        }
+    };
+    go(n, 0, 0.0);
+    for (size_t i = 0; i < best.size(); ++i) radix[i] = best[i];
+    return (int)best.size();
+}
+
+static int fft_transform(jx_ctx* ctx, FftBack& fb, int n, JxFft& f) {
+    f.n = n;
+    f.npass = fft_factor(n, f.radix);
+    for (int p = 0, ns = 1; p < f.npass; ns *= f.radix[p++]) {
+        f.ns[p] = ns;
+        f.tstep[p] = p ? n / (ns * f.radix[p]) : 0;
+        f.magic[p] = ns > 1 ? (unsigned)((((unsigned long long)1 << 32) + ns - 1) / ns) : 0u;
+    }
+    std::vector<double> root((size_t)2 * n);
+    for (int m = 0; m < n; ++m) {
+        const long double a = -2.0L * 3.14159265358979323846264338327950288L * (long double)m / (long double)n;
+        root[2 * m] = (double)cosl(a); root[2 * m + 1] = (double)sinl(a);
+    }
+    double* p;
+    int rc;
+    if ((rc = dev_put_l(ctx, fb.allocs, root.data(), root.size(), &p))) return rc;
+    f.root = reinterpret_cast<const double2*>(p);
+    return JX_OK;
+}
+
+// the column kernels come per rows-per-lane bound NU = ceil(length / 64): 8 columns per block up to 640, 4 beyond
+#define JX_FFT_NU_OF(n) (((n) + 63) / 64)
+#define JX_FFT_DISPATCH(nu, X) do {                                                                                     \
+        const int nu_ = (nu);                                                                                           \
+        if (nu_ <= 4) { X(8, 4); } else if (nu_ <= 8) { X(8, 8); } else if (nu_ <= 9) { X(8, 9); } else if (nu_ <= 10) { X(8, 10); }   \
+        else if (nu_ <= 16) { X(4, 16); } else if (nu_ <= 17) { X(4, 17); } else { X(4, 20); }                         \
+    } while (0)
+static inline int fft_cb(int n) { return JX_FFT_NU_OF(n) <= 10 ? 8 : 4; }
+// the roots of unity go to LDS when two blocks still fit a compute unit with them
+static inline int fft_roots_in_lds(int n) { return JX_FFT_ROOTS_IN_LDS(fft_cb(n)) ? 1 : 0; }
+
+static void fft_launch_beam(FftBack& fb, int walkers, hipStream_t st, int S) {
+    const int P = fb.P, r = fft_roots_in_lds(P);
+#define X(CB, NU) hipLaunchKernelGGL((jx_fft_beam_cols_kernel<CB, NU>), dim3(fb.ldc / CB, walkers), dim3(64 * CB), JX_FFT_LDS_BYTES(P, CB, r), st, fb.fP, fb.spec, fb.bhat_p, S, fb.ldc)
+    JX_FFT_DISPATCH(JX_FFT_NU_OF(P), X);
+#undef X
+}
+
+static void fft_launch_tf(FftBack& fb, int walkers, hipStream_t st, int Sh) {
+    const int S = fb.fS.n, r = fft_roots_in_lds(S);
+#define X(CB, NU) hipLaunchKernelGGL((jx_fft_tf_cols_kernel<CB, NU>), dim3(fb.ldt / CB, walkers), dim3(64 * CB), JX_FFT_LDS_BYTES(S, CB, r), st, fb.fS, fb.tfspec, fb.htab_p, fb.ldt, Sh, fb.zbuf, r)
+    JX_FFT_DISPATCH(JX_FFT_NU_OF(S), X);
+#undef X
+}
+
+static int fft_kernels(jx_ctx* ctx, FftBack& fb) {
+    const int S = ctx->cfg.S;
+    const int lp = (int)JX_FFT_LDS_BYTES(fb.P, fft_cb(fb.P), 1), ls = (int)JX_FFT_LDS_BYTES(S, fft_cb(S), 1);
+#define X(CB, NU) HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_fft_beam_cols_kernel<CB, NU>, hipFuncAttributeMaxDynamicSharedMemorySize, lp))
+    JX_FFT_DISPATCH(JX_FFT_NU_OF(fb.P), X);
+#undef X
+#define X(CB, NU) HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_fft_tf_cols_kernel<CB, NU>, hipFuncAttributeMaxDynamicSharedMemorySize, ls))
+    JX_FFT_DISPATCH(JX_FFT_NU_OF(S), X);
+#undef X
+    return JX_OK;
 }
 
 // tables (beam spectrum, transfer-function row table) and work buffers for `cap` walkers; P = padded side
@@ -438,7 +535,16 @@ static int fft_setup(jx_ctx* ctx, FftBack& fb, int cap, int P) {
     fb.d = ctx->d;
     JxDev& d = fb.d;
     d.P = P; d.Ph = fb.Ph;
-    d.quad = 0; d.img_ld = P; d.img_ws = (long long)P * P; d.cf_out = nullptr; d.xcol = nullptr;
+    // column passes: hand-written (jx_fft.hpp) when both sides are 2^a 3^b 5^c and short enough for one column per 32 / 64 threads
+    {
+        int rx[JX_FFT_MAXPASS];
+        const char* e = opt_str(ctx, "JOXSZ_FFT_COLUMNS");
+        const bool want = !(e && !strcmp(e, "rocfft"));
+        fb.cols = want && fft_factor(P, rx) > 0 && fft_factor(S, rx) > 0 && std::max(P, S) <= JX_FFT_MAX_PER_THREAD * 64;
+        fb.rows = fb.cols ? S : P;
+        fb.ldc = (fb.Ph + 7) & ~7; fb.ldt = (ctx->Sh + 7) & ~7;
+    }
+    d.quad = 0; d.img_ld = P; d.img_ws = (long long)fb.rows * P; d.cf_out = nullptr; d.xcol = nullptr;
     if (!map_geometry(d, 512, &fb.map_threads, &fb.map_lds, ctx->map_pair != 0)) { ctx->err = "radial grid too long for the LDS-resident spline"; return JX_ERR_UNSUPPORTED; }
     {
         std::vector<double> beam = host_vec<double>(ctx, JX_T_BEAM_2D), bh, H;
@@ -447,11 +553,23 @@ static int fft_setup(jx_ctx* ctx, FftBack& fb, int cap, int P) {
         if ((rc = dev_put_l(ctx, fb.allocs, bh.data(), bh.size(), &p))) return rc; d.bhat = p;
         jxt::tf_row_table(host_vec<double>(ctx, JX_T_FILTERING), S, H);
         if ((rc = dev_put_l(ctx, fb.allocs, H.data(), H.size(), &p))) return rc; d.htab = p;
+        if (fb.cols) {
+            std::vector<double> bp((size_t)2 * P * fb.ldc, 0.0), hp((size_t)2 * S * fb.ldt, 0.0);
+            for (int y = 0; y < P; ++y) std::copy(bh.begin() + (size_t)2 * y * fb.Ph, bh.begin() + (size_t)2 * (y + 1) * fb.Ph, bp.begin() + (size_t)2 * y * fb.ldc);
+            for (int y = 0; y < S; ++y) std::copy(H.begin() + (size_t)2 * y * ctx->Sh, H.begin() + (size_t)2 * (y + 1) * ctx->Sh, hp.begin() + (size_t)2 * y * fb.ldt);
+            if ((rc = dev_put_l(ctx, fb.allocs, bp.data(), bp.size(), &p))) return rc; fb.bhat_p = reinterpret_cast<double2*>(p);
+            if ((rc = dev_put_l(ctx, fb.allocs, hp.data(), hp.size(), &p))) return rc; fb.htab_p = reinterpret_cast<double2*>(p);
+            if ((rc = fft_transform(ctx, fb, P, fb.fP))) return rc;
+            if ((rc = fft_transform(ctx, fb, S, fb.fS))) return rc;
+            if ((rc = dev_new_l(ctx, fb.allocs, (size_t)cap * 2 * ctx->Sh, &fb.zbuf))) return rc;
+            if ((rc = fft_kernels(ctx, fb))) return rc;
+        }
     }
-    if ((rc = dev_new_l(ctx, fb.allocs, (size_t)cap * P * P, &fb.img, true))) return rc;       // padding stays zero for ever
-    if ((rc = dev_new_l(ctx, fb.allocs, (size_t)cap * P * P, &fb.conv))) return rc;
-    if ((rc = dev_new_l(ctx, fb.allocs, (size_t)cap * P * fb.Ph, &fb.spec))) return rc;
-    if ((rc = dev_new_l(ctx, fb.allocs, (size_t)cap * S * ctx->Sh, &fb.tfspec))) return rc;
+    const size_t R = fb.rows;
+    if ((rc = dev_new_l(ctx, fb.allocs, (size_t)cap * R * P, &fb.img, true))) return rc;       // padding stays zero for ever
+    if ((rc = dev_new_l(ctx, fb.allocs, (size_t)cap * R * P, &fb.conv))) return rc;
+    if ((rc = dev_new_l(ctx, fb.allocs, fb.cols ? (size_t)cap * S * fb.ldc : (size_t)cap * P * fb.Ph, &fb.spec, fb.cols))) return rc;
+    if ((rc = dev_new_l(ctx, fb.allocs, fb.cols ? (size_t)cap * S * fb.ldt : (size_t)cap * S * ctx->Sh, &fb.tfspec, fb.cols))) return rc;
     FFTCHK(ctx, rocfft_execution_info_create(&fb.info));
     FFTCHK(ctx, rocfft_execution_info_set_stream(fb.info, ctx->stream));
     HIPCHK(ctx, hipDeviceSynchronize());                        // (the zero fills ran on the null stream)
@@ -464,6 +582,29 @@ static int fft_plans(jx_ctx* ctx, FftBack& fb, int batch, Plan3** out) {
     if (it != fb.plans.end()) { *out = &it->second; return JX_OK; }
     Plan3 pl;
     const size_t P = fb.P, S = ctx->cfg.S, Sh = ctx->Sh;
+    rocfft_plan p1, p2, p3;
+    if (fb.cols) {
+        // rows only: img [batch * S][P] -> spec [batch * S][ldc]; spec -> conv [batch * S][P]; conv's first S columns -> tfspec [batch * S][ldt]
+        auto row_plan = [&](rocfft_plan* out, bool inverse, size_t len, size_t rdist, size_t cdist) -> int {
+            rocfft_plan_description desc = nullptr;
+            FFTCHK(ctx, rocfft_plan_description_create(&desc));
+            size_t one[1] = {1};
+            if (!inverse) FFTCHK(ctx, rocfft_plan_description_set_data_layout(desc, rocfft_array_type_real, rocfft_array_type_hermitian_interleaved,
+                                                                              nullptr, nullptr, 1, one, rdist, 1, one, cdist));
+            else FFTCHK(ctx, rocfft_plan_description_set_data_layout(desc, rocfft_array_type_hermitian_interleaved, rocfft_array_type_real,
+                                                                     nullptr, nullptr, 1, one, cdist, 1, one, rdist));
+            size_t l[1] = {len};
+            FFTCHK(ctx, rocfft_plan_create(out, rocfft_placement_notinplace, inverse ? rocfft_transform_type_real_inverse : rocfft_transform_type_real_forward,
+                                           rocfft_precision_double, 1, l, (size_t)batch * S, desc));
+            rocfft_plan_description_destroy(desc);
+            return JX_OK;
+        };
+        int rc;
+        if ((rc = row_plan(&pl.row_fwd, false, P, P, fb.ldc))) return rc;
+        if ((rc = row_plan(&pl.row_inv, true, P, P, fb.ldc))) return rc;
+        if ((rc = row_plan(&pl.row_tf, false, S, P, fb.ldt))) return rc;
+        p1 = pl.row_fwd; p2 = pl.row_inv; p3 = pl.row_tf;
+    } else {
     {   // beam convolution forward: real [P][P] -> hermitian [P][Ph]
         size_t len[2] = {P, P};
         FFTCHK(ctx, rocfft_plan_create(&pl.beam_fwd, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
@@ -482,10 +623,12 @@ static int fft_plans(jx_ctx* ctx, FftBack& fb, int batch, Plan3** out) {
                                        rocfft_precision_double, 2, len, (size_t)batch, desc));
         rocfft_plan_description_destroy(desc);
     }
+        p1 = pl.beam_fwd; p2 = pl.beam_inv; p3 = pl.tf_fwd;
+    }
     size_t w1 = 0, w2 = 0, w3 = 0;
-    FFTCHK(ctx, rocfft_plan_get_work_buffer_size(pl.beam_fwd, &w1));
-    FFTCHK(ctx, rocfft_plan_get_work_buffer_size(pl.beam_inv, &w2));
-    FFTCHK(ctx, rocfft_plan_get_work_buffer_size(pl.tf_fwd, &w3));
+    FFTCHK(ctx, rocfft_plan_get_work_buffer_size(p1, &w1));
+    FFTCHK(ctx, rocfft_plan_get_work_buffer_size(p2, &w2));
+    FFTCHK(ctx, rocfft_plan_get_work_buffer_size(p3, &w3));
     const size_t need = std::max(w1, std::max(w2, w3));
     if (need > fb.work_cap) {
         if (fb.work) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(fb.work)); fb.work = nullptr; }
@@ -2034,6 +2177,23 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
         launch_map(st, dm, fb.map_threads, fb.map_lds, theta_dev, w0, n, fb.img, t.pp, t.ab, t.y, false);
     }
     if (tm) HIPCHK(ctx, hipEventRecord(es.e[2], st));
+    const double* zin = nullptr;
+    if (fb.cols) {
+        // rows by rocFFT, columns by jx_fft.hpp: forward, times the beam spectrum, inverse in one pass over the row spectra; then the
+        // window's row spectra and its column pass, which leaves the spectrum of the extracted row
+        const int S = d.S;
+        void* a[1] = {fb.img};   void* b[1] = {fb.spec};
+        FFTCHK(ctx, rocfft_execute(pl->row_fwd, a, b, fb.info));
+        fft_launch_beam(fb, n, st, S);
+        void* c2[1] = {fb.conv};
+        FFTCHK(ctx, rocfft_execute(pl->row_inv, b, c2, fb.info));
+        if (tm) HIPCHK(ctx, hipEventRecord(es.e[3], st));
+        void* t2[1] = {fb.tfspec};
+        FFTCHK(ctx, rocfft_execute(pl->row_tf, c2, t2, fb.info));
+        fft_launch_tf(fb, n, st, d.Sh);
+        if (tm) HIPCHK(ctx, hipEventRecord(es.e[4], st));
+        zin = fb.zbuf;
+    } else {
     {
         void* in[1] = {fb.img};
         void* out[1] = {fb.spec};
@@ -2052,9 +2212,10 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
         FFTCHK(ctx, rocfft_execute(pl->tf_fwd, in, out, fb.info));
     }
     if (tm) HIPCHK(ctx, hipEventRecord(es.e[4], st));
+    }
     {
         const size_t sh = sizeof(double) * (JX_LDS_HDR + (size_t)2 * d.Sh + d.nrow + 8);
-        hipLaunchKernelGGL(jx_tail_kernel, dim3(n), dim3(JX_TAIL_THREADS), sh, st, fb.d, fb.tfspec, ctx->d_cfac, ctx->d_sz0,
+        hipLaunchKernelGGL(jx_tail_kernel, dim3(n), dim3(JX_TAIL_THREADS), sh, st, fb.d, fb.tfspec, zin, ctx->d_cfac, ctx->d_sz0,
                            ctx->d_base, logp_dev, w0, t.row, t.bright, t.chisq, t.parts);
     }
     if (tm) { HIPCHK(ctx, hipEventRecord(es.e[5], st)); ctx->ev_inflight.push_back(es); }
@@ -2532,7 +2693,7 @@ int jx_eval_stage(jx_ctx* ctx, const double* theta, int nwalkers, int stage, dou
                                    (size_t)ctx->d.img_ws, (int)S, ctx->t_y2d);
             const double* base = (stage == JX_STAGE_Y2D) ? (y2d_quad ? ctx->t_y2d : ctx->fft.img) : ctx->fft.conv;
             const size_t ld = (stage == JX_STAGE_Y2D && y2d_quad) ? S : P;
-            const size_t ws = (stage == JX_STAGE_Y2D && y2d_quad) ? S * S : P * P;
+            const size_t ws = (stage == JX_STAGE_Y2D && y2d_quad) ? S * S : P * (size_t)ctx->fft.rows;
             for (int w = 0; w < n; ++w)
                 HIPCHK(ctx, hipMemcpy2DAsync(dst + (size_t)w * S * S, S * sizeof(double), base + (size_t)w * ws,
                                              ld * sizeof(double), S * sizeof(double), S, hipMemcpyDeviceToHost, ctx->stream));

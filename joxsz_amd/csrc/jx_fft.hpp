@@ -1,0 +1,246 @@
+// Column passes of the rocFFT sequence (conv = rocfft, north_star's literal route: joxsz_funcs.py:464-467 executed as written).
+//
+// rocFFT's own 2-D plans move each spectrum through HBM once per dimension and once more for the multiplication, and fetch
+// 2.9 x the bytes on the strided (column) dimension (profiles/r04_pmc_traffic.json).  Here rocFFT keeps the contiguous row
+// transforms (batched 1-D plans) and the column dimension is hand-written:
+//
+//   jx_fft_beam_cols_kernel   per walker and group of CB adjacent columns kx of the row spectra [S][ldc]: the S values of each column
+//                             (rows S..P-1 of the padded image are zero and are never stored) -> LDS, forward transform of length P,
+//                             times the beam spectrum, inverse transform of length P, rows 0..S-1 (the 'same' window of
+//                             joxsz_funcs.py:464) written back in place.  One read and one write of the spectrum instead of
+//                             rocFFT column pass + jx_beam_mul_kernel + rocFFT column pass.
+//   jx_fft_tf_cols_kernel     the same load for the row spectra of the S x S window, forward transform of length S, times the
+//                             transfer-function table (joxsz_funcs.py:466-467; jx_tables.hpp tf_row_table, which carries the phase of
+//                             the extracted row S//2), summed over the column: Z[kc], the spectrum of the extracted row that
+//                             jx_tail_kernel turns into the row.  One read of the spectrum, nothing written but Z.
+//
+// The transform: Stockham autosort, radices 10 9 8 6 5 4 3 2, and 16 12 where the registers allow (any length 2^a 3^b 5^c in as few passes as the host finds: 540 = 10 9 6,
+// 512 = 8 8 8; the composite radices are two base butterflies inside the registers of a thread), one wave per column, in place
+// in LDS (every thread holds the inputs of its butterflies in registers across the barrier between the read and the write of a pass),
+// roots of unity from a table of the host (long double sincos) copied to LDS, fp64.  Global accesses are CB * 16 B contiguous per row (CB = 8: one
+// 128 B line, the leading dimensions ldc / ldt are multiples of 8 complex so that groups start on lines).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define JX_FFT_MAXPASS 12
+#define JX_FFT_MAX_PER_THREAD 20          // transform length / 64 (one wave per column) at most; the kernels come in NU = 4, 8, 9, 10 (8 columns per block) and 16, 17, 20 (4)
+
+struct JxFft {
+    int n;                                // transform length
+    int npass;
+    int radix[JX_FFT_MAXPASS];            // 2 3 4 5 (base butterflies), 6 8 9 10 12 16 (two of them in registers)
+    int ns[JX_FFT_MAXPASS];               // product of the radices before the pass
+    int tstep[JX_FFT_MAXPASS];            // n / (ns radix): stride of the pass's twiddles in the table of roots; 0 in the first pass (all twiddles = root[0] = 1)
+    unsigned magic[JX_FFT_MAXPASS];       // ceil(2^32 / ns): j / ns without a division
+    const double2* root;                  // [n] e^{-2 pi i m / n}
+};
+
+template <int R> struct JxRoot;
+#include "jx_fft_roots.inc"
+
+__device__ __forceinline__ double2 jx_cmul(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ double2 jx_cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ double2 jx_csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+// a * (DIR * i): DIR = -1 forward, +1 inverse
+template <int DIR> __device__ __forceinline__ double2 jx_cmuli(double2 a) { return DIR < 0 ? make_double2(a.y, -a.x) : make_double2(-a.y, a.x); }
+
+template <int DIR, int R> __device__ __forceinline__ void jx_dft(double2 (&v)[R]);
+
+// Cooley-Tukey inside the registers of one thread: R = R1 R2, n = R2 n1 + n2, k = k1 + R1 k2
+template <int DIR, int R1, int R2> __device__ __forceinline__ void jx_dft_ct(double2 (&v)[R1 * R2]) {
+    constexpr int R = R1 * R2;
+    double2 a[R2][R1];
+#pragma unroll
+    for (int n2 = 0; n2 < R2; ++n2) {
+        double2 t[R1];
+#pragma unroll
+        for (int n1 = 0; n1 < R1; ++n1) t[n1] = v[R2 * n1 + n2];
+        jx_dft<DIR, R1>(t);
+#pragma unroll
+        for (int k1 = 0; k1 < R1; ++k1) {
+            const int m = (n2 * k1) % R;
+            if (m == 0) a[n2][k1] = t[k1];
+            else if (4 * m == R) a[n2][k1] = jx_cmuli<DIR>(t[k1]);
+            else if (2 * m == R) a[n2][k1] = make_double2(-t[k1].x, -t[k1].y);
+            else if (4 * m == 3 * R) a[n2][k1] = jx_cmuli<-DIR>(t[k1]);
+            else a[n2][k1] = jx_cmul(t[k1], make_double2(JxRoot<R>::re[m], DIR < 0 ? JxRoot<R>::im[m] : -JxRoot<R>::im[m]));
+        }
+    }
+#pragma unroll
+    for (int k1 = 0; k1 < R1; ++k1) {
+        double2 t[R2];
+#pragma unroll
+        for (int n2 = 0; n2 < R2; ++n2) t[n2] = a[n2][k1];
+        jx_dft<DIR, R2>(t);
+#pragma unroll
+        for (int k2 = 0; k2 < R2; ++k2) v[k1 + R1 * k2] = t[k2];
+    }
+}
+
+template <int DIR, int R> __device__ __forceinline__ void jx_dft(double2 (&v)[R]) {
+    if constexpr (R == 2) {
+        const double2 a = v[0], b = v[1];
+        v[0] = jx_cadd(a, b); v[1] = jx_csub(a, b);
+    } else if constexpr (R == 3) {
+        const double s = 0.86602540378443864676;
+        const double2 t = jx_cadd(v[1], v[2]), d = jx_csub(v[1], v[2]);
+        const double2 m = make_double2(v[0].x - 0.5 * t.x, v[0].y - 0.5 * t.y);
+        const double2 e = jx_cmuli<DIR>(make_double2(s * d.x, s * d.y));
+        v[0] = jx_cadd(v[0], t); v[1] = jx_cadd(m, e); v[2] = jx_csub(m, e);
+    } else if constexpr (R == 4) {
+        const double2 a = jx_cadd(v[0], v[2]), b = jx_csub(v[0], v[2]), c = jx_cadd(v[1], v[3]), d = jx_cmuli<DIR>(jx_csub(v[1], v[3]));
+        v[0] = jx_cadd(a, c); v[1] = jx_cadd(b, d); v[2] = jx_csub(a, c); v[3] = jx_csub(b, d);
+    } else if constexpr (R == 5) {
+        const double c1 = 0.30901699437494742410, c2 = -0.80901699437494742410, s1 = 0.95105651629515357212, s2 = 0.58778525229247312917;
+        const double2 a1 = jx_cadd(v[1], v[4]), a2 = jx_cadd(v[2], v[3]), b1 = jx_csub(v[1], v[4]), b2 = jx_csub(v[2], v[3]);
+        const double2 r1 = make_double2(v[0].x + c1 * a1.x + c2 * a2.x, v[0].y + c1 * a1.y + c2 * a2.y);
+        const double2 r2 = make_double2(v[0].x + c2 * a1.x + c1 * a2.x, v[0].y + c2 * a1.y + c1 * a2.y);
+        const double2 i1 = jx_cmuli<DIR>(make_double2(s1 * b1.x + s2 * b2.x, s1 * b1.y + s2 * b2.y));
+        const double2 i2 = jx_cmuli<DIR>(make_double2(s2 * b1.x - s1 * b2.x, s2 * b1.y - s1 * b2.y));
+        v[0] = make_double2(v[0].x + a1.x + a2.x, v[0].y + a1.y + a2.y);
+        v[1] = jx_cadd(r1, i1); v[4] = jx_csub(r1, i1);
+        v[2] = jx_cadd(r2, i2); v[3] = jx_csub(r2, i2);
+    }
+    else if constexpr (R == 6) jx_dft_ct<DIR, 2, 3>(v);
+    else if constexpr (R == 8) jx_dft_ct<DIR, 2, 4>(v);
+    else if constexpr (R == 9) jx_dft_ct<DIR, 3, 3>(v);
+    else if constexpr (R == 10) jx_dft_ct<DIR, 2, 5>(v);
+    else if constexpr (R == 12) jx_dft_ct<DIR, 3, 4>(v);
+    else { static_assert(R == 16, "radix"); jx_dft_ct<DIR, 4, 4>(v); }
+}
+
+// The threads of a column are the lanes of one wave, and a wave's LDS instructions execute in program order: between the read
+// and the write of a pass, and between passes, nothing more is needed than keeping the compiler from moving LDS accesses across the point.
+#define JX_FFT_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+
+// one pass of radix R over the column `col` (n complex in LDS) by the 64 lanes of its wave; root: the table of the n roots (LDS, or global
+// memory where the columns leave no room)
+template <int DIR, int R, int NU, typename RootPtr>
+__device__ __forceinline__ void jx_fft_pass(double2* __restrict__ col, RootPtr root, int n, int ns, int tstep, unsigned magic, int jj) {
+    constexpr int MAXB = (NU + R - 1) / R;                       // NU: transform length / 64, rounded up
+    const int nb = n / R;
+    double2 v[MAXB][R];
+#pragma unroll
+    for (int i = 0; i < MAXB; ++i) {
+        const int j = jj + i * 64;
+        if (j < nb) {
+            const int ks = (j - (int)__umulhi((unsigned)j, magic) * ns) * tstep;          // (first pass: tstep = 0)
+            double2 w[R];
+#pragma unroll
+            for (int t = 0; t < R; ++t) v[i][t] = col[j + t * nb];
+#pragma unroll
+            for (int t = 1; t < R; ++t) w[t] = root[t * ks];
+#pragma unroll
+            for (int t = 1; t < R; ++t) {
+                if (DIR > 0) w[t].y = -w[t].y;
+                v[i][t] = jx_cmul(v[i][t], w[t]);
+            }
+            jx_dft<DIR, R>(v[i]);
+        }
+    }
+    JX_FFT_WAVE_SYNC();
+#pragma unroll
+    for (int i = 0; i < MAXB; ++i) {
+        const int j = jj + i * 64;
+        if (j < nb) {
+            const int k = tstep ? j - (int)__umulhi((unsigned)j, magic) * ns : 0, j0 = (j - k) * R + k;
+#pragma unroll
+            for (int t = 0; t < R; ++t) col[j0 + t * ns] = v[i][t];
+        }
+    }
+    JX_FFT_WAVE_SYNC();
+}
+
+// the whole transform of one column, natural order in, natural order out; called by the 64 lanes of the column's wave (no block barrier
+// inside: the caller puts one between its own accesses in another lane order and this)
+template <int DIR, int NU, bool BIG, typename RootPtr>
+__device__ __forceinline__ void jx_fft_lds(double2* __restrict__ col, RootPtr root, const JxFft& f, int jj) {
+    for (int p = 0; p < f.npass; ++p) {
+        const int ns = f.ns[p], ts = f.tstep[p];
+        const unsigned mg = f.magic[p];
+        switch (f.radix[p]) {
+#define JX_FFT_CASE(RR) case RR: jx_fft_pass<DIR, RR, NU>(col, root, f.n, ns, ts, mg, jj); break;
+            JX_FFT_CASE(2) JX_FFT_CASE(3) JX_FFT_CASE(4) JX_FFT_CASE(5) JX_FFT_CASE(6) JX_FFT_CASE(8) JX_FFT_CASE(9) JX_FFT_CASE(10)
+#undef JX_FFT_CASE
+            default:                                     // radices 12 and 16 only where a wave may hold 256 registers (4 columns per block)
+                if constexpr (BIG) {
+                    if (f.radix[p] == 12) jx_fft_pass<DIR, 12, NU>(col, root, f.n, ns, ts, mg, jj);
+                    else if (f.radix[p] == 16) jx_fft_pass<DIR, 16, NU>(col, root, f.n, ns, ts, mg, jj);
+                }
+                break;
+        }
+    }
+}
+
+// rows ly, ly + rpi, ... < n (at most NU of them): every load is requested before the first use (one trip to HBM / L2 instead of one per row)
+#define JX_FFT_BATCHED(n, LOAD, USE)                                                   \
+    for (int y0_ = ly; y0_ < (n); y0_ += rpi * NU) {                           \
+        double2 t_[NU];                                                        \
+        _Pragma("unroll") for (int u_ = 0; u_ < NU; ++u_) { const int y = y0_ + u_ * rpi; t_[u_] = y < (n) ? LOAD : make_double2(0.0, 0.0); }   \
+        _Pragma("unroll") for (int u_ = 0; u_ < NU; ++u_) { const int y = y0_ + u_ * rpi; const double2 t = t_[u_]; if (y < (n)) { USE; } }   \
+    }
+
+// 8 columns per block (lengths up to 640): the roots sit behind the columns in LDS; 4 columns (up to 1280): read from global memory
+#define JX_FFT_ROOTS_IN_LDS(CB) ((CB) == 8)
+#define JX_FFT_RUN(DIR, n) do {                                                                                         \
+        if constexpr (JX_FFT_ROOTS_IN_LDS(CB)) jx_fft_lds<DIR, NU, false>(jx_fft_sm + c * L, (const double2*)(jx_fft_sm + CB * L), f, jj);   \
+        else jx_fft_lds<DIR, NU, true>(jx_fft_sm + c * L, f.root, f, jj);                                              \
+    } while (0)
+#define JX_FFT_LDS_BYTES(n, CB, ROOTS) (((size_t)(CB) * ((size_t)(n) + 1) + ((ROOTS) ? (size_t)(n) : 0)) * sizeof(double2))      // the columns, then the roots
+
+// spec [walker][S][ldc] (row spectra of the padded image, rows 0..S-1), bhat [P][ldc] (beam spectrum times step^2 / P^2).
+// grid (ldc / CB, walkers), 64 CB threads (one wave per column), JX_FFT_LDS_BYTES(P, CB) of LDS (roots in LDS) or without the roots
+template <int CB, int NU>
+__global__ void __launch_bounds__(64 * CB) __attribute__((amdgpu_waves_per_eu(CB == 8 ? 4 : 2, CB == 8 ? 4 : 2)))
+jx_fft_beam_cols_kernel(JxFft f, double2* __restrict__ spec, const double2* __restrict__ bhat, int S, int ldc) {
+    extern __shared__ double2 jx_fft_sm[];
+    const int P = f.n, L = P + 1, tid = threadIdx.x;
+    constexpr int tpc = 64, rpi = 64, NT = 64 * CB;                            // lanes per column; rows per load instruction
+    const int c0 = blockIdx.x * CB;
+    double2* g = spec + (size_t)blockIdx.y * S * ldc + c0;
+    const int lc = tid % CB, ly = tid / CB, c = tid / tpc, jj = tid % tpc;
+    JX_FFT_BATCHED(P, (y < S ? g[(size_t)y * ldc + lc] : make_double2(0.0, 0.0)), jx_fft_sm[lc * L + y] = t)
+    if (JX_FFT_ROOTS_IN_LDS(CB)) for (int m = tid; m < P; m += NT) jx_fft_sm[CB * L + m] = f.root[m];
+    __syncthreads();
+    JX_FFT_RUN(-1, P);
+    __syncthreads();
+    const double2* b = bhat + c0;
+    JX_FFT_BATCHED(P, b[(size_t)y * ldc + lc], jx_fft_sm[lc * L + y] = jx_cmul(jx_fft_sm[lc * L + y], t))
+    __syncthreads();
+    JX_FFT_RUN(+1, P);
+    __syncthreads();
+    for (int y = ly; y < S; y += rpi) g[(size_t)y * ldc + lc] = jx_fft_sm[lc * L + y];
+}
+
+// tfspec [walker][S][ldt] (row spectra of the S x S window), htab [S][ldt] (tf_row_table, zero in the padding columns),
+// zout [walker][2][Sh]: re, im of Z[kc] = sum_kr X[kr][kc] H[kr][kc].   grid (ldt / CB, walkers), JX_FFT_LDS_BYTES(S, CB) of LDS
+template <int CB, int NU>
+__global__ void __launch_bounds__(64 * CB) __attribute__((amdgpu_waves_per_eu(CB == 8 ? 4 : 2, CB == 8 ? 4 : 2)))
+jx_fft_tf_cols_kernel(JxFft f, const double2* __restrict__ tfspec, const double2* __restrict__ htab, int ldt, int Sh, double* __restrict__ zout,
+                      int) {
+    extern __shared__ double2 jx_fft_sm[];
+    const int S = f.n, L = S + 1, tid = threadIdx.x;
+    constexpr int tpc = 64, rpi = 64, NT = 64 * CB;
+    const int c0 = blockIdx.x * CB;
+    const double2* g = tfspec + (size_t)blockIdx.y * S * ldt + c0;
+    const int lc = tid % CB, ly = tid / CB, c = tid / tpc, jj = tid % tpc;
+    JX_FFT_BATCHED(S, g[(size_t)y * ldt + lc], jx_fft_sm[lc * L + y] = t)
+    if (JX_FFT_ROOTS_IN_LDS(CB)) for (int m = tid; m < S; m += NT) jx_fft_sm[CB * L + m] = f.root[m];
+    __syncthreads();
+    JX_FFT_RUN(-1, S);
+    __syncthreads();
+    // times the table and down the column: lanes (lc, ly) as in the load, so that the table is read in lines
+    const double2* h = htab + c0;
+    double zr = 0.0, zi = 0.0;
+    JX_FFT_BATCHED(S, h[(size_t)y * ldt + lc], const double2 z = jx_cmul(jx_fft_sm[lc * L + y], t); zr += z.x; zi += z.y)
+    __syncthreads();
+    double* red = reinterpret_cast<double*>(jx_fft_sm);            // [2][rpi][CB]
+    red[ly * CB + lc] = zr; red[(rpi + ly) * CB + lc] = zi;
+    __syncthreads();
+    if (tid < 2 * CB) {
+        const int part = tid / CB, cc = tid % CB;
+        double a = 0.0;
+        for (int y = 0; y < rpi; ++y) a += red[(part * rpi + y) * CB + cc];
+        if (c0 + cc < Sh) zout[((size_t)blockIdx.y * 2 + part) * Sh + c0 + cc] = a;
+    }
+}

@@ -1368,7 +1368,7 @@ jx_expand_quad_kernel(const double* __restrict__ quad, size_t q_ld, size_t q_ws,
 //   chisq = nansum(((flux - model)/err)^2); logp = base - chisq/2   (joxsz_funcs.py:478-479, 538)
 // ------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(JX_TAIL_THREADS)
-jx_tail_kernel(JxDev c, const double2* __restrict__ tfspec,
+jx_tail_kernel(JxDev c, const double2* __restrict__ tfspec, const double* __restrict__ zin /* [walker][2][Sh]: Z already summed (jx_fft.hpp), or null */,
                const double* __restrict__ cfac, const double* __restrict__ sz0,
                const double* __restrict__ base, double* __restrict__ logp, int w0,
                double* __restrict__ tap_row, double* __restrict__ tap_bright, double* __restrict__ tap_chisq,
@@ -1383,7 +1383,12 @@ jx_tail_kernel(JxDev c, const double2* __restrict__ tfspec,
     const double2* X = tfspec + (size_t)w * S * Sh;
     const double2* H = reinterpret_cast<const double2*>(c.htab);
 
-    {
+    if (zin) {
+        for (int kc = tid; kc < Sh; kc += nth) {
+            s_zr[kc] = zin[((size_t)w * 2) * Sh + kc];
+            s_zi[kc] = zin[((size_t)w * 2 + 1) * Sh + kc];
+        }
+    } else {
         for (int kc = tid; kc < Sh; kc += nth) {
             double zr0 = 0.0, zi0 = 0.0, zr1 = 0.0, zi1 = 0.0;
             int kr = 0;
