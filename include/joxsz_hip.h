@@ -173,6 +173,8 @@ int  jx_finalize(jx_ctx* ctx);
  *   JOXSZ_FFT_PAD, JOXSZ_MAP_SPLIT, JOXSZ_MAP_PAIR         rocFFT sequence / Abel + map kernel: padded side, row slabs per walker, two walkers per block (1)
  *   JOXSZ_FFT_COLUMNS            custom|rocfft (custom)    rocFFT sequence: its column passes hand-written (jx_fft.hpp: rocFFT transforms the rows, one kernel per column group does
  *                                                          forward, times the beam spectrum, inverse) wherever both sides are 2^a 3^b 5^c and <= 1280; rocfft: rocFFT's own 2-D plans
+ *   JOXSZ_FFT_ROWS               custom|rocfft (custom)    beside the hand-written columns: the row transforms hand-written as well (two real rows per complex transform; the
+ *                                                          inverse rows of the convolution and the forward rows of the transfer function in one kernel) or batched 1-D rocFFT plans
  *   JOXSZ_EVAL_DIRECT            0..3 (3)                  jx_eval: bit 0 the tail stores into the caller-visible host buffer, bit 1 the per-walker kernel reads theta from it
  *   JOXSZ_PREP_SPLIT             1|0 (1)                   per-walker kernel as two blocks per walker (X-ray side beside the rest); same bits
  *   JOXSZ_PREP_LEAN              1|0 (1)                   the two-block form as jx_walker2_kernel (every table of a block in one batched copy into LDS); 0: inside jx_prep_kernel; same bits

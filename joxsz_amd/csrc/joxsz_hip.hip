@@ -62,7 +62,7 @@ struct FftBack {
     double2 *spec = nullptr, *tfspec = nullptr;
     // hand-written column passes (jx_fft.hpp): rows of the padded image kept (S: the zero rows are never stored), leading dimensions of the
     // row spectra (multiples of 8 complex), columns per block, the two transforms, the tables in those leading dimensions, Z of the tail
-    bool cols = false;
+    bool cols = false, rows_custom = false;
     int rows = 0, ldc = 0, ldt = 0;
     JxFft fP{}, fS{};
     double2 *bhat_p = nullptr, *htab_p = nullptr;
@@ -311,7 +311,7 @@ static std::vector<T> host_vec(jx_ctx* ctx, int id) {
 // SAMPLE_ ones), with the process environment as the default of each.  The list is the one include/joxsz_hip.h documents
 // (tests/test_abi.py holds the two and the uses in this file together).
 static const char* const kOptions[] = {
-    "JOXSZ_CONV", "JOXSZ_MIX_FORM", "JOXSZ_X_PAIRWISE", "JOXSZ_PRUNE_OUTPUTS", "JOXSZ_CHUNK", "JOXSZ_FFT_PAD", "JOXSZ_FFT_COLUMNS", "JOXSZ_MAP_SPLIT", "JOXSZ_MAP_PAIR",
+    "JOXSZ_CONV", "JOXSZ_MIX_FORM", "JOXSZ_X_PAIRWISE", "JOXSZ_PRUNE_OUTPUTS", "JOXSZ_CHUNK", "JOXSZ_FFT_PAD", "JOXSZ_FFT_COLUMNS", "JOXSZ_FFT_ROWS", "JOXSZ_MAP_SPLIT", "JOXSZ_MAP_PAIR",
     "JOXSZ_EVAL_DIRECT", "JOXSZ_PREP_SPLIT", "JOXSZ_PREP_LEAN", "JOXSZ_PREP_POW", "JOXSZ_PREP_FASTMATH", "JOXSZ_OP_NARROW", "JOXSZ_SAMPLE_FUSED", "JOXSZ_SAMPLE_VIRTUAL_RANKS",
     // the contracted forms of rounds 3-4 (JOXSZ_MIX_FORM=legacy|lowrank|full)
     "JOXSZ_LOWRANK_TOL", "JOXSZ_TRUNC_PROBE", "JOXSZ_TRUNC_BOUND", "JOXSZ_MIX_SUBSAMPLE", "JOXSZ_MIX_RANKCAP", "JOXSZ_MIX_MFMA", "JOXSZ_MIX_USPLIT", "JOXSZ_MIX_WPB",
@@ -493,12 +493,13 @@ static int fft_transform(jx_ctx* ctx, FftBack& fb, int n, JxFft& f) {
 #define JX_FFT_NU_OF(n) (((n) + 63) / 64)
 #define JX_FFT_DISPATCH(nu, X) do {                                                                                     \
         const int nu_ = (nu);                                                                                           \
-        if (nu_ <= 4) { X(8, 4); } else if (nu_ <= 8) { X(8, 8); } else if (nu_ <= 9) { X(8, 9); } else if (nu_ <= 10) { X(8, 10); }   \
+        if (getenv("JOXSZ_TMP_CB4") && nu_ <= 9) { if (nu_ <= 8) { X(4, 8); } else { X(4, 9); } }                      \
+        else if (nu_ <= 4) { X(8, 4); } else if (nu_ <= 8) { X(8, 8); } else if (nu_ <= 9) { X(8, 9); } else if (nu_ <= 10) { X(8, 10); }   \
         else if (nu_ <= 16) { X(4, 16); } else if (nu_ <= 17) { X(4, 17); } else { X(4, 20); }                         \
     } while (0)
-static inline int fft_cb(int n) { return JX_FFT_NU_OF(n) <= 10 ? 8 : 4; }
+static inline int fft_cb(int n) { return JX_FFT_NU_OF(n) <= 10 && !getenv("JOXSZ_TMP_CB4") ? 8 : 4; }
 // the roots of unity go to LDS when two blocks still fit a compute unit with them
-static inline int fft_roots_in_lds(int n) { return JX_FFT_ROOTS_IN_LDS(fft_cb(n)) ? 1 : 0; }
+static inline int fft_roots_in_lds(int n) { return JX_FFT_SMALL(JX_FFT_NU_OF(n)) ? 1 : 0; }
 
 static void fft_launch_beam(FftBack& fb, int walkers, hipStream_t st, int S) {
     const int P = fb.P, r = fft_roots_in_lds(P);
@@ -514,6 +515,30 @@ static void fft_launch_tf(FftBack& fb, int walkers, hipStream_t st, int Sh) {
 #undef X
 }
 
+// row kernels: 8 waves (pairs of rows) per block for the forward pass, 7 for the fused inverse + window + forward one (its second table of
+// roots takes the room of the eighth); 4 where the roots stay in global memory
+#define JX_FFT_ROWS_DISPATCH(nu, WS, X) do {                                                                            \
+        const int nu_ = (nu);                                                                                           \
+        if (nu_ <= 4) { X(WS, 4); } else if (nu_ <= 8) { X(WS, 8); } else if (nu_ <= 9) { X(WS, 9); } else if (nu_ <= 10) { X(WS, 10); }   \
+        else if (nu_ <= 16) { X(4, 16); } else if (nu_ <= 17) { X(4, 17); } else { X(4, 20); }                         \
+    } while (0)
+
+static void fft_launch_rows_fwd(FftBack& fb, int walkers, hipStream_t st, int S) {
+    const int P = fb.P, R = walkers * S, small = fft_roots_in_lds(P);
+#define X(WPB, NU) hipLaunchKernelGGL((jx_fft_rows_fwd_kernel<WPB, NU>), dim3(((R + 1) / 2 + WPB - 1) / WPB), dim3(64 * WPB), JX_FFT_ROWS_LDS_BYTES(P, WPB, small ? P : 0), st, \
+                                      fb.fP, fb.img, fb.spec, S, fb.ldc, R)
+    JX_FFT_ROWS_DISPATCH(JX_FFT_NU_OF(P), 8, X);
+#undef X
+}
+
+static void fft_launch_rows_inv_tf(FftBack& fb, int walkers, hipStream_t st, int S, bool want_conv) {
+    const int P = fb.P, R = walkers * S, small = fft_roots_in_lds(P);
+#define X(WPB, NU) hipLaunchKernelGGL((jx_fft_rows_inv_tf_kernel<WPB, NU>), dim3(((R + 1) / 2 + WPB - 1) / WPB), dim3(64 * WPB), JX_FFT_ROWS_LDS_BYTES(P, WPB, small ? P + S : 0), st, \
+                                      fb.fP, fb.fS, fb.spec, want_conv ? fb.conv : (double*)nullptr, fb.tfspec, fb.ldc, fb.ldt, R)
+    JX_FFT_ROWS_DISPATCH(JX_FFT_NU_OF(P), 7, X);
+#undef X
+}
+
 static int fft_kernels(jx_ctx* ctx, FftBack& fb) {
     const int S = ctx->cfg.S;
     const int lp = (int)JX_FFT_LDS_BYTES(fb.P, fft_cb(fb.P), 1), ls = (int)JX_FFT_LDS_BYTES(S, fft_cb(S), 1);
@@ -522,6 +547,13 @@ static int fft_kernels(jx_ctx* ctx, FftBack& fb) {
 #undef X
 #define X(CB, NU) HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_fft_tf_cols_kernel<CB, NU>, hipFuncAttributeMaxDynamicSharedMemorySize, ls))
     JX_FFT_DISPATCH(JX_FFT_NU_OF(S), X);
+#undef X
+    const int nroot = fft_roots_in_lds(fb.P) ? fb.P + S : 0;
+#define X(WPB, NU) HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_fft_rows_fwd_kernel<WPB, NU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)JX_FFT_ROWS_LDS_BYTES(fb.P, WPB, nroot)))
+    JX_FFT_ROWS_DISPATCH(JX_FFT_NU_OF(fb.P), 8, X);
+#undef X
+#define X(WPB, NU) HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_fft_rows_inv_tf_kernel<WPB, NU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)JX_FFT_ROWS_LDS_BYTES(fb.P, WPB, nroot)))
+    JX_FFT_ROWS_DISPATCH(JX_FFT_NU_OF(fb.P), 7, X);
 #undef X
     return JX_OK;
 }
@@ -540,7 +572,9 @@ static int fft_setup(jx_ctx* ctx, FftBack& fb, int cap, int P) {
         int rx[JX_FFT_MAXPASS];
         const char* e = opt_str(ctx, "JOXSZ_FFT_COLUMNS");
         const bool want = !(e && !strcmp(e, "rocfft"));
-        fb.cols = want && fft_factor(P, rx) > 0 && fft_factor(S, rx) > 0 && std::max(P, S) <= JX_FFT_MAX_PER_THREAD * 64;
+        fb.cols = want && fft_factor(P, rx) > 0 && fft_factor(S, rx) > 0 && std::max(P, S) <= JX_FFT_MAX_PER_THREAD * 64 && P % 2 == 0;
+        const char* er = opt_str(ctx, "JOXSZ_FFT_ROWS");
+        fb.rows_custom = fb.cols && !(er && !strcmp(er, "rocfft"));
         fb.rows = fb.cols ? S : P;
         fb.ldc = (fb.Ph + 7) & ~7; fb.ldt = (ctx->Sh + 7) & ~7;
     }
@@ -1833,6 +1867,7 @@ struct Taps {
     double *pp = nullptr, *ab = nullptr, *y = nullptr, *row = nullptr, *bright = nullptr, *chisq = nullptr,
            *tprof = nullptr, *xprofs = nullptr, *parts = nullptr, *integ = nullptr;
     bool need_img = false;            // the Compton-y map itself is wanted (y_2d tap)
+    bool need_conv = false;           // the beam-convolved map is wanted (conv_2d tap): the hand-written row kernels write it only then
 };
 
 // the reference facility of a contracted-route context: the rocFFT sequence for up to 16 walkers at a time
@@ -2170,7 +2205,7 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
     FftBack& fb = ctx->fft;
     if (n > fb.cap) { ctx->err = "rocFFT sequence: launch beyond its work buffers"; return JX_ERR_INVALID; }
     Plan3* pl = nullptr;
-    if ((rc = fft_plans(ctx, fb, n, &pl))) return rc;
+    if (!fb.rows_custom && (rc = fft_plans(ctx, fb, n, &pl))) return rc;          // (no rocFFT plan where rows and columns are hand-written)
     {
         JxDev dm = fb.d;
         dm.inject_pp = ctx->d.inject_pp;
@@ -2182,14 +2217,21 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
         // rows by rocFFT, columns by jx_fft.hpp: forward, times the beam spectrum, inverse in one pass over the row spectra; then the
         // window's row spectra and its column pass, which leaves the spectrum of the extracted row
         const int S = d.S;
-        void* a[1] = {fb.img};   void* b[1] = {fb.spec};
-        FFTCHK(ctx, rocfft_execute(pl->row_fwd, a, b, fb.info));
-        fft_launch_beam(fb, n, st, S);
-        void* c2[1] = {fb.conv};
-        FFTCHK(ctx, rocfft_execute(pl->row_inv, b, c2, fb.info));
-        if (tm) HIPCHK(ctx, hipEventRecord(es.e[3], st));
-        void* t2[1] = {fb.tfspec};
-        FFTCHK(ctx, rocfft_execute(pl->row_tf, c2, t2, fb.info));
+        if (fb.rows_custom) {
+            fft_launch_rows_fwd(fb, n, st, S);
+            fft_launch_beam(fb, n, st, S);
+            if (tm) HIPCHK(ctx, hipEventRecord(es.e[3], st));       // (the inverse row pass of the convolution is inside the next kernel)
+            fft_launch_rows_inv_tf(fb, n, st, S, t.need_conv);
+        } else {
+            void* a[1] = {fb.img};   void* b[1] = {fb.spec};
+            FFTCHK(ctx, rocfft_execute(pl->row_fwd, a, b, fb.info));
+            fft_launch_beam(fb, n, st, S);
+            void* c2[1] = {fb.conv};
+            FFTCHK(ctx, rocfft_execute(pl->row_inv, b, c2, fb.info));
+            if (tm) HIPCHK(ctx, hipEventRecord(es.e[3], st));
+            void* t2[1] = {fb.tfspec};
+            FFTCHK(ctx, rocfft_execute(pl->row_tf, c2, t2, fb.info));
+        }
         fft_launch_tf(fb, n, st, d.Sh);
         if (tm) HIPCHK(ctx, hipEventRecord(es.e[4], st));
         zin = fb.zbuf;
@@ -2665,6 +2707,7 @@ int jx_eval_stage(jx_ctx* ctx, const double* theta, int nwalkers, int stage, dou
     const bool profiles = !ctx->f32 || stage == JX_STAGE_PP || stage == JX_STAGE_AB || stage == JX_STAGE_Y;
     Taps t = all_taps(ctx, profiles);
     t.need_img = (stage == JX_STAGE_Y2D);
+    t.need_conv = (stage == JX_STAGE_CONV2D);
     const int step = via_ref ? ctx->fft.cap : ctx->chunk;
     for (int w0 = 0; w0 < nwalkers; w0 += step) {
         const int n = std::min(step, nwalkers - w0);

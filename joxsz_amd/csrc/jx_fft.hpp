@@ -180,10 +180,10 @@ __device__ __forceinline__ void jx_fft_lds(double2* __restrict__ col, RootPtr ro
         _Pragma("unroll") for (int u_ = 0; u_ < NU; ++u_) { const int y = y0_ + u_ * rpi; const double2 t = t_[u_]; if (y < (n)) { USE; } }   \
     }
 
-// 8 columns per block (lengths up to 640): the roots sit behind the columns in LDS; 4 columns (up to 1280): read from global memory
-#define JX_FFT_ROOTS_IN_LDS(CB) ((CB) == 8)
+// lengths up to 640 (NU <= 10): the roots sit behind the columns in LDS, four waves per SIMD; beyond (up to 1280): roots read from global memory, two
+#define JX_FFT_SMALL(NU) ((NU) <= 10)
 #define JX_FFT_RUN(DIR, n) do {                                                                                         \
-        if constexpr (JX_FFT_ROOTS_IN_LDS(CB)) jx_fft_lds<DIR, NU, false>(jx_fft_sm + c * L, (const double2*)(jx_fft_sm + CB * L), f, jj);   \
+        if constexpr (JX_FFT_SMALL(NU)) jx_fft_lds<DIR, NU, false>(jx_fft_sm + c * L, (const double2*)(jx_fft_sm + CB * L), f, jj);   \
         else jx_fft_lds<DIR, NU, true>(jx_fft_sm + c * L, f.root, f, jj);                                              \
     } while (0)
 #define JX_FFT_LDS_BYTES(n, CB, ROOTS) (((size_t)(CB) * ((size_t)(n) + 1) + ((ROOTS) ? (size_t)(n) : 0)) * sizeof(double2))      // the columns, then the roots
@@ -191,7 +191,7 @@ __device__ __forceinline__ void jx_fft_lds(double2* __restrict__ col, RootPtr ro
 // spec [walker][S][ldc] (row spectra of the padded image, rows 0..S-1), bhat [P][ldc] (beam spectrum times step^2 / P^2).
 // grid (ldc / CB, walkers), 64 CB threads (one wave per column), JX_FFT_LDS_BYTES(P, CB) of LDS (roots in LDS) or without the roots
 template <int CB, int NU>
-__global__ void __launch_bounds__(64 * CB) __attribute__((amdgpu_waves_per_eu(CB == 8 ? 4 : 2, CB == 8 ? 4 : 2)))
+__global__ void __launch_bounds__(64 * CB) __attribute__((amdgpu_waves_per_eu(JX_FFT_SMALL(NU) ? 4 : 2, JX_FFT_SMALL(NU) ? 4 : 2)))
 jx_fft_beam_cols_kernel(JxFft f, double2* __restrict__ spec, const double2* __restrict__ bhat, int S, int ldc) {
     extern __shared__ double2 jx_fft_sm[];
     const int P = f.n, L = P + 1, tid = threadIdx.x;
@@ -200,7 +200,7 @@ jx_fft_beam_cols_kernel(JxFft f, double2* __restrict__ spec, const double2* __re
     double2* g = spec + (size_t)blockIdx.y * S * ldc + c0;
     const int lc = tid % CB, ly = tid / CB, c = tid / tpc, jj = tid % tpc;
     JX_FFT_BATCHED(P, (y < S ? g[(size_t)y * ldc + lc] : make_double2(0.0, 0.0)), jx_fft_sm[lc * L + y] = t)
-    if (JX_FFT_ROOTS_IN_LDS(CB)) for (int m = tid; m < P; m += NT) jx_fft_sm[CB * L + m] = f.root[m];
+    if (JX_FFT_SMALL(NU)) for (int m = tid; m < P; m += NT) jx_fft_sm[CB * L + m] = f.root[m];
     __syncthreads();
     JX_FFT_RUN(-1, P);
     __syncthreads();
@@ -215,7 +215,7 @@ jx_fft_beam_cols_kernel(JxFft f, double2* __restrict__ spec, const double2* __re
 // tfspec [walker][S][ldt] (row spectra of the S x S window), htab [S][ldt] (tf_row_table, zero in the padding columns),
 // zout [walker][2][Sh]: re, im of Z[kc] = sum_kr X[kr][kc] H[kr][kc].   grid (ldt / CB, walkers), JX_FFT_LDS_BYTES(S, CB) of LDS
 template <int CB, int NU>
-__global__ void __launch_bounds__(64 * CB) __attribute__((amdgpu_waves_per_eu(CB == 8 ? 4 : 2, CB == 8 ? 4 : 2)))
+__global__ void __launch_bounds__(64 * CB) __attribute__((amdgpu_waves_per_eu(JX_FFT_SMALL(NU) ? 4 : 2, JX_FFT_SMALL(NU) ? 4 : 2)))
 jx_fft_tf_cols_kernel(JxFft f, const double2* __restrict__ tfspec, const double2* __restrict__ htab, int ldt, int Sh, double* __restrict__ zout,
                       int) {
     extern __shared__ double2 jx_fft_sm[];
@@ -225,7 +225,7 @@ jx_fft_tf_cols_kernel(JxFft f, const double2* __restrict__ tfspec, const double2
     const double2* g = tfspec + (size_t)blockIdx.y * S * ldt + c0;
     const int lc = tid % CB, ly = tid / CB, c = tid / tpc, jj = tid % tpc;
     JX_FFT_BATCHED(S, g[(size_t)y * ldt + lc], jx_fft_sm[lc * L + y] = t)
-    if (JX_FFT_ROOTS_IN_LDS(CB)) for (int m = tid; m < S; m += NT) jx_fft_sm[CB * L + m] = f.root[m];
+    if (JX_FFT_SMALL(NU)) for (int m = tid; m < S; m += NT) jx_fft_sm[CB * L + m] = f.root[m];
     __syncthreads();
     JX_FFT_RUN(-1, S);
     __syncthreads();
@@ -242,5 +242,114 @@ jx_fft_tf_cols_kernel(JxFft f, const double2* __restrict__ tfspec, const double2
         double a = 0.0;
         for (int y = 0; y < rpi; ++y) a += red[(part * rpi + y) * CB + cc];
         if (c0 + cc < Sh) zout[((size_t)blockIdx.y * 2 + part) * Sh + c0 + cc] = a;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Row passes.  Two real rows ride one complex transform (z = a + i b; A[k] = (Z[k] + conj Z[n-k]) / 2, B[k] = (Z[k] - conj Z[n-k]) / 2i),
+// one wave per pair of rows, its own n complex in LDS: no block barrier after the roots have been copied.  Rows are numbered through
+// the whole launch (walker * S + y), so a pair may straddle two walkers.
+//
+//   jx_fft_rows_fwd_kernel      img rows [R][P] (first S entries non-zero) -> hermitian row spectra spec [R][ldc]      (joxsz_funcs.py:464, the
+//                               forward half of fftconvolve)
+//   jx_fft_rows_inv_tf_kernel   spec rows -> inverse transform of length P -> the first S entries (the 'same' window; written to conv only
+//                               when the convolved map is tapped) -> forward transform of length S of the same pair -> tfspec [R][ldt]
+//                               (joxsz_funcs.py:464 inverse half, :466 forward half).  The convolved map never goes through HBM.
+// ---------------------------------------------------------------------------------------------------------------------------------
+#define JX_FFT_ROWS_LDS_BYTES(n, WPB, NROOT) (((size_t)(WPB) * ((size_t)(n) + 1) + (size_t)(NROOT)) * sizeof(double2))
+
+template <int WPB, int NU>
+__global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(JX_FFT_SMALL(NU) ? 4 : 2, JX_FFT_SMALL(NU) ? 4 : 2)))
+jx_fft_rows_fwd_kernel(JxFft f, const double* __restrict__ img, double2* __restrict__ spec, int S, int ldc, int R) {
+    extern __shared__ double2 jx_fft_sm[];
+    const int P = f.n, L = P + 1, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (JX_FFT_SMALL(NU)) {
+        for (int m = tid; m < P; m += 64 * WPB) jx_fft_sm[WPB * L + m] = f.root[m];
+        __syncthreads();
+    }
+    const int r0 = 2 * (blockIdx.x * WPB + wave);
+    if (r0 >= R) return;
+    const bool two = r0 + 1 < R;
+    double2* col = jx_fft_sm + wave * L;
+    const double* a = img + (size_t)r0 * P;
+    const double* b = a + P;
+    {
+        double2 va[NU / 2 + 1], vb[NU / 2 + 1];
+#pragma unroll
+        for (int u = 0; u < NU / 2 + 1; ++u) {                     // two entries of each row per lane and step
+            const int x = 2 * (lane + 64 * u);
+            va[u] = make_double2(0.0, 0.0); vb[u] = va[u];
+            if (x + 1 < S) { va[u] = *reinterpret_cast<const double2*>(a + x); if (two) vb[u] = *reinterpret_cast<const double2*>(b + x); }
+            else if (x < S) { va[u].x = a[x]; if (two) vb[u].x = b[x]; }
+        }
+#pragma unroll
+        for (int u = 0; u < NU / 2 + 1; ++u) {
+            const int x = 2 * (lane + 64 * u);
+            if (x < P) col[x] = make_double2(va[u].x, vb[u].x);
+            if (x + 1 < P) col[x + 1] = make_double2(va[u].y, vb[u].y);
+        }
+    }
+    JX_FFT_WAVE_SYNC();
+    if constexpr (JX_FFT_SMALL(NU)) jx_fft_lds<-1, NU, false>(col, (const double2*)(jx_fft_sm + WPB * L), f, lane);
+    else jx_fft_lds<-1, NU, true>(col, f.root, f, lane);
+    double2* sa = spec + (size_t)r0 * ldc;
+    double2* sb = sa + ldc;
+    for (int k = lane; k <= P / 2; k += 64) {
+        const double2 zk = col[k], zm = col[k ? P - k : 0];
+        sa[k] = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
+        if (two) sb[k] = make_double2(0.5 * (zk.y + zm.y), -0.5 * (zk.x - zm.x));
+    }
+}
+
+template <int WPB, int NU>
+__global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(JX_FFT_SMALL(NU) ? 4 : 2, JX_FFT_SMALL(NU) ? 4 : 2)))
+jx_fft_rows_inv_tf_kernel(JxFft fP, JxFft fS, const double2* __restrict__ spec, double* __restrict__ conv, double2* __restrict__ tfspec,
+                          int ldc, int ldt, int R) {
+    extern __shared__ double2 jx_fft_sm[];
+    const int P = fP.n, S = fS.n, L = P + 1, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (JX_FFT_SMALL(NU)) {
+        for (int m = tid; m < P; m += 64 * WPB) jx_fft_sm[WPB * L + m] = fP.root[m];
+        for (int m = tid; m < S; m += 64 * WPB) jx_fft_sm[WPB * L + P + m] = fS.root[m];
+        __syncthreads();
+    }
+    const int r0 = 2 * (blockIdx.x * WPB + wave);
+    if (r0 >= R) return;
+    const bool two = r0 + 1 < R;
+    double2* col = jx_fft_sm + wave * L;
+    const double2* sa = spec + (size_t)r0 * ldc;
+    const double2* sb = sa + ldc;
+    {
+        double2 va[NU / 2 + 1], vb[NU / 2 + 1];
+#pragma unroll
+        for (int u = 0; u < NU / 2 + 1; ++u) {
+            const int k = lane + 64 * u;
+            va[u] = make_double2(0.0, 0.0); vb[u] = va[u];
+            if (k <= P / 2) { va[u] = sa[k]; if (two) vb[u] = sb[k]; }
+        }
+#pragma unroll
+        for (int u = 0; u < NU / 2 + 1; ++u) {                     // Z[k] = A[k] + i B[k]; beyond n / 2 from the hermitian symmetry of A and B
+            const int k = lane + 64 * u;
+            if (k <= P / 2) {
+                col[k] = make_double2(va[u].x - vb[u].y, va[u].y + vb[u].x);
+                if (k && 2 * k < P) col[P - k] = make_double2(va[u].x + vb[u].y, vb[u].x - va[u].y);
+            }
+        }
+    }
+    JX_FFT_WAVE_SYNC();
+    if constexpr (JX_FFT_SMALL(NU)) jx_fft_lds<+1, NU, false>(col, (const double2*)(jx_fft_sm + WPB * L), fP, lane);
+    else jx_fft_lds<+1, NU, true>(col, fP.root, fP, lane);
+    if (conv) {
+        double* ca = conv + (size_t)r0 * P;
+        for (int x = lane; x < S; x += 64) { const double2 z = col[x]; ca[x] = z.x; if (two) ca[P + x] = z.y; }
+        JX_FFT_WAVE_SYNC();
+    }
+    if constexpr (JX_FFT_SMALL(NU)) jx_fft_lds<-1, NU, false>(col, (const double2*)(jx_fft_sm + WPB * L + P), fS, lane);
+    else jx_fft_lds<-1, NU, true>(col, fS.root, fS, lane);
+    double2* ta = tfspec + (size_t)r0 * ldt;
+    double2* tb = ta + ldt;
+    for (int k = lane; k <= S / 2; k += 64) {
+        const double2 zk = col[k], zm = col[k ? S - k : 0];
+        ta[k] = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
+        if (two) tb[k] = make_double2(0.5 * (zk.y + zm.y), -0.5 * (zk.x - zm.x));
     }
 }

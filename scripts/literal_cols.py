@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""The literal route (conv = rocfft) with its column passes hand-written (jx_fft.hpp, default) against the same route with rocFFT's own 2-D
-plans (JOXSZ_FFT_COLUMNS=rocfft): convolved map, extracted row and log-posterior differences, ms per launch and the stage split.
+"""The literal route (conv = rocfft) with its transforms hand-written (jx_fft.hpp: columns and rows, default; columns only with
+JOXSZ_FFT_ROWS=rocfft) against the same route with rocFFT's own 2-D plans (JOXSZ_FFT_COLUMNS=rocfft): convolved map, extracted row and log-posterior differences, ms per launch and the stage split.
     python scripts/literal_cols.py [W]      (GPU box)"""
 import os, sys, time
 import numpy as np
@@ -14,8 +14,8 @@ for S, N, nw in SHAPES:
     pb = datasets.synthetic_problem(S=S, N=N, seed=0)
     th = np.ascontiguousarray(datasets.walker_ball(pb, nw, spread=0.02, seed=1))
     res = {}
-    for cols in ('rocfft', 'custom'):
-        post = JoxszPosterior(pb, device=0, conv='rocfft', max_batch=nw, options={'FFT_COLUMNS': cols})
+    for cols, opts in (('rocfft', {'FFT_COLUMNS': 'rocfft'}), ('custom', {'FFT_ROWS': 'rocfft'}), ('all', {})):
+        post = JoxszPosterior(pb, device=0, conv='rocfft', max_batch=nw, options=opts)
         c = post.ctx
         small = th[:min(nw, 4)]
         conv = c.eval_stage(small, 'conv_2d'); row = c.eval_stage(small, 'map_row')
@@ -36,8 +36,12 @@ for S, N, nw in SHAPES:
         out = np.empty(nw); c.d2h(out, lp)
         res[cols] = (conv, row, out, ms, {k[:-3]: round(v / 3, 3) for k, v in tm.items() if k.endswith('_ms') and v}, c.fft_pad)
         post.close()
-    a, b = res['rocfft'], res['custom']
+    a = res['rocfft']
     fin = np.isfinite(a[2])
-    print('S=%d N=%d W=%d pad %d: conv %.1e row %.1e logp %.1e (nonfinite agree: %s) | rocfft cols %.3f ms %s | custom cols %.3f ms %s'
-          % (S, N, nw, b[5], np.max(np.abs(a[0] - b[0])) / np.max(np.abs(a[0])), np.max(np.abs(a[1] - b[1])) / np.max(np.abs(a[1])),
-             np.max(np.abs(a[2][fin] - b[2][fin]) / np.abs(a[2][fin])), bool(np.all(fin == np.isfinite(b[2]))), a[3], a[4], b[3], b[4]), flush=True)
+    print('S=%d N=%d W=%d pad %d: rocFFT 2-D plans %.3f ms %s' % (S, N, nw, a[5], a[3], a[4]), flush=True)
+    for name in ('custom', 'all'):
+        b = res[name]
+        print('    %-28s conv %.1e row %.1e logp %.1e (nonfinite agree: %s) %.3f ms %s'
+              % ('hand-written columns:' if name == 'custom' else 'hand-written rows + columns:', np.max(np.abs(a[0] - b[0])) / np.max(np.abs(a[0])),
+                 np.max(np.abs(a[1] - b[1])) / np.max(np.abs(a[1])), np.max(np.abs(a[2][fin] - b[2][fin]) / np.abs(a[2][fin])),
+                 bool(np.all(fin == np.isfinite(b[2]))), b[3], b[4]), flush=True)
