@@ -493,24 +493,23 @@ static int fft_transform(jx_ctx* ctx, FftBack& fb, int n, JxFft& f) {
 #define JX_FFT_NU_OF(n) (((n) + 63) / 64)
 #define JX_FFT_DISPATCH(nu, X) do {                                                                                     \
         const int nu_ = (nu);                                                                                           \
-        if (getenv("JOXSZ_TMP_CB4") && nu_ <= 9) { if (nu_ <= 8) { X(4, 8); } else { X(4, 9); } }                      \
-        else if (nu_ <= 4) { X(8, 4); } else if (nu_ <= 8) { X(8, 8); } else if (nu_ <= 9) { X(8, 9); } else if (nu_ <= 10) { X(8, 10); }   \
+        if (nu_ <= 4) { X(8, 4); } else if (nu_ <= 8) { X(8, 8); } else if (nu_ <= 9) { X(8, 9); } else if (nu_ <= 10) { X(8, 10); }   \
         else if (nu_ <= 16) { X(4, 16); } else if (nu_ <= 17) { X(4, 17); } else { X(4, 20); }                         \
     } while (0)
-static inline int fft_cb(int n) { return JX_FFT_NU_OF(n) <= 10 && !getenv("JOXSZ_TMP_CB4") ? 8 : 4; }
+static inline int fft_cb(int n) { return JX_FFT_NU_OF(n) <= 10 ? 8 : 4; }
 // the roots of unity go to LDS when two blocks still fit a compute unit with them
 static inline int fft_roots_in_lds(int n) { return JX_FFT_SMALL(JX_FFT_NU_OF(n)) ? 1 : 0; }
 
 static void fft_launch_beam(FftBack& fb, int walkers, hipStream_t st, int S) {
     const int P = fb.P, r = fft_roots_in_lds(P);
-#define X(CB, NU) hipLaunchKernelGGL((jx_fft_beam_cols_kernel<CB, NU>), dim3(fb.ldc / CB, walkers), dim3(64 * CB), JX_FFT_LDS_BYTES(P, CB, r), st, fb.fP, fb.spec, fb.bhat_p, S, fb.ldc)
+#define X(CB, NU) hipLaunchKernelGGL((jx_fft_beam_cols_kernel<CB, NU>), dim3(walkers, fb.ldc / CB), dim3(64 * CB), JX_FFT_LDS_BYTES(P, CB, r), st, fb.fP, fb.spec, fb.bhat_p, S, fb.ldc)
     JX_FFT_DISPATCH(JX_FFT_NU_OF(P), X);
 #undef X
 }
 
 static void fft_launch_tf(FftBack& fb, int walkers, hipStream_t st, int Sh) {
     const int S = fb.fS.n, r = fft_roots_in_lds(S);
-#define X(CB, NU) hipLaunchKernelGGL((jx_fft_tf_cols_kernel<CB, NU>), dim3(fb.ldt / CB, walkers), dim3(64 * CB), JX_FFT_LDS_BYTES(S, CB, r), st, fb.fS, fb.tfspec, fb.htab_p, fb.ldt, Sh, fb.zbuf, r)
+#define X(CB, NU) hipLaunchKernelGGL((jx_fft_tf_cols_kernel<CB, NU>), dim3(walkers, fb.ldt / CB), dim3(64 * CB), JX_FFT_LDS_BYTES(S, CB, r), st, fb.fS, fb.tfspec, fb.htab_p, fb.ldt, Sh, fb.zbuf, r)
     JX_FFT_DISPATCH(JX_FFT_NU_OF(S), X);
 #undef X
 }
@@ -572,7 +571,7 @@ static int fft_setup(jx_ctx* ctx, FftBack& fb, int cap, int P) {
         int rx[JX_FFT_MAXPASS];
         const char* e = opt_str(ctx, "JOXSZ_FFT_COLUMNS");
         const bool want = !(e && !strcmp(e, "rocfft"));
-        fb.cols = want && fft_factor(P, rx) > 0 && fft_factor(S, rx) > 0 && std::max(P, S) <= JX_FFT_MAX_PER_THREAD * 64 && P % 2 == 0;
+        fb.cols = want && fft_factor(P, rx) > 1 && fft_factor(S, rx) > 1 && std::max(P, S) <= JX_FFT_MAX_PER_THREAD * 64 && P % 2 == 0;
         const char* er = opt_str(ctx, "JOXSZ_FFT_ROWS");
         fb.rows_custom = fb.cols && !(er && !strcmp(er, "rocfft"));
         fb.rows = fb.cols ? S : P;
@@ -588,9 +587,12 @@ static int fft_setup(jx_ctx* ctx, FftBack& fb, int cap, int P) {
         jxt::tf_row_table(host_vec<double>(ctx, JX_T_FILTERING), S, H);
         if ((rc = dev_put_l(ctx, fb.allocs, H.data(), H.size(), &p))) return rc; d.htab = p;
         if (fb.cols) {
+            // the two tables one column after the other (the lanes of a column's wave read consecutive entries), zero in the padding columns
             std::vector<double> bp((size_t)2 * P * fb.ldc, 0.0), hp((size_t)2 * S * fb.ldt, 0.0);
-            for (int y = 0; y < P; ++y) std::copy(bh.begin() + (size_t)2 * y * fb.Ph, bh.begin() + (size_t)2 * (y + 1) * fb.Ph, bp.begin() + (size_t)2 * y * fb.ldc);
-            for (int y = 0; y < S; ++y) std::copy(H.begin() + (size_t)2 * y * ctx->Sh, H.begin() + (size_t)2 * (y + 1) * ctx->Sh, hp.begin() + (size_t)2 * y * fb.ldt);
+            for (int y = 0; y < P; ++y)
+                for (int x = 0; x < fb.Ph; ++x) { bp[2 * ((size_t)x * P + y)] = bh[2 * ((size_t)y * fb.Ph + x)]; bp[2 * ((size_t)x * P + y) + 1] = bh[2 * ((size_t)y * fb.Ph + x) + 1]; }
+            for (int y = 0; y < S; ++y)
+                for (int x = 0; x < ctx->Sh; ++x) { hp[2 * ((size_t)x * S + y)] = H[2 * ((size_t)y * ctx->Sh + x)]; hp[2 * ((size_t)x * S + y) + 1] = H[2 * ((size_t)y * ctx->Sh + x) + 1]; }
             if ((rc = dev_put_l(ctx, fb.allocs, bp.data(), bp.size(), &p))) return rc; fb.bhat_p = reinterpret_cast<double2*>(p);
             if ((rc = dev_put_l(ctx, fb.allocs, hp.data(), hp.size(), &p))) return rc; fb.htab_p = reinterpret_cast<double2*>(p);
             if ((rc = fft_transform(ctx, fb, P, fb.fP))) return rc;

@@ -115,8 +115,12 @@ template <int DIR, int R> __device__ __forceinline__ void jx_dft(double2 (&v)[R]
 
 // one pass of radix R over the column `col` (n complex in LDS) by the 64 lanes of its wave; root: the table of the n roots (LDS, or global
 // memory where the columns leave no room)
-template <int DIR, int R, int NU, typename RootPtr>
-__device__ __forceinline__ void jx_fft_pass(double2* __restrict__ col, RootPtr root, int n, int ns, int tstep, unsigned magic, int jj) {
+// MODE 1: the inputs are multiplied by gtab[input index] first (the beam spectrum between forward and inverse transform); MODE 2: the outputs
+// are not stored but multiplied by gtab[output index] and summed into acc (transfer-function table and column sum); gtab is laid out per
+// column, so that the lanes of the wave read consecutive entries
+template <int DIR, int R, int NU, bool TW, int MODE, typename RootPtr>
+__device__ __forceinline__ void jx_fft_pass(double2* __restrict__ col, RootPtr root, int n, int ns, int tstep, unsigned magic, int jj,
+                                            const double2* __restrict__ gtab, double2& acc) {
     constexpr int MAXB = (NU + R - 1) / R;                       // NU: transform length / 64, rounded up
     const int nb = n / R;
     double2 v[MAXB][R];
@@ -124,26 +128,50 @@ __device__ __forceinline__ void jx_fft_pass(double2* __restrict__ col, RootPtr r
     for (int i = 0; i < MAXB; ++i) {
         const int j = jj + i * 64;
         if (j < nb) {
-            const int ks = (j - (int)__umulhi((unsigned)j, magic) * ns) * tstep;          // (first pass: tstep = 0)
-            double2 w[R];
 #pragma unroll
             for (int t = 0; t < R; ++t) v[i][t] = col[j + t * nb];
+            if constexpr (MODE == 1) {
+                double2 g[R];
 #pragma unroll
-            for (int t = 1; t < R; ++t) w[t] = root[t * ks];
+                for (int t = 0; t < R; ++t) g[t] = gtab[j + t * nb];
 #pragma unroll
-            for (int t = 1; t < R; ++t) {
-                if (DIR > 0) w[t].y = -w[t].y;
-                v[i][t] = jx_cmul(v[i][t], w[t]);
+                for (int t = 0; t < R; ++t) v[i][t] = jx_cmul(v[i][t], g[t]);
+            }
+            if constexpr (TW) {                                      // (the first pass has none: TW = false)
+                const int ks = (j - (int)__umulhi((unsigned)j, magic) * ns) * tstep;
+                double2 w[R];
+#pragma unroll
+                for (int t = 1; t < R; ++t) w[t] = root[t * ks];
+#pragma unroll
+                for (int t = 1; t < R; ++t) {
+                    if (DIR > 0) w[t].y = -w[t].y;
+                    v[i][t] = jx_cmul(v[i][t], w[t]);
+                }
             }
             jx_dft<DIR, R>(v[i]);
         }
+    }
+    if constexpr (MODE == 2) {
+#pragma unroll
+        for (int i = 0; i < MAXB; ++i) {
+            const int j = jj + i * 64;
+            if (j < nb) {
+                const int k = TW ? j - (int)__umulhi((unsigned)j, magic) * ns : 0, j0 = (j - k) * R + k;
+                double2 g[R];
+#pragma unroll
+                for (int t = 0; t < R; ++t) g[t] = gtab[j0 + t * ns];
+#pragma unroll
+                for (int t = 0; t < R; ++t) { const double2 z = jx_cmul(v[i][t], g[t]); acc.x += z.x; acc.y += z.y; }
+            }
+        }
+        return;
     }
     JX_FFT_WAVE_SYNC();
 #pragma unroll
     for (int i = 0; i < MAXB; ++i) {
         const int j = jj + i * 64;
         if (j < nb) {
-            const int k = tstep ? j - (int)__umulhi((unsigned)j, magic) * ns : 0, j0 = (j - k) * R + k;
+            const int k = TW ? j - (int)__umulhi((unsigned)j, magic) * ns : 0, j0 = (j - k) * R + k;
 #pragma unroll
             for (int t = 0; t < R; ++t) col[j0 + t * ns] = v[i][t];
         }
@@ -152,24 +180,28 @@ __device__ __forceinline__ void jx_fft_pass(double2* __restrict__ col, RootPtr r
 }
 
 // the whole transform of one column, natural order in, natural order out; called by the 64 lanes of the column's wave (no block barrier
-// inside: the caller puts one between its own accesses in another lane order and this)
-template <int DIR, int NU, bool BIG, typename RootPtr>
-__device__ __forceinline__ void jx_fft_lds(double2* __restrict__ col, RootPtr root, const JxFft& f, int jj) {
-    for (int p = 0; p < f.npass; ++p) {
-        const int ns = f.ns[p], ts = f.tstep[p];
-        const unsigned mg = f.magic[p];
-        switch (f.radix[p]) {
-#define JX_FFT_CASE(RR) case RR: jx_fft_pass<DIR, RR, NU>(col, root, f.n, ns, ts, mg, jj); break;
-            JX_FFT_CASE(2) JX_FFT_CASE(3) JX_FFT_CASE(4) JX_FFT_CASE(5) JX_FFT_CASE(6) JX_FFT_CASE(8) JX_FFT_CASE(9) JX_FFT_CASE(10)
-#undef JX_FFT_CASE
-            default:                                     // radices 12 and 16 only where a wave may hold 256 registers (4 columns per block)
-                if constexpr (BIG) {
-                    if (f.radix[p] == 12) jx_fft_pass<DIR, 12, NU>(col, root, f.n, ns, ts, mg, jj);
-                    else if (f.radix[p] == 16) jx_fft_pass<DIR, 16, NU>(col, root, f.n, ns, ts, mg, jj);
-                }
-                break;
-        }
+// inside: the caller puts one between its own accesses in another lane order and this).  At least two passes (the host sees to it).
+// PRE: the first pass multiplies its inputs by gtab; POST: the last pass leaves sum(output * gtab) of the lane in acc instead of the outputs.
+template <int DIR, int NU, bool BIG, bool PRE, bool POST, typename RootPtr>
+__device__ __forceinline__ void jx_fft_lds(double2* __restrict__ col, RootPtr root, const JxFft& f, int jj, const double2* __restrict__ gtab, double2& acc) {
+#define JX_FFT_SWITCH(TW, MODE, p)                                                                                      \
+    switch (f.radix[p]) {                                                                                               \
+        JX_FFT_CASE(2, TW, MODE, p) JX_FFT_CASE(3, TW, MODE, p) JX_FFT_CASE(4, TW, MODE, p) JX_FFT_CASE(5, TW, MODE, p) JX_FFT_CASE(6, TW, MODE, p)   \
+        JX_FFT_CASE(8, TW, MODE, p) JX_FFT_CASE(9, TW, MODE, p) JX_FFT_CASE(10, TW, MODE, p)                            \
+        default:                                     /* radices 12 and 16 only where a wave may hold 256 registers */  \
+            if constexpr (BIG) {                                                                                        \
+                if (f.radix[p] == 12) jx_fft_pass<DIR, 12, NU, TW, MODE>(col, root, f.n, f.ns[p], f.tstep[p], f.magic[p], jj, gtab, acc);   \
+                else if (f.radix[p] == 16) jx_fft_pass<DIR, 16, NU, TW, MODE>(col, root, f.n, f.ns[p], f.tstep[p], f.magic[p], jj, gtab, acc);   \
+            }                                                                                                           \
+            break;                                                                                                      \
     }
+#define JX_FFT_CASE(RR, TW, MODE, p) case RR: jx_fft_pass<DIR, RR, NU, TW, MODE>(col, root, f.n, f.ns[p], f.tstep[p], f.magic[p], jj, gtab, acc); break;
+    const int last = f.npass - 1;
+    JX_FFT_SWITCH(false, (PRE ? 1 : 0), 0)
+    for (int p = 1; p < last; ++p) JX_FFT_SWITCH(true, 0, p)
+    JX_FFT_SWITCH(true, (POST ? 2 : 0), last)
+#undef JX_FFT_CASE
+#undef JX_FFT_SWITCH
 }
 
 // rows ly, ly + rpi, ... < n (at most NU of them): every load is requested before the first use (one trip to HBM / L2 instead of one per row)
@@ -182,38 +214,35 @@ __device__ __forceinline__ void jx_fft_lds(double2* __restrict__ col, RootPtr ro
 
 // lengths up to 640 (NU <= 10): the roots sit behind the columns in LDS, four waves per SIMD; beyond (up to 1280): roots read from global memory, two
 #define JX_FFT_SMALL(NU) ((NU) <= 10)
-#define JX_FFT_RUN(DIR, n) do {                                                                                         \
-        if constexpr (JX_FFT_SMALL(NU)) jx_fft_lds<DIR, NU, false>(jx_fft_sm + c * L, (const double2*)(jx_fft_sm + CB * L), f, jj);   \
-        else jx_fft_lds<DIR, NU, true>(jx_fft_sm + c * L, f.root, f, jj);                                              \
+#define JX_FFT_RUN(DIR, PRE, POST, gtab, acc) do {                                                                      \
+        if constexpr (JX_FFT_SMALL(NU)) jx_fft_lds<DIR, NU, false, PRE, POST>(jx_fft_sm + c * L, (const double2*)(jx_fft_sm + CB * L), f, jj, gtab, acc);   \
+        else jx_fft_lds<DIR, NU, true, PRE, POST>(jx_fft_sm + c * L, f.root, f, jj, gtab, acc);                        \
     } while (0)
 #define JX_FFT_LDS_BYTES(n, CB, ROOTS) (((size_t)(CB) * ((size_t)(n) + 1) + ((ROOTS) ? (size_t)(n) : 0)) * sizeof(double2))      // the columns, then the roots
 
-// spec [walker][S][ldc] (row spectra of the padded image, rows 0..S-1), bhat [P][ldc] (beam spectrum times step^2 / P^2).
-// grid (ldc / CB, walkers), 64 CB threads (one wave per column), JX_FFT_LDS_BYTES(P, CB) of LDS (roots in LDS) or without the roots
+// spec [walker][S][ldc] (row spectra of the padded image, rows 0..S-1), bhat [ldc][P] (beam spectrum times step^2 / P^2, one column after the other).
+// grid (walkers, ldc / CB), 64 CB threads (one wave per column), JX_FFT_LDS_BYTES(P, CB) of LDS (roots in LDS) or without the roots
 template <int CB, int NU>
 __global__ void __launch_bounds__(64 * CB) __attribute__((amdgpu_waves_per_eu(JX_FFT_SMALL(NU) ? 4 : 2, JX_FFT_SMALL(NU) ? 4 : 2)))
 jx_fft_beam_cols_kernel(JxFft f, double2* __restrict__ spec, const double2* __restrict__ bhat, int S, int ldc) {
     extern __shared__ double2 jx_fft_sm[];
     const int P = f.n, L = P + 1, tid = threadIdx.x;
     constexpr int tpc = 64, rpi = 64, NT = 64 * CB;                            // lanes per column; rows per load instruction
-    const int c0 = blockIdx.x * CB;
-    double2* g = spec + (size_t)blockIdx.y * S * ldc + c0;
+    const int c0 = blockIdx.y * CB;                                            // (walkers fastest: the blocks in flight share a slice of bhat)
+    double2* g = spec + (size_t)blockIdx.x * S * ldc + c0;
     const int lc = tid % CB, ly = tid / CB, c = tid / tpc, jj = tid % tpc;
     JX_FFT_BATCHED(P, (y < S ? g[(size_t)y * ldc + lc] : make_double2(0.0, 0.0)), jx_fft_sm[lc * L + y] = t)
     if (JX_FFT_SMALL(NU)) for (int m = tid; m < P; m += NT) jx_fft_sm[CB * L + m] = f.root[m];
     __syncthreads();
-    JX_FFT_RUN(-1, P);
-    __syncthreads();
-    const double2* b = bhat + c0;
-    JX_FFT_BATCHED(P, b[(size_t)y * ldc + lc], jx_fft_sm[lc * L + y] = jx_cmul(jx_fft_sm[lc * L + y], t))
-    __syncthreads();
-    JX_FFT_RUN(+1, P);
+    double2 none;
+    JX_FFT_RUN(-1, false, false, (const double2*)nullptr, none);
+    JX_FFT_RUN(+1, true, false, bhat + (size_t)(c0 + c) * P, none);        // (the column belongs to this wave from the first pass to the last)
     __syncthreads();
     for (int y = ly; y < S; y += rpi) g[(size_t)y * ldc + lc] = jx_fft_sm[lc * L + y];
 }
 
-// tfspec [walker][S][ldt] (row spectra of the S x S window), htab [S][ldt] (tf_row_table, zero in the padding columns),
-// zout [walker][2][Sh]: re, im of Z[kc] = sum_kr X[kr][kc] H[kr][kc].   grid (ldt / CB, walkers), JX_FFT_LDS_BYTES(S, CB) of LDS
+// tfspec [walker][S][ldt] (row spectra of the S x S window), htab [ldt][S] (tf_row_table one column after the other, zero in the padding columns),
+// zout [walker][2][Sh]: re, im of Z[kc] = sum_kr X[kr][kc] H[kr][kc].   grid (walkers, ldt / CB), JX_FFT_LDS_BYTES(S, CB) of LDS
 template <int CB, int NU>
 __global__ void __launch_bounds__(64 * CB) __attribute__((amdgpu_waves_per_eu(JX_FFT_SMALL(NU) ? 4 : 2, JX_FFT_SMALL(NU) ? 4 : 2)))
 jx_fft_tf_cols_kernel(JxFft f, const double2* __restrict__ tfspec, const double2* __restrict__ htab, int ldt, int Sh, double* __restrict__ zout,
@@ -221,27 +250,20 @@ jx_fft_tf_cols_kernel(JxFft f, const double2* __restrict__ tfspec, const double2
     extern __shared__ double2 jx_fft_sm[];
     const int S = f.n, L = S + 1, tid = threadIdx.x;
     constexpr int tpc = 64, rpi = 64, NT = 64 * CB;
-    const int c0 = blockIdx.x * CB;
-    const double2* g = tfspec + (size_t)blockIdx.y * S * ldt + c0;
+    const int c0 = blockIdx.y * CB;
+    const double2* g = tfspec + (size_t)blockIdx.x * S * ldt + c0;
     const int lc = tid % CB, ly = tid / CB, c = tid / tpc, jj = tid % tpc;
     JX_FFT_BATCHED(S, g[(size_t)y * ldt + lc], jx_fft_sm[lc * L + y] = t)
     if (JX_FFT_SMALL(NU)) for (int m = tid; m < S; m += NT) jx_fft_sm[CB * L + m] = f.root[m];
     __syncthreads();
-    JX_FFT_RUN(-1, S);
-    __syncthreads();
-    // times the table and down the column: lanes (lc, ly) as in the load, so that the table is read in lines
-    const double2* h = htab + c0;
-    double zr = 0.0, zi = 0.0;
-    JX_FFT_BATCHED(S, h[(size_t)y * ldt + lc], const double2 z = jx_cmul(jx_fft_sm[lc * L + y], t); zr += z.x; zi += z.y)
-    __syncthreads();
-    double* red = reinterpret_cast<double*>(jx_fft_sm);            // [2][rpi][CB]
-    red[ly * CB + lc] = zr; red[(rpi + ly) * CB + lc] = zi;
-    __syncthreads();
-    if (tid < 2 * CB) {
-        const int part = tid / CB, cc = tid % CB;
-        double a = 0.0;
-        for (int y = 0; y < rpi; ++y) a += red[(part * rpi + y) * CB + cc];
-        if (c0 + cc < Sh) zout[((size_t)blockIdx.y * 2 + part) * Sh + c0 + cc] = a;
+    // the last pass multiplies by the table and sums down the column instead of storing; then across the lanes of the column's wave
+    double2 z = make_double2(0.0, 0.0);
+    JX_FFT_RUN(-1, false, true, htab + (size_t)(c0 + c) * S, z);
+#pragma unroll
+    for (int o = 32; o; o >>= 1) { z.x += __shfl_xor(z.x, o); z.y += __shfl_xor(z.y, o); }
+    if (jj == 0 && c0 + c < Sh) {
+        zout[((size_t)blockIdx.x * 2) * Sh + c0 + c] = z.x;
+        zout[((size_t)blockIdx.x * 2 + 1) * Sh + c0 + c] = z.y;
     }
 }
 
@@ -290,8 +312,9 @@ jx_fft_rows_fwd_kernel(JxFft f, const double* __restrict__ img, double2* __restr
         }
     }
     JX_FFT_WAVE_SYNC();
-    if constexpr (JX_FFT_SMALL(NU)) jx_fft_lds<-1, NU, false>(col, (const double2*)(jx_fft_sm + WPB * L), f, lane);
-    else jx_fft_lds<-1, NU, true>(col, f.root, f, lane);
+    double2 none;
+    if constexpr (JX_FFT_SMALL(NU)) jx_fft_lds<-1, NU, false, false, false>(col, (const double2*)(jx_fft_sm + WPB * L), f, lane, (const double2*)nullptr, none);
+    else jx_fft_lds<-1, NU, true, false, false>(col, f.root, f, lane, (const double2*)nullptr, none);
     double2* sa = spec + (size_t)r0 * ldc;
     double2* sb = sa + ldc;
     for (int k = lane; k <= P / 2; k += 64) {
@@ -336,15 +359,16 @@ jx_fft_rows_inv_tf_kernel(JxFft fP, JxFft fS, const double2* __restrict__ spec, 
         }
     }
     JX_FFT_WAVE_SYNC();
-    if constexpr (JX_FFT_SMALL(NU)) jx_fft_lds<+1, NU, false>(col, (const double2*)(jx_fft_sm + WPB * L), fP, lane);
-    else jx_fft_lds<+1, NU, true>(col, fP.root, fP, lane);
+    double2 none;
+    if constexpr (JX_FFT_SMALL(NU)) jx_fft_lds<+1, NU, false, false, false>(col, (const double2*)(jx_fft_sm + WPB * L), fP, lane, (const double2*)nullptr, none);
+    else jx_fft_lds<+1, NU, true, false, false>(col, fP.root, fP, lane, (const double2*)nullptr, none);
     if (conv) {
         double* ca = conv + (size_t)r0 * P;
         for (int x = lane; x < S; x += 64) { const double2 z = col[x]; ca[x] = z.x; if (two) ca[P + x] = z.y; }
         JX_FFT_WAVE_SYNC();
     }
-    if constexpr (JX_FFT_SMALL(NU)) jx_fft_lds<-1, NU, false>(col, (const double2*)(jx_fft_sm + WPB * L + P), fS, lane);
-    else jx_fft_lds<-1, NU, true>(col, fS.root, fS, lane);
+    if constexpr (JX_FFT_SMALL(NU)) jx_fft_lds<-1, NU, false, false, false>(col, (const double2*)(jx_fft_sm + WPB * L + P), fS, lane, (const double2*)nullptr, none);
+    else jx_fft_lds<-1, NU, true, false, false>(col, fS.root, fS, lane, (const double2*)nullptr, none);
     double2* ta = tfspec + (size_t)r0 * ldt;
     double2* tb = ta + ldt;
     for (int k = lane; k <= S / 2; k += 64) {
