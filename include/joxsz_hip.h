@@ -314,6 +314,12 @@ int  jx_get_info(jx_ctx* ctx, int32_t* fft_pad, int32_t* chunk, int32_t* spline_
                  int32_t* nrow, int64_t* device_bytes);
 /* 1 = rocFFT sequence, 2 = contracted route (what `conv_mode` resolved to); <0 on error */
 int  jx_get_conv_mode(jx_ctx* ctx);
+/* The transforms of the rocFFT sequence of this context (its own route with conv_mode 1, or the reference facility of a contracted-route
+ * context once jx_audit / a conv_2d tap / the truncation probe has built it): out = {built (0: nothing else is filled), columns hand-written
+ * (jx_fft.hpp) 0|1, rows hand-written 0|1, padded side P, leading dimension of the row spectra of the padded image, of the window,
+ * columns per block, passes of the length-P transform, then its radices (up to 12), passes of the length-S transform, its radices}.
+ * columns = 0: rocFFT's own 2-D plans (a side with a prime factor beyond 5, or beyond 1280, or JOXSZ_FFT_COLUMNS=rocfft). */
+int  jx_get_fft_info(jx_ctx* ctx, int32_t out[34]);
 /* What the hand-written route looks like on this problem: out = {form, NU, rank, beam_terms, R, RT, nxt, ntile, ksteps, tW,
  * ldx, ksplit}.  form 2 = exact (default): out[2] = ordinates the row operator reads (the radial grid beyond the map's corner plus the
  * band of the spline's moment operator does not reach the row: 400 of 500 at 512^2), out[3] = the same in whole tiles of 16, out[6] = output

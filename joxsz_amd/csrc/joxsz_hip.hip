@@ -2887,6 +2887,21 @@ int jx_get_info(jx_ctx* ctx, int32_t* fft_pad, int32_t* chunk, int32_t* band, in
     return JX_OK;
 }
 
+int jx_get_fft_info(jx_ctx* ctx, int32_t out[34]) {
+    if (!ctx || !ctx->finalized || !out) return JX_ERR_STATE;
+    const FftBack& fb = ctx->fft;
+    for (int i = 0; i < 34; ++i) out[i] = 0;
+    if (!fb.ready) return JX_OK;
+    out[0] = 1; out[1] = fb.cols ? 1 : 0; out[2] = fb.rows_custom ? 1 : 0; out[3] = fb.P;
+    if (!fb.cols) return JX_OK;
+    out[4] = fb.ldc; out[5] = fb.ldt; out[6] = fft_cb(fb.P);
+    out[7] = fb.fP.npass;
+    for (int p = 0; p < fb.fP.npass && p < JX_FFT_MAXPASS; ++p) out[8 + p] = fb.fP.radix[p];
+    out[20] = fb.fS.npass;
+    for (int p = 0; p < fb.fS.npass && p < JX_FFT_MAXPASS; ++p) out[21 + p] = fb.fS.radix[p];
+    return JX_OK;
+}
+
 int jx_get_conv_mode(jx_ctx* ctx) {
     if (!ctx || !ctx->finalized) return JX_ERR_STATE;
     return ctx->conv_mode;

@@ -17,7 +17,7 @@ EXPORTS = (
     'jx_create', 'jx_upload', 'jx_finalize', 'jx_eval', 'jx_eval_device', 'jx_sync', 'jx_set_stream', 'jx_sample', 'jx_eval_stage',
     'jx_set_route', 'jx_get_route', 'jx_get_operator', 'jx_set_option', 'jx_audit',
     'jx_set_par_vals', 'jx_dev_alloc', 'jx_dev_free', 'jx_memcpy_h2d', 'jx_memcpy_d2h',
-    'jx_timing_reset', 'jx_timing_enable', 'jx_timing_get', 'jx_get_info', 'jx_get_conv_mode', 'jx_get_conv_layout', 'jx_debug_workspace', 'jx_device_count',
+    'jx_timing_reset', 'jx_timing_enable', 'jx_timing_get', 'jx_get_info', 'jx_get_conv_mode', 'jx_get_conv_layout', 'jx_get_fft_info', 'jx_debug_workspace', 'jx_device_count',
     'jx_device_name', 'jx_strerror', 'jx_last_error', 'jx_destroy',
     'jx_get_truncation', 'jx_get_output_pruning', 'jx_get_sampling', 'jx_get_radial_sampling', 'jx_comm_unique_id', 'jx_comm_init_rank', 'jx_allgather_logp', 'jx_comm_allreduce_max', 'jx_comm_destroy',
     'jx_comm_count', 'jx_comm_set_overlap', 'jx_comm_gather_time', 'jx_map_kernel_time', 'jx_event_bracket_time', 'jx_fastmath_eval', 'jx_copy_bandwidth', 'jx_stream_bandwidth',
@@ -236,6 +236,19 @@ class HipContext:
             except Exception:
                 self.close()
                 raise
+
+    def fft_info(self):
+        """Transforms of the rocFFT sequence (this context's own route, or its reference facility once built): hand-written columns / rows or
+        rocFFT plans, padded side, radices of the two transform lengths (jx_get_fft_info)."""
+        o = (ctypes.c_int32 * 34)()
+        self._chk(self.lib.jx_get_fft_info(self._h, o), 'jx_get_fft_info')
+        v = [int(x) for x in o]
+        if not v[0]:
+            return {'built': False}
+        d = {'built': True, 'columns': 'custom' if v[1] else 'rocfft', 'rows': 'custom' if v[2] else 'rocfft', 'fft_pad': v[3]}
+        if v[1]:
+            d.update(ld_padded=v[4], ld_window=v[5], columns_per_block=v[6], radices_padded=v[8:8 + v[7]], radices_window=v[21:21 + v[20]])
+        return d
 
     def _layout(self):
         lay = (ctypes.c_int32 * 12)()
