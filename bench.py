@@ -39,6 +39,7 @@ bracketed by barrier + synchronisation; `ms_per_step_min` / `_max`, `timed_regio
   `other_configs`       strong-scaling rows of BASELINE configs[3] and configs[4] (this rank's shard).
 """
 import argparse
+import glob
 import json
 import os
 import subprocess
@@ -643,8 +644,8 @@ def main():
         cr = pr.ctx
         tr_, lr_ = cr.dev_alloc(theta.nbytes), cr.dev_alloc(8 * W)
         cr.h2d(tr_, theta)
-        nst = 5 if label == 'literal' else max(20, min(args.steps, 100))
-        dts_ = [time_steps(cr, tr_, W, lr_, nst, 3) for _ in range(1 if label == 'literal' else 5)]
+        nst = 10 if label == 'literal' else max(20, min(args.steps, 100))
+        dts_ = [time_steps(cr, tr_, W, lr_, nst, 3) for _ in range(3 if label == 'literal' else 5)]
         dt = float(np.median(dts_))
         cr.timing_enable(1); cr.timing_reset()
         for _ in range(3):
@@ -666,11 +667,26 @@ def main():
     if rank == 0 and comm is None and args.route == 'map' and not args.no_full_map and ctx.conv == 'custom':
         try:
             pr, cr, ns_route = side_route(lambda: JoxszPosterior(pb, device=local_rank, conv='rocfft', max_batch=W), 'literal',
-                                          'the same library with conv = rocfft: every map, its padded spectrum and the convolved map go through HBM')
-            ns_route['route'] = 'jx_abel_map_sym_kernel -> rocFFT R2C -> jx_beam_mul_kernel -> rocFFT C2R -> rocFFT R2C of the S x S window -> jx_tail_kernel'
+                                          'the same library with conv = rocfft: every map and its spectra go through HBM (map written; row spectra written, read and written by the column '
+                                          'pass, read by the fused inverse-row / window / forward-row pass; window spectra written and read once)')
+            fi = cr.fft_info()
+            ns_route['transforms'] = fi
+            if fi.get('columns') == 'custom' and fi.get('rows') == 'custom':
+                ns_route['route'] = ('jx_abel_map_sym_kernel -> jx_fft_rows_fwd_kernel -> jx_fft_beam_cols_kernel (forward, x beam spectrum, inverse) -> jx_fft_rows_inv_tf_kernel '
+                                     '(inverse rows, S x S window, forward rows) -> jx_fft_tf_cols_kernel (forward, x transfer function, column sum) -> jx_tail_kernel')
+            else:
+                ns_route['route'] = 'jx_abel_map_sym_kernel -> rocFFT R2C -> jx_beam_mul_kernel -> rocFFT C2R -> rocFFT R2C of the S x S window -> jx_tail_kernel'
             ns_route['fft_pad'] = cr.fft_pad
             ns_route['survey_8d_bytes_per_step'] = 2.0 * W * args.S * args.S * 8.0
             ns_route['frac_of_hbm_peak_on_survey_8d_bytes'] = ns_route['survey_8d_bytes_per_step'] / (ns_route['ms_per_step'] * 1e-3) / 1e9 / HBM_PEAK_GBS
+            # HBM bytes of the route from the latest committed PMC pass over it (scripts/measure_traffic.py <tag> literal), same shape and launch size only
+            for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic_literal.json')), reverse=True):
+                pj = json.load(open(f))
+                if pj.get('S') == args.S and pj.get('N') == args.N and pj.get('walkers_per_launch') == W:
+                    ns_route['pmc_traffic'] = {'file': os.path.relpath(f, ROOT), 'total_bytes': pj['total_bytes'], 'over_survey_8d_bytes': pj['total_over_survey_8d_bytes'],
+                                               'per_kernel_bytes': {k: v['total_bytes'] for k, v in pj['kernels'].items()},
+                                               'frac_of_hbm_peak_on_pmc_bytes': pj['total_bytes'] / (ns_route['ms_per_step'] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                    break
             pr.close()
         except Exception as exc:
             ns_route = {'error': str(exc)}

@@ -68,7 +68,8 @@ typedef struct jx_config {
     int32_t max_batch;        /* walkers processed per internal chunk (0 = library default)    */
     int32_t fft_pad;          /* padded side of the beam convolution (0 = library default)     */
     int32_t map_split;        /* row slabs per walker in the Abel+map kernel (0 = default)     */
-    int32_t conv_mode;        /* beam + transfer-function step: 0 auto, 1 rocFFT sequence (joxsz_funcs.py:460-467 executed literally), 2 hand-written kernels:
+    int32_t conv_mode;        /* beam + transfer-function step: 0 auto, 1 the literal FFT sequence (joxsz_funcs.py:460-467 executed pass by pass; called "rocFFT sequence" below: its transforms are hand-written
+                               * LDS transforms, csrc/jx_fft.hpp, wherever both sides are 2^a 3^b 5^c, and rocFFT plans elsewhere or on request, see jx_get_fft_info), 2 hand-written kernels:
                                * the exact form (default: the row as one constant operator on the spline ordinates, see jx_get_conv_layout) or, behind the option
                                * JOXSZ_MIX_FORM, the contracted forms of rounds 3-4 */
     int32_t dtype;            /* arithmetic of the SZ stages: 0 = f64 (the reference's; the exact form).  The fp32 variants run on the contracted low-rank form of
@@ -143,8 +144,10 @@ typedef struct jx_timing {
     double prep_ms;       /* priors, mass veto, T profile, X-ray Cash      */
     double abel_map_ms;   /* exact form: ordinate product (Abel transform + Compton-y scale) and row product on the matrix cores (jx_ordrow_kernel); contracted forms:
                            * Abel integral + spline arrays as one matrix product; rocFFT sequence: profile -> Abel -> spline -> y map */
-    double beam_fft_ms;   /* exact form: 0; contracted forms: stage 1 (jx_rowmix_kernel); rocFFT: R2C + multiply + C2R */
-    double tf_fft_ms;     /* exact form: 0; contracted forms: stage 2 / the full form's product (jx_opgemm_kernel); rocFFT: R2C of the S x S window */
+    double beam_fft_ms;   /* exact form: 0; contracted forms: stage 1 (jx_rowmix_kernel); rocFFT sequence: forward rows + column kernel (hand-written transforms; the inverse rows are
+                           * inside the next kernel), or R2C + multiply + C2R (rocFFT plans) */
+    double tf_fft_ms;     /* exact form: 0; contracted forms: stage 2 / the full form's product (jx_opgemm_kernel); rocFFT sequence: inverse rows + window + forward rows, then the
+                           * transfer-function column kernel (hand-written), or R2C of the S x S window (rocFFT plans) */
     double tail_ms;       /* exact form: partial rows added, conversion, data radii, chi^2, total (jx_rowsum_tail_kernel); otherwise filter + central row + conversion + chi^2 */
     double total_ms;      /* first event to last event of each launch      */
     int64_t launches;     /* internal chunks timed                         */

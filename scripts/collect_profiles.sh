@@ -8,6 +8,14 @@ set -e
 python scripts/measure_traffic.py ${TAG} > gpurun_out/${TAG}_pmc_traffic.log 2>&1
 rm -rf gpurun_out/traffic_${TAG}_fetch gpurun_out/traffic_${TAG}_write
 cp gpurun_out/${TAG}_pmc_traffic.json profiles/${TAG}_pmc_traffic.json
+# 1a. the same for the literal route (conv = rocfft) at 512^2 / 1024 walkers: HBM bytes of its kernels, SQ counters, kernel statistics, the three transform modes
+python scripts/measure_traffic.py ${TAG} literal > gpurun_out/${TAG}_pmc_traffic_literal.log 2>&1
+rm -rf gpurun_out/traffic_${TAG}_fetch gpurun_out/traffic_${TAG}_write
+cp gpurun_out/${TAG}_pmc_traffic_literal.json profiles/${TAG}_pmc_traffic_literal.json
+python scripts/sq_counters.py literal 512 500 1024 2 > gpurun_out/${TAG}_sq_counters_literal.log 2>&1
+rm -rf gpurun_out/sq_pmc
+bash scripts/prof_literal.sh ${TAG}_literal > /dev/null 2>&1
+python scripts/literal_cols.py > gpurun_out/${TAG}_literal_transforms.log 2>&1
 # 1b. where the wave cycles go (SQ counters, one pass) and the idle time between the kernels of a step under the profiler -- also ahead of the bench lines, which quote the shares
 python scripts/sq_counters.py > gpurun_out/${TAG}_sq_counters.log 2>&1
 mv gpurun_out/sq_counters.csv gpurun_out/${TAG}_sq_counters.csv

@@ -34,11 +34,11 @@ for S, N, nw in SHAPES:
             c.eval_device(tp, nw, lp)
         tm = c.timing(); c.timing_enable(0)
         out = np.empty(nw); c.d2h(out, lp)
-        res[cols] = (conv, row, out, ms, {k[:-3]: round(v / 3, 3) for k, v in tm.items() if k.endswith('_ms') and v}, c.fft_pad)
+        res[cols] = (conv, row, out, ms, {k[:-3]: round(v / 3, 3) for k, v in tm.items() if k.endswith('_ms') and v}, c.fft_pad, c.fft_info())
         post.close()
     a = res['rocfft']
     fin = np.isfinite(a[2])
-    print('S=%d N=%d W=%d pad %d: rocFFT 2-D plans %.3f ms %s' % (S, N, nw, a[5], a[3], a[4]), flush=True)
+    print('S=%d N=%d W=%d pad %d (radices %s | %s): rocFFT 2-D plans %.3f ms %s' % (S, N, nw, a[5], res['all'][6].get('radices_padded'), res['all'][6].get('radices_window'), a[3], a[4]), flush=True)
     for name in ('custom', 'all'):
         b = res[name]
         print('    %-28s conv %.1e row %.1e logp %.1e (nonfinite agree: %s) %.3f ms %s'
