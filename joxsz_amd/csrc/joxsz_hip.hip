@@ -147,7 +147,7 @@ struct jx_ctx {
     // spline arrays as one matrix product (jx_abel_gemm_kernel)
     double* d_Tm = nullptr; int tm_ld = 0, tm_ntile = 0, tm_npair = 0;
     double* d_ppc = nullptr;           // [chunk][N] prep kernel -> jx_abel_gemm_kernel
-    // radial sub-grid of the spline-array product: Tm through the interpolation from the kept radii, their indices, the first k-step of every column tile
+    // radial sub-grid of the spline-array product (DESIGN of round 4, 6.3): Tm through the interpolation from the kept radii, their indices, the first k-step of every column tile
     bool ag_sub = true;                // JOXSZ_AG_SUBSAMPLE=0: every radius of the profile; "u0,u1,npts": another sub-grid
     int ag_u0 = 64, ag_u1 = 256, ag_npts = 18;
     bool ag_sub_on = false;            // in use (set at the end of finalize_impl; the guard of jx_finalize may take it away)
@@ -175,7 +175,7 @@ struct jx_ctx {
     bool usplit_forced = false;        // (otherwise plan_mix picks it from the columns stage 1 walks and the chunk)
     int rank_cap = 16;                 // low-rank form: a rank within JX_MIX_CAP_REACH terms above this is cut to it, so that stage 1 fits one 16-row matrix-core
                                        // tile (the guard measures the result and takes the cap away when it costs accuracy; JOXSZ_MIX_RANKCAP=0: never)
-    bool mix_mfma = false;             // JOXSZ_MIX_MFMA=1: stage 1 on the fp64 matrix cores when R <= 16 (measured slower than the vector-unit kernel: DESIGN 6.1)
+    bool mix_mfma = false;             // JOXSZ_MIX_MFMA=1: stage 1 on the fp64 matrix cores when R <= 16 (measured slower than the vector-unit kernel: DESIGN of round 4, 6.1)
 
     // batch staging for the host-pointer API
     double *d_theta = nullptr, *d_logp = nullptr;

@@ -1743,7 +1743,7 @@ __global__ void __launch_bounds__(256)
 jx_abel_gemm_kernel(const double* __restrict__ pp /*[launch][N]*/, int n, int N, const double* __restrict__ Tm /*[JX_AG_ROWS(N)][ldt], zero rows behind N-1*/,
                     int ldt, int K, int ntile, int npair, TO* __restrict__ cf /*[launch][cf_ws]; float for the fp32 variant (rounded once, on store)*/, long long cf_ws,
                     long long ncol = 0,
-                    // radial sub-grid: the rows of Tm are then N of the Npp radii of a profile (rsub[k] = the radius of row k), the
+                    // radial sub-grid (DESIGN of round 4, 6.3): the rows of Tm are then N of the Npp radii of a profile (rsub[k] = the radius of row k), the
                     // interpolation to the others folded into Tm, and tks[t] = the first k-step of column tile t with entries (null: all radii)
                     const int* __restrict__ rsub = nullptr, int Npp = 0, const int* __restrict__ tks = nullptr) {
     JX_LDS_DECL;

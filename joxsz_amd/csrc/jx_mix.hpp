@@ -302,7 +302,7 @@ jx_rowmix_f32_kernel(JxMix m, const float2* __restrict__ cft, float* __restrict_
 // Stage 1 on the fp64 matrix cores, for R <= 16 rows per column (one 16-row tile).  OPT-IN (JOXSZ_MIX_MFMA=1): measured at 100 us
 // per 1024 walkers at 512^2 against the 81 us of jx_rowmix_kernel -- a wave's per-sample loop costs about as many cycles per
 // instruction whatever the instruction's kind, and the staging, the group counter and the dispatch weigh as much as the 16
-// multiply-adds they replace (profiles/r04_stage1_mfma_*.log).  Same walk as jx_rowmix_kernel: one
+// multiply-adds they replace (DESIGN of round 4, 6.1; profiles/r04_stage1_mfma_*.log).  Same walk as jx_rowmix_kernel: one
 // wave = one piece of column x' x 64 walkers, lane = walker, knots in the ring of NS named slots, the four spline weights
 // of a sample through the scalar unit, the sample evaluated by its walker's lane (4 FMAs; joxsz_funcs.py:460-462).  What
 // changes is the mixing: instead of R scalar-operand FMAs per sample, the samples of four consecutive rows u0 .. u0+3 go
