@@ -1726,6 +1726,9 @@ static int finalize_impl(jx_ctx* ctx) {
     ctx->chunk = chunk;
     if (!map_geometry(d, 512, &ctx->map_threads, &ctx->map_lds)) {
         if (ctx->conv_mode != 2) { ctx->err = "radial grid too long for the LDS-resident spline of the Abel + map kernel (the rocFFT sequence needs it)"; return JX_ERR_UNSUPPORTED; }
+        // the contracted forms decided their truncation and sub-grids on the earlier check of the same geometry: had that one passed and this one not,
+        // those approximations would run with nothing to measure them -- refuse rather than run unguarded; the exact form takes none
+        if (ctx->map_ok && mixb.form != 2) { ctx->err = "radial grid too long for the Abel + map kernel after the contracted tables were planned with it: use the exact form (JOXSZ_MIX_FORM=exact)"; return JX_ERR_UNSUPPORTED; }
         ctx->map_ok = false;
     }
     {
@@ -2258,7 +2261,7 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
     if (tm) HIPCHK(ctx, hipEventRecord(es.e[4], st));
     }
     {
-        const size_t sh = sizeof(double) * (JX_LDS_HDR + (size_t)2 * d.Sh + d.nrow + 8);
+        const size_t sh = sizeof(double) * (JX_LDS_HDR + (size_t)2 * d.Sh + d.nrow + 8 + (size_t)2 * d.S);      // (+ the roots of unity of the row)
         hipLaunchKernelGGL(jx_tail_kernel, dim3(n), dim3(JX_TAIL_THREADS), sh, st, fb.d, fb.tfspec, zin, ctx->d_cfac, ctx->d_sz0,
                            ctx->d_base, logp_dev, w0, t.row, t.bright, t.chisq, t.parts);
     }

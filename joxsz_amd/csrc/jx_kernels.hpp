@@ -1408,7 +1408,13 @@ jx_tail_kernel(JxDev c, const double2* __restrict__ tfspec, const double* __rest
     }
     __syncthreads();
 
-    const double2* tw = reinterpret_cast<const double2*>(c.twid);
+    // the S roots of unity of the row's inverse transform: into LDS first (the loop below reads one per term at a data-dependent index)
+    double2* tw = reinterpret_cast<double2*>(s_prof + ((nrow + 1) & ~1));
+    {
+        const double2* twg = reinterpret_cast<const double2*>(c.twid);
+        for (int m = tid; m < S; m += nth) tw[m] = twg[m];
+    }
+    __syncthreads();
     const int c0 = S / 2;
     for (int k = tid; k < nrow; k += nth) {
         const int col = c0 + k;
