@@ -360,6 +360,7 @@ __device__ __forceinline__ void jx_xray_side(const JxDev& c, const JxXrTab& xt, 
         }
     }
     __syncthreads();
+    JX_PSTAMP(c, 2);
     const int nba = c.nband * c.nann;
     for (int q = tid; q < nba; q += nth) {
         const int b = q / c.nann, j = q - b * c.nann;
@@ -371,6 +372,7 @@ __device__ __forceinline__ void jx_xray_side(const JxDev& c, const JxXrTab& xt, 
         s_rate[q] = (z0 + (z1 - z0) * p[P_Z]) * s_ne[j] * s_ne[j];
     }
     __syncthreads();
+    JX_PSTAMP(c, 3);
     int bad = 0;
     for (int q = tid; q < nba; q += nth) {
         const int b = q / c.nann, i = q - b * c.nann;
@@ -383,7 +385,9 @@ __device__ __forceinline__ void jx_xray_side(const JxDev& c, const JxXrTab& xt, 
         const double ct = xt.cts[q];
         s_term[q] = (ct == ct) ? ct * mt.l(model) - model : 0.0;
     }
+    JX_PSTAMP(c, 4);
     int xbad = jx_block_or(bad, redi);     // (its barriers order s_term as well)
+    JX_PSTAMP(c, 5);
     if (tid < 64) {
         double tot = 0.0;
         for (int q0 = 0; q0 < nba; q0 += 64) {
