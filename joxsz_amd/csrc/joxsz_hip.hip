@@ -442,32 +442,7 @@ static void fft_teardown(FftBack& fb) {
     fb.ready = false;
 }
 
-// radices of a transform length for jx_fft.hpp: the split into the fewest passes, among those the one with the least work per thread
-// (butterflies of a column per thread x size of the butterfly); largest radix first (the first pass has no twiddles).  0 passes: the
-// length has a prime factor beyond 5.
-static int fft_factor(int n, int* radix, int tpc = 64) {
-    static const int kR[] = {16, 12, 10, 9, 8, 6, 5, 4, 3, 2};
-    const int first = n > 640 ? 0 : 2;                            // (radices 16 and 12: the 4-columns-per-block kernels only, jx_fft.hpp)
-    std::vector<int> best, cur;
-    double best_cost = 0.0;
-    std::function<void(int, int, double)> go = [&](int rem, int at, double cost) {
-        if (rem == 1) {
-            if (best.empty() || cur.size() < best.size() || (cur.size() == best.size() && cost < best_cost)) { best = cur; best_cost = cost; }
-            return;
-        }
-        if ((int)cur.size() >= JX_FFT_MAXPASS || (!best.empty() && cur.size() >= best.size())) return;
-        for (int i = std::max(at, first); i < (int)(sizeof(kR) / sizeof(kR[0])); ++i) {
-            const int r = kR[i];
-            if (rem % r) continue;
-            cur.push_back(r);
-            go(rem / r, i, cost + (double)((n / r + tpc - 1) / tpc) * r * (std::log2((double)r) + 1.0));
-            cur.pop_back();
-        }
-    };
-    go(n, 0, 0.0);
-    for (size_t i = 0; i < best.size(); ++i) radix[i] = best[i];
-    return (int)best.size();
-}
+static int fft_factor(int n, int* radix) { return jxt::fft_radices(n, radix, JX_FFT_MAXPASS); }
 
 static int fft_transform(jx_ctx* ctx, FftBack& fb, int n, JxFft& f) {
     f.n = n;

@@ -336,6 +336,41 @@ inline void tf_row_table(const std::vector<double>& filt, int S, std::vector<dou
 
 
 // ---------------------------------------------------------------------------------------
+// Radices of a transform length for the LDS transforms of the literal route (jx_fft.hpp): the split into the fewest
+// passes, among those the one with the least work per lane (butterflies of a sequence per lane x size of the butterfly,
+// 64 lanes per sequence); largest radix first (the first pass has no twiddles).  Radices 10 9 8 6 5 4 3 2, and 16 12 for
+// lengths beyond 640 (the kernels that may hold 256 registers).  Returns the number of passes; 0: the length has a prime
+// factor beyond 5, or needs more than maxpass passes.
+// ---------------------------------------------------------------------------------------
+inline int fft_radices(int n, int* radix, int maxpass) {
+    static const int kR[] = {16, 12, 10, 9, 8, 6, 5, 4, 3, 2};
+    const int nR = (int)(sizeof(kR) / sizeof(kR[0])), tpc = 64;
+    const int first = n > 640 ? 0 : 2;
+    if (n < 2) return 0;
+    std::vector<int> best, cur;
+    double best_cost = 0.0;
+    struct Rec {
+        static void go(int n, int rem, int at, double cost, int first, int nR, int tpc, int maxpass, std::vector<int>& cur, std::vector<int>& best, double& best_cost) {
+            if (rem == 1) {
+                if (best.empty() || cur.size() < best.size() || (cur.size() == best.size() && cost < best_cost)) { best = cur; best_cost = cost; }
+                return;
+            }
+            if ((int)cur.size() >= maxpass || (!best.empty() && cur.size() >= best.size())) return;
+            for (int i = std::max(at, first); i < nR; ++i) {
+                const int r = kR[i];
+                if (rem % r) continue;
+                cur.push_back(r);
+                go(n, rem / r, i, cost + (double)((n / r + tpc - 1) / tpc) * r * (std::log2((double)r) + 1.0), first, nR, tpc, maxpass, cur, best, best_cost);
+                cur.pop_back();
+            }
+        }
+    };
+    Rec::go(n, n, 0, 0.0, first, nR, tpc, maxpass, cur, best, best_cost);
+    for (size_t i = 0; i < best.size(); ++i) radix[i] = best[i];
+    return (int)best.size();
+}
+
+// ---------------------------------------------------------------------------------------
 // Small host FFT (recursive Cooley-Tukey on the smallest prime factor, naive DFT for
 // primes); sign = -1 forward, +1 inverse, unnormalised.  Used only to build tables.
 // ---------------------------------------------------------------------------------------

@@ -220,4 +220,7 @@ int jxt_abel_ordinate_layout(const double* r, int n, double y_scale, int nS, int
     return 0;
 }
 
+// radices of the LDS transforms of the literal route for length n (jx_fft.hpp): passes, or 0 when the length is not 2^a 3^b 5^c
+int jxt_fft_radices(int n, int* radix /*[12]*/) { return jxt::fft_radices(n, radix, 12); }
+
 }  // extern "C"

@@ -620,3 +620,51 @@ def test_exact_form_operand_layouts(lib):
                     x, i = 16 * (g * NXT + t) + li, 16 * s + 4 * lk + e
                     want = np.where((x < nrow) & (i < N), Wy[np.minimum(x, nrow - 1), np.minimum(i, N - 1)], 0.0)
                     np.testing.assert_array_equal(Opk[g, s, e, :, t], want)
+
+
+def _stockham(x, radices, sign):
+    """The passes of csrc/jx_fft.hpp restated in numpy: in place, every butterfly of a pass read before any is written; butterfly j of a
+    pass of radix R behind sub-transforms of size ns reads x[j + t n/R], multiplies by root^(t (j mod ns) n/(ns R)), transforms the R values and
+    writes them to y[(j - j mod ns) R + j mod ns + t ns]."""
+    n = x.size
+    root = np.exp(sign * 2j * np.pi * np.arange(n) / n)
+    ns = 1
+    for R in radices:
+        nb, tstep = n // R, n // (ns * R)
+        j = np.arange(nb)
+        k = j % ns
+        v = np.stack([x[j + t * nb] * root[(t * k * tstep) % n] for t in range(R)])            # [R][nb]
+        v = np.exp(sign * 2j * np.pi * np.outer(np.arange(R), np.arange(R)) / R) @ v            # the R-point transform
+        y = np.empty_like(x)
+        for t in range(R):
+            y[(j - k) * R + k + t * ns] = v[t]
+        x, ns = y, ns * R
+    return x
+
+
+def test_fft_radices_and_the_stockham_passes_of_the_literal_route(lib):
+    """jx_fft.hpp's host side: every 2^a 3^b 5^c length up to 1280 splits into at most four passes of the radices the kernels have (<= 10 up to
+    640: the 128-register kernels; 12 and 16 beyond), other lengths are refused; the pass formulas with those radices are the DFT."""
+    rng = np.random.default_rng(5)
+    smooth = [n for n in range(2, 1281) if max((p for p in range(2, n + 1) if n % p == 0 and all(p % q for q in range(2, p))), default=1) <= 5]
+    assert 540 in smooth and 512 in smooth and 1080 in smooth
+    for n in range(2, 1281):
+        rx = (ctypes.c_int * 12)()
+        npass = lib.jxt_fft_radices(n, rx)
+        if n not in smooth:
+            assert npass == 0, n
+            continue
+        r = list(rx[:npass])
+        assert 1 <= npass <= 4 and int(np.prod(r)) == n, (n, r)
+        assert set(r) <= ({2, 3, 4, 5, 6, 8, 9, 10} if n <= 640 else {2, 3, 4, 5, 6, 8, 9, 10, 12, 16}), (n, r)
+        assert r == sorted(r, reverse=True), (n, r)                      # largest first: the pass without twiddles is the widest
+        nu = next(v for v in (4, 8, 9, 10, 16, 17, 20) if v >= -(-n // 64))        # the kernel instance of this length (rows per lane, rounded up)
+        assert all(-(-(n // R) // 64) <= -(-nu // R) for R in r), (n, r)               # butterflies per lane of a pass fit its register array
+    assert list((lambda a: (lib.jxt_fft_radices(540, a), a[:3])[1])((ctypes.c_int * 12)())) == [10, 9, 6]
+    assert list((lambda a: (lib.jxt_fft_radices(512, a), a[:3])[1])((ctypes.c_int * 12)())) == [8, 8, 8]
+    for n in (12, 96, 160, 288, 512, 540, 1024, 1080, 75, 135, 243):
+        rx = (ctypes.c_int * 12)()
+        r = list(rx[:lib.jxt_fft_radices(n, rx)])
+        x = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+        np.testing.assert_allclose(_stockham(x.copy(), r, -1), np.fft.fft(x), rtol=0, atol=1e-12 * n)
+        np.testing.assert_allclose(_stockham(x.copy(), r, +1), np.fft.ifft(x) * n, rtol=0, atol=1e-12 * n)
