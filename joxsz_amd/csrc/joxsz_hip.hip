@@ -514,19 +514,19 @@ static void fft_launch_rows_inv_tf(FftBack& fb, int walkers, hipStream_t st, int
 }
 
 static int fft_kernels(jx_ctx* ctx, FftBack& fb) {
-    const int S = ctx->cfg.S;
-    const int lp = (int)JX_FFT_LDS_BYTES(fb.P, fft_cb(fb.P), 1), ls = (int)JX_FFT_LDS_BYTES(S, fft_cb(S), 1);
-#define X(CB, NU) HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_fft_beam_cols_kernel<CB, NU>, hipFuncAttributeMaxDynamicSharedMemorySize, lp))
+    // the attribute belongs to the kernel instance, not to the context: another context of the process may launch the same instance with a
+    // longer transform, so every instance is allowed the whole LDS of a compute unit (as the Abel + map kernel is)
+    const int S = ctx->cfg.S, lds = 160 * 1024 - 1024;
+#define X(CB, NU) HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_fft_beam_cols_kernel<CB, NU>, hipFuncAttributeMaxDynamicSharedMemorySize, lds))
     JX_FFT_DISPATCH(JX_FFT_NU_OF(fb.P), X);
 #undef X
-#define X(CB, NU) HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_fft_tf_cols_kernel<CB, NU>, hipFuncAttributeMaxDynamicSharedMemorySize, ls))
+#define X(CB, NU) HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_fft_tf_cols_kernel<CB, NU>, hipFuncAttributeMaxDynamicSharedMemorySize, lds))
     JX_FFT_DISPATCH(JX_FFT_NU_OF(S), X);
 #undef X
-    const int nroot = fft_roots_in_lds(fb.P) ? fb.P + S : 0;
-#define X(WPB, NU) HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_fft_rows_fwd_kernel<WPB, NU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)JX_FFT_ROWS_LDS_BYTES(fb.P, WPB, nroot)))
+#define X(WPB, NU) HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_fft_rows_fwd_kernel<WPB, NU>, hipFuncAttributeMaxDynamicSharedMemorySize, lds))
     JX_FFT_ROWS_DISPATCH(JX_FFT_NU_OF(fb.P), 8, X);
 #undef X
-#define X(WPB, NU) HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_fft_rows_inv_tf_kernel<WPB, NU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)JX_FFT_ROWS_LDS_BYTES(fb.P, WPB, nroot)))
+#define X(WPB, NU) HIPCHK(ctx, hipFuncSetAttribute((const void*)jx_fft_rows_inv_tf_kernel<WPB, NU>, hipFuncAttributeMaxDynamicSharedMemorySize, lds))
     JX_FFT_ROWS_DISPATCH(JX_FFT_NU_OF(fb.P), 7, X);
 #undef X
     return JX_OK;

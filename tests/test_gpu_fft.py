@@ -67,3 +67,24 @@ def test_reference_facility_of_the_exact_form_uses_the_same_transforms():
     assert info['built'] and info['columns'] == 'custom' and info['rows'] == 'custom', info
     assert a['walkers_compared'] > 0 and a['max_rel_row_diff'] <= 1e-12 and a['max_abs_sz_loglike_diff'] <= 1e-8, a
     post.close()
+
+
+def test_two_contexts_that_share_a_kernel_instance_keep_their_own_sizes():
+    """Sides 540, 512 and 500 (padded 576, 540, 540) share kernel instances (9 rows per lane): the LDS allowance of an instance must not be the
+    last context's -- a context built later with a shorter transform would leave the longer one unable to launch.  All alive, evaluated in turn."""
+    from joxsz_amd import datasets
+    from joxsz_amd.posterior import JoxszPosterior
+    posts = []
+    for S, N in ((540, 560), (512, 500), (500, 520)):
+        pb = datasets.synthetic_problem(S=S, N=N, seed=3)
+        th = np.ascontiguousarray(datasets.walker_ball(pb, 3, spread=0.02, seed=4))
+        ref = _run(pb, th, MODES['rocfft'])
+        posts.append((JoxszPosterior(pb, device=0, conv='rocfft'), th, ref))
+    for rep in range(2):
+        for post, th, ref in posts:
+            assert post.ctx.fft_info()['columns'] == 'custom'
+            got = post.log_prob(th)
+            fin = np.isfinite(ref[2])
+            np.testing.assert_allclose(got[fin], ref[2][fin], rtol=1e-11)
+    for post, _, _ in posts:
+        post.close()
