@@ -2048,6 +2048,14 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
                         for (int k = 0; k < 5; ++k) { const double v = (h[(size_t)b * 8 + k] - t0) * 0.01; mx[k] = std::max(mx[k], v); sm[k] += v / nb; }
                     fprintf(stderr, "ordrow stamps (us after the first block's start; mean / max over %d blocks): start %.2f/%.2f  first loads %.2f/%.2f  k loop %.2f/%.2f  ordinates %.2f/%.2f  end %.2f/%.2f\n",
                             nb, sm[0], mx[0], sm[1], mx[1], sm[2], mx[2], sm[3], mx[3], sm[4], mx[4]);
+                    for (int pp_ = 0; pp_ < m.x_npair; ++pp_) {                  // per pair: mean first loads | k loop | end
+                        double a[3] = {0, 0, 0}, e_max = 0; int cnt = 0;
+                        for (int b = 0; b < nb; ++b) if ((b >> 3) % m.x_npair == pp_) {
+                            a[0] += (h[(size_t)b * 8 + 1] - t0) * 0.01; a[1] += (h[(size_t)b * 8 + 2] - t0) * 0.01; a[2] += (h[(size_t)b * 8 + 4] - t0) * 0.01;
+                            e_max = std::max(e_max, (h[(size_t)b * 8 + 4] - t0) * 0.01); ++cnt;
+                        }
+                        fprintf(stderr, "  pair %2d: first loads %.2f  k loop %.2f  end %.2f (max %.2f)\n", pp_, a[0] / cnt, a[1] / cnt, a[2] / cnt, e_max);
+                    }
                 }
             }
 #endif
