@@ -2048,6 +2048,23 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
                         for (int k = 0; k < 5; ++k) { const double v = (h[(size_t)b * 8 + k] - t0) * 0.01; mx[k] = std::max(mx[k], v); sm[k] += v / nb; }
                     fprintf(stderr, "ordrow stamps (us after the first block's start; mean / max over %d blocks): start %.2f/%.2f  first loads %.2f/%.2f  k loop %.2f/%.2f  ordinates %.2f/%.2f  end %.2f/%.2f\n",
                             nb, sm[0], mx[0], sm[1], mx[1], sm[2], mx[2], sm[3], mx[3], sm[4], mx[4]);
+                    {                                                            // where the late first operands are: by XCD, by eighth of the grid, and the ten latest blocks
+                        double bx[8] = {0}, bo[8] = {0}; int cx[8] = {0}, co[8] = {0}, late = 0;
+                        std::vector<std::pair<double, int>> fl;
+                        for (int b = 0; b < nb; ++b) {
+                            const double v = (h[(size_t)b * 8 + 1] - h[(size_t)b * 8]) * 0.01;
+                            bx[b & 7] += v; ++cx[b & 7]; bo[b * 8 / nb] += v; ++co[b * 8 / nb]; if (v > 3.0) ++late;
+                            fl.push_back({v, b});
+                        }
+                        std::sort(fl.rbegin(), fl.rend());
+                        fprintf(stderr, "  first operands after the block's own start, mean by XCD:");
+                        for (int k = 0; k < 8; ++k) fprintf(stderr, " %.2f", bx[k] / std::max(1, cx[k]));
+                        fprintf(stderr, " | by eighth of the grid:");
+                        for (int k = 0; k < 8; ++k) fprintf(stderr, " %.2f", bo[k] / std::max(1, co[k]));
+                        fprintf(stderr, " | %d blocks beyond 3 us; latest:", late);
+                        for (int k = 0; k < 10 && k < (int)fl.size(); ++k) fprintf(stderr, " %d(%.1f, start %.1f)", fl[k].second, fl[k].first, (h[(size_t)fl[k].second * 8] - t0) * 0.01);
+                        fprintf(stderr, "\n");
+                    }
                     for (int pp_ = 0; pp_ < m.x_npair; ++pp_) {                  // per pair: mean first loads | k loop | end
                         double a[3] = {0, 0, 0}, e_max = 0; int cnt = 0;
                         for (int b = 0; b < nb; ++b) if ((b >> 3) % m.x_npair == pp_) {
