@@ -171,6 +171,8 @@ int  jx_finalize(jx_ctx* ctx);
  *   JOXSZ_MIX_FORM               exact|legacy|lowrank|full (exact)  form of the hand-written route: the exact form, or the contracted forms of rounds 3-4
  *                                                          (legacy: the cheaper of low-rank and full, as round 4 picked; they carry their own options below)
  *   JOXSZ_X_PAIRWISE             1|0 (1)                   exact form: 0 = its reference kernels (one block per 16 walkers reads the ordinates back; jx_rowop_tail_kernel)
+ *   JOXSZ_X_FOLD                 1|0 (1)                   exact form, odd number of 16-ordinate tiles: the last tile's share of the row as an operator on the profile inside the row
+ *                                                          product, the others in exact pairs (one block fewer per 16 walkers: 768 instead of 832 at 512^2 / 1024 walkers); 0: every tile in the ordinate product
  *   JOXSZ_PRUNE_OUTPUTS          1|0 (1)                   0: the row product computes every output of the row, read by the data-radii spline or not
  *   JOXSZ_CHUNK                  walkers                   overrides jx_config.max_batch
  *   JOXSZ_FFT_PAD, JOXSZ_MAP_SPLIT, JOXSZ_MAP_PAIR         rocFFT sequence / Abel + map kernel: padded side, row slabs per walker, two walkers per block (1)

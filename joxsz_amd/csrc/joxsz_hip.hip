@@ -79,7 +79,8 @@ struct MixBack {
     bool ready = false;
     int form = 0;                      // 0 low-rank (stage 1 + stage 2), 1 full operator on the samples (round 3-4, JOXSZ_MIX_FORM=legacy|lowrank|full); 2 exact (default)
     // exact form (jx_exact.hpp): the ordinate product's operator Ty and first k-steps, the row operator Opk, the ordinates y
-    int Nk = 0, Nkp = 0, x_nxt = 0, x_ng = 0, x_ng_use = 0, x_npair = 0, x_nSj = 0, x_ldpp = 0;
+    int Nk = 0, Nkp = 0, x_nxt = 0, x_ng = 0, x_ng_use = 0, x_npair = 0, x_nSj = 0, x_ldpp = 0, x_nfold = 0;
+    double *x_Wfk = nullptr;           // odd number of ordinate tiles: the last one's share of the row as an operator on the profile (timed path; jxt::exact_fold_layout)
     double *x_Typ = nullptr, *x_Opk = nullptr, *x_y = nullptr, *x_cf = nullptr, *x_P = nullptr, *x_ppi = nullptr;
     bool x_pairwise = true;            // JOXSZ_X_PAIRWISE=0: the ordinates read back by one block per 16 walkers (jx_rowop_tail_kernel)
     JxMix mx{};
@@ -311,7 +312,7 @@ static std::vector<T> host_vec(jx_ctx* ctx, int id) {
 // SAMPLE_ ones), with the process environment as the default of each.  The list is the one include/joxsz_hip.h documents
 // (tests/test_abi.py holds the two and the uses in this file together).
 static const char* const kOptions[] = {
-    "JOXSZ_CONV", "JOXSZ_MIX_FORM", "JOXSZ_X_PAIRWISE", "JOXSZ_PRUNE_OUTPUTS", "JOXSZ_CHUNK", "JOXSZ_FFT_PAD", "JOXSZ_FFT_COLUMNS", "JOXSZ_FFT_ROWS", "JOXSZ_MAP_SPLIT", "JOXSZ_MAP_PAIR",
+    "JOXSZ_CONV", "JOXSZ_MIX_FORM", "JOXSZ_X_PAIRWISE", "JOXSZ_X_FOLD", "JOXSZ_PRUNE_OUTPUTS", "JOXSZ_CHUNK", "JOXSZ_FFT_PAD", "JOXSZ_FFT_COLUMNS", "JOXSZ_FFT_ROWS", "JOXSZ_MAP_SPLIT", "JOXSZ_MAP_PAIR",
     "JOXSZ_EVAL_DIRECT", "JOXSZ_PREP_SPLIT", "JOXSZ_PREP_LEAN", "JOXSZ_PREP_POW", "JOXSZ_PREP_FASTMATH", "JOXSZ_OP_NARROW", "JOXSZ_SAMPLE_FUSED", "JOXSZ_SAMPLE_VIRTUAL_RANKS",
     // the contracted forms of rounds 3-4 (JOXSZ_MIX_FORM=legacy|lowrank|full)
     "JOXSZ_LOWRANK_TOL", "JOXSZ_TRUNC_PROBE", "JOXSZ_TRUNC_BOUND", "JOXSZ_MIX_SUBSAMPLE", "JOXSZ_MIX_RANKCAP", "JOXSZ_MIX_MFMA", "JOXSZ_MIX_USPLIT", "JOXSZ_MIX_WPB",
@@ -681,7 +682,8 @@ struct MixBuild {
     double tol = 0.0, beam_tol = 0.0;
     double cost_lowrank = 0.0, cost_full = 0.0;
     // exact form
-    int Nk = 0, Nkp = 0, x_nxt = 0, x_ng = 0, x_ng_use = 0, x_npair = 0, x_nSj = 0;
+    int Nk = 0, Nkp = 0, x_nxt = 0, x_ng = 0, x_ng_use = 0, x_npair = 0, x_nSj = 0, x_nfold = 0;
+    std::vector<double> xWfk;
     std::vector<double> xTyp, xOpk;
 };
 
@@ -737,6 +739,14 @@ static void plan_mix(jx_ctx* ctx, const std::vector<double>& beam, const std::ve
         mb.x_npair = (mb.Nkp / 16 + 1) / 2;
         mb.x_nSj = (c.N + 15) / 16;
         jxt::abel_ordinate_layout(r, c.kpc_cm * c.sigma_T / c.m_e, mb.Nkp / 16, mb.x_nSj, mb.xTyp);
+        {   // an odd number of ordinate tiles: the last one folded into the row product (timed path), the others pair up exactly
+            const int nS = mb.Nkp / 16;
+            const char* e = opt_str(ctx, "JOXSZ_X_FOLD");
+            if ((nS & 1) && nS >= 3 && !(e && atoi(e) == 0)) {
+                mb.x_nfold = mb.x_nSj - (nS - 1);
+                jxt::exact_fold_layout(Wy, nrow, r, c.kpc_cm * c.sigma_T / c.m_e, nS, mb.x_nSj, mb.x_nxt, mb.x_ng, mb.xWfk);
+            }
+        }
         mb.r = 0; mb.ns = 0; mb.R = 0; mb.RT = 0; mb.NU_full = NU; mb.krows = 0;
         mb.ok = true;
         return;
@@ -955,7 +965,8 @@ static int mix_setup(jx_ctx* ctx, const MixBuild& mb, long long tW) {
     if (mb.form == 2) {
         // exact form: two constant operators and the ordinates of a chunk; none of the work buffers of the contracted forms
         m.Nk = mb.Nk; m.Nkp = mb.Nkp; m.x_nxt = mb.x_nxt; m.x_ng = mb.x_ng; m.x_ng_use = mb.x_ng_use;
-        m.x_npair = mb.x_npair; m.x_nSj = mb.x_nSj; m.x_ldpp = 16 * mb.x_nSj;
+        m.x_npair = mb.x_npair; m.x_nSj = mb.x_nSj; m.x_ldpp = 16 * mb.x_nSj; m.x_nfold = mb.x_nfold;
+        if (mb.x_nfold && (rc = dev_put_l(ctx, m.allocs, mb.xWfk.data(), mb.xWfk.size(), &m.x_Wfk))) return rc;
         m.cft = nullptr; m.Dt = nullptr; m.Pt = nullptr; m.x_cf = nullptr; m.x_ppi = nullptr; m.has_u = false; m.ncol = 2 * N;
         if ((rc = dev_put_l(ctx, m.allocs, mb.xTyp.data(), mb.xTyp.size(), &m.x_Typ))) return rc;
         if ((rc = dev_put_l(ctx, m.allocs, mb.xOpk.data(), mb.xOpk.size(), &m.x_Opk))) return rc;
@@ -2029,6 +2040,10 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
             ro.ldr = (ro.nuse + 1) | 1;
             ro.lde = ro.nuse;
             ro.ldpp = m.x_ldpp; ro.nSj = m.x_nSj; ro.npair = m.x_npair;
+            ro.nfold = 0; ro.s0f = 0; ro.Wfk = nullptr;
+            if (m.x_nfold && m.x_pairwise && !all) {             // folded form: the last ordinate tile is not computed (nothing reads the ordinates), one pair fewer
+                ro.nfold = m.x_nfold; ro.s0f = ro.nS - 1; ro.Wfk = m.x_Wfk; ro.npair = (ro.nS - 1) / 2;
+            }
 #ifdef JOXSZ_ABLATIONS
             ro.dbg = m.dbg;
             if (opt_str(ctx, "JOXSZ_X_STAMPS")) {                    // (diagnostic build only: the environment is read on the launch path here)
@@ -2038,7 +2053,7 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
                 static int calls = 0;
                 if (++calls == 40) {
                     HIPCHK(ctx, hipStreamSynchronize(st));
-                    const int nb = 8 * ((((n + 15) / 16) + 7) / 8) * m.x_npair;
+                    const int nb = 8 * ((((n + 15) / 16) + 7) / 8) * ro.npair;
                     std::vector<long long> h((size_t)nb * 8);
                     HIPCHK(ctx, hipMemcpy(h.data(), stamps, sizeof(long long) * h.size(), hipMemcpyDeviceToHost));
                     long long t0 = h[0];
@@ -2065,9 +2080,9 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
                         for (int k = 0; k < 10 && k < (int)fl.size(); ++k) fprintf(stderr, " %d(%.1f, start %.1f)", fl[k].second, fl[k].first, (h[(size_t)fl[k].second * 8] - t0) * 0.01);
                         fprintf(stderr, "\n");
                     }
-                    for (int pp_ = 0; pp_ < m.x_npair; ++pp_) {                  // per pair: mean first loads | k loop | end
+                    for (int pp_ = 0; pp_ < ro.npair; ++pp_) {                  // per pair: mean first loads | k loop | end
                         double a[3] = {0, 0, 0}, e_max = 0; int cnt = 0;
-                        for (int b = 0; b < nb; ++b) if ((b >> 3) % m.x_npair == pp_) {
+                        for (int b = 0; b < nb; ++b) if ((b >> 3) % ro.npair == pp_) {
                             a[0] += (h[(size_t)b * 8 + 1] - t0) * 0.01; a[1] += (h[(size_t)b * 8 + 2] - t0) * 0.01; a[2] += (h[(size_t)b * 8 + 4] - t0) * 0.01;
                             e_max = std::max(e_max, (h[(size_t)b * 8 + 4] - t0) * 0.01); ++cnt;
                         }
@@ -2083,7 +2098,7 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
                 JxRowOp r1 = ro;
                 if (!pairwise) r1.ng = 0;                        // (the ordinates alone: the row product reads them back)
                 const int ntw = (n + 15) / 16;
-                const dim3 grid((unsigned)(8 * ((ntw + 7) / 8) * m.x_npair));
+                const dim3 grid((unsigned)(8 * ((ntw + 7) / 8) * r1.npair));
                 const size_t sh1 = sizeof(double) * JX_ORD_LDS_DOUBLES;
                 if (tm2 && es.p1stage == 2) HIPCHK(ctx, hipEventRecord(es.e[2], st));
                 bool done = false;

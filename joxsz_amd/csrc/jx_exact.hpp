@@ -10,6 +10,8 @@
 // parameters: the pressure profile (jx_prep_kernel), its forward Abel transform and the Compton-y scale y = y_scale A pp
 // (joxsz_funcs.py:457-459), the product with Wy, and the tail (joxsz_funcs.py:472-479, 538).
 //
+//                           (With an odd number of ordinate tiles the last one -- the cheapest -- has no partner: in the timed path its share of
+//                           the row is folded into the row product as an operator on the profile, jxt::exact_fold_layout, and the others pair up.)
 //   jx_ordrow_kernel        one block = 16 walkers (one matrix-core tile) x one PAIR of 16-ordinate column tiles (p, last - p: the
 //                           Abel matrix is triangular, the two k-ranges add up to the same length for every pair); its four waves
 //                           take every fourth 16-radius step of the k-range each, straight from memory (no LDS staging, no barrier
@@ -45,6 +47,8 @@ struct JxRowOp {
     int lde;                       // doubles per data radius of the data-radii matrix in LDS; 0: read from memory
     int dbg;                       // diagnostic build only (make ABLATIONS=1; JOXSZ_X_DBG): 1 no matrix instructions in the ordinate product, 2 no row product, 4 no partial-row stores, 8 no operator loads
     int ldpp, nSj, npair;          // ordinate product: doubles per profile (16 nSj, zeros behind the grid), macro steps of 16 radii, column-tile pairs
+    int nfold, s0f;                // folded form (odd nS, timed path): macro steps of 16 radii of the last ordinate tile's share of the row, the first of them; 0: none
+    const double* Wfk;             // [ng_all][nfold][4][64][NXT]  the last ordinate tile's share of the row as an operator on the profile (jxt::exact_fold_layout)
     const double* Opk;             // [ng_all][nS][4][64][NXT]     row operator (jxt::exact_row_layout)
     const double* Typ;             // [nSj][nS][64][4]             ordinate operator (jxt::abel_ordinate_layout)
     const double* pp;              // [n][ldpp] pressure profiles (jx_prep_kernel)
@@ -261,6 +265,21 @@ jx_ordrow_kernel(JxRowOp g) {
     const jx_ro_v4d yq = *reinterpret_cast<const jx_ro_v4d*>(s_yt + li * 36 + 16 + 4 * lk);
     for (int gi = 0; gi < (JX_DBG(g, 2) ? 0 : g.ng); ++gi) {
         load_op(gi);
+        // folded form: pair p also takes the macro steps p, p + npair, ... of the last ordinate tile's share of the row, an operator on the
+        // profile (requested with the row operator above: one trip; requesting both ahead of the reduction was measured: slower)
+        const bool fold = p < g.nfold;
+        jx_ro_v4d af = jx_ro_v4d{0.0, 0.0, 0.0, 0.0};
+        double bfv[NTT][4];
+        if (fold) {
+            af = load_a(g.s0f + p);
+#pragma unroll
+            for (int tt = 0; tt < NTT; ++tt) {
+                const int t = min(wv + 4 * tt, NXT - 1);
+                const double* __restrict__ ob = g.Wfk + ((((size_t)gi * g.nfold + p) * 4) * 64 + lane) * NXT + t;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bfv[tt][e] = ob[(size_t)e * 64 * NXT];
+            }
+        }
         double* __restrict__ Pb = g.P + (((size_t)wt * g.npair + p) * g.ng + gi) * (size_t)(256 * NXT);
 #pragma unroll
         for (int tt = 0; tt < NTT; ++tt) {
@@ -272,6 +291,16 @@ jx_ordrow_kernel(JxRowOp g) {
                 if (hasq) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(yq[e], bqv[tt][e], c1, 0, 0, 0);
+                }
+                if (fold) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[e], bfv[tt][e], c1, 0, 0, 0);
+                    for (int sf = p + g.npair; sf < g.nfold; sf += g.npair) {        // (more macro steps than pairs: short grids only)
+                        const jx_ro_v4d a2 = load_a(g.s0f + sf);
+                        const double* __restrict__ ob = g.Wfk + ((((size_t)gi * g.nfold + sf) * 4) * 64 + lane) * NXT + t;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[e], ob[(size_t)e * 64 * NXT], c1, 0, 0, 0);
+                    }
                 }
                 const jx_ro_v4d cs = c0 + c1;
 #pragma unroll

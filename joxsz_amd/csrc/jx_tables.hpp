@@ -1029,6 +1029,30 @@ inline void exact_row_layout(const std::vector<double>& Wy, int nrow, int N, int
                     }
 }
 
+// The LAST ordinate tile folded into the row product (jx_ordrow_kernel with an odd number nS of ordinate tiles: its 16 ordinates
+// y_i = sum_k y_scale A[i][k] pp_k, i >= 16 (nS - 1), enter the row only through Wy, so their share of the row is a constant
+// operator on the profile itself,   Wf[x][k] = sum_i Wy[x][i] y_scale A[i][k],   k >= 16 (nS - 1) (A is upper triangular).
+// The remaining nS - 1 tiles pair up exactly and the launch has one block fewer per walker tile: 768 instead of 832 blocks at 512^2
+// / 1024 walkers, three on every compute unit.  Sums in long double; layout as exact_row_layout with the nSf = nSj - (nS - 1) macro
+// steps of 16 radii in the place of the ordinate tiles:  Wfk[(((g nSf + sf) 4 + e) 64 + lane) NXT + t].
+inline void exact_fold_layout(const std::vector<double>& Wy, int nrow, const std::vector<double>& r, double y_scale, int nS, int nSj, int NXT, int ng,
+                              std::vector<double>& Wfk) {
+    const int N = (int)r.size(), s0 = nS - 1, nSf = nSj - s0, K = 16 * nSf;
+    std::vector<double> A;
+    abel_matrix(r, A);
+    std::vector<double> Wf((size_t)nrow * K, 0.0);
+    for (int x = 0; x < nrow; ++x)
+        for (int kk = 0; kk < K; ++kk) {
+            const int k = 16 * s0 + kk;
+            if (k >= N) continue;
+            long double acc = 0.0L;
+            for (int i = 16 * s0; i < std::min(N, 16 * s0 + 16); ++i)
+                if (i <= k) acc += (long double)Wy[(size_t)x * N + i] * ((long double)y_scale * (long double)A[(size_t)i * N + k]);
+            Wf[(size_t)x * K + kk] = (double)acc;
+        }
+    exact_row_layout(Wf, nrow, K, nSf, NXT, ng, Wfk);
+}
+
 // B operand of the ordinate product (jx_ordrow_kernel): y_k = sum_j y_scale A[k][j] pp_j (joxsz_funcs.py:457-459), macro step s (16
 // radii) x column tile t (16 ordinates) x lane (lk, li) x sub-step e,   Typ[((s nS + t) 64 + 16 lk + li) 4 + e] = y_scale A[16 t + li][16 s + 4 lk + e]
 // (zero beyond the grid; A is upper triangular, so tile t has entries from step s = t on).

@@ -213,6 +213,13 @@ int jxt_exact_row_layout(const double* Wy, int nrow, int N, int nS, int NXT, int
     std::copy(o.begin(), o.end(), Opk);
     return 0;
 }
+// the last ordinate tile's share of the row as an operator on the profile (odd nS), in the row operator's layout: out [ng][nSj - (nS - 1)][4][64][NXT]
+int jxt_exact_fold_layout(const double* Wy, int nrow, const double* r, int N, double y_scale, int nS, int nSj, int NXT, int ng, double* out) {
+    std::vector<double> o;
+    jxt::exact_fold_layout(std::vector<double>(Wy, Wy + (size_t)nrow * N), nrow, std::vector<double>(r, r + N), y_scale, nS, nSj, NXT, ng, o);
+    std::copy(o.begin(), o.end(), out);
+    return 0;
+}
 int jxt_abel_ordinate_layout(const double* r, int n, double y_scale, int nS, int nSj, double* out) {
     std::vector<double> o;
     jxt::abel_ordinate_layout(std::vector<double>(r, r + n), y_scale, nS, nSj, o);

@@ -81,12 +81,13 @@ def test_exact_form_against_the_rocfft_sequence(S, N, measured, kw):
 def test_ordinates_against_the_abel_kernel(S, N, W):
     """The ordinate product (y = y_scale A pp on the matrix cores, jx_ordrow_kernel) against the Abel kernel's own evaluation of the same
     three lines (joxsz_funcs.py:453-459; the 'y' tap, itself held to the oracle in test_gpu_parity.py): every ordinate the row operator
-    reads, ragged walker counts, a rejected walker."""
+    reads, ragged walker counts, a rejected walker.  (JOXSZ_X_FOLD=0: with an odd number of ordinate tiles the timed path does not form the last
+    tile's ordinates at all -- their share of the row is an operator on the profile -- see test_folded_last_tile_against_the_plain_pairing.)"""
     from joxsz_amd import datasets
     pb = datasets.synthetic_problem(S=S, N=N, seed=S)
     th = datasets.walker_ball(pb, W, spread=0.03, seed=S)
     th[1, 1] = 9.0
-    post = _post(pb)
+    post = _post(pb, options={'X_FOLD': '0'})
     lay = post.ctx.conv_layout
     nk = lay['rank']                                                  # ordinates in use (the grid beyond the map's corner + the spline's band does not reach the row)
     assert lay['form'] == 'exact' and 0 < nk <= N and lay['beam_terms'] % 16 == 0
@@ -97,6 +98,28 @@ def test_ordinates_against_the_abel_kernel(S, N, W):
     assert np.max(np.abs(y - y_tap) / np.abs(y_tap).max(axis=1, keepdims=True)) < 1e-13
     st = orc.sz_stages(pb, orc.pars_dict(pb, th[0]))
     assert np.max(np.abs(y[0] - st['y'][:nk])) / np.abs(st['y']).max() < 1e-12
+
+
+@pytest.mark.parametrize('S,N,W', [(512, 500, 130), (96, 120, 21), (256, 300, 40), (513, 500, 17), (1025, 1000, 9)])
+def test_folded_last_tile_against_the_plain_pairing(S, N, W):
+    """An odd number of 16-ordinate tiles (25 at 512^2): the timed path folds the last tile's share of the row into the row product as a
+    constant operator on the profile (jxt::exact_fold_layout) and pairs the other tiles exactly; against the plain pairing that computes every
+    ordinate (JOXSZ_X_FOLD=0): log-posterior to 1e-13, extracted row (a tap: always the plain pairing) identical, same rejections."""
+    from joxsz_amd import datasets
+    pb = datasets.synthetic_problem(S=S, N=N, seed=S + 1)
+    th = datasets.walker_ball(pb, W, spread=0.03, seed=S)
+    th[2, 1] = 9.0
+    a, b = _post(pb), _post(pb, options={'X_FOLD': '0'})
+    la, lb = a.log_prob(th), b.log_prob(th)
+    ra, rb = a.stage(th, 'map_row'), b.stage(th, 'map_row')
+    ntiles = a.ctx.conv_layout['beam_terms'] // 16
+    a.close(); b.close()
+    fin = np.isfinite(lb)
+    assert fin.any() and np.array_equal(fin, np.isfinite(la)) and not fin[2]
+    np.testing.assert_allclose(la[fin], lb[fin], rtol=1e-13)
+    assert np.array_equal(ra, rb)
+    if ntiles % 2 == 0:
+        assert np.array_equal(la[fin], lb[fin])                     # (an even number of tiles: nothing to fold, the same launches)
 
 
 def test_pairwise_kernel_against_the_reference_form(monkeypatch):

@@ -622,6 +622,38 @@ def test_exact_form_operand_layouts(lib):
                     np.testing.assert_array_equal(Opk[g, s, e, :, t], want)
 
 
+def test_folded_last_ordinate_tile(lib):
+    """An odd number of ordinate tiles: the last tile's ordinates enter the row only through Wy, so their share of the row is a constant operator
+    on the profile, Wf = Wy[:, tile] (y_scale A)[tile, :] (jxt::exact_fold_layout, what jx_ordrow_kernel's row product adds in the timed path).
+    Entry by entry in the row operator's layout against numpy in long double, and the identity itself on a random profile."""
+    r = np.ascontiguousarray(GRIDS['arange'][:100])
+    N = r.size
+    A = np.zeros((N, N))
+    lib.jxt_abel_matrix(_p(r), N, _p(A))
+    ysc, nS, nSj, nrow, NXT, ng = 2.9, 5, (N + 15) // 16, 37, 2, 2     # 80 ordinates (5 tiles) of 100 radii (7 macro steps): tile 4 folded, its k-range = steps 4..6
+    rng = np.random.default_rng(2)
+    Wy = np.zeros((nrow, N))
+    Wy[:, :16 * nS] = rng.normal(size=(nrow, 16 * nS))
+    s0, nSf = nS - 1, nSj - (nS - 1)
+    out = np.zeros((ng, nSf, 4, 64, NXT))
+    lib.jxt_exact_fold_layout(_p(Wy), nrow, _p(r), N, ctypes.c_double(ysc), nS, nSj, NXT, ng, _p(out))
+    T = np.triu(ysc * A.astype(np.longdouble))                          # y = T pp
+    Wf = (Wy[:, 16 * s0:16 * s0 + 16].astype(np.longdouble) @ T[16 * s0:16 * s0 + 16, :]).astype(np.float64)   # [nrow][N], zero before 16 s0
+    assert np.all(Wf[:, :16 * s0] == 0.0)
+    lane = np.arange(64)
+    li, lk = lane & 15, lane >> 4
+    for g in range(ng):
+        for sf in range(nSf):
+            for e in range(4):
+                for t in range(NXT):
+                    x, k = 16 * (g * NXT + t) + li, 16 * (s0 + sf) + 4 * lk + e
+                    want = np.where((x < nrow) & (k < N), Wf[np.minimum(x, nrow - 1), np.minimum(k, N - 1)], 0.0)
+                    np.testing.assert_allclose(out[g, sf, e, :, t], want, rtol=1e-15, atol=1e-300)
+    pp = rng.normal(size=N)
+    y = (T @ pp.astype(np.longdouble)).astype(np.float64)
+    np.testing.assert_allclose(Wf @ pp + Wy[:, :16 * s0] @ y[:16 * s0], Wy @ y, rtol=1e-12, atol=1e-12 * np.abs(Wy @ y).max())
+
+
 def _stockham(x, radices, sign):
     """The passes of csrc/jx_fft.hpp restated in numpy: in place, every butterfly of a pass read before any is written; butterfly j of a
     pass of radix R behind sub-transforms of size ns reads x[j + t n/R], multiplies by root^(t (j mod ns) n/(ns R)), transforms the R values and
