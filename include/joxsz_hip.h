@@ -171,8 +171,9 @@ int  jx_finalize(jx_ctx* ctx);
  *   JOXSZ_MIX_FORM               exact|legacy|lowrank|full (exact)  form of the hand-written route: the exact form, or the contracted forms of rounds 3-4
  *                                                          (legacy: the cheaper of low-rank and full, as round 4 picked; they carry their own options below)
  *   JOXSZ_X_PAIRWISE             1|0 (1)                   exact form: 0 = its reference kernels (one block per 16 walkers reads the ordinates back; jx_rowop_tail_kernel)
- *   JOXSZ_X_FOLD                 1|0 (1)                   exact form, odd number of 16-ordinate tiles: the last tile's share of the row as an operator on the profile inside the row
- *                                                          product, the others in exact pairs (one block fewer per 16 walkers: 768 instead of 832 at 512^2 / 1024 walkers); 0: every tile in the ordinate product
+ *   JOXSZ_X_FOLD                 1|0 (1)                   exact form, timed path: the ordinates stay in LDS (nothing reads them), and with an odd number of 16-ordinate tiles the last tile's
+ *                                                          share of the row is an operator on the profile inside the row product, the others in exact pairs (one block fewer per 16
+ *                                                          walkers: 768 instead of 832 at 512^2 / 1024 walkers); 0: every tile through the ordinate product, ordinates stored (as calls with taps do)
  *   JOXSZ_PRUNE_OUTPUTS          1|0 (1)                   0: the row product computes every output of the row, read by the data-radii spline or not
  *   JOXSZ_CHUNK                  walkers                   overrides jx_config.max_batch
  *   JOXSZ_FFT_PAD, JOXSZ_MAP_SPLIT, JOXSZ_MAP_PAIR         rocFFT sequence / Abel + map kernel: padded side, row slabs per walker, two walkers per block (1)
@@ -385,7 +386,7 @@ int  jx_get_truncation(jx_ctx* ctx, double out[12]);
  *   4 stage-1 operator C[u][j] (low-rank form), rows of `cld` doubles: geom = {1, wld, cld, 8}
  *   5 operator of the matrix-core product, Op[(kappa * 16 + (x & 15)) * ntile + (x >> 4)]: geom = {4 ksteps, 16, ntile, 8}
  * exact form (the others belong to the contracted forms):
- *   6 Compton-y ordinates of the last chunk, walker-major y[w][k]: geom = {1, tW, Nkp, 8}
+ *   6 Compton-y ordinates of the last chunk, walker-major y[w][k]: geom = {1, tW, Nkp, 8} (written by calls with taps, by the reference kernels and with JOXSZ_X_FOLD=0: the timed path keeps them in LDS)
  *   7 row operator as the matrix cores read it, Opk[(((g nS + s) 4 + e) 64 + lane) nxt + t] = Wy[16 (g nxt + t) + (lane & 15)][16 s + 4 (lane >> 4) + e]: geom = {ng nS 4, 64, nxt, 8} */
 int  jx_debug_workspace(jx_ctx* ctx, int which, void** dev, int32_t geom[4]);
 /* Duration (ms, HIP events on the context's stream, mean of `repeats` launches) of the Abel + map kernel writing the full

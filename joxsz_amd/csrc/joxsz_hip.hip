@@ -80,6 +80,7 @@ struct MixBack {
     int form = 0;                      // 0 low-rank (stage 1 + stage 2), 1 full operator on the samples (round 3-4, JOXSZ_MIX_FORM=legacy|lowrank|full); 2 exact (default)
     // exact form (jx_exact.hpp): the ordinate product's operator Ty and first k-steps, the row operator Opk, the ordinates y
     int Nk = 0, Nkp = 0, x_nxt = 0, x_ng = 0, x_ng_use = 0, x_npair = 0, x_nSj = 0, x_ldpp = 0, x_nfold = 0;
+    bool x_lean = true;                // JOXSZ_X_FOLD=0 clears it: the timed path then stores the ordinates and forms every tile, like a call with taps
     double *x_Wfk = nullptr;           // odd number of ordinate tiles: the last one's share of the row as an operator on the profile (timed path; jxt::exact_fold_layout)
     double *x_Typ = nullptr, *x_Opk = nullptr, *x_y = nullptr, *x_cf = nullptr, *x_P = nullptr, *x_ppi = nullptr;
     bool x_pairwise = true;            // JOXSZ_X_PAIRWISE=0: the ordinates read back by one block per 16 walkers (jx_rowop_tail_kernel)
@@ -683,6 +684,7 @@ struct MixBuild {
     double cost_lowrank = 0.0, cost_full = 0.0;
     // exact form
     int Nk = 0, Nkp = 0, x_nxt = 0, x_ng = 0, x_ng_use = 0, x_npair = 0, x_nSj = 0, x_nfold = 0;
+    bool x_lean = true;
     std::vector<double> xWfk;
     std::vector<double> xTyp, xOpk;
 };
@@ -742,7 +744,8 @@ static void plan_mix(jx_ctx* ctx, const std::vector<double>& beam, const std::ve
         {   // an odd number of ordinate tiles: the last one folded into the row product (timed path), the others pair up exactly
             const int nS = mb.Nkp / 16;
             const char* e = opt_str(ctx, "JOXSZ_X_FOLD");
-            if ((nS & 1) && nS >= 3 && !(e && atoi(e) == 0)) {
+            mb.x_lean = !(e && atoi(e) == 0);
+            if ((nS & 1) && nS >= 3 && mb.x_lean) {
                 mb.x_nfold = mb.x_nSj - (nS - 1);
                 jxt::exact_fold_layout(Wy, nrow, r, c.kpc_cm * c.sigma_T / c.m_e, nS, mb.x_nSj, mb.x_nxt, mb.x_ng, mb.xWfk);
             }
@@ -965,7 +968,7 @@ static int mix_setup(jx_ctx* ctx, const MixBuild& mb, long long tW) {
     if (mb.form == 2) {
         // exact form: two constant operators and the ordinates of a chunk; none of the work buffers of the contracted forms
         m.Nk = mb.Nk; m.Nkp = mb.Nkp; m.x_nxt = mb.x_nxt; m.x_ng = mb.x_ng; m.x_ng_use = mb.x_ng_use;
-        m.x_npair = mb.x_npair; m.x_nSj = mb.x_nSj; m.x_ldpp = 16 * mb.x_nSj; m.x_nfold = mb.x_nfold;
+        m.x_npair = mb.x_npair; m.x_nSj = mb.x_nSj; m.x_ldpp = 16 * mb.x_nSj; m.x_nfold = mb.x_nfold; m.x_lean = mb.x_lean;
         if (mb.x_nfold && (rc = dev_put_l(ctx, m.allocs, mb.xWfk.data(), mb.xWfk.size(), &m.x_Wfk))) return rc;
         m.cft = nullptr; m.Dt = nullptr; m.Pt = nullptr; m.x_cf = nullptr; m.x_ppi = nullptr; m.has_u = false; m.ncol = 2 * N;
         if ((rc = dev_put_l(ctx, m.allocs, mb.xTyp.data(), mb.xTyp.size(), &m.x_Typ))) return rc;
@@ -2041,7 +2044,8 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
             ro.lde = ro.nuse;
             ro.ldpp = m.x_ldpp; ro.nSj = m.x_nSj; ro.npair = m.x_npair;
             ro.nfold = 0; ro.s0f = 0; ro.Wfk = nullptr;
-            if (m.x_nfold && m.x_pairwise && !all) {             // folded form: the last ordinate tile is not computed (nothing reads the ordinates), one pair fewer
+            const bool lean = m.x_lean && m.x_pairwise && !all && !want_abel_taps;     // the timed path: nothing reads the ordinates
+            if (m.x_nfold && lean) {                             // folded form: the last ordinate tile is not computed, one pair fewer
                 ro.nfold = m.x_nfold; ro.s0f = ro.nS - 1; ro.Wfk = m.x_Wfk; ro.npair = (ro.nS - 1) / 2;
             }
 #ifdef JOXSZ_ABLATIONS
@@ -2091,7 +2095,7 @@ static int run_chunk(jx_ctx* ctx, const double* theta_dev, double* logp_dev, int
                 }
             }
 #endif
-            ro.Opk = m.x_Opk; ro.Typ = m.x_Typ; ro.pp = pp_src; ro.y = m.x_y; ro.P = m.x_P;
+            ro.Opk = m.x_Opk; ro.Typ = m.x_Typ; ro.pp = pp_src; ro.y = lean ? (double*)nullptr : m.x_y; ro.P = m.x_P;      // (lean: the ordinates stay in LDS)
             const size_t lds_max = (size_t)158 * 1024;
             const bool pairwise = m.x_pairwise;
             {

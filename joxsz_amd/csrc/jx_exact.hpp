@@ -52,7 +52,7 @@ struct JxRowOp {
     const double* Opk;             // [ng_all][nS][4][64][NXT]     row operator (jxt::exact_row_layout)
     const double* Typ;             // [nSj][nS][64][4]             ordinate operator (jxt::abel_ordinate_layout)
     const double* pp;              // [n][ldpp] pressure profiles (jx_prep_kernel)
-    double* y;                     // [tW][ldy] ordinates, walker-major
+    double* y;                     // [tW][ldy] ordinates, walker-major; null: not stored (timed path: nothing reads them)
     double* P;                     // [walker tiles][npair][ng_all][16][16 NXT] partial rows
     long long* stamps;             // diagnostic build only: [blocks][8] wall-clock stamps (100 MHz) of jx_ordrow_kernel's phases
 };
@@ -255,7 +255,7 @@ jx_ordrow_kernel(JxRowOp g) {
         const double v = ((s1[((0 * 2 + t) * 16 + w) * 16 + cc] + s1[((1 * 2 + t) * 16 + w) * 16 + cc]) + s1[((2 * 2 + t) * 16 + w) * 16 + cc]) + s1[((3 * 2 + t) * 16 + w) * 16 + cc];
         s_yt[w * 36 + 16 * t + cc] = v;
         const int tile = t ? q : p;
-        if (tile < g.nS && wb + w < g.n) g.y[(size_t)(wb + w) * g.ldy + 16 * tile + cc] = v;
+        if (g.y && tile < g.nS && wb + w < g.n) g.y[(size_t)(wb + w) * g.ldy + 16 * tile + cc] = v;
     }
     __syncthreads();
     JX_STAMP(g, 3);
@@ -266,7 +266,7 @@ jx_ordrow_kernel(JxRowOp g) {
     for (int gi = 0; gi < (JX_DBG(g, 2) ? 0 : g.ng); ++gi) {
         load_op(gi);
         // folded form: pair p also takes the macro steps p, p + npair, ... of the last ordinate tile's share of the row, an operator on the
-        // profile (requested with the row operator above: one trip; requesting both ahead of the reduction was measured: slower)
+        // profile (requested with the row operator above: one trip; requesting both ahead of the reduction was measured twice: slower)
         const bool fold = p < g.nfold;
         jx_ro_v4d af = jx_ro_v4d{0.0, 0.0, 0.0, 0.0};
         double bfv[NTT][4];
