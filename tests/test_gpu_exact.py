@@ -100,11 +100,12 @@ def test_ordinates_against_the_abel_kernel(S, N, W):
     assert np.max(np.abs(y[0] - st['y'][:nk])) / np.abs(st['y']).max() < 1e-12
 
 
-@pytest.mark.parametrize('S,N,W', [(512, 500, 130), (96, 120, 21), (256, 300, 40), (513, 500, 17), (1025, 1000, 9)])
+@pytest.mark.parametrize('S,N,W', [(512, 500, 130), (31, 40, 7), (56, 70, 5), (64, 80, 19), (96, 120, 21), (256, 300, 40), (513, 500, 17), (1025, 1000, 9)])
 def test_folded_last_tile_against_the_plain_pairing(S, N, W):
     """An odd number of 16-ordinate tiles (25 at 512^2): the timed path folds the last tile's share of the row into the row product as a
     constant operator on the profile (jxt::exact_fold_layout) and pairs the other tiles exactly; against the plain pairing that computes every
-    ordinate (JOXSZ_X_FOLD=0): log-posterior to 1e-13, extracted row (a tap: always the plain pairing) identical, same rejections."""
+    ordinate (JOXSZ_X_FOLD=0): log-posterior to 1e-13 (1e-10 below side 128, where the tail's extrapolating spline amplifies rounding), extracted
+    row (a tap: always the plain pairing) identical, same rejections; 3, 5, 7 and 25 tiles (one pair and a fold with more macro steps than pairs ... )."""
     from joxsz_amd import datasets
     pb = datasets.synthetic_problem(S=S, N=N, seed=S + 1)
     th = datasets.walker_ball(pb, W, spread=0.03, seed=S)
@@ -116,8 +117,9 @@ def test_folded_last_tile_against_the_plain_pairing(S, N, W):
     a.close(); b.close()
     fin = np.isfinite(lb)
     assert fin.any() and np.array_equal(fin, np.isfinite(la)) and not fin[2]
-    np.testing.assert_allclose(la[fin], lb[fin], rtol=1e-13)
+    np.testing.assert_allclose(la[fin], lb[fin], rtol=1e-13 if S >= 128 else 1e-10)
     assert np.array_equal(ra, rb)
+    assert ntiles % 2 == {512: 1, 31: 1, 56: 1, 64: 1, 96: 1, 256: 0, 513: 1, 1025: 0}[S]
     if ntiles % 2 == 0:
         assert np.array_equal(la[fin], lb[fin])                     # (an even number of tiles: nothing to fold, the same launches)
 
