@@ -1,24 +1,29 @@
-// Column passes of the rocFFT sequence (conv = rocfft, north_star's literal route: joxsz_funcs.py:464-467 executed as written).
+// Transforms of the literal route (conv = rocfft: joxsz_funcs.py:464-467 executed pass by pass), hand-written for gfx950.
 //
-// rocFFT's own 2-D plans move each spectrum through HBM once per dimension and once more for the multiplication, and fetch
-// 2.9 x the bytes on the strided (column) dimension (profiles/r04_pmc_traffic.json).  Here rocFFT keeps the contiguous row
-// transforms (batched 1-D plans) and the column dimension is hand-written:
+// rocFFT's own 2-D plans move each spectrum through HBM once per dimension and once more for the multiplication, fetch 2.9 x the bytes
+// on the strided (column) dimension and need two kernels for the real-to-complex rows of 540 (profiles/r04_pmc_traffic.json: 53 GB per
+// 1024 walkers at 512^2).  Wherever both sides are 2^a 3^b 5^c and <= 1280 the sequence runs on four kernels of this file instead
+// (19 GB; JOXSZ_FFT_COLUMNS=rocfft / JOXSZ_FFT_ROWS=rocfft bring rocFFT's plans back, for all of it or for the rows):
 //
-//   jx_fft_beam_cols_kernel   per walker and group of CB adjacent columns kx of the row spectra [S][ldc]: the S values of each column
-//                             (rows S..P-1 of the padded image are zero and are never stored) -> LDS, forward transform of length P,
-//                             times the beam spectrum, inverse transform of length P, rows 0..S-1 (the 'same' window of
-//                             joxsz_funcs.py:464) written back in place.  One read and one write of the spectrum instead of
-//                             rocFFT column pass + jx_beam_mul_kernel + rocFFT column pass.
-//   jx_fft_tf_cols_kernel     the same load for the row spectra of the S x S window, forward transform of length S, times the
-//                             transfer-function table (joxsz_funcs.py:466-467; jx_tables.hpp tf_row_table, which carries the phase of
-//                             the extracted row S//2), summed over the column: Z[kc], the spectrum of the extracted row that
-//                             jx_tail_kernel turns into the row.  One read of the spectrum, nothing written but Z.
+//   jx_fft_rows_fwd_kernel      S rows of the padded image (the zero rows are never stored) -> hermitian row spectra; two real rows per
+//                               complex transform of length P, one wave per pair.
+//   jx_fft_beam_cols_kernel     per walker and group of 8 (4) adjacent columns of the row spectra -- one 128-byte line per row --: the S
+//                               values of each column -> LDS, forward transform of length P, the beam spectrum multiplied in by the first
+//                               pass of the inverse transform (table stored one column after the other), rows 0..S-1 (the 'same'
+//                               window) written back in place.  One read and one write of the spectrum.
+//   jx_fft_rows_inv_tf_kernel   inverse rows of length P, the first S entries kept (the convolved map: written to memory only for the
+//                               conv_2d tap), forward rows of length S of the same pair -> row spectra of the S x S window.
+//   jx_fft_tf_cols_kernel       forward transform of length S of each column; its last pass multiplies by the transfer-function table
+//                               (jx_tables.hpp tf_row_table, which carries the phase of the extracted row S//2) and sums down the
+//                               column: Z[kc], the spectrum of the extracted row that jx_tail_kernel turns into the row.  One read of the
+//                               spectrum, nothing written but Z.
 //
-// The transform: Stockham autosort, radices 10 9 8 6 5 4 3 2, and 16 12 where the registers allow (any length 2^a 3^b 5^c in as few passes as the host finds: 540 = 10 9 6,
-// 512 = 8 8 8; the composite radices are two base butterflies inside the registers of a thread), one wave per column, in place
-// in LDS (every thread holds the inputs of its butterflies in registers across the barrier between the read and the write of a pass),
-// roots of unity from a table of the host (long double sincos) copied to LDS, fp64.  Global accesses are CB * 16 B contiguous per row (CB = 8: one
-// 128 B line, the leading dimensions ldc / ldt are multiples of 8 complex so that groups start on lines).
+// The transform: Stockham autosort in LDS, in place (a lane holds the inputs of its butterflies in registers between the read and the write
+// of a pass), ONE WAVE PER SEQUENCE -- passes need no block barrier, only the order of a wave's own LDS instructions --, radices 10 9 8 6 5 4 3 2
+// (12 and 16 in the kernels of lengths beyond 640, which may hold 256 registers) chosen on the host for the fewest passes and the least idle
+// lanes (jxt::fft_radices: 540 = 10 9 6, 512 = 8 8 8), composite radices as two base butterflies inside the registers with correctly rounded
+// constant roots (jx_fft_roots.inc), the twiddles of a pass from a table of the n roots (host, long double) in LDS, j mod ns by a
+// multiply-high, fp64 throughout.  The leading dimensions of the spectra are multiples of 8 complex, so that column groups start on lines.
 #pragma once
 #include <hip/hip_runtime.h>
 
