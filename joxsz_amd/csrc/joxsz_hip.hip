@@ -6,7 +6,8 @@
 //   * the contracted forms of rounds 3-4 (jx_mix.hpp; option JOXSZ_MIX_FORM=legacy|lowrank|full, kept for one round): low-rank (stage 1 on
 //     the vector units + stage 2 on the matrix cores) or full (one matrix-core product fed by the sample evaluation), with their
 //     truncation guard;
-//   * the rocFFT sequence (2-D R2C -> beam multiply -> C2R -> R2C of the S x S window): the reference's lines executed literally -- the
+//   * the literal sequence, "rocFFT sequence" below (forward transforms -> beam multiply -> inverse -> window -> forward transforms, on the
+//     hand-written LDS transforms of jx_fft.hpp or on rocFFT's plans): the reference's lines executed pass by pass -- the
 //     independent cross-check, the fallback for inputs without the mirror structure, and, as a small reference facility inside every other
 //     context, the source of the beam-convolved-map tap and of jx_audit.
 // Every switch is an option of the context (jx_set_option; the process environment is the default of each name), read once, in

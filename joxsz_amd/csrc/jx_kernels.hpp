@@ -7,11 +7,12 @@
 //   jx_abel_gemm_kernel     Abel integral, Compton-y scale and spline moments of a launch as one fp64 matrix-core product
 //   jx_abel_map_sym_kernel  FUSED gNFW profile -> Abel integral -> Compton y -> cubic spline -> S x S map (symmetric
 //   jx_abel_map_kernel      d_mat / any d_mat): the profile taps, the y_2d tap, the rocFFT sequence, the full-map measurement
-//   jx_beam_mul_kernel      spectrum *= beam spectrum (rocFFT sequence)
-//   jx_tail_kernel          rocFFT sequence: extracted row of the filtered map, conversion, chi^2, total
+//   jx_beam_mul_kernel      spectrum *= beam spectrum (rocFFT sequence on rocFFT's own 2-D plans)
+//   jx_tail_kernel          rocFFT sequence: extracted row of the filtered map (from the window's spectrum, or from its column sums when the
+//                           transforms are jx_fft.hpp's), conversion, chi^2, total
 //   jx_operator_*_kernel    collapsed route (jx_set_route)
 //   jx_sm_*_kernel          device-resident stretch move
-// The exact form's kernels live in jx_exact.hpp, the contracted forms' (rounds 3-4) in jx_mix.hpp.
+// The exact form's kernels live in jx_exact.hpp, the literal sequence's transforms in jx_fft.hpp, the contracted forms' (rounds 3-4) in jx_mix.hpp.
 //
 // JOXSZ_DBG (JxDev::dbg; diagnostic build only, make ABLATIONS=1) holds timing-only ablation switches of the map kernel;
 // results are wrong when any is set: 1 skip phases 1-4, 2 skip phase 5, 4 phase 5 = stores only,
